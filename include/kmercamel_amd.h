@@ -1,0 +1,122 @@
+/* kmercamel_amd -- C ABI of the MI355X-native BIGREEDY hot path (libkmercamel_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, no exceptions.  Every entry point names
+ * the reference interface it stands in for (file:line relative to the KmerCamel v2.3.0 tree).  The C++ headers in
+ * kmercamel_amd/src/ (global.h, simplitigs.h, parser.h) re-create the reference's template signatures on top of
+ * these calls; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * All functions return 0 on success or a negative KC_E_* code; kc_last_error() gives the message of the last
+ * failure on that context.  All functions fail with KC_E_NO_DEVICE when no HIP device is present -- there is no
+ * CPU fallback behind this ABI.
+ *
+ * Keys: a k-mer is 2 bits/nucleotide (A=0,C=1,G=2,T=3), first nucleotide most significant (kmers.h:15-44), held in
+ * W = 1/2/4 little-endian 64-bit words for k<32 / k<64 / k<=127 (main.cpp:309-315).
+ */
+#ifndef KMERCAMEL_AMD_H
+#define KMERCAMEL_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KC_OK 0
+#define KC_E_NO_DEVICE (-1)   /* no HIP device / HIP runtime error */
+#define KC_E_EMPTY (-2)       /* "input cannot be empty" (global.h:219-221) */
+#define KC_E_INVALID_CHAR (-3)/* non-ACGT where the reference asserts / throws (simplitigs.h:82, masks.h:75-77) */
+#define KC_E_ARG (-4)         /* bad argument (k out of 1..127, null pointer, ...) */
+#define KC_E_CAPACITY (-5)    /* hash set capacity exhausted (kh_put's ret=-1, khash.h:314-321) */
+#define KC_E_IO (-6)          /* "couldn't open file" (parser.h:95-97) */
+#define KC_E_NO_KMERS (-7)    /* input holds no k-mers (main.cpp:155-158) */
+
+typedef struct kc_ctx kc_ctx;
+typedef struct kc_set kc_set;
+typedef struct kc_simplitigs kc_simplitigs;
+typedef struct kc_result kc_result;
+
+/* ---- context: one per GPU (one host thread / process per GPU); owns a private HIP stream and a memory pool ---- */
+int kc_ctx_create(int device, kc_ctx **out);
+void kc_ctx_destroy(kc_ctx *ctx);
+const char *kc_last_error(const kc_ctx *ctx);
+/* the private HIP stream (hipStream_t) the kernels are launched on */
+void *kc_ctx_stream(kc_ctx *ctx);
+int kc_ctx_synchronize(kc_ctx *ctx);
+
+/* ---- k-mer set: replaces kh_S64/S128/S256 + kmer_dictNN_t (khash_utils.h:28-95) ---- */
+/* wrapper.kh_init_set() (khash_utils.h:43). capacity_hint = expected number of k-mer occurrences to be added (0 = grow on demand). */
+int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capacity_hint, kc_set **out);
+void kc_set_destroy(kc_set *set); /* wrapper.kh_destroy_set (khash_utils.h:55) */
+/* AddKMers (parser.h:22-49): all k-mers of one record; non-ACGT bytes break k-mers; `case_sensitive` keeps a k-mer
+ * only if its first base is upper case.  Separate records by any non-ACGT byte (e.g. '\n') to add many at once. */
+int kc_set_add_sequence(kc_set *set, const char *seq, uint64_t len, int case_sensitive);
+/* same, sequence bytes already resident in device memory */
+int kc_set_add_sequence_device(kc_set *set, const void *d_seq, uint64_t len, int case_sensitive);
+/* kh_size (khash.h:543) */
+int kc_set_size(kc_set *set, uint64_t *n);
+/* kMersToVec (khash_utils.h:131-141): all keys, arbitrary order, W words each; `out` holds kc_set_size()*W words */
+int kc_set_export(kc_set *set, uint64_t *out_words);
+/* kh_get != kh_end for n keys of W words each (khash.h:232-246); exact-key membership (no RC lookup) */
+int kc_set_contains(kc_set *set, const uint64_t *key_words, uint64_t n, uint8_t *out);
+
+/* ---- simplitigs: replaces std::vector<simplitig_t> (simplitigs.h:11) as a packed, device-resident collection ---- */
+/* get_simplitigs (simplitigs.h:191-205): greedy simplitigs of the set by de Bruijn neighbour lookup. The reference
+ * consumes the set; here the set stays intact (it is reused for the -M mask). Order/orientation follow the
+ * canonical rule, not the khash bucket order. */
+int kc_simplitigs_build(kc_set *set, kc_simplitigs **out);
+/* simplitigs_from_fasta / simplitig_from_string (simplitigs.h:78-103): n records, ACGT only (else KC_E_INVALID_CHAR),
+ * record i = seqs[offsets[i] .. offsets[i+1]) , record order kept. */
+int kc_simplitigs_from_strings(kc_ctx *ctx, int k, const char *seqs, const uint64_t *offsets, uint64_t n, kc_simplitigs **out);
+void kc_simplitigs_destroy(kc_simplitigs *s);
+int kc_simplitigs_count(kc_simplitigs *s, uint64_t *n, uint64_t *total_bases);
+/* ASCII export: `seqs` holds total_bases bytes, `offsets` n+1 entries */
+int kc_simplitigs_export(kc_simplitigs *s, char *seqs, uint64_t *offsets);
+/* simplitigs_to_kmer_vec + PartialPreSort (simplitigs.h:53-65, global_sparse.h:14-35): the sparse branch's vertex
+ * list as 1-k-mer simplitigs */
+int kc_simplitigs_to_sparse(kc_simplitigs *s, kc_simplitigs **out);
+
+/* ---- global greedy ---- */
+/* OverlapHamiltonianPath (global.h:43-133) / OverlapHamiltonianPathSparse (global_sparse.h:43-132).
+ * edge_from: V = n*(1+complements) entries (UINT64_MAX = none), overlaps: V bytes (0xFF = none); host buffers. */
+int kc_overlap_path(kc_simplitigs *s, int complements, int lower_bound, uint64_t *edge_from, uint8_t *overlaps);
+/* SuperstringFromPath (global.h:149-210). `set` (may be NULL) enables the max-one mask output (the -M stream,
+ * global.h:185-195); it must hold exactly the k-mers of `s` (fill_kmers, simplitigs.h:41-51).
+ * *out / *mask_out are malloc'd NUL-terminated strings (free with kc_free); *length = returned size_t. */
+int kc_superstring_from_path(kc_simplitigs *s, const uint64_t *edge_from, const uint8_t *overlaps, int complements,
+                             kc_set *set, char **out, char **mask_out, uint64_t *length);
+/* Global (global.h:217-226) = path + superstring, device-resident in between. want_mask builds the k-mer set of `s`
+ * internally when `set` is NULL. */
+int kc_global(kc_simplitigs *s, int complements, kc_set *set, int want_mask, char **out, char **mask_out, uint64_t *length);
+/* LowerBoundLength (lower_bound.h:7-21) */
+int kc_lower_bound(kc_simplitigs *s, int complements, uint64_t *length);
+void kc_free(void *p);
+
+/* ---- fused device-resident pipeline: the greedy branch of kmercamel<>() (main.cpp:122-212) ---- */
+#define KC_FLAG_COMPLEMENTS 1u       /* bidirectional (absence = -u) */
+#define KC_FLAG_SIMPLITIGS_INPUT 2u  /* -S: records are simplitigs */
+#define KC_FLAG_WANT_MASK 4u         /* -M: also produce the max-one mask */
+#define KC_FLAG_INPUT_ON_DEVICE 8u   /* seq points to device memory */
+/* seq: record sequences separated by one '\n' (any non-ACGT byte separates k-mers); for -S `offsets` (host, n+1) is
+ * required.  The result stays on the device until copied out. */
+int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offsets, uint64_t n_records, int k, uint32_t flags,
+               kc_result **out);
+/* stats[16]: 0 n_kmers, 1 n_simplitigs, 2 length, 3 sparse_branch, 4 n_vertices, 5 matching_rounds,
+ *            6.. device time per phase in microseconds: 6 pack+insert, 7 simplitigs, 8 overlap path, 9 emit(+mask),
+ *            10 dominant-kernel time (us, summed over its launches), 11 dominant-kernel launches, 12 table capacity,
+ *            13 overlap repair rounds, 14 total device us, 15 reserved */
+int kc_result_stats(kc_result *r, uint64_t *stats);
+/* device pointers to the output characters (length bytes each; mask NULL unless requested) */
+int kc_result_device_ptrs(kc_result *r, void **d_out, void **d_mask);
+/* copy to host buffers of `length` bytes (mask may be NULL) */
+int kc_result_copy(kc_result *r, char *out, char *mask_out);
+void kc_result_destroy(kc_result *r);
+
+/* ---- next row 1: maskopt -t max-one / min-one (masks.h:40-78, 239-261) ---- */
+/* ms: one masked superstring (ACGTacgt, else KC_E_INVALID_CHAR after output like the reference). out: len bytes. */
+int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out);
+
+/* library/ABI version string */
+const char *kc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

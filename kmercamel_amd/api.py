@@ -1,0 +1,455 @@
+"""ctypes binding of libkmercamel_amd.so (include/kmercamel_amd.h) plus the host-side mirror of the reference's
+operator interface for the BIGREEDY path.
+
+Nothing here computes on the CPU: every operator goes through the C ABI into the HIP kernels and raises
+`KcError` if the library or a GPU is missing.  Function names follow the reference
+(`/root/reference/src/{parser,simplitigs,global}.h`): ReadKMers, get_simplitigs, simplitigs_from_fasta,
+OverlapHamiltonianPath, SuperstringFromPath, Global, LowerBoundLength, Optimize (max-one/min-one).
+"""
+import ctypes
+import gzip
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkmercamel_amd.so")
+
+KC_OK = 0
+KC_E_NO_DEVICE, KC_E_EMPTY, KC_E_INVALID_CHAR, KC_E_ARG, KC_E_CAPACITY, KC_E_IO, KC_E_NO_KMERS = -1, -2, -3, -4, -5, -6, -7
+FLAG_COMPLEMENTS, FLAG_SIMPLITIGS_INPUT, FLAG_WANT_MASK, FLAG_INPUT_ON_DEVICE = 1, 2, 4, 8
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_vp = ctypes.c_void_p
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+
+# every symbol include/kmercamel_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "kc_ctx_create": (ctypes.c_int, [ctypes.c_int, _vpp]),
+    "kc_ctx_destroy": (None, [_vp]),
+    "kc_last_error": (ctypes.c_char_p, [_vp]),
+    "kc_ctx_stream": (_vp, [_vp]),
+    "kc_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "kc_set_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vpp]),
+    "kc_set_destroy": (None, [_vp]),
+    "kc_set_add_sequence": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int]),
+    "kc_set_add_sequence_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_int]),
+    "kc_set_size": (ctypes.c_int, [_vp, _u64p]),
+    "kc_set_export": (ctypes.c_int, [_vp, _u64p]),
+    "kc_set_contains": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint64, _u8p]),
+    "kc_simplitigs_build": (ctypes.c_int, [_vp, _vpp]),
+    "kc_simplitigs_from_strings": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, _u64p, ctypes.c_uint64, _vpp]),
+    "kc_simplitigs_destroy": (None, [_vp]),
+    "kc_simplitigs_count": (ctypes.c_int, [_vp, _u64p, _u64p]),
+    "kc_simplitigs_export": (ctypes.c_int, [_vp, ctypes.c_char_p, _u64p]),
+    "kc_simplitigs_to_sparse": (ctypes.c_int, [_vp, _vpp]),
+    "kc_overlap_path": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _u64p, _u8p]),
+    "kc_superstring_from_path": (ctypes.c_int, [_vp, _u64p, _u8p, ctypes.c_int, _vp, _vpp, _vpp, _u64p]),
+    "kc_global": (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vpp, _vpp, _u64p]),
+    "kc_lower_bound": (ctypes.c_int, [_vp, ctypes.c_int, _u64p]),
+    "kc_free": (None, [_vp]),
+    "kc_compute": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
+    "kc_result_stats": (ctypes.c_int, [_vp, _u64p]),
+    "kc_result_device_ptrs": (ctypes.c_int, [_vp, _vpp, _vpp]),
+    "kc_result_copy": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_char_p]),
+    "kc_result_destroy": (None, [_vp]),
+    "kc_maskopt_ones": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "kc_version": (ctypes.c_char_p, []),
+}
+
+STAT_NAMES = ["n_kmers", "n_simplitigs", "length", "sparse_branch", "n_vertices", "matching_rounds", "us_insert_phase",
+              "us_simplitig_phase", "us_overlap_phase", "us_emit_phase", "us_probe_kernel", "us_insert_kernel", "table_capacity",
+              "overlap_repairs", "us_total", "reserved"]
+
+
+class KcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("kmercamel_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the C-ABI library; fails loudly if it was not built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KcError(KC_E_NO_DEVICE, "libkmercamel_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI symbol missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def words_for_k(k):
+    return 1 if k < 32 else (2 if k < 64 else 4)
+
+
+class Context:
+    """One per GPU: private HIP stream + device memory pool (kc_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = ctypes.c_void_p()
+        rc = self.lib.kc_ctx_create(device, ctypes.byref(h))
+        if rc != KC_OK:
+            raise KcError(rc, "kc_ctx_create failed (no HIP device?)")
+        self.h = h
+
+    def check(self, rc):
+        if rc != KC_OK:
+            raise KcError(rc, (self.lib.kc_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.lib.kc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KmerSet:
+    """kh_S64/S128/S256 + kmer_dictNN_t (khash_utils.h:28-95) on the device."""
+
+    def __init__(self, ctx, k, complements=True, capacity_hint=0):
+        self.ctx, self.k, self.complements = ctx, k, bool(complements)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.kc_set_create(ctx.h, k, int(self.complements), capacity_hint, ctypes.byref(h)))
+        self.h = h
+
+    def AddKMers(self, seq, case_sensitive=False):  # parser.h:22-49
+        if isinstance(seq, str):
+            seq = seq.encode()
+        self.ctx.check(self.ctx.lib.kc_set_add_sequence(self.h, seq, len(seq), int(case_sensitive)))
+
+    def add_device(self, ptr, length, case_sensitive=False):
+        self.ctx.check(self.ctx.lib.kc_set_add_sequence_device(self.h, ctypes.c_void_p(ptr), length, int(case_sensitive)))
+
+    def size(self):  # kh_size
+        n = ctypes.c_uint64()
+        self.ctx.check(self.ctx.lib.kc_set_size(self.h, ctypes.byref(n)))
+        return n.value
+
+    def keys(self):
+        """kMersToVec (khash_utils.h:131-141): python ints, unsorted."""
+        n, W = self.size(), words_for_k(self.k)
+        buf = (ctypes.c_uint64 * max(1, n * W))()
+        self.ctx.check(self.ctx.lib.kc_set_export(self.h, buf))
+        out = []
+        for i in range(n):
+            v = 0
+            for j in range(W):
+                v |= buf[i * W + j] << (64 * j)
+            out.append(v)
+        return out
+
+    def contains(self, keys):
+        W = words_for_k(self.k)
+        n = len(keys)
+        buf = (ctypes.c_uint64 * max(1, n * W))()
+        for i, v in enumerate(keys):
+            for j in range(W):
+                buf[i * W + j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        out = (ctypes.c_uint8 * max(1, n))()
+        self.ctx.check(self.ctx.lib.kc_set_contains(self.h, buf, n, out))
+        return [bool(out[i]) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.kc_set_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Simplitigs:
+    """std::vector<simplitig_t> (simplitigs.h:11) as a packed device-resident collection."""
+
+    def __init__(self, ctx, h, k):
+        self.ctx, self.h, self.k = ctx, h, k
+
+    def count(self):
+        n, t = ctypes.c_uint64(), ctypes.c_uint64()
+        self.ctx.check(self.ctx.lib.kc_simplitigs_count(self.h, ctypes.byref(n), ctypes.byref(t)))
+        return n.value, t.value
+
+    def strings(self):
+        n, t = self.count()
+        buf = ctypes.create_string_buffer(max(1, t))
+        off = (ctypes.c_uint64 * (n + 1))()
+        self.ctx.check(self.ctx.lib.kc_simplitigs_export(self.h, buf, off))
+        raw = buf.raw
+        return [raw[off[i]:off[i + 1]].decode() for i in range(n)]
+
+    def to_sparse(self):
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.kc_simplitigs_to_sparse(self.h, ctypes.byref(h)))
+        return Simplitigs(self.ctx, h, self.k)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.kc_simplitigs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _take_string(lib, p):
+    if not p:
+        return None
+    s = ctypes.string_at(p).decode()
+    lib.kc_free(p)
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host-side record reader with kseq semantics (kseq.h:183-224; gz transparently like parser.h:88-101)
+def read_records(path):
+    """[(name, comment, sequence)] of a FASTA/FASTQ(.gz) file, multi-line records joined."""
+    if path == "-":
+        import sys
+        data = sys.stdin.buffer.read()
+    else:
+        with open(path, "rb") as f:
+            data = f.read()
+    if data[:2] == b"\x1f\x8b":
+        data = gzip.decompress(data)
+    out = []
+    n, p, last_char = len(data), 0, 0
+
+    def take_line(dst):
+        nonlocal p
+        e = data.find(b"\n", p)
+        if e < 0:
+            e = n
+        dst += data[p:e]
+        if len(dst) > 1 and dst[-1:] == b"\r":
+            del dst[-1]
+        p = e + 1 if e < n else n
+
+    while True:
+        if last_char == 0:
+            while p < n and data[p] not in (0x3E, 0x40):
+                p += 1
+            if p >= n:
+                break
+            last_char = data[p]
+            p += 1
+        if p >= n:
+            break
+        q = p
+        while q < n and data[q] not in b" \t\n\r\x0b\x0c":
+            q += 1
+        name = data[p:q]
+        comment = bytearray()
+        if q < n:
+            delim = data[q]
+            p = q + 1
+            if delim != 0x0A:
+                take_line(comment)
+        else:
+            p = n
+        seq = bytearray()
+        c = -1
+        while p < n:
+            c = data[p]
+            p += 1
+            if c in (0x3E, 0x2B, 0x40):
+                break
+            if c == 0x0A:
+                c = -1
+                continue
+            seq.append(c)
+            take_line(seq)
+            c = -1
+        if c in (0x3E, 0x40):
+            last_char = c
+        if c != 0x2B:
+            out.append((name.decode(), bytes(comment).decode(), bytes(seq)))
+            if c == -1:
+                break
+            continue
+        e = data.find(b"\n", p)
+        if e < 0:
+            break
+        p = e + 1
+        qual = bytearray()
+        while p < n:
+            take_line(qual)
+            if not len(qual) < len(seq):
+                break
+        last_char = 0
+        if len(qual) != len(seq):
+            break
+        out.append((name.decode(), bytes(comment).decode(), bytes(seq)))
+    return out
+
+
+def ReadKMers(ctx, path, k, complements=True, case_sensitive=False):
+    """parser.h:106-118: k-mer set of every record of a FASTA file."""
+    recs = read_records(path)
+    joined = b"\n".join(r[2] for r in recs)
+    s = KmerSet(ctx, k, complements, capacity_hint=len(joined))
+    if joined:
+        s.AddKMers(joined, case_sensitive)
+    return s
+
+
+def get_simplitigs(kmer_set):
+    """simplitigs.h:191-205 (canonical order; the set is not consumed)."""
+    ctx = kmer_set.ctx
+    h = ctypes.c_void_p()
+    ctx.check(ctx.lib.kc_simplitigs_build(kmer_set.h, ctypes.byref(h)))
+    return Simplitigs(ctx, h, kmer_set.k)
+
+
+def simplitigs_from_strings(ctx, strings, k):
+    """simplitig_from_string (simplitigs.h:78-87) for each string, order kept."""
+    bs = [s.encode() if isinstance(s, str) else bytes(s) for s in strings]
+    off = (ctypes.c_uint64 * (len(bs) + 1))()
+    o = 0
+    for i, b in enumerate(bs):
+        off[i] = o
+        o += len(b)
+    off[len(bs)] = o
+    h = ctypes.c_void_p()
+    ctx.check(ctx.lib.kc_simplitigs_from_strings(ctx.h, k, b"".join(bs), off, len(bs), ctypes.byref(h)))
+    return Simplitigs(ctx, h, k)
+
+
+def simplitigs_from_fasta(ctx, path, k):
+    """simplitigs.h:89-103"""
+    return simplitigs_from_strings(ctx, [r[2] for r in read_records(path)], k)
+
+
+def OverlapHamiltonianPath(simplitigs, complements=True, lower_bound=False):
+    """global.h:43-133 -> (edgeFrom list with None for -1, overlaps list with None for 0xFF)."""
+    ctx = simplitigs.ctx
+    n, _ = simplitigs.count()
+    V = n * (2 if complements else 1)
+    ef = (ctypes.c_uint64 * max(1, V))()
+    ov = (ctypes.c_uint8 * max(1, V))()
+    ctx.check(ctx.lib.kc_overlap_path(simplitigs.h, int(bool(complements)), int(bool(lower_bound)), ef, ov))
+    return list(ef)[:V], list(ov)[:V]
+
+
+def SuperstringFromPath(simplitigs, edge_from, overlaps, complements=True, kmer_set=None, want_mask=False):
+    """global.h:149-210 -> (superstring, max-one mask or None, length)."""
+    ctx = simplitigs.ctx
+    V = len(edge_from)
+    ef = (ctypes.c_uint64 * max(1, V))(*edge_from)
+    ov = (ctypes.c_uint8 * max(1, V))(*overlaps)
+    out, mask, L = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+    ctx.check(ctx.lib.kc_superstring_from_path(simplitigs.h, ef, ov, int(bool(complements)), kmer_set.h if kmer_set else None,
+                                               ctypes.byref(out), ctypes.byref(mask) if want_mask else None, ctypes.byref(L)))
+    return _take_string(ctx.lib, out), _take_string(ctx.lib, mask) if want_mask else None, L.value
+
+
+def Global(simplitigs, complements=True, want_mask=False, kmer_set=None):
+    """global.h:217-226 -> (superstring, mask or None, length); raises KcError(KC_E_EMPTY) on empty input."""
+    ctx = simplitigs.ctx
+    out, mask, L = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+    ctx.check(ctx.lib.kc_global(simplitigs.h, int(bool(complements)), kmer_set.h if kmer_set else None, int(bool(want_mask)),
+                                ctypes.byref(out), ctypes.byref(mask) if want_mask else None, ctypes.byref(L)))
+    return _take_string(ctx.lib, out), _take_string(ctx.lib, mask) if want_mask else None, L.value
+
+
+def LowerBoundLength(simplitigs, complements=True):
+    """lower_bound.h:7-21"""
+    ctx = simplitigs.ctx
+    L = ctypes.c_uint64()
+    ctx.check(ctx.lib.kc_lower_bound(simplitigs.h, int(bool(complements)), ctypes.byref(L)))
+    return L.value
+
+
+def Optimize(ctx, masked_superstring, k, complements=True, algorithm="max-one"):
+    """masks.h:239-261 for max-one / min-one on the sequence line of a masked superstring."""
+    if algorithm not in ("max-one", "min-one"):
+        raise KcError(KC_E_ARG, "Algorithm '%s' not recognized." % algorithm)
+    ms = masked_superstring.encode() if isinstance(masked_superstring, str) else bytes(masked_superstring)
+    out = ctypes.create_string_buffer(len(ms) + 1)
+    ctx.check(ctx.lib.kc_maskopt_ones(ctx.h, ms, len(ms), k, int(bool(complements)), int(algorithm == "min-one"), out))
+    return out.raw[:len(ms)].decode()
+
+
+class ComputeResult:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+        st = (ctypes.c_uint64 * 16)()
+        ctx.check(ctx.lib.kc_result_stats(h, st))
+        self.stats = dict(zip(STAT_NAMES, list(st)))
+        self.length = self.stats["length"]
+
+    def device_ptrs(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self.ctx.check(self.ctx.lib.kc_result_device_ptrs(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def strings(self, want_mask=False):
+        out = ctypes.create_string_buffer(self.length + 1)
+        mask = ctypes.create_string_buffer(self.length + 1) if want_mask else None
+        self.ctx.check(self.ctx.lib.kc_result_copy(self.h, out, mask))
+        return out.raw[:self.length].decode(), (mask.raw[:self.length].decode() if want_mask else None)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.kc_result_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def compute(ctx, seq, k, complements=True, want_mask=False, simplitig_offsets=None, device_ptr=None, length=None):
+    """Fused device-resident greedy branch of kmercamel<>() (main.cpp:122-212).
+
+    seq: bytes of the record sequences joined by '\\n' (or, with device_ptr/length, already on the GPU);
+    simplitig_offsets: for -S, the n+1 record offsets into seq (records then are NOT separated)."""
+    flags = (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0)
+    off, nrec = None, 0
+    if simplitig_offsets is not None:
+        flags |= FLAG_SIMPLITIGS_INPUT
+        nrec = len(simplitig_offsets) - 1
+        off = (ctypes.c_uint64 * len(simplitig_offsets))(*simplitig_offsets)
+    h = ctypes.c_void_p()
+    if device_ptr is not None:
+        flags |= FLAG_INPUT_ON_DEVICE
+        ctx.check(ctx.lib.kc_compute(ctx.h, ctypes.c_void_p(device_ptr), length, off, nrec, k, flags, ctypes.byref(h)))
+    else:
+        buf = seq if isinstance(seq, (bytes, bytearray)) else seq.encode()
+        ctx.check(ctx.lib.kc_compute(ctx.h, ctypes.cast(ctypes.c_char_p(bytes(buf)), ctypes.c_void_p), len(buf), off, nrec, k, flags,
+                                     ctypes.byref(h)))
+    return ComputeResult(ctx, h)
+
+
+def compute_file(ctx, path, k, complements=True, want_mask=False, assume_simplitigs=False):
+    """`kmercamel compute -k K [-u] [-S] [-M f] path` on the sequence lines (no FASTA header)."""
+    recs = [r[2] for r in read_records(path)]
+    if assume_simplitigs:
+        offs, o = [], 0
+        for r in recs:
+            offs.append(o)
+            o += len(r)
+        offs.append(o)
+        return compute(ctx, b"".join(recs), k, complements, want_mask, simplitig_offsets=offs)
+    return compute(ctx, b"\n".join(recs), k, complements, want_mask)

@@ -1,0 +1,200 @@
+// C-ABI glue: Global / SuperstringFromPath entry points and the fused, device-resident greedy branch of
+// kmercamel<>() (main.cpp:122-212).
+#include "kc_internal.h"
+
+static int copy_out_string(kc_ctx *ctx, const char *d, u64 L, char **out) {
+    char *h = (char *)malloc(L + 1);
+    if (!h) return kc_fail(ctx, KC_E_ARG, "host allocation failed");
+    if (L) {
+        if (hipMemcpyAsync(h, d, L, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            free(h);
+            return kc_fail(ctx, KC_E_NO_DEVICE, "D2H copy failed");
+        }
+    }
+    h[L] = 0;
+    *out = h;
+    return KC_OK;
+}
+
+extern "C" int kc_superstring_from_path(kc_simplitigs *s, const uint64_t *edge_from, const uint8_t *overlaps, int complements,
+                                        kc_set *set, char **out, char **mask_out, uint64_t *length) {
+    if (!s || !edge_from || !overlaps || !out) return KC_E_ARG;
+    kc_ctx *ctx = s->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->n == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    KcPathDev p;
+    p.V = s->n * (complements ? 2 : 1);
+    KC_TRY(kc_alloc(ctx, &p.edge_from, p.V));
+    KC_TRY(kc_alloc(ctx, &p.overlaps, p.V));
+    KC_HIP(ctx, hipMemcpyAsync(p.edge_from, edge_from, p.V * 8, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(p.overlaps, overlaps, p.V, hipMemcpyHostToDevice, ctx->stream));
+    char *d_out = nullptr, *d_mask = nullptr;
+    u64 L = 0;
+    int rc = kce_superstring(s, &p, complements ? 1 : 0, mask_out ? set : nullptr, &d_out, mask_out ? &d_mask : nullptr, &L);
+    if (rc == KC_OK) rc = copy_out_string(ctx, d_out, L, out);
+    if (rc == KC_OK && mask_out) {
+        if (d_mask) rc = copy_out_string(ctx, d_mask, L, mask_out);
+        else *mask_out = nullptr;
+    }
+    if (length) *length = L;
+    kc_release(ctx, d_out); kc_release(ctx, d_mask);
+    kco_path_release(ctx, &p);
+    return rc;
+}
+
+extern "C" int kc_global(kc_simplitigs *s, int complements, kc_set *set, int want_mask, char **out, char **mask_out, uint64_t *length) {
+    if (!s || !out) return KC_E_ARG;
+    kc_ctx *ctx = s->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->n == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    kc_set *own = nullptr;
+    if (want_mask && mask_out && !set) {   // fill_kmers (simplitigs.h:41-51)
+        KC_TRY(kc_set_create(ctx, s->k, complements ? 1 : 0, s->total_bases, &own));
+        int rc = kcp_insert_simplitig_kmers(own, s);
+        if (rc != KC_OK) { kc_set_destroy(own); return rc; }
+        set = own;
+    }
+    KcPathDev p;
+    int rc = kco_overlap_path_device(s, complements ? 1 : 0, 0, &p);
+    char *d_out = nullptr, *d_mask = nullptr;
+    u64 L = 0;
+    bool mask = want_mask && mask_out && set;
+    if (rc == KC_OK) rc = kce_superstring(s, &p, complements ? 1 : 0, mask ? set : nullptr, &d_out, mask ? &d_mask : nullptr, &L);
+    if (rc == KC_OK) rc = copy_out_string(ctx, d_out, L, out);
+    if (rc == KC_OK && mask) rc = copy_out_string(ctx, d_mask, L, mask_out);
+    if (length) *length = L;
+    kc_release(ctx, d_out); kc_release(ctx, d_mask);
+    kco_path_release(ctx, &p);
+    if (own) kc_set_destroy(own);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ms;
+}
+
+extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offsets, uint64_t n_records, int k, uint32_t flags,
+                          kc_result **out) {
+    if (!ctx || !out || (!seq && len)) return KC_E_ARG;
+    *out = nullptr;
+    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;
+    const bool from_simplitigs = (flags & KC_FLAG_SIMPLITIGS_INPUT) != 0;
+    const bool want_mask = (flags & KC_FLAG_WANT_MASK) != 0;
+    const bool on_device = (flags & KC_FLAG_INPUT_ON_DEVICE) != 0;
+    if (from_simplitigs && !offsets) return kc_fail(ctx, KC_E_ARG, "-S input needs record offsets");
+
+    hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1], e2 = ctx->ev[2], e3 = ctx->ev[3];
+    hipEvent_t eend;
+    KC_HIP(ctx, hipEventCreate(&eend));
+    u8 *d_own = nullptr;
+    const u8 *d_seq = (const u8 *)seq;
+    if (!on_device) {
+        KC_TRY(kc_alloc(ctx, &d_own, len + 64));
+        KC_HIP(ctx, hipMemcpyAsync(d_own, seq, len, hipMemcpyHostToDevice, ctx->stream));
+        d_seq = d_own;
+    }
+    kc_result *r = new kc_result();
+    r->ctx = ctx;
+    kc_set *set = nullptr;
+    kc_simplitigs *simp = nullptr, *sparse = nullptr;
+    u64 rounds = 0, n_kmers = 0;
+    int rc = KC_OK;
+    double dom_us = 0;
+    KC_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    if (!from_simplitigs) {
+        // phase 0: ReadKMers/AddKMers (parser.h:22-49,106-118)
+        u64 occ = len >= (u64)k ? len - k + 1 : 0;
+        rc = kc_set_create(ctx, k, complements, occ, &set);
+        u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
+        if (rc == KC_OK && len >= (u64)k) {
+            rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
+            if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, 0);
+        }
+        if (rc == KC_OK) rc = kcs_refresh_size(set);
+        kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low);
+        if (rc == KC_OK && set->size_host == 0) rc = kc_fail(ctx, KC_E_NO_KMERS, "input contains no k-mers");
+        if (rc == KC_OK) { n_kmers = set->size_host; dom_us += 1000.0 * ev_ms(ctx->ev[6], ctx->ev[7]); }
+        KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        // phase 1: get_simplitigs (simplitigs.h:191-205)
+        if (rc == KC_OK) rc = kcp_build_simplitigs(set, &simp, &rounds);
+        if (rc == KC_OK) r->stats[10] = (u64)(1000.0 * ev_ms(ctx->ev[4], ctx->ev[5]));   // neighbour-probe kernel
+    } else {
+        KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        // simplitigs_from_fasta (simplitigs.h:89-103)
+        rc = kcp_simplitigs_from_device_ascii(ctx, k, d_seq, len, offsets, n_records, 1, &simp);
+        if (rc == KC_OK) n_kmers = simp->total_bases - simp->n * (u64)(k - 1);
+        if (rc == KC_OK && want_mask) {
+            rc = kc_set_create(ctx, k, complements, simp->total_bases, &set);
+            if (rc == KC_OK) rc = kcp_insert_simplitig_kmers(set, simp);
+        }
+    }
+    KC_HIP(ctx, hipEventRecord(e2, ctx->stream));
+    u64 S = 0;
+    kc_simplitigs *use = simp;
+    if (rc == KC_OK) {
+        S = simp->n;
+        // main.cpp:175: too many simplitigs => overlap graph over single k-mers (global_sparse.h)
+        if (!from_simplitigs && S * 5 >= n_kmers) {
+            rc = kcp_to_sparse(simp, &sparse);
+            if (rc == KC_OK) { use = sparse; r->stats[3] = 1; }
+        }
+    }
+    KcPathDev p;
+    if (rc == KC_OK) rc = kco_overlap_path_device(use, complements, 0, &p);
+    KC_HIP(ctx, hipEventRecord(e3, ctx->stream));
+    if (rc == KC_OK) {
+        rc = kce_superstring(use, &p, complements, want_mask ? set : nullptr, &r->d_out, want_mask ? &r->d_mask : nullptr, &r->length);
+        r->stats[4] = p.V; r->stats[13] = p.repairs;
+        kco_path_release(ctx, &p);
+    }
+    KC_HIP(ctx, hipEventRecord(eend, ctx->stream));
+    KC_HIP(ctx, hipEventSynchronize(eend));
+    if (rc == KC_OK) {
+        r->stats[0] = n_kmers; r->stats[1] = S; r->stats[2] = r->length; r->stats[5] = rounds;
+        r->stats[6] = (u64)(1000.0 * ev_ms(e0, e1)); r->stats[7] = (u64)(1000.0 * ev_ms(e1, e2));
+        r->stats[8] = (u64)(1000.0 * ev_ms(e2, e3)); r->stats[9] = (u64)(1000.0 * ev_ms(e3, eend));
+        r->stats[11] = (u64)dom_us;   // insert kernel
+        r->stats[12] = set ? set->cap : 0;
+        r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
+    }
+    (void)hipEventDestroy(eend);
+    if (sparse) kc_simplitigs_destroy(sparse);
+    if (simp) kc_simplitigs_destroy(simp);
+    if (set) kc_set_destroy(set);
+    kc_release(ctx, d_own);
+    if (rc != KC_OK) { kc_result_destroy(r); return rc; }
+    *out = r;
+    return KC_OK;
+}
+
+extern "C" int kc_result_stats(kc_result *r, uint64_t *stats) {
+    if (!r || !stats) return KC_E_ARG;
+    memcpy(stats, r->stats, sizeof r->stats);
+    return KC_OK;
+}
+extern "C" int kc_result_device_ptrs(kc_result *r, void **d_out, void **d_mask) {
+    if (!r) return KC_E_ARG;
+    if (d_out) *d_out = r->d_out;
+    if (d_mask) *d_mask = r->d_mask;
+    return KC_OK;
+}
+extern "C" int kc_result_copy(kc_result *r, char *out, char *mask_out) {
+    if (!r || !out) return KC_E_ARG;
+    kc_ctx *ctx = r->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    KC_HIP(ctx, hipMemcpyAsync(out, r->d_out, r->length, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out && r->d_mask) KC_HIP(ctx, hipMemcpyAsync(mask_out, r->d_mask, r->length, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+extern "C" void kc_result_destroy(kc_result *r) {
+    if (!r) return;
+    (void)hipStreamSynchronize(r->ctx->stream);
+    kc_release(r->ctx, r->d_out); kc_release(r->ctx, r->d_mask);
+    delete r;
+}

@@ -1,0 +1,216 @@
+// Phase 3 of the BIGREEDY path on gfx950: masked superstring from the overlap path.
+// Replaces SuperstringFromPath / SuperstringFromPathSparse (global.h:136-210, global_sparse.h:138-202) and, as the
+// first "next" row, OptimizeOnes (masks.h:40-78).
+//
+// The reference walks edgeFrom sequentially.  Here: the start vertex is the smallest vertex without in-edge
+// (global.h:156-161); every vertex v on its path contributes the block simplitig_v[0 .. len_v - ov_v) (upper case up
+// to index len_v - k, lower case after; ov_v = overlap of the edge leaving v, 0 for the last vertex, which yields the
+// trailing k-1 lower-case characters of global.h:202-205); block offsets come from a weighted list ranking by pointer
+// jumping; one wavefront per vertex then writes its block with coalesced byte stores.  The -M mask (global.h:185-195)
+// is a per-position probe of the k-mer set over the finished string.
+#include "kc_internal.h"
+#include "kc_set_dev.h"
+
+__global__ void __launch_bounds__(256) em_pred_kernel(const u64 *__restrict__ edge_from, u64 V, u64 *pred) {
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    u64 e = edge_from[v];
+    if (e != KC_NONE64) pred[e] = v;
+}
+__global__ void __launch_bounds__(256) em_start_kernel(const u64 *__restrict__ pred, u64 V, u64 *start) {
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    if (pred[v] == KC_NONE64) atomicMin((ull *)start, (ull)v);
+}
+__global__ void __launch_bounds__(256) em_rank_init_kernel(const u64 *__restrict__ edge_from, const u8 *__restrict__ overlaps,
+                                                           const u64 *__restrict__ lens, u64 S, u64 V, u64 *nxt, u64 *dist, u64 *endv,
+                                                           u64 *weight) {
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    u64 e = edge_from[v];
+    u64 L = lens[v < S ? v : v - S];
+    u64 w = L - (e != KC_NONE64 ? (u64)overlaps[v] : 0);
+    nxt[v] = e; dist[v] = w; endv[v] = v; weight[v] = w;
+}
+__global__ void __launch_bounds__(256) em_rank_step_kernel(const u64 *__restrict__ nxt, const u64 *__restrict__ dist,
+                                                           const u64 *__restrict__ endv, u64 V, u64 *nxt2, u64 *dist2, u64 *endv2) {
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    u64 n = nxt[v];
+    if (n == KC_NONE64) { nxt2[v] = n; dist2[v] = dist[v]; endv2[v] = endv[v]; }
+    else { nxt2[v] = nxt[n]; dist2[v] = dist[v] + dist[n]; endv2[v] = endv[n]; }
+}
+
+// one wavefront per vertex on the start path
+__global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ words, const u64 *__restrict__ woff,
+                                                      const u64 *__restrict__ lens, u64 S, u64 V, int k, const u64 *__restrict__ dist,
+                                                      const u64 *__restrict__ endv, const u64 *__restrict__ weight, u64 start, char *out) {
+    u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (v >= V) return;
+    if (endv[v] != endv[start]) return;
+    u64 off = dist[start] - dist[v];
+    u64 sidx = v < S ? v : v - S;
+    bool rc = v >= S;
+    u64 L = lens[sidx], wb = woff[sidx], n = weight[v];
+    u64 upper_end = L - (u64)k;   // indices <= upper_end are k-mer starts of the simplitig
+    for (u64 t = lane; t < n; t += 64) {
+        u64 j = rc ? (L - 1 - t) : t;
+        u64 b = (words[wb + (j >> 5)] >> (62 - 2 * (j & 31))) & 3;
+        if (rc) b = 3 - b;
+        char c = "ACGT"[b];
+        if (t > upper_end) c = (char)(c + ('a' - 'A'));
+        out[off + t] = c;
+    }
+}
+
+// -M: every lower-case position p <= L-k is switched on iff the k-mer starting at p is in the set (global.h:185-195)
+template <int W>
+__global__ void __launch_bounds__(256) em_mask_kernel(const char *__restrict__ out, u64 L, int k, int complements, SetView<W> set, char *mask) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= L) return;
+    char c = out[p];
+    if (c <= 'Z' || p + (u64)k > L) { mask[p] = c; return; }
+    Key<W> x = key_zero<W>();
+    for (int i = 0; i < k; ++i) {
+        u32 up = ((u32)(u8)out[p + i]) & 0xDFu;
+        u32 code = (up >> 1) & 3u;
+        code ^= code >> 1;
+        x = key_append(x, (u64)code, k);
+    }
+    if (complements) { Key<W> r = key_rc(x, k); if (key_lt(r, x)) x = r; }
+    bool in = set_find(set, x) != KC_NONE64;
+    mask[p] = in ? (char)(c - ('a' - 'A')) : c;
+}
+
+int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc_set *set_for_mask, char **d_out, char **d_mask, u64 *length) {
+    kc_ctx *ctx = s->ctx;
+    const u64 S = s->n, V = path->V;
+    const int k = s->k;
+    u64 *pred = nullptr, *start = nullptr, *nxt, *dist, *endv, *nxt2, *dist2, *endv2, *weight;
+    KC_TRY(kc_alloc(ctx, &pred, V)); KC_TRY(kc_alloc(ctx, &start, 2));
+    KC_TRY(kc_alloc(ctx, &nxt, V)); KC_TRY(kc_alloc(ctx, &dist, V)); KC_TRY(kc_alloc(ctx, &endv, V));
+    KC_TRY(kc_alloc(ctx, &nxt2, V)); KC_TRY(kc_alloc(ctx, &dist2, V)); KC_TRY(kc_alloc(ctx, &endv2, V)); KC_TRY(kc_alloc(ctx, &weight, V));
+    KC_HIP(ctx, hipMemsetAsync(pred, 0xff, V * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(start, 0xff, 16, ctx->stream));
+    unsigned g = kc_grid(V, 256);
+    hipLaunchKernelGGL(em_pred_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, V, pred);
+    hipLaunchKernelGGL(em_start_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)pred, V, start);
+    hipLaunchKernelGGL(em_rank_init_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, (const u8 *)path->overlaps,
+                       (const u64 *)s->lens, S, V, nxt, dist, endv, weight);
+    for (u64 span = 1; span < V; span <<= 1) {
+        hipLaunchKernelGGL(em_rank_step_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)nxt, (const u64 *)dist, (const u64 *)endv, V, nxt2,
+                           dist2, endv2);
+        std::swap(nxt, nxt2); std::swap(dist, dist2); std::swap(endv, endv2);
+    }
+    KC_HIP(ctx, hipGetLastError());
+    u64 h_start = 0;
+    KC_HIP(ctx, hipMemcpyAsync(&h_start, start, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_start == KC_NONE64) return kc_fail(ctx, KC_E_ARG, "overlap path has no start vertex (cycle cover?)");
+    u64 L = 0;
+    KC_HIP(ctx, hipMemcpyAsync(&L, dist + h_start, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    char *out = nullptr, *mask = nullptr;
+    KC_TRY(kc_alloc(ctx, &out, L + 1));
+    hipLaunchKernelGGL(em_emit_kernel, dim3(kc_grid(V * 64, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+                       (const u64 *)s->lens, S, V, k, (const u64 *)dist, (const u64 *)endv, (const u64 *)weight, h_start, out);
+    if (d_mask && set_for_mask) {
+        KC_TRY(kc_alloc(ctx, &mask, L + 1));
+        unsigned gm = kc_grid(L, 256);
+        switch (set_for_mask->W) {
+            case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, SetView<1>{set_for_mask->keys, set_for_mask->state, set_for_mask->cap}, mask); break;
+            case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, SetView<2>{set_for_mask->keys, set_for_mask->state, set_for_mask->cap}, mask); break;
+            default: hipLaunchKernelGGL((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, SetView<4>{set_for_mask->keys, set_for_mask->state, set_for_mask->cap}, mask); break;
+        }
+    }
+    KC_HIP(ctx, hipGetLastError());
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void *rel[] = {pred, start, nxt, dist, endv, nxt2, dist2, endv2, weight};
+    for (void *p : rel) kc_release(ctx, p);
+    *d_out = out;
+    if (d_mask) *d_mask = mask;
+    *length = L;
+    return KC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// maskopt -t max-one / min-one (masks.h:40-78): position p (k-mer start) is ON iff its canonical k-mer is in the set of
+// k-mers that start at an upper-case position (AddKMers(case_sensitive=true), masks.h:243); min-one keeps only the
+// first occurrence of each k-mer (the reference deletes the k-mer after its first hit, masks.h:60-62).
+template <int W, int PASS>
+__global__ void __launch_bounds__(256) mo_kernel(const char *__restrict__ ms, u64 len, int k, int complements, int minimize, SetView<W> set,
+                                                 u64 *firstpos, char *out, u64 *bad) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= len) return;
+    char c = ms[p];
+    bool upper = c <= 'Z';
+    if (p + (u64)k > len) {   // trailing k-1 characters are switched off (masks.h:70-72)
+        if (PASS == 1) out[p] = upper ? (char)(c + ('a' - 'A')) : c;
+        return;
+    }
+    Key<W> x = key_zero<W>();
+    bool invalid = false;
+    for (int i = 0; i < k; ++i) {
+        u32 ch = (u32)(u8)ms[p + i];
+        u32 up = ch & 0xDFu;
+        invalid = invalid || !((up == 'A') | (up == 'C') | (up == 'G') | (up == 'T'));
+        u32 code = (up >> 1) & 3u;
+        code ^= code >> 1;
+        x = key_append(x, (u64)code, k);
+    }
+    if (invalid) { if (PASS == 0) atomicExch((ull *)bad, 1ULL); if (PASS == 1) out[p] = c; return; }
+    if (complements) { Key<W> r = key_rc(x, k); if (key_lt(r, x)) x = r; }
+    u64 slot = set_find(set, x);
+    bool on = slot != KC_NONE64;
+    if (PASS == 0) {
+        if (on && minimize) atomicMin((ull *)&firstpos[slot], (ull)p);
+        return;
+    }
+    if (on && minimize) on = (firstpos[slot] == p);
+    out[p] = on ? (upper ? c : (char)(c - ('a' - 'A'))) : (upper ? (char)(c + ('a' - 'A')) : c);
+}
+
+template <int W> static int maskopt_w(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out) {
+    kc_set *set = nullptr;
+    KC_TRY(kc_set_create(ctx, k, complements, len, &set));
+    char *d_ms = nullptr, *d_out = nullptr; u64 *firstpos = nullptr, *bad = nullptr;
+    int rc = kc_alloc(ctx, &d_ms, len + 64);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &d_out, len + 64);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &bad, 1);
+    if (rc == KC_OK && hipMemcpyAsync(d_ms, ms, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    if (rc == KC_OK) rc = kc_set_add_sequence_device(set, d_ms, len, 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &firstpos, set->cap);
+    if (rc != KC_OK) { kc_set_destroy(set); return rc; }
+    KC_HIP(ctx, hipMemsetAsync(firstpos, 0xff, set->cap * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
+    SetView<W> sv{set->keys, set->state, set->cap};
+    unsigned g = kc_grid(len, 256);
+    hipLaunchKernelGGL((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
+    hipLaunchKernelGGL((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
+    KC_HIP(ctx, hipGetLastError());
+    u64 hbad = 0;
+    KC_HIP(ctx, hipMemcpyAsync(out, d_out, len, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(&hbad, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, d_ms); kc_release(ctx, d_out); kc_release(ctx, firstpos); kc_release(ctx, bad);
+    kc_set_destroy(set);
+    if (hbad) return kc_fail(ctx, KC_E_INVALID_CHAR, "Masked superstring contains invalid characters.");
+    return KC_OK;
+}
+
+int kce_maskopt(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out) {
+    switch (kc_words_for_k(k)) {
+        case 1: return maskopt_w<1>(ctx, ms, len, k, complements, minimize, out);
+        case 2: return maskopt_w<2>(ctx, ms, len, k, complements, minimize, out);
+        default: return maskopt_w<4>(ctx, ms, len, k, complements, minimize, out);
+    }
+}
+
+extern "C" int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out) {
+    if (!ctx || !ms || !out) return KC_E_ARG;
+    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
+    if (len < (u64)k) return kc_fail(ctx, KC_E_ARG, "masked superstring shorter than k");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    return kce_maskopt(ctx, ms, len, k, complements ? 1 : 0, minimize ? 1 : 0, out);
+}

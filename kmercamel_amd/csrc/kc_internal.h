@@ -1,0 +1,118 @@
+// Internal structures shared by the HIP translation units of libkmercamel_amd.so. Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "../../include/kmercamel_amd.h"
+#include "kc_key.h"
+
+typedef unsigned long long ull;
+
+struct KcPool {
+    struct Blk { size_t size; void *p; };
+    std::vector<Blk> free_list;
+    std::map<void *, size_t> live;
+    size_t live_bytes = 0, peak_bytes = 0;
+    hipError_t alloc(void **out, size_t bytes);
+    void release(void *p);
+    void trim();      // hipFree everything cached
+    ~KcPool();
+};
+
+struct kc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    KcPool pool;
+    hipEvent_t ev[8] = {nullptr};
+    // dominant-kernel timing (filled by the pipeline)
+    double dom_us = 0; uint64_t dom_launches = 0;
+};
+
+struct kc_set {
+    kc_ctx *ctx = nullptr;
+    int k = 0, W = 1, complements = 1;
+    u64 cap = 0;          // slots
+    u64 *keys = nullptr;  // cap * W words; W==1: EMPTY = ~0
+    u32 *state = nullptr; // W>1: 0 empty, 1 busy, 2 full
+    u64 *counters = nullptr;  // device: [0] size, [1] overflow flag
+    u64 size_host = 0;
+};
+
+struct kc_simplitigs {
+    kc_ctx *ctx = nullptr;
+    int k = 0, W = 1;
+    u64 n = 0, total_bases = 0, nwords = 0;
+    u64 *lens = nullptr;   // n: bases per simplitig
+    u64 *woff = nullptr;   // n+1: first 64-bit word of each simplitig (32 bases per word, MSB first, word aligned)
+    u64 *words = nullptr;  // nwords
+    u64 *firstK = nullptr; // n*W: first k-mer
+    u64 *lastK = nullptr;  // n*W: last k-mer
+};
+
+struct kc_result {
+    kc_ctx *ctx = nullptr;
+    char *d_out = nullptr, *d_mask = nullptr;
+    u64 length = 0;
+    u64 stats[16] = {0};
+};
+
+#define KC_HIP(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e__ = (call);                                                                           \
+        if (e__ != hipSuccess) {                                                                           \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
+            return KC_E_NO_DEVICE;                                                                         \
+        }                                                                                                  \
+    } while (0)
+
+#define KC_TRY(expr)                 \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != KC_OK) return rc__; \
+    } while (0)
+
+static inline int kc_fail(kc_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <typename T> static inline int kc_alloc(kc_ctx *ctx, T **out, size_t count) {
+    void *p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = ctx->pool.alloc(&p, bytes);
+    if (e != hipSuccess) {
+        ctx->err = std::string("device allocation of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e);
+        return KC_E_NO_DEVICE;
+    }
+    *out = (T *)p;
+    return KC_OK;
+}
+static inline void kc_release(kc_ctx *ctx, void *p) { if (p) ctx->pool.release(p); }
+
+static inline unsigned kc_grid(u64 n, unsigned block) { u64 g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
+
+// ---- cross-TU host entry points (each dispatches on W internally) ----
+// kc_set.hip
+int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk, u64 **d_low);
+int kcs_reserve(kc_set *set, u64 additional);
+int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive);
+int kcs_refresh_size(kc_set *set);
+// kc_simplitigs.hip
+int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds);
+int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 len, const u64 *h_offsets, u64 n, int offsets_are_host_positions,
+                                     kc_simplitigs **out);
+int kcp_to_sparse(kc_simplitigs *s, kc_simplitigs **out);
+int kcp_insert_simplitig_kmers(kc_set *set, kc_simplitigs *s);
+// kc_overlap.hip
+struct KcPathDev { u64 V = 0; u64 *edge_from = nullptr; u8 *overlaps = nullptr; u64 *pred = nullptr; u64 repairs = 0; };
+int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out);
+void kco_path_release(kc_ctx *ctx, KcPathDev *p);
+// kc_emit.hip
+int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc_set *set_for_mask, char **d_out, char **d_mask, u64 *length);
+int kce_maskopt(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out);

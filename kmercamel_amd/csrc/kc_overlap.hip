@@ -1,0 +1,500 @@
+// Phase 2 of the BIGREEDY path on gfx950: greedy largest-overlap Hamiltonian path over the simplitigs.
+// Replaces OverlapHamiltonianPath / OverlapHamiltonianPathSparse (global.h:43-133, global_sparse.h:43-132) with
+// byte-identical edge_from / overlaps arrays.
+//
+// The reference scans every vertex 16 times per overlap length d (MEMORY_REDUCTION_FACTOR, global.h:33,64-66) against
+// a hash map of 1/16 of the prefixes.  Here each level d does
+//   1. bucket : insert the d-mer prefix keys of all active prefix vertices into a level hash table in HBM (CAS claim),
+//               probe it with the d-mer suffix keys of all active suffix vertices, flag keys seen from both sides;
+//   2. compact: ordered stream compaction of the vertices whose key was seen from both sides (the "hits"), only for
+//               the representative key of each {key, RC(key)} pair;
+//   3. sort   : stable radix sort of the hits by key (ids stay ascending inside a key);
+//   4. match  : one thread per key bucket replays the reference's event order for that bucket pair
+//               (kc_overlap_logic.h), buckets run in parallel;
+//   5. verify : path ends of merged paths are recomputed from the level's new edges; a cycle can only appear when two
+//               buckets extended the same path in one level and the stale cycle test let an edge through -- the
+//               earliest such event is blacklisted, the level is undone and replayed (exactness argument in DESIGN.md);
+//   6. shrink : ordered compaction of the active lists.
+// Levels without hits (almost all d > log4 V) cost two streaming kernels.
+#include "kc_internal.h"
+#include "kc_overlap_logic.h"
+#include <hipcub/hipcub.hpp>
+
+#define LV_EMPTY (~(u64)0)
+
+template <int W> struct LevelTable {
+    u64 *slot;     // W==1: the d-mer key; W>1: a representative prefix vertex (its key is re-derived from pre[])
+    u32 *flags;    // bit0: has an active prefix, bit1: has an active suffix
+    u64 mask;      // capacity - 1 (power of two)
+};
+
+template <int W> __device__ __forceinline__ Key<W> load_key(const u64 *a, u64 i) {
+    Key<W> r;
+    for (int j = 0; j < W; ++j) r.w[j] = a[i * W + j];
+    return r;
+}
+
+// insert-or-find for a prefix vertex j with d-mer key `key`
+template <int W>
+__device__ __forceinline__ u64 level_insert(const LevelTable<W> &t, const Key<W> &key, u64 j, const u64 *pre, int k, int d) {
+    u64 s = key_hash(key) & t.mask;
+    while (true) {
+        u64 cur = __hip_atomic_load(&t.slot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == LV_EMPTY) {
+            u64 want = (W == 1) ? key.w[0] : j;
+            u64 prev = atomicCAS((ull *)&t.slot[s], (ull)LV_EMPTY, (ull)want);
+            if (prev == LV_EMPTY) return s;
+            cur = prev;
+        }
+        bool same;
+        if constexpr (W == 1) same = (cur == key.w[0]);
+        else same = key_eq(key_prefix(load_key<W>(pre, cur), k, d), key);
+        if (same) return s;
+        s = (s + 1) & t.mask;
+    }
+}
+template <int W>
+__device__ __forceinline__ u64 level_find(const LevelTable<W> &t, const Key<W> &key, const u64 *pre, int k, int d) {
+    u64 s = key_hash(key) & t.mask;
+    while (true) {
+        u64 cur = t.slot[s];
+        if (cur == LV_EMPTY) return KC_NONE64;
+        bool same;
+        if constexpr (W == 1) same = (cur == key.w[0]);
+        else same = key_eq(key_prefix(load_key<W>(pre, cur), k, d), key);
+        if (same) return s;
+        s = (s + 1) & t.mask;
+    }
+}
+
+// vertex end k-mers: pre[v] / suf[v] (accessPrefix / accessSuffix, global.h:16-21)
+template <int W>
+__global__ void __launch_bounds__(256) ov_init_kernel(const u64 *__restrict__ firstK, const u64 *__restrict__ lastK, u64 S, u64 V, int k,
+                                                      u64 *pre, u64 *suf, u64 *edge_from, u8 *overlaps, u64 *pred, u64 *first, u64 *last,
+                                                      u64 *first_snap, u64 *last_snap, u64 *actS, u64 *actP, u64 *eidx) {
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    Key<W> p, s;
+    if (v < S) { p = load_key<W>(firstK, v); s = load_key<W>(lastK, v); }
+    else { p = key_rc(load_key<W>(lastK, v - S), k); s = key_rc(load_key<W>(firstK, v - S), k); }
+    for (int j = 0; j < W; ++j) { pre[v * W + j] = p.w[j]; suf[v * W + j] = s.w[j]; }
+    edge_from[v] = KC_NONE64; overlaps[v] = 0xff; pred[v] = KC_NONE64;
+    first_snap[v] = last_snap[v] = v;
+    actS[v] = v; actP[v] = v; eidx[v] = KC_NONE64;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) ov_insert_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
+                                                               const u64 *__restrict__ pre, int k, int d, u64 *pslot) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nP) return;
+    u64 j = actP[i];
+    Key<W> key = key_prefix(load_key<W>(pre, j), k, d);
+    u64 s = level_insert(t, key, j, pre, k, d);
+    atomicOr(&t.flags[s], 1u);
+    pslot[i] = s;
+}
+
+// representative rule: a {key, RC(key)} pair is handled by the smaller of the two keys
+template <int W> __device__ __forceinline__ bool is_representative(const Key<W> &key, int d, int complements) {
+    if (!complements || d == 0) return true;
+    Key<W> r = key_rc(key, d);
+    return !key_lt(r, key);
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, const u64 *__restrict__ actS, u64 nS,
+                                                              const u64 *__restrict__ suf, const u64 *__restrict__ pre, int k, int d,
+                                                              int complements, u8 *hitS, u64 *hit_count) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nS) return;
+    u64 v = actS[i];
+    Key<W> key = key_suffix(load_key<W>(suf, v), d);
+    u64 s = level_find(t, key, pre, k, d);
+    u8 hit = 0;
+    if (s != KC_NONE64) {
+        atomicOr(&t.flags[s], 2u);
+        if (is_representative(key, d, complements)) hit = 1;
+    }
+    hitS[i] = hit;
+    if (hit) atomicAdd((ull *)hit_count, 1ULL);
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
+                                                             const u64 *__restrict__ pre, const u64 *__restrict__ pslot, int k, int d,
+                                                             int complements, u8 *hitP) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nP) return;
+    u8 hit = 0;
+    if (t.flags[pslot[i]] & 2u) {
+        Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
+        if (is_representative(key, d, complements)) hit = 1;
+    }
+    hitP[i] = hit;
+}
+
+template <int W, bool SUFFIX>
+__global__ void __launch_bounds__(256) ov_hit_keys_kernel(const u64 *__restrict__ ids, u64 n, const u64 *__restrict__ ends, int k, int d,
+                                                          u64 *keys) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Key<W> e = load_key<W>(ends, ids[i]);
+    Key<W> key = SUFFIX ? key_suffix(e, d) : key_prefix(e, k, d);
+    for (int j = 0; j < W; ++j) keys[i * W + j] = key.w[j];
+}
+
+__global__ void __launch_bounds__(256) ov_iota_kernel(u64 *a, u64 n) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] = t;
+}
+__global__ void __launch_bounds__(256) ov_gather_word_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ perm, u64 n, int W,
+                                                             int word, u64 *out) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = keys[perm[t] * W + word];
+}
+__global__ void __launch_bounds__(256) ov_gather_rows_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ ids,
+                                                             const u64 *__restrict__ perm, u64 n, int W, u64 *keys_out, u64 *ids_out) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 p = perm[t];
+    for (int j = 0; j < W; ++j) keys_out[t * W + j] = keys[p * W + j];
+    ids_out[t] = ids[p];
+}
+
+template <int W> __device__ __forceinline__ int cmp_rows(const u64 *a, u64 i, const Key<W> &key) {  // -1 a<key, 0 eq, 1 a>key
+    Key<W> x = load_key<W>(a, i);
+    if (key_lt(x, key)) return -1;
+    return key_eq(x, key) ? 0 : 1;
+}
+
+// one thread per sorted suffix hit; the first hit of a key run replays the whole bucket (pair)
+template <int W>
+__global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__restrict__ hsk, const u64 *__restrict__ hsv, u64 nHS,
+                                                      const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nHS) return;
+    Key<W> key = load_key<W>(hsk, t);
+    if (t > 0 && key_eq(load_key<W>(hsk, t - 1), key)) return;
+    u64 a1 = t + 1;
+    while (a1 < nHS && key_eq(load_key<W>(hsk, a1), key)) ++a1;
+    u64 lo = 0, hi = nHP;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (cmp_rows<W>(hpk, mid, key) < 0) lo = mid + 1; else hi = mid; }
+    u64 b0 = lo, b1 = lo;
+    while (b1 < nHP && key_eq(load_key<W>(hpk, b1), key)) ++b1;
+    if (b1 == b0) return;
+    int mode = KC_MODE_UNI;
+    if (g.complements) mode = (g.d == 0 || key_eq(key_rc(key, g.d), key)) ? KC_MODE_PAL : KC_MODE_PAIR;
+    kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, (u32)t);
+}
+
+// remember, per vertex, which log entry created its in-edge (used only by the cycle repair)
+__global__ void __launch_bounds__(256) ov_index_edges_kernel(const u64 *__restrict__ ne, u64 n, u64 *eidx) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) eidx[ne[t * 5 + 1]] = t;
+}
+
+// Path ends after the level: walk back from every merged path's tail over the level's new edges.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) ov_fix_kernel(const u64 *__restrict__ ne, u64 n, const u64 *__restrict__ edge_from,
+                                                     const u64 *__restrict__ pred, u64 *first_snap, u64 *last_snap, u8 *cov, u64 *covered) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 y = ne[t * 5 + 1];
+    u64 l0 = last_snap[y];
+    if (edge_from[l0] != KC_NONE64) return;   // not the tail of its merged path
+    u64 f = y, steps = 0;
+    while (steps <= n) {
+        u64 xp = pred[f];
+        if (xp == KC_NONE64) break;
+        if (!WRITE) cov[f] = 1;
+        ++steps;
+        f = first_snap[xp];
+    }
+    if (WRITE) { first_snap[l0] = f; last_snap[f] = l0; }
+    else atomicAdd((ull *)covered, (ull)steps);
+}
+
+// cycle repair (rare, one thread): among the cycles left uncovered, find the one whose latest event is earliest, and
+// report that event (u, c).  res = {found, part, u, c}
+__global__ void ov_find_cycle_kernel(const u64 *__restrict__ ne, u64 n, const u64 *__restrict__ first_snap, const u64 *__restrict__ eidx,
+                                     u8 *cov, u64 *res) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    u64 best_part = ~0ull, best_u = ~0ull, best_c = 0, found = 0;
+    for (u64 e = 0; e < n; ++e) {
+        u64 y0 = ne[e * 5 + 1];
+        if (cov[y0]) continue;
+        u64 cur = y0, mp = 0, mu = 0, mc = 0;
+        bool any = false;
+        do {
+            cov[cur] = 1;
+            const u64 *ed = ne + eidx[cur] * 5;
+            u64 part = ed[4], eu = ed[2], ec = ed[3];
+            if (!any || part > mp || (part == mp && eu > mu)) { mp = part; mu = eu; mc = ec; any = true; }
+            cur = first_snap[ed[0]];
+        } while (cur != y0);
+        if (!found || mp < best_part || (mp == best_part && mu < best_u)) { best_part = mp; best_u = mu; best_c = mc; found = 1; }
+    }
+    res[0] = found; res[1] = best_part; res[2] = best_u; res[3] = best_c;
+}
+
+__global__ void __launch_bounds__(256) ov_undo_kernel(const u64 *__restrict__ ne, u64 n, u64 *edge_from, u8 *overlaps, u64 *pred, u64 *eidx,
+                                                      u8 *cov) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 x = ne[t * 5], y = ne[t * 5 + 1];
+    edge_from[x] = KC_NONE64; overlaps[x] = 0xff; pred[y] = KC_NONE64; eidx[y] = KC_NONE64; cov[y] = 0;
+}
+__global__ void __launch_bounds__(256) ov_clear_cov_kernel(const u64 *__restrict__ ne, u64 n, u8 *cov) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) cov[ne[t * 5 + 1]] = 0;
+}
+
+template <bool SUFFIX>
+__global__ void __launch_bounds__(256) ov_still_active_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ edge_from,
+                                                              const u64 *__restrict__ pred, u8 *keep) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 v = act[t];
+    keep[t] = SUFFIX ? (edge_from[v] == KC_NONE64) : (pred[v] == KC_NONE64);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct OvWork {
+    kc_ctx *ctx;
+    void *tmp = nullptr; size_t tmp_bytes = 0;
+    u64 *d_num = nullptr;
+    int ensure_tmp(size_t bytes) {
+        if (bytes <= tmp_bytes) return KC_OK;
+        kc_release(ctx, tmp);
+        tmp = nullptr; tmp_bytes = 0;
+        u8 *p = nullptr;
+        KC_TRY(kc_alloc(ctx, &p, bytes));
+        tmp = p; tmp_bytes = bytes;
+        return KC_OK;
+    }
+};
+
+static int select_flagged(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u64 n, u64 *h_count) {
+    kc_ctx *ctx = w.ctx;
+    size_t bytes = 0;
+    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
+    KC_TRY(w.ensure_tmp(bytes));
+    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(w.tmp, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(h_count, w.d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+
+// stable sort of n rows (W-word keys, 2*d significant bits) with their ids; outputs in keys_out / ids_out
+static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, int d, u64 *keys_out, u64 *ids_out, u64 *s0, u64 *s1,
+                     u64 *s2, u64 *s3) {
+    kc_ctx *ctx = w.ctx;
+    int total_bits = 2 * d;
+    if (total_bits == 0) {
+        KC_HIP(ctx, hipMemcpyAsync(keys_out, keys, n * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(ids_out, ids, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return KC_OK;
+    }
+    if (W == 1) {
+        size_t bytes = 0;
+        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys_out, ids, ids_out, (int)n, 0, total_bits, ctx->stream));
+        KC_TRY(w.ensure_tmp(bytes));
+        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(w.tmp, bytes, keys, keys_out, ids, ids_out, (int)n, 0, total_bits, ctx->stream));
+        return KC_OK;
+    }
+    u64 *perm = s0, *perm2 = s1, *kw = s2, *kw2 = s3;
+    hipLaunchKernelGGL(ov_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
+    for (int word = 0; word < W; ++word) {
+        int bits = total_bits - 64 * word;
+        if (bits <= 0) break;
+        if (bits > 64) bits = 64;
+        hipLaunchKernelGGL(ov_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, (const u64 *)perm, n, W, word, kw);
+        size_t bytes = 0;
+        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kw, kw2, perm, perm2, (int)n, 0, bits, ctx->stream));
+        KC_TRY(w.ensure_tmp(bytes));
+        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(w.tmp, bytes, kw, kw2, perm, perm2, (int)n, 0, bits, ctx->stream));
+        std::swap(perm, perm2);
+    }
+    hipLaunchKernelGGL(ov_gather_rows_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, (const u64 *)perm, n, W, keys_out,
+                       ids_out);
+    KC_HIP(ctx, hipGetLastError());
+    return KC_OK;
+}
+
+template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out) {
+    kc_ctx *ctx = s->ctx;
+    const int k = s->k;
+    const u64 S = s->n, V = S * (complements ? 2 : 1);
+    if (S == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    if (V >= ((u64)1 << 31)) return kc_fail(ctx, KC_E_ARG, "more than 2^31 overlap-graph vertices are not supported yet");
+    OvWork w; w.ctx = ctx;
+    u64 *pre, *suf, *edge_from, *pred, *first, *last, *first_snap, *last_snap, *actS, *actP, *actS2, *actP2, *eidx;
+    u8 *overlaps, *hitS, *hitP, *cov;
+    u64 *pslot, *ne, *cnt, *bl;
+    KC_TRY(kc_alloc(ctx, &pre, V * W)); KC_TRY(kc_alloc(ctx, &suf, V * W));
+    KC_TRY(kc_alloc(ctx, &edge_from, V)); KC_TRY(kc_alloc(ctx, &pred, V)); KC_TRY(kc_alloc(ctx, &overlaps, V));
+    KC_TRY(kc_alloc(ctx, &first, V)); KC_TRY(kc_alloc(ctx, &last, V)); KC_TRY(kc_alloc(ctx, &first_snap, V)); KC_TRY(kc_alloc(ctx, &last_snap, V));
+    KC_TRY(kc_alloc(ctx, &actS, V)); KC_TRY(kc_alloc(ctx, &actP, V)); KC_TRY(kc_alloc(ctx, &actS2, V)); KC_TRY(kc_alloc(ctx, &actP2, V));
+    KC_TRY(kc_alloc(ctx, &eidx, V)); KC_TRY(kc_alloc(ctx, &hitS, V)); KC_TRY(kc_alloc(ctx, &hitP, V)); KC_TRY(kc_alloc(ctx, &cov, V));
+    KC_TRY(kc_alloc(ctx, &pslot, V)); KC_TRY(kc_alloc(ctx, &ne, V * 10 + 10)); KC_TRY(kc_alloc(ctx, &cnt, 16));  // ne: up to two log entries per event
+    const u64 BL_MAX = 4096;
+    KC_TRY(kc_alloc(ctx, &bl, BL_MAX * 2));
+    KC_TRY(kc_alloc(ctx, &w.d_num, 2));
+    u64 tcap = 64;
+    while (tcap < 2 * V + 16) tcap <<= 1;
+    LevelTable<W> tab;
+    KC_TRY(kc_alloc(ctx, &tab.slot, tcap)); KC_TRY(kc_alloc(ctx, &tab.flags, tcap));
+    // hit buffers
+    u64 *hs_ids, *hp_ids, *hs_keys, *hp_keys, *hs_ids2, *hp_ids2, *hs_keys2, *hp_keys2, *sc0, *sc1, *sc2, *sc3;
+    KC_TRY(kc_alloc(ctx, &hs_ids, V)); KC_TRY(kc_alloc(ctx, &hp_ids, V)); KC_TRY(kc_alloc(ctx, &hs_ids2, V)); KC_TRY(kc_alloc(ctx, &hp_ids2, V));
+    KC_TRY(kc_alloc(ctx, &hs_keys, V * W)); KC_TRY(kc_alloc(ctx, &hp_keys, V * W)); KC_TRY(kc_alloc(ctx, &hs_keys2, V * W)); KC_TRY(kc_alloc(ctx, &hp_keys2, V * W));
+    sc0 = sc1 = sc2 = sc3 = nullptr;
+    if (W > 1) { KC_TRY(kc_alloc(ctx, &sc0, V)); KC_TRY(kc_alloc(ctx, &sc1, V)); KC_TRY(kc_alloc(ctx, &sc2, V)); KC_TRY(kc_alloc(ctx, &sc3, V)); }
+
+    KC_HIP(ctx, hipMemsetAsync(cov, 0, V, ctx->stream));
+    hipLaunchKernelGGL((ov_init_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->firstK, (const u64 *)s->lastK, S, V, k,
+                       pre, suf, edge_from, overlaps, pred, first, last, first_snap, last_snap, actS, actP, eidx);
+    KC_HIP(ctx, hipGetLastError());
+
+    OvArgs g;
+    g.S = S; g.V = V; g.batch = V / 16 + 1; g.complements = complements; g.lower_bound = lower_bound;
+    g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
+    g.first_snap = first_snap; g.last_snap = last_snap;
+    g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0;
+    u64 nS = V, nP = V, repairs = 0;
+    std::vector<u64> h_bl;
+
+    for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
+        g.d = d;
+        // 1. bucket
+        u64 lcap = 64;
+        while (lcap < 2 * nP + 16) lcap <<= 1;
+        tab.mask = lcap - 1;
+        KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 8, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(tab.flags, 0, lcap * 4, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
+                           (const u64 *)pre, k, d, pslot);
+        hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
+                           (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1);
+        u64 h2[2];
+        KC_HIP(ctx, hipMemcpyAsync(h2, cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h2[1] == 0) continue;   // no key seen from both sides at this overlap length
+        // 2. compact the hits (ordered)
+        hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
+                           (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP);
+        u64 nHS = 0, nHP = 0;
+        KC_TRY(select_flagged(w, actS, hitS, hs_ids, nS, &nHS));
+        KC_TRY(select_flagged(w, actP, hitP, hp_ids, nP, &nHP));
+        if (nHS == 0 || nHP == 0) continue;
+        hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
+                           (const u64 *)suf, k, d, hs_keys);
+        hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
+                           (const u64 *)pre, k, d, hp_keys);
+        // 3. sort by key (stable: ids ascending inside a key)
+        KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
+        KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3));
+        // 4./5. match, verify, repair
+        while (true) {
+            KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+            if (!lower_bound) {   // forget the path-end entries other levels / replays wrote (tag = none)
+                KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
+                KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
+            }
+            hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
+                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP);
+            KC_HIP(ctx, hipGetLastError());
+            u64 nNew = 0;
+            KC_HIP(ctx, hipMemcpyAsync(&nNew, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (nNew == 0 || lower_bound) break;
+            hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew,
+                               (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
+            u64 covered = 0;
+            KC_HIP(ctx, hipMemcpyAsync(&covered, cnt + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (covered == nNew) {
+                hipLaunchKernelGGL((ov_fix_kernel<true>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew,
+                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
+                hipLaunchKernelGGL(ov_clear_cov_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, cov);
+                break;
+            }
+            // a cycle slipped through a stale path-end test: blacklist its earliest closing event, undo, replay
+            ++repairs;
+            if (h_bl.size() / 2 >= BL_MAX) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap repair list exhausted");
+            hipLaunchKernelGGL(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, eidx);
+            hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)ne, nNew, (const u64 *)first_snap,
+                               (const u64 *)eidx, cov, cnt + 4);
+            u64 res[4];
+            KC_HIP(ctx, hipMemcpyAsync(res, cnt + 4, 32, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (!res[0]) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap verification failed without a cycle");
+            h_bl.push_back(res[2]); h_bl.push_back(res[3]);
+            KC_HIP(ctx, hipMemcpyAsync(bl, h_bl.data(), h_bl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            g.nbl = h_bl.size() / 2;
+            hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, edge_from, overlaps, pred,
+                               eidx, cov);
+        }
+        h_bl.clear(); g.nbl = 0;   // the blacklist is per level
+        // 6. shrink the active lists
+        hipLaunchKernelGGL((ov_still_active_kernel<true>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, nS,
+                           (const u64 *)edge_from, (const u64 *)pred, hitS);
+        hipLaunchKernelGGL((ov_still_active_kernel<false>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP,
+                           (const u64 *)edge_from, (const u64 *)pred, hitP);
+        u64 nS2 = 0, nP2 = 0;
+        KC_TRY(select_flagged(w, actS, hitS, actS2, nS, &nS2));
+        KC_TRY(select_flagged(w, actP, hitP, actP2, nP, &nP2));
+        std::swap(actS, actS2); std::swap(actP, actP2);
+        nS = nS2; nP = nP2;
+    }
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
+    void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt, bl, w.d_num,
+                   tab.slot, tab.flags, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
+    for (void *p : rel) kc_release(ctx, p);
+    return KC_OK;
+}
+
+int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out) {
+    switch (s->W) {
+        case 1: return overlap_path_w<1>(s, complements, lower_bound, out);
+        case 2: return overlap_path_w<2>(s, complements, lower_bound, out);
+        default: return overlap_path_w<4>(s, complements, lower_bound, out);
+    }
+}
+void kco_path_release(kc_ctx *ctx, KcPathDev *p) {
+    kc_release(ctx, p->edge_from); kc_release(ctx, p->overlaps); kc_release(ctx, p->pred);
+    p->edge_from = nullptr; p->overlaps = nullptr; p->pred = nullptr;
+}
+
+extern "C" int kc_overlap_path(kc_simplitigs *s, int complements, int lower_bound, uint64_t *edge_from, uint8_t *overlaps) {
+    if (!s || !edge_from || !overlaps) return KC_E_ARG;
+    kc_ctx *ctx = s->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    KcPathDev p;
+    KC_TRY(kco_overlap_path_device(s, complements ? 1 : 0, lower_bound ? 1 : 0, &p));
+    KC_HIP(ctx, hipMemcpyAsync(edge_from, p.edge_from, p.V * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(overlaps, p.overlaps, p.V, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kco_path_release(ctx, &p);
+    return KC_OK;
+}
+
+extern "C" int kc_lower_bound(kc_simplitigs *s, int complements, uint64_t *length) {   // lower_bound.h:7-21
+    if (!s || !length) return KC_E_ARG;
+    kc_ctx *ctx = s->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    KcPathDev p;
+    KC_TRY(kco_overlap_path_device(s, complements ? 1 : 0, 1, &p));
+    std::vector<u8> ov(p.V);
+    KC_HIP(ctx, hipMemcpyAsync(ov.data(), p.overlaps, p.V, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kco_path_release(ctx, &p);
+    // res = sum(simplitig.size()/(2-complements)) [size in bits] - sum(overlaps incl. 0xFF wrap like the reference's size_t arithmetic]
+    u64 res = s->total_bases * 2 / (complements ? 1 : 2);
+    for (u8 o : ov) res -= o;
+    *length = res / (complements ? 2 : 1);
+    return KC_OK;
+}

@@ -1,0 +1,135 @@
+// Sequential-equivalent greedy matching inside one key bucket of one overlap length d.
+// Restates the inner loops of OverlapHamiltonianPath (global.h:63-128) in a layout-free form:
+//
+//   reference event order      : for d = k-1..0, for part = 0..15, for suffix vertex i ascending (global.h:63,66,86)
+//   candidates of an event      : prefix vertices j with prefix_d(j) == suffix_d(i) inside part's index range
+//                                 [part*batch, (part+1)*batch), batch = V/16+1, in DESCENDING j (the per-key chains are
+//                                 built by head insertion, global.h:73-85), skipping j that already has an in-edge,
+//                                 j == mirror(i) and j == first vertex of i's path (global.h:91-105)
+//   accepted edge               : i -> j with overlap d, plus the mirrored edge mirror(j) -> mirror(i) (global.h:108-122)
+//
+// Vertices with the same d-mer key only interact with each other and -- through the mirrored edge -- with the bucket
+// of the reverse-complement key, whose members are exactly the mirrors of this bucket's members.  One call of
+// kc_match_bucket therefore replays, in the reference's order, all events of the bucket pair {key, RC(key)}.
+// The cycle test needs the first vertex of i's path.  Buckets of one level run concurrently and another bucket may be
+// ahead in the reference's event order, so a bucket must not read path ends written by other buckets in this level:
+// live path-end entries carry the id of the bucket that wrote them; a bucket trusts only its own entries and
+// otherwise falls back to the level-start snapshot.  The information it uses is therefore always a sub-forest of
+// the true path forest at that event, so the test can only MISS a cycle (never reject a legal edge); a missed cycle
+// shows up as a cycle after the level, which the caller detects and repairs (DESIGN.md "Exactness of phase 2").
+//
+// Compiles for the device (hipcc) and for the host (g++, used by tests/sim to check this logic without a GPU).
+#pragma once
+#include "kc_key.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KC_LOG_APPEND(ptr) atomicAdd((unsigned long long *)(ptr), 1ULL)
+#else
+#define KC_LOG_APPEND(ptr) ((*(ptr))++)
+#endif
+
+struct OvArgs {
+    u64 S, V, batch;
+    int d, complements, lower_bound;
+    u64 *edge_from; u8 *overlaps; u64 *pred;      // live state, V entries each
+    u64 *first; u64 *last;                        // live path ends of this level: (writer tag << 32) | vertex
+    const u64 *first_snap; const u64 *last_snap;  // exact path ends at the start of the level
+    u64 *ne;            // new-edge log: 5 words per edge {x, y, event_u, event_c, part}
+    u64 *ne_count;
+    const u64 *bl;      // blacklist of (u, c) pairs proven to close a cycle
+    u64 nbl;
+};
+
+#define KC_MODE_UNI 0
+#define KC_MODE_PAL 1
+#define KC_MODE_PAIR 2
+
+struct OvList {      // ascending list of vertex ids; `mirrored` views base[] through v -> mirror(v), still ascending
+    const u64 *base;
+    u64 n, split, S;
+    int mirrored;
+    KC_HD u64 get(u64 t) const {
+        if (!mirrored) return base[t];
+        u64 hi = n - split;  // elements >= S come first after mirroring (v - S), then the ones < S (v + S)
+        return t < hi ? base[split + t] - S : base[t - hi] + S;
+    }
+};
+KC_HD u64 ov_lower_bound(const OvList &l, u64 v) {  // first t with l.get(t) >= v
+    u64 lo = 0, hi = l.n;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (l.get(mid) < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+KC_HD u64 ov_split(const u64 *a, u64 n, u64 S) {  // first index with a[idx] >= S
+    u64 lo = 0, hi = n;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (a[mid] < S) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+KC_HD u64 ov_mirror(u64 v, u64 S) { return v < S ? v + S : v - S; }
+
+#define KC_NO_TAG 0xffffffffu
+KC_HD u64 ov_end_of(const u64 *live, const u64 *snap, u64 v, u32 tag) {
+    u64 w = live[v];
+    return ((u32)(w >> 32) == tag) ? (w & 0xffffffffull) : snap[v];
+}
+
+KC_HD void ov_add_edge(const OvArgs &g, u64 x, u64 y, u64 eu, u64 ec, u64 part, u32 tag) {  // global.h:113-122
+    g.edge_from[x] = y;
+    g.overlaps[x] = (u8)g.d;
+    g.pred[y] = x;
+    if (!g.lower_bound) {   // path ends are only needed by the cycle test
+        u64 lastY = ov_end_of(g.last, g.last_snap, y, tag), firstX = ov_end_of(g.first, g.first_snap, x, tag);
+        g.first[lastY] = ((u64)tag << 32) | firstX;
+        g.last[firstX] = ((u64)tag << 32) | lastY;
+    }
+    u64 pos = KC_LOG_APPEND(g.ne_count);
+    u64 *e = g.ne + pos * 5;
+    e[0] = x; e[1] = y; e[2] = eu; e[3] = ec; e[4] = part;
+}
+
+// A: suffix-side members (vertex ids ascending) of the bucket, B: prefix-side members (ascending).
+KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, u64 nB, int mode, u32 tag) {
+    const u64 S = g.S;
+    OvList E1{A, nA, 0, S, 0}, C1{B, nB, 0, S, 0};
+    OvList E2{B, 0, 0, S, 1}, C2{A, 0, 0, S, 1};
+    if (mode == KC_MODE_PAIR) {
+        E2.n = nB; E2.split = ov_split(B, nB, S);
+        C2.n = nA; C2.split = ov_split(A, nA, S);
+    }
+    for (u64 part = 0; part < 16; ++part) {
+        u64 lo_v = part * g.batch, hi_v = (part + 1) * g.batch;
+        if (lo_v >= g.V) break;
+        u64 cl1 = ov_lower_bound(C1, lo_v), top1 = ov_lower_bound(C1, hi_v);
+        u64 cl2 = 0, top2 = 0;
+        if (mode == KC_MODE_PAIR) { cl2 = ov_lower_bound(C2, lo_v); top2 = ov_lower_bound(C2, hi_v); }
+        if (top1 == cl1 && top2 == cl2) continue;
+        u64 i1 = 0, i2 = 0;
+        while (i1 < E1.n || i2 < E2.n) {
+            u64 u; int from;
+            if (i2 >= E2.n) { u = E1.get(i1++); from = 1; }
+            else if (i1 >= E1.n) { u = E2.get(i2++); from = 2; }
+            else {
+                u64 a = E1.get(i1), b = E2.get(i2);
+                if (a <= b) { u = a; ++i1; from = 1; } else { u = b; ++i2; from = 2; }
+            }
+            if (g.edge_from[u] != KC_NONE64) continue;                       // suffixForbidden (global.h:87)
+            const OvList &C = (from == 1) ? C1 : C2;
+            u64 &top = (from == 1) ? top1 : top2;
+            const u64 cl = (from == 1) ? cl1 : cl2;
+            while (top > cl && g.pred[C.get(top - 1)] != KC_NONE64) --top;    // used candidates never come back
+            for (u64 t = top; t > cl; --t) {
+                u64 c = C.get(t - 1);
+                if (g.pred[c] != KC_NONE64) continue;                         // prefixForbidden (global.h:97)
+                if (!g.lower_bound) {
+                    if (g.complements && c == ov_mirror(u, S)) continue;      // complementary (global.h:93)
+                    if (ov_end_of(g.first, g.first_snap, u, tag) == c) continue;   // would close a cycle (global.h:95)
+                    bool banned = false;
+                    for (u64 q = 0; q < g.nbl; ++q) banned = banned || (g.bl[2 * q] == u && g.bl[2 * q + 1] == c);
+                    if (banned) continue;
+                }
+                ov_add_edge(g, u, c, u, c, part, tag);
+                if (g.complements) ov_add_edge(g, ov_mirror(c, S), ov_mirror(u, S), u, c, part, tag);   // global.h:110-112
+                break;
+            }
+        }
+    }
+}

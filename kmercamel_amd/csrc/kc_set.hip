@@ -1,0 +1,392 @@
+// Phase 0 of the BIGREEDY path on gfx950: ASCII -> packed 2-bit sequence, rolling canonical k-mers, open-addressing
+// set build in HBM.  Replaces AddKMers + kh_put (parser.h:22-49, khash.h:311-352) and the khash set itself
+// (khash.h:215-359, khash_utils.h:28-95).  Integer/byte work, HBM-bound: no LDS tiling is needed for the packed
+// stream (each thread reads its own few words, neighbouring lanes read neighbouring words), the cost is the random
+// 8-byte (W*8-byte) slot access of the insert.
+#include "kc_internal.h"
+#include "kc_set_dev.h"
+
+// ------------------------------------------------------------------------------------------------- pool / ctx
+hipError_t KcPool::alloc(void **out, size_t bytes) {
+    const size_t gran = (size_t)2 << 20;
+    size_t need = (bytes + gran - 1) / gran * gran;
+    int best = -1;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+        if (free_list[i].size >= need && free_list[i].size <= need * 2 + gran) {
+            if (best < 0 || free_list[i].size < free_list[best].size) best = (int)i;
+        }
+    }
+    if (best >= 0) {
+        *out = free_list[best].p;
+        live[*out] = free_list[best].size;
+        live_bytes += free_list[best].size;
+        free_list.erase(free_list.begin() + best);
+        if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, need);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        trim();
+        e = hipMalloc(out, need);
+        if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    }
+    live[*out] = need;
+    live_bytes += need;
+    if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+    return hipSuccess;
+}
+void KcPool::release(void *p) {
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    free_list.push_back({it->second, p});
+    live_bytes -= it->second;
+    live.erase(it);
+}
+void KcPool::trim() {
+    for (auto &b : free_list) (void)hipFree(b.p);
+    free_list.clear();
+}
+KcPool::~KcPool() {
+    trim();
+    for (auto &kv : live) (void)hipFree(kv.first);
+    live.clear();
+}
+
+extern "C" int kc_ctx_create(int device, kc_ctx **out) {
+    if (!out) return KC_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return KC_E_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return KC_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return KC_E_NO_DEVICE;
+    kc_ctx *ctx = new kc_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KC_E_NO_DEVICE; }
+    for (int i = 0; i < 8; ++i) {
+        if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return KC_E_NO_DEVICE; }
+    }
+    *out = ctx;
+    return KC_OK;
+}
+extern "C" void kc_ctx_destroy(kc_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+extern "C" const char *kc_last_error(const kc_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" void *kc_ctx_stream(kc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int kc_ctx_synchronize(kc_ctx *ctx) {
+    if (!ctx) return KC_E_ARG;
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+extern "C" void kc_free(void *p) { free(p); }
+extern "C" const char *kc_version(void) { return "kmercamel_amd 0.1 (gfx950; path of KmerCamel v2.3.0 compute/greedy)"; }
+
+// ------------------------------------------------------------------------------------------------- pack2bit
+// One thread per 64 input bytes: two 2-bit code words (32 bases each, first base in bits 63:62), one break-bit word
+// (bit j = byte j is not ACGTacgt, kmers.h:15-32) and one lower-case-bit word (bit j = byte > 'Z', parser.h:41).
+__global__ void __launch_bounds__(256) kc_pack2bit_kernel(const u8 *__restrict__ seq, u64 len, u64 *__restrict__ codes,
+                                                          u64 *__restrict__ brk, u64 *__restrict__ low, u64 nblk) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblk) return;
+    u64 base = t * 64;
+    u8 b[64];
+    if (base + 64 <= len && (((uintptr_t)seq) & 15) == 0) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(seq + base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint4 v = p[i];
+            u32 vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[i * 16 + j * 4 + q] = (u8)(vv[j] >> (8 * q));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) b[i] = (base + i < len) ? seq[base + i] : (u8)'\n';
+    }
+    u64 c0 = 0, c1 = 0, bm = 0, lm = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        u32 ch = b[i];
+        u32 up = ch & 0xDFu;
+        bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+        u32 code = (up >> 1) & 3u;   // A0 C1 G3 T2
+        code ^= code >> 1;           // A0 C1 G2 T3
+        if (i < 32) c0 |= (u64)code << (62 - 2 * i);
+        else c1 |= (u64)code << (62 - 2 * (i - 32));
+        bm |= (u64)(!ok) << i;
+        lm |= (u64)(ch > (u32)'Z') << i;
+    }
+    codes[2 * t] = c0;
+    codes[2 * t + 1] = c1;
+    brk[t] = bm;
+    low[t] = lm;
+}
+
+int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk, u64 **d_low) {
+    u64 nblk = (len + 63) / 64;
+    if (nblk == 0) nblk = 1;
+    KC_TRY(kc_alloc(ctx, d_codes, nblk * 2 + 2));
+    KC_TRY(kc_alloc(ctx, d_brk, nblk + 1));
+    KC_TRY(kc_alloc(ctx, d_low, nblk + 1));
+    hipLaunchKernelGGL(kc_pack2bit_kernel, dim3(kc_grid(nblk, 256)), dim3(256), 0, ctx->stream, (const u8 *)d_seq, len, *d_codes,
+                       *d_brk, *d_low, nblk);
+    KC_HIP(ctx, hipGetLastError());
+    return KC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- extract + insert
+// AddKMers (parser.h:22-49) over the packed stream: each thread owns PPT consecutive k-mer end positions, warms the
+// rolling forward / reverse-complement windows up over the k-1 preceding bases, then rolls (parser.h:38-39) and
+// inserts the canonical k-mer (parser.h:44) of every window that holds k valid bases (and, if case_sensitive, whose
+// first base is upper case, parser.h:41-42).
+template <int W>
+__global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
+                                                        const u64 *__restrict__ low, u64 len, int k, int complements,
+                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 e0 = t * (u64)ppt;
+    if (e0 >= len) return;
+    u64 e1 = e0 + (u64)ppt;
+    if (e1 > len) e1 = len;
+    u64 s = e0 >= (u64)(k - 1) ? e0 - (u64)(k - 1) : 0;
+    Key<W> cur = key_zero<W>(), rc = key_zero<W>();
+    int run = 0;
+    u64 added = 0;
+    bool overflow = false;
+    u64 cw = codes[s >> 5], bw = brk[s >> 6];
+    for (u64 p = s; p < e1; ++p) {
+        if ((p & 31) == 0) cw = codes[p >> 5];
+        if ((p & 63) == 0) bw = brk[p >> 6];
+        u64 b = (cw >> (62 - 2 * (p & 31))) & 3;
+        if ((bw >> (p & 63)) & 1) { run = 0; continue; }
+        cur = key_append(cur, b, k);
+        rc = key_prepend(rc, 3 - b, k);
+        if (run < k) ++run;
+        if (p >= e0 && run >= k) {
+            if (case_sensitive) {
+                u64 fp = p - (u64)(k - 1);
+                if ((low[fp >> 6] >> (fp & 63)) & 1) continue;
+            }
+            const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
+            u64 slot;
+            int r = set_insert(set, key, &slot);
+            if (r > 0) ++added;
+            else if (r < 0) overflow = true;
+        }
+    }
+    if (added) atomicAdd((ull *)&counters[0], (ull)added);
+    if (overflow) atomicExch((ull *)&counters[1], 1ULL);
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) kc_rehash_kernel(SetView<W> from, SetView<W> to, u64 *counters) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= from.cap) return;
+    if (!set_slot_full(from, t)) return;
+    Key<W> key = set_key_at(from, t);
+    u64 slot;
+    int r = set_insert(to, key, &slot);
+    if (r < 0) atomicExch((ull *)&counters[1], 1ULL);
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) kc_export_kernel(SetView<W> set, u64 *out, u64 *cursor) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= set.cap) return;
+    if (!set_slot_full(set, t)) return;
+    u64 pos = atomicAdd((ull *)cursor, 1ULL);
+    for (int i = 0; i < W; ++i) out[pos * W + i] = set.keys[t * W + i];
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) kc_contains_kernel(SetView<W> set, const u64 *keys, u64 n, u8 *out) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Key<W> key;
+    for (int i = 0; i < W; ++i) key.w[i] = keys[t * W + i];
+    out[t] = set_find(set, key) != KC_NONE64 ? 1 : 0;
+}
+
+static int set_alloc_table(kc_set *set, u64 cap, u64 **keys, u32 **state) {
+    kc_ctx *ctx = set->ctx;
+    KC_TRY(kc_alloc(ctx, keys, cap * set->W));
+    *state = nullptr;
+    if (set->W == 1) {
+        KC_HIP(ctx, hipMemsetAsync(*keys, 0xff, cap * 8, ctx->stream));
+    } else {
+        KC_TRY(kc_alloc(ctx, state, cap));
+        KC_HIP(ctx, hipMemsetAsync(*state, 0, cap * sizeof(u32), ctx->stream));
+    }
+    return KC_OK;
+}
+
+extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capacity_hint, kc_set **out) {
+    if (!ctx || !out) return KC_E_ARG;
+    *out = nullptr;
+    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    kc_set *s = new kc_set();
+    s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
+    u64 cap = (u64)((double)capacity_hint / 0.66) + 1024;
+    s->cap = cap;
+    int rc = set_alloc_table(s, cap, &s->keys, &s->state);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 4);
+    if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    if (rc != KC_OK) { kc_set_destroy(s); return rc; }
+    *out = s;
+    return KC_OK;
+}
+extern "C" void kc_set_destroy(kc_set *set) {
+    if (!set) return;
+    kc_ctx *ctx = set->ctx;
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, set->keys);
+    kc_release(ctx, set->state);
+    kc_release(ctx, set->counters);
+    delete set;
+}
+
+int kcs_refresh_size(kc_set *set) {
+    kc_ctx *ctx = set->ctx;
+    u64 h[2] = {0, 0};
+    KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    set->size_host = h[0];
+    if (h[1]) return kc_fail(ctx, KC_E_CAPACITY, "k-mer set capacity exhausted");
+    return KC_OK;
+}
+
+template <int W> static SetView<W> view_of(const kc_set *s) { return SetView<W>{s->keys, s->state, s->cap}; }
+
+// Make room for `additional` more k-mer occurrences: grow + rehash when the load could exceed 0.7.
+int kcs_reserve(kc_set *set, u64 additional) {
+    kc_ctx *ctx = set->ctx;
+    KC_TRY(kcs_refresh_size(set));
+    u64 worst = set->size_host + additional;
+    if ((double)worst <= 0.7 * (double)set->cap) return KC_OK;
+    u64 ncap = (u64)((double)worst / 0.6) + 1024;
+    if (ncap < set->cap * 2) ncap = set->cap * 2;
+    u64 *nkeys = nullptr; u32 *nstate = nullptr;
+    KC_TRY(set_alloc_table(set, ncap, &nkeys, &nstate));
+    if (set->size_host) {
+        unsigned g = kc_grid(set->cap, 256);
+        switch (set->W) {
+            case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), SetView<1>{nkeys, nstate, ncap}, set->counters); break;
+            case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), SetView<2>{nkeys, nstate, ncap}, set->counters); break;
+            default: hipLaunchKernelGGL(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), SetView<4>{nkeys, nstate, ncap}, set->counters); break;
+        }
+        KC_HIP(ctx, hipGetLastError());
+    }
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, set->keys);
+    kc_release(ctx, set->state);
+    set->keys = nkeys; set->state = nstate; set->cap = ncap;
+    return KC_OK;
+}
+
+int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+    kc_ctx *ctx = set->ctx;
+    if (len == 0) return KC_OK;
+    int ppt = set->W == 1 ? 16 : (set->W == 2 ? 32 : 64);
+    u64 nthreads = (len + ppt - 1) / ppt;
+    unsigned g = kc_grid(nthreads, 256);
+    hipEventRecord(ctx->ev[6], ctx->stream);
+    switch (set->W) {
+        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt); break;
+        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt); break;
+        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt); break;
+    }
+    hipEventRecord(ctx->ev[7], ctx->stream);
+    KC_HIP(ctx, hipGetLastError());
+    return KC_OK;
+}
+
+extern "C" int kc_set_add_sequence_device(kc_set *set, const void *d_seq, uint64_t len, int case_sensitive) {
+    if (!set || (!d_seq && len)) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (len < (u64)set->k) return KC_OK;
+    KC_TRY(kcs_reserve(set, len - set->k + 1));
+    u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
+    int rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
+    if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, case_sensitive);
+    if (rc == KC_OK) rc = kcs_refresh_size(set);
+    kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low);
+    return rc;
+}
+
+extern "C" int kc_set_add_sequence(kc_set *set, const char *seq, uint64_t len, int case_sensitive) {
+    if (!set || (!seq && len)) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (len < (u64)set->k) return KC_OK;
+    u8 *d = nullptr;
+    KC_TRY(kc_alloc(ctx, &d, len + 64));
+    int rc = KC_OK;
+    if (hipMemcpyAsync(d, seq, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "H2D copy failed");
+    if (rc == KC_OK) rc = kc_set_add_sequence_device(set, d, len, case_sensitive);
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, d);
+    return rc;
+}
+
+extern "C" int kc_set_size(kc_set *set, uint64_t *n) {
+    if (!set || !n) return KC_E_ARG;
+    KC_TRY(kcs_refresh_size(set));
+    *n = set->size_host;
+    return KC_OK;
+}
+
+extern "C" int kc_set_export(kc_set *set, uint64_t *out_words) {
+    if (!set || !out_words) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    KC_TRY(kcs_refresh_size(set));
+    u64 n = set->size_host;
+    if (!n) return KC_OK;
+    u64 *d_out = nullptr, *cursor = nullptr;
+    KC_TRY(kc_alloc(ctx, &d_out, n * set->W));
+    KC_TRY(kc_alloc(ctx, &cursor, 1));
+    KC_HIP(ctx, hipMemsetAsync(cursor, 0, 8, ctx->stream));
+    unsigned g = kc_grid(set->cap, 256);
+    switch (set->W) {
+        case 1: hipLaunchKernelGGL(kc_export_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_out, cursor); break;
+        case 2: hipLaunchKernelGGL(kc_export_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_out, cursor); break;
+        default: hipLaunchKernelGGL(kc_export_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), d_out, cursor); break;
+    }
+    KC_HIP(ctx, hipGetLastError());
+    KC_HIP(ctx, hipMemcpyAsync(out_words, d_out, n * set->W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, d_out); kc_release(ctx, cursor);
+    return KC_OK;
+}
+
+extern "C" int kc_set_contains(kc_set *set, const uint64_t *key_words, uint64_t n, uint8_t *out) {
+    if (!set || (!key_words && n) || (!out && n)) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!n) return KC_OK;
+    u64 *d_keys = nullptr; u8 *d_out = nullptr;
+    KC_TRY(kc_alloc(ctx, &d_keys, n * set->W));
+    KC_TRY(kc_alloc(ctx, &d_out, n));
+    KC_HIP(ctx, hipMemcpyAsync(d_keys, key_words, n * set->W * 8, hipMemcpyHostToDevice, ctx->stream));
+    unsigned g = kc_grid(n, 256);
+    switch (set->W) {
+        case 1: hipLaunchKernelGGL(kc_contains_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_keys, n, d_out); break;
+        case 2: hipLaunchKernelGGL(kc_contains_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_keys, n, d_out); break;
+        default: hipLaunchKernelGGL(kc_contains_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), d_keys, n, d_out); break;
+    }
+    KC_HIP(ctx, hipGetLastError());
+    KC_HIP(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, d_keys); kc_release(ctx, d_out);
+    return KC_OK;
+}

@@ -1,0 +1,756 @@
+// Phase 1 of the BIGREEDY path on gfx950: greedy simplitigs by de Bruijn neighbour lookup.
+// Replaces simplitig_right_rev_extension / next_simplitig / get_simplitigs (simplitigs.h:105-205) and
+// simplitigs_from_fasta (simplitigs.h:78-103).
+//
+// The reference walks the hash table sequentially, deleting k-mers as it goes, so its result depends on the khash
+// bucket layout.  Here the same object -- a vertex-disjoint path cover of the node-centric de Bruijn
+// graph in which no two path ends could still be joined -- is computed by a scheduling-free rule (DESIGN.md
+// "Canonical simplitigs", restated on the CPU in oracle/kc_oracle.cpp simplitigs_canonical_order):
+//   * every k-mer has two ports, L (prepend side) and R (append side); an edge joins two ports;
+//   * edges are matched greedily by a symmetric 64-bit priority (locally dominant edges, iterated to a fixpoint:
+//     every open port picks its best still-available edge, an edge is accepted when both of its ports picked it);
+//   * chains start at the end with the smaller key and are ordered by that key; cycles are cut at their minimum key.
+// Kernels: neighbour_choose (4 probes per port), accept, heads, walk (measure), walk (emit packed 2-bit).
+#include "kc_internal.h"
+#include "kc_set_dev.h"
+#include <hipcub/hipcub.hpp>
+
+#define LK_OPEN 0ull
+#define LK_CHOICE 1ull
+#define LK_MATCHED 2ull
+#define LK_DEAD 3ull
+#define LK_STATE(w) ((w) & 3ull)
+#define LK_PORT(w) (((w) >> 2) & 1ull)
+#define LK_BASE(w) (((w) >> 3) & 3ull)
+#define LK_SLOT(w) ((w) >> 5)
+#define LK_PID(w) ((LK_SLOT(w) << 1) | LK_PORT(w))
+#define LK_MAKE(state, port, base, slot) ((u64)(state) | ((u64)(port) << 2) | ((u64)(base) << 3) | ((u64)(slot) << 5))
+
+// "edge (x,px)-(y1,q1) is preferred over edge (x,px)-(y2,q2)": higher priority first, ties by the ordered endpoint tuple.
+template <int W>
+__device__ __forceinline__ bool edge_preferred(const Key<W> &x, int px, const Key<W> &y1, int q1, u64 pr1, const Key<W> &y2, int q2,
+                                               u64 pr2) {
+    if (pr1 != pr2) return pr1 > pr2;
+    // tuple (ka,pa,kb,pb) with (ka,pa) <= (kb,pb)
+    bool x_first1 = key_lt(x, y1) || (key_eq(x, y1) && px <= q1);
+    bool x_first2 = key_lt(x, y2) || (key_eq(x, y2) && px <= q2);
+    const Key<W> &a1 = x_first1 ? x : y1; int pa1 = x_first1 ? px : q1;
+    const Key<W> &b1 = x_first1 ? y1 : x; int pb1 = x_first1 ? q1 : px;
+    const Key<W> &a2 = x_first2 ? x : y2; int pa2 = x_first2 ? px : q2;
+    const Key<W> &b2 = x_first2 ? y2 : x; int pb2 = x_first2 ? q2 : px;
+    if (!key_eq(a1, a2)) return key_lt(a1, a2);
+    if (pa1 != pa2) return pa1 < pa2;
+    if (!key_eq(b1, b2)) return key_lt(b1, b2);
+    return pb1 < pb2;
+}
+
+// One thread per port.  FIRST: port id = thread id over all 2*cap ports (round 1, nothing is matched yet, so the
+// neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
+template <int W, bool FIRST>
+__global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements,
+                                                        const u64 *__restrict__ work, u64 nwork) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwork) return;
+    u64 pid = FIRST ? t : work[t];
+    u64 slot = pid >> 1;
+    int port = (int)(pid & 1);
+    if (FIRST) { if (!set_slot_full(set, slot)) return; }
+    Key<W> x = set_key_at(set, slot);
+    if (complements && port == 1) {
+        Key<W> xr = key_rc(x, k);
+        if (key_eq(x, xr)) { link[pid] = LK_DEAD; return; }  // palindromes link on port L only
+    }
+    u64 hx = kc_port_term(key_hash(x), port);
+    bool have = false;
+    Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0; u32 bbase = 0;
+    for (u32 c = 0; c < 4; ++c) {
+        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+        Key<W> y = nf;
+        int q;
+        if (complements) {
+            Key<W> r = key_rc(nf, k);
+            bool pal = key_eq(nf, r);
+            bool fwd = !key_lt(r, nf);  // canonical is nf itself
+            if (!fwd) y = r;
+            // append: entering y on L if y==nf else R; prepend: entering y on R if y==nf else L; palindromes: L
+            q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
+        } else {
+            q = port ? 0 : 1;
+        }
+        if (key_eq(y, x)) continue;
+        u64 tslot = set_find(set, y);
+        if (tslot == KC_NONE64) continue;
+        if (!FIRST) {
+            u64 wt = link[(tslot << 1) | (u64)q];
+            if (LK_STATE(wt) == LK_MATCHED) continue;
+        }
+        u64 pr = kc_mix64(hx + kc_port_term(key_hash(y), q));
+        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) {
+            have = true; by = y; bq = q; bpr = pr; bslot = tslot;
+            bbase = port ? c : 3 - c;
+        }
+    }
+    link[pid] = have ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__restrict__ work, u64 nwork, u64 *work_out,
+                                                        u64 *cursor) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwork) return;
+    u64 pid = FIRST ? t : work[t];
+    u64 w = link[pid];
+    if (LK_STATE(w) != LK_CHOICE) return;
+    u64 wt = __hip_atomic_load(&link[LK_PID(w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 st = LK_STATE(wt);
+    if ((st == LK_CHOICE || st == LK_MATCHED) && LK_PID(wt) == pid) {
+        __hip_atomic_store(&link[pid], (w & ~3ull) | LK_MATCHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        u64 pos = atomicAdd((ull *)cursor, 1ULL);
+        work_out[pos] = pid;
+    }
+}
+
+// count unresolved ports after round 1 (sizes the work lists)
+__global__ void __launch_bounds__(256) kc_count_unresolved_kernel(const u64 *__restrict__ link, u64 nports, u64 *counter) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nports) return;
+    u64 w = link[t];
+    if (LK_STATE(w) != LK_CHOICE) return;
+    u64 wt = link[LK_PID(w)];
+    u64 st = LK_STATE(wt);
+    if (!((st == LK_CHOICE || st == LK_MATCHED) && LK_PID(wt) == t)) atomicAdd((ull *)counter, 1ULL);
+}
+
+// heads of directed chains: oriented node (slot, o) whose entry port (L for o=0, R for o=1) is not matched.
+template <int W, bool FILL>
+__global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, u64 *heads,
+                                                       u64 *cursor) {
+    u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= set.cap) return;
+    if (!set_slot_full(set, slot)) return;
+    int no = complements ? 2 : 1;
+    for (int o = 0; o < no; ++o) {
+        u64 w = link[(slot << 1) | (u64)(o == 0 ? 0 : 1)];
+        if (LK_STATE(w) == LK_MATCHED) continue;
+        u64 pos = atomicAdd((ull *)cursor, 1ULL);
+        if (FILL) heads[pos] = (slot << 1) | (u64)o;
+    }
+}
+
+// measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a
+// chain is emitted (bi: the one starting at the smaller key) and records the winners.
+template <int W>
+__global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
+                                                              const u64 *__restrict__ heads, u64 nheads, u8 *visited,
+                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nheads) return;
+    u64 h = heads[t];
+    u64 slot = h >> 1, cur = slot;
+    int o = (int)(h & 1), co = o;
+    u64 len = 1;
+    while (true) {
+        visited[cur] = 1;
+        u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+        if (LK_STATE(w) != LK_MATCHED) break;
+        cur = LK_SLOT(w);
+        co = LK_PORT(w) == 0 ? 0 : 1;
+        ++len;
+    }
+    Key<W> hk = set_key_at(set, slot);
+    bool winner = true;
+    if (complements) winner = (len == 1) ? (o == 0) : key_lt(hk, set_key_at(set, cur));
+    if (!winner) return;
+    u64 pos = atomicAdd((ull *)cursor, 1ULL);
+    chain_head[pos] = h;
+    chain_len[pos] = len;
+    for (int i = 0; i < W; ++i) chain_key[pos * W + i] = hk.w[i];
+}
+
+template <int W, bool FILL>
+__global__ void __launch_bounds__(256) kc_unvisited_kernel(SetView<W> set, const u8 *__restrict__ visited, u64 *list, u64 *cursor) {
+    u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= set.cap) return;
+    if (!set_slot_full(set, slot) || visited[slot]) return;
+    u64 pos = atomicAdd((ull *)cursor, 1ULL);
+    if (FILL) list[pos] = slot;
+}
+
+// cycles (rare): one thread, sequential. Cut each cycle at its minimum key, on that node's port L.
+template <int W>
+__global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, u8 *visited, u64 *chain_head,
+                                 u64 *chain_len, u64 *chain_key, u64 *cursor) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (u64 i = 0; i < nlist; ++i) {
+        u64 start = list[i];
+        if (visited[start]) continue;
+        u64 cur = start, best = start, len = 0;
+        int co = 0;
+        Key<W> bk = set_key_at(set, start);
+        do {
+            visited[cur] = 1;
+            ++len;
+            Key<W> ck = set_key_at(set, cur);
+            if (key_lt(ck, bk)) { bk = ck; best = cur; }
+            u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+            cur = LK_SLOT(w);
+            co = LK_PORT(w) == 0 ? 0 : 1;
+        } while (cur != start);
+        u64 wl = link[(best << 1) | 0];
+        link[LK_PID(wl)] = LK_DEAD;
+        link[(best << 1) | 0] = LK_DEAD;
+        u64 pos = atomicAdd((ull *)cursor, 1ULL);
+        chain_head[pos] = (best << 1) | 0;
+        chain_len[pos] = len;
+        for (int j = 0; j < W; ++j) chain_key[pos * W + j] = bk.w[j];
+    }
+}
+
+__global__ void __launch_bounds__(256) kc_iota_kernel(u64 *a, u64 n) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] = t;
+}
+__global__ void __launch_bounds__(256) kc_gather_word_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ perm, u64 n, int W,
+                                                             int word, u64 *out) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = keys[perm[t] * W + word];
+}
+// lens (bases) and word counts (len/32 + 1: always at least one padding base, so that packed simplitigs can be fed
+// to the k-mer insert kernel with the padding marked as a break)
+__global__ void __launch_bounds__(256) kc_chain_sizes_kernel(const u64 *__restrict__ chain_len, const u64 *__restrict__ perm, u64 n,
+                                                             int k, u64 *lens, u64 *nwords) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 L = chain_len[perm[t]] + (u64)(k - 1);
+    lens[t] = L;
+    nwords[t] = L / 32 + 1;
+}
+__global__ void kc_finish_offsets_kernel(u64 *woff, const u64 *nwords, u64 n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) woff[n] = n ? woff[n - 1] + nwords[n - 1] : 0;
+}
+
+// emit pass: one thread per chain (in final order): spell the simplitig into packed 2-bit words (32 bases per word,
+// first base in bits 63:62) and record its first and last k-mer.
+template <int W>
+__global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const u64 *__restrict__ link, int k,
+                                                           const u64 *__restrict__ chain_head, const u64 *__restrict__ perm, u64 n,
+                                                           const u64 *__restrict__ woff, u64 *words, u64 *firstK, u64 *lastK) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 h = chain_head[perm[t]];
+    u64 cur = h >> 1;
+    int co = (int)(h & 1);
+    Key<W> kx = set_key_at(set, cur);
+    if (co) kx = key_rc(kx, k);
+    for (int i = 0; i < W; ++i) firstK[t * W + i] = kx.w[i];
+    u64 wp = woff[t], acc = 0;
+    int nacc = 0;
+    for (int i = 0; i < k; ++i) {
+        acc = (acc << 2) | key_at(kx, k, i);
+        if (++nacc == 32) { words[wp++] = acc; acc = 0; nacc = 0; }
+    }
+    while (true) {
+        u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+        if (LK_STATE(w) != LK_MATCHED) break;
+        u64 b = LK_BASE(w);
+        kx = key_append(kx, b, k);
+        acc = (acc << 2) | b;
+        if (++nacc == 32) { words[wp++] = acc; acc = 0; nacc = 0; }
+        cur = LK_SLOT(w);
+        co = LK_PORT(w) == 0 ? 0 : 1;
+    }
+    words[wp] = nacc ? (acc << (64 - 2 * nacc)) : 0;
+    for (int i = 0; i < W; ++i) lastK[t * W + i] = kx.w[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out) {
+    // LSD over the key words (least significant word first), each pass a stable radix sort of (word, perm).
+    u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr;
+    KC_TRY(kc_alloc(ctx, &perm, n));
+    KC_TRY(kc_alloc(ctx, &perm2, n));
+    KC_TRY(kc_alloc(ctx, &kw, n));
+    KC_TRY(kc_alloc(ctx, &kw2, n));
+    hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
+    size_t tmp_bytes = 0;
+    KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kw, kw2, perm, perm2, n, 0, 64, ctx->stream));
+    void *tmp = nullptr;
+    KC_TRY(kc_alloc(ctx, (u8 **)&tmp, tmp_bytes));
+    for (int word = 0; word < W; ++word) {
+        int bits = 2 * k - 64 * word;
+        if (bits <= 0) break;
+        if (bits > 64) bits = 64;
+        hipLaunchKernelGGL(kc_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, d_keys, perm, n, W, word, kw);
+        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kw, kw2, perm, perm2, n, 0, bits, ctx->stream));
+        std::swap(perm, perm2);
+    }
+    KC_HIP(ctx, hipGetLastError());
+    kc_release(ctx, perm2); kc_release(ctx, kw); kc_release(ctx, kw2); kc_release(ctx, tmp);
+    *perm_out = perm;
+    return KC_OK;
+}
+
+static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h) {
+    KC_HIP(ctx, hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+
+template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out) {
+    kc_ctx *ctx = set->ctx;
+    const int k = set->k, compl_ = set->complements;
+    SetView<W> sv{set->keys, set->state, set->cap};
+    const u64 cap = set->cap, nports = cap * 2;
+    KC_TRY(kcs_refresh_size(set));
+    const u64 N = set->size_host;
+    if (N == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    u64 *link = nullptr, *cnt = nullptr;
+    KC_TRY(kc_alloc(ctx, &link, nports));
+    KC_TRY(kc_alloc(ctx, &cnt, 8));
+    KC_HIP(ctx, hipMemsetAsync(link, 0, nports * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    // round 1 over all ports (the dominant kernel of this phase: 4 table probes per port)
+    KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    hipLaunchKernelGGL((kc_choose_kernel<W, true>), dim3(kc_grid(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                       (const u64 *)nullptr, nports);
+    KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    hipLaunchKernelGGL(kc_count_unresolved_kernel, dim3(kc_grid(nports, 256)), dim3(256), 0, ctx->stream, link, nports, cnt);
+    u64 nun = 0;
+    KC_TRY(read_u64(ctx, cnt, &nun));
+    u64 *work_a = nullptr, *work_b = nullptr;
+    KC_TRY(kc_alloc(ctx, &work_a, nun + 1));
+    KC_TRY(kc_alloc(ctx, &work_b, nun + 1));
+    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
+                       nports, work_a, cnt);
+    u64 nwork = 0, rounds = 1;
+    KC_TRY(read_u64(ctx, cnt, &nwork));
+    while (nwork) {
+        ++rounds;
+        if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
+        hipLaunchKernelGGL((kc_choose_kernel<W, false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)work_a, nwork);
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+        hipLaunchKernelGGL((kc_accept_kernel<false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
+                           nwork, work_b, cnt);
+        KC_TRY(read_u64(ctx, cnt, &nwork));
+        std::swap(work_a, work_b);
+    }
+    KC_HIP(ctx, hipGetLastError());
+    kc_release(ctx, work_a); kc_release(ctx, work_b);
+    if (rounds_out) *rounds_out = rounds;
+
+    // chain heads
+    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    hipLaunchKernelGGL((kc_heads_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                       (u64 *)nullptr, cnt);
+    u64 nheads = 0;
+    KC_TRY(read_u64(ctx, cnt, &nheads));
+    u64 *heads = nullptr;
+    KC_TRY(kc_alloc(ctx, &heads, nheads + 1));
+    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    hipLaunchKernelGGL((kc_heads_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
+                       cnt);
+    u8 *visited = nullptr;
+    KC_TRY(kc_alloc(ctx, &visited, cap));
+    KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
+    // chain records: at most nheads chains from heads (+ cycles appended later; reallocated if needed)
+    u64 max_chains = nheads + 1;
+    u64 *chain_head = nullptr, *chain_len = nullptr, *chain_key = nullptr;
+    KC_TRY(kc_alloc(ctx, &chain_head, max_chains));
+    KC_TRY(kc_alloc(ctx, &chain_len, max_chains));
+    KC_TRY(kc_alloc(ctx, &chain_key, max_chains * W));
+    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    if (nheads)
+        hipLaunchKernelGGL((kc_walk_measure_kernel<W>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                           (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt);
+    // cycles
+    hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
+                       (u64 *)nullptr, cnt + 1);
+    u64 hc[2] = {0, 0};
+    KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u64 nchains = hc[0], nunvis = hc[1];
+    if (nunvis) {
+        u64 *ulist = nullptr;
+        KC_TRY(kc_alloc(ctx, &ulist, nunvis));
+        KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
+        hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
+                           cnt + 1);
+        // room for up to nunvis more chains
+        u64 *ch2 = nullptr, *cl2 = nullptr, *ck2 = nullptr;
+        u64 nmax2 = nchains + nunvis + 1;
+        KC_TRY(kc_alloc(ctx, &ch2, nmax2)); KC_TRY(kc_alloc(ctx, &cl2, nmax2)); KC_TRY(kc_alloc(ctx, &ck2, nmax2 * W));
+        KC_HIP(ctx, hipMemcpyAsync(ch2, chain_head, nchains * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(cl2, chain_len, nchains * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(ck2, chain_key, nchains * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        kc_release(ctx, chain_head); kc_release(ctx, chain_len); kc_release(ctx, chain_key);
+        chain_head = ch2; chain_len = cl2; chain_key = ck2;
+        hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited, chain_head,
+                           chain_len, chain_key, cnt);
+        KC_TRY(read_u64(ctx, cnt, &nchains));
+        kc_release(ctx, ulist);
+    }
+    KC_HIP(ctx, hipGetLastError());
+    kc_release(ctx, heads);
+    kc_release(ctx, visited);
+
+    // order chains by head key, size them, emit
+    const u64 S = nchains;
+    kc_simplitigs *s = new kc_simplitigs();
+    s->ctx = ctx; s->k = k; s->W = W; s->n = S;
+    u64 *perm = nullptr, *nwords = nullptr;
+    int rc = sort_perm_by_keys(ctx, chain_key, S, W, k, &perm);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->lens, S + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->woff, S + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &nwords, S + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->firstK, S * W);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->lastK, S * W);
+    if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
+    hipLaunchKernelGGL(kc_chain_sizes_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)chain_len, (const u64 *)perm, S, k,
+                       s->lens, nwords);
+    size_t tmp_bytes = 0;
+    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, nwords, s->woff, S, ctx->stream));
+    u8 *tmp = nullptr;
+    KC_TRY(kc_alloc(ctx, &tmp, tmp_bytes));
+    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, nwords, s->woff, S, ctx->stream));
+    hipLaunchKernelGGL(kc_finish_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, s->woff, (const u64 *)nwords, S);
+    KC_TRY(read_u64(ctx, s->woff + S, &s->nwords));
+    s->total_bases = N + S * (u64)(k - 1);
+    rc = kc_alloc(ctx, &s->words, s->nwords + 1);
+    if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
+    hipLaunchKernelGGL((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
+                       (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
+    KC_HIP(ctx, hipGetLastError());
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, tmp); kc_release(ctx, nwords); kc_release(ctx, perm);
+    kc_release(ctx, chain_head); kc_release(ctx, chain_len); kc_release(ctx, chain_key);
+    kc_release(ctx, link); kc_release(ctx, cnt);
+    *out = s;
+    return KC_OK;
+}
+
+int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds) {
+    switch (set->W) {
+        case 1: return build_simplitigs_w<1>(set, out, rounds);
+        case 2: return build_simplitigs_w<2>(set, out, rounds);
+        default: return build_simplitigs_w<4>(set, out, rounds);
+    }
+}
+
+extern "C" int kc_simplitigs_build(kc_set *set, kc_simplitigs **out) {
+    if (!set || !out) return KC_E_ARG;
+    *out = nullptr;
+    KC_HIP(set->ctx, hipSetDevice(set->ctx->device));
+    return kcp_build_simplitigs(set, out, nullptr);
+}
+
+extern "C" void kc_simplitigs_destroy(kc_simplitigs *s) {
+    if (!s) return;
+    kc_ctx *ctx = s->ctx;
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, s->lens); kc_release(ctx, s->woff); kc_release(ctx, s->words);
+    kc_release(ctx, s->firstK); kc_release(ctx, s->lastK);
+    delete s;
+}
+
+extern "C" int kc_simplitigs_count(kc_simplitigs *s, uint64_t *n, uint64_t *total_bases) {
+    if (!s) return KC_E_ARG;
+    if (n) *n = s->n;
+    if (total_bases) *total_bases = s->total_bases;
+    return KC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// -S input: ASCII records -> packed simplitigs (simplitig_from_string, simplitigs.h:78-87).
+__device__ __forceinline__ u64 kc_upper_bound(const u64 *a, u64 n, u64 v) {  // first index with a[idx] > v
+    u64 lo = 0, hi = n;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) kc_pack_records_kernel(const u8 *__restrict__ seq, const u64 *__restrict__ rec_off,
+                                                              const u64 *__restrict__ lens, const u64 *__restrict__ woff, u64 n,
+                                                              u64 nwords, u64 *words, u64 *bad) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwords) return;
+    u64 i = kc_upper_bound(woff, n + 1, t) - 1;
+    u64 b0 = (t - woff[i]) * 32, L = lens[i];
+    u64 acc = 0;
+    bool isbad = false;
+    for (int j = 0; j < 32; ++j) {
+        u64 code = 0;
+        if (b0 + j < L) {
+            u32 ch = seq[rec_off[i] + b0 + j];
+            u32 up = ch & 0xDFu;
+            bool ok = (up == 'A') | (up == 'C') | (up == 'G') | (up == 'T');
+            if (!ok) isbad = true;
+            code = (up >> 1) & 3u;
+            code ^= code >> 1;
+        }
+        acc = (acc << 2) | code;
+    }
+    words[t] = acc;
+    if (isbad) atomicExch((ull *)bad, 1ULL);
+}
+
+template <int W>
+__device__ __forceinline__ Key<W> kc_extract_kmer(const u64 *words, u64 base, int k) {  // bases [base, base+k) of a packed stream
+    Key<W> r = key_zero<W>();
+    for (int i = 0; i < k; ++i) {
+        u64 p = base + i;
+        u64 b = (words[p >> 5] >> (62 - 2 * (p & 31))) & 3;
+        r = key_append(r, b, k);
+    }
+    return r;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) kc_end_kmers_kernel(const u64 *__restrict__ words, const u64 *__restrict__ woff,
+                                                           const u64 *__restrict__ lens, u64 n, int k, u64 *firstK, u64 *lastK) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 b = woff[t] * 32;
+    Key<W> f = kc_extract_kmer<W>(words, b, k), l = kc_extract_kmer<W>(words, b + lens[t] - k, k);
+    for (int i = 0; i < W; ++i) { firstK[t * W + i] = f.w[i]; lastK[t * W + i] = l.w[i]; }
+}
+
+int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 len, const u64 *h_offsets, u64 n,
+                                     int offsets_are_host_positions, kc_simplitigs **out) {
+    (void)len; (void)offsets_are_host_positions;
+    if (n == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    const int W = kc_words_for_k(k);
+    std::vector<u64> lens(n), woff(n + 1);
+    u64 total = 0, w = 0;
+    for (u64 i = 0; i < n; ++i) {
+        lens[i] = h_offsets[i + 1] - h_offsets[i];
+        if (lens[i] < (u64)k) return kc_fail(ctx, KC_E_ARG, "simplitig record shorter than k");
+        woff[i] = w;
+        w += lens[i] / 32 + 1;
+        total += lens[i];
+    }
+    woff[n] = w;
+    kc_simplitigs *s = new kc_simplitigs();
+    s->ctx = ctx; s->k = k; s->W = W; s->n = n; s->total_bases = total; s->nwords = w;
+    u64 *d_recoff = nullptr, *bad = nullptr;
+    int rc = kc_alloc(ctx, &s->lens, n + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->woff, n + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->words, w + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->firstK, n * W);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->lastK, n * W);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &d_recoff, n + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &bad, 1);
+    if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
+    KC_HIP(ctx, hipMemcpyAsync(s->lens, lens.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(s->woff, woff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(d_recoff, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(kc_pack_records_kernel, dim3(kc_grid(w, 256)), dim3(256), 0, ctx->stream, d_seq, (const u64 *)d_recoff,
+                       (const u64 *)s->lens, (const u64 *)s->woff, n, w, s->words, bad);
+    unsigned g = kc_grid(n, 256);
+    switch (W) {
+        case 1: hipLaunchKernelGGL((kc_end_kmers_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
+        case 2: hipLaunchKernelGGL((kc_end_kmers_kernel<2>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
+        default: hipLaunchKernelGGL((kc_end_kmers_kernel<4>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
+    }
+    KC_HIP(ctx, hipGetLastError());
+    u64 hbad = 0;
+    rc = read_u64(ctx, bad, &hbad);
+    kc_release(ctx, d_recoff); kc_release(ctx, bad);
+    if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
+    if (hbad) { kc_simplitigs_destroy(s); return kc_fail(ctx, KC_E_INVALID_CHAR, "simplitig input holds a non-ACGT character"); }
+    *out = s;
+    return KC_OK;
+}
+
+extern "C" int kc_simplitigs_from_strings(kc_ctx *ctx, int k, const char *seqs, const uint64_t *offsets, uint64_t n, kc_simplitigs **out) {
+    if (!ctx || !out || (!seqs && n) || (!offsets && n)) return KC_E_ARG;
+    *out = nullptr;
+    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
+    if (n == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    u64 len = offsets[n];
+    u8 *d = nullptr;
+    KC_TRY(kc_alloc(ctx, &d, len + 64));
+    KC_HIP(ctx, hipMemcpyAsync(d, seqs, len, hipMemcpyHostToDevice, ctx->stream));
+    int rc = kcp_simplitigs_from_device_ascii(ctx, k, d, len, offsets, n, 1, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, d);
+    return rc;
+}
+
+// ASCII export
+__global__ void __launch_bounds__(256) kc_unpack_kernel(const u64 *__restrict__ words, const u64 *__restrict__ woff,
+                                                        const u64 *__restrict__ lens, const u64 *__restrict__ out_off, u64 n, char *out) {
+    // one wave per simplitig
+    u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    u64 L = lens[wave], wb = woff[wave], ob = out_off[wave];
+    for (u64 j = lane; j < L; j += 64) {
+        u64 b = (words[wb + (j >> 5)] >> (62 - 2 * (j & 31))) & 3;
+        out[ob + j] = "ACGT"[b];
+    }
+}
+
+extern "C" int kc_simplitigs_export(kc_simplitigs *s, char *seqs, uint64_t *offsets) {
+    if (!s || !seqs || !offsets) return KC_E_ARG;
+    kc_ctx *ctx = s->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<u64> lens(s->n);
+    KC_HIP(ctx, hipMemcpyAsync(lens.data(), s->lens, s->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u64 o = 0;
+    for (u64 i = 0; i < s->n; ++i) { offsets[i] = o; o += lens[i]; }
+    offsets[s->n] = o;
+    u64 *d_off = nullptr; char *d_out = nullptr;
+    KC_TRY(kc_alloc(ctx, &d_off, s->n + 1));
+    KC_TRY(kc_alloc(ctx, &d_out, o + 1));
+    KC_HIP(ctx, hipMemcpyAsync(d_off, offsets, (s->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(kc_unpack_kernel, dim3(kc_grid(s->n * 64, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+                       (const u64 *)s->lens, (const u64 *)d_off, s->n, d_out);
+    KC_HIP(ctx, hipGetLastError());
+    KC_HIP(ctx, hipMemcpyAsync(seqs, d_out, o, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, d_off); kc_release(ctx, d_out);
+    return KC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fill_kmers (simplitigs.h:41-51): insert every k-mer of the packed simplitigs into a set. The packed words are a
+// valid 2-bit stream for the insert kernel once the padding bases are marked as breaks.
+__global__ void __launch_bounds__(256) kc_padding_breaks_kernel(const u64 *__restrict__ woff, const u64 *__restrict__ lens, u64 n,
+                                                                u64 nwords, u64 *brk, u64 nbrk) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbrk) return;
+    u64 m = 0;
+    for (int half = 0; half < 2; ++half) {
+        u64 cw = 2 * t + half;
+        u64 bits = 0xffffffffull;  // all 32 positions break
+        if (cw < nwords) {
+            u64 i = kc_upper_bound(woff, n + 1, cw) - 1;
+            u64 start = (cw - woff[i]) * 32, L = lens[i];
+            u64 valid = L > start ? (L - start > 32 ? 32 : L - start) : 0;
+            bits = valid >= 32 ? 0 : (0xffffffffull & ~((1ull << valid) - 1));
+        }
+        m |= bits << (32 * half);
+    }
+    brk[t] = m;
+}
+
+int kcp_insert_simplitig_kmers(kc_set *set, kc_simplitigs *s) {
+    kc_ctx *ctx = set->ctx;
+    u64 nbrk = (s->nwords + 1) / 2;
+    u64 *brk = nullptr, *low = nullptr;
+    KC_TRY(kcs_reserve(set, s->total_bases));
+    KC_TRY(kc_alloc(ctx, &brk, nbrk + 1));
+    KC_TRY(kc_alloc(ctx, &low, nbrk + 1));
+    KC_HIP(ctx, hipMemsetAsync(low, 0, (nbrk + 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(kc_padding_breaks_kernel, dim3(kc_grid(nbrk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->woff,
+                       (const u64 *)s->lens, s->n, s->nwords, brk, nbrk);
+    int rc = kcs_insert_packed(set, s->words, brk, low, s->nwords * 32, 0);
+    if (rc == KC_OK) rc = kcs_refresh_size(set);
+    kc_release(ctx, brk); kc_release(ctx, low);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Sparse branch vertex list: simplitigs_to_kmer_vec + PartialPreSort (simplitigs.h:53-65, global_sparse.h:14-35).
+template <int W>
+__global__ void __launch_bounds__(256) kc_expand_kmers_kernel(const u64 *__restrict__ words, const u64 *__restrict__ woff,
+                                                              const u64 *__restrict__ lens, const u64 *__restrict__ koff, u64 n, int k,
+                                                              u64 nk, u64 *kmers, u64 *sortkey) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nk) return;
+    u64 i = kc_upper_bound(koff, n + 1, t) - 1;
+    Key<W> x = kc_extract_kmer<W>(words, woff[i] * 32 + (t - koff[i]), k);
+    for (int j = 0; j < W; ++j) kmers[t * W + j] = x.w[j];
+    int bits = 2 * k < 8 ? 2 * k : 8;
+    Key<W> top = key_shr(x, 2 * k - bits);
+    sortkey[t] = top.w[0] & ((1ull << bits) - 1);
+    (void)lens;
+}
+__global__ void __launch_bounds__(256) kc_kmer_counts_kernel(const u64 *__restrict__ lens, u64 n, int k, u64 *cnt) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) cnt[t] = lens[t] - (u64)k + 1;
+}
+template <int W>
+__global__ void __launch_bounds__(256) kc_sparse_fill_kernel(const u64 *__restrict__ kmers, const u64 *__restrict__ perm, u64 nk, int k,
+                                                             int wpk, u64 *lens, u64 *woff, u64 *words, u64 *firstK, u64 *lastK) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nk) return;
+    if (t == nk) { woff[nk] = nk * (u64)wpk; return; }
+    u64 src = perm[t];
+    Key<W> x;
+    for (int j = 0; j < W; ++j) { x.w[j] = kmers[src * W + j]; firstK[t * W + j] = x.w[j]; lastK[t * W + j] = x.w[j]; }
+    lens[t] = (u64)k;
+    woff[t] = t * (u64)wpk;
+    u64 acc = 0; int nacc = 0; u64 wp = t * (u64)wpk;
+    for (int i = 0; i < k; ++i) {
+        acc = (acc << 2) | key_at(x, k, i);
+        if (++nacc == 32) { words[wp++] = acc; acc = 0; nacc = 0; }
+    }
+    words[wp] = nacc ? (acc << (64 - 2 * nacc)) : 0;
+}
+
+template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
+    kc_ctx *ctx = s->ctx;
+    const int k = s->k;
+    u64 n = s->n;
+    u64 *cnt = nullptr, *koff = nullptr;
+    KC_TRY(kc_alloc(ctx, &cnt, n + 1));
+    KC_TRY(kc_alloc(ctx, &koff, n + 1));
+    hipLaunchKernelGGL(kc_kmer_counts_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->lens, n, k, cnt);
+    size_t tmp_bytes = 0;
+    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, koff, n, ctx->stream));
+    u8 *tmp = nullptr;
+    KC_TRY(kc_alloc(ctx, &tmp, tmp_bytes));
+    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, koff, n, ctx->stream));
+    hipLaunchKernelGGL(kc_finish_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, koff, (const u64 *)cnt, n);
+    u64 nk = 0;
+    KC_TRY(read_u64(ctx, koff + n, &nk));
+    kc_release(ctx, tmp);
+    u64 *kmers = nullptr, *sk = nullptr, *sk2 = nullptr, *perm = nullptr, *perm2 = nullptr;
+    KC_TRY(kc_alloc(ctx, &kmers, nk * W));
+    KC_TRY(kc_alloc(ctx, &sk, nk)); KC_TRY(kc_alloc(ctx, &sk2, nk));
+    KC_TRY(kc_alloc(ctx, &perm, nk)); KC_TRY(kc_alloc(ctx, &perm2, nk));
+    hipLaunchKernelGGL((kc_expand_kmers_kernel<W>), dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words,
+                       (const u64 *)s->woff, (const u64 *)s->lens, (const u64 *)koff, n, k, nk, kmers, sk);
+    hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, perm, nk);
+    KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, sk, sk2, perm, perm2, nk, 0, 8, ctx->stream));
+    KC_TRY(kc_alloc(ctx, &tmp, tmp_bytes));
+    KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, sk, sk2, perm, perm2, nk, 0, 8, ctx->stream));
+    kc_simplitigs *r = new kc_simplitigs();
+    int wpk = k / 32 + 1;
+    r->ctx = ctx; r->k = k; r->W = W; r->n = nk; r->total_bases = nk * (u64)k; r->nwords = nk * (u64)wpk;
+    int rc = kc_alloc(ctx, &r->lens, nk + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &r->woff, nk + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &r->words, r->nwords + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &r->firstK, nk * W);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &r->lastK, nk * W);
+    if (rc != KC_OK) { kc_simplitigs_destroy(r); return rc; }
+    hipLaunchKernelGGL((kc_sparse_fill_kernel<W>), dim3(kc_grid(nk + 1, 256)), dim3(256), 0, ctx->stream, (const u64 *)kmers,
+                       (const u64 *)perm2, nk, k, wpk, r->lens, r->woff, r->words, r->firstK, r->lastK);
+    KC_HIP(ctx, hipGetLastError());
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, tmp); kc_release(ctx, cnt); kc_release(ctx, koff); kc_release(ctx, kmers);
+    kc_release(ctx, sk); kc_release(ctx, sk2); kc_release(ctx, perm); kc_release(ctx, perm2);
+    *out = r;
+    return KC_OK;
+}
+
+int kcp_to_sparse(kc_simplitigs *s, kc_simplitigs **out) {
+    switch (s->W) {
+        case 1: return to_sparse_w<1>(s, out);
+        case 2: return to_sparse_w<2>(s, out);
+        default: return to_sparse_w<4>(s, out);
+    }
+}
+extern "C" int kc_simplitigs_to_sparse(kc_simplitigs *s, kc_simplitigs **out) {
+    if (!s || !out) return KC_E_ARG;
+    *out = nullptr;
+    KC_HIP(s->ctx, hipSetDevice(s->ctx->device));
+    return kcp_to_sparse(s, out);
+}

@@ -1,0 +1,338 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bar: bit-exact everywhere (integer / byte / index work).  Tiers:
+  T-A  byte-exact vs the reference semantics: primitives, set contents, C1 edge arrays, C2 bytes, Global, sparse branch,
+       `compute -S`, lower bound, maskopt.
+  T-B  raw-FASTA compute: identical N and k-mer set, ones == N, -M == maskopt max-one of -o, L reported vs reference L.
+  T-C  raw-FASTA compute byte-identical to the oracle's canonical-order mode.
+"""
+import hashlib
+import json
+import os
+import random
+
+import pytest
+
+import gen
+import oracle_lib
+import kmercamel_amd as kc
+
+pytestmark = pytest.mark.gpu
+
+NONE = (1 << 64) - 1
+KS = [2, 5, 13, 31, 32, 47, 63, 64, 100, 127]
+
+
+def _rand_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+# ------------------------------------------------------------------------------------------------ A2/A6: set contents
+@pytest.mark.parametrize("k", KS)
+@pytest.mark.parametrize("complements", [True, False])
+def test_set_contents_match_oracle(ctx, oracle, k, complements):
+    rng = random.Random(1000 + k)
+    for case_sensitive in (False, True):
+        parts = []
+        for _ in range(30):
+            s = _rand_seq(rng, rng.choice([0, 1, k - 1, k, k + 1, 3 * k, 500]), "ACGTacgtN" if rng.random() < 0.5 else "ACGT")
+            parts.append(s)
+        # AddKMers is per record (parser.h:22-49): feed the records one by one AND joined by a separator
+        seq = "\n".join(parts)
+        want = sorted(set(x for p in parts for x in oracle.kmer_set(p, k, complements, case_sensitive)))
+        s1 = kc.KmerSet(ctx, k, complements, capacity_hint=len(seq))
+        s1.AddKMers(seq, case_sensitive)
+        assert s1.size() == len(want)
+        assert sorted(s1.keys()) == want
+        s2 = kc.KmerSet(ctx, k, complements)   # grows on demand
+        for p in parts:
+            s2.AddKMers(p, case_sensitive)
+        assert sorted(s2.keys()) == want
+        probe = want[:50] + [(x + 1) & ((1 << (2 * k)) - 1) for x in want[:50]]
+        wset = set(want)
+        assert s1.contains(probe) == [p in wset for p in probe]
+        s1.close(); s2.close()
+
+
+def test_read_kmers_counts_reference_kats(ctx, golden_dir):
+    # tests/parser_unittest.h:38-63 on tests/testdata/test.fa
+    path = os.path.join(golden_dir, "test.fa")
+    for k, complements, case_sensitive, want in [(10, True, False, 3), (10, True, True, 2), (5, True, False, 11), (5, False, False, 11),
+                                                  (2, True, False, 9), (2, False, False, 11)]:
+        s = kc.ReadKMers(ctx, path, k, complements, case_sensitive)
+        assert s.size() == want
+        s.close()
+
+
+def test_empty_and_short_inputs(ctx):
+    s = kc.KmerSet(ctx, 31, True)
+    s.AddKMers("")
+    s.AddKMers("ACGT")
+    s.AddKMers("N" * 100)
+    assert s.size() == 0
+    with pytest.raises(kc.KcError) as e:
+        kc.get_simplitigs(s)
+    assert e.value.code == kc.api.KC_E_EMPTY
+    s.close()
+    with pytest.raises(kc.KcError) as e:
+        kc.compute(ctx, b"ACGTNNNN\nAC", 5)
+    assert e.value.code == kc.api.KC_E_NO_KMERS
+    with pytest.raises(kc.KcError) as e:
+        kc.simplitigs_from_strings(ctx, [], 3)
+    assert e.value.code == kc.api.KC_E_EMPTY
+    with pytest.raises(kc.KcError) as e:
+        kc.simplitigs_from_strings(ctx, ["ACGN"], 3)   # assert in simplitigs.h:82
+    assert e.value.code == kc.api.KC_E_INVALID_CHAR
+    with pytest.raises(kc.KcError):
+        kc.KmerSet(ctx, 128, True)
+
+
+# ------------------------------------------------------------------------------------------------ B: simplitigs (T-C)
+@pytest.mark.parametrize("k", [3, 4, 8, 13, 31, 32, 63, 64, 127])
+@pytest.mark.parametrize("complements", [True, False])
+def test_simplitigs_match_canonical_oracle(ctx, oracle, k, complements):
+    rng = random.Random(77 + k)
+    cases = []
+    cases.append("\n".join(r.decode() for r in gen.stress_reads(4000, 120, 150 if k < 100 else 300, seed=k)))
+    cases.append(_rand_seq(rng, 3000, "AC"))            # low complexity: heavy branching, palindromes for even k, cycles
+    cases.append("A" * 200 + "C" * 50 + "ACACACACACACACACAC" * 10)
+    cases.append(_rand_seq(rng, 2000) * 2)              # repeat
+    circ = _rand_seq(rng, 400)
+    cases.append(circ + circ[:k - 1] + circ[: k])      # closes a cycle in the de Bruijn graph
+    for seq in cases:
+        want = oracle.simplitigs_of_sequence(seq.replace("\n", "N"), k, complements, mode=1)
+        s = kc.KmerSet(ctx, k, complements, capacity_hint=len(seq))
+        s.AddKMers(seq)
+        sim = kc.get_simplitigs(s)
+        got = sim.strings()
+        assert got == want
+        # every k-mer of the set is covered exactly once
+        n, total = sim.count()
+        assert total - n * (k - 1) == s.size()
+        sim.close(); s.close()
+
+
+def test_simplitigs_reference_kats(ctx):
+    # tests/simplitigs_unittest.h:183-208 (order-tolerant there: sorted by length)
+    enc = oracle_lib.encode_kmer
+    for kmers, k, want in [(["GCT", "TAA", "AAA"], 3, ["GCT", "TAAA"]), (["TAA", "AAA", "GCT"], 3, ["GCT", "TAAA"]),
+                           (["TTTCTTTTTTTTTTTTTTTTTTTTTTTTTTG", "TTCTTTTTTTTTTTTTTTTTTTTTTTTTTGA"], 31, ["TTTCTTTTTTTTTTTTTTTTTTTTTTTTTTGA"])]:
+        s = kc.KmerSet(ctx, k, False)
+        s.AddKMers("N".join(kmers))
+        assert sorted(s.keys()) == sorted(enc(x) for x in kmers)
+        got = kc.get_simplitigs(s).strings()
+        assert sorted(got, key=len) == want
+        s.close()
+
+
+# ------------------------------------------------------------------------------------------------ C1: overlap path (T-A)
+OHP_KATS = [  # tests/global_unittest.h:53-111
+    (["AT"], 2, True, False, [NONE, NONE], [255, 255]),
+    (["ACG", "TAC", "GGC"], 3, False, False, [2, 0, NONE], [1, 2, 255]),
+    (["ACAA", "ATTT", "AACA"], 4, True, False, [4, 3, 0, 5, NONE, NONE], [2, 2, 3, 3, 255, 255]),
+    (["ACG", "CGT", "TAA"], 3, False, True, [1, 2, 0], [2, 1, 1]),
+    (["ACGT", "TAA"], 3, False, True, [1, 0], [1, 1]),
+    (["ACC", "CGG"], 3, True, True, [3, 2, 0, 1], [2, 2, 0, 2]),
+]
+
+
+@pytest.mark.parametrize("strs,k,complements,lb,want_ef,want_ov", OHP_KATS)
+def test_overlap_path_reference_kats(ctx, strs, k, complements, lb, want_ef, want_ov):
+    s = kc.simplitigs_from_strings(ctx, strs, k)
+    ef, ov = kc.OverlapHamiltonianPath(s, complements, lb)
+    assert ef == want_ef and ov == want_ov
+    s.close()
+
+
+def _random_simplitig_set(rng, k, n, alphabet):
+    base = _rand_seq(rng, max(k, 600), alphabet)
+    out = []
+    for _ in range(n):
+        L = k + rng.choice([0, 0, 1, 2, 5, 20, 100])
+        if rng.random() < 0.6 and len(base) >= L:
+            p = rng.randrange(0, len(base) - L + 1)
+            out.append(base[p:p + L])
+        else:
+            out.append(_rand_seq(rng, L, alphabet))
+    return out
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 9, 13, 31, 33, 63, 70, 127])
+def test_overlap_path_random_vs_oracle(ctx, oracle, k):
+    rng = random.Random(500 + k)
+    for n in (1, 2, 7, 60, 700, 5000):
+        strs = _random_simplitig_set(rng, k, n, "ACGT" if rng.random() < 0.7 else "AC")
+        s = kc.simplitigs_from_strings(ctx, strs, k)
+        assert s.strings() == strs
+        for complements in (True, False):
+            for lb in (False, True):
+                want = oracle.overlap_path(strs, k, complements, lb)
+                got = kc.OverlapHamiltonianPath(s, complements, lb)
+                assert got == want, (k, n, complements, lb)
+        s.close()
+
+
+# ------------------------------------------------------------------------------------------------ C2/C3 (T-A)
+def test_superstring_from_path_reference_kats(ctx):
+    # tests/global_unittest.h:11-51
+    for ef, ov, strs, k, want, complements in [
+        ([2, 0, NONE], [1, 2, 255], ["ACG", "TAC", "GGC"], 3, "TAcGgc", False),
+        ([4, 3, 1, NONE, 5, NONE], [1, 2, 1, 255, 2, 255], ["GCC", "ACG", "TAC"], 3, "GcCGta", True),
+        ([3, 1, NONE, NONE], [1, 1, 255, 255], ["GCC", "TACG"], 3, "GcCGta", True),
+    ]:
+        s = kc.simplitigs_from_strings(ctx, strs, k)
+        out, _, L = kc.SuperstringFromPath(s, ef, ov, complements)
+        assert out == want and L == len(want)
+        s.close()
+
+
+def test_global_reference_kats(ctx):
+    # tests/global_unittest.h:113-138
+    for want, k, strs, complements in [
+        ("TACgt", 3, ["CGT", "TAC", "ACG"], False), ("ACGT", 1, ["ACGT"], False), ("ACgTtt", 3, ["CGT", "TTT", "ACG"], False),
+        ("ACgTtt", 3, ["ACGT", "TTT"], False), ("TActt", 4, ["TACT", "ACTT"], False),
+        ("TActTaaGgac", 4, ["TACT", "ACTT", "GGAC", "TAAG"], False),
+        ("TTtcttttttttttttttttttttttttttga", 31, ["TTTCTTTTTTTTTTTTTTTTTTTTTTTTTTG", "TTCTTTTTTTTTTTTTTTTTTTTTTTTTTGA"], False),
+        ("AtTTgtt", 4, ["ACAA", "ATTT", "AACA"], True),
+    ]:
+        s = kc.simplitigs_from_strings(ctx, strs, k)
+        out, _, L = kc.Global(s, complements)
+        assert out == want and L == len(want)
+        s.close()
+
+
+@pytest.mark.parametrize("k", [3, 5, 13, 31, 63, 127])
+def test_global_random_with_mask_vs_oracle(ctx, oracle, k):
+    rng = random.Random(900 + k)
+    for n in (1, 3, 40, 1500):
+        strs = _random_simplitig_set(rng, k, n, "ACGT")
+        for complements in (True, False):
+            rc, want, want_mask = oracle.global_(strs, k, complements, want_mask=True)
+            assert rc == 0
+            s = kc.simplitigs_from_strings(ctx, strs, k)
+            out, mask, L = kc.Global(s, complements, want_mask=True)
+            assert out == want and mask == want_mask and L == len(want)
+            s.close()
+
+
+def test_sparse_branch_vs_oracle(ctx, oracle):
+    # D1: GlobalSparse over PartialPreSort'ed k-mers == Global over the 1-k-mer simplitigs kc_simplitigs_to_sparse builds
+    rng = random.Random(4)
+    for k in (3, 8, 31, 40):
+        strs = _random_simplitig_set(rng, k, 300, "ACGT")
+        kmers = [oracle_lib.encode_kmer(s[i:i + k]) for s in strs for i in range(len(s) - k + 1)]
+        for complements in (True, False):
+            rc, want, want_mask = oracle.global_sparse(kmers, k, complements, presort=True, want_mask=True)
+            s = kc.simplitigs_from_strings(ctx, strs, k)
+            sp = s.to_sparse()
+            out, mask, _ = kc.Global(sp, complements, want_mask=True)
+            assert out == want and mask == want_mask
+            sp.close(); s.close()
+
+
+def test_lower_bound_vs_oracle(ctx, oracle):
+    rng = random.Random(11)
+    for k in (3, 7, 31):
+        strs = _random_simplitig_set(rng, k, 200, "ACGT")
+        s = kc.simplitigs_from_strings(ctx, strs, k)
+        for complements in (True, False):
+            assert kc.LowerBoundLength(s, complements) == oracle.lower_bound(strs, k, complements)
+        s.close()
+
+
+# ------------------------------------------------------------------------------------------------ compute, goldens
+def _golden(golden_dir):
+    with open(os.path.join(golden_dir, "golden.json")) as f:
+        return json.load(f)
+
+
+def test_compute_S_golden_byte_exact(ctx, golden_dir):
+    # `compute -k 31 -S data/simplitigs-k31.fa` is hash-layout independent => must equal the reference byte for byte
+    g = _golden(golden_dir)["simplitigs-k31"]
+    r = kc.compute_file(ctx, os.path.join(golden_dir, "simplitigs-k31.fa.gz"), 31, True, want_mask=True, assume_simplitigs=True)
+    out, mask = r.strings(want_mask=True)
+    assert r.stats["n_simplitigs"] == g["S"] and r.length == g["L"] and r.stats["n_kmers"] == g["N"]
+    assert hashlib.md5(out.encode()).hexdigest() == g["md5"]
+    assert hashlib.md5(mask.encode()).hexdigest() == g["md5_mask"]
+    r.close()
+
+
+@pytest.mark.parametrize("k", [13, 31, 63, 127])
+@pytest.mark.parametrize("complements", [True, False])
+def test_compute_spneumoniae(ctx, oracle, golden_dir, k, complements):
+    path = os.path.join(golden_dir, "spneumoniae.fa.gz")
+    g = _golden(golden_dir)["spneumoniae"]["%d_%d" % (k, int(complements))]
+    r = kc.compute_file(ctx, path, k, complements, want_mask=True)
+    out, mask = r.strings(want_mask=True)
+    # T-B: identical N, identical k-mer set, min-one mask, -M == maskopt max-one of -o
+    assert r.stats["n_kmers"] == g["N"]
+    got_set, ones = oracle_lib.kmers_of_masked_superstring(out, k, complements)
+    assert ones == g["N"] and len(got_set) == g["N"]
+    mset, mones = oracle_lib.kmers_of_masked_superstring(mask, k, complements)
+    assert mset == got_set
+    rc, want_mask = oracle.maskopt(out, k, complements, minimize=False)
+    assert rc == 0 and mask == want_mask
+    assert hashlib.md5("".join(sorted(got_set)).encode()).hexdigest() == g["set_md5"]
+    # superstring length vs the reference (reported; equality is not required when the simplitig set differs)
+    assert abs(r.length - g["L"]) / g["L"] < 1e-3
+    # T-C: byte-identical to the oracle's canonical-order mode
+    rc, want, wmask, st = oracle.compute_file(path, k, complements, False, mode=1)
+    assert rc == 0 and out == want and mask == wmask
+    assert r.stats["n_simplitigs"] == st[1]
+    r.close()
+
+
+def test_compute_stress_reads_all_modes(ctx, oracle, tmp_path):
+    reads = gen.stress_reads(20000, 400, 150, seed=3)
+    fa = tmp_path / "reads.fa"
+    fa.write_bytes(b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    for k in (11, 31, 45):
+        for complements in (True, False):
+            r = kc.compute_file(ctx, str(fa), k, complements, want_mask=True)
+            out, mask = r.strings(want_mask=True)
+            rc, want, wmask, st = oracle.compute_file(str(fa), k, complements, False, mode=1)
+            assert (out, mask) == (want, wmask)
+            assert r.stats["n_kmers"] == st[0]
+            r.close()
+
+
+def test_compute_sparse_branch_end_to_end(ctx, oracle, tmp_path):
+    # many isolated k-mers: S*5 >= N triggers the GlobalSparse branch (main.cpp:175-181)
+    rng = random.Random(9)
+    fa = tmp_path / "frag.fa"
+    fa.write_text("".join(">%d\n%s\n" % (i, _rand_seq(rng, 31 + rng.choice([0, 0, 1]))) for i in range(500)))
+    r = kc.compute_file(ctx, str(fa), 31, True, want_mask=True)
+    assert r.stats["sparse_branch"] == 1
+    out, mask = r.strings(want_mask=True)
+    rc, want, wmask, st = oracle.compute_file(str(fa), 31, True, False, mode=1)
+    assert st[3] == 1 and (out, mask) == (want, wmask)
+    r.close()
+
+
+# ------------------------------------------------------------------------------------------------ next row 1: maskopt
+def test_maskopt_ones_vs_oracle(ctx, oracle, golden_dir):
+    rng = random.Random(21)
+    for k in (2, 5, 31, 63):
+        for _ in range(5):
+            up = _rand_seq(rng, 400)
+            ms = "".join(c if rng.random() < 0.4 else c.lower() for c in up)
+            for complements in (True, False):
+                for alg in ("max-one", "min-one"):
+                    rc, want = oracle.maskopt(ms, k, complements, alg == "min-one")
+                    assert rc == 0
+                    assert kc.Optimize(ctx, ms, k, complements, alg) == want
+    with pytest.raises(kc.KcError) as e:
+        kc.Optimize(ctx, "ACGTNACGTACGT", 3, True, "max-one")
+    assert e.value.code == kc.api.KC_E_INVALID_CHAR
+
+
+@pytest.mark.parametrize("k", [13, 31, 63, 127])
+def test_maskopt_on_reference_fixtures(ctx, oracle, golden_dir, k):
+    # data/global-k{K}c.fa: older-version masked superstrings kept as maskopt inputs (Makefile:18-22)
+    recs = kc.read_records(os.path.join(golden_dir, "global-k%dc.fa.gz" % k))
+    assert len(recs) == 1
+    ms = recs[0][2].decode()
+    g = _golden(golden_dir)["maskopt"][str(k)]
+    for alg in ("max-one", "min-one"):
+        got = kc.Optimize(ctx, ms, k, True, alg)
+        assert hashlib.md5(got.encode()).hexdigest() == g[alg]
