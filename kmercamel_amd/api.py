@@ -100,15 +100,27 @@ class Context:
         if rc != KC_OK:
             raise KcError(rc, "kc_ctx_create failed (no HIP device?)")
         self.h = h
+        self._children = []
 
     def check(self, rc):
         if rc != KC_OK:
             raise KcError(rc, (self.lib.kc_last_error(self.h) or b"").decode())
 
     def close(self):
+        """Destroys the context. Objects created from it (sets, simplitigs, results) must be closed first; any that are
+        still alive are invalidated here so that their finalisers do not touch freed device state."""
         if self.h:
+            for ref in list(self._children):
+                obj = ref()
+                if obj is not None:
+                    obj.close()
+            self._children = []
             self.lib.kc_ctx_destroy(self.h)
             self.h = None
+
+    def _adopt(self, obj):
+        import weakref
+        self._children.append(weakref.ref(obj))
 
     def __del__(self):
         try:
@@ -125,6 +137,7 @@ class KmerSet:
         h = ctypes.c_void_p()
         ctx.check(ctx.lib.kc_set_create(ctx.h, k, int(self.complements), capacity_hint, ctypes.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def AddKMers(self, seq, case_sensitive=False):  # parser.h:22-49
         if isinstance(seq, str):
@@ -180,6 +193,7 @@ class Simplitigs:
 
     def __init__(self, ctx, h, k):
         self.ctx, self.h, self.k = ctx, h, k
+        ctx._adopt(self)
 
     def count(self):
         n, t = ctypes.c_uint64(), ctypes.c_uint64()
@@ -392,6 +406,7 @@ def Optimize(ctx, masked_superstring, k, complements=True, algorithm="max-one"):
 class ComputeResult:
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
+        ctx._adopt(self)
         st = (ctypes.c_uint64 * 16)()
         ctx.check(ctx.lib.kc_result_stats(h, st))
         self.stats = dict(zip(STAT_NAMES, list(st)))
