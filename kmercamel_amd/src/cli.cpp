@@ -1,0 +1,265 @@
+// kmercamel (MI355X build): the `compute` (greedy), `maskopt` (max-one / min-one) and `lowerbound` subcommands of the
+// reference CLI (main.cpp:214-459, 669-691) with the same options, validation messages, log lines and output format,
+// running the hot path on the GPU through the C ABI.  `compute` uses the fused device-resident pipeline (kc_compute);
+// everything the hot-path scope leaves out (other algorithms, min-run masks, converters, -z) is rejected explicitly.
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+#include <unistd.h>
+#include "global.h"
+#include "parser.h"
+#include "kc_runtime.h"
+
+static const char *KC_CLI_VERSION = "v2.3.0-mi355x";
+static const int MAX_K = 127;   // main.cpp:93
+
+namespace {
+
+struct Opt { const char *flag, *arg, *help; const char *subs; };   // subs: letters c(ompute) m(askopt) l(owerbound)
+const Opt OPTIONS[] = {
+    {"-k", "INT ", "k-mer size [required; up to 127]", "cml"},
+    {"-a", "STR ", "the algorithm to be run [greedy (default); the MI355X build implements greedy only]", "c"},
+    {"-t", "STR ", "the target mask type to be run [max-one (default), min-one]", "m"},
+    {"-o", "FILE", "output for the (min-one) masked superstring; if not specified, printed to stdout", "cm"},
+    {"-M", "FILE", "if given, print also ms with mask maximizing ones (only with greedy)", "c"},
+    {"-S", "    ", "optimize for the input being pre-computed simplitigs or unitigs (only with greedy)", "cl"},
+    {"-u", "    ", "treat k-mer and its reverse complement as distinct", "cml"},
+    {"-h", "    ", "print help", "cml"},
+};
+
+int usage() {
+    std::cerr << "\nProgram: KmerCamel - a tool for computation of masked superstrings (MI355X-native greedy path).\n"
+              << "Version: " << KC_CLI_VERSION << "\n\nUsage:   kmercamel <command> [options]\n\nCommand:\n"
+              << "    compute    - Compute an approximately shortest masked superstring from input FASTA.\n"
+              << "    maskopt    - Optimize a given masked superstring (max-one / min-one).\n"
+              << "    lowerbound - Compute the lower bound on masked superstring size of a k-mer set.\n\n";
+    return 1;
+}
+
+int usage_subcommand(const std::string &sub) {
+    char tag = sub == "compute" ? 'c' : (sub == "maskopt" ? 'm' : 'l');
+    std::cerr << "\nUsage:   kmercamel " << sub << " [options] " << (tag == 'm' ? "<ms>" : "<fasta>") << "\n\nOptions:\n";
+    for (const Opt &o : OPTIONS)
+        if (std::string(o.subs).find(tag) != std::string::npos) std::cerr << "  " << o.flag << " " << o.arg << " - " << o.help << "\n";
+    std::cerr << std::endl;
+    return 1;
+}
+
+std::string normalize_compute_algorithm(const std::string &a) {   // main.cpp:97-106
+    if (a == "global") return "greedy";
+    if (a == "local" || a == "localgreedy") return "local-greedy";
+    if (a == "globalAC" || a == "greedyAC") return "greedy-ac";
+    if (a == "localAC" || a == "localgreedyAC") return "local-greedy-ac";
+    return a;
+}
+std::string normalize_maskopt_algorithm(const std::string &a) {   // main.cpp:109-115
+    if (a == "maxone") return "max-one";
+    if (a == "minone") return "min-one";
+    if (a == "minrun") return "min-run";
+    if (a == "approxminrun") return "approx-min-run";
+    return a;
+}
+
+struct Records {
+    std::string joined;               // sequences joined by '\n' (compute) or concatenated (-S)
+    std::vector<uint64_t> offsets;    // -S only
+    uint64_t n = 0;
+};
+Records load_records(const std::string &path, bool simplitigs) {
+    Records r;
+    auto recs = kcamd::read_records(path);
+    r.n = recs.size();
+    size_t total = 0;
+    for (auto &x : recs) total += x.seq.size() + 1;
+    r.joined.reserve(total);
+    for (auto &x : recs) {
+        if (simplitigs) r.offsets.push_back(r.joined.size());
+        r.joined += x.seq;
+        if (!simplitigs) r.joined.push_back('\n');
+    }
+    if (simplitigs) r.offsets.push_back(r.joined.size());
+    return r;
+}
+
+// greedy branch of kmercamel<>() (main.cpp:122-212)
+int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound) {
+    if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
+    else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");
+    Records recs = load_records(path, assume_simplitigs);
+    kc_ctx *ctx = kcamd::context();
+    if (lower_bound) {
+        // LowerBoundLength (lower_bound.h:7-36): simplitigs, then the cycle cover of the overlap graph
+        kc_simplitigs *s = nullptr;
+        if (assume_simplitigs) kcamd::check(kc_simplitigs_from_strings(ctx, k, recs.joined.data(), recs.offsets.data(), recs.n, &s));
+        else {
+            kc_set *set = nullptr;
+            kcamd::check(kc_set_create(ctx, k, complements, recs.joined.size(), &set));
+            kcamd::check(kc_set_add_sequence(set, recs.joined.data(), recs.joined.size(), 0));
+            uint64_t n = 0;
+            kcamd::check(kc_set_size(set, &n));
+            if (!n) {
+                std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
+                return usage_subcommand("compute");
+            }
+            WriteLog("Finished collecting k-mers: " + std::to_string(n) + " " + std::to_string(k) + "-mers.");
+            kcamd::check(kc_simplitigs_build(set, &s));
+            uint64_t S = 0;
+            kc_simplitigs_count(s, &S, nullptr);
+            if (S * 5 >= n) {   // main.cpp:175-181
+                kc_simplitigs *sp = nullptr;
+                kcamd::check(kc_simplitigs_to_sparse(s, &sp));
+                kc_simplitigs_destroy(s);
+                s = sp;
+            }
+            kc_set_destroy(set);
+        }
+        uint64_t S = 0, lb = 0;
+        kc_simplitigs_count(s, &S, nullptr);
+        WriteLog("Finished 1. part: simplitigs (" + std::to_string(S) + " simplitigs).");
+        kcamd::check(kc_lower_bound(s, complements, &lb));
+        kc_simplitigs_destroy(s);
+        WriteLog("Finished 2. part: Hamiltonian path.");
+        WriteLog("Finished 3. part: lower bound = " + std::to_string(lb) + ".");
+        std::cout << lb;
+        *of << std::endl;
+        return 0;
+    }
+    uint32_t flags = (complements ? KC_FLAG_COMPLEMENTS : 0) | (assume_simplitigs ? KC_FLAG_SIMPLITIGS_INPUT : 0) | (maskf ? KC_FLAG_WANT_MASK : 0);
+    kc_result *res = nullptr;
+    int rc = kc_compute(ctx, recs.joined.data(), recs.joined.size(), assume_simplitigs ? recs.offsets.data() : nullptr, recs.n, k, flags, &res);
+    if (rc == KC_E_NO_KMERS) {
+        std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
+        return usage_subcommand("compute");
+    }
+    kcamd::check(rc);
+    uint64_t st[16];
+    kc_result_stats(res, st);
+    if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
+    WriteName(path, "greedy", k, false, !complements, *of);
+    if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
+    WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
+    if (st[3]) WriteLog("2. part: Number of simplitigs over threshold, computing directly from k-mers.");
+    WriteLog("Finished 2. part: Hamiltonian path.");
+    std::string out(st[2], 'N'), mask(maskf ? st[2] : 0, 'N');
+    kcamd::check(kc_result_copy(res, out.data(), maskf ? mask.data() : nullptr));
+    kc_result_destroy(res);
+    of->write(out.data(), (std::streamsize)out.size());
+    if (maskf != nullptr) { maskf->write(mask.data(), (std::streamsize)mask.size()); (*maskf) << std::endl; }
+    WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
+    *of << std::endl;   // main.cpp:210
+    return 0;
+}
+
+int camel_compute(int argc, char **argv, bool lowerbound) {
+    std::string subcommand = lowerbound ? "lowerbound" : "compute";
+    std::string path;
+    if (argc > 1 && std::string(argv[argc - 1]) != "-h") { path = argv[argc - 1]; argc--; }
+    int k = 0, d_max = 5, opt;
+    std::ofstream output, maskOutput;
+    std::ostream *of = &std::cout, *maskf = nullptr;
+    std::string algorithm = "greedy";
+    bool complements = true, d_set = false, assume_simplitigs = false;
+    int min_frequency = 1;
+    try {
+        while ((opt = getopt(argc, argv, lowerbound ? "k:huxSz:" : "k:d:a:o:huxM:Sz:")) != -1) {
+            switch (opt) {
+                case 'o': output.open(optarg); of = &output; break;
+                case 'k': k = std::stoi(optarg); break;
+                case 'd': d_set = true; d_max = std::stoi(optarg); break;
+                case 'a': algorithm = optarg; break;
+                case 'u': complements = false; break;
+                case 'x': std::cerr << "Warning: The parameter -x currently has no effect due to the improvement in the underlying algorithm." << std::endl; break;
+                case 'M': maskOutput.open(optarg); maskf = &maskOutput; break;
+                case 'S': assume_simplitigs = true; break;
+                case 'h': usage_subcommand(subcommand); return 0;
+                case 'z': min_frequency = std::stoi(optarg); break;
+                default: return usage_subcommand(subcommand);
+            }
+        }
+    } catch (std::invalid_argument &) {
+        return usage_subcommand(subcommand);
+    }
+    algorithm = normalize_compute_algorithm(algorithm);
+    auto fail = [&](const std::string &m) { std::cerr << m << std::endl; return usage_subcommand(subcommand); };
+    if (path.empty()) return fail("Required positional parameter path to the file not set.");
+    if (k == 0) return fail("Required parameter k not set.");
+    if (k < 0) return fail("k must be positive.");
+    if (d_max < 0) return fail("d must be non-negative.");
+    if (k > MAX_K && (algorithm == "local-greedy" || algorithm == "greedy"))
+        return fail("k > " + std::to_string(MAX_K) + " not supported for the algorithm '" + algorithm + "'. Use the  AC version of the algorithm instead.");
+    if (d_set && (algorithm == "greedy-ac" || algorithm == "greedy" || algorithm == "streaming")) return fail("Unsupported argument d for algorithm '" + algorithm + "'.");
+    if (maskf != nullptr && algorithm != "greedy")
+        return fail("Outputting mask maximizing number of ones is possible only with greedy. For other algorithms, use separately kmercamel optimize.");
+    if (assume_simplitigs && algorithm != "greedy") return fail("Optimization for the input being simplitigs is possible only with greedy.");
+    if (min_frequency >= 256 || min_frequency < 1) return fail("Minimum frequency '-z' must be between 1 and 255.");
+    if (min_frequency != 1 && assume_simplitigs) return fail("Inputting simplitigs is not compatible with frequency filterring.");
+    if (algorithm != "greedy") return fail("Algorithm '" + algorithm + "' not supported by the MI355X build (greedy only).");
+    if (min_frequency != 1) return fail("Minimum frequency filtering (-z) is not implemented in the MI355X build yet.");
+    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound);
+}
+
+// Optimize (masks.h:239-261) for max-one / min-one
+int camel_optimize(int argc, char **argv) {
+    std::string subcommand = "maskopt", path;
+    if (argc > 1 && std::string(argv[argc - 1]) != "-h") { path = argv[argc - 1]; argc--; }
+    int k = 0, opt;
+    std::ofstream output;
+    std::ostream *of = &std::cout;
+    std::string algorithm = "max-one";
+    bool complements = true;
+    try {
+        while ((opt = getopt(argc, argv, "k:t:o:hu")) != -1) {
+            switch (opt) {
+                case 'o': output.open(optarg); of = &output; break;
+                case 'k': k = std::stoi(optarg); break;
+                case 't': algorithm = optarg; break;
+                case 'u': complements = false; break;
+                case 'h': usage_subcommand(subcommand); return 0;
+                default: return usage_subcommand(subcommand);
+            }
+        }
+    } catch (std::invalid_argument &) {
+        return usage_subcommand(subcommand);
+    }
+    algorithm = normalize_maskopt_algorithm(algorithm);
+    auto fail = [&](const std::string &m) { std::cerr << m << std::endl; return usage_subcommand(subcommand); };
+    if (path.empty()) return fail("Required positional parameter path to the file not set.");
+    if (k == 0) return fail("Required parameter k not set.");
+    if (k < 0) return fail("k must be positive.");
+    WriteLog("Started optimization of a masked superstring from '" + path + "'.");
+    if (algorithm == "min-run" || algorithm == "approx-min-run") return fail("Algorithm '" + algorithm + "' (GLPK ILP) is outside the MI355X build's scope.");
+    if (algorithm != "max-one" && algorithm != "min-one") return fail("Algorithm '" + algorithm + "' not recognized.");
+    auto recs = kcamd::read_records(path);
+    if (recs.empty()) throw std::invalid_argument("couldn't read a masked superstring from " + path);
+    const kcamd::Record &ms = recs[0];
+    std::string out(ms.seq.size(), 'N');
+    int rc = kc_maskopt_ones(kcamd::context(), ms.seq.data(), ms.seq.size(), k, complements, algorithm == "min-one", out.data());
+    // ReprintSequenceHeader (masks.h:27-37)
+    *of << ">" << ms.name << " reoptimized=" << algorithm;
+    if (!ms.comment.empty()) *of << " " << ms.comment;
+    *of << std::endl;
+    if (rc == KC_OK || rc == KC_E_INVALID_CHAR) *of << out << std::endl;
+    if (rc == KC_E_INVALID_CHAR) throw std::invalid_argument("Masked superstring contains invalid characters.");   // masks.h:75-77
+    kcamd::check(rc);
+    if (recs.size() > 1) throw std::invalid_argument("Expecting only a single FASTA record -- the masked superstring.");   // masks.h:258
+    WriteLog("Finished optimization.");
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc == 1 || std::string(argv[1]) == "-h") { usage(); return 0; }
+    std::string cmd = argv[1];
+    if (cmd == "-v" || cmd == "--version") { std::cerr << KC_CLI_VERSION << std::endl; return 0; }
+    if (cmd == "compute") return camel_compute(argc - 1, argv + 1, false);
+    if (cmd == "lowerbound") return camel_compute(argc - 1, argv + 1, true);
+    if (cmd == "maskopt") return camel_optimize(argc - 1, argv + 1);
+    if (cmd == "ms2mssep" || cmd == "mssep2ms" || cmd == "ms2spss" || cmd == "spss2ms") {
+        std::cerr << "Command '" << cmd << "' (format conversion) is not part of the MI355X build; use the reference binary." << std::endl;
+        return usage();
+    }
+    std::cerr << "Command '" << argv[1] << "' not recognized." << std::endl;
+    return usage();
+}
