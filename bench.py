@@ -50,6 +50,23 @@ def cpu_baseline(k, read_len, sample_records, seed):
                 "sample": "%d records x %d bp (seed %d): %d k-mers in %.1f s (oracle restatement, reference order)" % (sample_records, read_len, seed, st[0], dt)}
 
 
+def shard_seed(rank):
+    """records of rank r are generated with seed 1+r (independent shards, weak scaling)"""
+    return 1 + rank
+
+
+def aggregate(dist, dev, elapsed, n_kmers):
+    """(max over ranks of elapsed, sum over ranks of the k-mer counts); identity without a process group"""
+    if dist is None:
+        return float(elapsed), float(n_kmers)
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    nk = torch.tensor([float(n_kmers)], dtype=torch.float64, device=dev)
+    dist.all_reduce(nk, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(nk.item())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +100,7 @@ def main():
     torch.cuda.set_device(dev)
 
     ctx = kc.Context(local_rank)
-    host = gen.random_joined(args.records, read_len, seed=1 + rank)
+    host = gen.random_joined(args.records, read_len, seed=shard_seed(rank))
     d_seq = torch.from_numpy(host).to(dev)
     torch.cuda.synchronize()
     nbytes = int(d_seq.numel())
@@ -109,15 +126,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        nk = torch.tensor([float(stats[-1]["n_kmers"])], dtype=torch.float64, device=dev)
-        dist.all_reduce(nk, op=dist.ReduceOp.SUM)
-        total_kmers = float(nk.item())
-    else:
-        total_kmers = float(stats[-1]["n_kmers"])
+    elapsed, total_kmers = aggregate(dist, dev, elapsed, stats[-1]["n_kmers"])
 
     if args.check and rank == 0:
         import oracle_lib
