@@ -9,7 +9,6 @@
 // jumping; one wavefront per vertex then writes its block with coalesced byte stores.  The -M mask (global.h:185-195)
 // is a per-position probe of the k-mer set over the finished string.
 #include "kc_internal.h"
-#include "kc_set_dev.h"
 
 __global__ void __launch_bounds__(256) em_pred_kernel(const u64 *__restrict__ edge_from, u64 V, u64 *pred) {
     u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,9 +118,9 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
         KC_TRY(kc_alloc(ctx, &mask, L + 1));
         unsigned gm = kc_grid(L, 256);
         switch (set_for_mask->W) {
-            case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, SetView<1>{set_for_mask->keys, set_for_mask->state, set_for_mask->cap}, mask); break;
-            case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, SetView<2>{set_for_mask->keys, set_for_mask->state, set_for_mask->cap}, mask); break;
-            default: hipLaunchKernelGGL((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, SetView<4>{set_for_mask->keys, set_for_mask->state, set_for_mask->cap}, mask); break;
+            case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<1>(set_for_mask), mask); break;
+            case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<2>(set_for_mask), mask); break;
+            default: hipLaunchKernelGGL((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<4>(set_for_mask), mask); break;
         }
     }
     KC_HIP(ctx, hipGetLastError());
@@ -184,7 +183,7 @@ template <int W> static int maskopt_w(kc_ctx *ctx, const char *ms, u64 len, int 
     if (rc != KC_OK) { kc_set_destroy(set); return rc; }
     KC_HIP(ctx, hipMemsetAsync(firstpos, 0xff, set->cap * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
-    SetView<W> sv{set->keys, set->state, set->cap};
+    SetView<W> sv = kc_view<W>(set);
     unsigned g = kc_grid(len, 256);
     hipLaunchKernelGGL((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
     hipLaunchKernelGGL((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);

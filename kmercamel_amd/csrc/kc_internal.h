@@ -9,6 +9,7 @@
 #include <cstring>
 #include "../../include/kmercamel_amd.h"
 #include "kc_key.h"
+#include "kc_set_dev.h"
 
 typedef unsigned long long ull;
 
@@ -36,12 +37,21 @@ struct kc_ctx {
 struct kc_set {
     kc_ctx *ctx = nullptr;
     int k = 0, W = 1, complements = 1;
-    u64 cap = 0;          // slots
+    u64 cap = 0;          // slots = nblocks << bshift
+    u64 nblocks = 0;
+    int bshift = 12;      // 4096 slots per block
+    int mlen = 0;         // minimizer length (0 = plain hashing)
+    u32 local_probes = 128;
     u64 *keys = nullptr;  // cap * W words; W==1: EMPTY = ~0
     u32 *state = nullptr; // W>1: 0 empty, 1 busy, 2 full
+    u8 *tags = nullptr;   // cap bytes
     u64 *counters = nullptr;  // device: [0] size, [1] overflow flag
     u64 size_host = 0;
 };
+
+template <int W> static inline SetView<W> kc_view(const kc_set *s) {
+    return SetView<W>{s->keys, s->state, s->tags, s->cap, s->nblocks, s->bshift, s->mlen, s->k, s->local_probes};
+}
 
 struct kc_simplitigs {
     kc_ctx *ctx = nullptr;
@@ -96,6 +106,7 @@ template <typename T> static inline int kc_alloc(kc_ctx *ctx, T **out, size_t co
 static inline void kc_release(kc_ctx *ctx, void *p) { if (p) ctx->pool.release(p); }
 
 static inline unsigned kc_grid(u64 n, unsigned block) { u64 g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
+static inline unsigned kc_grid8(u64 n, unsigned block) { u64 g = (n + block - 1) / block; g = (g + 7) / 8 * 8; return (unsigned)(g ? g : 8); }  // for kc_xcd_block_id()
 
 // ---- cross-TU host entry points (each dispatches on W internally) ----
 // kc_set.hip

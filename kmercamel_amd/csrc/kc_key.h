@@ -43,24 +43,39 @@ template <int W> KC_HD bool key_is_ones(const Key<W> &a) {
     for (int i = 0; i < W; ++i) e = e && (a.w[i] == ~(u64)0);
     return e;
 }
-// logical shifts by 0 <= s < 64*W
+// logical shifts by 0 <= s < 64*W.  All word indices are compile-time constants (a barrel shifter over the words): a
+// runtime-indexed register array would be placed in scratch memory by hipcc.
 template <int W> KC_HD Key<W> key_shr(const Key<W> &a, int s) {
+    if constexpr (W == 1) { Key<W> r; r.w[0] = a.w[0] >> s; return r; }
+    Key<W> t = a;
+    const int ws = s >> 6, bs = s & 63;
+    for (int step = 1; step < W; step <<= 1) {
+        const bool on = (ws & step) != 0;
+        Key<W> u;
+        for (int i = 0; i < W; ++i) u.w[i] = (i + step < W) ? t.w[i + step] : 0;
+        for (int i = 0; i < W; ++i) t.w[i] = on ? u.w[i] : t.w[i];
+    }
     Key<W> r;
-    int ws = s >> 6, bs = s & 63;
     for (int i = 0; i < W; ++i) {
-        u64 lo = (i + ws < W) ? a.w[i + ws] : 0;
-        u64 hi = (i + ws + 1 < W) ? a.w[i + ws + 1] : 0;
-        r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        u64 hi = (i + 1 < W) ? t.w[i + 1] : 0;
+        r.w[i] = bs ? ((t.w[i] >> bs) | (hi << (64 - bs))) : t.w[i];
     }
     return r;
 }
 template <int W> KC_HD Key<W> key_shl(const Key<W> &a, int s) {
+    if constexpr (W == 1) { Key<W> r; r.w[0] = a.w[0] << s; return r; }
+    Key<W> t = a;
+    const int ws = s >> 6, bs = s & 63;
+    for (int step = 1; step < W; step <<= 1) {
+        const bool on = (ws & step) != 0;
+        Key<W> u;
+        for (int i = 0; i < W; ++i) u.w[i] = (i - step >= 0) ? t.w[i - step] : 0;
+        for (int i = 0; i < W; ++i) t.w[i] = on ? u.w[i] : t.w[i];
+    }
     Key<W> r;
-    int ws = s >> 6, bs = s & 63;
     for (int i = W - 1; i >= 0; --i) {
-        u64 hi = (i - ws >= 0) ? a.w[i - ws] : 0;
-        u64 lo = (i - ws - 1 >= 0) ? a.w[i - ws - 1] : 0;
-        r.w[i] = bs ? ((hi << bs) | (lo >> (64 - bs))) : hi;
+        u64 lo = (i - 1 >= 0) ? t.w[i - 1] : 0;
+        r.w[i] = bs ? ((t.w[i] << bs) | (lo >> (64 - bs))) : t.w[i];
     }
     return r;
 }
@@ -85,8 +100,9 @@ template <int W> KC_HD Key<W> key_append(const Key<W> &x, u64 c, int k) {
 // (x >> 2) | (c << 2(k-1))     -- prepend nucleotide c on the left (parser.h:39, simplitigs.h:113,116)
 template <int W> KC_HD Key<W> key_prepend(const Key<W> &x, u64 c, int k) {
     Key<W> r = key_shr(x, 2);
-    int s = 2 * (k - 1);
-    r.w[s >> 6] |= c << (s & 63);
+    const int s = 2 * (k - 1), ws = s >> 6;
+    const u64 bits = c << (s & 63);
+    for (int i = 0; i < W; ++i) r.w[i] |= (ws == i) ? bits : 0;
     return r;
 }
 // BitPrefix(x, k, d) = x >> 2(k-d); BitSuffix(x, d) = x & (4^d - 1)    (kmers.h:36-44)
@@ -94,8 +110,10 @@ template <int W> KC_HD Key<W> key_prefix(const Key<W> &x, int k, int d) { return
 template <int W> KC_HD Key<W> key_suffix(const Key<W> &x, int d) { return key_and(x, key_lowmask<W>(2 * d)); }
 // nucleotide at index i (0 = first)   (kmers.h:99-102)
 template <int W> KC_HD u32 key_at(const Key<W> &x, int k, int i) {
-    int s = 2 * (k - 1 - i);
-    return (u32)((x.w[s >> 6] >> (s & 63)) & 3);
+    const int s = 2 * (k - 1 - i), ws = s >> 6;
+    u64 v = x.w[0];
+    for (int j = 1; j < W; ++j) v = (ws == j) ? x.w[j] : v;
+    return (u32)((v >> (s & 63)) & 3);
 }
 
 KC_HD u64 kc_brev64(u64 x) {

@@ -4,7 +4,6 @@
 // stream (each thread reads its own few words, neighbouring lanes read neighbouring words), the cost is the random
 // 8-byte (W*8-byte) slot access of the insert.
 #include "kc_internal.h"
-#include "kc_set_dev.h"
 
 // ------------------------------------------------------------------------------------------------- pool / ctx
 hipError_t KcPool::alloc(void **out, size_t bytes) {
@@ -215,9 +214,11 @@ __global__ void __launch_bounds__(256) kc_contains_kernel(SetView<W> set, const 
     out[t] = set_find(set, key) != KC_NONE64 ? 1 : 0;
 }
 
-static int set_alloc_table(kc_set *set, u64 cap, u64 **keys, u32 **state) {
+static int set_alloc_table(kc_set *set, u64 cap, u64 **keys, u32 **state, u8 **tags) {
     kc_ctx *ctx = set->ctx;
     KC_TRY(kc_alloc(ctx, keys, cap * set->W));
+    KC_TRY(kc_alloc(ctx, tags, cap + 8));
+    KC_HIP(ctx, hipMemsetAsync(*tags, 0, cap + 8, ctx->stream));
     *state = nullptr;
     if (set->W == 1) {
         KC_HIP(ctx, hipMemsetAsync(*keys, 0xff, cap * 8, ctx->stream));
@@ -235,9 +236,16 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     KC_HIP(ctx, hipSetDevice(ctx->device));
     kc_set *s = new kc_set();
     s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
+    s->mlen = k >= 16 ? 15 : 0;
+    s->bshift = 15;   // 32768 slots per block (256 KB of 64-bit keys): large enough that the skewed minimizer popularity does not overflow blocks
+    if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v < k) ? v : 0; }   // tuning/ablation knobs
+    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 20) s->bshift = v; }
+    if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
     u64 cap = (u64)((double)capacity_hint / 0.66) + 1024;
+    s->nblocks = (cap + (((u64)1 << s->bshift) - 1)) >> s->bshift;
+    cap = s->nblocks << s->bshift;
     s->cap = cap;
-    int rc = set_alloc_table(s, cap, &s->keys, &s->state);
+    int rc = set_alloc_table(s, cap, &s->keys, &s->state, &s->tags);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 4);
     if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     if (rc != KC_OK) { kc_set_destroy(s); return rc; }
@@ -250,6 +258,7 @@ extern "C" void kc_set_destroy(kc_set *set) {
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, set->keys);
     kc_release(ctx, set->state);
+    kc_release(ctx, set->tags);
     kc_release(ctx, set->counters);
     delete set;
 }
@@ -264,7 +273,7 @@ int kcs_refresh_size(kc_set *set) {
     return KC_OK;
 }
 
-template <int W> static SetView<W> view_of(const kc_set *s) { return SetView<W>{s->keys, s->state, s->cap}; }
+template <int W> static SetView<W> view_of(const kc_set *s) { return kc_view<W>(s); }
 
 // Make room for `additional` more k-mer occurrences: grow + rehash when the load could exceed 0.7.
 int kcs_reserve(kc_set *set, u64 additional) {
@@ -274,21 +283,26 @@ int kcs_reserve(kc_set *set, u64 additional) {
     if ((double)worst <= 0.7 * (double)set->cap) return KC_OK;
     u64 ncap = (u64)((double)worst / 0.6) + 1024;
     if (ncap < set->cap * 2) ncap = set->cap * 2;
-    u64 *nkeys = nullptr; u32 *nstate = nullptr;
-    KC_TRY(set_alloc_table(set, ncap, &nkeys, &nstate));
+    u64 nnblocks = (ncap + (((u64)1 << set->bshift) - 1)) >> set->bshift;
+    ncap = nnblocks << set->bshift;
+    u64 *nkeys = nullptr; u32 *nstate = nullptr; u8 *ntags = nullptr;
+    KC_TRY(set_alloc_table(set, ncap, &nkeys, &nstate, &ntags));
+    kc_set to = *set;
+    to.keys = nkeys; to.state = nstate; to.tags = ntags; to.cap = ncap; to.nblocks = nnblocks;
     if (set->size_host) {
         unsigned g = kc_grid(set->cap, 256);
         switch (set->W) {
-            case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), SetView<1>{nkeys, nstate, ncap}, set->counters); break;
-            case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), SetView<2>{nkeys, nstate, ncap}, set->counters); break;
-            default: hipLaunchKernelGGL(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), SetView<4>{nkeys, nstate, ncap}, set->counters); break;
+            case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), view_of<1>(&to), set->counters); break;
+            case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), view_of<2>(&to), set->counters); break;
+            default: hipLaunchKernelGGL(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), view_of<4>(&to), set->counters); break;
         }
         KC_HIP(ctx, hipGetLastError());
     }
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     kc_release(ctx, set->keys);
     kc_release(ctx, set->state);
-    set->keys = nkeys; set->state = nstate; set->cap = ncap;
+    kc_release(ctx, set->tags);
+    set->keys = nkeys; set->state = nstate; set->tags = ntags; set->cap = ncap; set->nblocks = nnblocks;
     return KC_OK;
 }
 

@@ -1,8 +1,16 @@
 // Device-side view of the open-addressing k-mer set in HBM (replaces khash's S64/S128/S256, khash.h:215-359).
 //
-// Layout: `cap` slots, linear probing from fastrange(hash) (slot = mulhi(hash, cap)), no deletions (the simplitig
-// phase marks k-mers as consumed through port links instead of tombstones, so the table stays probe-able for the
-// -M mask pass).  W == 1: the slot is the 64-bit key itself, EMPTY = all ones (never a k-mer: the top bit pair is
+// Layout: `cap` = nblocks * B slots (B = 2^bshift = 4096 slots = one 32 KB region for 64-bit keys), no deletions (the
+// simplitig phase marks k-mers as consumed through port links instead of tombstones, so the table stays probe-able
+// for the -M mask pass).
+//
+// Home slot = locality-preserving: block = fastrange(hash of the k-mer's canonical minimizer (m-mer with the smallest
+// hash over both strands)), offset inside the block = key hash.  Overlapping k-mers -- in particular the 8 de Bruijn
+// neighbours the simplitig phase probes -- share their minimizer ~90 % of the time, so their slots lie in the same
+// 32 KB region that the probing workgroup (and its XCD's L2) is streaming anyway: random HBM line fetches become L2
+// hits.  Probe sequence: `local_probes` linear steps from the block home, then (overfull block, e.g. a low-complexity
+// minimizer) linear probing from a second, minimizer-independent home.  m = 0 (k < 16) falls back to the plain home.
+// W == 1: the slot is the 64-bit key itself, EMPTY = all ones (never a k-mer: the top bit pair is
 // spare for k <= 31), claimed with one 64-bit CAS.  W > 1: a 32-bit state word per slot (EMPTY/BUSY/FULL) is
 // claimed by CAS, the key words are then written with agent-scope stores and published by the FULL store.
 #pragma once
@@ -15,43 +23,108 @@
 template <int W> struct SetView {
     u64 *keys;
     u32 *state;
-    u64 cap;
+    u8 *tags;       // 0 = empty, else 0x80 | 7 hash bits: lookups scan 8 slots per 8-byte load and touch a key only on a tag hit
+    u64 cap;        // nblocks << bshift
+    u64 nblocks;
+    int bshift;     // log2(slots per block)
+    int m;          // minimizer length (0: plain hashing)
+    int k;
+    u32 local_probes;
 };
+
+KC_HD u8 kc_tag_of(u64 keyhash) { return (u8)(0x80u | (u32)(keyhash >> 57)); }
+
+// hash of a canonical m-mer (f forward, r its reverse complement), 32 bit
+KC_HD u32 kc_mmer_hash(u32 f, u32 r) {
+    u32 c = f < r ? f : r;
+    c *= 0x9E3779B1u; c ^= c >> 15; c *= 0x85EBCA77u; c ^= c >> 13;
+    return c;
+}
+// smallest canonical m-mer hash over the m-mers starting at positions i0..i1 (inclusive) of the k-mer x
+template <int W> KC_HD u32 key_min_mmh(const Key<W> &x, int k, int m, int i0, int i1) {
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const int top = 2 * (m - 1);
+    u32 f = 0, r = 0;
+    for (int j = 0; j < m - 1; ++j) {
+        u32 b = key_at(x, k, i0 + j);
+        f = (f << 2) | b;
+        r = (r >> 2) | ((3u - b) << top);
+    }
+    u32 best = ~0u;
+    for (int i = i0; i <= i1; ++i) {
+        u32 b = key_at(x, k, i + m - 1);
+        f = ((f << 2) | b) & maskm;
+        r = (r >> 2) | ((3u - b) << top);
+        u32 h = kc_mmer_hash(f, r);
+        best = h < best ? h : best;
+    }
+    return best;
+}
+// block home from a minimizer hash and the key hash
+template <int W> KC_HD u64 set_block_home(const SetView<W> &s, u32 mmh, u64 keyhash) {
+    // mmh is a minimum of ~k-m+1 uniform hashes, i.e. concentrated near 0: re-mix it before the range reduction
+    u32 u = mmh * 0x85EBCA6Bu; u ^= u >> 16; u *= 0xC2B2AE35u; u ^= u >> 13; u *= 0x27D4EB2Fu; u ^= u >> 16;
+    u64 blk = ((u64)u * s.nblocks) >> 32;
+    return (blk << s.bshift) | (keyhash & (((u64)1 << s.bshift) - 1));
+}
+template <int W> KC_HD u64 set_global_home(const SetView<W> &s, u64 keyhash) {
+    return kc_mulhi64(kc_mix64(keyhash ^ 0x6a09e667f3bcc909ULL), s.cap);
+}
+template <int W> KC_HD u64 set_home_kh(const SetView<W> &s, const Key<W> &key, u64 keyhash) {
+    if (s.m == 0) return kc_mulhi64(keyhash, s.cap);
+    return set_block_home(s, key_min_mmh(key, s.k, s.m, 0, s.k - s.m), keyhash);
+}
+// XCD-aware workgroup order for kernels that sweep the table: workgroups are dealt round-robin over the 8 XCDs, so give
+// XCD j the j-th contiguous eighth of the sweep -- the workgroups resident on one XCD then work on neighbouring table
+// regions and share them through that XCD's L2 (speed only; correctness never depends on placement). Grid = multiple of 8.
+#if defined(__HIPCC__)
+__device__ __forceinline__ u64 kc_xcd_block_id(int xcd_aware = 1) {
+    u64 b = blockIdx.x, chunk = gridDim.x >> 3;
+    return xcd_aware ? (b & 7) * chunk + (b >> 3) : b;
+}
+#endif
+// reverse complement of an m-mer held in the low 2m bits
+KC_HD u32 kc_mmer_rc(u32 f, int m) { return (u32)(kc_rc_word((u64)f) >> (64 - 2 * m)); }
+
+// i-th slot of the probe sequence that starts at `home`
+template <int W> KC_HD u64 set_probe_slot(const SetView<W> &s, u64 home, u64 ghome, u64 i) {
+    u64 p = (s.m != 0 && i >= s.local_probes) ? ghome + (i - s.local_probes) : home + i;
+    return p >= s.cap ? p - s.cap : p;
+}
 
 #if defined(__HIPCC__)
 
-template <int W> __device__ __forceinline__ u64 set_home(const SetView<W> &s, const Key<W> &key) {
-    return kc_mulhi64(key_hash(key), s.cap);
-}
 
 // Insert during the build kernel (concurrent with other inserts). Returns 1 if this call added the key, 0 if it was
 // present, -1 if the table is full. *slot_out receives the slot.
 template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, const Key<W> &key, u64 *slot_out) {
-    u64 slot = set_home(s, key);
+    const u64 kh = key_hash(key);
+    const u64 home = set_home_kh(s, key, kh), ghome = set_global_home(s, kh);
+    const u64 limit = s.m ? s.cap + s.local_probes : s.cap;
     if constexpr (W == 1) {
         unsigned long long *keys = (unsigned long long *)s.keys;
         const unsigned long long kv = key.w[0];
-        for (u64 probes = 0; probes < s.cap; ++probes) {
+        for (u64 probes = 0; probes < limit; ++probes) {
+            u64 slot = set_probe_slot(s, home, ghome, probes);
             unsigned long long cur = keys[slot];
             if (cur == kv) { *slot_out = slot; return 0; }
             if (cur == ~0ULL) {
                 unsigned long long prev = atomicCAS(&keys[slot], ~0ULL, kv);
-                if (prev == ~0ULL) { *slot_out = slot; return 1; }
+                if (prev == ~0ULL) { s.tags[slot] = kc_tag_of(kh); *slot_out = slot; return 1; }
                 if (prev == kv) { *slot_out = slot; return 0; }
             }
-            slot = (slot + 1 == s.cap) ? 0 : slot + 1;
         }
         return -1;
     } else {
         u64 probes = 0;
-        while (probes < s.cap) {
+        while (probes < limit) {
+            u64 slot = set_probe_slot(s, home, ghome, probes);
             u32 st = __hip_atomic_load(&s.state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st == KC_ST_FULL) {
                 bool eq = true;
                 for (int i = 0; i < W; ++i)
                     eq = eq && (__hip_atomic_load(&s.keys[slot * W + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key.w[i]);
                 if (eq) { *slot_out = slot; return 0; }
-                slot = (slot + 1 == s.cap) ? 0 : slot + 1;
                 ++probes;
             } else if (st == KC_ST_EMPTY) {
                 u32 prev = atomicCAS(&s.state[slot], KC_ST_EMPTY, KC_ST_BUSY);
@@ -59,6 +132,7 @@ template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, 
                     for (int i = 0; i < W; ++i)
                         __hip_atomic_store(&s.keys[slot * W + i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&s.state[slot], KC_ST_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    s.tags[slot] = kc_tag_of(kh);
                     *slot_out = slot;
                     return 1;
                 }
@@ -72,28 +146,50 @@ template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, 
 }
 
 // Lookup in a finished table (launched after the build kernels completed). Returns the slot or KC_NONE64.
-template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) {
-    u64 slot = set_home(s, key);
-    if constexpr (W == 1) {
-        const u64 kv = key.w[0];
-        for (u64 probes = 0; probes < s.cap; ++probes) {
-            u64 cur = s.keys[slot];
-            if (cur == kv) return slot;
-            if (cur == ~(u64)0) return KC_NONE64;
-            slot = (slot + 1 == s.cap) ? 0 : slot + 1;
-        }
-        return KC_NONE64;
-    } else {
-        for (u64 probes = 0; probes < s.cap; ++probes) {
-            u32 st = s.state[slot];
-            if (st == KC_ST_EMPTY) return KC_NONE64;
+// Tag scan: `count` slots from `start` (wrapping), 8 per aligned 8-byte load. Returns the slot, KC_NONE64 for a proven
+// miss (an empty slot was reached), or KC_SCAN_MORE when neither happened within `count` slots.
+#define KC_SCAN_MORE (~(u64)1)
+template <int W> __device__ __forceinline__ u64 set_scan(const SetView<W> &s, const Key<W> &key, u8 tag, u64 start, u64 count) {
+    const u64 pat = 0x0101010101010101ULL * (u64)tag, hi7 = 0x8080808080808080ULL, lo7 = 0x7f7f7f7f7f7f7f7fULL;
+    u64 wbase = start & ~(u64)7;
+    int off = (int)(start & 7);
+    while (count) {
+        u64 word = *reinterpret_cast<const u64 *>(s.tags + wbase);
+        int nvalid = 8 - off;
+        if ((u64)nvalid > count) nvalid = (int)count;
+        u64 x = word ^ pat;
+        u64 zero = ~(((x & lo7) + lo7) | x | lo7);   // 0x80 in every byte of x that is 0  (tag match)
+        u64 empty = ~word & hi7;                      // valid tags have bit 7 set
+        u64 valid = (nvalid == 8 ? ~(u64)0 : ((((u64)1 << (8 * nvalid)) - 1))) << (8 * off);
+        u64 cand = (zero | empty) & valid;
+        while (cand) {
+            int b = __builtin_ctzll(cand) >> 3;
+            u64 slot = wbase + (u64)b;
+            if ((empty >> (8 * b)) & 0x80) return KC_NONE64;
             bool eq = true;
             for (int i = 0; i < W; ++i) eq = eq && (s.keys[slot * W + i] == key.w[i]);
             if (eq) return slot;
-            slot = (slot + 1 == s.cap) ? 0 : slot + 1;
+            cand &= cand - 1;
         }
-        return KC_NONE64;
+        count -= (u64)nvalid;
+        off = 0;
+        wbase += 8;
+        if (wbase >= s.cap) wbase = 0;
     }
+    return KC_SCAN_MORE;
+}
+// `home` must be the key's block home (set_home_kh, or set_block_home with a minimizer hash derived incrementally)
+template <int W> __device__ __forceinline__ u64 set_find_from(const SetView<W> &s, const Key<W> &key, u64 keyhash, u64 home) {
+    const u8 tag = kc_tag_of(keyhash);
+    if (s.m == 0) { u64 r = set_scan(s, key, tag, home, s.cap); return r == KC_SCAN_MORE ? KC_NONE64 : r; }
+    u64 r = set_scan(s, key, tag, home, (u64)s.local_probes);
+    if (r != KC_SCAN_MORE) return r;
+    r = set_scan(s, key, tag, set_global_home(s, keyhash), s.cap);
+    return r == KC_SCAN_MORE ? KC_NONE64 : r;
+}
+template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) {
+    const u64 kh = key_hash(key);
+    return set_find_from(s, key, kh, set_home_kh(s, key, kh));
 }
 
 template <int W> __device__ __forceinline__ bool set_slot_full(const SetView<W> &s, u64 slot) {

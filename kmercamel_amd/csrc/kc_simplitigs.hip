@@ -12,7 +12,6 @@
 //   * chains start at the end with the smaller key and are ordered by that key; cycles are cut at their minimum key.
 // Kernels: neighbour_choose (4 probes per port), accept, heads, walk (measure), walk (emit packed 2-bit).
 #include "kc_internal.h"
-#include "kc_set_dev.h"
 #include <hipcub/hipcub.hpp>
 
 #define LK_OPEN 0ull
@@ -44,12 +43,14 @@ __device__ __forceinline__ bool edge_preferred(const Key<W> &x, int px, const Ke
     return pb1 < pb2;
 }
 
-// One thread per port.  FIRST: port id = thread id over all 2*cap ports (round 1, nothing is matched yet, so the
-// neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
+// One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
+// yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
+// The 4 candidate neighbours of a port share k-1 bases with x, hence all m-mers but one: their minimizer (= their table
+// region) is min(shared part, one new m-mer), computed once per port.
 template <int W, bool FIRST>
 __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements,
-                                                        const u64 *__restrict__ work, u64 nwork) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+                                                        const u64 *__restrict__ work, u64 nwork, int xcd_aware) {
+    u64 t = (FIRST ? kc_xcd_block_id(xcd_aware) : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
     u64 pid = FIRST ? t : work[t];
     u64 slot = pid >> 1;
@@ -60,6 +61,9 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         Key<W> xr = key_rc(x, k);
         if (key_eq(x, xr)) { link[pid] = LK_DEAD; return; }  // palindromes link on port L only
     }
+    const int m = set.m;
+    u32 shared = ~0u;
+    if (m) shared = port ? key_min_mmh(x, k, m, 1, k - m) : key_min_mmh(x, k, m, 0, k - m - 1);
     u64 hx = kc_port_term(key_hash(x), port);
     bool have = false;
     Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0; u32 bbase = 0;
@@ -78,13 +82,20 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
             q = port ? 0 : 1;
         }
         if (key_eq(y, x)) continue;
-        u64 tslot = set_find(set, y);
+        const u64 hy = key_hash(y);
+        u64 home;
+        if (m) {
+            u32 f = port ? (u32)(nf.w[0] & ((m >= 16) ? ~0u : ((1u << (2 * m)) - 1u))) : (u32)key_prefix(nf, k, m).w[0];
+            u32 h = kc_mmer_hash(f, kc_mmer_rc(f, m));
+            home = set_block_home(set, h < shared ? h : shared, hy);
+        } else home = kc_mulhi64(hy, set.cap);
+        u64 tslot = set_find_from(set, y, hy, home);
         if (tslot == KC_NONE64) continue;
         if (!FIRST) {
             u64 wt = link[(tslot << 1) | (u64)q];
             if (LK_STATE(wt) == LK_MATCHED) continue;
         }
-        u64 pr = kc_mix64(hx + kc_port_term(key_hash(y), q));
+        u64 pr = kc_mix64(hx + kc_port_term(hy, q));
         if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) {
             have = true; by = y; bq = q; bpr = pr; bslot = tslot;
             bbase = port ? c : 3 - c;
@@ -96,7 +107,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
 template <bool FIRST>
 __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__restrict__ work, u64 nwork, u64 *work_out,
                                                         u64 *cursor) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 t = (FIRST ? kc_xcd_block_id() : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
     u64 pid = FIRST ? t : work[t];
     u64 w = link[pid];
@@ -113,7 +124,7 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
 
 // count unresolved ports after round 1 (sizes the work lists)
 __global__ void __launch_bounds__(256) kc_count_unresolved_kernel(const u64 *__restrict__ link, u64 nports, u64 *counter) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 t = kc_xcd_block_id() * blockDim.x + threadIdx.x;
     if (t >= nports) return;
     u64 w = link[t];
     if (LK_STATE(w) != LK_CHOICE) return;
@@ -300,8 +311,9 @@ static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h) {
 template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out) {
     kc_ctx *ctx = set->ctx;
     const int k = set->k, compl_ = set->complements;
-    SetView<W> sv{set->keys, set->state, set->cap};
+    SetView<W> sv = kc_view<W>(set);
     const u64 cap = set->cap, nports = cap * 2;
+    const int xcd_aware = getenv("KC_NOXCD") ? 0 : 1;
     KC_TRY(kcs_refresh_size(set));
     const u64 N = set->size_host;
     if (N == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
@@ -312,17 +324,17 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     // round 1 over all ports (the dominant kernel of this phase: 4 table probes per port)
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    hipLaunchKernelGGL((kc_choose_kernel<W, true>), dim3(kc_grid(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                       (const u64 *)nullptr, nports);
+    hipLaunchKernelGGL((kc_choose_kernel<W, true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                       (const u64 *)nullptr, nports, xcd_aware);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(kc_count_unresolved_kernel, dim3(kc_grid(nports, 256)), dim3(256), 0, ctx->stream, link, nports, cnt);
+    hipLaunchKernelGGL(kc_count_unresolved_kernel, dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, nports, cnt);
     u64 nun = 0;
     KC_TRY(read_u64(ctx, cnt, &nun));
     u64 *work_a = nullptr, *work_b = nullptr;
     KC_TRY(kc_alloc(ctx, &work_a, nun + 1));
     KC_TRY(kc_alloc(ctx, &work_b, nun + 1));
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-    hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
+    hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
                        nports, work_a, cnt);
     u64 nwork = 0, rounds = 1;
     KC_TRY(read_u64(ctx, cnt, &nwork));
@@ -330,7 +342,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
         hipLaunchKernelGGL((kc_choose_kernel<W, false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)work_a, nwork);
+                           (const u64 *)work_a, nwork, 0);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_accept_kernel<false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
                            nwork, work_b, cnt);
