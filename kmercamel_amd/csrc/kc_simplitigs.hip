@@ -43,13 +43,22 @@ __device__ __forceinline__ bool edge_preferred(const Key<W> &x, int px, const Ke
     return pb1 < pb2;
 }
 
+// A port that ends DEAD (no partner left) is the entry port of a directed chain: oriented node (slot, o = port).  Every
+// port ends either MATCHED or DEAD, so the heads are exactly the ports that die (unidirectional mode: the L ports).
+__device__ __forceinline__ void kc_push_head(u64 pid, int complements, u64 *heads, u64 heads_cap, u64 *heads_cursor) {
+    if (!complements && (pid & 1)) return;
+    u64 pos = atomicAdd((ull *)heads_cursor, 1ULL);
+    if (pos < heads_cap) heads[pos] = pid;
+}
+
 // One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
 // yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
 // The 4 candidate neighbours of a port share k-1 bases with x, hence all m-mers but one: their minimizer (= their table
 // region) is min(shared part, one new m-mer), computed once per port.
 template <int W, bool FIRST>
 __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements,
-                                                        const u64 *__restrict__ work, u64 nwork, int xcd_aware) {
+                                                        const u64 *__restrict__ work, u64 nwork, int xcd_aware, u64 *heads,
+                                                        u64 heads_cap, u64 *heads_cursor) {
     u64 t = (FIRST ? kc_xcd_block_id(xcd_aware) : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
     u64 pid = FIRST ? t : work[t];
@@ -59,7 +68,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
     Key<W> x = set_key_at(set, slot);
     if (complements && port == 1) {
         Key<W> xr = key_rc(x, k);
-        if (key_eq(x, xr)) { link[pid] = LK_DEAD; return; }  // palindromes link on port L only
+        if (key_eq(x, xr)) { link[pid] = LK_DEAD; kc_push_head(pid, complements, heads, heads_cap, heads_cursor); return; }  // palindromes link on port L only
     }
     const int m = set.m;
     u32 shared = ~0u;
@@ -102,11 +111,12 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         }
     }
     link[pid] = have ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
+    if (!have) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
 }
 
 template <bool FIRST>
 __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__restrict__ work, u64 nwork, u64 *work_out,
-                                                        u64 *cursor) {
+                                                        u64 work_cap, u64 *cursor) {
     u64 t = (FIRST ? kc_xcd_block_id() : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
     u64 pid = FIRST ? t : work[t];
@@ -118,7 +128,7 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
         __hip_atomic_store(&link[pid], (w & ~3ull) | LK_MATCHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         u64 pos = atomicAdd((ull *)cursor, 1ULL);
-        work_out[pos] = pid;
+        if (pos < work_cap) work_out[pos] = pid;
     }
 }
 
@@ -151,7 +161,8 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 
 // measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a
 // chain is emitted (bi: the one starting at the smaller key) and records the winners.
-template <int W>
+// MARK: also flag visited nodes (only needed when the node count shows that cycles exist).
+template <int W, bool MARK>
 __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
                                                               const u64 *__restrict__ heads, u64 nheads, u8 *visited,
                                                               u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor) {
@@ -162,7 +173,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     int o = (int)(h & 1), co = o;
     u64 len = 1;
     while (true) {
-        visited[cur] = 1;
+        if (MARK) visited[cur] = 1;
         u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         if (LK_STATE(w) != LK_MATCHED) break;
         cur = LK_SLOT(w);
@@ -173,6 +184,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     bool winner = true;
     if (complements) winner = (len == 1) ? (o == 0) : key_lt(hk, set_key_at(set, cur));
     if (!winner) return;
+    atomicAdd((ull *)(cursor + 3), (ull)len);   // nodes covered by chains that have ends
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
     chain_head[pos] = h;
     chain_len[pos] = len;
@@ -322,31 +334,42 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_TRY(kc_alloc(ctx, &cnt, 8));
     KC_HIP(ctx, hipMemsetAsync(link, 0, nports * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+    // heads (ports that die) and the work list of unresolved ports are collected on the fly into bounded buffers; an
+    // overflow (never seen on read-like inputs) falls back to exact counting passes.
+    u64 heads_cap = N / 4 + 65536, work_cap = N / 8 + 65536;
+    u64 *heads = nullptr, *work_a = nullptr, *work_b = nullptr;
+    KC_TRY(kc_alloc(ctx, &heads, heads_cap));
+    KC_TRY(kc_alloc(ctx, &work_a, work_cap));
+    KC_TRY(kc_alloc(ctx, &work_b, work_cap));
+    u64 *heads_cursor = cnt + 2, *work_cursor = cnt;
     // round 1 over all ports (the dominant kernel of this phase: 4 table probes per port)
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     hipLaunchKernelGGL((kc_choose_kernel<W, true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                       (const u64 *)nullptr, nports, xcd_aware);
+                       (const u64 *)nullptr, nports, xcd_aware, heads, heads_cap, heads_cursor);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(kc_count_unresolved_kernel, dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, nports, cnt);
-    u64 nun = 0;
-    KC_TRY(read_u64(ctx, cnt, &nun));
-    u64 *work_a = nullptr, *work_b = nullptr;
-    KC_TRY(kc_alloc(ctx, &work_a, nun + 1));
-    KC_TRY(kc_alloc(ctx, &work_b, nun + 1));
-    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
-                       nports, work_a, cnt);
+                       nports, work_a, work_cap, work_cursor);
     u64 nwork = 0, rounds = 1;
-    KC_TRY(read_u64(ctx, cnt, &nwork));
+    KC_TRY(read_u64(ctx, work_cursor, &nwork));
+    if (nwork > work_cap) {   // exact-size retry (accept is idempotent: matched ports are skipped)
+        kc_release(ctx, work_a); kc_release(ctx, work_b);
+        work_cap = nwork;
+        KC_TRY(kc_alloc(ctx, &work_a, work_cap));
+        KC_TRY(kc_alloc(ctx, &work_b, work_cap));
+        KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
+        hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
+                           nports, work_a, work_cap, work_cursor);
+        KC_TRY(read_u64(ctx, work_cursor, &nwork));
+    }
     while (nwork) {
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
         hipLaunchKernelGGL((kc_choose_kernel<W, false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)work_a, nwork, 0);
-        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+                           (const u64 *)work_a, nwork, 0, heads, heads_cap, heads_cursor);
+        KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_accept_kernel<false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
-                           nwork, work_b, cnt);
-        KC_TRY(read_u64(ctx, cnt, &nwork));
+                           nwork, work_b, work_cap, work_cursor);
+        KC_TRY(read_u64(ctx, work_cursor, &nwork));   // shrinks every round, so work_cap still bounds it
         std::swap(work_a, work_b);
     }
     KC_HIP(ctx, hipGetLastError());
@@ -354,19 +377,19 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rounds_out) *rounds_out = rounds;
 
     // chain heads
-    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-    hipLaunchKernelGGL((kc_heads_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
-                       (u64 *)nullptr, cnt);
     u64 nheads = 0;
-    KC_TRY(read_u64(ctx, cnt, &nheads));
-    u64 *heads = nullptr;
-    KC_TRY(kc_alloc(ctx, &heads, nheads + 1));
-    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-    hipLaunchKernelGGL((kc_heads_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
-                       cnt);
-    u8 *visited = nullptr;
-    KC_TRY(kc_alloc(ctx, &visited, cap));
-    KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
+    KC_TRY(read_u64(ctx, heads_cursor, &nheads));
+    if (nheads > heads_cap) {   // overflow: exact count + fill
+        kc_release(ctx, heads);
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        hipLaunchKernelGGL((kc_heads_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                           (u64 *)nullptr, cnt);
+        KC_TRY(read_u64(ctx, cnt, &nheads));
+        KC_TRY(kc_alloc(ctx, &heads, nheads + 1));
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        hipLaunchKernelGGL((kc_heads_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
+                           cnt);
+    }
     // chain records: at most nheads chains from heads (+ cycles appended later; reallocated if needed)
     u64 max_chains = nheads + 1;
     u64 *chain_head = nullptr, *chain_len = nullptr, *chain_key = nullptr;
@@ -375,14 +398,25 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_TRY(kc_alloc(ctx, &chain_key, max_chains * W));
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     if (nheads)
-        hipLaunchKernelGGL((kc_walk_measure_kernel<W>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
-                           (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt);
-    // cycles
-    hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
-                       (u64 *)nullptr, cnt + 1);
-    u64 hc[2] = {0, 0};
-    KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
+        hipLaunchKernelGGL((kc_walk_measure_kernel<W, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                           (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt);
+    u64 hc[4] = {0, 0, 0, 0};
+    KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u8 *visited = nullptr;
+    if (hc[3] != N) {
+        // some k-mers are on cycles (every port matched, no head reaches them): mark what the chains cover, list the rest
+        KC_TRY(kc_alloc(ctx, &visited, cap));
+        KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        if (nheads)
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
+                               compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt);
+        hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
+                           (u64 *)nullptr, cnt + 1);
+        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     u64 nchains = hc[0], nunvis = hc[1];
     if (nunvis) {
         u64 *ulist = nullptr;
