@@ -54,11 +54,15 @@ __device__ __forceinline__ void kc_push_head(u64 pid, int complements, u64 *head
 // One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
 // yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
 // The 4 candidate neighbours of a port share k-1 bases with x, hence all m-mers but one: their minimizer (= their table
-// region) is min(shared part, one new m-mer), computed once per port.
-template <int W, bool FIRST>
-__global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements,
+// region) is min(shared part, one new m-mer), computed once per port; their reverse complements are one shift away from
+// RC(x).  KC != 0 fixes k = KC and m = 15 at compile time: every loop below then has a constant trip count and is fully
+// unrolled -- the kernel is otherwise bound by scalar loop-control / exec-mask instructions, not by memory.
+template <int W, bool FIRST, int KC>
+__global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
                                                         const u64 *__restrict__ work, u64 nwork, int xcd_aware, u64 *heads,
                                                         u64 heads_cap, u64 *heads_cursor) {
+    const int k = KC ? KC : k_rt;
+    const int m = KC ? 15 : set.m;
     u64 t = (FIRST ? kc_xcd_block_id(xcd_aware) : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
     u64 pid = FIRST ? t : work[t];
@@ -66,22 +70,44 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
     int port = (int)(pid & 1);
     if (FIRST) { if (!set_slot_full(set, slot)) return; }
     Key<W> x = set_key_at(set, slot);
-    if (complements && port == 1) {
-        Key<W> xr = key_rc(x, k);
-        if (key_eq(x, xr)) { link[pid] = LK_DEAD; kc_push_head(pid, complements, heads, heads_cap, heads_cursor); return; }  // palindromes link on port L only
+    Key<W> xr = key_rc(x, k);
+    if (complements && port == 1 && key_eq(x, xr)) {   // palindromes link on port L only
+        link[pid] = LK_DEAD;
+        kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
+        return;
     }
-    const int m = set.m;
     u32 shared = ~0u;
-    if (m) shared = port ? key_min_mmh(x, k, m, 1, k - m) : key_min_mmh(x, k, m, 0, k - m - 1);
-    u64 hx = kc_port_term(key_hash(x), port);
-    bool have = false;
-    Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0; u32 bbase = 0;
+    if (m) {
+        // min over the m-mers the candidates share with x: positions 1..k-m (append side) or 0..k-m-1 (prepend side)
+        const int i0 = port ? 1 : 0;
+        const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+        const int top = 2 * (m - 1);
+        u32 f = 0, r = 0;
+#pragma unroll
+        for (int j = 0; j < m - 1; ++j) {
+            u32 b = key_at(x, k, i0 + j);
+            f = (f << 2) | b;
+            r = (r >> 2) | ((3u - b) << top);
+        }
+#pragma unroll
+        for (int i = 0; i < k - m; ++i) {
+            u32 b = key_at(x, k, i0 + i + m - 1);
+            f = ((f << 2) | b) & maskm;
+            r = (r >> 2) | ((3u - b) << top);
+            u32 h = kc_mmer_hash(f, r);
+            shared = h < shared ? h : shared;
+        }
+    }
+    const u64 hxk = key_hash(x);
+    int nfound = 0;
+    Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0, bhy = 0; u32 bbase = 0;
+#pragma unroll
     for (u32 c = 0; c < 4; ++c) {
         Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
         Key<W> y = nf;
         int q;
         if (complements) {
-            Key<W> r = key_rc(nf, k);
+            Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
             bool pal = key_eq(nf, r);
             bool fwd = !key_lt(r, nf);  // canonical is nf itself
             if (!fwd) y = r;
@@ -104,14 +130,14 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
             u64 wt = link[(tslot << 1) | (u64)q];
             if (LK_STATE(wt) == LK_MATCHED) continue;
         }
-        u64 pr = kc_mix64(hx + kc_port_term(hy, q));
-        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) {
-            have = true; by = y; bq = q; bpr = pr; bslot = tslot;
-            bbase = port ? c : 3 - c;
-        }
+        // priorities are only needed to choose between two existing candidates
+        if (nfound == 0) { by = y; bq = q; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; nfound = 1; continue; }
+        if (nfound == 1) { bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(bhy, bq)); nfound = 2; }
+        u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(hy, q));
+        if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
     }
-    link[pid] = have ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
-    if (!have) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
+    link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
+    if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
 }
 
 template <bool FIRST>
@@ -344,8 +370,13 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 *heads_cursor = cnt + 2, *work_cursor = cnt;
     // round 1 over all ports (the dominant kernel of this phase: 4 table probes per port)
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    hipLaunchKernelGGL((kc_choose_kernel<W, true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                       (const u64 *)nullptr, nports, xcd_aware, heads, heads_cap, heads_cursor);
+    const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
+    if (k31)
+        hipLaunchKernelGGL((kc_choose_kernel<W, true, (W == 1 ? 31 : 0)>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)nullptr, nports, xcd_aware, heads, heads_cap, heads_cursor);
+    else
+        hipLaunchKernelGGL((kc_choose_kernel<W, true, 0>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)nullptr, nports, xcd_aware, heads, heads_cap, heads_cursor);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
                        nports, work_a, work_cap, work_cursor);
@@ -364,7 +395,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     while (nwork) {
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
-        hipLaunchKernelGGL((kc_choose_kernel<W, false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+        hipLaunchKernelGGL((kc_choose_kernel<W, false, 0>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
                            (const u64 *)work_a, nwork, 0, heads, heads_cap, heads_cursor);
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_accept_kernel<false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
