@@ -51,6 +51,164 @@ __device__ __forceinline__ void kc_push_head(u64 pid, int complements, u64 *head
     if (pos < heads_cap) heads[pos] = pid;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Ordered compaction of the occupied slots (tag != 0) into `occ`: per 2048-slot tile a count, an exclusive scan of the
+// tile counts, then every wave ranks its 64 slots with a ballot + popcount prefix and scatters.  Keeps slot order, so
+// a sweep over `occ` still walks the table region by region.
+#define KC_TILE 2048
+__global__ void __launch_bounds__(256) kc_occ_count_kernel(const u8 *__restrict__ tags, u64 cap, u64 *tile_count) {
+    __shared__ u32 wsum[4];
+    u64 base = (u64)blockIdx.x * KC_TILE;
+    u32 c = 0;
+    for (int r = 0; r < KC_TILE / 256 / 8; ++r) {   // 8 tags per thread per round
+        u64 off = base + ((u64)r * 256 + threadIdx.x) * 8;
+        if (off < cap) {
+            u64 w = *reinterpret_cast<const u64 *>(tags + off);
+            c += (u32)__popcll(w & 0x8080808080808080ULL);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = (u64)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void __launch_bounds__(256) kc_occ_fill_kernel(const u8 *__restrict__ tags, u64 cap, const u64 *__restrict__ tile_off, u64 *occ) {
+    __shared__ u32 wcount[4][KC_TILE / 256];
+    u64 base = (u64)blockIdx.x * KC_TILE;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // pass 1: per wave and round, number of occupied slots among its 64
+    u64 masks[KC_TILE / 256];
+#pragma unroll
+    for (int r = 0; r < KC_TILE / 256; ++r) {
+        u64 slot = base + (u64)r * 256 + threadIdx.x;
+        bool occd = slot < cap && tags[slot] != 0;
+        u64 m = __ballot(occd);
+        masks[r] = m;
+        if (lane == 0) wcount[wave][r] = (u32)__popcll(m);
+    }
+    __syncthreads();
+    u64 out = tile_off[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < KC_TILE / 256; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            u32 cnt = wcount[w][r];
+            if (w == wave) {
+                u64 m = masks[r];
+                if ((m >> lane) & 1) occ[out + (u64)__popcll(m & (((u64)1 << lane) - 1))] = base + (u64)r * 256 + threadIdx.x;
+            }
+            out += cnt;
+        }
+    }
+}
+
+// Round 1 over the compacted k-mers: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
+// over the m-mer hashes whose prefix/suffix minima give both ports' shared minimizer part).
+template <int W, int KC>
+__global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
+                                                              const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
+                                                              u64 heads_cap, u64 *heads_cursor) {
+    const int k = KC ? KC : k_rt;
+    const int m = KC ? 15 : set.m;
+    u64 t = kc_xcd_block_id(xcd_aware) * blockDim.x + threadIdx.x;
+    if (t >= nocc) return;
+    const u64 slot = occ[t];
+    const Key<W> x = set_key_at(set, slot);
+    const Key<W> xr = key_rc(x, k);
+    const bool xpal = complements && key_eq(x, xr);
+    u32 sharedR = ~0u, sharedL = ~0u;   // min over m-mer positions 1..k-m (append side) / 0..k-m-1 (prepend side)
+    if (m) {
+        const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+        const int top = 2 * (m - 1);
+        u32 f = 0, r = 0;
+#pragma unroll
+        for (int j = 0; j < m - 1; ++j) {
+            u32 b = key_at(x, k, j);
+            f = (f << 2) | b;
+            r = (r >> 2) | ((3u - b) << top);
+        }
+        u32 first = ~0u, mid = ~0u, last = ~0u;
+#pragma unroll
+        for (int i = 0; i <= k - m; ++i) {
+            u32 b = key_at(x, k, i + m - 1);
+            f = ((f << 2) | b) & maskm;
+            r = (r >> 2) | ((3u - b) << top);
+            u32 h = kc_mmer_hash(f, r);
+            if (i == 0) first = h;
+            else if (i == k - m) last = h;
+            else mid = h < mid ? h : mid;
+        }
+        if (k - m == 0) { sharedR = ~0u; sharedL = ~0u; }
+        else { sharedR = mid < last ? mid : last; sharedL = mid < first ? mid : first; }
+    }
+    const u64 hxk = key_hash(x);
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        const u64 pid = (slot << 1) | (u64)port;
+        if (port == 1 && xpal) {   // palindromes link on port L only
+            link[pid] = LK_DEAD;
+            kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
+            continue;
+        }
+        const u32 shared = port ? sharedR : sharedL;
+        int nfound = 0;
+        Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0, bhy = 0; u32 bbase = 0;
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c) {
+            Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+            Key<W> y = nf;
+            int q;
+            if (complements) {
+                Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
+                bool pal = key_eq(nf, r);
+                bool fwd = !key_lt(r, nf);
+                if (!fwd) y = r;
+                q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
+            } else {
+                q = port ? 0 : 1;
+            }
+            if (key_eq(y, x)) continue;
+            const u64 hy = key_hash(y);
+            u64 home;
+            if (m) {
+                u32 f = port ? (u32)(nf.w[0] & ((m >= 16) ? ~0u : ((1u << (2 * m)) - 1u))) : (u32)key_prefix(nf, k, m).w[0];
+                u32 h = kc_mmer_hash(f, kc_mmer_rc(f, m));
+                home = set_block_home(set, h < shared ? h : shared, hy);
+            } else home = kc_mulhi64(hy, set.cap);
+            u64 tslot = set_find_from(set, y, hy, home);
+            if (tslot == KC_NONE64) continue;
+            if (nfound == 0) { by = y; bq = q; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; nfound = 1; continue; }
+            if (nfound == 1) { bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(bhy, bq)); nfound = 2; }
+            u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(hy, q));
+            if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
+        }
+        link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
+        if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
+    }
+}
+
+// accept for round 1 over the compacted k-mers (both ports per thread)
+__global__ void __launch_bounds__(256) kc_accept_dense_kernel(u64 *link, const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *work_out,
+                                                              u64 work_cap, u64 *cursor) {
+    u64 t = kc_xcd_block_id(xcd_aware) * blockDim.x + threadIdx.x;
+    if (t >= nocc) return;
+    const u64 slot = occ[t];
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        const u64 pid = (slot << 1) | (u64)port;
+        u64 w = link[pid];
+        if (LK_STATE(w) != LK_CHOICE) continue;
+        u64 wt = __hip_atomic_load(&link[LK_PID(w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 st = LK_STATE(wt);
+        if ((st == LK_CHOICE || st == LK_MATCHED) && LK_PID(wt) == pid) {
+            __hip_atomic_store(&link[pid], (w & ~3ull) | LK_MATCHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            u64 pos = atomicAdd((ull *)cursor, 1ULL);
+            if (pos < work_cap) work_out[pos] = pid;
+        }
+    }
+}
+
 // One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
 // yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
 // The 4 candidate neighbours of a port share k-1 bases with x, hence all m-mers but one: their minimizer (= their table
@@ -368,18 +526,35 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_TRY(kc_alloc(ctx, &work_a, work_cap));
     KC_TRY(kc_alloc(ctx, &work_b, work_cap));
     u64 *heads_cursor = cnt + 2, *work_cursor = cnt;
-    // round 1 over all ports (the dominant kernel of this phase: 4 table probes per port)
-    KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    // compacted list of occupied slots (slot order kept)
+    const u64 ntiles = (cap + KC_TILE - 1) / KC_TILE;
+    u64 *tile_cnt = nullptr, *tile_off = nullptr, *occ = nullptr;
+    KC_TRY(kc_alloc(ctx, &tile_cnt, ntiles + 1));
+    KC_TRY(kc_alloc(ctx, &tile_off, ntiles + 1));
+    KC_TRY(kc_alloc(ctx, &occ, N + 1));
+    hipLaunchKernelGGL(kc_occ_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u8 *)set->tags, cap, tile_cnt);
+    {
+        size_t tb = 0;
+        KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, tile_cnt, tile_off, (int)ntiles, ctx->stream));
+        u8 *tmp = nullptr;
+        KC_TRY(kc_alloc(ctx, &tmp, tb));
+        KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, tile_cnt, tile_off, (int)ntiles, ctx->stream));
+        hipLaunchKernelGGL(kc_occ_fill_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u8 *)set->tags, cap, (const u64 *)tile_off, occ);
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        kc_release(ctx, tmp);
+    }
+    // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
     const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
+    KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (k31)
-        hipLaunchKernelGGL((kc_choose_kernel<W, true, (W == 1 ? 31 : 0)>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)nullptr, nports, xcd_aware, heads, heads_cap, heads_cursor);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor);
     else
-        hipLaunchKernelGGL((kc_choose_kernel<W, true, 0>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)nullptr, nports, xcd_aware, heads, heads_cap, heads_cursor);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
-                       nports, work_a, work_cap, work_cursor);
+    hipLaunchKernelGGL(kc_accept_dense_kernel, dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, xcd_aware, work_a,
+                       work_cap, work_cursor);
     u64 nwork = 0, rounds = 1;
     KC_TRY(read_u64(ctx, work_cursor, &nwork));
     if (nwork > work_cap) {   // exact-size retry (accept is idempotent: matched ports are skipped)
@@ -388,10 +563,11 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(kc_alloc(ctx, &work_a, work_cap));
         KC_TRY(kc_alloc(ctx, &work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_accept_kernel<true>), dim3(kc_grid8(nports, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)nullptr,
-                           nports, work_a, work_cap, work_cursor);
+        hipLaunchKernelGGL(kc_accept_dense_kernel, dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, xcd_aware, work_a,
+                           work_cap, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
+    kc_release(ctx, tile_cnt); kc_release(ctx, tile_off); kc_release(ctx, occ);
     while (nwork) {
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
