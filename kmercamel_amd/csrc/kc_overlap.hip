@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, c
 template <int W>
 __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
                                                              const u64 *__restrict__ pre, const u64 *__restrict__ pslot, int k, int d,
-                                                             int complements, u8 *hitP) {
+                                                             int complements, u8 *hitP, u64 *hit_count) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nP) return;
     u8 hit = 0;
@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
         if (is_representative(key, d, complements)) hit = 1;
     }
     hitP[i] = hit;
+    if (hit) atomicAdd((ull *)hit_count, 1ULL);
 }
 
 template <int W, bool SUFFIX>
@@ -196,9 +197,10 @@ __global__ void __launch_bounds__(256) ov_index_edges_kernel(const u64 *__restri
 
 // Path ends after the level: walk back from every merged path's tail over the level's new edges.
 template <bool WRITE>
-__global__ void __launch_bounds__(256) ov_fix_kernel(const u64 *__restrict__ ne, u64 n, const u64 *__restrict__ edge_from,
+__global__ void __launch_bounds__(256) ov_fix_kernel(const u64 *__restrict__ ne, const u64 *__restrict__ n_ptr, const u64 *__restrict__ edge_from,
                                                      const u64 *__restrict__ pred, u64 *first_snap, u64 *last_snap, u8 *cov, u64 *covered) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n = *n_ptr;   // number of edges the match kernel logged (device-resident: no host round trip in between)
     if (t >= n) return;
     u64 y = ne[t * 5 + 1];
     u64 l0 = last_snap[y];
@@ -250,6 +252,7 @@ __global__ void __launch_bounds__(256) ov_clear_cov_kernel(const u64 *__restrict
     if (t < n) cov[ne[t * 5 + 1]] = 0;
 }
 
+
 template <bool SUFFIX>
 __global__ void __launch_bounds__(256) ov_still_active_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ edge_from,
                                                               const u64 *__restrict__ pred, u8 *keep) {
@@ -260,6 +263,12 @@ __global__ void __launch_bounds__(256) ov_still_active_kernel(const u64 *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+struct OvWork;
+static int read_back(kc_ctx *ctx, u64 *h_pinned, const u64 *d, int n) {
+    KC_HIP(ctx, hipMemcpyAsync(h_pinned, d, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
 struct OvWork {
     kc_ctx *ctx;
     void *tmp = nullptr; size_t tmp_bytes = 0;
@@ -283,6 +292,15 @@ static int select_flagged(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u
     KC_HIP(ctx, hipcub::DeviceSelect::Flagged(w.tmp, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
     KC_HIP(ctx, hipMemcpyAsync(h_count, w.d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+
+static int select_flagged_nosync(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u64 n) {
+    kc_ctx *ctx = w.ctx;
+    size_t bytes = 0;
+    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
+    KC_TRY(w.ensure_tmp(bytes));
+    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(w.tmp, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
     return KC_OK;
 }
 
@@ -365,9 +383,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u64 nS = V, nP = V, repairs = 0;
     std::vector<u64> h_bl;
 
+    u64 *hp = nullptr;   // pinned readback buffer
+    KC_HIP(ctx, hipHostMalloc((void **)&hp, 64, hipHostMallocDefault));
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
         g.d = d;
-        // 1. bucket
+        // 1. bucket: cnt[1] = suffix hits, cnt[3] = prefix hits
         u64 lcap = 64;
         while (lcap < 2 * nP + 16) lcap <<= 1;
         tab.mask = lcap - 1;
@@ -378,17 +398,14 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                            (const u64 *)pre, k, d, pslot);
         hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
                            (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1);
-        u64 h2[2];
-        KC_HIP(ctx, hipMemcpyAsync(h2, cnt, 16, hipMemcpyDeviceToHost, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (h2[1] == 0) continue;   // no key seen from both sides at this overlap length
-        // 2. compact the hits (ordered)
         hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
-                           (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP);
-        u64 nHS = 0, nHP = 0;
-        KC_TRY(select_flagged(w, actS, hitS, hs_ids, nS, &nHS));
-        KC_TRY(select_flagged(w, actP, hitP, hp_ids, nP, &nHP));
-        if (nHS == 0 || nHP == 0) continue;
+                           (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3);
+        KC_TRY(read_back(ctx, hp, cnt, 4));
+        const u64 nHS = hp[1], nHP = hp[3];
+        if (nHS == 0 || nHP == 0) continue;   // no key seen from both sides at this overlap length
+        // 2. compact the hits (ordered); the counts are already known
+        KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
+        KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, nP));
         hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
                            (const u64 *)suf, k, d, hs_keys);
         hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
@@ -397,6 +414,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
         KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3));
         // 4./5. match, verify, repair
+        u64 nNew = 0;
+        const u64 max_new = (complements ? 2 : 1) * nHS;   // every event logs at most 1 (+1 mirrored) edge
         while (true) {
             KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
             if (!lower_bound) {   // forget the path-end entries other levels / replays wrote (tag = none)
@@ -405,18 +424,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             }
             hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
                                (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP);
+            if (!lower_bound)
+                hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
+                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
             KC_HIP(ctx, hipGetLastError());
-            u64 nNew = 0;
-            KC_HIP(ctx, hipMemcpyAsync(&nNew, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            KC_TRY(read_back(ctx, hp, cnt, 3));
+            nNew = hp[0];
+            const u64 covered = hp[2];
             if (nNew == 0 || lower_bound) break;
-            hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew,
-                               (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
-            u64 covered = 0;
-            KC_HIP(ctx, hipMemcpyAsync(&covered, cnt + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             if (covered == nNew) {
-                hipLaunchKernelGGL((ov_fix_kernel<true>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew,
+                hipLaunchKernelGGL((ov_fix_kernel<true>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
                                    (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
                 hipLaunchKernelGGL(ov_clear_cov_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, cov);
                 break;
@@ -427,28 +444,35 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             hipLaunchKernelGGL(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, eidx);
             hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)ne, nNew, (const u64 *)first_snap,
                                (const u64 *)eidx, cov, cnt + 4);
-            u64 res[4];
-            KC_HIP(ctx, hipMemcpyAsync(res, cnt + 4, 32, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (!res[0]) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap verification failed without a cycle");
-            h_bl.push_back(res[2]); h_bl.push_back(res[3]);
+            KC_TRY(read_back(ctx, hp, cnt + 4, 4));
+            if (!hp[0]) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap verification failed without a cycle");
+            h_bl.push_back(hp[2]); h_bl.push_back(hp[3]);
             KC_HIP(ctx, hipMemcpyAsync(bl, h_bl.data(), h_bl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             g.nbl = h_bl.size() / 2;
             hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, edge_from, overlaps, pred,
                                eidx, cov);
         }
         h_bl.clear(); g.nbl = 0;   // the blacklist is per level
+        if (nNew == 0) continue;
         // 6. shrink the active lists
         hipLaunchKernelGGL((ov_still_active_kernel<true>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, nS,
                            (const u64 *)edge_from, (const u64 *)pred, hitS);
         hipLaunchKernelGGL((ov_still_active_kernel<false>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP,
                            (const u64 *)edge_from, (const u64 *)pred, hitP);
-        u64 nS2 = 0, nP2 = 0;
-        KC_TRY(select_flagged(w, actS, hitS, actS2, nS, &nS2));
-        KC_TRY(select_flagged(w, actP, hitP, actP2, nP, &nP2));
+        if (lower_bound) {   // an edge may have been logged twice: take the exact counts
+            u64 nS2 = 0, nP2 = 0;
+            KC_TRY(select_flagged(w, actS, hitS, actS2, nS, &nS2));
+            KC_TRY(select_flagged(w, actP, hitP, actP2, nP, &nP2));
+            nS = nS2; nP = nP2;
+        } else {             // every new edge removes exactly one suffix vertex and one prefix vertex
+            KC_TRY(select_flagged_nosync(w, actS, hitS, actS2, nS));
+            KC_TRY(select_flagged_nosync(w, actP, hitP, actP2, nP));
+            nS -= nNew; nP -= nNew;
+        }
         std::swap(actS, actS2); std::swap(actP, actP2);
-        nS = nS2; nP = nP2;
     }
+    (void)hipHostFree(hp);
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
     void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt, bl, w.d_num,
