@@ -172,7 +172,7 @@ template <int W> __device__ __forceinline__ int cmp_rows(const u64 *a, u64 i, co
 // one thread per sorted suffix hit; the first hit of a key run replays the whole bucket (pair)
 template <int W>
 __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__restrict__ hsk, const u64 *__restrict__ hsv, u64 nHS,
-                                                      const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP) {
+                                                      const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP, u64 *scrS, u64 *scrP) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHS) return;
     Key<W> key = load_key<W>(hsk, t);
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
     if (b1 == b0) return;
     int mode = KC_MODE_UNI;
     if (g.complements) mode = (g.d == 0 || key_eq(key_rc(key, g.d), key)) ? KC_MODE_PAL : KC_MODE_PAIR;
-    kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, (u32)t);
+    kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, (u32)t, scrS + t, scrP + b0);
 }
 
 // remember, per vertex, which log entry created its in-edge (used only by the cycle repair)
@@ -423,7 +423,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
             }
             hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
-                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP);
+                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids);
             if (!lower_bound)
                 hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
                                    (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);

@@ -87,7 +87,9 @@ KC_HD void ov_add_edge(const OvArgs &g, u64 x, u64 y, u64 eu, u64 ec, u64 part, 
 }
 
 // A: suffix-side members (vertex ids ascending) of the bucket, B: prefix-side members (ascending).
-KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, u64 nB, int mode, u32 tag) {
+// sA / sB: scratch of nA / nB words owned by this bucket: after the first part it holds the (shrinking) ordered list of
+// still unmatched event vertices, so later parts do not re-scan the matched ones.
+KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, u64 nB, int mode, u32 tag, u64 *sA, u64 *sB) {
     const u64 S = g.S;
     OvList E1{A, nA, 0, S, 0}, C1{B, nB, 0, S, 0};
     OvList E2{B, 0, 0, S, 1}, C2{A, 0, 0, S, 1};
@@ -95,23 +97,32 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
         E2.n = nB; E2.split = ov_split(B, nB, S);
         C2.n = nA; C2.split = ov_split(A, nA, S);
     }
-    for (u64 part = 0; part < 16; ++part) {
+    // every event vertex is an active (unmatched) suffix at level start; an accepted event consumes u and, in
+    // bidirectional mode, mirror(c), which is an event vertex of this bucket pair as well
+    u64 left = E1.n + E2.n, cur_n = 0;
+    bool use_scratch = false;
+    for (u64 part = 0; part < 16 && left > 0; ++part) {
         u64 lo_v = part * g.batch, hi_v = (part + 1) * g.batch;
         if (lo_v >= g.V) break;
         u64 cl1 = ov_lower_bound(C1, lo_v), top1 = ov_lower_bound(C1, hi_v);
         u64 cl2 = 0, top2 = 0;
         if (mode == KC_MODE_PAIR) { cl2 = ov_lower_bound(C2, lo_v); top2 = ov_lower_bound(C2, hi_v); }
         if (top1 == cl1 && top2 == cl2) continue;
-        u64 i1 = 0, i2 = 0;
-        while (i1 < E1.n || i2 < E2.n) {
+        u64 i1 = 0, i2 = 0, si = 0, out_n = 0;
+        while (use_scratch ? (si < cur_n) : (i1 < E1.n || i2 < E2.n)) {
             u64 u; int from;
-            if (i2 >= E2.n) { u = E1.get(i1++); from = 1; }
+            if (use_scratch) {
+                u64 v = si < nA ? sA[si] : sB[si - nA];
+                ++si;
+                u = v >> 1; from = (v & 1) ? 2 : 1;
+            } else if (i2 >= E2.n) { u = E1.get(i1++); from = 1; }
             else if (i1 >= E1.n) { u = E2.get(i2++); from = 2; }
             else {
                 u64 a = E1.get(i1), b = E2.get(i2);
                 if (a <= b) { u = a; ++i1; from = 1; } else { u = b; ++i2; from = 2; }
             }
             if (g.edge_from[u] != KC_NONE64) continue;                       // suffixForbidden (global.h:87)
+            bool matched = false;
             const OvList &C = (from == 1) ? C1 : C2;
             u64 &top = (from == 1) ? top1 : top2;
             const u64 cl = (from == 1) ? cl1 : cl2;
@@ -127,9 +138,21 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
                     if (banned) continue;
                 }
                 ov_add_edge(g, u, c, u, c, part, tag);
-                if (g.complements) ov_add_edge(g, ov_mirror(c, S), ov_mirror(u, S), u, c, part, tag);   // global.h:110-112
+                left -= 1;
+                if (g.complements) {
+                    ov_add_edge(g, ov_mirror(c, S), ov_mirror(u, S), u, c, part, tag);   // global.h:110-112
+                    if (!g.lower_bound || ov_mirror(c, S) != u) left -= (left > 0);
+                }
+                matched = true;
                 break;
             }
+            if (!matched) {   // keep for the next part (written behind the read position: in-place safe)
+                u64 v = (u << 1) | (u64)(from == 2);
+                if (out_n < nA) sA[out_n] = v; else sB[out_n - nA] = v;
+                ++out_n;
+            }
         }
+        use_scratch = true;
+        cur_n = out_n;
     }
 }

@@ -57,8 +57,10 @@ int sim(const char **strs, u64 n, int k, int complements, int lower_bound, u64 *
         while (true) {
             ne_count = 0;
             if (!lower_bound) { std::fill(first.begin(), first.end(), ~0ull); std::fill(last.begin(), last.end(), ~0ull); }
-            for (size_t t = 0; t < todo.size(); ++t)
-                kc_match_bucket(g, todo[t].A->data(), todo[t].A->size(), todo[t].Bp->data(), todo[t].Bp->size(), todo[t].mode, (u32)t);
+            for (size_t t = 0; t < todo.size(); ++t) {
+                std::vector<u64> sA(todo[t].A->size() + 1), sB(todo[t].Bp->size() + 1);
+                kc_match_bucket(g, todo[t].A->data(), todo[t].A->size(), todo[t].Bp->data(), todo[t].Bp->size(), todo[t].mode, (u32)t, sA.data(), sB.data());
+            }
             u64 nNew = ne_count;
             if (nNew == 0 || lower_bound) break;
             u64 covered = 0;
