@@ -21,9 +21,15 @@
 #define LK_STATE(w) ((w) & 3ull)
 #define LK_PORT(w) (((w) >> 2) & 1ull)
 #define LK_BASE(w) (((w) >> 3) & 3ull)
-#define LK_SLOT(w) ((w) >> 5)
+#define LK_REJ 32ull                  /* bit 5: the choice is not (yet) known to be reciprocated */
+#define LK_SLOT(w) ((w) >> 6)
 #define LK_PID(w) ((LK_SLOT(w) << 1) | LK_PORT(w))
-#define LK_MAKE(state, port, base, slot) ((u64)(state) | ((u64)(port) << 2) | ((u64)(base) << 3) | ((u64)(slot) << 5))
+#define LK_MAKE(state, port, base, slot) ((u64)(state) | ((u64)(port) << 2) | ((u64)(base) << 3) | ((u64)(slot) << 6))
+// Round 1 needs no accept pass: the edge relation is symmetric, so a port's choice can only be unreciprocated if its
+// target had at least two candidates; such "branch" ports (rare) are listed by the choose kernel and send explicit
+// rejections (LK_REJ) to the candidates they did not choose.  A round-1 choice without LK_REJ is therefore mutual.
+// Later rounds write their tentative choices WITH LK_REJ and confirm them to LK_MATCHED in kc_accept_kernel.
+#define LK_IS_MATCHED(w) (LK_STATE(w) == LK_MATCHED || (LK_STATE(w) == LK_CHOICE && !((w) & LK_REJ)))
 
 // "edge (x,px)-(y1,q1) is preferred over edge (x,px)-(y2,q2)": higher priority first, ties by the ordered endpoint tuple.
 template <int W>
@@ -107,7 +113,8 @@ __global__ void __launch_bounds__(256) kc_occ_fill_kernel(const u8 *__restrict__
 template <int W, int KC>
 __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
                                                               const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
-                                                              u64 heads_cap, u64 *heads_cursor) {
+                                                              u64 heads_cap, u64 *heads_cursor, u64 *branch, u64 branch_cap,
+                                                              u64 *branch_cursor) {
     const int k = KC ? KC : k_rt;
     const int m = KC ? 15 : set.m;
     u64 t = kc_xcd_block_id(xcd_aware) * blockDim.x + threadIdx.x;
@@ -184,27 +191,46 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
         }
         link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
         if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
+        if (nfound >= 2) {   // branch port: it will have to reject the candidates it did not choose
+            u64 pos = atomicAdd((ull *)branch_cursor, 1ULL);
+            if (pos < branch_cap) branch[pos] = pid;
+        }
     }
 }
 
-// accept for round 1 over the compacted k-mers (both ports per thread)
-__global__ void __launch_bounds__(256) kc_accept_dense_kernel(u64 *link, const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *work_out,
-                                                              u64 work_cap, u64 *cursor) {
-    u64 t = kc_xcd_block_id(xcd_aware) * blockDim.x + threadIdx.x;
-    if (t >= nocc) return;
-    const u64 slot = occ[t];
-#pragma unroll
-    for (int port = 0; port < 2; ++port) {
-        const u64 pid = (slot << 1) | (u64)port;
-        u64 w = link[pid];
-        if (LK_STATE(w) != LK_CHOICE) continue;
-        u64 wt = __hip_atomic_load(&link[LK_PID(w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u64 st = LK_STATE(wt);
-        if ((st == LK_CHOICE || st == LK_MATCHED) && LK_PID(wt) == pid) {
-            __hip_atomic_store(&link[pid], (w & ~3ull) | LK_MATCHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
+// Branch ports re-enumerate their candidates and reject every existing one they did not choose: the rejected port's
+// round-1 choice (which can only have been this port) is not reciprocated, so it joins the work list of round 2.
+template <int W>
+__global__ void __launch_bounds__(256) kc_reject_kernel(SetView<W> set, u64 *link, int k, int complements, const u64 *__restrict__ branch,
+                                                        u64 nbranch, u64 *work_out, u64 work_cap, u64 *cursor) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbranch) return;
+    const u64 pid = branch[t];
+    const u64 slot = pid >> 1;
+    const int port = (int)(pid & 1);
+    const Key<W> x = set_key_at(set, slot);
+    const u64 chosen = LK_PID(link[pid]);
+    for (u32 c = 0; c < 4; ++c) {
+        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+        Key<W> y = nf;
+        int q;
+        if (complements) {
+            Key<W> r = key_rc(nf, k);
+            bool pal = key_eq(nf, r);
+            bool fwd = !key_lt(r, nf);
+            if (!fwd) y = r;
+            q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
+        } else q = port ? 0 : 1;
+        if (key_eq(y, x)) continue;
+        u64 tslot = set_find(set, y);
+        if (tslot == KC_NONE64) continue;
+        u64 cpid = (tslot << 1) | (u64)q;
+        if (cpid == chosen) continue;
+        u64 wc = link[cpid];   // round-1 words are stable here apart from their LK_REJ bit
+        if (LK_STATE(wc) == LK_CHOICE && LK_PID(wc) == pid) {   // it chose this port, this port chose another: void, round 2
+            atomicOr((ull *)&link[cpid], (ull)LK_REJ);           // (only its target can reject a port, so this happens once)
             u64 pos = atomicAdd((ull *)cursor, 1ULL);
-            if (pos < work_cap) work_out[pos] = pid;
+            if (pos < work_cap) work_out[pos] = cpid;
         }
     }
 }
@@ -286,7 +312,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         if (tslot == KC_NONE64) continue;
         if (!FIRST) {
             u64 wt = link[(tslot << 1) | (u64)q];
-            if (LK_STATE(wt) == LK_MATCHED) continue;
+            if (LK_IS_MATCHED(wt)) continue;
         }
         // priorities are only needed to choose between two existing candidates
         if (nfound == 0) { by = y; bq = q; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; nfound = 1; continue; }
@@ -294,37 +320,45 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(hy, q));
         if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
     }
-    link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
+    // FIRST is no longer launched (round 1 = kc_choose_dense_kernel); later rounds mark their choice as tentative
+    link[pid] = nfound ? (LK_MAKE(LK_CHOICE, bq, bbase, bslot) | (FIRST ? 0 : LK_REJ)) : LK_DEAD;
     if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
 }
 
-template <bool FIRST>
+// Fallback for heavily branching graphs (the branch list overflowed): check every round-1 choice against its target
+// directly. FILL = false counts the unreciprocated ports, FILL = true marks them LK_REJ and lists them.
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, const u64 *__restrict__ occ, u64 nocc, u64 *work_out, u64 *cursor) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nocc) return;
+    const u64 slot = occ[t];
+    for (int port = 0; port < 2; ++port) {
+        const u64 pid = (slot << 1) | (u64)port;
+        u64 w = link[pid];
+        if (LK_STATE(w) != LK_CHOICE) continue;
+        u64 wt = link[LK_PID(w)];   // only LK_REJ bits change concurrently
+        if (LK_STATE(wt) == LK_CHOICE && LK_PID(wt) == pid) continue;
+        u64 pos = atomicAdd((ull *)cursor, 1ULL);
+        if (FILL) { atomicOr((ull *)&link[pid], (ull)LK_REJ); work_out[pos] = pid; }
+    }
+}
+
+// Later rounds: a tentative choice (CHOICE|REJ) is confirmed when its target's tentative choice points back.
 __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__restrict__ work, u64 nwork, u64 *work_out,
                                                         u64 work_cap, u64 *cursor) {
-    u64 t = (FIRST ? kc_xcd_block_id() : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
-    u64 pid = FIRST ? t : work[t];
+    u64 pid = work[t];
     u64 w = link[pid];
-    if (LK_STATE(w) != LK_CHOICE) return;
+    if (LK_STATE(w) != LK_CHOICE || !(w & LK_REJ)) return;
     u64 wt = __hip_atomic_load(&link[LK_PID(w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u64 st = LK_STATE(wt);
-    if ((st == LK_CHOICE || st == LK_MATCHED) && LK_PID(wt) == pid) {
-        __hip_atomic_store(&link[pid], (w & ~3ull) | LK_MATCHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool back = LK_PID(wt) == pid && ((LK_STATE(wt) == LK_CHOICE && (wt & LK_REJ)) || LK_STATE(wt) == LK_MATCHED);
+    if (back) {
+        __hip_atomic_store(&link[pid], (w & ~(3ull | LK_REJ)) | LK_MATCHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         u64 pos = atomicAdd((ull *)cursor, 1ULL);
         if (pos < work_cap) work_out[pos] = pid;
     }
-}
-
-// count unresolved ports after round 1 (sizes the work lists)
-__global__ void __launch_bounds__(256) kc_count_unresolved_kernel(const u64 *__restrict__ link, u64 nports, u64 *counter) {
-    u64 t = kc_xcd_block_id() * blockDim.x + threadIdx.x;
-    if (t >= nports) return;
-    u64 w = link[t];
-    if (LK_STATE(w) != LK_CHOICE) return;
-    u64 wt = link[LK_PID(w)];
-    u64 st = LK_STATE(wt);
-    if (!((st == LK_CHOICE || st == LK_MATCHED) && LK_PID(wt) == t)) atomicAdd((ull *)counter, 1ULL);
 }
 
 // heads of directed chains: oriented node (slot, o) whose entry port (L for o=0, R for o=1) is not matched.
@@ -337,7 +371,7 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
     int no = complements ? 2 : 1;
     for (int o = 0; o < no; ++o) {
         u64 w = link[(slot << 1) | (u64)(o == 0 ? 0 : 1)];
-        if (LK_STATE(w) == LK_MATCHED) continue;
+        if (LK_IS_MATCHED(w)) continue;
         u64 pos = atomicAdd((ull *)cursor, 1ULL);
         if (FILL) heads[pos] = (slot << 1) | (u64)o;
     }
@@ -359,7 +393,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     while (true) {
         if (MARK) visited[cur] = 1;
         u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
-        if (LK_STATE(w) != LK_MATCHED) break;
+        if (!LK_IS_MATCHED(w)) break;
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
         ++len;
@@ -459,7 +493,7 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
     }
     while (true) {
         u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
-        if (LK_STATE(w) != LK_MATCHED) break;
+        if (!LK_IS_MATCHED(w)) break;
         u64 b = LK_BASE(w);
         kx = key_append(kx, b, k);
         acc = (acc << 2) | b;
@@ -545,26 +579,36 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     }
     // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
     const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
+    u64 *branch = work_b, *branch_cursor = cnt + 4;   // branch ports of round 1 (work_b is free until round 2)
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (k31)
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor);
+                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor);
     else
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor);
+                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    hipLaunchKernelGGL(kc_accept_dense_kernel, dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, xcd_aware, work_a,
-                       work_cap, work_cursor);
-    u64 nwork = 0, rounds = 1;
-    KC_TRY(read_u64(ctx, work_cursor, &nwork));
-    if (nwork > work_cap) {   // exact-size retry (accept is idempotent: matched ports are skipped)
+    u64 nbranch = 0, nwork = 0, rounds = 1;
+    KC_TRY(read_u64(ctx, branch_cursor, &nbranch));
+    if (nbranch && nbranch <= work_cap) {
+        hipLaunchKernelGGL((kc_reject_kernel<W>), dim3(kc_grid(nbranch, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)branch,
+                           nbranch, work_a, work_cap, work_cursor);
+        KC_TRY(read_u64(ctx, work_cursor, &nwork));
+    }
+    if (nbranch > work_cap || nwork > work_cap) {
+        // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
+        // kc_reject_kernel run may already have set are simply found again
+        KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), dim3(kc_grid(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N,
+                           (u64 *)nullptr, work_cursor);
+        KC_TRY(read_u64(ctx, work_cursor, &nwork));
         kc_release(ctx, work_a); kc_release(ctx, work_b);
-        work_cap = nwork;
+        work_cap = nwork + 1;
         KC_TRY(kc_alloc(ctx, &work_a, work_cap));
         KC_TRY(kc_alloc(ctx, &work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(kc_accept_dense_kernel, dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, xcd_aware, work_a,
-                           work_cap, work_cursor);
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), dim3(kc_grid(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, work_a,
+                           work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
     kc_release(ctx, tile_cnt); kc_release(ctx, tile_off); kc_release(ctx, occ);
@@ -574,7 +618,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         hipLaunchKernelGGL((kc_choose_kernel<W, false, 0>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
                            (const u64 *)work_a, nwork, 0, heads, heads_cap, heads_cursor);
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_accept_kernel<false>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
+        hipLaunchKernelGGL(kc_accept_kernel, dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
                            nwork, work_b, work_cap, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));   // shrinks every round, so work_cap still bounds it
         std::swap(work_a, work_b);
