@@ -160,6 +160,11 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
     int run = 0;
     u64 added = 0;
     bool overflow = false;
+    // minimizer: every base contributes ONE new canonical m-mer hash; the last k-m+1 of them live in a per-thread LDS
+    // ring (ring[j * blockDim + tid], conflict-free), the k-mer's minimizer hash is the minimum over the ring
+    extern __shared__ u32 kc_ring[];
+    const int m = set.m, win = k - m + 1;
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     u64 cw = codes[s >> 5], bw = brk[s >> 6];
     for (u64 p = s; p < e1; ++p) {
         if ((p & 31) == 0) cw = codes[p >> 5];
@@ -169,14 +174,23 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
         cur = key_append(cur, b, k);
         rc = key_prepend(rc, 3 - b, k);
         if (run < k) ++run;
+        if (m && run >= m)
+            kc_ring[(u32)(p % (u64)win) * blockDim.x + threadIdx.x] = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
         if (p >= e0 && run >= k) {
             if (case_sensitive) {
                 u64 fp = p - (u64)(k - 1);
                 if ((low[fp >> 6] >> (fp & 63)) & 1) continue;
             }
             const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
+            const u64 kh = key_hash(key);
+            u64 home;
+            if (m) {
+                u32 mmh = ~0u;
+                for (int j = 0; j < win; ++j) { u32 h = kc_ring[j * blockDim.x + threadIdx.x]; mmh = h < mmh ? h : mmh; }
+                home = set_block_home(set, mmh, kh);
+            } else home = kc_mulhi64(kh, set.cap);
             u64 slot;
-            int r = set_insert(set, key, &slot);
+            int r = set_insert_at(set, key, kh, home, &slot);
             if (r > 0) ++added;
             else if (r < 0) overflow = true;
         }
@@ -311,14 +325,17 @@ int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u
     if (len == 0) return KC_OK;
     int ppt = set->W == 1 ? 16 : (set->W == 2 ? 32 : 64);
     u64 nthreads = (len + ppt - 1) / ppt;
-    unsigned g = kc_grid(nthreads, 256);
-    hipEventRecord(ctx->ev[6], ctx->stream);
+    const int win = set->mlen ? set->k - set->mlen + 1 : 1;
+    const unsigned bs = win <= 40 ? 256 : (win <= 80 ? 128 : 64);    // LDS ring: win * bs * 4 bytes (<= 40 KB)
+    const size_t lds = (size_t)win * bs * 4;
+    unsigned g = kc_grid(nthreads, bs);
+    (void)hipEventRecord(ctx->ev[6], ctx->stream);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt); break;
-        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt); break;
-        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt); break;
+        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt); break;
+        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt); break;
+        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt); break;
     }
-    hipEventRecord(ctx->ev[7], ctx->stream);
+    (void)hipEventRecord(ctx->ev[7], ctx->stream);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
 }

@@ -97,9 +97,14 @@ template <int W> KC_HD u64 set_probe_slot(const SetView<W> &s, u64 home, u64 gho
 
 // Insert during the build kernel (concurrent with other inserts). Returns 1 if this call added the key, 0 if it was
 // present, -1 if the table is full. *slot_out receives the slot.
+template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, u64 kh, u64 home, u64 *slot_out);
 template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, const Key<W> &key, u64 *slot_out) {
     const u64 kh = key_hash(key);
-    const u64 home = set_home_kh(s, key, kh), ghome = set_global_home(s, kh);
+    return set_insert_at(s, key, kh, set_home_kh(s, key, kh), slot_out);
+}
+// `home` = set_home_kh(s, key, kh) (callers that know the minimizer hash already pass set_block_home(...))
+template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, u64 kh, u64 home, u64 *slot_out) {
+    const u64 ghome = set_global_home(s, kh);
     const u64 limit = s.m ? s.cap + s.local_probes : s.cap;
     if constexpr (W == 1) {
         unsigned long long *keys = (unsigned long long *)s.keys;
