@@ -21,6 +21,23 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6.29 TB/s
+# HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profile.sh ->
+# tools/summarize_profile.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE x2 on gfx950 as calibrated on
+# the pack kernel). Only valid for the default workload it was collected on.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_final_cfg2_traffic.json")
+
+
+def measured_traffic(kernel_substr, default_workload):
+    if not default_workload or not os.path.exists(TRAFFIC_FILE):
+        return None
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+        for k, v in t.items():
+            if kernel_substr in k:
+                return int(v["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(k, read_len, sample_records, seed):
@@ -146,10 +163,10 @@ def main():
         us_probe = sum(s["us_probe_kernel"] for s in stats) / len(stats)
         us_insert = sum(s["us_insert_kernel"] for s in stats) / len(stats)
         if us_probe >= us_insert:
-            name, us = "kc_choose_kernel<W,FIRST> (neighbour probe)", us_probe
+            name, us, ksub = "kc_choose_dense_kernel<W,K> (neighbour probe, round 1)", us_probe, "kc_choose_dense_kernel"
             alg_bytes = N * (2 * W + 16)          # one successful probe read per side (2W) + the two 8-B port links written
         else:
-            name, us = "kc_insert_kernel<W> (k-mer extract + set insert)", us_insert
+            name, us, ksub = "kc_insert_kernel<W> (k-mer extract + set insert)", us_insert, "kc_insert_kernel"
             alg_bytes = 0.25 * nbytes + N * 2 * W  # packed 2-bit read + one probe read and one key write per distinct k-mer
         achieved = alg_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
         phases = {p: round(sum(s[p] for s in stats) / len(stats) / 1000.0, 3) for p in
@@ -173,7 +190,8 @@ def main():
             "phases_ms": phases,
             "matching_rounds": st["matching_rounds"], "overlap_repairs": st["overlap_repairs"],
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic(ksub, args.records == 100000 and k == 31 and not args.read_len),
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(us, 1),
                          "whole_path_alg_bytes": int(N * (1.5 + 4 * W + 16) + S * 2 * k * (2 * W + 8)),
                          "whole_path_achieved_GBs": round((N * (1.5 + 4 * W + 16) + S * 2 * k * (2 * W + 8)) / (phases["us_total"] * 1e-3) / 1e9, 2)},
