@@ -50,6 +50,11 @@ void kc_set_destroy(kc_set *set); /* wrapper.kh_destroy_set (khash_utils.h:55) *
 int kc_set_add_sequence(kc_set *set, const char *seq, uint64_t len, int case_sensitive);
 /* same, sequence bytes already resident in device memory */
 int kc_set_add_sequence_device(kc_set *set, const void *d_seq, uint64_t len, int case_sensitive);
+/* -z support (ReadKMersFiltered / AddKMersWithFrequencies, parser.h:51-85,122-141): call kc_set_enable_counting on an empty set,
+ * add sequences as usual (every k-mer occurrence is counted), then kc_set_filter_min_frequency keeps the k-mers seen
+ * at least `min_frequency` (1..255) times and turns counting off again. */
+int kc_set_enable_counting(kc_set *set);
+int kc_set_filter_min_frequency(kc_set *set, int min_frequency);
 /* kh_size (khash.h:543) */
 int kc_set_size(kc_set *set, uint64_t *n);
 /* kMersToVec (khash_utils.h:131-141): all keys, arbitrary order, W words each; `out` holds kc_set_size()*W words */
@@ -94,6 +99,7 @@ void kc_free(void *p);
 #define KC_FLAG_SIMPLITIGS_INPUT 2u  /* -S: records are simplitigs */
 #define KC_FLAG_WANT_MASK 4u         /* -M: also produce the max-one mask */
 #define KC_FLAG_INPUT_ON_DEVICE 8u   /* seq points to device memory */
+#define KC_FLAG_MIN_FREQUENCY(z) (((uint32_t)(z) & 0xffu) << 8) /* -z INT (1..255; 0/1 = no filter; not with -S) */
 /* seq: record sequences separated by one '\n' (any non-ACGT byte separates k-mers); for -S `offsets` (host, n+1) is
  * required.  The result stays on the device until copied out. */
 int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offsets, uint64_t n_records, int k, uint32_t flags,

@@ -33,6 +33,8 @@ SIGNATURES = {
     "kc_set_destroy": (None, [_vp]),
     "kc_set_add_sequence": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int]),
     "kc_set_add_sequence_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_int]),
+    "kc_set_enable_counting": (ctypes.c_int, [_vp]),
+    "kc_set_filter_min_frequency": (ctypes.c_int, [_vp, ctypes.c_int]),
     "kc_set_size": (ctypes.c_int, [_vp, _u64p]),
     "kc_set_export": (ctypes.c_int, [_vp, _u64p]),
     "kc_set_contains": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint64, _u8p]),
@@ -326,6 +328,18 @@ def ReadKMers(ctx, path, k, complements=True, case_sensitive=False):
     return s
 
 
+def ReadKMersFiltered(ctx, path, k, complements=True, min_frequency=1):
+    """parser.h:122-141: k-mers seen at least min_frequency times (-z)."""
+    recs = read_records(path)
+    joined = b"\n".join(r[2] for r in recs)
+    s = KmerSet(ctx, k, complements, capacity_hint=len(joined))
+    ctx.check(ctx.lib.kc_set_enable_counting(s.h))
+    if joined:
+        s.AddKMers(joined)
+    ctx.check(ctx.lib.kc_set_filter_min_frequency(s.h, min_frequency))
+    return s
+
+
 def get_simplitigs(kmer_set):
     """simplitigs.h:191-205 (canonical order; the set is not consumed)."""
     ctx = kmer_set.ctx
@@ -435,12 +449,12 @@ class ComputeResult:
             pass
 
 
-def compute(ctx, seq, k, complements=True, want_mask=False, simplitig_offsets=None, device_ptr=None, length=None):
+def compute(ctx, seq, k, complements=True, want_mask=False, simplitig_offsets=None, device_ptr=None, length=None, min_frequency=1):
     """Fused device-resident greedy branch of kmercamel<>() (main.cpp:122-212).
 
     seq: bytes of the record sequences joined by '\\n' (or, with device_ptr/length, already on the GPU);
     simplitig_offsets: for -S, the n+1 record offsets into seq (records then are NOT separated)."""
-    flags = (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0)
+    flags = (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0) | ((min_frequency & 0xFF) << 8)
     off, nrec = None, 0
     if simplitig_offsets is not None:
         flags |= FLAG_SIMPLITIGS_INPUT
@@ -457,7 +471,7 @@ def compute(ctx, seq, k, complements=True, want_mask=False, simplitig_offsets=No
     return ComputeResult(ctx, h)
 
 
-def compute_file(ctx, path, k, complements=True, want_mask=False, assume_simplitigs=False):
+def compute_file(ctx, path, k, complements=True, want_mask=False, assume_simplitigs=False, min_frequency=1):
     """`kmercamel compute -k K [-u] [-S] [-M f] path` on the sequence lines (no FASTA header)."""
     recs = [r[2] for r in read_records(path)]
     if assume_simplitigs:
@@ -467,4 +481,4 @@ def compute_file(ctx, path, k, complements=True, want_mask=False, assume_simplit
             o += len(r)
         offs.append(o)
         return compute(ctx, b"".join(recs), k, complements, want_mask, simplitig_offsets=offs)
-    return compute(ctx, b"\n".join(recs), k, complements, want_mask)
+    return compute(ctx, b"\n".join(recs), k, complements, want_mask, min_frequency=min_frequency)

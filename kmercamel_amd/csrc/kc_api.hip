@@ -86,6 +86,8 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     const bool from_simplitigs = (flags & KC_FLAG_SIMPLITIGS_INPUT) != 0;
     const bool want_mask = (flags & KC_FLAG_WANT_MASK) != 0;
     const bool on_device = (flags & KC_FLAG_INPUT_ON_DEVICE) != 0;
+    const int min_frequency = (int)((flags >> 8) & 0xff);
+    if (min_frequency > 1 && from_simplitigs) return kc_fail(ctx, KC_E_ARG, "Inputting simplitigs is not compatible with frequency filterring.");
     if (from_simplitigs && !offsets) return kc_fail(ctx, KC_E_ARG, "-S input needs record offsets");
 
     hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1], e2 = ctx->ev[2], e3 = ctx->ev[3];
@@ -110,12 +112,14 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         // phase 0: ReadKMers/AddKMers (parser.h:22-49,106-118)
         u64 occ = len >= (u64)k ? len - k + 1 : 0;
         rc = kc_set_create(ctx, k, complements, occ, &set);
+        if (rc == KC_OK && min_frequency > 1) rc = kc_set_enable_counting(set);
         u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
         if (rc == KC_OK && len >= (u64)k) {
             rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
             if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, 0);
         }
         if (rc == KC_OK) rc = kcs_refresh_size(set);
+        if (rc == KC_OK && min_frequency > 1) rc = kc_set_filter_min_frequency(set, min_frequency);   // ReadKMersFiltered (parser.h:122-141)
         kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low);
         if (rc == KC_OK && set->size_host == 0) rc = kc_fail(ctx, KC_E_NO_KMERS, "input contains no k-mers");
         if (rc == KC_OK) { n_kmers = set->size_host; dom_us += 1000.0 * ev_ms(ctx->ev[6], ctx->ev[7]); }

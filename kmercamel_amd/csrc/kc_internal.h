@@ -45,6 +45,7 @@ struct kc_set {
     u64 *keys = nullptr;  // cap * W words; W==1: EMPTY = ~0
     u32 *state = nullptr; // W>1: 0 empty, 1 busy, 2 full
     u8 *tags = nullptr;   // cap bytes
+    u32 *counts = nullptr; // cap entries, only while counting occurrences for -z
     u64 *counters = nullptr;  // device: [0] size, [1] overflow flag
     u64 size_host = 0;
 };

@@ -149,7 +149,7 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
 template <int W>
 __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
                                                         const u64 *__restrict__ low, u64 len, int k, int complements,
-                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt) {
+                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt, u32 *occ_counts) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 e0 = t * (u64)ppt;
     if (e0 >= len) return;
@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
             } else home = kc_mulhi64(kh, set.cap);
             u64 slot;
             int r = set_insert_at(set, key, kh, home, &slot);
+            if (occ_counts && r >= 0) atomicAdd(&occ_counts[slot], 1u);   // AddKMersWithFrequencies (parser.h:51-85)
             if (r > 0) ++added;
             else if (r < 0) overflow = true;
         }
@@ -199,15 +200,20 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
     if (overflow) atomicExch((ull *)&counters[1], 1ULL);
 }
 
+// re-insert into a new table; with counts: carry the occurrence counters, and keep only k-mers seen >= min_count times
 template <int W>
-__global__ void __launch_bounds__(256) kc_rehash_kernel(SetView<W> from, SetView<W> to, u64 *counters) {
+__global__ void __launch_bounds__(256) kc_rehash_kernel(SetView<W> from, SetView<W> to, u64 *counters, const u32 *from_counts,
+                                                        u32 *to_counts, u32 min_count) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= from.cap) return;
     if (!set_slot_full(from, t)) return;
+    if (from_counts && from_counts[t] < min_count) return;
     Key<W> key = set_key_at(from, t);
     u64 slot;
     int r = set_insert(to, key, &slot);
     if (r < 0) atomicExch((ull *)&counters[1], 1ULL);
+    else if (to_counts) to_counts[slot] = from_counts[t];
+    if (r > 0 && min_count > 0) atomicAdd((ull *)&counters[2], 1ULL);   // survivors of a filter pass
 }
 
 template <int W>
@@ -273,6 +279,7 @@ extern "C" void kc_set_destroy(kc_set *set) {
     kc_release(ctx, set->keys);
     kc_release(ctx, set->state);
     kc_release(ctx, set->tags);
+    kc_release(ctx, set->counts);
     kc_release(ctx, set->counters);
     delete set;
 }
@@ -289,6 +296,34 @@ int kcs_refresh_size(kc_set *set) {
 
 template <int W> static SetView<W> view_of(const kc_set *s) { return kc_view<W>(s); }
 
+// Move every k-mer (min_count == 0) or every k-mer counted >= min_count times into the freshly allocated table.
+static int kcs_rebuild(kc_set *set, u64 ncap, u64 nnblocks, u64 *nkeys, u32 *nstate, u8 *ntags, u32 min_count) {
+    kc_ctx *ctx = set->ctx;
+    kc_set to = *set;
+    to.keys = nkeys; to.state = nstate; to.tags = ntags; to.cap = ncap; to.nblocks = nnblocks;
+    u32 *ncounts = nullptr;
+    if (set->counts && min_count == 0) {   // growing while counting: the counters move with their k-mers
+        KC_TRY(kc_alloc(ctx, &ncounts, ncap));
+        KC_HIP(ctx, hipMemsetAsync(ncounts, 0, ncap * 4, ctx->stream));
+    }
+    if (set->size_host) {
+        unsigned g = kc_grid(set->cap, 256);
+        switch (set->W) {
+            case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), view_of<1>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
+            case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), view_of<2>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
+            default: hipLaunchKernelGGL(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), view_of<4>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
+        }
+        KC_HIP(ctx, hipGetLastError());
+    }
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, set->keys);
+    kc_release(ctx, set->state);
+    kc_release(ctx, set->tags);
+    kc_release(ctx, set->counts);
+    set->keys = nkeys; set->state = nstate; set->tags = ntags; set->counts = ncounts; set->cap = ncap; set->nblocks = nnblocks;
+    return KC_OK;
+}
+
 // Make room for `additional` more k-mer occurrences: grow + rehash when the load could exceed 0.7.
 int kcs_reserve(kc_set *set, u64 additional) {
     kc_ctx *ctx = set->ctx;
@@ -301,23 +336,7 @@ int kcs_reserve(kc_set *set, u64 additional) {
     ncap = nnblocks << set->bshift;
     u64 *nkeys = nullptr; u32 *nstate = nullptr; u8 *ntags = nullptr;
     KC_TRY(set_alloc_table(set, ncap, &nkeys, &nstate, &ntags));
-    kc_set to = *set;
-    to.keys = nkeys; to.state = nstate; to.tags = ntags; to.cap = ncap; to.nblocks = nnblocks;
-    if (set->size_host) {
-        unsigned g = kc_grid(set->cap, 256);
-        switch (set->W) {
-            case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), view_of<1>(&to), set->counters); break;
-            case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), view_of<2>(&to), set->counters); break;
-            default: hipLaunchKernelGGL(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), view_of<4>(&to), set->counters); break;
-        }
-        KC_HIP(ctx, hipGetLastError());
-    }
-    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    kc_release(ctx, set->keys);
-    kc_release(ctx, set->state);
-    kc_release(ctx, set->tags);
-    set->keys = nkeys; set->state = nstate; set->tags = ntags; set->cap = ncap; set->nblocks = nnblocks;
-    return KC_OK;
+    return kcs_rebuild(set, ncap, nnblocks, nkeys, nstate, ntags, 0);
 }
 
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
@@ -331,9 +350,9 @@ int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u
     unsigned g = kc_grid(nthreads, bs);
     (void)hipEventRecord(ctx->ev[6], ctx->stream);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt); break;
-        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt); break;
-        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt); break;
+        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts); break;
+        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt, set->counts); break;
+        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt, set->counts); break;
     }
     (void)hipEventRecord(ctx->ev[7], ctx->stream);
     KC_HIP(ctx, hipGetLastError());
@@ -367,6 +386,43 @@ extern "C" int kc_set_add_sequence(kc_set *set, const char *seq, uint64_t len, i
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d);
     return rc;
+}
+
+extern "C" int kc_set_enable_counting(kc_set *set) {
+    if (!set) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    KC_TRY(kcs_refresh_size(set));
+    if (set->size_host) return kc_fail(ctx, KC_E_ARG, "counting must be enabled on an empty set");
+    if (!set->counts) KC_TRY(kc_alloc(ctx, &set->counts, set->cap));
+    KC_HIP(ctx, hipMemsetAsync(set->counts, 0, set->cap * 4, ctx->stream));
+    return KC_OK;
+}
+
+// kMersToVecFiltered + kMersFromVec (khash_utils.h:143-159): keep count >= min_frequency (counts saturate at 255 in the
+// reference; min_frequency <= 255, so the unsaturated 32-bit counter gives the same decision)
+extern "C" int kc_set_filter_min_frequency(kc_set *set, int min_frequency) {
+    if (!set) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (min_frequency < 1 || min_frequency > 255) return kc_fail(ctx, KC_E_ARG, "Minimum frequency '-z' must be between 1 and 255.");
+    if (!set->counts) return kc_fail(ctx, KC_E_ARG, "kc_set_enable_counting was not called");
+    KC_TRY(kcs_refresh_size(set));
+    u64 ncap = (u64)((double)set->size_host / 0.6) + 1024;
+    u64 nnblocks = (ncap + (((u64)1 << set->bshift) - 1)) >> set->bshift;
+    ncap = nnblocks << set->bshift;
+    u64 *nkeys = nullptr; u32 *nstate = nullptr; u8 *ntags = nullptr;
+    KC_TRY(set_alloc_table(set, ncap, &nkeys, &nstate, &ntags));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 8, ctx->stream));
+    KC_TRY(kcs_rebuild(set, ncap, nnblocks, nkeys, nstate, ntags, (u32)min_frequency));
+    u64 h[3];
+    KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h[0] = h[2];   // size = survivors
+    KC_HIP(ctx, hipMemcpyAsync(set->counters, h, 8, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    set->size_host = h[2];
+    return KC_OK;
 }
 
 extern "C" int kc_set_size(kc_set *set, uint64_t *n) {

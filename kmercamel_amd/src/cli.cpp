@@ -25,6 +25,7 @@ const Opt OPTIONS[] = {
     {"-M", "FILE", "if given, print also ms with mask maximizing ones (only with greedy)", "c"},
     {"-S", "    ", "optimize for the input being pre-computed simplitigs or unitigs (only with greedy)", "cl"},
     {"-u", "    ", "treat k-mer and its reverse complement as distinct", "cml"},
+    {"-z", "INT ", "minimum frequency to represent a k-mer; default 1", "cl"},
     {"-h", "    ", "print help", "cml"},
 };
 
@@ -83,7 +84,8 @@ Records load_records(const std::string &path, bool simplitigs) {
 }
 
 // greedy branch of kmercamel<>() (main.cpp:122-212)
-int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound) {
+int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
+                int min_frequency) {
     if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
     else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");
     Records recs = load_records(path, assume_simplitigs);
@@ -95,7 +97,9 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         else {
             kc_set *set = nullptr;
             kcamd::check(kc_set_create(ctx, k, complements, recs.joined.size(), &set));
+            if (min_frequency > 1) kcamd::check(kc_set_enable_counting(set));
             kcamd::check(kc_set_add_sequence(set, recs.joined.data(), recs.joined.size(), 0));
+            if (min_frequency > 1) kcamd::check(kc_set_filter_min_frequency(set, min_frequency));
             uint64_t n = 0;
             kcamd::check(kc_set_size(set, &n));
             if (!n) {
@@ -125,7 +129,8 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         *of << std::endl;
         return 0;
     }
-    uint32_t flags = (complements ? KC_FLAG_COMPLEMENTS : 0) | (assume_simplitigs ? KC_FLAG_SIMPLITIGS_INPUT : 0) | (maskf ? KC_FLAG_WANT_MASK : 0);
+    uint32_t flags = (complements ? KC_FLAG_COMPLEMENTS : 0) | (assume_simplitigs ? KC_FLAG_SIMPLITIGS_INPUT : 0) | (maskf ? KC_FLAG_WANT_MASK : 0) |
+                     KC_FLAG_MIN_FREQUENCY(min_frequency);
     kc_result *res = nullptr;
     int rc = kc_compute(ctx, recs.joined.data(), recs.joined.size(), assume_simplitigs ? recs.offsets.data() : nullptr, recs.n, k, flags, &res);
     if (rc == KC_E_NO_KMERS) {
@@ -195,8 +200,7 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     if (min_frequency >= 256 || min_frequency < 1) return fail("Minimum frequency '-z' must be between 1 and 255.");
     if (min_frequency != 1 && assume_simplitigs) return fail("Inputting simplitigs is not compatible with frequency filterring.");
     if (algorithm != "greedy") return fail("Algorithm '" + algorithm + "' not supported by the MI355X build (greedy only).");
-    if (min_frequency != 1) return fail("Minimum frequency filtering (-z) is not implemented in the MI355X build yet.");
-    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound);
+    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency);
 }
 
 // Optimize (masks.h:239-261) for max-one / min-one

@@ -142,6 +142,7 @@ template <typename K> struct KhSet {
     u64 n_buckets = 0, size = 0, n_occupied = 0, upper_bound = 0;
     std::vector<uint8_t> st;
     std::vector<K> keys;
+    std::vector<uint8_t> vals;   // only used when the table plays the Q-map (k-mer -> saturating count - 1, khash_utils.h:30,34,38)
     static u64 roundup(u64 x) { --x; x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16; x |= x >> 32; return ++x; }
     // kh_get (khash.h:232-246)
     u64 get(const K &key) const {
@@ -160,11 +161,12 @@ template <typename K> struct KhSet {
         if (new_n < 4) new_n = 4;
         if (size >= (u64)(new_n * 0.77 + 0.5)) return;
         std::vector<uint8_t> nst(new_n, 2);
-        if (n_buckets < new_n) keys.resize(new_n);
+        if (n_buckets < new_n) { keys.resize(new_n); vals.resize(new_n); }
         u64 nmask = new_n - 1;
         for (u64 j = 0; j != n_buckets; ++j) {
             if (st[j] != 0) continue;
             K key = keys[j];
+            uint8_t val = vals[j];
             st[j] = 1;
             while (true) {
                 u64 i = ref_hash(key) & nmask, step = 0;
@@ -172,21 +174,23 @@ template <typename K> struct KhSet {
                 nst[i] = 0;
                 if (i < n_buckets && st[i] == 0) {
                     std::swap(keys[i], key);
+                    std::swap(vals[i], val);
                     st[i] = 1;
                 } else {
                     keys[i] = key;
+                    vals[i] = val;
                     break;
                 }
             }
         }
-        if (n_buckets > new_n) keys.resize(new_n);
+        if (n_buckets > new_n) { keys.resize(new_n); vals.resize(new_n); }
         st.swap(nst);
         n_buckets = new_n;
         n_occupied = size;
         upper_bound = (u64)(n_buckets * 0.77 + 0.5);
     }
-    // kh_put (khash.h:311-352). Returns true if newly inserted.
-    bool put(const K &key) {
+    // kh_put (khash.h:311-352). Returns true if newly inserted. *where receives the bucket.
+    bool put(const K &key, u64 *where = nullptr) {
         if (n_occupied >= upper_bound) {
             if (n_buckets > (size << 1)) resize(n_buckets - 1);
             else resize(n_buckets + 1);
@@ -205,6 +209,7 @@ template <typename K> struct KhSet {
                 else x = i;
             }
         }
+        if (where) *where = x;
         if (st[x] == 2) { keys[x] = key; st[x] = 0; ++size; ++n_occupied; return true; }
         if (st[x] == 1) { keys[x] = key; st[x] = 0; ++size; return true; }
         return false;
@@ -310,6 +315,27 @@ void for_each_kmer(const char *seq, size_t len, int k, bool complements, bool ca
 template <typename K>
 void add_kmers(KhSet<K> &set, const char *seq, size_t len, int k, bool complements, bool case_sensitive) {
     for_each_kmer<K>(seq, len, k, complements, case_sensitive, [&](const K &x, size_t) { set.put(x); });
+}
+
+// AddKMersWithFrequencies (parser.h:51-85): value = min(255, occurrences) - 1
+template <typename K>
+void add_kmers_with_frequencies(KhSet<K> &map, const char *seq, size_t len, int k, bool complements) {
+    for_each_kmer<K>(seq, len, k, complements, false, [&](const K &x, size_t) {
+        u64 it = map.get(x);
+        if (map.n_buckets && it != map.n_buckets) {
+            unsigned count = map.vals[it];
+            map.vals[it] = (uint8_t)std::min(255u, count + 1);
+        } else {
+            u64 w = 0;
+            map.put(x, &w);
+            map.vals[w] = 0;
+        }
+    });
+}
+// kMersToVecFiltered + kMersFromVec (khash_utils.h:143-159, parser.h:122-141): survivors in bucket order into a fresh set
+template <typename K> void filter_into_set(const KhSet<K> &map, unsigned min_frequency, KhSet<K> &set) {
+    for (u64 i = 0; i < map.n_buckets; ++i)
+        if (map.st[i] == 0 && (unsigned)map.vals[i] + 1 >= min_frequency) set.put(map.keys[i]);
 }
 
 typedef std::vector<uint8_t> Simplitig;  // base codes 0..3 (B1: simplitigs.h:11 stores the same as 2 bits/nt MSB first)
@@ -745,7 +771,7 @@ std::vector<Simplitig> build_simplitigs(KhSet<K> &set, int k, bool complements, 
 // Greedy branch of kmercamel<>() (main.cpp:122-212) without the FASTA header lines.
 template <typename K>
 int compute(const std::string &path, int k, bool complements, bool assume_simplitigs, int mode, std::string &out,
-            std::string *mask_out, u64 *stats) {
+            std::string *mask_out, u64 *stats, unsigned min_frequency = 1) {
     std::string buf;
     if (!slurp(path, buf)) return -1;  // parser.h:96 throws invalid_argument("couldn't open file ...")
     double t0 = now_s();
@@ -755,7 +781,13 @@ int compute(const std::string &path, int k, bool complements, bool assume_simpli
     double t1 = t0;
     if (!assume_simplitigs) {
         KhSet<K> set;
-        for (auto &r : recs) add_kmers(set, r.seq.data(), r.seq.size(), k, complements, false);
+        if (min_frequency <= 1) {
+            for (auto &r : recs) add_kmers(set, r.seq.data(), r.seq.size(), k, complements, false);
+        } else {   // ReadKMersFiltered (parser.h:122-141)
+            KhSet<K> freq;
+            for (auto &r : recs) add_kmers_with_frequencies(freq, r.seq.data(), r.seq.size(), k, complements);
+            filter_into_set(freq, min_frequency, set);
+        }
         if (!set.size) return 1;
         kmer_count = set.size;
         t1 = now_s();
@@ -814,6 +846,44 @@ int kco_compute_file(const char *path, int k, int complements, int assume_simpli
     if (mask_out) *mask_out = dup_string(m);
     if (stats) memcpy(stats, st, sizeof st);
     return 0;
+}
+
+// compute with the -z filter (main.cpp:150-153)
+int kco_compute_file_z(const char *path, int k, int complements, int mode, int min_frequency, char **out, char **mask_out, uint64_t *stats) {
+    std::string o, m;
+    uint64_t st[8] = {0};
+    int rc = dispatch(k, [&](auto kt) {
+        using K = decltype(kt);
+        return compute<K>(path, k, complements != 0, false, mode, o, mask_out ? &m : nullptr, st, (unsigned)min_frequency);
+    });
+    if (rc) return rc;
+    if (!m.empty() && m.back() == '\n') m.pop_back();
+    *out = dup_string(o);
+    if (mask_out) *mask_out = dup_string(m);
+    if (stats) memcpy(stats, st, sizeof st);
+    return 0;
+}
+
+// ReadKMersFiltered (parser.h:122-141): sorted surviving k-mers of a file
+int64_t kco_file_kmer_set_z(const char *path, int k, int complements, int min_frequency, uint64_t **out) {
+    std::string buf;
+    if (!slurp(path, buf)) return -1;
+    auto recs = parse_records(buf);
+    return dispatch(k, [&](auto kt) -> int64_t {
+        using K = decltype(kt);
+        KhSet<K> freq, set;
+        for (auto &r : recs) add_kmers_with_frequencies(freq, r.seq.data(), r.seq.size(), k, complements != 0);
+        filter_into_set(freq, (unsigned)min_frequency, set);
+        std::vector<K> v;
+        for (u64 i = 0; i < set.n_buckets; ++i) if (set.st[i] == 0) v.push_back(set.keys[i]);
+        std::sort(v.begin(), v.end());
+        if (out) {
+            u64 *w = (u64 *)malloc(std::max<size_t>(1, v.size()) * 32);
+            for (size_t i = 0; i < v.size(); ++i) KT<K>::to_words(v[i], w + 4 * i);
+            *out = w;
+        }
+        return (int64_t)v.size();
+    });
 }
 
 int64_t kco_kmer_set(const char *seq, uint64_t len, int k, int complements, int case_sensitive, uint64_t **out) {

@@ -73,12 +73,13 @@ struct Stats {
 template <typename kmer_t, typename kh_wrapper_t>
 int run_compute(kh_wrapper_t wrapper, kmer_t kt, std::string path, int k, bool complements, bool assume_simplitigs,
                 std::ostream &of, std::ostream *maskf, Stats &st, std::vector<std::string> *simplitig_dump,
-                overlapPath *path_dump) {
+                overlapPath *path_dump, uint16_t min_frequency = 1) {
     auto *kMers = wrapper.kh_init_set();
     size_t kmer_count = 0;
     double t0 = now_s();
     if (!assume_simplitigs) {
-        ReadKMers(kMers, wrapper, kt, path, k, complements);
+        if (min_frequency == 1) ReadKMers(kMers, wrapper, kt, path, k, complements);
+        else ReadKMersFiltered(kMers, wrapper, kt, path, k, complements, min_frequency);   // main.cpp:150-153
         if (!kh_size(kMers)) return 1;
         kmer_count = kh_size(kMers);
     }
@@ -172,6 +173,41 @@ int kcref_compute_file(const char *path, int k, int complements, int assume_simp
         std::cerr << "kcref: " << e.what() << std::endl;
         return -1;
     }
+}
+
+// compute with -z (ReadKMersFiltered, parser.h:122-141)
+int kcref_compute_file_z(const char *path, int k, int complements, int min_frequency, const char *out_path, const char *mask_path,
+                         uint64_t *stats) {
+    try {
+        std::ofstream of(out_path);
+        std::ofstream mf;
+        std::ostream *maskf = nullptr;
+        if (mask_path && mask_path[0]) { mf.open(mask_path); maskf = &mf; }
+        Stats st;
+        int rc = dispatch_k(k, [&](auto wrapper, auto kt) {
+            return run_compute(wrapper, kt, std::string(path), k, complements != 0, false, of, maskf, st, nullptr, nullptr, (uint16_t)min_frequency);
+        });
+        of << std::endl;
+        if (stats) { stats[0] = st.n_kmers; stats[1] = st.n_simplitigs; stats[2] = st.length; stats[3] = st.sparse; }
+        return rc;
+    } catch (std::exception &e) {
+        std::cerr << "kcref: " << e.what() << std::endl;
+        return -1;
+    }
+}
+
+// Number of k-mers ReadKMersFiltered keeps (tests/parser_unittest.h:64-91)
+int64_t kcref_read_kmers_filtered_count(const char *path, int k, int complements, int min_frequency) {
+    try {
+        return dispatch_k(k, [&](auto wrapper, auto kt) -> int64_t {
+            auto *set = wrapper.kh_init_set();
+            std::string p(path);
+            ReadKMersFiltered(set, wrapper, kt, p, k, complements != 0, (uint16_t)min_frequency);
+            int64_t n = kh_size(set);
+            wrapper.kh_destroy_set(set);
+            return n;
+        });
+    } catch (std::exception &e) { return -1; }
 }
 
 // Sorted canonical k-mer set of one sequence through AddKMers (parser.h:22-49). Returns count, *out = malloc'd

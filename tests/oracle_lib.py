@@ -194,6 +194,29 @@ class Oracle(_Lib):
             return rc, None, None, None
         return 0, self._take(out), (self._take(mask) if want_mask else None), list(st)
 
+    def compute_file_z(self, path, k, complements=True, mode=1, min_frequency=2, want_mask=True):
+        """compute -z: -> (rc, out, mask, stats[8])"""
+        out, mask = ctypes.c_void_p(), ctypes.c_void_p()
+        st = (ctypes.c_uint64 * 8)()
+        f = self.fn("compute_file_z")
+        f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp, _vpp, _u64p]
+        rc = f(path.encode(), k, int(complements), mode, min_frequency, ctypes.byref(out), ctypes.byref(mask) if want_mask else None, st)
+        if rc:
+            return rc, None, None, None
+        return 0, self._take(out), (self._take(mask) if want_mask else None), list(st)
+
+    def file_kmer_set_z(self, path, k, complements=True, min_frequency=2):
+        out = _u64p()
+        f = self.fn("file_kmer_set_z")
+        f.restype = ctypes.c_int64
+        f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_u64p)]
+        n = f(path.encode(), k, int(complements), min_frequency, ctypes.byref(out))
+        if n < 0:
+            return None
+        res = [_from_words(out, i) for i in range(n)]
+        self.free(ctypes.cast(out, ctypes.c_void_p))
+        return res
+
     def file_kmer_set(self, path, k, complements=True, case_sensitive=False):
         out = _u64p()
         f = self.fn("file_kmer_set")
@@ -269,6 +292,34 @@ class Reference(_Lib):
             if os.path.exists(p):
                 os.remove(p)
         return 0, out, mask, list(st)
+
+
+def _ref_z(self, path, k, complements, min_frequency, want_mask=True, tmpdir="/tmp"):
+    st = (ctypes.c_uint64 * 8)()
+    o = os.path.join(tmpdir, "kcref_zout_%d.txt" % os.getpid())
+    m = os.path.join(tmpdir, "kcref_zmask_%d.txt" % os.getpid())
+    f = self.fn("compute_file_z")
+    f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, _u64p]
+    rc = f(path.encode(), k, int(complements), min_frequency, o.encode(), m.encode() if want_mask else b"", st)
+    if rc:
+        return rc, None, None, None
+    out = open(o).read().rstrip("\n")
+    mask = open(m).read().rstrip("\n") if want_mask else None
+    for pth in (o, m):
+        if os.path.exists(pth):
+            os.remove(pth)
+    return 0, out, mask, list(st)
+
+
+def _ref_zcount(self, path, k, complements, min_frequency):
+    f = self.fn("read_kmers_filtered_count")
+    f.restype = ctypes.c_int64
+    f.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return f(path.encode(), k, int(complements), min_frequency)
+
+
+Reference.compute_file_z = _ref_z
+Reference.read_kmers_filtered_count = _ref_zcount
 
 
 def have_reference():

@@ -40,6 +40,7 @@ def test_cli_usage_and_validation_messages():
         (["compute", "-k", "31", "-a", "streaming", "-M", "m.fa", "x.fa"], "Outputting mask maximizing number of ones is possible only with greedy."),
         (["compute", "-k", "31", "-a", "local", "-S", "x.fa"], "Optimization for the input being simplitigs is possible only with greedy."),
         (["compute", "-k", "31", "-z", "0", "x.fa"], "Minimum frequency '-z' must be between 1 and 255."),
+        (["lowerbound", "-k", "31", "-z", "256", "x.fa"], "Minimum frequency '-z' must be between 1 and 255."),
         (["compute", "-k", "31", "-z", "300", "x.fa"], "Minimum frequency '-z' must be between 1 and 255."),
         (["compute", "-k", "31", "-z", "2", "-S", "x.fa"], "Inputting simplitigs is not compatible with frequency filterring."),
         (["compute", "-k", "abc", "x.fa"], "Usage:"),
@@ -99,6 +100,12 @@ def test_cli_compute_raw_fasta_and_maskopt_and_lowerbound(tmp_path, oracle):
     want = oracle.lower_bound([r[2] for r in recs], 31, True)
     p = run("lowerbound", "-k", "31", "-S", os.path.join(GOLDEN, "simplitigs-k31.fa.gz"))
     assert p.returncode == 0 and p.stdout.strip() == str(want)
+    # -z 2 on a file where every record is duplicated once
+    dup = tmp_path / "dup.fa"
+    dup.write_text(">a\nACGTTGCAAGGCTTACCGATAGGCTAGCTAGGATCGA\n>b\nACGTTGCAAGGCTTACCGATAGGCTAGCTAGGATCGA\n>c\nTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTGGGG\n")
+    p = run("compute", "-k", "11", "-z", "2", str(dup))
+    rc, want, _, st = oracle.compute_file_z(str(dup), 11, True, 1, 2, want_mask=False)
+    assert p.returncode == 0 and p.stdout.split("\n")[1] == want
     # no k-mers (main.cpp:155-158)
     fa = tmp_path / "n.fa"
     fa.write_text(">x\nACGT\n")

@@ -336,3 +336,36 @@ def test_maskopt_on_reference_fixtures(ctx, oracle, golden_dir, k):
     for alg in ("max-one", "min-one"):
         got = kc.Optimize(ctx, ms, k, True, alg)
         assert hashlib.md5(got.encode()).hexdigest() == g[alg]
+
+
+# ------------------------------------------------------------------------------------------------ next row 2: -z
+def test_min_frequency_filter(ctx, oracle, golden_dir, tmp_path):
+    tfa = os.path.join(golden_dir, "test.fa")
+    for k, c, z, want in [(3, True, 2, 6), (3, False, 2, 5), (3, True, 3, 2), (4, True, 2, 3), (1, False, 5, 4), (1, False, 6, 2), (1, False, 10, 1)]:
+        s = kc.ReadKMersFiltered(ctx, tfa, k, c, z)   # tests/parser_unittest.h:64-91
+        assert s.size() == want
+        assert sorted(s.keys()) == oracle.file_kmer_set_z(tfa, k, c, z)
+        s.close()
+    reads = gen.stress_reads(3000, 300, 100, seed=5)
+    fa = tmp_path / "cov.fa"
+    fa.write_bytes(b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    for k in (9, 31, 40):
+        for c in (True, False):
+            for z in (2, 3, 7):
+                rc, want, wmask, st = oracle.compute_file_z(str(fa), k, c, 1, z)
+                if rc != 0:
+                    with pytest.raises(kc.KcError):
+                        kc.compute_file(ctx, str(fa), k, c, want_mask=True, min_frequency=z)
+                    continue
+                r = kc.compute_file(ctx, str(fa), k, c, want_mask=True, min_frequency=z)
+                out, mask = r.strings(want_mask=True)
+                assert (out, mask) == (want, wmask) and r.stats["n_kmers"] == st[0]
+                r.close()
+    # growing while counting (many small adds) keeps the counters
+    s = kc.KmerSet(ctx, 21, True)
+    ctx.check(ctx.lib.kc_set_enable_counting(s.h))
+    for r in reads:
+        s.AddKMers(r)
+    ctx.check(ctx.lib.kc_set_filter_min_frequency(s.h, 3))
+    assert sorted(s.keys()) == oracle.file_kmer_set_z(str(fa), 21, True, 3)
+    s.close()

@@ -93,3 +93,23 @@ def test_sparse_branch_end_to_end_matches_reference(oracle, reference, tmp_path)
     rc, want, wmask, wst = reference.compute_file(str(fa), 31, True, False, True, tmpdir=str(tmp_path))
     rc2, out, mask, st = oracle.compute_file(str(fa), 31, True, False, mode=0)
     assert wst[3] == 1 and st[3] == 1 and (out, mask) == (want, wmask)
+
+
+def test_min_frequency_filter_matches_reference(oracle, reference, tmp_path):
+    # next row 2: -z (ReadKMersFiltered, parser.h:122-141); KATs of tests/parser_unittest.h:64-91 + end-to-end bytes
+    tfa = os.path.join(GOLDEN, "test.fa")
+    for k, c, z, want in [(3, True, 2, 6), (3, False, 2, 5), (3, True, 3, 2), (4, True, 2, 3), (1, False, 5, 4), (1, False, 6, 2), (1, False, 10, 1)]:
+        assert reference.read_kmers_filtered_count(tfa, k, c, z) == want
+        assert len(oracle.file_kmer_set_z(tfa, k, c, z)) == want
+    import gen
+    reads = gen.stress_reads(3000, 300, 100, seed=5)
+    fa = tmp_path / "cov.fa"
+    fa.write_bytes(b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    for k in (9, 31, 40):
+        for c in (True, False):
+            for z in (2, 3, 7):
+                rc, want, wmask, wst = reference.compute_file_z(str(fa), k, c, z, True, tmpdir=str(tmp_path))
+                rc2, out, mask, st = oracle.compute_file_z(str(fa), k, c, 0, z)
+                assert rc == rc2
+                if rc == 0:
+                    assert (out, mask, st[:3]) == (want, wmask, wst[:3])
