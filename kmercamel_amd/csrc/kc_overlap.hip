@@ -18,9 +18,12 @@
 // Levels without hits (almost all d > log4 V) cost two streaming kernels.
 #include "kc_internal.h"
 #include "kc_overlap_logic.h"
+#include "kc_overlap_lds.h"
 #include <hipcub/hipcub.hpp>
 
 #define LV_EMPTY (~(u64)0)
+#define KC_LDS_MIN 12      /* buckets with fewer members are replayed by a single thread straight from global memory */
+#define KC_LDS_MAX 1200    /* 39 B of LDS per member: 46 KB */
 
 template <int W> struct LevelTable {
     u64 *slot;     // W==1: the d-mer key; W>1: a representative prefix vertex (its key is re-derived from pre[])
@@ -172,7 +175,8 @@ template <int W> __device__ __forceinline__ int cmp_rows(const u64 *a, u64 i, co
 // one thread per sorted suffix hit; the first hit of a key run replays the whole bucket (pair)
 template <int W>
 __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__restrict__ hsk, const u64 *__restrict__ hsv, u64 nHS,
-                                                      const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP, u64 *scrS, u64 *scrP) {
+                                                      const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP, u64 *scrS, u64 *scrP,
+                                                      u64 *big, u64 big_cap, u64 *big_count) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHS) return;
     Key<W> key = load_key<W>(hsk, t);
@@ -186,7 +190,27 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
     if (b1 == b0) return;
     int mode = KC_MODE_UNI;
     if (g.complements) mode = (g.d == 0 || key_eq(key_rc(key, g.d), key)) ? KC_MODE_PAL : KC_MODE_PAIR;
+    const u64 members = (a1 - t) + (b1 - b0);
+    if (members >= KC_LDS_MIN && members <= KC_LDS_MAX) {   // medium buckets: replayed out of LDS by a wavefront of their own
+        u64 pos = atomicAdd((ull *)big_count, 1ULL);
+        if (pos < big_cap) {
+            u64 *dsc = big + pos * 5;
+            dsc[0] = t; dsc[1] = a1; dsc[2] = b0; dsc[3] = b1; dsc[4] = (u64)mode;
+            return;
+        }
+    }
     kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, (u32)t, scrS + t, scrP + b0);
+}
+
+// one wavefront per medium bucket (descriptors listed by ov_match_kernel); the grid is an upper bound, surplus blocks exit
+__global__ void __launch_bounds__(64) ov_match_lds_kernel(OvArgs g, const u64 *__restrict__ hsv, const u64 *__restrict__ hpv,
+                                                          const u64 *__restrict__ big, u64 big_cap, const u64 *__restrict__ big_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char kc_lds[];
+    u64 nb = *big_count;
+    if (nb > big_cap) nb = big_cap;
+    if ((u64)blockIdx.x >= nb) return;
+    const u64 *dsc = big + (u64)blockIdx.x * 5;
+    kc_match_bucket_lds(g, hsv + dsc[0], (u32)(dsc[1] - dsc[0]), hpv + dsc[2], (u32)(dsc[3] - dsc[2]), (int)dsc[4], kc_lds);
 }
 
 // remember, per vertex, which log entry created its in-edge (used only by the cycle repair)
@@ -359,6 +383,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     const u64 BL_MAX = 4096;
     KC_TRY(kc_alloc(ctx, &bl, BL_MAX * 2));
     KC_TRY(kc_alloc(ctx, &w.d_num, 2));
+    u64 *big = nullptr;
+    const u64 big_cap = 2 * V / KC_LDS_MIN + 16;
+    KC_TRY(kc_alloc(ctx, &big, big_cap * 5));
     u64 tcap = 64;
     while (tcap < 2 * V + 16) tcap <<= 1;
     LevelTable<W> tab;
@@ -393,7 +420,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         tab.mask = lcap - 1;
         KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 8, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(tab.flags, 0, lcap * 4, ctx->stream));
-        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 128, ctx->stream));
         hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                            (const u64 *)pre, k, d, pslot);
         hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
@@ -417,13 +444,19 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         u64 nNew = 0;
         const u64 max_new = (complements ? 2 : 1) * nHS;   // every event logs at most 1 (+1 mirrored) edge
         while (true) {
-            KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(cnt, 0, 128, ctx->stream));
             if (!lower_bound) {   // forget the path-end entries other levels / replays wrote (tag = none)
                 KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
                 KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
             }
             hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
-                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids);
+                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8);
+            {
+                u64 nblk = (nHS + nHP) / KC_LDS_MIN + 1;
+                if (nblk > big_cap) nblk = big_cap;
+                hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
+                                   (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8));
+            }
             if (!lower_bound)
                 hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
                                    (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
@@ -475,6 +508,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     (void)hipHostFree(hp);
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
+    kc_release(ctx, big);
     void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt, bl, w.d_num,
                    tab.slot, tab.flags, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
     for (void *p : rel) kc_release(ctx, p);

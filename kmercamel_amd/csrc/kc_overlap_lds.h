@@ -1,0 +1,207 @@
+// LDS-resident replay of one key bucket (pair) of the greedy overlap matching -- same event order and decisions as
+// kc_match_bucket (kc_overlap_logic.h, restating global.h:63-128), but every piece of mutable state lives in the LDS of
+// the wavefront that owns the bucket.  The global-memory replay pays one L2 round trip per dependent access AND a drain
+// of the previous event's stores (vmcnt counts stores on gfx950): ~4 us per event.  Here a wavefront loads the bucket
+// (vertex ids, used flags, path ends) cooperatively, lane 0 replays the events out of LDS (~64-cycle accesses), and the
+// wavefront writes the accepted edges back in parallel.
+//
+// State per suffix-side member A[i]: usedA[i] (A[i] has an out-edge == mirror(A[i]) has an in-edge), firstA[i] = first
+// vertex of the path ending at A[i].  Per prefix-side member B[j]: usedB[j], lastB[j] = last vertex of the path starting
+// at B[j].  The mirrored lists of PAIR mode share these entries (accessFirstLast's trick, global.h:28-29).  Every stored
+// path end carries the indices under which it is itself a member of this bucket ("who has to be told when my path
+// changes"), so an accepted edge updates at most four entries without any search:
+//   path-first vertex F is stored as {F, iB(F): index of F in B, iA(mF): index of mirror(F) in A}
+//   path-last  vertex L is stored as {L, iA(L): index of L in A, iB(mL): index of mirror(L) in B}
+// Path ends that are not members are never read again by this bucket, so they are not tracked (other buckets never trust
+// them either, see kc_overlap_logic.h); the exact ends are recomputed after the level by ov_fix_kernel.
+#pragma once
+#include "kc_overlap_logic.h"
+
+#if defined(__HIPCC__)
+
+#define KC_LDS_NONE 0xffffffffu
+struct LdsEnd { u32 v, i1, i2; };   // vertex, index in its natural list, index of its mirror in the other list
+
+struct LdsBucket {
+    u64 *A, *B;            // vertex ids (ascending)
+    LdsEnd *firstA, *lastB;
+    u32 *piA, *piB;        // PAL only: index in B of mirror(A[i]) / index in A of mirror(B[j])
+    u32 *evU, *evC;        // accepted events: (from<<31 | index), (candidate index)
+    u32 *scr;              // unmatched events between parts: (from<<31 | index)
+    u8 *usedA, *usedB, *evPart;
+};
+
+__device__ __forceinline__ size_t kc_lds_bytes(u64 nA, u64 nB) {
+    u64 n = nA + nB;
+    return (size_t)(n * 8 + n * sizeof(LdsEnd) + n * 4 + n * 4 * 3 + n * 3 + 64);
+}
+__host__ __device__ __forceinline__ size_t kc_lds_bytes_bound(u64 n) { return (size_t)(n * 8 + n * 12 + n * 4 + n * 12 + n * 3 + 64); }
+
+__device__ __forceinline__ u32 lds_find(const u64 *a, u32 n, u64 v) {   // index of v in the ascending list a, or NONE
+    u32 lo = 0, hi = n;
+    while (lo < hi) { u32 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return (lo < n && a[lo] == v) ? lo : KC_LDS_NONE;
+}
+
+// one wavefront (blockDim = 64); smem = dynamic LDS of at least kc_lds_bytes(nA, nB)
+__device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, const u64 *gB, u32 nB, int mode, unsigned char *smem) {
+    const int lane = threadIdx.x & 63;
+    const u64 S = g.S;
+    const bool bi = g.complements != 0;
+    const u32 n = nA + nB;
+    LdsBucket b;
+    unsigned char *p = smem;
+    b.A = (u64 *)p; p += (size_t)nA * 8;
+    b.B = (u64 *)p; p += (size_t)nB * 8;
+    b.firstA = (LdsEnd *)p; p += (size_t)nA * sizeof(LdsEnd);
+    b.lastB = (LdsEnd *)p; p += (size_t)nB * sizeof(LdsEnd);
+    b.piA = (u32 *)p; p += (size_t)nA * 4;
+    b.piB = (u32 *)p; p += (size_t)nB * 4;
+    b.evU = (u32 *)p; p += (size_t)n * 4;
+    b.evC = (u32 *)p; p += (size_t)n * 4;
+    b.scr = (u32 *)p; p += (size_t)n * 4;
+    b.usedA = (u8 *)p; p += nA;
+    b.usedB = (u8 *)p; p += nB;
+    b.evPart = (u8 *)p;
+
+    // ---- cooperative load
+    for (u32 i = lane; i < nA; i += 64) { b.A[i] = gA[i]; b.usedA[i] = 0; }
+    for (u32 j = lane; j < nB; j += 64) { b.B[j] = gB[j]; b.usedB[j] = 0; }
+    __syncthreads();
+    for (u32 i = lane; i < nA; i += 64) {
+        u64 F = g.lower_bound ? 0 : g.first_snap[b.A[i]];
+        LdsEnd e;
+        e.v = (u32)F;
+        e.i1 = g.lower_bound ? KC_LDS_NONE : lds_find(b.B, nB, F);
+        e.i2 = (bi && !g.lower_bound) ? lds_find(b.A, nA, ov_mirror(F, S)) : KC_LDS_NONE;
+        b.firstA[i] = e;
+        b.piA[i] = (mode == KC_MODE_PAL) ? lds_find(b.B, nB, ov_mirror(b.A[i], S)) : KC_LDS_NONE;
+    }
+    for (u32 j = lane; j < nB; j += 64) {
+        u64 L = g.lower_bound ? 0 : g.last_snap[b.B[j]];
+        LdsEnd e;
+        e.v = (u32)L;
+        e.i1 = g.lower_bound ? KC_LDS_NONE : lds_find(b.A, nA, L);
+        e.i2 = (bi && !g.lower_bound) ? lds_find(b.B, nB, ov_mirror(L, S)) : KC_LDS_NONE;
+        b.lastB[j] = e;
+        b.piB[j] = (mode == KC_MODE_PAL) ? lds_find(b.A, nA, ov_mirror(b.B[j], S)) : KC_LDS_NONE;
+    }
+    __syncthreads();
+
+    __shared__ u32 nev_shared;
+    if (lane == 0) {
+        // ---- sequential replay (reference event order: part, then suffix vertex ascending; candidates descending)
+        OvList E1{b.A, nA, 0, S, 0}, C1{b.B, nB, 0, S, 0};
+        OvList E2{b.B, 0, 0, S, 1}, C2{b.A, 0, 0, S, 1};
+        if (mode == KC_MODE_PAIR) {
+            E2.n = nB; E2.split = ov_split(b.B, nB, S);
+            C2.n = nA; C2.split = ov_split(b.A, nA, S);
+        }
+        // index of the t-th element of a mirrored list inside its base array
+        auto mirrored_index = [](const OvList &l, u64 t) -> u32 { u64 hi = l.n - l.split; return (u32)(t < hi ? l.split + t : t - hi); };
+        u32 nev = 0, cur_n = 0;
+        u64 left = E1.n + E2.n;
+        bool use_scratch = false;
+        for (u64 part = 0; part < 16 && left > 0; ++part) {
+            u64 lo_v = part * g.batch, hi_v = (part + 1) * g.batch;
+            if (lo_v >= g.V) break;
+            u64 cl1 = ov_lower_bound(C1, lo_v), top1 = ov_lower_bound(C1, hi_v);
+            u64 cl2 = 0, top2 = 0;
+            if (mode == KC_MODE_PAIR) { cl2 = ov_lower_bound(C2, lo_v); top2 = ov_lower_bound(C2, hi_v); }
+            if (top1 == cl1 && top2 == cl2) continue;
+            u64 i1 = 0, i2 = 0;
+            u32 si = 0, out_n = 0;
+            while (use_scratch ? (si < cur_n) : (i1 < E1.n || i2 < E2.n)) {
+                u32 eidx; int from;   // event: from 1 = A[eidx], from 2 = mirror(B[eidx])
+                if (use_scratch) { u32 v = b.scr[si++]; eidx = v & 0x7fffffffu; from = (v >> 31) ? 2 : 1; }
+                else if (i2 >= E2.n) { eidx = (u32)i1++; from = 1; }
+                else if (i1 >= E1.n) { eidx = mirrored_index(E2, i2++); from = 2; }
+                else {
+                    u64 a = E1.get(i1), bb = E2.get(i2);
+                    if (a <= bb) { eidx = (u32)i1++; from = 1; } else { eidx = mirrored_index(E2, i2++); from = 2; }
+                }
+                const bool used = (from == 1) ? b.usedA[eidx] : b.usedB[eidx];
+                if (used) continue;                                              // suffixForbidden (global.h:87)
+                const u64 u = (from == 1) ? b.A[eidx] : ov_mirror(b.B[eidx], S);
+                // first vertex of u's path, as a path-first triple
+                LdsEnd F;
+                if (from == 1) F = b.firstA[eidx];
+                else { LdsEnd L = b.lastB[eidx]; F.v = (u32)ov_mirror(L.v, S); F.i1 = L.i2; F.i2 = L.i1; }
+                const OvList &C = (from == 1) ? C1 : C2;
+                u64 &top = (from == 1) ? top1 : top2;
+                const u64 cl = (from == 1) ? cl1 : cl2;
+                auto cand_index = [&](u64 t) -> u32 { return (from == 1) ? (u32)t : mirrored_index(C2, t); };
+                auto cand_used = [&](u32 ci) -> bool { return (from == 1) ? b.usedB[ci] : b.usedA[ci]; };
+                while (top > cl && cand_used(cand_index(top - 1))) --top;        // used candidates never come back
+                bool matched = false;
+                for (u64 t = top; t > cl; --t) {
+                    const u32 ci = cand_index(t - 1);
+                    if (cand_used(ci)) continue;                                 // prefixForbidden (global.h:97)
+                    const u64 c = (from == 1) ? b.B[ci] : ov_mirror(b.A[ci], S);
+                    if (!g.lower_bound) {
+                        if (bi && c == ov_mirror(u, S)) continue;                // complementary (global.h:93)
+                        if ((u64)F.v == c) continue;                             // would close a cycle (global.h:95)
+                        bool banned = false;
+                        for (u64 q = 0; q < g.nbl; ++q) banned = banned || (g.bl[2 * q] == u && g.bl[2 * q + 1] == c);
+                        if (banned) continue;
+                    }
+                    // ---- accept u -> c (+ mirror(c) -> mirror(u))
+                    if (from == 1) { b.usedA[eidx] = 1; b.usedB[ci] = 1; } else { b.usedB[eidx] = 1; b.usedA[ci] = 1; }
+                    if (mode == KC_MODE_PAL) {       // the mirrored edge consumes members of the same lists
+                        u32 ma = b.piB[ci], mb = b.piA[eidx];     // mirror(c) in A, mirror(u) in B
+                        if (ma != KC_LDS_NONE) b.usedA[ma] = 1;
+                        if (mb != KC_LDS_NONE) b.usedB[mb] = 1;
+                    }
+                    if (!g.lower_bound) {
+                        LdsEnd L;                    // last vertex of c's path, as a path-last triple
+                        if (from == 1) L = b.lastB[ci];
+                        else { LdsEnd Fc = b.firstA[ci]; L.v = (u32)ov_mirror(Fc.v, S); L.i1 = Fc.i2; L.i2 = Fc.i1; }
+                        // new path F .. u c .. L (and its mirror): tell the members among the four end vertices
+                        if (L.i1 != KC_LDS_NONE) b.firstA[L.i1] = F;                                       // first_of(L) = F
+                        if (L.i2 != KC_LDS_NONE) { LdsEnd m; m.v = (u32)ov_mirror(F.v, S); m.i1 = F.i2; m.i2 = F.i1; b.lastB[L.i2] = m; }   // last_of(mL) = mF
+                        if (F.i1 != KC_LDS_NONE) b.lastB[F.i1] = L;                                        // last_of(F) = L
+                        if (F.i2 != KC_LDS_NONE) { LdsEnd m; m.v = (u32)ov_mirror(L.v, S); m.i1 = L.i2; m.i2 = L.i1; b.firstA[F.i2] = m; }  // first_of(mF) = mL
+                    }
+                    b.evU[nev] = ((u32)(from == 2) << 31) | eidx;
+                    b.evC[nev] = ci;
+                    b.evPart[nev] = (u8)part;
+                    ++nev;
+                    left -= 1;
+                    if (bi && (!g.lower_bound || ov_mirror(c, S) != u)) left -= (left > 0);
+                    matched = true;
+                    break;
+                }
+                if (!matched) b.scr[out_n++] = ((u32)(from == 2) << 31) | eidx;
+            }
+            use_scratch = true;
+            cur_n = out_n;
+        }
+        nev_shared = nev;
+    }
+    __syncthreads();
+
+    // ---- parallel write-back of the accepted events (edge arrays + new-edge log)
+    const u32 nev = nev_shared;
+    if (nev == 0) return;
+    __shared__ u64 base_shared;
+    if (lane == 0) base_shared = atomicAdd((unsigned long long *)g.ne_count, (unsigned long long)nev * (bi ? 2 : 1));
+    __syncthreads();
+    const u64 base = base_shared;
+    for (u32 e = lane; e < nev; e += 64) {
+        const u32 ev = b.evU[e], eidx = ev & 0x7fffffffu, ci = b.evC[e];
+        const bool from2 = (ev >> 31) != 0;
+        const u64 u = from2 ? ov_mirror(b.B[eidx], S) : b.A[eidx];
+        const u64 c = from2 ? ov_mirror(b.A[ci], S) : b.B[ci];
+        const u64 part = b.evPart[e];
+        g.edge_from[u] = c; g.overlaps[u] = (u8)g.d; g.pred[c] = u;
+        u64 *le = g.ne + (base + (u64)e * (bi ? 2 : 1)) * 5;
+        le[0] = u; le[1] = c; le[2] = u; le[3] = c; le[4] = part;
+        if (bi) {
+            const u64 x2 = ov_mirror(c, S), y2 = ov_mirror(u, S);
+            g.edge_from[x2] = y2; g.overlaps[x2] = (u8)g.d; g.pred[y2] = x2;
+            le[5] = x2; le[6] = y2; le[7] = u; le[8] = c; le[9] = part;
+        }
+    }
+}
+
+#endif  // __HIPCC__

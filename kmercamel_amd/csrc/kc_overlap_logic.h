@@ -72,18 +72,43 @@ KC_HD u64 ov_end_of(const u64 *live, const u64 *snap, u64 v, u32 tag) {
     return ((u32)(w >> 32) == tag) ? (w & 0xffffffffull) : snap[v];
 }
 
-KC_HD void ov_add_edge(const OvArgs &g, u64 x, u64 y, u64 eu, u64 ec, u64 part, u32 tag) {  // global.h:113-122
-    g.edge_from[x] = y;
-    g.overlaps[x] = (u8)g.d;
-    g.pred[y] = x;
-    if (!g.lower_bound) {   // path ends are only needed by the cycle test
-        u64 lastY = ov_end_of(g.last, g.last_snap, y, tag), firstX = ov_end_of(g.first, g.first_snap, x, tag);
-        g.first[lastY] = ((u64)tag << 32) | firstX;
-        g.last[firstX] = ((u64)tag << 32) | lastY;
+// Accept the event u -> c (and, bidirectional, the mirrored edge mirror(c) -> mirror(u)), global.h:108-122.
+// All path-end loads of both edges are independent of each other and of this event's stores (a path never contains
+// its own mirror), so they are issued together: one memory round trip instead of six.
+KC_HD void ov_add_event(const OvArgs &g, u64 u, u64 c, u64 firstU, u64 part, u32 tag) {
+    const u64 S = g.S;
+    const bool two = g.complements != 0;
+    const u64 x2 = two ? ov_mirror(c, S) : 0, y2 = two ? ov_mirror(u, S) : 0;
+    u64 lastC = 0, firstX2 = 0, lastY2 = 0;
+    if (!g.lower_bound) {
+        u64 l1 = g.last[c], s1 = g.last_snap[c];
+        u64 l2 = two ? g.first[x2] : 0, s2 = two ? g.first_snap[x2] : 0;
+        u64 l3 = two ? g.last[y2] : 0, s3 = two ? g.last_snap[y2] : 0;
+        lastC = ((u32)(l1 >> 32) == tag) ? (l1 & 0xffffffffull) : s1;
+        firstX2 = ((u32)(l2 >> 32) == tag) ? (l2 & 0xffffffffull) : s2;
+        lastY2 = ((u32)(l3 >> 32) == tag) ? (l3 & 0xffffffffull) : s3;
     }
-    u64 pos = KC_LOG_APPEND(g.ne_count);
+    u64 pos = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    pos = atomicAdd((unsigned long long *)g.ne_count, two ? 2ULL : 1ULL);
+#else
+    pos = *g.ne_count; *g.ne_count += two ? 2 : 1;
+#endif
+    g.edge_from[u] = c; g.overlaps[u] = (u8)g.d; g.pred[c] = u;
+    if (!g.lower_bound) {
+        g.first[lastC] = ((u64)tag << 32) | firstU;
+        g.last[firstU] = ((u64)tag << 32) | lastC;
+    }
     u64 *e = g.ne + pos * 5;
-    e[0] = x; e[1] = y; e[2] = eu; e[3] = ec; e[4] = part;
+    e[0] = u; e[1] = c; e[2] = u; e[3] = c; e[4] = part;
+    if (two) {
+        g.edge_from[x2] = y2; g.overlaps[x2] = (u8)g.d; g.pred[y2] = x2;
+        if (!g.lower_bound) {
+            g.first[lastY2] = ((u64)tag << 32) | firstX2;
+            g.last[firstX2] = ((u64)tag << 32) | lastY2;
+        }
+        e[5] = x2; e[6] = y2; e[7] = u; e[8] = c; e[9] = part;
+    }
 }
 
 // A: suffix-side members (vertex ids ascending) of the bucket, B: prefix-side members (ascending).
@@ -121,7 +146,11 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
                 u64 a = E1.get(i1), b = E2.get(i2);
                 if (a <= b) { u = a; ++i1; from = 1; } else { u = b; ++i2; from = 2; }
             }
-            if (g.edge_from[u] != KC_NONE64) continue;                       // suffixForbidden (global.h:87)
+            // independent loads of the event, issued together
+            const u64 ef = g.edge_from[u];
+            const u64 fl = g.lower_bound ? 0 : g.first[u], fsn = g.lower_bound ? 0 : g.first_snap[u];
+            if (ef != KC_NONE64) continue;                                   // suffixForbidden (global.h:87)
+            const u64 firstU = ((u32)(fl >> 32) == tag) ? (fl & 0xffffffffull) : fsn;
             bool matched = false;
             const OvList &C = (from == 1) ? C1 : C2;
             u64 &top = (from == 1) ? top1 : top2;
@@ -132,17 +161,14 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
                 if (g.pred[c] != KC_NONE64) continue;                         // prefixForbidden (global.h:97)
                 if (!g.lower_bound) {
                     if (g.complements && c == ov_mirror(u, S)) continue;      // complementary (global.h:93)
-                    if (ov_end_of(g.first, g.first_snap, u, tag) == c) continue;   // would close a cycle (global.h:95)
+                    if (firstU == c) continue;                                // would close a cycle (global.h:95)
                     bool banned = false;
                     for (u64 q = 0; q < g.nbl; ++q) banned = banned || (g.bl[2 * q] == u && g.bl[2 * q + 1] == c);
                     if (banned) continue;
                 }
-                ov_add_edge(g, u, c, u, c, part, tag);
+                ov_add_event(g, u, c, firstU, part, tag);
                 left -= 1;
-                if (g.complements) {
-                    ov_add_edge(g, ov_mirror(c, S), ov_mirror(u, S), u, c, part, tag);   // global.h:110-112
-                    if (!g.lower_bound || ov_mirror(c, S) != u) left -= (left > 0);
-                }
+                if (g.complements && (!g.lower_bound || ov_mirror(c, S) != u)) left -= (left > 0);
                 matched = true;
                 break;
             }
