@@ -92,7 +92,7 @@ def main():
     ap.add_argument("-k", type=int, default=31)
     ap.add_argument("--records", type=int, default=100000)
     ap.add_argument("--read-len", type=int, default=0, help="default k-1+1000 (1030 for k=31)")
-    ap.add_argument("--cpu-sample-records", type=int, default=12000)
+    ap.add_argument("--cpu-sample-records", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify size-independent properties of the output")
     args = ap.parse_args()
