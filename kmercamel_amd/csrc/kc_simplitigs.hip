@@ -22,7 +22,8 @@
 #define LK_PORT(w) (((w) >> 2) & 1ull)
 #define LK_BASE(w) (((w) >> 3) & 3ull)
 #define LK_REJ 32ull                  /* bit 5: the choice is not (yet) known to be reciprocated */
-#define LK_SLOT(w) ((w) >> 6)
+#define LK_SPLIT (1ull << 63)          /* the node of this port is a splitter: a segment start for the parallel chain walks */
+#define LK_SLOT(w) (((w) & ~LK_SPLIT) >> 6)
 #define LK_PID(w) ((LK_SLOT(w) << 1) | LK_PORT(w))
 #define LK_MAKE(state, port, base, slot) ((u64)(state) | ((u64)(port) << 2) | ((u64)(base) << 3) | ((u64)(slot) << 6))
 // Round 1 needs no accept pass: the edge relation is symmetric, so a port's choice can only be unreciprocated if its
@@ -114,7 +115,7 @@ template <int W, int KC>
 __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
                                                               const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
                                                               u64 heads_cap, u64 *heads_cursor, u64 *branch, u64 branch_cap,
-                                                              u64 *branch_cursor) {
+                                                              u64 *branch_cursor, u64 *splits, u64 splits_cap, u64 *splits_cursor) {
     const int k = KC ? KC : k_rt;
     const int m = KC ? 15 : set.m;
     u64 t = kc_xcd_block_id(xcd_aware) * blockDim.x + threadIdx.x;
@@ -149,11 +150,17 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
         else { sharedR = mid < last ? mid : last; sharedL = mid < first ? mid : first; }
     }
     const u64 hxk = key_hash(x);
+    // every ~256th k-mer (by key hash) is a splitter: chains are walked segment-wise between splitters
+    const u64 splitbit = (((hxk >> 24) & 0xffull) == 0) ? LK_SPLIT : 0;
+    if (splitbit) {
+        u64 pos = atomicAdd((ull *)splits_cursor, 1ULL);
+        if (pos < splits_cap) splits[pos] = slot;
+    }
 #pragma unroll
     for (int port = 0; port < 2; ++port) {
         const u64 pid = (slot << 1) | (u64)port;
         if (port == 1 && xpal) {   // palindromes link on port L only
-            link[pid] = LK_DEAD;
+            link[pid] = LK_DEAD | splitbit;
             kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
             continue;
         }
@@ -189,7 +196,7 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
             u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(hy, q));
             if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
         }
-        link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD;
+        link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD) | splitbit;
         if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
         if (nfound >= 2) {   // branch port: it will have to reject the candidates it did not choose
             u64 pos = atomicAdd((ull *)branch_cursor, 1ULL);
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
     Key<W> x = set_key_at(set, slot);
     Key<W> xr = key_rc(x, k);
     if (complements && port == 1 && key_eq(x, xr)) {   // palindromes link on port L only
-        link[pid] = LK_DEAD;
+        link[pid] = LK_DEAD | (link[pid] & LK_SPLIT);
         kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
         return;
     }
@@ -321,7 +328,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
     }
     // FIRST is no longer launched (round 1 = kc_choose_dense_kernel); later rounds mark their choice as tentative
-    link[pid] = nfound ? (LK_MAKE(LK_CHOICE, bq, bbase, bslot) | (FIRST ? 0 : LK_REJ)) : LK_DEAD;
+    link[pid] = (nfound ? (LK_MAKE(LK_CHOICE, bq, bbase, bslot) | (FIRST ? 0 : LK_REJ)) : LK_DEAD) | (link[pid] & LK_SPLIT);
     if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
 }
 
@@ -383,7 +390,8 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 template <int W, bool MARK>
 __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
                                                               const u64 *__restrict__ heads, u64 nheads, u8 *visited,
-                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor) {
+                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit) {
+    // limit: give up (cursor[7] = 1) on a chain longer than this; the caller then switches to the segment-parallel path
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nheads) return;
     u64 h = heads[t];
@@ -396,7 +404,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         if (!LK_IS_MATCHED(w)) break;
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
-        ++len;
+        if (++len > limit) { atomicExch((ull *)(cursor + 7), 1ULL); return; }
     }
     Key<W> hk = set_key_at(set, slot);
     bool winner = true;
@@ -506,6 +514,136 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Segment-parallel chain processing.  Starts = chain heads + oriented splitters whose entry port is matched; every start
+// walks its segment (to the next splitter or the chain tail) in parallel; one thread per head then walks the short list
+// of its segments (length/256 steps) to get the chain's length, tail and segment offsets; segments finally emit their
+// bases in parallel.  A multi-Mbp chain therefore costs ~256 sequential steps instead of millions.
+#define KC_SEG_NONE (~(u64)0)
+__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, const u64 *__restrict__ splits, u64 nsplit,
+                                                              int complements, u64 *starts, u64 *cursor) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsplit) return;
+    const u64 slot = splits[t];
+    const int no = complements ? 2 : 1;
+    for (int o = 0; o < no; ++o) {
+        u64 w = link[(slot << 1) | (u64)o];          // entry port of orientation o is port o
+        if (!LK_IS_MATCHED(w)) continue;              // dead entry port: this oriented node is a head (already listed)
+        u64 pos = atomicAdd((ull *)cursor, 1ULL);
+        starts[pos] = (slot << 1) | (u64)o;
+    }
+}
+__device__ __forceinline__ u64 kc_find_start(const u64 *starts, u64 n, u64 id) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (starts[mid] < id) lo = mid + 1; else hi = mid; }
+    return lo;   // callers only look up ids that are present
+}
+// one thread per start (sorted ascending): nodes until the next splitter (exclusive) or the tail (inclusive)
+__global__ void __launch_bounds__(256) kc_segment_walk_kernel(const u64 *__restrict__ link, const u64 *__restrict__ starts, u64 nstarts,
+                                                              u64 *seg_len, u64 *seg_next, u64 *seg_tail) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nstarts) return;
+    u64 cur = starts[j] >> 1;
+    int co = (int)(starts[j] & 1);
+    u64 len = 1;
+    u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+    while (true) {
+        if (!LK_IS_MATCHED(w)) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (cur << 1) | (u64)co; break; }
+        u64 nxt = LK_SLOT(w);
+        int no = LK_PORT(w) == 0 ? 0 : 1;
+        u64 wn = link[(nxt << 1) | (u64)(no == 0 ? 1 : 0)];
+        if (wn & LK_SPLIT) { seg_next[j] = kc_find_start(starts, nstarts, (nxt << 1) | (u64)no); seg_tail[j] = KC_SEG_NONE; break; }
+        cur = nxt; co = no; w = wn; ++len;
+    }
+    seg_len[j] = len;
+}
+// one thread per start that is a chain head: walk the list of segments
+template <int W>
+__global__ void __launch_bounds__(256) kc_chain_reduce_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
+                                                              const u64 *__restrict__ starts, u64 nstarts, const u64 *__restrict__ seg_len,
+                                                              const u64 *__restrict__ seg_next, const u64 *__restrict__ seg_tail,
+                                                              u64 *seg_chain, u64 *seg_off, u64 *chain_head, u64 *chain_len, u64 *chain_key,
+                                                              u64 *cursor) {
+    u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j0 >= nstarts) return;
+    const u64 id = starts[j0];
+    if (LK_IS_MATCHED(link[id])) return;             // entry port matched: a splitter start, not a head
+    u64 total = 0, j = j0, tail = 0;
+    while (true) {
+        total += seg_len[j];
+        if (seg_next[j] == KC_SEG_NONE) { tail = seg_tail[j]; break; }
+        j = seg_next[j];
+    }
+    Key<W> hk = set_key_at(set, id >> 1);
+    bool winner = true;
+    if (complements) winner = (total == 1) ? ((id & 1) == 0) : key_lt(hk, set_key_at(set, tail >> 1));
+    if (!winner) return;
+    atomicAdd((ull *)(cursor + 3), (ull)total);
+    u64 pos = atomicAdd((ull *)cursor, 1ULL);
+    chain_head[pos] = id;
+    chain_len[pos] = total;
+    for (int i = 0; i < W; ++i) chain_key[pos * W + i] = hk.w[i];
+    u64 off = 0;
+    j = j0;
+    while (true) {
+        seg_chain[j] = pos;
+        seg_off[j] = off;
+        off += seg_len[j];
+        if (seg_next[j] == KC_SEG_NONE) break;
+        j = seg_next[j];
+    }
+}
+__global__ void __launch_bounds__(256) kc_inverse_perm_kernel(const u64 *__restrict__ perm, u64 n, u64 *rank) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) rank[perm[t]] = t;
+}
+// one thread per segment of an emitted chain: spell its bases into the (zeroed) packed words with 64-bit atomic ORs
+template <int W>
+__global__ void __launch_bounds__(256) kc_segment_emit_kernel(SetView<W> set, const u64 *__restrict__ link, int k,
+                                                              const u64 *__restrict__ starts, u64 nstarts, const u64 *__restrict__ seg_chain,
+                                                              const u64 *__restrict__ seg_off, const u64 *__restrict__ rank,
+                                                              const u64 *__restrict__ woff, u64 *words, u64 *firstK, u64 *lastK) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nstarts) return;
+    const u64 ch = seg_chain[j];
+    if (ch == KC_SEG_NONE) return;
+    const u64 r = rank[ch], wb = woff[r], off = seg_off[j];
+    u64 cur = starts[j] >> 1;
+    int co = (int)(starts[j] & 1);
+    Key<W> kx = set_key_at(set, cur);
+    if (co) kx = key_rc(kx, k);
+    u64 pos, acc = 0, wi;   // pos = next base position in the chain's string; acc = bits gathered for word wi
+    auto put = [&](u64 b) {
+        acc |= b << (62 - 2 * (pos & 31));
+        ++pos;
+        if ((pos & 31) == 0) { atomicOr((ull *)&words[wi], (ull)acc); acc = 0; ++wi; }
+    };
+    if (off == 0) {               // chain head: the whole first k-mer
+        for (int i = 0; i < W; ++i) firstK[r * W + i] = kx.w[i];
+        pos = 0; wi = wb;
+        for (int i = 0; i < k; ++i) put((u64)key_at(kx, k, i));
+    } else {                      // later segment: its first node contributes the last base of its oriented k-mer
+        pos = (u64)(k - 1) + off; wi = wb + (pos >> 5);
+        put(kx.w[0] & 3);
+    }
+    u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+    while (true) {
+        if (!LK_IS_MATCHED(w)) {  // tail of the chain
+            for (int i = 0; i < W; ++i) lastK[r * W + i] = kx.w[i];
+            break;
+        }
+        u64 nxt = LK_SLOT(w);
+        int no = LK_PORT(w) == 0 ? 0 : 1;
+        u64 wn = link[(nxt << 1) | (u64)(no == 0 ? 1 : 0)];
+        if (wn & LK_SPLIT) break;
+        u64 b = LK_BASE(w);
+        kx = key_append(kx, b, k);
+        put(b);
+        cur = nxt; co = no; w = wn;
+    }
+    if (acc) atomicOr((ull *)&words[wi], (ull)acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out) {
     // LSD over the key words (least significant word first), each pass a stable radix sort of (word, perm).
     u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr;
@@ -580,13 +718,16 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
     const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
     u64 *branch = work_b, *branch_cursor = cnt + 4;   // branch ports of round 1 (work_b is free until round 2)
+    const u64 splits_cap = N / 64 + 65536;             // expected N/256 splitters
+    u64 *splits = nullptr, *splits_cursor = cnt + 5;
+    KC_TRY(kc_alloc(ctx, &splits, splits_cap));
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (k31)
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor);
+                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor, splits, splits_cap, splits_cursor);
     else
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor);
+                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor, splits, splits_cap, splits_cursor);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     u64 nbranch = 0, nwork = 0, rounds = 1;
     KC_TRY(read_u64(ctx, branch_cursor, &nbranch));
@@ -628,7 +769,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rounds_out) *rounds_out = rounds;
 
     // chain heads
-    u64 nheads = 0;
+    u64 nheads = 0, nsplit = 0;
+    KC_TRY(read_u64(ctx, splits_cursor, &nsplit));
     KC_TRY(read_u64(ctx, heads_cursor, &nheads));
     if (nheads > heads_cap) {   // overflow: exact count + fill
         kc_release(ctx, heads);
@@ -647,13 +789,68 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_TRY(kc_alloc(ctx, &chain_head, max_chains));
     KC_TRY(kc_alloc(ctx, &chain_len, max_chains));
     KC_TRY(kc_alloc(ctx, &chain_key, max_chains * W));
+    // ---- per-chain measure pass with a step limit: read-like inputs (chains of ~1000 nodes) finish here
+    u64 KC_CHAIN_LIMIT = 16384;
+    if (const char *e = getenv("KC_CHAIN_LIMIT")) { long v = atol(e); if (v >= 1) KC_CHAIN_LIMIT = (u64)v; }   // tests force the segment path
+    bool seg_ok = false;
+    u64 nstarts = 0;
+    u64 *starts = nullptr, *seg_len = nullptr, *seg_next = nullptr, *seg_tail = nullptr, *seg_chain = nullptr, *seg_off = nullptr;
+    u64 hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     if (nheads)
         hipLaunchKernelGGL((kc_walk_measure_kernel<W, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
-                           (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt);
-    u64 hc[4] = {0, 0, 0, 0};
-    KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+                           (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, KC_CHAIN_LIMIT);
+    KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool too_long = hc[7] != 0;
+    // ---- some chain is long: segment-parallel path (needs: no cycles, splitter list did not overflow)
+    if (too_long && nsplit <= splits_cap) {
+        const u64 max_starts = nheads + 2 * nsplit + 1;
+        u64 *starts_raw = nullptr;
+        KC_TRY(kc_alloc(ctx, &starts_raw, max_starts));
+        KC_TRY(kc_alloc(ctx, &starts, max_starts));
+        KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
+        if (nsplit)
+            hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)splits,
+                               nsplit, compl_, starts_raw, cnt + 6);
+        KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
+        {
+            size_t tb = 0;
+            KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
+            u8 *tmp = nullptr;
+            KC_TRY(kc_alloc(ctx, &tmp, tb));
+            KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            kc_release(ctx, tmp);
+        }
+        kc_release(ctx, starts_raw);
+        KC_TRY(kc_alloc(ctx, &seg_len, nstarts + 1)); KC_TRY(kc_alloc(ctx, &seg_next, nstarts + 1)); KC_TRY(kc_alloc(ctx, &seg_tail, nstarts + 1));
+        KC_TRY(kc_alloc(ctx, &seg_chain, nstarts + 1)); KC_TRY(kc_alloc(ctx, &seg_off, nstarts + 1));
+        KC_HIP(ctx, hipMemsetAsync(seg_chain, 0xff, (nstarts + 1) * 8, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
+        if (nstarts) {
+            hipLaunchKernelGGL(kc_segment_walk_kernel, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)starts,
+                               nstarts, seg_len, seg_next, seg_tail);
+            hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                               (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
+                               seg_off, chain_head, chain_len, chain_key, cnt);
+        }
+        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        seg_ok = (hc[3] == N);
+        hc[1] = 0;
+    }
+    kc_release(ctx, splits);
+    // ---- long chains but the segment path is not applicable (cycles / splitter overflow): unlimited per-chain pass
+    if (too_long && !seg_ok) {
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        if (nheads)
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                               (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, ~(u64)0);
+        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     u8 *visited = nullptr;
     if (hc[3] != N) {
         // some k-mers are on cycles (every port matched, no head reaches them): mark what the chains cover, list the rest
@@ -662,7 +859,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         if (nheads)
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
-                               compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt);
+                               compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0);
         hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
                            (u64 *)nullptr, cnt + 1);
         KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -718,8 +915,22 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     s->total_bases = N + S * (u64)(k - 1);
     rc = kc_alloc(ctx, &s->words, s->nwords + 1);
     if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
-    hipLaunchKernelGGL((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
-                       (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
+    if (seg_ok) {
+        u64 *rank = nullptr;
+        KC_TRY(kc_alloc(ctx, &rank, S + 1));
+        KC_HIP(ctx, hipMemsetAsync(s->words, 0, (s->nwords + 1) * 8, ctx->stream));
+        hipLaunchKernelGGL(kc_inverse_perm_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)perm, S, rank);
+        hipLaunchKernelGGL((kc_segment_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
+                           (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
+                           s->words, s->firstK, s->lastK);
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        kc_release(ctx, rank);
+    } else {
+        hipLaunchKernelGGL((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
+                           (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
+    }
+    kc_release(ctx, starts); kc_release(ctx, seg_len); kc_release(ctx, seg_next); kc_release(ctx, seg_tail); kc_release(ctx, seg_chain);
+    kc_release(ctx, seg_off);
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     kc_release(ctx, tmp); kc_release(ctx, nwords); kc_release(ctx, perm);

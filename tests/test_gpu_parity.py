@@ -112,6 +112,27 @@ def test_simplitigs_match_canonical_oracle(ctx, oracle, k, complements):
         sim.close(); s.close()
 
 
+@pytest.mark.parametrize("k", [4, 13, 31, 40, 127])
+def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
+    # KC_CHAIN_LIMIT=2 makes every chain of more than 2 k-mers "long": the splitter/segment path handles all of them
+    monkeypatch.setenv("KC_CHAIN_LIMIT", "2")
+    rng = random.Random(31 + k)
+    cases = ["\n".join(r.decode() for r in gen.stress_reads(6000, 150, 200 if k < 100 else 400, seed=100 + k)),
+             _rand_seq(rng, 30000), _rand_seq(rng, 3000, "AC"), _rand_seq(rng, 1500) * 3]
+    for complements in (True, False):
+        for seq in cases:
+            want = oracle.simplitigs_of_sequence(seq.replace("\n", "N"), k, complements, mode=1)
+            s = kc.KmerSet(ctx, k, complements, capacity_hint=len(seq))
+            s.AddKMers(seq)
+            sim = kc.get_simplitigs(s)
+            assert sim.strings() == want
+            # downstream phases read firstK/lastK written by the segment emitter
+            rc, wout, wmask = oracle.global_(want, k, complements, want_mask=True)
+            out, mask, _ = kc.Global(sim, complements, want_mask=True, kmer_set=s)
+            assert (out, mask) == (wout, wmask)
+            sim.close(); s.close()
+
+
 def test_simplitigs_reference_kats(ctx):
     # tests/simplitigs_unittest.h:183-208 (order-tolerant there: sorted by length)
     enc = oracle_lib.encode_kmer
