@@ -261,7 +261,17 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v < k) ? v : 0; }   // tuning/ablation knobs
     if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 20) s->bshift = v; }
     if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
-    u64 cap = (u64)((double)capacity_hint / 0.66) + 1024;
+    // target load 0.5 (shorter tag scans, measured 10 % faster neighbour probes) when table + links + occ list at that load
+    // stay below 60 % of the device memory, else 0.66
+    double load = 0.5;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+        double per_slot = 8.0 * s->W + 1 + 16, need = (double)capacity_hint / load * per_slot + (double)capacity_hint * 12;
+        if (total_b && need > 0.6 * (double)total_b) load = 0.66;
+    }
+    if (const char *e = getenv("KC_LOAD")) { double v = atof(e); if (v >= 0.2 && v <= 0.9) load = v; }
+    u64 cap = (u64)((double)capacity_hint / load) + 1024;
     s->nblocks = (cap + (((u64)1 << s->bshift) - 1)) >> s->bshift;
     cap = s->nblocks << s->bshift;
     s->cap = cap;
