@@ -84,12 +84,13 @@ __global__ void __launch_bounds__(256) em_mask_kernel(const char *__restrict__ o
 
 int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc_set *set_for_mask, char **d_out, char **d_mask, u64 *length) {
     kc_ctx *ctx = s->ctx;
+    KcScope scope(ctx);
     const u64 S = s->n, V = path->V;
     const int k = s->k;
     u64 *pred = nullptr, *start = nullptr, *nxt, *dist, *endv, *nxt2, *dist2, *endv2, *weight;
-    KC_TRY(kc_alloc(ctx, &pred, V)); KC_TRY(kc_alloc(ctx, &start, 2));
-    KC_TRY(kc_alloc(ctx, &nxt, V)); KC_TRY(kc_alloc(ctx, &dist, V)); KC_TRY(kc_alloc(ctx, &endv, V));
-    KC_TRY(kc_alloc(ctx, &nxt2, V)); KC_TRY(kc_alloc(ctx, &dist2, V)); KC_TRY(kc_alloc(ctx, &endv2, V)); KC_TRY(kc_alloc(ctx, &weight, V));
+    KC_TRY(scope.alloc(&pred, V)); KC_TRY(scope.alloc(&start, 2));
+    KC_TRY(scope.alloc(&nxt, V)); KC_TRY(scope.alloc(&dist, V)); KC_TRY(scope.alloc(&endv, V));
+    KC_TRY(scope.alloc(&nxt2, V)); KC_TRY(scope.alloc(&dist2, V)); KC_TRY(scope.alloc(&endv2, V)); KC_TRY(scope.alloc(&weight, V));
     KC_HIP(ctx, hipMemsetAsync(pred, 0xff, V * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(start, 0xff, 16, ctx->stream));
     unsigned g = kc_grid(V, 256);
@@ -126,7 +127,7 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     void *rel[] = {pred, start, nxt, dist, endv, nxt2, dist2, endv2, weight};
-    for (void *p : rel) kc_release(ctx, p);
+    for (void *p : rel) scope.release(p);
     *d_out = out;
     if (d_mask) *d_mask = mask;
     *length = L;

@@ -106,6 +106,31 @@ template <typename T> static inline int kc_alloc(kc_ctx *ctx, T **out, size_t co
 }
 static inline void kc_release(kc_ctx *ctx, void *p) { if (p) ctx->pool.release(p); }
 
+// Temporaries of one call: everything allocated through the scope goes back to the pool when the scope ends, whatever
+// the exit path (KcPool::release ignores pointers it does not hold, so an explicit earlier kc_release stays harmless).
+struct KcScope {
+    kc_ctx *ctx;
+    std::vector<void *> ptrs;
+    explicit KcScope(kc_ctx *c) : ctx(c) {}
+    KcScope(const KcScope &) = delete;
+    KcScope &operator=(const KcScope &) = delete;
+    ~KcScope() {
+        if (!ptrs.empty()) (void)hipStreamSynchronize(ctx->stream);   // nothing in flight may still use them
+        for (void *p : ptrs) kc_release(ctx, p);
+    }
+    template <typename T> int alloc(T **out, size_t count) {
+        int rc = kc_alloc(ctx, out, count);
+        if (rc == KC_OK) ptrs.push_back((void *)*out);
+        return rc;
+    }
+    void keep(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }   // ownership moves to the caller
+    void release(void *p) {                                                // early release of one temporary
+        if (!p) return;
+        for (auto &q : ptrs) if (q == p) q = nullptr;   // forget it first: the pool may hand the block to someone else
+        kc_release(ctx, p);
+    }
+};
+
 static inline unsigned kc_grid(u64 n, unsigned block) { u64 g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
 static inline unsigned kc_grid8(u64 n, unsigned block) { u64 g = (n + block - 1) / block; g = (g + 7) / 8 * 8; return (unsigned)(g ? g : 8); }  // for kc_xcd_block_id()
 

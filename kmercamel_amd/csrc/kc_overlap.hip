@@ -366,6 +366,7 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
 
 template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out) {
     kc_ctx *ctx = s->ctx;
+    KcScope scope(ctx);
     const int k = s->k;
     const u64 S = s->n, V = S * (complements ? 2 : 1);
     if (S == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
@@ -374,28 +375,28 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u64 *pre, *suf, *edge_from, *pred, *first, *last, *first_snap, *last_snap, *actS, *actP, *actS2, *actP2, *eidx;
     u8 *overlaps, *hitS, *hitP, *cov;
     u64 *pslot, *ne, *cnt, *bl;
-    KC_TRY(kc_alloc(ctx, &pre, V * W)); KC_TRY(kc_alloc(ctx, &suf, V * W));
+    KC_TRY(scope.alloc(&pre, V * W)); KC_TRY(scope.alloc(&suf, V * W));
     KC_TRY(kc_alloc(ctx, &edge_from, V)); KC_TRY(kc_alloc(ctx, &pred, V)); KC_TRY(kc_alloc(ctx, &overlaps, V));
-    KC_TRY(kc_alloc(ctx, &first, V)); KC_TRY(kc_alloc(ctx, &last, V)); KC_TRY(kc_alloc(ctx, &first_snap, V)); KC_TRY(kc_alloc(ctx, &last_snap, V));
-    KC_TRY(kc_alloc(ctx, &actS, V)); KC_TRY(kc_alloc(ctx, &actP, V)); KC_TRY(kc_alloc(ctx, &actS2, V)); KC_TRY(kc_alloc(ctx, &actP2, V));
-    KC_TRY(kc_alloc(ctx, &eidx, V)); KC_TRY(kc_alloc(ctx, &hitS, V)); KC_TRY(kc_alloc(ctx, &hitP, V)); KC_TRY(kc_alloc(ctx, &cov, V));
-    KC_TRY(kc_alloc(ctx, &pslot, V)); KC_TRY(kc_alloc(ctx, &ne, V * 10 + 10)); KC_TRY(kc_alloc(ctx, &cnt, 16));  // ne: up to two log entries per event
+    KC_TRY(scope.alloc(&first, V)); KC_TRY(scope.alloc(&last, V)); KC_TRY(scope.alloc(&first_snap, V)); KC_TRY(scope.alloc(&last_snap, V));
+    KC_TRY(scope.alloc(&actS, V)); KC_TRY(scope.alloc(&actP, V)); KC_TRY(scope.alloc(&actS2, V)); KC_TRY(scope.alloc(&actP2, V));
+    KC_TRY(scope.alloc(&eidx, V)); KC_TRY(scope.alloc(&hitS, V)); KC_TRY(scope.alloc(&hitP, V)); KC_TRY(scope.alloc(&cov, V));
+    KC_TRY(scope.alloc(&pslot, V)); KC_TRY(scope.alloc(&ne, V * 10 + 10)); KC_TRY(scope.alloc(&cnt, 16));  // ne: up to two log entries per event
     const u64 BL_MAX = 4096;
-    KC_TRY(kc_alloc(ctx, &bl, BL_MAX * 2));
-    KC_TRY(kc_alloc(ctx, &w.d_num, 2));
+    KC_TRY(scope.alloc(&bl, BL_MAX * 2));
+    KC_TRY(scope.alloc(&w.d_num, 2));
     u64 *big = nullptr;
     const u64 big_cap = 2 * V / KC_LDS_MIN + 16;
-    KC_TRY(kc_alloc(ctx, &big, big_cap * 5));
+    KC_TRY(scope.alloc(&big, big_cap * 5));
     u64 tcap = 64;
     while (tcap < 2 * V + 16) tcap <<= 1;
     LevelTable<W> tab;
-    KC_TRY(kc_alloc(ctx, &tab.slot, tcap)); KC_TRY(kc_alloc(ctx, &tab.flags, tcap));
+    KC_TRY(scope.alloc(&tab.slot, tcap)); KC_TRY(scope.alloc(&tab.flags, tcap));
     // hit buffers
     u64 *hs_ids, *hp_ids, *hs_keys, *hp_keys, *hs_ids2, *hp_ids2, *hs_keys2, *hp_keys2, *sc0, *sc1, *sc2, *sc3;
-    KC_TRY(kc_alloc(ctx, &hs_ids, V)); KC_TRY(kc_alloc(ctx, &hp_ids, V)); KC_TRY(kc_alloc(ctx, &hs_ids2, V)); KC_TRY(kc_alloc(ctx, &hp_ids2, V));
-    KC_TRY(kc_alloc(ctx, &hs_keys, V * W)); KC_TRY(kc_alloc(ctx, &hp_keys, V * W)); KC_TRY(kc_alloc(ctx, &hs_keys2, V * W)); KC_TRY(kc_alloc(ctx, &hp_keys2, V * W));
+    KC_TRY(scope.alloc(&hs_ids, V)); KC_TRY(scope.alloc(&hp_ids, V)); KC_TRY(scope.alloc(&hs_ids2, V)); KC_TRY(scope.alloc(&hp_ids2, V));
+    KC_TRY(scope.alloc(&hs_keys, V * W)); KC_TRY(scope.alloc(&hp_keys, V * W)); KC_TRY(scope.alloc(&hs_keys2, V * W)); KC_TRY(scope.alloc(&hp_keys2, V * W));
     sc0 = sc1 = sc2 = sc3 = nullptr;
-    if (W > 1) { KC_TRY(kc_alloc(ctx, &sc0, V)); KC_TRY(kc_alloc(ctx, &sc1, V)); KC_TRY(kc_alloc(ctx, &sc2, V)); KC_TRY(kc_alloc(ctx, &sc3, V)); }
+    if (W > 1) { KC_TRY(scope.alloc(&sc0, V)); KC_TRY(scope.alloc(&sc1, V)); KC_TRY(scope.alloc(&sc2, V)); KC_TRY(scope.alloc(&sc3, V)); }
 
     KC_HIP(ctx, hipMemsetAsync(cov, 0, V, ctx->stream));
     hipLaunchKernelGGL((ov_init_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->firstK, (const u64 *)s->lastK, S, V, k,
@@ -508,10 +509,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     (void)hipHostFree(hp);
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
-    kc_release(ctx, big);
+    scope.release(big);
     void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt, bl, w.d_num,
                    tab.slot, tab.flags, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
-    for (void *p : rel) kc_release(ctx, p);
+    for (void *p : rel) scope.release(p);
     return KC_OK;
 }
 

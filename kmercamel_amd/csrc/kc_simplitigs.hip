@@ -647,15 +647,16 @@ __global__ void __launch_bounds__(256) kc_segment_emit_kernel(SetView<W> set, co
 static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out) {
     // LSD over the key words (least significant word first), each pass a stable radix sort of (word, perm).
     u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr;
-    KC_TRY(kc_alloc(ctx, &perm, n));
-    KC_TRY(kc_alloc(ctx, &perm2, n));
-    KC_TRY(kc_alloc(ctx, &kw, n));
-    KC_TRY(kc_alloc(ctx, &kw2, n));
+    KcScope scope(ctx);
+    KC_TRY(scope.alloc(&perm, n));
+    KC_TRY(scope.alloc(&perm2, n));
+    KC_TRY(scope.alloc(&kw, n));
+    KC_TRY(scope.alloc(&kw2, n));
     hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
     size_t tmp_bytes = 0;
     KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kw, kw2, perm, perm2, n, 0, 64, ctx->stream));
     void *tmp = nullptr;
-    KC_TRY(kc_alloc(ctx, (u8 **)&tmp, tmp_bytes));
+    KC_TRY(scope.alloc((u8 **)&tmp, tmp_bytes));
     for (int word = 0; word < W; ++word) {
         int bits = 2 * k - 64 * word;
         if (bits <= 0) break;
@@ -665,7 +666,7 @@ static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k
         std::swap(perm, perm2);
     }
     KC_HIP(ctx, hipGetLastError());
-    kc_release(ctx, perm2); kc_release(ctx, kw); kc_release(ctx, kw2); kc_release(ctx, tmp);
+    scope.keep(perm);   // (perm and perm2 may have been swapped: keep whichever holds the result)
     *perm_out = perm;
     return KC_OK;
 }
@@ -678,6 +679,7 @@ static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h) {
 
 template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out) {
     kc_ctx *ctx = set->ctx;
+    KcScope scope(ctx);
     const int k = set->k, compl_ = set->complements;
     SetView<W> sv = kc_view<W>(set);
     const u64 cap = set->cap, nports = cap * 2;
@@ -686,41 +688,41 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     const u64 N = set->size_host;
     if (N == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
     u64 *link = nullptr, *cnt = nullptr;
-    KC_TRY(kc_alloc(ctx, &link, nports));
-    KC_TRY(kc_alloc(ctx, &cnt, 8));
+    KC_TRY(scope.alloc(&link, nports));
+    KC_TRY(scope.alloc(&cnt, 8));
     KC_HIP(ctx, hipMemsetAsync(link, 0, nports * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     // heads (ports that die) and the work list of unresolved ports are collected on the fly into bounded buffers; an
     // overflow (never seen on read-like inputs) falls back to exact counting passes.
     u64 heads_cap = N / 4 + 65536, work_cap = N / 8 + 65536;
     u64 *heads = nullptr, *work_a = nullptr, *work_b = nullptr;
-    KC_TRY(kc_alloc(ctx, &heads, heads_cap));
-    KC_TRY(kc_alloc(ctx, &work_a, work_cap));
-    KC_TRY(kc_alloc(ctx, &work_b, work_cap));
+    KC_TRY(scope.alloc(&heads, heads_cap));
+    KC_TRY(scope.alloc(&work_a, work_cap));
+    KC_TRY(scope.alloc(&work_b, work_cap));
     u64 *heads_cursor = cnt + 2, *work_cursor = cnt;
     // compacted list of occupied slots (slot order kept)
     const u64 ntiles = (cap + KC_TILE - 1) / KC_TILE;
     u64 *tile_cnt = nullptr, *tile_off = nullptr, *occ = nullptr;
-    KC_TRY(kc_alloc(ctx, &tile_cnt, ntiles + 1));
-    KC_TRY(kc_alloc(ctx, &tile_off, ntiles + 1));
-    KC_TRY(kc_alloc(ctx, &occ, N + 1));
+    KC_TRY(scope.alloc(&tile_cnt, ntiles + 1));
+    KC_TRY(scope.alloc(&tile_off, ntiles + 1));
+    KC_TRY(scope.alloc(&occ, N + 1));
     hipLaunchKernelGGL(kc_occ_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u8 *)set->tags, cap, tile_cnt);
     {
         size_t tb = 0;
         KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, tile_cnt, tile_off, (int)ntiles, ctx->stream));
         u8 *tmp = nullptr;
-        KC_TRY(kc_alloc(ctx, &tmp, tb));
+        KC_TRY(scope.alloc(&tmp, tb));
         KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, tile_cnt, tile_off, (int)ntiles, ctx->stream));
         hipLaunchKernelGGL(kc_occ_fill_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u8 *)set->tags, cap, (const u64 *)tile_off, occ);
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        kc_release(ctx, tmp);
+        scope.release(tmp);
     }
     // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
     const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
     u64 *branch = work_b, *branch_cursor = cnt + 4;   // branch ports of round 1 (work_b is free until round 2)
     const u64 splits_cap = N / 64 + 65536;             // expected N/256 splitters
     u64 *splits = nullptr, *splits_cursor = cnt + 5;
-    KC_TRY(kc_alloc(ctx, &splits, splits_cap));
+    KC_TRY(scope.alloc(&splits, splits_cap));
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     if (k31)
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
@@ -743,16 +745,16 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), dim3(kc_grid(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
-        kc_release(ctx, work_a); kc_release(ctx, work_b);
+        scope.release(work_a); scope.release(work_b);
         work_cap = nwork + 1;
-        KC_TRY(kc_alloc(ctx, &work_a, work_cap));
-        KC_TRY(kc_alloc(ctx, &work_b, work_cap));
+        KC_TRY(scope.alloc(&work_a, work_cap));
+        KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), dim3(kc_grid(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
-    kc_release(ctx, tile_cnt); kc_release(ctx, tile_off); kc_release(ctx, occ);
+    scope.release(tile_cnt); scope.release(tile_off); scope.release(occ);
     while (nwork) {
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
@@ -765,7 +767,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         std::swap(work_a, work_b);
     }
     KC_HIP(ctx, hipGetLastError());
-    kc_release(ctx, work_a); kc_release(ctx, work_b);
+    scope.release(work_a); scope.release(work_b);
     if (rounds_out) *rounds_out = rounds;
 
     // chain heads
@@ -773,12 +775,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_TRY(read_u64(ctx, splits_cursor, &nsplit));
     KC_TRY(read_u64(ctx, heads_cursor, &nheads));
     if (nheads > heads_cap) {   // overflow: exact count + fill
-        kc_release(ctx, heads);
+        scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         hipLaunchKernelGGL((kc_heads_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                            (u64 *)nullptr, cnt);
         KC_TRY(read_u64(ctx, cnt, &nheads));
-        KC_TRY(kc_alloc(ctx, &heads, nheads + 1));
+        KC_TRY(scope.alloc(&heads, nheads + 1));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         hipLaunchKernelGGL((kc_heads_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
                            cnt);
@@ -786,9 +788,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // chain records: at most nheads chains from heads (+ cycles appended later; reallocated if needed)
     u64 max_chains = nheads + 1;
     u64 *chain_head = nullptr, *chain_len = nullptr, *chain_key = nullptr;
-    KC_TRY(kc_alloc(ctx, &chain_head, max_chains));
-    KC_TRY(kc_alloc(ctx, &chain_len, max_chains));
-    KC_TRY(kc_alloc(ctx, &chain_key, max_chains * W));
+    KC_TRY(scope.alloc(&chain_head, max_chains));
+    KC_TRY(scope.alloc(&chain_len, max_chains));
+    KC_TRY(scope.alloc(&chain_key, max_chains * W));
     // ---- per-chain measure pass with a step limit: read-like inputs (chains of ~1000 nodes) finish here
     u64 KC_CHAIN_LIMIT = 16384;
     if (const char *e = getenv("KC_CHAIN_LIMIT")) { long v = atol(e); if (v >= 1) KC_CHAIN_LIMIT = (u64)v; }   // tests force the segment path
@@ -807,8 +809,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (too_long && nsplit <= splits_cap) {
         const u64 max_starts = nheads + 2 * nsplit + 1;
         u64 *starts_raw = nullptr;
-        KC_TRY(kc_alloc(ctx, &starts_raw, max_starts));
-        KC_TRY(kc_alloc(ctx, &starts, max_starts));
+        KC_TRY(scope.alloc(&starts_raw, max_starts));
+        KC_TRY(scope.alloc(&starts, max_starts));
         KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
         if (nsplit)
@@ -819,14 +821,14 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             size_t tb = 0;
             KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
             u8 *tmp = nullptr;
-            KC_TRY(kc_alloc(ctx, &tmp, tb));
+            KC_TRY(scope.alloc(&tmp, tb));
             KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            kc_release(ctx, tmp);
+            scope.release(tmp);
         }
-        kc_release(ctx, starts_raw);
-        KC_TRY(kc_alloc(ctx, &seg_len, nstarts + 1)); KC_TRY(kc_alloc(ctx, &seg_next, nstarts + 1)); KC_TRY(kc_alloc(ctx, &seg_tail, nstarts + 1));
-        KC_TRY(kc_alloc(ctx, &seg_chain, nstarts + 1)); KC_TRY(kc_alloc(ctx, &seg_off, nstarts + 1));
+        scope.release(starts_raw);
+        KC_TRY(scope.alloc(&seg_len, nstarts + 1)); KC_TRY(scope.alloc(&seg_next, nstarts + 1)); KC_TRY(scope.alloc(&seg_tail, nstarts + 1));
+        KC_TRY(scope.alloc(&seg_chain, nstarts + 1)); KC_TRY(scope.alloc(&seg_off, nstarts + 1));
         KC_HIP(ctx, hipMemsetAsync(seg_chain, 0xff, (nstarts + 1) * 8, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
         if (nstarts) {
@@ -841,7 +843,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         seg_ok = (hc[3] == N);
         hc[1] = 0;
     }
-    kc_release(ctx, splits);
+    scope.release(splits);
     // ---- long chains but the segment path is not applicable (cycles / splitter overflow): unlimited per-chain pass
     if (too_long && !seg_ok) {
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
@@ -854,7 +856,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u8 *visited = nullptr;
     if (hc[3] != N) {
         // some k-mers are on cycles (every port matched, no head reaches them): mark what the chains cover, list the rest
-        KC_TRY(kc_alloc(ctx, &visited, cap));
+        KC_TRY(scope.alloc(&visited, cap));
         KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         if (nheads)
@@ -868,28 +870,28 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 nchains = hc[0], nunvis = hc[1];
     if (nunvis) {
         u64 *ulist = nullptr;
-        KC_TRY(kc_alloc(ctx, &ulist, nunvis));
+        KC_TRY(scope.alloc(&ulist, nunvis));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
                            cnt + 1);
         // room for up to nunvis more chains
         u64 *ch2 = nullptr, *cl2 = nullptr, *ck2 = nullptr;
         u64 nmax2 = nchains + nunvis + 1;
-        KC_TRY(kc_alloc(ctx, &ch2, nmax2)); KC_TRY(kc_alloc(ctx, &cl2, nmax2)); KC_TRY(kc_alloc(ctx, &ck2, nmax2 * W));
+        KC_TRY(scope.alloc(&ch2, nmax2)); KC_TRY(scope.alloc(&cl2, nmax2)); KC_TRY(scope.alloc(&ck2, nmax2 * W));
         KC_HIP(ctx, hipMemcpyAsync(ch2, chain_head, nchains * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemcpyAsync(cl2, chain_len, nchains * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemcpyAsync(ck2, chain_key, nchains * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        kc_release(ctx, chain_head); kc_release(ctx, chain_len); kc_release(ctx, chain_key);
+        scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
         chain_head = ch2; chain_len = cl2; chain_key = ck2;
         hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited, chain_head,
                            chain_len, chain_key, cnt);
         KC_TRY(read_u64(ctx, cnt, &nchains));
-        kc_release(ctx, ulist);
+        scope.release(ulist);
     }
     KC_HIP(ctx, hipGetLastError());
-    kc_release(ctx, heads);
-    kc_release(ctx, visited);
+    scope.release(heads);
+    scope.release(visited);
 
     // order chains by head key, size them, emit
     const u64 S = nchains;
@@ -899,7 +901,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     int rc = sort_perm_by_keys(ctx, chain_key, S, W, k, &perm);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->lens, S + 1);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->woff, S + 1);
-    if (rc == KC_OK) rc = kc_alloc(ctx, &nwords, S + 1);
+    if (rc == KC_OK) rc = scope.alloc(&nwords, S + 1);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->firstK, S * W);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->lastK, S * W);
     if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
@@ -908,7 +910,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     size_t tmp_bytes = 0;
     KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, nwords, s->woff, S, ctx->stream));
     u8 *tmp = nullptr;
-    KC_TRY(kc_alloc(ctx, &tmp, tmp_bytes));
+    KC_TRY(scope.alloc(&tmp, tmp_bytes));
     KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, nwords, s->woff, S, ctx->stream));
     hipLaunchKernelGGL(kc_finish_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, s->woff, (const u64 *)nwords, S);
     KC_TRY(read_u64(ctx, s->woff + S, &s->nwords));
@@ -917,25 +919,25 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
     if (seg_ok) {
         u64 *rank = nullptr;
-        KC_TRY(kc_alloc(ctx, &rank, S + 1));
+        KC_TRY(scope.alloc(&rank, S + 1));
         KC_HIP(ctx, hipMemsetAsync(s->words, 0, (s->nwords + 1) * 8, ctx->stream));
         hipLaunchKernelGGL(kc_inverse_perm_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)perm, S, rank);
         hipLaunchKernelGGL((kc_segment_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
                            (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
                            s->words, s->firstK, s->lastK);
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        kc_release(ctx, rank);
+        scope.release(rank);
     } else {
         hipLaunchKernelGGL((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
                            (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
     }
-    kc_release(ctx, starts); kc_release(ctx, seg_len); kc_release(ctx, seg_next); kc_release(ctx, seg_tail); kc_release(ctx, seg_chain);
-    kc_release(ctx, seg_off);
+    scope.release(starts); scope.release(seg_len); scope.release(seg_next); scope.release(seg_tail); scope.release(seg_chain);
+    scope.release(seg_off);
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    kc_release(ctx, tmp); kc_release(ctx, nwords); kc_release(ctx, perm);
-    kc_release(ctx, chain_head); kc_release(ctx, chain_len); kc_release(ctx, chain_key);
-    kc_release(ctx, link); kc_release(ctx, cnt);
+    scope.release(tmp); scope.release(nwords); kc_release(ctx, perm);
+    scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
+    scope.release(link); scope.release(cnt);
     *out = s;
     return KC_OK;
 }
