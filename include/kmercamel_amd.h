@@ -106,7 +106,8 @@ int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offse
                kc_result **out);
 /* stats[16]: 0 n_kmers, 1 n_simplitigs, 2 length, 3 sparse_branch, 4 n_vertices, 5 matching_rounds,
  *            6.. device time per phase in microseconds: 6 pack+insert, 7 simplitigs, 8 overlap path, 9 emit(+mask),
- *            10 dominant-kernel time (us, summed over its launches), 11 dominant-kernel launches, 12 table capacity,
+ *            10 neighbour-probe kernel time (us, HIP events around the launch of kc_choose_dense_kernel -- the dominant
+ *            kernel), 11 k-mer insert kernel time (us, summed over its launches), 12 table capacity,
  *            13 overlap repair rounds, 14 total device us, 15 reserved */
 int kc_result_stats(kc_result *r, uint64_t *stats);
 /* device pointers to the output characters (length bytes each; mask NULL unless requested) */

@@ -1,7 +1,8 @@
-// kmercamel (MI355X build): the `compute` (greedy), `maskopt` (max-one / min-one) and `lowerbound` subcommands of the
-// reference CLI (main.cpp:214-459, 669-691) with the same options, validation messages, log lines and output format,
-// running the hot path on the GPU through the C ABI.  `compute` uses the fused device-resident pipeline (kc_compute);
-// everything the hot-path scope leaves out (other algorithms, min-run masks, converters, -z) is rejected explicitly.
+// kmercamel (MI355X build): the `compute` (greedy, incl. -S / -M / -z), `maskopt` (max-one / min-one), `lowerbound` and the
+// four format-converter subcommands of the reference CLI (main.cpp:214-691) with the same options, validation messages,
+// log lines and output format, running the hot path on the GPU through the C ABI.  `compute` uses the fused
+// device-resident pipeline (kc_compute); the converters are host-side byte shuffles (conversions.h); everything the
+// hot-path scope leaves out (other algorithms, min-run masks) is rejected explicitly.
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -9,6 +10,7 @@
 #include <unistd.h>
 #include "global.h"
 #include "parser.h"
+#include "conversions.h"
 #include "kc_runtime.h"
 
 static const char *KC_CLI_VERSION = "v2.3.0-mi355x";
@@ -16,17 +18,22 @@ static const int MAX_K = 127;   // main.cpp:93
 
 namespace {
 
-struct Opt { const char *flag, *arg, *help; const char *subs; };   // subs: letters c(ompute) m(askopt) l(owerbound)
+// subs: letters c(ompute) m(askopt) l(owerbound) s(ms2mssep) j(mssep2ms) r(ms2spss) p(spss2ms)
+struct Opt { const char *flag, *arg, *help; const char *subs; };
 const Opt OPTIONS[] = {
-    {"-k", "INT ", "k-mer size [required; up to 127]", "cml"},
+    {"-k", "INT ", "k-mer size [required; up to 127]", "cmlrp"},
     {"-a", "STR ", "the algorithm to be run [greedy (default); the MI355X build implements greedy only]", "c"},
     {"-t", "STR ", "the target mask type to be run [max-one (default), min-one]", "m"},
-    {"-o", "FILE", "output for the (min-one) masked superstring; if not specified, printed to stdout", "cm"},
+    {"-o", "FILE", "output for the (min-one) masked superstring; if not specified, printed to stdout", "cmjrp"},
     {"-M", "FILE", "if given, print also ms with mask maximizing ones (only with greedy)", "c"},
     {"-S", "    ", "optimize for the input being pre-computed simplitigs or unitigs (only with greedy)", "cl"},
     {"-u", "    ", "treat k-mer and its reverse complement as distinct", "cml"},
     {"-z", "INT ", "minimum frequency to represent a k-mer; default 1", "cl"},
-    {"-h", "    ", "print help", "cml"},
+    {"-m", "FILE", "input file with mask", "j"},
+    {"-s", "FILE", "input file with superstring", "j"},
+    {"-m", "FILE", "output file with mask", "s"},
+    {"-s", "FILE", "output file with superstring", "s"},
+    {"-h", "    ", "print help", "cmlsjrp"},
 };
 
 int usage() {
@@ -34,13 +41,19 @@ int usage() {
               << "Version: " << KC_CLI_VERSION << "\n\nUsage:   kmercamel <command> [options]\n\nCommand:\n"
               << "    compute    - Compute an approximately shortest masked superstring from input FASTA.\n"
               << "    maskopt    - Optimize a given masked superstring (max-one / min-one).\n"
+              << "    ms2mssep   - Split a masked superstring into a superstring and a mask.\n"
+              << "    mssep2ms   - Join a masked superstring from a superstring and a mask.\n"
+              << "    ms2spss    - Compute rSPSS from a masked superstring (may be of much larger total length).\n"
+              << "    spss2ms    - Compute masked superstring corresponding to (r)SPSS.\n"
               << "    lowerbound - Compute the lower bound on masked superstring size of a k-mer set.\n\n";
     return 1;
 }
 
 int usage_subcommand(const std::string &sub) {
-    char tag = sub == "compute" ? 'c' : (sub == "maskopt" ? 'm' : 'l');
-    std::cerr << "\nUsage:   kmercamel " << sub << " [options] " << (tag == 'm' ? "<ms>" : "<fasta>") << "\n\nOptions:\n";
+    char tag = sub == "compute" ? 'c' : sub == "maskopt" ? 'm' : sub == "ms2mssep" ? 's' : sub == "mssep2ms" ? 'j' : sub == "ms2spss" ? 'r'
+             : sub == "spss2ms" ? 'p' : 'l';
+    const char *positional = (tag == 'c' || tag == 'l' || tag == 'p') ? " <fasta>" : (tag == 'j' ? "" : " <ms>");   // main.cpp:45-48
+    std::cerr << "\nUsage:   kmercamel " << sub << " [options]" << positional << "\n\nOptions:\n";
     for (const Opt &o : OPTIONS)
         if (std::string(o.subs).find(tag) != std::string::npos) std::cerr << "  " << o.flag << " " << o.arg << " - " << o.help << "\n";
     std::cerr << std::endl;
@@ -251,6 +264,100 @@ int camel_optimize(int argc, char **argv) {
     return 0;
 }
 
+// ms2mssep (main.cpp:445-504).  As in the reference, `-s` alone does not count as a redirection: at least `-m` is needed.
+int camel_split_ms(int argc, char **argv) {
+    std::string subcommand = "ms2mssep", path;
+    if (argc > 1 && std::string(argv[argc - 1]) != "-h") { path = argv[argc - 1]; argc--; }
+    bool mask_set = false;
+    std::ofstream mask, superstring;
+    std::ostream *maskf = &std::cout, *superstringf = &std::cout;
+    int opt;
+    while ((opt = getopt(argc, argv, "m:s:h")) != -1) {
+        switch (opt) {
+            case 'm':
+                if (mask_set) { std::cerr << "Error: -m parameter provided multiple times" << std::endl; return usage_subcommand(subcommand); }
+                mask_set = true; mask.open(optarg); maskf = &mask; break;
+            case 's': superstring.open(optarg); superstringf = &superstring; break;
+            case 'h': usage_subcommand(subcommand); return 0;
+            default: return usage_subcommand(subcommand);
+        }
+    }
+    auto fail = [&](const std::string &m) { std::cerr << m << std::endl; return usage_subcommand(subcommand); };
+    if (path.empty()) return fail("Required positional parameter path to the file not set.");
+    if (!mask_set) return fail("Cannot have both superstring and mask redirected to stdout.");
+    WriteLog("Started splitting masked superstring '" + path + "'.");
+    split_ms(*superstringf, *maskf, path);
+    WriteLog("Finished masked superstring splitting.");
+    return 0;
+}
+
+// mssep2ms (main.cpp:506-568)
+int camel_join_ms(int argc, char **argv) {
+    std::string subcommand = "mssep2ms";
+    bool mask_set = false, superstring_set = false;
+    std::ifstream mask, superstring;
+    std::istream *maskf = &std::cin, *superstringf = &std::cin;
+    std::ofstream output;
+    std::ostream *of = &std::cout;
+    int opt;
+    while ((opt = getopt(argc, argv, "m:s:o:h")) != -1) {
+        switch (opt) {
+            case 'm':
+                if (mask_set) { std::cerr << "Error: -m parameter provided multiple times" << std::endl; return usage_subcommand(subcommand); }
+                mask_set = true; mask.open(optarg); maskf = &mask; break;
+            case 's':
+                if (superstring_set) { std::cerr << "Error: -s parameter provided multiple times" << std::endl; return usage_subcommand(subcommand); }
+                superstring_set = true; superstring.open(optarg); superstringf = &superstring; break;
+            case 'o': output.open(optarg); of = &output; break;
+            case 'h': usage_subcommand(subcommand); return 0;
+            default: return usage_subcommand(subcommand);
+        }
+    }
+    if (!mask_set && !superstring_set) {
+        std::cerr << "Cannot have both superstring and mask redirected from stdin." << std::endl;
+        return usage_subcommand(subcommand);
+    }
+    WriteLog("Started masked superstring joining.");
+    join_ms(*superstringf, *maskf, *of);
+    WriteLog("Finished masked superstring joining.");
+    return 0;
+}
+
+// ms2spss / spss2ms (main.cpp:570-667)
+int camel_spss(int argc, char **argv, bool to_spss) {
+    std::string subcommand = to_spss ? "ms2spss" : "spss2ms", path;
+    if (argc > 1 && std::string(argv[argc - 1]) != "-h") { path = argv[argc - 1]; argc--; }
+    std::ofstream output;
+    std::ostream *of = &std::cout;
+    int k = 0, opt;
+    try {
+        while ((opt = getopt(argc, argv, "o:k:h")) != -1) {
+            switch (opt) {
+                case 'o': output.open(optarg); of = &output; break;
+                case 'k': k = std::stoi(optarg); break;
+                case 'h': usage_subcommand(subcommand); return 0;
+                default: return usage_subcommand(subcommand);
+            }
+        }
+    } catch (std::invalid_argument &) {
+        return usage_subcommand(subcommand);
+    }
+    auto fail = [&](const std::string &m) { std::cerr << m << std::endl; return usage_subcommand(subcommand); };
+    if (path.empty()) return fail("Required positional parameter path to the file not set.");
+    if (k == 0) return fail("Required parameter k not set.");
+    if (k < 0) return fail("k must be positive.");
+    if (to_spss) {
+        WriteLog("Started rSPSS computation from masked supertring '" + path + "'.");
+        ms_to_spss(path, *of, k);
+        WriteLog("Finished computing a rSPSS representing the same set.");
+    } else {
+        WriteLog("Started masked superstring computation corresponding to (r)SPSS '" + path + "'.");
+        spss_to_ms(path, *of, k);
+        WriteLog("Finished computing a masked superstring corresponding to the (r)SPSS.");
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -260,10 +367,10 @@ int main(int argc, char **argv) {
     if (cmd == "compute") return camel_compute(argc - 1, argv + 1, false);
     if (cmd == "lowerbound") return camel_compute(argc - 1, argv + 1, true);
     if (cmd == "maskopt") return camel_optimize(argc - 1, argv + 1);
-    if (cmd == "ms2mssep" || cmd == "mssep2ms" || cmd == "ms2spss" || cmd == "spss2ms") {
-        std::cerr << "Command '" << cmd << "' (format conversion) is not part of the MI355X build; use the reference binary." << std::endl;
-        return usage();
-    }
+    if (cmd == "ms2mssep") return camel_split_ms(argc - 1, argv + 1);
+    if (cmd == "mssep2ms") return camel_join_ms(argc - 1, argv + 1);
+    if (cmd == "ms2spss") return camel_spss(argc - 1, argv + 1, true);
+    if (cmd == "spss2ms") return camel_spss(argc - 1, argv + 1, false);
     std::cerr << "Command '" << argv[1] << "' not recognized." << std::endl;
     return usage();
 }

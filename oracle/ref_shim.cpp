@@ -30,6 +30,7 @@
 #include "global.h"
 #include "global_sparse.h"
 #include "lower_bound.h"
+#include "conversions.h"
 
 namespace {
 
@@ -361,6 +362,40 @@ void kcref_bit_suffix(const uint64_t *in, int k, int d, uint64_t *out) {
         return 0;
     });
 }
+// Representation converters (conversions.h:16-91); results are malloc'ed C strings released with kcref_free.
+int kcref_split_ms(const char *path, char **superstring, char **mask) {
+    try {
+        std::ostringstream s, m;
+        split_ms(s, m, std::string(path));
+        *superstring = dup_string(s.str());
+        *mask = dup_string(m.str());
+        return 0;
+    } catch (std::exception &) { return -1; }
+}
+int kcref_join_ms(const char *superstring_text, const char *mask_text, char **out) {
+    std::istringstream s{std::string(superstring_text)}, m{std::string(mask_text)};
+    std::ostringstream o;
+    join_ms(s, m, o);
+    *out = dup_string(o.str());
+    return 0;
+}
+int kcref_ms_to_spss(const char *path, int k, char **out) {
+    try {
+        std::ostringstream o;
+        ms_to_spss(std::string(path), o, k);
+        *out = dup_string(o.str());
+        return 0;
+    } catch (std::exception &) { return -1; }
+}
+int kcref_spss_to_ms(const char *path, int k, char **out) {
+    try {
+        std::ostringstream o;
+        spss_to_ms(std::string(path), o, k);
+        *out = dup_string(o.str());
+        return 0;
+    } catch (std::exception &) { return -1; }
+}
+
 char kcref_masked(char c, int m) { return Masked(c, m != 0); }
 int kcref_nucleotide_to_int(int c) { return nucleotideToInt[(uint8_t)c]; }
 

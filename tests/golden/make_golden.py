@@ -66,6 +66,20 @@ def main():
         d["N"] = len(kset)
         assert d["N"] == out["spneumoniae"]["%d_1" % k]["N"]
         out["maskopt"][str(k)] = d
+    # format converters: the reference's conversions.h compiled in place, on the reference's own test data
+    out["converters"] = {}
+    for k in (13, 31, 63, 127):
+        p = unz("global-k%dc.fa.gz" % k)
+        sup, mask = ref.split_ms(p)
+        spss = ref.ms_to_spss(p, k)
+        sp_path = os.path.join(tmp, "spss-k%d.fa" % k)
+        with open(sp_path, "w") as f:
+            f.write(spss)
+        back = ref.spss_to_ms(sp_path, k)
+        assert back.startswith(">superstring " + sp_path + "\n")
+        out["converters"][str(k)] = {"superstring": md5(sup), "mask": md5(mask), "joined": md5(ref.join_ms(sup, mask)), "spss": md5(spss),
+                                     "spss_ms_seq": md5(back.split("\n")[1])}
+    out["converters"]["spss.fa"] = {str(k): md5(ref.spss_to_ms(os.path.join(HERE, "spss.fa"), k).split("\n", 1)[1]) for k in (3, 5)}
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote golden.json")

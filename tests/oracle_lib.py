@@ -318,6 +318,38 @@ def _ref_zcount(self, path, k, complements, min_frequency):
     return f(path.encode(), k, int(complements), min_frequency)
 
 
+def _ref_split_ms(self, path):
+    f = self.fn("split_ms")
+    f.argtypes = [ctypes.c_char_p, _vpp, _vpp]
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    if f(path.encode(), ctypes.byref(a), ctypes.byref(b)):
+        return None
+    return self._take(a), self._take(b)
+
+
+def _ref_join_ms(self, superstring_text, mask_text):
+    f = self.fn("join_ms")
+    f.argtypes = [ctypes.c_char_p, ctypes.c_char_p, _vpp]
+    a = ctypes.c_void_p()
+    f(superstring_text.encode(), mask_text.encode(), ctypes.byref(a))
+    return self._take(a)
+
+
+def _ref_convert(name):
+    def call(self, path, k):
+        f = self.fn(name)
+        f.argtypes = [ctypes.c_char_p, ctypes.c_int, _vpp]
+        a = ctypes.c_void_p()
+        if f(path.encode(), k, ctypes.byref(a)):
+            return None
+        return self._take(a)
+    return call
+
+
+Reference.split_ms = _ref_split_ms
+Reference.join_ms = _ref_join_ms
+Reference.ms_to_spss = _ref_convert("ms_to_spss")
+Reference.spss_to_ms = _ref_convert("spss_to_ms")
 Reference.compute_file_z = _ref_z
 Reference.read_kmers_filtered_count = _ref_zcount
 
