@@ -152,6 +152,17 @@ template <int W> KC_HD u64 key_hash(const Key<W> &x) {
     for (int i = W - 2; i >= 0; --i) h = kc_mix64(h ^ x.w[i]);
     return h;
 }
+// Placement hash of the k-mer set: 32 bits, two 32-bit multiplies per key word (the 64-bit murmur finaliser above costs
+// ~4x as many multiply issues, and the neighbour-probe kernel hashes 8 candidates per k-mer).  Only the LAYOUT of the
+// table depends on it -- results never do (the canonical simplitig rule uses key_hash) -- so it is free to be cheap.
+template <int W> KC_HD u64 key_place_hash(const Key<W> &x) {
+    u32 h = 0;
+    for (int i = W - 1; i >= 0; --i) {
+        h = (h ^ (u32)x.w[i]) * 0x9E3779B1u; h ^= h >> 15;
+        h = (h ^ (u32)(x.w[i] >> 32)) * 0x85EBCA77u; h ^= h >> 13;
+    }
+    return (u64)h;
+}
 KC_HD u64 kc_port_term(u64 keyhash, int port) {
     return kc_mix64(keyhash ^ (port ? 0x9e3779b97f4a7c15ULL : 0x7f4a7c159e3779b9ULL));
 }

@@ -27,7 +27,7 @@
 
 template <int W> struct LevelTable {
     u64 *slot;     // W==1: the d-mer key; W>1: a representative prefix vertex (its key is re-derived from pre[])
-    u32 *flags;    // bit0: has an active prefix, bit1: has an active suffix
+    u32 *flags;    // INVERTED (so that one 0xff fill clears slots and flags): bit0 clear = has an active prefix, bit1 clear = suffix
     u64 mask;      // capacity - 1 (power of two)
 };
 
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) ov_insert_prefix_kernel(LevelTable<W> t, 
     u64 j = actP[i];
     Key<W> key = key_prefix(load_key<W>(pre, j), k, d);
     u64 s = level_insert(t, key, j, pre, k, d);
-    atomicOr(&t.flags[s], 1u);
+    atomicAnd(&t.flags[s], ~1u);
     pslot[i] = s;
 }
 
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, c
     u64 s = level_find(t, key, pre, k, d);
     u8 hit = 0;
     if (s != KC_NONE64) {
-        atomicOr(&t.flags[s], 2u);
+        atomicAnd(&t.flags[s], ~2u);
         if (is_representative(key, d, complements)) hit = 1;
     }
     hitS[i] = hit;
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nP) return;
     u8 hit = 0;
-    if (t.flags[pslot[i]] & 2u) {
+    if (!(t.flags[pslot[i]] & 2u)) {
         Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
         if (is_representative(key, d, complements)) hit = 1;
     }
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
             return;
         }
     }
-    kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, (u32)t, scrS + t, scrP + b0);
+    kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, g.tag_base + (u32)t, scrS + t, scrP + b0);
 }
 
 // one wavefront per medium bucket (descriptors listed by ov_match_kernel); the grid is an upper bound, surplus blocks exit
@@ -390,7 +390,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u64 tcap = 64;
     while (tcap < 2 * V + 16) tcap <<= 1;
     LevelTable<W> tab;
-    KC_TRY(scope.alloc(&tab.slot, tcap)); KC_TRY(scope.alloc(&tab.flags, tcap));
+    KC_TRY(scope.alloc(&tab.slot, tcap + tcap / 2 + 1));   // slots (8 B) directly followed by the flags (4 B): one fill per level
+    tab.flags = nullptr;
     // hit buffers
     u64 *hs_ids, *hp_ids, *hs_keys, *hp_keys, *hs_ids2, *hp_ids2, *hs_keys2, *hp_keys2, *sc0, *sc1, *sc2, *sc3;
     KC_TRY(scope.alloc(&hs_ids, V)); KC_TRY(scope.alloc(&hp_ids, V)); KC_TRY(scope.alloc(&hs_ids2, V)); KC_TRY(scope.alloc(&hp_ids2, V));
@@ -408,8 +409,12 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
     g.first_snap = first_snap; g.last_snap = last_snap;
     g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0;
-    u64 nS = V, nP = V, repairs = 0;
+    u64 nS = V, nP = V, repairs = 0, tag_base = 0;
     std::vector<u64> h_bl;
+    if (!lower_bound) {   // tag 0xffffffff = written by nobody
+        KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
+    }
 
     u64 *hp = nullptr;   // pinned readback buffer
     KC_HIP(ctx, hipHostMalloc((void **)&hp, 64, hipHostMallocDefault));
@@ -419,8 +424,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         u64 lcap = 64;
         while (lcap < 2 * nP + 16) lcap <<= 1;
         tab.mask = lcap - 1;
-        KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 8, ctx->stream));
-        KC_HIP(ctx, hipMemsetAsync(tab.flags, 0, lcap * 4, ctx->stream));
+        tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
+        KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 128, ctx->stream));
         hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                            (const u64 *)pre, k, d, pslot);
@@ -446,9 +451,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         const u64 max_new = (complements ? 2 : 1) * nHS;   // every event logs at most 1 (+1 mirrored) edge
         while (true) {
             KC_HIP(ctx, hipMemsetAsync(cnt, 0, 128, ctx->stream));
-            if (!lower_bound) {   // forget the path-end entries other levels / replays wrote (tag = none)
-                KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
-                KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
+            if (!lower_bound) {
+                // path-end entries carry the tag of the bucket that wrote them; every launch draws its tags from a fresh
+                // range, so entries of other levels / replays are simply never trusted (no clearing between launches)
+                if (tag_base + nHS >= 0xfffffff0ull) {
+                    KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
+                    KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
+                    tag_base = 0;
+                }
+                g.tag_base = (u32)tag_base;
+                tag_base += nHS;
             }
             hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
                                (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8);
@@ -511,7 +523,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
     scope.release(big);
     void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt, bl, w.d_num,
-                   tab.slot, tab.flags, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
+                   tab.slot, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
     for (void *p : rel) scope.release(p);
     return KC_OK;
 }

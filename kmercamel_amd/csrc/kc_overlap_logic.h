@@ -38,6 +38,7 @@ struct OvArgs {
     u64 *ne_count;
     const u64 *bl;      // blacklist of (u, c) pairs proven to close a cycle
     u64 nbl;
+    u32 tag_base = 0;   // first writer tag of the current launch (tags are never reused between launches)
 };
 
 #define KC_MODE_UNI 0

@@ -182,13 +182,13 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
                 if ((low[fp >> 6] >> (fp & 63)) & 1) continue;
             }
             const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
-            const u64 kh = key_hash(key);
+            const u64 kh = key_place_hash(key);
             u64 home;
             if (m) {
                 u32 mmh = ~0u;
                 for (int j = 0; j < win; ++j) { u32 h = kc_ring[j * blockDim.x + threadIdx.x]; mmh = h < mmh ? h : mmh; }
                 home = set_block_home(set, mmh, kh);
-            } else home = kc_mulhi64(kh, set.cap);
+            } else home = kc_mulhi64(kc_mix64(kh), set.cap);
             u64 slot;
             int r = set_insert_at(set, key, kh, home, &slot);
             if (occ_counts && r >= 0) atomicAdd(&occ_counts[slot], 1u);   // AddKMersWithFrequencies (parser.h:51-85)

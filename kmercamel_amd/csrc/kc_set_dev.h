@@ -32,12 +32,13 @@ template <int W> struct SetView {
     u32 local_probes;
 };
 
-KC_HD u8 kc_tag_of(u64 keyhash) { return (u8)(0x80u | (u32)(keyhash >> 57)); }
+// `ph` below is always key_place_hash(key): bits 0..bshift-1 give the offset inside a block, bits 25..31 the tag.
+KC_HD u8 kc_tag_of(u64 ph) { return (u8)(0x80u | ((u32)ph >> 25)); }
 
 // hash of a canonical m-mer (f forward, r its reverse complement), 32 bit
 KC_HD u32 kc_mmer_hash(u32 f, u32 r) {
     u32 c = f < r ? f : r;
-    c *= 0x9E3779B1u; c ^= c >> 15; c *= 0x85EBCA77u; c ^= c >> 13;
+    c *= 0x9E3779B1u; c ^= c >> 15;   // one multiply: this runs once per base in the insert kernel and 25x per k-mer in the probe kernel
     return c;
 }
 // smallest canonical m-mer hash over the m-mers starting at positions i0..i1 (inclusive) of the k-mer x
@@ -63,7 +64,7 @@ template <int W> KC_HD u32 key_min_mmh(const Key<W> &x, int k, int m, int i0, in
 // block home from a minimizer hash and the key hash
 template <int W> KC_HD u64 set_block_home(const SetView<W> &s, u32 mmh, u64 keyhash) {
     // mmh is a minimum of ~k-m+1 uniform hashes, i.e. concentrated near 0: re-mix it before the range reduction
-    u32 u = mmh * 0x85EBCA6Bu; u ^= u >> 16; u *= 0xC2B2AE35u; u ^= u >> 13; u *= 0x27D4EB2Fu; u ^= u >> 16;
+    u32 u = mmh * 0x85EBCA6Bu; u ^= u >> 16; u *= 0xC2B2AE35u;   // the range reduction below takes the high bits
     u64 blk = ((u64)u * s.nblocks) >> 32;
     return (blk << s.bshift) | (keyhash & (((u64)1 << s.bshift) - 1));
 }
@@ -71,7 +72,7 @@ template <int W> KC_HD u64 set_global_home(const SetView<W> &s, u64 keyhash) {
     return kc_mulhi64(kc_mix64(keyhash ^ 0x6a09e667f3bcc909ULL), s.cap);
 }
 template <int W> KC_HD u64 set_home_kh(const SetView<W> &s, const Key<W> &key, u64 keyhash) {
-    if (s.m == 0) return kc_mulhi64(keyhash, s.cap);
+    if (s.m == 0) return kc_mulhi64(kc_mix64(keyhash), s.cap);
     return set_block_home(s, key_min_mmh(key, s.k, s.m, 0, s.k - s.m), keyhash);
 }
 // XCD-aware workgroup order for kernels that sweep the table: workgroups are dealt round-robin over the 8 XCDs, so give
@@ -93,13 +94,18 @@ template <int W> KC_HD u64 set_probe_slot(const SetView<W> &s, u64 home, u64 gho
 }
 
 #if defined(__HIPCC__)
+// tag of a freshly inserted key; the first 8 tags are mirrored behind the table for set_scan's unaligned 8-byte loads
+template <int W> __device__ __forceinline__ void set_write_tag(const SetView<W> &s, u64 slot, u8 tag) {
+    s.tags[slot] = tag;
+    if (slot < 8) s.tags[s.cap + slot] = tag;
+}
 
 
 // Insert during the build kernel (concurrent with other inserts). Returns 1 if this call added the key, 0 if it was
 // present, -1 if the table is full. *slot_out receives the slot.
 template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, u64 kh, u64 home, u64 *slot_out);
 template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, const Key<W> &key, u64 *slot_out) {
-    const u64 kh = key_hash(key);
+    const u64 kh = key_place_hash(key);
     return set_insert_at(s, key, kh, set_home_kh(s, key, kh), slot_out);
 }
 // `home` = set_home_kh(s, key, kh) (callers that know the minimizer hash already pass set_block_home(...))
@@ -115,7 +121,7 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
             if (cur == kv) { *slot_out = slot; return 0; }
             if (cur == ~0ULL) {
                 unsigned long long prev = atomicCAS(&keys[slot], ~0ULL, kv);
-                if (prev == ~0ULL) { s.tags[slot] = kc_tag_of(kh); *slot_out = slot; return 1; }
+                if (prev == ~0ULL) { set_write_tag(s, slot, kc_tag_of(kh)); *slot_out = slot; return 1; }
                 if (prev == kv) { *slot_out = slot; return 0; }
             }
         }
@@ -137,7 +143,7 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
                     for (int i = 0; i < W; ++i)
                         __hip_atomic_store(&s.keys[slot * W + i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&s.state[slot], KC_ST_FULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    s.tags[slot] = kc_tag_of(kh);
+                    set_write_tag(s, slot, kc_tag_of(kh));
                     *slot_out = slot;
                     return 1;
                 }
@@ -151,35 +157,35 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
 }
 
 // Lookup in a finished table (launched after the build kernels completed). Returns the slot or KC_NONE64.
-// Tag scan: `count` slots from `start` (wrapping), 8 per aligned 8-byte load. Returns the slot, KC_NONE64 for a proven
+// Tag scan: `count` slots from `start` (wrapping), 8 per (unaligned) 8-byte load. Returns the slot, KC_NONE64 for a proven
 // miss (an empty slot was reached), or KC_SCAN_MORE when neither happened within `count` slots.
 #define KC_SCAN_MORE (~(u64)1)
 template <int W> __device__ __forceinline__ u64 set_scan(const SetView<W> &s, const Key<W> &key, u8 tag, u64 start, u64 count) {
     const u64 pat = 0x0101010101010101ULL * (u64)tag, hi7 = 0x8080808080808080ULL, lo7 = 0x7f7f7f7f7f7f7f7fULL;
-    u64 wbase = start & ~(u64)7;
-    int off = (int)(start & 7);
+    u64 pos = start;
     while (count) {
-        u64 word = *reinterpret_cast<const u64 *>(s.tags + wbase);
-        int nvalid = 8 - off;
-        if ((u64)nvalid > count) nvalid = (int)count;
+        // 8 tags from `pos` on in one unaligned load (tags[cap..cap+7] mirror tags[0..7], so no wrap handling here)
+        u64 word;
+        __builtin_memcpy(&word, s.tags + pos, 8);
         u64 x = word ^ pat;
         u64 zero = ~(((x & lo7) + lo7) | x | lo7);   // 0x80 in every byte of x that is 0  (tag match)
         u64 empty = ~word & hi7;                      // valid tags have bit 7 set
-        u64 valid = (nvalid == 8 ? ~(u64)0 : ((((u64)1 << (8 * nvalid)) - 1))) << (8 * off);
-        u64 cand = (zero | empty) & valid;
+        u64 cand = zero | empty;
+        if (count < 8) cand &= ((u64)1 << (8 * count)) - 1;
         while (cand) {
             int b = __builtin_ctzll(cand) >> 3;
-            u64 slot = wbase + (u64)b;
             if ((empty >> (8 * b)) & 0x80) return KC_NONE64;
+            u64 slot = pos + (u64)b;
+            if (slot >= s.cap) slot -= s.cap;
             bool eq = true;
             for (int i = 0; i < W; ++i) eq = eq && (s.keys[slot * W + i] == key.w[i]);
             if (eq) return slot;
             cand &= cand - 1;
         }
-        count -= (u64)nvalid;
-        off = 0;
-        wbase += 8;
-        if (wbase >= s.cap) wbase = 0;
+        if (count <= 8) break;
+        count -= 8;
+        pos += 8;
+        if (pos >= s.cap) pos -= s.cap;
     }
     return KC_SCAN_MORE;
 }
@@ -193,7 +199,7 @@ template <int W> __device__ __forceinline__ u64 set_find_from(const SetView<W> &
     return r == KC_SCAN_MORE ? KC_NONE64 : r;
 }
 template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) {
-    const u64 kh = key_hash(key);
+    const u64 kh = key_place_hash(key);
     return set_find_from(s, key, kh, set_home_kh(s, key, kh));
 }
 

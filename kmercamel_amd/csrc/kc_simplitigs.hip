@@ -58,6 +58,42 @@ __device__ __forceinline__ void kc_push_head(u64 pid, int complements, u64 *head
     if (pos < heads_cap) heads[pos] = pid;
 }
 
+// Round 1 lists its heads and branch ports through KC_NSHARD cursors (one 128-byte line each, picked by workgroup): chain
+// heads are sparse (2 per simplitig), so the compiler's wave-level aggregation of the atomic leaves ~1 atomic per event,
+// and ~10^5..10^6 atomics on ONE address serialise at ~13 ns each -- longer than the kernel's real work.  The sharded
+// lists are gathered into one contiguous list afterwards (kc_gather_shards_kernel).
+#define KC_NSHARD 64
+#define KC_SHARD_STRIDE 16
+__device__ __forceinline__ void kc_push_sharded(u64 val, u64 *list, u64 shard_cap, u64 *cursors) {
+    const u64 sh = blockIdx.x & (KC_NSHARD - 1);
+    u64 pos = atomicAdd((ull *)&cursors[sh * KC_SHARD_STRIDE], 1ULL);
+    if (pos < shard_cap) list[sh * shard_cap + pos] = val;
+}
+// grid (x, KC_NSHARD): shard blockIdx.y is copied behind the shards before it; *total_out = total, or dst_cap + 1 when a
+// shard (or the destination) overflowed, which the caller treats like any other list overflow.
+__global__ void __launch_bounds__(256) kc_gather_shards_kernel(const u64 *__restrict__ src, u64 shard_cap, const u64 *__restrict__ cursors,
+                                                               u64 *dst, u64 dst_cap, u64 *total_out) {
+    __shared__ u64 pre[KC_NSHARD + 1];
+    __shared__ int ovf;
+    if (threadIdx.x == 0) {
+        u64 a = 0;
+        int o = 0;
+        for (int sh = 0; sh < KC_NSHARD; ++sh) {
+            u64 c = cursors[sh * KC_SHARD_STRIDE];
+            if (c > shard_cap) { o = 1; c = shard_cap; }
+            pre[sh] = a;
+            a += c;
+        }
+        pre[KC_NSHARD] = a;
+        ovf = o || a > dst_cap;
+    }
+    __syncthreads();
+    const u64 sh = blockIdx.y, base = pre[sh], n = pre[sh + 1] - pre[sh];
+    if (!ovf)
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[base + i] = src[sh * shard_cap + i];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_out = ovf ? dst_cap + 1 : pre[KC_NSHARD];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Ordered compaction of the occupied slots (tag != 0) into `occ`: per 2048-slot tile a count, an exclusive scan of the
 // tile counts, then every wave ranks its 64 slots with a ballot + popcount prefix and scatters.  Keeps slot order, so
@@ -111,97 +147,211 @@ __global__ void __launch_bounds__(256) kc_occ_fill_kernel(const u8 *__restrict__
 
 // Round 1 over the compacted k-mers: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
 // over the m-mer hashes whose prefix/suffix minima give both ports' shared minimizer part).
+// `stage` (LDS) holds the tag bytes of table block `sblk` (+ 8 bytes of the next one) when sblk != ~0: see the kernel below.
 template <int W, int KC>
-__global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
-                                                              const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
-                                                              u64 heads_cap, u64 *heads_cursor, u64 *branch, u64 branch_cap,
-                                                              u64 *branch_cursor, u64 *splits, u64 splits_cap, u64 *splits_cursor) {
+__device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *__restrict__ link, int k_rt, int complements, const u64 slot,
+                                                    const u64 *stage, const u64 sblk, u64 *heads, u64 heads_shard_cap, u64 *heads_cursors,
+                                                    u64 *branch, u64 branch_shard_cap, u64 *branch_cursors) {
     const int k = KC ? KC : k_rt;
     const int m = KC ? 15 : set.m;
-    u64 t = kc_xcd_block_id(xcd_aware) * blockDim.x + threadIdx.x;
-    if (t >= nocc) return;
-    const u64 slot = occ[t];
     const Key<W> x = set_key_at(set, slot);
     const Key<W> xr = key_rc(x, k);
-    const bool xpal = complements && key_eq(x, xr);
+    const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
     u32 sharedR = ~0u, sharedL = ~0u;   // min over m-mer positions 1..k-m (append side) / 0..k-m-1 (prepend side)
+    u32 f_first = 0, r_first = 0, f_last = 0, r_last = 0;   // first / last m-mer of x, forward and reverse complement
     if (m) {
         const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
         const int top = 2 * (m - 1);
         u32 f = 0, r = 0;
+        if constexpr (W != 1) {
 #pragma unroll
-        for (int j = 0; j < m - 1; ++j) {
-            u32 b = key_at(x, k, j);
-            f = (f << 2) | b;
-            r = (r >> 2) | ((3u - b) << top);
+            for (int j = 0; j < m - 1; ++j) {
+                u32 b = key_at(x, k, j);
+                f = (f << 2) | b;
+                r = (r >> 2) | ((3u - b) << top);
+            }
         }
         u32 first = ~0u, mid = ~0u, last = ~0u;
 #pragma unroll
         for (int i = 0; i <= k - m; ++i) {
-            u32 b = key_at(x, k, i + m - 1);
-            f = ((f << 2) | b) & maskm;
-            r = (r >> 2) | ((3u - b) << top);
+            if constexpr (W == 1) {   // one word: every m-mer is a shift of x / RC(x), no serial dependency between positions
+                f = (u32)(x.w[0] >> (2 * (k - m - i))) & maskm;
+                r = (u32)(xr.w[0] >> (2 * i)) & maskm;
+            } else {
+                u32 b = key_at(x, k, i + m - 1);
+                f = ((f << 2) | b) & maskm;
+                r = (r >> 2) | ((3u - b) << top);
+            }
             u32 h = kc_mmer_hash(f, r);
-            if (i == 0) first = h;
-            else if (i == k - m) last = h;
-            else mid = h < mid ? h : mid;
+            if (i == 0) { first = h; f_first = f; r_first = r; }
+            if (i == k - m) last = h;
+            if (i != 0 && i != k - m) mid = h < mid ? h : mid;
         }
+        f_last = f; r_last = r;
         if (k - m == 0) { sharedR = ~0u; sharedL = ~0u; }
         else { sharedR = mid < last ? mid : last; sharedL = mid < first ? mid : first; }
     }
-    const u64 hxk = key_hash(x);
-    // every ~256th k-mer (by key hash) is a splitter: chains are walked segment-wise between splitters
-    const u64 splitbit = (((hxk >> 24) & 0xffull) == 0) ? LK_SPLIT : 0;
-    if (splitbit) {
-        u64 pos = atomicAdd((ull *)splits_cursor, 1ULL);
-        if (pos < splits_cap) splits[pos] = slot;
+    // every ~256th k-mer (by slot) is a splitter: chains are walked segment-wise between splitters
+    const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;
+    // The 8 candidate lookups are independent, so they are issued as a batch: (A) all candidate keys and their homes,
+    // (B) all first tag windows (one unaligned 8-byte load each), (C) the key loads of the tag hits, (D) compares.  A
+    // lookup that the first window does not settle (tag false positive, probe run longer than 8) is rare; those are
+    // redone by the generic scan in ONE loop after the batch, so a wave pays that latency once, not once per candidate.
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const int top = 2 * (m - 1);
+    // candidate (port, c): canonical key y, the port q it is entered on, placement hash and home
+    auto make_cand = [&](const int port, const u32 c, Key<W> &y, int &q, u64 &hy, u64 &home) {
+        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+        y = nf;
+        if (complements) {
+            Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
+            bool pal = (KC & 1) ? false : key_eq(nf, r);
+            bool fwd = !key_lt(r, nf);
+            if (!fwd) y = r;
+            q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
+        } else {
+            q = port ? 0 : 1;
+        }
+        hy = key_place_hash(y);
+        if (m) {
+            // the one m-mer the candidate does not share with x, one shift away from x's last / first m-mer
+            u32 nfw = port ? (((f_last << 2) | c) & maskm) : ((f_first >> 2) | (c << top));
+            u32 nrc = port ? ((r_last >> 2) | ((3u - c) << top)) : (((r_first << 2) | (3u - c)) & maskm);
+            u32 h = kc_mmer_hash(nfw, nrc);
+            const u32 shared = port ? sharedR : sharedL;
+            home = set_block_home(set, h < shared ? h : shared, hy);
+        } else home = kc_mulhi64(kc_mix64(hy), set.cap);
+    };
+    Key<W> cy[8];
+    u64 chome[8], cph[8], cword[8], cslot[8];
+    u32 live = 0, qbits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int q;
+        make_cand(i >> 2, (u32)(i & 3), cy[i], q, cph[i], chome[i]);
+        const bool ok = !key_eq(cy[i], x) && !((i >> 2) == 1 && xpal);   // no self edges; palindromes link on port L only
+        live |= (u32)ok << i;
+        qbits |= (u32)q << i;
+    }
+    // first tag window of every candidate: from the staged block (LDS) when the home lies in it, else from global memory
+    u32 inblk = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 in = (chome[i] >> set.bshift) == sblk ? 1u : 0u;
+        inblk |= in << i;
+        if (!in) __builtin_memcpy(&cword[i], set.tags + chome[i], 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((inblk >> i) & 1) {
+            const u32 o = (u32)chome[i] & ((1u << set.bshift) - 1u);
+            const u64 w0 = stage[o >> 3], w1 = stage[(o >> 3) + 1];
+            const u32 sh = (o & 7u) * 8u;
+            cword[i] = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+        }
+    // branch-free on purpose: a conditional here lets the compiler sink a candidate's load into the branch and wait for it
+    u32 pending = 0, slow = 0, settled2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u64 hi7 = 0x8080808080808080ULL, lo7 = 0x7f7f7f7f7f7f7f7fULL;
+        u32 t32 = kc_tag_of(cph[i]);
+        t32 |= t32 << 8; t32 |= t32 << 16;
+        const u64 xw = cword[i] ^ (((u64)t32 << 32) | t32);
+        const u64 zero = ~(((xw & lo7) + lo7) | xw | lo7);
+        const u64 empty = ~cword[i] & hi7;
+        const u64 cand = zero | empty;
+        const u32 lv = (live >> i) & 1u;
+        const u32 none = cand == 0 ? 1u : 0u;                        // window full of other tags: keep scanning (slow path)
+        const int b = __builtin_ctzll(cand | ((u64)1 << 63)) >> 3;
+        const u32 hit = (u32)(((empty >> (8 * b)) & 0x80) == 0) & (none ^ 1u);   // first candidate is a tag match, not an empty slot
+        u64 sl = chome[i] + (u64)b;
+        sl = sl >= set.cap ? sl - set.cap : sl;
+        const u32 pend = lv & hit;
+        // if that tag match turns out to be another key, the next candidate of the window usually is the empty slot
+        // that proves the miss: note it now, so that a tag false positive does not cost a trip through the slow path
+        const u64 cand2 = cand & (cand - 1);
+        const int b2 = __builtin_ctzll(cand2 | ((u64)1 << 63)) >> 3;
+        const u32 miss2 = (u32)(cand2 != 0) & (u32)(((empty >> (8 * b2)) & 0x80) != 0);
+        slow |= (lv & none) << i;
+        pending |= pend << i;
+        settled2 |= miss2 << i;
+        cslot[i] = pend ? sl : slot;   // non-pending candidates re-read x's own slot: an unconditional, harmless load
+    }
+    Key<W> ck[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ck[i] = set_key_at(set, cslot[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 pend = (pending >> i) & 1u;
+        const u32 eq = key_eq(ck[i], cy[i]) ? 1u : 0u;
+        slow |= (pend & (eq ^ 1u) & (((settled2 >> i) & 1u) ^ 1u)) << i;   // tag false positive, miss not proven yet: slow path
+        cslot[i] = (pend & eq) ? cslot[i] : KC_NONE64;
+    }
+    while (slow) {   // rare per lane, but some lane of nearly every wave gets here: redo only the scan, from the known home
+        const int i = __builtin_ctz(slow);
+        slow &= slow - 1;
+        Key<W> y; int q; u64 hy, home;
+        make_cand(i >> 2, (u32)(i & 3), y, q, hy, home);
+        const u64 ts = set_find_from(set, y, hy, home);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j == i) cslot[j] = ts;
     }
 #pragma unroll
     for (int port = 0; port < 2; ++port) {
         const u64 pid = (slot << 1) | (u64)port;
-        if (port == 1 && xpal) {   // palindromes link on port L only
+        if (port == 1 && xpal) {
             link[pid] = LK_DEAD | splitbit;
-            kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
+            if (complements) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);
             continue;
         }
-        const u32 shared = port ? sharedR : sharedL;
         int nfound = 0;
-        Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0, bhy = 0; u32 bbase = 0;
+        Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0, hxk = 0; u32 bbase = 0;
 #pragma unroll
         for (u32 c = 0; c < 4; ++c) {
-            Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
-            Key<W> y = nf;
-            int q;
-            if (complements) {
-                Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
-                bool pal = key_eq(nf, r);
-                bool fwd = !key_lt(r, nf);
-                if (!fwd) y = r;
-                q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
-            } else {
-                q = port ? 0 : 1;
-            }
-            if (key_eq(y, x)) continue;
-            const u64 hy = key_hash(y);
-            u64 home;
-            if (m) {
-                u32 f = port ? (u32)(nf.w[0] & ((m >= 16) ? ~0u : ((1u << (2 * m)) - 1u))) : (u32)key_prefix(nf, k, m).w[0];
-                u32 h = kc_mmer_hash(f, kc_mmer_rc(f, m));
-                home = set_block_home(set, h < shared ? h : shared, hy);
-            } else home = kc_mulhi64(hy, set.cap);
-            u64 tslot = set_find_from(set, y, hy, home);
+            const int i = port * 4 + (int)c;
+            const u64 tslot = cslot[i];
             if (tslot == KC_NONE64) continue;
-            if (nfound == 0) { by = y; bq = q; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; nfound = 1; continue; }
-            if (nfound == 1) { bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(bhy, bq)); nfound = 2; }
-            u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(hy, q));
-            if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
+            const Key<W> y = cy[i];
+            const int q = (int)((qbits >> i) & 1);
+            if (nfound == 0) { by = y; bq = q; bslot = tslot; bbase = port ? c : 3 - c; nfound = 1; continue; }
+            // priorities (the layout-free key hash) are only needed to choose between two existing candidates
+            if (nfound == 1) { hxk = key_hash(x); bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(by), bq)); nfound = 2; }
+            u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
+            if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bbase = port ? c : 3 - c; }
         }
         link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD) | splitbit;
-        if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
-        if (nfound >= 2) {   // branch port: it will have to reject the candidates it did not choose
-            u64 pos = atomicAdd((ull *)branch_cursor, 1ULL);
-            if (pos < branch_cap) branch[pos] = pid;
-        }
+        if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+        if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);   // branch port: it has to reject the others
+    }
+}
+
+// The kernel: a workgroup owns KC_CHOOSE_PER_WG consecutive entries of `occ` (slot order, i.e. mostly one table block) and
+// first copies that block's tag bytes into LDS.  ~90 % of the candidate lookups start in that very block (shared
+// minimizer), so their tag windows are read from LDS instead of each dragging a 128-byte line through the L1: the kernel
+// was bound by exactly that L2->L1 fill traffic (8 scattered tag lines per k-mer), not by HBM, ALU work or latency.
+#define KC_CHOOSE_PER_WG 1024
+template <int W, int KC>
+__global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
+                                                              const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
+                                                              u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
+                                                              u64 branch_shard_cap, u64 *branch_cursors, int stage_words) {
+    extern __shared__ u64 kc_stage[];
+    const u64 t0 = kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_PER_WG;
+    if (t0 >= nocc) return;
+    u64 sblk = ~(u64)0;
+    if (stage_words) {
+        sblk = occ[t0] >> set.bshift;
+        const u64 *src = reinterpret_cast<const u64 *>(set.tags + (sblk << set.bshift));
+        for (int j = threadIdx.x; j < stage_words; j += 256) kc_stage[j] = src[j];
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int it = 0; it < KC_CHOOSE_PER_WG / 256; ++it) {
+        const u64 t = t0 + (u64)it * 256 + threadIdx.x;
+        if (t >= nocc) break;
+        kc_choose_dense_one<W, KC>(set, link, k_rt, complements, occ[t], kc_stage, sblk, heads, heads_shard_cap, heads_cursors, branch,
+                                   branch_shard_cap, branch_cursors);
     }
 }
 
@@ -291,7 +441,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
     }
     const u64 hxk = key_hash(x);
     int nfound = 0;
-    Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0, bhy = 0; u32 bbase = 0;
+    Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0; u32 bbase = 0;
 #pragma unroll
     for (u32 c = 0; c < 4; ++c) {
         Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
@@ -308,13 +458,13 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
             q = port ? 0 : 1;
         }
         if (key_eq(y, x)) continue;
-        const u64 hy = key_hash(y);
+        const u64 hy = key_place_hash(y);
         u64 home;
         if (m) {
             u32 f = port ? (u32)(nf.w[0] & ((m >= 16) ? ~0u : ((1u << (2 * m)) - 1u))) : (u32)key_prefix(nf, k, m).w[0];
             u32 h = kc_mmer_hash(f, kc_mmer_rc(f, m));
             home = set_block_home(set, h < shared ? h : shared, hy);
-        } else home = kc_mulhi64(hy, set.cap);
+        } else home = kc_mulhi64(kc_mix64(hy), set.cap);
         u64 tslot = set_find_from(set, y, hy, home);
         if (tslot == KC_NONE64) continue;
         if (!FIRST) {
@@ -322,10 +472,10 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
             if (LK_IS_MATCHED(wt)) continue;
         }
         // priorities are only needed to choose between two existing candidates
-        if (nfound == 0) { by = y; bq = q; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; nfound = 1; continue; }
-        if (nfound == 1) { bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(bhy, bq)); nfound = 2; }
-        u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(hy, q));
-        if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bhy = hy; bbase = port ? c : 3 - c; }
+        if (nfound == 0) { by = y; bq = q; bslot = tslot; bbase = port ? c : 3 - c; nfound = 1; continue; }
+        if (nfound == 1) { bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(by), bq)); nfound = 2; }
+        u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
+        if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bbase = port ? c : 3 - c; }
     }
     // FIRST is no longer launched (round 1 = kc_choose_dense_kernel); later rounds mark their choice as tentative
     link[pid] = (nfound ? (LK_MAKE(LK_CHOICE, bq, bbase, bslot) | (FIRST ? 0 : LK_REJ)) : LK_DEAD) | (link[pid] & LK_SPLIT);
@@ -404,7 +554,10 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         if (!LK_IS_MATCHED(w)) break;
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
-        if (++len > limit) { atomicExch((ull *)(cursor + 7), 1ULL); return; }
+        if (++len > limit) {
+            if (__hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicExch((ull *)(cursor + 7), 1ULL);
+            return;
+        }
     }
     Key<W> hk = set_key_at(set, slot);
     bool winner = true;
@@ -519,11 +672,11 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
 // of its segments (length/256 steps) to get the chain's length, tail and segment offsets; segments finally emit their
 // bases in parallel.  A multi-Mbp chain therefore costs ~256 sequential steps instead of millions.
 #define KC_SEG_NONE (~(u64)0)
-__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, const u64 *__restrict__ splits, u64 nsplit,
+__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, const u8 *__restrict__ tags, u64 cap,
                                                               int complements, u64 *starts, u64 *cursor) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nsplit) return;
-    const u64 slot = splits[t];
+    // splitters are the occupied slots whose index is a multiple of 256 (the choose kernel flags exactly those LK_SPLIT)
+    const u64 slot = ((u64)blockIdx.x * blockDim.x + threadIdx.x) << 8;
+    if (slot >= cap || tags[slot] == 0) return;
     const int no = complements ? 2 : 1;
     for (int o = 0; o < no; ++o) {
         u64 w = link[(slot << 1) | (u64)o];          // entry port of orientation o is port o
@@ -690,7 +843,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 *link = nullptr, *cnt = nullptr;
     KC_TRY(scope.alloc(&link, nports));
     KC_TRY(scope.alloc(&cnt, 8));
-    KC_HIP(ctx, hipMemsetAsync(link, 0, nports * 8, ctx->stream));
+    // (no clearing of `link`: round 1 writes both words of every occupied slot, and nothing ever reads an empty slot's)
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     // heads (ports that die) and the work list of unresolved ports are collected on the fly into bounded buffers; an
     // overflow (never seen on read-like inputs) falls back to exact counting passes.
@@ -720,19 +873,35 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
     const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
     u64 *branch = work_b, *branch_cursor = cnt + 4;   // branch ports of round 1 (work_b is free until round 2)
-    const u64 splits_cap = N / 64 + 65536;             // expected N/256 splitters
-    u64 *splits = nullptr, *splits_cursor = cnt + 5;
-    KC_TRY(scope.alloc(&splits, splits_cap));
+    // sharded round-1 lists (gathered into `heads` / `branch` right after the kernel)
+    u64 *heads_sh = nullptr, *branch_sh = nullptr, *shard_cur = nullptr;
+    const u64 heads_shard_cap = heads_cap / KC_NSHARD, branch_shard_cap = work_cap / KC_NSHARD;
+    KC_TRY(scope.alloc(&heads_sh, heads_shard_cap * KC_NSHARD));
+    KC_TRY(scope.alloc(&branch_sh, branch_shard_cap * KC_NSHARD));
+    KC_TRY(scope.alloc(&shard_cur, 2 * KC_NSHARD * KC_SHARD_STRIDE));
+    KC_HIP(ctx, hipMemsetAsync(shard_cur, 0, 2 * KC_NSHARD * KC_SHARD_STRIDE * 8, ctx->stream));
+    u64 *heads_cursors = shard_cur, *branch_cursors = shard_cur + KC_NSHARD * KC_SHARD_STRIDE;
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    // tag staging: one table block's tags (+ 8 bytes) in LDS, when the set has minimizer blocks of at most 32 KB
+    const int stage_words = (set->mlen && set->bshift <= 15 && !getenv("KC_NOSTAGE")) ? (int)(((u64)1 << set->bshift) / 8 + 1) : 0;
+    const size_t stage_lds = (size_t)stage_words * 8;
+    const unsigned cgrid = kc_grid8(N, KC_CHOOSE_PER_WG);
     if (k31)
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor, splits, splits_cap, splits_cursor);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
+                           stage_words);
     else
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(kc_grid8(N, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads, heads_cap, heads_cursor, branch, work_cap, branch_cursor, splits, splits_cap, splits_cursor);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
+                           (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
+                           stage_words);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
+                       (const u64 *)heads_cursors, heads, heads_cap, heads_cursor);
+    hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)branch_sh, branch_shard_cap,
+                       (const u64 *)branch_cursors, branch, work_cap, branch_cursor);
     u64 nbranch = 0, nwork = 0, rounds = 1;
     KC_TRY(read_u64(ctx, branch_cursor, &nbranch));
+    scope.release(heads_sh); scope.release(branch_sh); scope.release(shard_cur);
     if (nbranch && nbranch <= work_cap) {
         hipLaunchKernelGGL((kc_reject_kernel<W>), dim3(kc_grid(nbranch, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)branch,
                            nbranch, work_a, work_cap, work_cursor);
@@ -771,8 +940,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rounds_out) *rounds_out = rounds;
 
     // chain heads
-    u64 nheads = 0, nsplit = 0;
-    KC_TRY(read_u64(ctx, splits_cursor, &nsplit));
+    u64 nheads = 0;
+    const u64 nsplit_max = (cap + 255) >> 8;   // splitters: occupied slots with index % 256 == 0
     KC_TRY(read_u64(ctx, heads_cursor, &nheads));
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
@@ -806,16 +975,15 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool too_long = hc[7] != 0;
     // ---- some chain is long: segment-parallel path (needs: no cycles, splitter list did not overflow)
-    if (too_long && nsplit <= splits_cap) {
-        const u64 max_starts = nheads + 2 * nsplit + 1;
+    if (too_long) {
+        const u64 max_starts = nheads + 2 * nsplit_max + 1;
         u64 *starts_raw = nullptr;
         KC_TRY(scope.alloc(&starts_raw, max_starts));
         KC_TRY(scope.alloc(&starts, max_starts));
         KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
-        if (nsplit)
-            hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)splits,
-                               nsplit, compl_, starts_raw, cnt + 6);
+        hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                           (const u8 *)set->tags, cap, compl_, starts_raw, cnt + 6);
         KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
         {
             size_t tb = 0;
@@ -843,7 +1011,6 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         seg_ok = (hc[3] == N);
         hc[1] = 0;
     }
-    scope.release(splits);
     // ---- long chains but the segment path is not applicable (cycles / splitter overflow): unlimited per-chain pass
     if (too_long && !seg_ok) {
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
