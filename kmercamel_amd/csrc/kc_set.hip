@@ -146,10 +146,10 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
 // rolling forward / reverse-complement windows up over the k-1 preceding bases, then rolls (parser.h:38-39) and
 // inserts the canonical k-mer (parser.h:44) of every window that holds k valid bases (and, if case_sensitive, whose
 // first base is upper case, parser.h:41-42).
-template <int W>
-__global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
-                                                        const u64 *__restrict__ low, u64 len, int k, int complements,
-                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt, u32 *occ_counts) {
+// kc_roll_kmers walks one thread's window run and hands every k-mer to `emit(key, minimizer hash, first position)`.
+template <int W, typename F>
+__device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len,
+                                              int k, int complements, int case_sensitive, int m, int ppt, u32 *ring, F &&emit) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 e0 = t * (u64)ppt;
     if (e0 >= len) return;
@@ -158,12 +158,9 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
     u64 s = e0 >= (u64)(k - 1) ? e0 - (u64)(k - 1) : 0;
     Key<W> cur = key_zero<W>(), rc = key_zero<W>();
     int run = 0;
-    u64 added = 0;
-    bool overflow = false;
     // minimizer: every base contributes ONE new canonical m-mer hash; the last k-m+1 of them live in a per-thread LDS
     // ring (ring[j * blockDim + tid], conflict-free), the k-mer's minimizer hash is the minimum over the ring
-    extern __shared__ u32 kc_ring[];
-    const int m = set.m, win = k - m + 1;
+    const int win = k - m + 1;
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     u64 cw = codes[s >> 5], bw = brk[s >> 6];
     for (u64 p = s; p < e1; ++p) {
@@ -175,29 +172,130 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
         rc = key_prepend(rc, 3 - b, k);
         if (run < k) ++run;
         if (m && run >= m)
-            kc_ring[(u32)(p % (u64)win) * blockDim.x + threadIdx.x] = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
+            ring[(u32)(p % (u64)win) * blockDim.x + threadIdx.x] = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
         if (p >= e0 && run >= k) {
             if (case_sensitive) {
                 u64 fp = p - (u64)(k - 1);
                 if ((low[fp >> 6] >> (fp & 63)) & 1) continue;
             }
             const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
-            const u64 kh = key_place_hash(key);
-            u64 home;
-            if (m) {
-                u32 mmh = ~0u;
-                for (int j = 0; j < win; ++j) { u32 h = kc_ring[j * blockDim.x + threadIdx.x]; mmh = h < mmh ? h : mmh; }
-                home = set_block_home(set, mmh, kh);
-            } else home = kc_mulhi64(kc_mix64(kh), set.cap);
-            u64 slot;
-            int r = set_insert_at(set, key, kh, home, &slot);
-            if (occ_counts && r >= 0) atomicAdd(&occ_counts[slot], 1u);   // AddKMersWithFrequencies (parser.h:51-85)
-            if (r > 0) ++added;
-            else if (r < 0) overflow = true;
+            u32 mmh = ~0u;
+            if (m)
+                for (int j = 0; j < win; ++j) { u32 h = ring[j * blockDim.x + threadIdx.x]; mmh = h < mmh ? h : mmh; }
+            emit(key, mmh);
         }
     }
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
+                                                        const u64 *__restrict__ low, u64 len, int k, int complements,
+                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt, u32 *occ_counts) {
+    extern __shared__ u32 kc_ring[];
+    u64 added = 0;
+    bool overflow = false;
+    const int m = set.m;
+    kc_roll_kmers<W>(codes, brk, low, len, k, complements, case_sensitive, m, ppt, kc_ring, [&](const Key<W> &key, u32 mmh) {
+        const u64 kh = key_place_hash(key);
+        const u64 home = m ? set_block_home(set, mmh, kh) : kc_mulhi64(kc_mix64(kh), set.cap);
+        u64 slot;
+        int r = set_insert_at(set, key, kh, home, &slot);
+        if (occ_counts && r >= 0) atomicAdd(&occ_counts[slot], 1u);   // AddKMersWithFrequencies (parser.h:51-85)
+        if (r > 0) ++added;
+        else if (r < 0) overflow = true;
+    });
     if (added) atomicAdd((ull *)&counters[0], (ull)added);
     if (overflow) atomicExch((ull *)&counters[1], 1ULL);
+}
+
+// ---- bucketed build (single-word keys): global CAS inserts pay a fabric atomic plus two scattered line round trips per
+// k-mer and were the slowest kernel of the path.  Instead (1) scatter the canonical k-mers into one bucket per table
+// block -- consecutive k-mers share their minimizer, so a thread reserves space once per RUN of equal blocks; (2) one
+// workgroup per block builds that block's 16384-slot table in LDS (LDS compare-and-swap, no global atomics) and writes it
+// out with coalesced stores; (3) the few keys whose 128 local probes were all taken go through the global insert.
+#define KC_BUCKET_PPT 16
+__global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
+                                                                const u64 *__restrict__ low, u64 len, int k, int complements,
+                                                                int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters) {
+    extern __shared__ u32 kc_ring[];
+    const int win = k - set.m + 1;
+    u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)win * blockDim.x);   // stage[j * blockDim + tid]: keys of the open run
+    const u64 bs = (u64)1 << set.bshift;
+    u32 nrun = 0;
+    u64 run_blk = 0;
+    bool overflow = false;
+    auto flush = [&]() {
+        if (!nrun) return;
+        const u64 base = atomicAdd((ull *)&bcursor[run_blk], (ull)nrun);
+        if (base + nrun <= bs) {
+            u64 *dst = bucket + (run_blk << set.bshift) + base;
+            for (u32 j = 0; j < nrun; ++j) dst[j] = stage[j * blockDim.x + threadIdx.x];
+        } else overflow = true;
+        nrun = 0;
+    };
+    kc_roll_kmers<1>(codes, brk, low, len, k, complements, case_sensitive, set.m, KC_BUCKET_PPT, kc_ring, [&](const Key<1> &key, u32 mmh) {
+        const u64 blk = set_block_home(set, mmh, 0) >> set.bshift;
+        if (nrun && blk != run_blk) flush();
+        run_blk = blk;
+        stage[nrun * blockDim.x + threadIdx.x] = key.w[0];
+        ++nrun;
+    });
+    flush();
+    if (overflow) atomicExch((ull *)&counters[3], 1ULL);
+}
+
+// one workgroup per table block; dynamic LDS: (1 << bshift) keys + (1 << bshift) tag bytes
+__global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<1> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
+                                                              int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap) {
+    extern __shared__ u64 kc_blk[];
+    const u32 bs = 1u << set.bshift;
+    u64 *lk = kc_blk;
+    u8 *lt = reinterpret_cast<u8 *>(kc_blk + bs);
+    __shared__ u32 added_s;
+    const u64 base = (u64)blockIdx.x << set.bshift;
+    if (threadIdx.x == 0) added_s = 0;
+    for (u32 i = threadIdx.x; i < bs; i += blockDim.x) lk[i] = fresh ? ~(u64)0 : set.keys[base + i];
+    for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
+        reinterpret_cast<u64 *>(lt)[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
+    __syncthreads();
+    u64 n = bcursor[blockIdx.x];
+    if (n > bs) n = bs;   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
+    const u32 span = set_block_span(set);
+    u32 added = 0;
+    for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
+        const u64 kv = bucket[base + j];
+        Key<1> key; key.w[0] = kv;
+        const u64 ph = key_place_hash(key);
+        const u32 off = (u32)(((u64)(u32)ph * span) >> 32);
+        bool done = false;
+        for (u32 p = 0; p < set.local_probes && !done; ++p) {
+            const u32 s = off + p;
+            u64 cur = lk[s];
+            if (cur == ~(u64)0) cur = atomicCAS((ull *)&lk[s], ~0ULL, (ull)kv);
+            if (cur == ~(u64)0) { lt[s] = kc_tag_of(ph); ++added; done = true; }
+            else if (cur == kv) done = true;
+        }
+        if (!done) {   // block-local run exhausted: the global insert (second home) takes it after all blocks are written
+            const u64 pos = atomicAdd((ull *)&counters[2], 1ULL);
+            if (pos < ovf_cap) ovf_list[pos] = kv;
+        }
+    }
+    if (added) atomicAdd(&added_s, added);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.keys[base + i] = lk[i];
+    for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x) reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(lt)[i];
+    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.cap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at cap
+    if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
+}
+
+__global__ void __launch_bounds__(256) kc_insert_list_kernel(SetView<1> set, const u64 *__restrict__ list, u64 n, u64 *counters) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Key<1> key; key.w[0] = list[t];
+    u64 slot;
+    int r = set_insert(set, key, &slot);
+    if (r > 0) atomicAdd((ull *)&counters[0], 1ULL);
+    else if (r < 0) atomicExch((ull *)&counters[1], 1ULL);
 }
 
 // re-insert into a new table; with counts: carry the occurrence counters, and keep only k-mers seen >= min_count times
@@ -257,9 +355,11 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     kc_set *s = new kc_set();
     s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
     s->mlen = k >= 16 ? 15 : 0;
-    s->bshift = 15;   // 32768 slots per block (256 KB of 64-bit keys): large enough that the skewed minimizer popularity does not overflow blocks
+    // slots per block: large enough that the skewed minimizer popularity does not overflow blocks; single-word keys use
+    // 16384 so that one block (128 KB of keys + 16 KB of tags) fits the LDS of a CU for the bucketed build
+    s->bshift = s->W == 1 ? 14 : 15;
     if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v < k) ? v : 0; }   // tuning/ablation knobs
-    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 6 && v <= 20) s->bshift = v; }
+    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= 20) s->bshift = v; }
     if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
     // target load 0.5 (shorter tag scans, measured 10 % faster neighbour probes) when table + links + occ list at that load
     // stay below 60 % of the device memory, else 0.66
@@ -349,24 +449,79 @@ int kcs_reserve(kc_set *set, u64 additional) {
     return kcs_rebuild(set, ncap, nnblocks, nkeys, nstate, ntags, 0);
 }
 
-int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
     kc_ctx *ctx = set->ctx;
-    if (len == 0) return KC_OK;
     int ppt = set->W == 1 ? 16 : (set->W == 2 ? 32 : 64);
     u64 nthreads = (len + ppt - 1) / ppt;
     const int win = set->mlen ? set->k - set->mlen + 1 : 1;
     const unsigned bs = win <= 40 ? 256 : (win <= 80 ? 128 : 64);    // LDS ring: win * bs * 4 bytes (<= 40 KB)
     const size_t lds = (size_t)win * bs * 4;
     unsigned g = kc_grid(nthreads, bs);
-    (void)hipEventRecord(ctx->ev[6], ctx->stream);
     switch (set->W) {
         case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts); break;
         case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt, set->counts); break;
         default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt, set->counts); break;
     }
-    (void)hipEventRecord(ctx->ev[7], ctx->stream);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
+}
+
+// bucketed build: see kc_bucket_scatter_kernel.  Needs single-word keys, minimizer blocks whose table fits the LDS of a
+// CU (16384 slots), no occurrence counting; small inputs are not worth the three launches.
+static bool bucketed_applies(const kc_set *set, u64 len) {
+    u64 min_len = (u64)1 << 20;
+    if (const char *e = getenv("KC_BUCKET_MIN")) min_len = (u64)atoll(e);   // tests force either path
+    return set->W == 1 && set->mlen && set->bshift <= 14 && set->bshift >= 9 && !set->counts && len >= min_len &&
+           set->local_probes + 8 < ((u32)1 << set->bshift) / 2;
+}
+
+static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+    kc_ctx *ctx = set->ctx;
+    KcScope scope(ctx);
+    const u64 bs = (u64)1 << set->bshift;
+    const u64 ovf_cap = (u64)1 << 20;
+    u64 *bucket = nullptr, *bcursor = nullptr, *ovf = nullptr;
+    KC_TRY(scope.alloc(&bucket, set->cap));
+    KC_TRY(scope.alloc(&bcursor, set->nblocks));
+    KC_TRY(scope.alloc(&ovf, ovf_cap));
+    KC_HIP(ctx, hipMemsetAsync(bcursor, 0, set->nblocks * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
+    const int win = set->k - set->mlen + 1;
+    const size_t lds_scatter = (size_t)win * 256 * 4 + (size_t)KC_BUCKET_PPT * 256 * 8;
+    const u64 nthreads = (len + KC_BUCKET_PPT - 1) / KC_BUCKET_PPT;
+    hipLaunchKernelGGL(kc_bucket_scatter_kernel, dim3(kc_grid(nthreads, 256)), dim3(256), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
+                       set->k, set->complements, case_sensitive, view_of<1>(set), bucket, bcursor, set->counters);
+    const size_t lds_build = (size_t)bs * 9;
+    static bool attr_done = false;
+    if (!attr_done) {
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_done = true;
+    }
+    const int fresh = set->size_host == 0 ? 1 : 0;
+    hipLaunchKernelGGL(kc_block_build_kernel, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, view_of<1>(set), (const u64 *)bucket,
+                       (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap);
+    KC_HIP(ctx, hipGetLastError());
+    u64 h[4] = {0, 0, 0, 0};
+    KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[3] || h[2] > ovf_cap)   // a bucket (or the spill list) overflowed: the global path inserts whatever is still missing
+        return insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);
+    if (h[2]) {
+        hipLaunchKernelGGL(kc_insert_list_kernel, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<1>(set), (const u64 *)ovf, h[2],
+                           set->counters);
+        KC_HIP(ctx, hipGetLastError());
+    }
+    return KC_OK;
+}
+
+int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+    kc_ctx *ctx = set->ctx;
+    if (len == 0) return KC_OK;
+    (void)hipEventRecord(ctx->ev[6], ctx->stream);
+    int rc = bucketed_applies(set, len) ? insert_bucketed(set, d_codes, d_brk, d_low, len, case_sensitive)
+                                        : insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);
+    (void)hipEventRecord(ctx->ev[7], ctx->stream);
+    return rc;
 }
 
 extern "C" int kc_set_add_sequence_device(kc_set *set, const void *d_seq, uint64_t len, int case_sensitive) {

@@ -32,8 +32,15 @@ template <int W> struct SetView {
     u32 local_probes;
 };
 
-// `ph` below is always key_place_hash(key): bits 0..bshift-1 give the offset inside a block, bits 25..31 the tag.
-KC_HD u8 kc_tag_of(u64 ph) { return (u8)(0x80u | ((u32)ph >> 25)); }
+// `ph` below is always key_place_hash(key): its low 7 bits give the tag, the offset inside a block is a range reduction
+// of all 32 bits (i.e. mostly the high ones).
+KC_HD u8 kc_tag_of(u64 ph) { return (u8)(0x80u | ((u32)ph & 0x7fu)); }
+// Homes are confined to the first (block size - local probes - 8) slots of a block: a key's local probe run and the 8-tag
+// window of a lookup then never leave the block, so a block can be built or scanned on its own (in LDS).
+template <int W> KC_HD u32 set_block_span(const SetView<W> &s) {
+    const u32 bs = 1u << s.bshift, tail = s.local_probes + 8u;
+    return bs > 2u * tail ? bs - tail : bs / 2u;
+}
 
 // hash of a canonical m-mer (f forward, r its reverse complement), 32 bit
 KC_HD u32 kc_mmer_hash(u32 f, u32 r) {
@@ -66,7 +73,7 @@ template <int W> KC_HD u64 set_block_home(const SetView<W> &s, u32 mmh, u64 keyh
     // mmh is a minimum of ~k-m+1 uniform hashes, i.e. concentrated near 0: re-mix it before the range reduction
     u32 u = mmh * 0x85EBCA6Bu; u ^= u >> 16; u *= 0xC2B2AE35u;   // the range reduction below takes the high bits
     u64 blk = ((u64)u * s.nblocks) >> 32;
-    return (blk << s.bshift) | (keyhash & (((u64)1 << s.bshift) - 1));
+    return (blk << s.bshift) | (((u64)(u32)keyhash * set_block_span(s)) >> 32);
 }
 template <int W> KC_HD u64 set_global_home(const SetView<W> &s, u64 keyhash) {
     return kc_mulhi64(kc_mix64(keyhash ^ 0x6a09e667f3bcc909ULL), s.cap);
