@@ -16,6 +16,7 @@
 //               earliest such event is blacklisted, the level is undone and replayed (exactness argument in DESIGN.md);
 //   6. shrink : ordered compaction of the active lists.
 // Levels without hits (almost all d > log4 V) cost two streaming kernels.
+#include <chrono>
 #include "kc_internal.h"
 #include "kc_overlap_logic.h"
 #include "kc_overlap_lds.h"
@@ -417,9 +418,13 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     }
 
     u64 *hp = nullptr;   // pinned readback buffer
-    KC_HIP(ctx, hipHostMalloc((void **)&hp, 64, hipHostMallocDefault));
+    KC_HIP(ctx, hipHostMalloc((void **)&hp, 128, hipHostMallocDefault));
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
         g.d = d;
+        const bool trace = getenv("KC_OV_TRACE") != nullptr;
+        auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_level = 0, t_hits = 0, t_sorted = 0, t_matched = 0;
+        if (trace) { (void)hipStreamSynchronize(ctx->stream); t_level = now_us(); }
         // 1. bucket: cnt[1] = suffix hits, cnt[3] = prefix hits
         u64 lcap = 64;
         while (lcap < 2 * nP + 16) lcap <<= 1;
@@ -435,6 +440,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                            (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3);
         KC_TRY(read_back(ctx, hp, cnt, 4));
         const u64 nHS = hp[1], nHP = hp[3];
+        if (trace) t_hits = now_us();
+        if ((nHS == 0 || nHP == 0) && trace) fprintf(stderr, "[ov] d=%d nS=%llu no hits: %.0f us\n", d, (unsigned long long)nS, t_hits - t_level);
         if (nHS == 0 || nHP == 0) continue;   // no key seen from both sides at this overlap length
         // 2. compact the hits (ordered); the counts are already known
         KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
@@ -446,6 +453,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         // 3. sort by key (stable: ids ascending inside a key)
         KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
         KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3));
+        if (trace) { (void)hipStreamSynchronize(ctx->stream); t_sorted = now_us(); }
         // 4./5. match, verify, repair
         u64 nNew = 0;
         const u64 max_new = (complements ? 2 : 1) * nHS;   // every event logs at most 1 (+1 mirrored) edge
@@ -474,7 +482,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
                                    (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
             KC_HIP(ctx, hipGetLastError());
-            KC_TRY(read_back(ctx, hp, cnt, 3));
+            KC_TRY(read_back(ctx, hp, cnt, 9));
             nNew = hp[0];
             const u64 covered = hp[2];
             if (nNew == 0 || lower_bound) break;
@@ -498,6 +506,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             g.nbl = h_bl.size() / 2;
             hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, edge_from, overlaps, pred,
                                eidx, cov);
+        }
+        if (trace) {
+            (void)hipStreamSynchronize(ctx->stream); t_matched = now_us();
+            fprintf(stderr, "[ov] d=%d nS=%llu hitS=%llu new=%llu big=%llu | probe %.0f  select+sort %.0f  match+fix %.0f us\n", d, (unsigned long long)nS,
+                    (unsigned long long)nHS, (unsigned long long)nNew, (unsigned long long)hp[8], t_hits - t_level, t_sorted - t_hits, t_matched - t_sorted);
         }
         h_bl.clear(); g.nbl = 0;   // the blacklist is per level
         if (nNew == 0) continue;

@@ -111,7 +111,14 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
             if (top1 == cl1 && top2 == cl2) continue;
             u64 i1 = 0, i2 = 0;
             u32 si = 0, out_n = 0;
+            bool exhausted = false;   // every candidate of this part is used: no later event of the part can match
             while (use_scratch ? (si < cur_n) : (i1 < E1.n || i2 < E2.n)) {
+                if (exhausted && use_scratch) {   // the rest of the list is carried over as it is (moved down behind the kept events)
+                    const u32 tail = cur_n - si;
+                    if (out_n != si) for (u32 q = 0; q < tail; ++q) b.scr[out_n + q] = b.scr[si + q];
+                    out_n += tail;
+                    break;
+                }
                 u32 eidx; int from;   // event: from 1 = A[eidx], from 2 = mirror(B[eidx])
                 if (use_scratch) { u32 v = b.scr[si++]; eidx = v & 0x7fffffffu; from = (v >> 31) ? 2 : 1; }
                 else if (i2 >= E2.n) { eidx = (u32)i1++; from = 1; }
@@ -122,6 +129,7 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
                 }
                 const bool used = (from == 1) ? b.usedA[eidx] : b.usedB[eidx];
                 if (used) continue;                                              // suffixForbidden (global.h:87)
+                if (exhausted) { b.scr[out_n++] = ((u32)(from == 2) << 31) | eidx; continue; }   // first part: just list the event
                 const u64 u = (from == 1) ? b.A[eidx] : ov_mirror(b.B[eidx], S);
                 // first vertex of u's path, as a path-first triple
                 LdsEnd F;
@@ -133,6 +141,11 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
                 auto cand_index = [&](u64 t) -> u32 { return (from == 1) ? (u32)t : mirrored_index(C2, t); };
                 auto cand_used = [&](u32 ci) -> bool { return (from == 1) ? b.usedB[ci] : b.usedA[ci]; };
                 while (top > cl && cand_used(cand_index(top - 1))) --top;        // used candidates never come back
+                if (top == cl) {   // this event's candidates are gone; if the other list's are too, the part is over
+                    while (top1 > cl1 && b.usedB[top1 - 1]) --top1;
+                    while (top2 > cl2 && b.usedA[mirrored_index(C2, top2 - 1)]) --top2;
+                    exhausted = (top1 == cl1 && top2 == cl2);
+                }
                 bool matched = false;
                 for (u64 t = top; t > cl; --t) {
                     const u32 ci = cand_index(t - 1);

@@ -135,7 +135,16 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
         if (mode == KC_MODE_PAIR) { cl2 = ov_lower_bound(C2, lo_v); top2 = ov_lower_bound(C2, hi_v); }
         if (top1 == cl1 && top2 == cl2) continue;
         u64 i1 = 0, i2 = 0, si = 0, out_n = 0;
+        bool exhausted = false;   // every candidate of this part is used: no later event of the part can match
         while (use_scratch ? (si < cur_n) : (i1 < E1.n || i2 < E2.n)) {
+            if (exhausted && use_scratch) {   // the rest of the list is carried over as it is (moved down behind the kept events)
+                for (; si < cur_n; ++si, ++out_n) {
+                    if (out_n == si) continue;
+                    const u64 v = si < nA ? sA[si] : sB[si - nA];
+                    if (out_n < nA) sA[out_n] = v; else sB[out_n - nA] = v;
+                }
+                break;
+            }
             u64 u; int from;
             if (use_scratch) {
                 u64 v = si < nA ? sA[si] : sB[si - nA];
@@ -151,12 +160,23 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
             const u64 ef = g.edge_from[u];
             const u64 fl = g.lower_bound ? 0 : g.first[u], fsn = g.lower_bound ? 0 : g.first_snap[u];
             if (ef != KC_NONE64) continue;                                   // suffixForbidden (global.h:87)
+            if (exhausted) {   // first part: just list the event
+                u64 v = (u << 1) | (u64)(from == 2);
+                if (out_n < nA) sA[out_n] = v; else sB[out_n - nA] = v;
+                ++out_n;
+                continue;
+            }
             const u64 firstU = ((u32)(fl >> 32) == tag) ? (fl & 0xffffffffull) : fsn;
             bool matched = false;
             const OvList &C = (from == 1) ? C1 : C2;
             u64 &top = (from == 1) ? top1 : top2;
             const u64 cl = (from == 1) ? cl1 : cl2;
             while (top > cl && g.pred[C.get(top - 1)] != KC_NONE64) --top;    // used candidates never come back
+            if (top == cl) {   // this event's candidates are gone; if the other list's are too, the part is over
+                while (top1 > cl1 && g.pred[C1.get(top1 - 1)] != KC_NONE64) --top1;
+                while (top2 > cl2 && g.pred[C2.get(top2 - 1)] != KC_NONE64) --top2;
+                exhausted = (top1 == cl1 && top2 == cl2);
+            }
             for (u64 t = top; t > cl; --t) {
                 u64 c = C.get(t - 1);
                 if (g.pred[c] != KC_NONE64) continue;                         // prefixForbidden (global.h:97)

@@ -335,9 +335,9 @@ template <int W, int KC>
 __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
                                                               const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
                                                               u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
-                                                              u64 branch_shard_cap, u64 *branch_cursors, int stage_words) {
+                                                              u64 branch_shard_cap, u64 *branch_cursors, int stage_words, int per_wg) {
     extern __shared__ u64 kc_stage[];
-    const u64 t0 = kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_PER_WG;
+    const u64 t0 = kc_xcd_block_id(xcd_aware) * (u64)per_wg;
     if (t0 >= nocc) return;
     u64 sblk = ~(u64)0;
     if (stage_words) {
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
         __syncthreads();
     }
 #pragma unroll 1
-    for (int it = 0; it < KC_CHOOSE_PER_WG / 256; ++it) {
+    for (int it = 0; it < per_wg / 256; ++it) {
         const u64 t = t0 + (u64)it * 256 + threadIdx.x;
         if (t >= nocc) break;
         kc_choose_dense_one<W, KC>(set, link, k_rt, complements, occ[t], kc_stage, sblk, heads, heads_shard_cap, heads_cursors, branch,
@@ -537,10 +537,23 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 // measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a
 // chain is emitted (bi: the one starting at the smaller key) and records the winners.
 // MARK: also flag visited nodes (only needed when the node count shows that cycles exist).
-template <int W, bool MARK>
+// REC: also record the bases appended along the walk (32 per word, first base in bits 63:62) into 32-word chunks drawn
+// from `pool`, so that the winning direction is later emitted by copying its recording instead of walking the chain a
+// third time (every step of a walk is a scattered 128-byte line fetch; the recording is 2 bits per step).
+#define KC_CHUNK_WORDS 32
+#define KC_NO_CHUNK 0xffffffffu
+struct KcRec {
+    u64 *pool;          // chunks of KC_CHUNK_WORDS words
+    u32 *chunk_next;    // next chunk of the same walk
+    u64 pool_cap;       // chunks
+    u64 *pool_cursor;
+    u64 *chain_stream;  // per chain: first chunk (KC_NO_CHUNK if it has a single node)
+    u64 *chain_tail;    // per chain: oriented last node (slot << 1 | orientation)
+};
+template <int W, bool MARK, bool REC>
 __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
                                                               const u64 *__restrict__ heads, u64 nheads, u8 *visited,
-                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit) {
+                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit, KcRec rec) {
     // limit: give up (cursor[7] = 1) on a chain longer than this; the caller then switches to the segment-parallel path
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nheads) return;
@@ -548,10 +561,28 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     u64 slot = h >> 1, cur = slot;
     int o = (int)(h & 1), co = o;
     u64 len = 1;
+    u64 acc = 0;
+    int nacc = 0, wi = 0;
+    u32 chunk = KC_NO_CHUNK, first_chunk = KC_NO_CHUNK;
+    bool rec_ok = true;
+    auto flush_word = [&](u64 word) {
+        if (chunk == KC_NO_CHUNK || wi == KC_CHUNK_WORDS) {
+            const u64 nc = atomicAdd((ull *)rec.pool_cursor, 1ULL);
+            if (nc >= rec.pool_cap) { rec_ok = false; return; }
+            if (first_chunk == KC_NO_CHUNK) first_chunk = (u32)nc; else rec.chunk_next[chunk] = (u32)nc;
+            chunk = (u32)nc;
+            wi = 0;
+        }
+        rec.pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++] = word;
+    };
     while (true) {
         if (MARK) visited[cur] = 1;
         u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         if (!LK_IS_MATCHED(w)) break;
+        if (REC) {
+            acc = (acc << 2) | LK_BASE(w);
+            if (++nacc == 32) { if (rec_ok) flush_word(acc); acc = 0; nacc = 0; }
+        }
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
         if (++len > limit) {
@@ -563,11 +594,16 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     bool winner = true;
     if (complements) winner = (len == 1) ? (o == 0) : key_lt(hk, set_key_at(set, cur));
     if (!winner) return;
+    if (REC) {
+        if (nacc && rec_ok) flush_word(acc << (64 - 2 * nacc));
+        if (!rec_ok) atomicExch((ull *)(cursor + 6), 1ULL);   // pool exhausted (cannot happen with the caller's sizing): no stream emit
+    }
     atomicAdd((ull *)(cursor + 3), (ull)len);   // nodes covered by chains that have ends
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
     chain_head[pos] = h;
     chain_len[pos] = len;
     for (int i = 0; i < W; ++i) chain_key[pos * W + i] = hk.w[i];
+    if (REC) { rec.chain_stream[pos] = first_chunk; rec.chain_tail[pos] = (cur << 1) | (u64)co; }
 }
 
 template <int W, bool FILL>
@@ -664,6 +700,57 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
     }
     words[wp] = nacc ? (acc << (64 - 2 * nacc)) : 0;
     for (int i = 0; i < W; ++i) lastK[t * W + i] = kx.w[i];
+}
+
+// emit from the recordings of the measure pass: first k bases from the head key, then the recorded appended bases
+template <int W>
+__global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, int k, const u64 *__restrict__ chain_head,
+                                                             const u64 *__restrict__ chain_len, const u64 *__restrict__ chain_stream,
+                                                             const u64 *__restrict__ chain_tail, const u64 *__restrict__ perm, u64 n,
+                                                             const u64 *__restrict__ pool, const u32 *__restrict__ chunk_next,
+                                                             const u64 *__restrict__ woff, u64 *words, u64 *firstK, u64 *lastK) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 p = perm[t];
+    const u64 h = chain_head[p], len = chain_len[p], tail = chain_tail[p];
+    Key<W> kx = set_key_at(set, h >> 1);
+    if (h & 1) kx = key_rc(kx, k);
+    for (int i = 0; i < W; ++i) firstK[t * W + i] = kx.w[i];
+    Key<W> kl = set_key_at(set, tail >> 1);
+    if (tail & 1) kl = key_rc(kl, k);
+    for (int i = 0; i < W; ++i) lastK[t * W + i] = kl.w[i];
+    u64 wp = woff[t], acc = 0;
+    int nacc = 0;
+    for (int i = 0; i < k; ++i) {
+        acc = (acc << 2) | key_at(kx, k, i);
+        if (++nacc == 32) { words[wp++] = acc; acc = 0; nacc = 0; }
+    }
+    // the remaining len-1 bases: whole recorded words, shifted by the nacc bases already pending
+    u32 chunk = (u32)chain_stream[p];
+    u64 left = len - 1;
+    int wi = 0;
+    while (left) {
+        if (wi == KC_CHUNK_WORDS) { chunk = chunk_next[chunk]; wi = 0; }
+        const u64 sw = pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++];
+        const int nb = left >= 32 ? 32 : (int)left;          // valid bases in sw (left-aligned)
+        left -= (u64)nb;
+        if (nacc == 0) {
+            if (nb == 32) words[wp++] = sw;
+            else { acc = sw >> (64 - 2 * nb); nacc = nb; }
+        } else {
+            const int room = 32 - nacc;                        // bases still missing in the pending word
+            if (nb >= room) {
+                words[wp++] = (acc << (2 * room)) | (sw >> (64 - 2 * room));
+                const int rest = nb - room;
+                acc = rest ? ((sw << (2 * room)) >> (64 - 2 * rest)) : 0;
+                nacc = rest;
+            } else {
+                acc = (acc << (2 * nb)) | (sw >> (64 - 2 * nb));
+                nacc += nb;
+            }
+        }
+    }
+    words[wp] = nacc ? (acc << (64 - 2 * nacc)) : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -885,15 +972,17 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // tag staging: one table block's tags (+ 8 bytes) in LDS, when the set has minimizer blocks of at most 32 KB
     const int stage_words = (set->mlen && set->bshift <= 15 && !getenv("KC_NOSTAGE")) ? (int)(((u64)1 << set->bshift) / 8 + 1) : 0;
     const size_t stage_lds = (size_t)stage_words * 8;
-    const unsigned cgrid = kc_grid8(N, KC_CHOOSE_PER_WG);
+    int per_wg = KC_CHOOSE_PER_WG;
+    if (const char *e = getenv("KC_PER_WG")) { int v = atoi(e); if (v >= 256 && v % 256 == 0) per_wg = v; }
+    const unsigned cgrid = kc_grid8(N, (unsigned)per_wg);
     if (k31)
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
                            (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
-                           stage_words);
+                           stage_words, per_wg);
     else
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
                            (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
-                           stage_words);
+                           stage_words, per_wg);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
                        (const u64 *)heads_cursors, heads, heads_cap, heads_cursor);
@@ -968,12 +1057,34 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 *starts = nullptr, *seg_len = nullptr, *seg_next = nullptr, *seg_tail = nullptr, *seg_chain = nullptr, *seg_off = nullptr;
     u64 hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-    if (nheads)
-        hipLaunchKernelGGL((kc_walk_measure_kernel<W, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
-                           (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, KC_CHAIN_LIMIT);
+    // recording pool of the measure pass: every walk needs at most steps/1024 + 1 chunks, all walks together make 2N steps
+    KcRec rec{};
+    const KcRec no_rec{};
+    u32 *chunk_next = nullptr;
+    u64 *pool = nullptr, *chain_stream = nullptr, *chain_tail = nullptr;
+    const bool want_rec = !getenv("KC_NOREC");
+    if (want_rec) {
+        rec.pool_cap = 2 * N / (32 * KC_CHUNK_WORDS) + 2 * nheads + 1024;
+        KC_TRY(scope.alloc(&pool, rec.pool_cap * KC_CHUNK_WORDS));
+        KC_TRY(scope.alloc(&chunk_next, rec.pool_cap));
+        KC_TRY(scope.alloc(&chain_stream, max_chains));
+        KC_TRY(scope.alloc(&chain_tail, max_chains));
+        rec.pool = pool; rec.chunk_next = chunk_next; rec.pool_cursor = cnt + 5; rec.chain_stream = chain_stream; rec.chain_tail = chain_tail;
+    }
+    if (nheads) {
+        if (want_rec)
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
+                               compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, KC_CHAIN_LIMIT, rec);
+        else
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
+                               compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, KC_CHAIN_LIMIT, no_rec);
+    }
     KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const bool too_long = hc[7] != 0;
+    // the recordings are used when this pass was the one that produced the chains: no long chain, no cycles, pool not exhausted
+    const bool use_stream = want_rec && !too_long && hc[3] == N && hc[6] == 0;
+    if (!use_stream) { scope.release(pool); scope.release(chunk_next); scope.release(chain_stream); scope.release(chain_tail); }
     // ---- some chain is long: segment-parallel path (needs: no cycles, splitter list did not overflow)
     if (too_long) {
         const u64 max_starts = nheads + 2 * nsplit_max + 1;
@@ -1015,8 +1126,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (too_long && !seg_ok) {
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         if (nheads)
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
-                               (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, ~(u64)0);
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
+                               compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -1027,8 +1138,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         if (nheads)
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
-                               compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0);
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
+                               compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
                            (u64 *)nullptr, cnt + 1);
         KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -1094,6 +1205,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                            s->words, s->firstK, s->lastK);
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(rank);
+    } else if (use_stream) {
+        hipLaunchKernelGGL((kc_stream_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, k, (const u64 *)chain_head,
+                           (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
+                           (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
     } else {
         hipLaunchKernelGGL((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
                            (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
