@@ -48,10 +48,18 @@ struct kc_set {
     u32 *counts = nullptr; // cap entries, only while counting occurrences for -z
     u64 *counters = nullptr;  // device: [0] size, [1] overflow flag
     u64 size_host = 0;
+    mutable bool unclean = false;   // table allocated but not filled with EMPTY yet (a bucketed build of a fresh set overwrites every
+                                    // slot, so the 9 B/slot fill is deferred until something else needs the table)
 };
+int kcs_clean_table(const kc_set *s);   // kc_set.hip
 
-template <int W> static inline SetView<W> kc_view(const kc_set *s) {
+template <int W> static inline SetView<W> kc_view_raw(const kc_set *s) {
     return SetView<W>{s->keys, s->state, s->tags, s->cap, s->nblocks, s->bshift, s->mlen, s->k, s->local_probes};
+}
+// every kernel reaches the table through a view: this is where a deferred fill happens
+template <int W> static inline SetView<W> kc_view(const kc_set *s) {
+    if (s->unclean) (void)kcs_clean_table(s);
+    return kc_view_raw<W>(s);
 }
 
 struct kc_simplitigs {

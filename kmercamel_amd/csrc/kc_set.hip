@@ -332,19 +332,25 @@ __global__ void __launch_bounds__(256) kc_contains_kernel(SetView<W> set, const 
     out[t] = set_find(set, key) != KC_NONE64 ? 1 : 0;
 }
 
-static int set_alloc_table(kc_set *set, u64 cap, u64 **keys, u32 **state, u8 **tags) {
+static int set_fill_table(kc_ctx *ctx, int W, u64 cap, u64 *keys, u32 *state, u8 *tags) {
+    KC_HIP(ctx, hipMemsetAsync(tags, 0, cap + 8, ctx->stream));
+    if (W == 1) { KC_HIP(ctx, hipMemsetAsync(keys, 0xff, cap * 8, ctx->stream)); }
+    else { KC_HIP(ctx, hipMemsetAsync(state, 0, cap * sizeof(u32), ctx->stream)); }
+    return KC_OK;
+}
+static int set_alloc_table(kc_set *set, u64 cap, u64 **keys, u32 **state, u8 **tags, bool fill = true) {
     kc_ctx *ctx = set->ctx;
     KC_TRY(kc_alloc(ctx, keys, cap * set->W));
     KC_TRY(kc_alloc(ctx, tags, cap + 8));
-    KC_HIP(ctx, hipMemsetAsync(*tags, 0, cap + 8, ctx->stream));
     *state = nullptr;
-    if (set->W == 1) {
-        KC_HIP(ctx, hipMemsetAsync(*keys, 0xff, cap * 8, ctx->stream));
-    } else {
-        KC_TRY(kc_alloc(ctx, state, cap));
-        KC_HIP(ctx, hipMemsetAsync(*state, 0, cap * sizeof(u32), ctx->stream));
-    }
+    if (set->W != 1) KC_TRY(kc_alloc(ctx, state, cap));
+    if (fill) KC_TRY(set_fill_table(ctx, set->W, cap, *keys, *state, *tags));
     return KC_OK;
+}
+int kcs_clean_table(const kc_set *s) {
+    if (!s->unclean) return KC_OK;
+    s->unclean = false;
+    return set_fill_table(s->ctx, s->W, s->cap, s->keys, s->state, s->tags);
 }
 
 extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capacity_hint, kc_set **out) {
@@ -375,7 +381,8 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     s->nblocks = (cap + (((u64)1 << s->bshift) - 1)) >> s->bshift;
     cap = s->nblocks << s->bshift;
     s->cap = cap;
-    int rc = set_alloc_table(s, cap, &s->keys, &s->state, &s->tags);
+    int rc = set_alloc_table(s, cap, &s->keys, &s->state, &s->tags, false);   // filled on first use (kc_view), or never (bucketed build)
+    s->unclean = true;
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 4);
     if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     if (rc != KC_OK) { kc_set_destroy(s); return rc; }
@@ -490,7 +497,7 @@ static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, co
     const size_t lds_scatter = (size_t)win * 256 * 4 + (size_t)KC_BUCKET_PPT * 256 * 8;
     const u64 nthreads = (len + KC_BUCKET_PPT - 1) / KC_BUCKET_PPT;
     hipLaunchKernelGGL(kc_bucket_scatter_kernel, dim3(kc_grid(nthreads, 256)), dim3(256), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
-                       set->k, set->complements, case_sensitive, view_of<1>(set), bucket, bcursor, set->counters);
+                       set->k, set->complements, case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters);
     const size_t lds_build = (size_t)bs * 9;
     static bool attr_done = false;
     if (!attr_done) {
@@ -498,7 +505,9 @@ static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, co
         attr_done = true;
     }
     const int fresh = set->size_host == 0 ? 1 : 0;
-    hipLaunchKernelGGL(kc_block_build_kernel, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, view_of<1>(set), (const u64 *)bucket,
+    if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
+    set->unclean = false;                        // the build kernel writes every slot and tag of every block
+    hipLaunchKernelGGL(kc_block_build_kernel, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<1>(set), (const u64 *)bucket,
                        (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap);
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};

@@ -259,7 +259,8 @@ __device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *
         const u64 xw = cword[i] ^ (((u64)t32 << 32) | t32);
         const u64 zero = ~(((xw & lo7) + lo7) | xw | lo7);
         const u64 empty = ~cword[i] & hi7;
-        const u64 cand = zero | empty;
+        u64 cand = zero | empty;
+        if (set.local_probes < 8) cand &= ((u64)1 << (8 * set.local_probes)) - 1;   // an empty slot proves a miss only inside the local probe run
         const u32 lv = (live >> i) & 1u;
         const u32 none = cand == 0 ? 1u : 0u;                        // window full of other tags: keep scanning (slow path)
         const int b = __builtin_ctzll(cand | ((u64)1 << 63)) >> 3;

@@ -133,6 +133,41 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
             sim.close(); s.close()
 
 
+@pytest.mark.parametrize("knobs", [{"KC_BUCKET_MIN": "0"}, {"KC_BUCKET_MIN": "1000000000"}, {"KC_NOREC": "1"}, {"KC_NOSTAGE": "1"},
+                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}],
+                         ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills"])
+def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
+    """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
+    walk, LDS tag staging) must give the same set and the same simplitigs; KC_LOCAL_PROBES=2 makes block-local probe runs
+    overflow, so the spill list + global second home of the bucketed build are exercised too."""
+    for name, value in knobs.items():
+        monkeypatch.setenv(name, value)
+    rng = random.Random(4242)
+    for k in (16, 23, 31):          # single-word keys with minimizer blocks (k >= 16)
+        reads = [r.decode() for r in gen.stress_reads(20000, 200, 250, seed=500 + k)]
+        seq = "\n".join(reads)
+        for complements in (True, False):
+            want_set = sorted(oracle.kmer_set(seq.replace("\n", "N"), k, complements))
+            # one call, and the same records added in three calls (the later ones update a non-empty table)
+            s1 = kc.KmerSet(ctx, k, complements, capacity_hint=len(seq))
+            s1.AddKMers(seq)
+            s2 = kc.KmerSet(ctx, k, complements)
+            third = len(reads) // 3
+            for part in (reads[:third], reads[third:2 * third], reads[2 * third:] + reads[:5]):
+                s2.AddKMers("\n".join(part))
+            assert s1.size() == len(want_set) and s2.size() == len(want_set)
+            assert sorted(s1.keys()) == want_set and sorted(s2.keys()) == want_set
+            probe = want_set[:200] + [(x + 1) & ((1 << (2 * k)) - 1) for x in want_set[:200]]
+            wset = set(want_set)
+            assert s2.contains(probe) == [x in wset for x in probe]
+            want = oracle.simplitigs_of_sequence(seq.replace("\n", "N"), k, complements, mode=1)
+            for s in (s1, s2):
+                sim = kc.get_simplitigs(s)
+                assert sim.strings() == want
+                sim.close()
+            s1.close(); s2.close()
+
+
 def test_simplitigs_reference_kats(ctx):
     # tests/simplitigs_unittest.h:183-208 (order-tolerant there: sorted by length)
     enc = oracle_lib.encode_kmer
