@@ -127,13 +127,18 @@ KC_HD void kc_match_bucket(const OvArgs &g, const u64 *A, u64 nA, const u64 *B, 
     // bidirectional mode, mirror(c), which is an event vertex of this bucket pair as well
     u64 left = E1.n + E2.n, cur_n = 0;
     bool use_scratch = false;
-    for (u64 part = 0; part < 16 && left > 0; ++part) {
-        u64 lo_v = part * g.batch, hi_v = (part + 1) * g.batch;
-        if (lo_v >= g.V) break;
-        u64 cl1 = ov_lower_bound(C1, lo_v), top1 = ov_lower_bound(C1, hi_v);
-        u64 cl2 = 0, top2 = 0;
-        if (mode == KC_MODE_PAIR) { cl2 = ov_lower_bound(C2, lo_v); top2 = ov_lower_bound(C2, hi_v); }
-        if (top1 == cl1 && top2 == cl2) continue;
+    // parts (candidate index ranges of V/16+1 vertices, global.h:63-72) without a candidate of this bucket do nothing in the
+    // reference either: go from one non-empty part to the next by following the (ascending) candidate lists
+    u64 nx1 = 0, nx2 = 0;   // first candidate of C1 / C2 not yet assigned to a part
+    while (left > 0) {
+        const u64 v1 = nx1 < C1.n ? C1.get(nx1) : ~(u64)0, v2 = nx2 < C2.n ? C2.get(nx2) : ~(u64)0;
+        const u64 vmin = v1 < v2 ? v1 : v2;
+        if (vmin == ~(u64)0) break;
+        const u64 part = vmin / g.batch, hi_v = (part + 1) * g.batch;
+        const u64 cl1 = nx1, cl2 = nx2;
+        while (nx1 < C1.n && C1.get(nx1) < hi_v) ++nx1;
+        while (nx2 < C2.n && C2.get(nx2) < hi_v) ++nx2;
+        u64 top1 = nx1, top2 = nx2;
         u64 i1 = 0, i2 = 0, si = 0, out_n = 0;
         bool exhausted = false;   // every candidate of this part is used: no later event of the part can match
         while (use_scratch ? (si < cur_n) : (i1 < E1.n || i2 < E2.n)) {
