@@ -88,22 +88,35 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
     }
     __syncthreads();
 
+    // Live events are kept in two linked lists in reference order (list 1: the members of A ascending; list 2, PAIR mode
+    // only: the members of B viewed through mirror(), ascending).  b.scr[i] = next live event of list 1 after A[i],
+    // b.scr[nA + j] = next of list 2 after B[j].  A matched (or otherwise consumed) event is unlinked, so later parts never
+    // see it again, and a list whose candidates are exhausted in the current part is not traversed at all.
+    const u32 splitB = (mode == KC_MODE_PAIR) ? (u32)ov_split(b.B, nB, S) : 0;
+    for (u32 i = lane; i < nA; i += 64) b.scr[i] = (i + 1 < nA) ? i + 1 : KC_LDS_NONE;
+    for (u32 j = lane; j < nB; j += 64) {
+        u32 nx = (j + 1 < nB) ? j + 1 : KC_LDS_NONE;
+        if (splitB > 0 && splitB < nB) {          // order: splitB .. nB-1, then 0 .. splitB-1
+            if (j == nB - 1) nx = 0;
+            if (j == splitB - 1) nx = KC_LDS_NONE;
+        }
+        b.scr[nA + j] = nx;
+    }
+    __syncthreads();
+
     __shared__ u32 nev_shared;
     if (lane == 0) {
         // ---- sequential replay (reference event order: part, then suffix vertex ascending; candidates descending)
-        OvList E1{b.A, nA, 0, S, 0}, C1{b.B, nB, 0, S, 0};
-        OvList E2{b.B, 0, 0, S, 1}, C2{b.A, 0, 0, S, 1};
-        if (mode == KC_MODE_PAIR) {
-            E2.n = nB; E2.split = ov_split(b.B, nB, S);
-            C2.n = nA; C2.split = ov_split(b.A, nA, S);
-        }
+        OvList C1{b.B, nB, 0, S, 0}, C2{b.A, 0, 0, S, 1};
+        if (mode == KC_MODE_PAIR) { C2.n = nA; C2.split = ov_split(b.A, nA, S); }
         // index of the t-th element of a mirrored list inside its base array
         auto mirrored_index = [](const OvList &l, u64 t) -> u32 { u64 hi = l.n - l.split; return (u32)(t < hi ? l.split + t : t - hi); };
-        u32 nev = 0, cur_n = 0;
-        u64 left = E1.n + E2.n;
-        bool use_scratch = false;
+        u32 head1 = nA ? 0 : KC_LDS_NONE;
+        u32 head2 = (mode == KC_MODE_PAIR && nB) ? ((splitB < nB) ? splitB : 0) : KC_LDS_NONE;
+        u32 nev = 0;
+        u64 left = (u64)nA + (mode == KC_MODE_PAIR ? (u64)nB : 0);
         u64 nx1 = 0, nx2 = 0;   // first candidate of C1 / C2 not yet assigned to a part (empty parts are skipped, cf. kc_match_bucket)
-        while (left > 0) {
+        while (left > 0 && (head1 != KC_LDS_NONE || head2 != KC_LDS_NONE)) {
             const u64 v1 = nx1 < C1.n ? C1.get(nx1) : ~(u64)0, v2 = nx2 < C2.n ? C2.get(nx2) : ~(u64)0;
             const u64 vmin = v1 < v2 ? v1 : v2;
             if (vmin == ~(u64)0) break;
@@ -112,85 +125,77 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
             while (nx1 < C1.n && C1.get(nx1) < hi_v) ++nx1;
             while (nx2 < C2.n && C2.get(nx2) < hi_v) ++nx2;
             u64 top1 = nx1, top2 = nx2;
-            u64 i1 = 0, i2 = 0;
-            u32 si = 0, out_n = 0;
-            bool exhausted = false;   // every candidate of this part is used: no later event of the part can match
-            while (use_scratch ? (si < cur_n) : (i1 < E1.n || i2 < E2.n)) {
-                if (exhausted && use_scratch) {   // the rest of the list is carried over as it is (moved down behind the kept events)
-                    const u32 tail = cur_n - si;
-                    if (out_n != si) for (u32 q = 0; q < tail; ++q) b.scr[out_n + q] = b.scr[si + q];
-                    out_n += tail;
-                    break;
-                }
-                u32 eidx; int from;   // event: from 1 = A[eidx], from 2 = mirror(B[eidx])
-                if (use_scratch) { u32 v = b.scr[si++]; eidx = v & 0x7fffffffu; from = (v >> 31) ? 2 : 1; }
-                else if (i2 >= E2.n) { eidx = (u32)i1++; from = 1; }
-                else if (i1 >= E1.n) { eidx = mirrored_index(E2, i2++); from = 2; }
-                else {
-                    u64 a = E1.get(i1), bb = E2.get(i2);
-                    if (a <= bb) { eidx = (u32)i1++; from = 1; } else { eidx = mirrored_index(E2, i2++); from = 2; }
-                }
-                const bool used = (from == 1) ? b.usedA[eidx] : b.usedB[eidx];
-                if (used) continue;                                              // suffixForbidden (global.h:87)
-                if (exhausted) { b.scr[out_n++] = ((u32)(from == 2) << 31) | eidx; continue; }   // first part: just list the event
-                const u64 u = (from == 1) ? b.A[eidx] : ov_mirror(b.B[eidx], S);
-                // first vertex of u's path, as a path-first triple
-                LdsEnd F;
-                if (from == 1) F = b.firstA[eidx];
-                else { LdsEnd L = b.lastB[eidx]; F.v = (u32)ov_mirror(L.v, S); F.i1 = L.i2; F.i2 = L.i1; }
-                const OvList &C = (from == 1) ? C1 : C2;
-                u64 &top = (from == 1) ? top1 : top2;
-                const u64 cl = (from == 1) ? cl1 : cl2;
-                auto cand_index = [&](u64 t) -> u32 { return (from == 1) ? (u32)t : mirrored_index(C2, t); };
-                auto cand_used = [&](u32 ci) -> bool { return (from == 1) ? b.usedB[ci] : b.usedA[ci]; };
-                while (top > cl && cand_used(cand_index(top - 1))) --top;        // used candidates never come back
-                if (top == cl) {   // this event's candidates are gone; if the other list's are too, the part is over
-                    while (top1 > cl1 && b.usedB[top1 - 1]) --top1;
-                    while (top2 > cl2 && b.usedA[mirrored_index(C2, top2 - 1)]) --top2;
-                    exhausted = (top1 == cl1 && top2 == cl2);
-                }
+            u32 cur1 = head1, prev1 = KC_LDS_NONE, cur2 = head2, prev2 = KC_LDS_NONE;
+            u64 u1 = cur1 != KC_LDS_NONE ? b.A[cur1] : 0, u2 = cur2 != KC_LDS_NONE ? ov_mirror(b.B[cur2], S) : 0;
+            while (true) {
+                while (top1 > cl1 && b.usedB[top1 - 1]) --top1;                              // used candidates never come back
+                while (top2 > cl2 && b.usedA[mirrored_index(C2, top2 - 1)]) --top2;
+                const bool can1 = cur1 != KC_LDS_NONE && top1 > cl1, can2 = cur2 != KC_LDS_NONE && top2 > cl2;
+                if (!can1 && !can2) break;                                                   // no event of this part can match any more
+                const int from = (can1 && (!can2 || u1 <= u2)) ? 1 : 2;                      // event: from 1 = A[eidx], from 2 = mirror(B[eidx])
+                const u32 eidx = (from == 1) ? cur1 : cur2;
+                const u64 u = (from == 1) ? u1 : u2;
+                const u32 nxt = b.scr[(from == 1 ? 0 : nA) + eidx];
+                const bool used = (from == 1) ? b.usedA[eidx] : b.usedB[eidx];               // suffixForbidden (global.h:87)
                 bool matched = false;
-                for (u64 t = top; t > cl; --t) {
-                    const u32 ci = cand_index(t - 1);
-                    if (cand_used(ci)) continue;                                 // prefixForbidden (global.h:97)
-                    const u64 c = (from == 1) ? b.B[ci] : ov_mirror(b.A[ci], S);
-                    if (!g.lower_bound) {
-                        if (bi && c == ov_mirror(u, S)) continue;                // complementary (global.h:93)
-                        if ((u64)F.v == c) continue;                             // would close a cycle (global.h:95)
-                        bool banned = false;
-                        for (u64 q = 0; q < g.nbl; ++q) banned = banned || (g.bl[2 * q] == u && g.bl[2 * q + 1] == c);
-                        if (banned) continue;
+                if (!used) {
+                    // first vertex of u's path, as a path-first triple
+                    LdsEnd F;
+                    if (from == 1) F = b.firstA[eidx];
+                    else { LdsEnd L = b.lastB[eidx]; F.v = (u32)ov_mirror(L.v, S); F.i1 = L.i2; F.i2 = L.i1; }
+                    const u64 top = (from == 1) ? top1 : top2;
+                    const u64 cl = (from == 1) ? cl1 : cl2;
+                    auto cand_index = [&](u64 t) -> u32 { return (from == 1) ? (u32)t : mirrored_index(C2, t); };
+                    auto cand_used = [&](u32 ci) -> bool { return (from == 1) ? b.usedB[ci] : b.usedA[ci]; };
+                    for (u64 t = top; t > cl; --t) {
+                        const u32 ci = cand_index(t - 1);
+                        if (cand_used(ci)) continue;                                 // prefixForbidden (global.h:97)
+                        const u64 c = (from == 1) ? b.B[ci] : ov_mirror(b.A[ci], S);
+                        if (!g.lower_bound) {
+                            if (bi && c == ov_mirror(u, S)) continue;                // complementary (global.h:93)
+                            if ((u64)F.v == c) continue;                             // would close a cycle (global.h:95)
+                            bool banned = false;
+                            for (u64 q = 0; q < g.nbl; ++q) banned = banned || (g.bl[2 * q] == u && g.bl[2 * q + 1] == c);
+                            if (banned) continue;
+                        }
+                        // ---- accept u -> c (+ mirror(c) -> mirror(u))
+                        if (from == 1) { b.usedA[eidx] = 1; b.usedB[ci] = 1; } else { b.usedB[eidx] = 1; b.usedA[ci] = 1; }
+                        if (mode == KC_MODE_PAL) {       // the mirrored edge consumes members of the same lists
+                            u32 ma = b.piB[ci], mb = b.piA[eidx];     // mirror(c) in A, mirror(u) in B
+                            if (ma != KC_LDS_NONE) b.usedA[ma] = 1;
+                            if (mb != KC_LDS_NONE) b.usedB[mb] = 1;
+                        }
+                        if (!g.lower_bound) {
+                            LdsEnd L;                    // last vertex of c's path, as a path-last triple
+                            if (from == 1) L = b.lastB[ci];
+                            else { LdsEnd Fc = b.firstA[ci]; L.v = (u32)ov_mirror(Fc.v, S); L.i1 = Fc.i2; L.i2 = Fc.i1; }
+                            // new path F .. u c .. L (and its mirror): tell the members among the four end vertices
+                            if (L.i1 != KC_LDS_NONE) b.firstA[L.i1] = F;                                       // first_of(L) = F
+                            if (L.i2 != KC_LDS_NONE) { LdsEnd m; m.v = (u32)ov_mirror(F.v, S); m.i1 = F.i2; m.i2 = F.i1; b.lastB[L.i2] = m; }   // last_of(mL) = mF
+                            if (F.i1 != KC_LDS_NONE) b.lastB[F.i1] = L;                                        // last_of(F) = L
+                            if (F.i2 != KC_LDS_NONE) { LdsEnd m; m.v = (u32)ov_mirror(L.v, S); m.i1 = L.i2; m.i2 = L.i1; b.firstA[F.i2] = m; }  // first_of(mF) = mL
+                        }
+                        b.evU[nev] = ((u32)(from == 2) << 31) | eidx;
+                        b.evC[nev] = ci;
+                        b.evPart[nev] = (u8)part;
+                        ++nev;
+                        left -= 1;
+                        if (bi && (!g.lower_bound || ov_mirror(c, S) != u)) left -= (left > 0);
+                        matched = true;
+                        break;
                     }
-                    // ---- accept u -> c (+ mirror(c) -> mirror(u))
-                    if (from == 1) { b.usedA[eidx] = 1; b.usedB[ci] = 1; } else { b.usedB[eidx] = 1; b.usedA[ci] = 1; }
-                    if (mode == KC_MODE_PAL) {       // the mirrored edge consumes members of the same lists
-                        u32 ma = b.piB[ci], mb = b.piA[eidx];     // mirror(c) in A, mirror(u) in B
-                        if (ma != KC_LDS_NONE) b.usedA[ma] = 1;
-                        if (mb != KC_LDS_NONE) b.usedB[mb] = 1;
-                    }
-                    if (!g.lower_bound) {
-                        LdsEnd L;                    // last vertex of c's path, as a path-last triple
-                        if (from == 1) L = b.lastB[ci];
-                        else { LdsEnd Fc = b.firstA[ci]; L.v = (u32)ov_mirror(Fc.v, S); L.i1 = Fc.i2; L.i2 = Fc.i1; }
-                        // new path F .. u c .. L (and its mirror): tell the members among the four end vertices
-                        if (L.i1 != KC_LDS_NONE) b.firstA[L.i1] = F;                                       // first_of(L) = F
-                        if (L.i2 != KC_LDS_NONE) { LdsEnd m; m.v = (u32)ov_mirror(F.v, S); m.i1 = F.i2; m.i2 = F.i1; b.lastB[L.i2] = m; }   // last_of(mL) = mF
-                        if (F.i1 != KC_LDS_NONE) b.lastB[F.i1] = L;                                        // last_of(F) = L
-                        if (F.i2 != KC_LDS_NONE) { LdsEnd m; m.v = (u32)ov_mirror(L.v, S); m.i1 = L.i2; m.i2 = L.i1; b.firstA[F.i2] = m; }  // first_of(mF) = mL
-                    }
-                    b.evU[nev] = ((u32)(from == 2) << 31) | eidx;
-                    b.evC[nev] = ci;
-                    b.evPart[nev] = (u8)part;
-                    ++nev;
-                    left -= 1;
-                    if (bi && (!g.lower_bound || ov_mirror(c, S) != u)) left -= (left > 0);
-                    matched = true;
-                    break;
                 }
-                if (!matched) b.scr[out_n++] = ((u32)(from == 2) << 31) | eidx;
+                // advance; a used or matched event leaves its list for good
+                if (from == 1) {
+                    if (used || matched) { if (prev1 == KC_LDS_NONE) head1 = nxt; else b.scr[prev1] = nxt; } else prev1 = eidx;
+                    cur1 = nxt;
+                    if (cur1 != KC_LDS_NONE) u1 = b.A[cur1];
+                } else {
+                    if (used || matched) { if (prev2 == KC_LDS_NONE) head2 = nxt; else b.scr[nA + prev2] = nxt; } else prev2 = eidx;
+                    cur2 = nxt;
+                    if (cur2 != KC_LDS_NONE) u2 = ov_mirror(b.B[cur2], S);
+                }
             }
-            use_scratch = true;
-            cur_n = out_n;
         }
         nev_shared = nev;
     }
