@@ -168,6 +168,58 @@ def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, mon
             s1.close(); s2.close()
 
 
+def _export_keys_np(s):
+    """the set's keys as a numpy array (single-word keys), through the C ABI"""
+    import ctypes
+    import numpy as np
+    n = s.size()
+    buf = np.empty(max(1, n), dtype=np.uint64)
+    s.ctx.check(s.ctx.lib.kc_set_export(s.h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    return buf[:n]
+
+
+def test_full_size_properties_cfg1(ctx):
+    """BASELINE configs[1] at full size (100 000 records x 1 030 bp, k = 31: 10^8 k-mers), checked through properties that
+    do not need the oracle: (a) two runs give identical bytes (the result does not depend on the schedule); (b) min-one
+    mask: ones == N; (c) round trip: the k-mers starting at the upper-case positions of the output (re-read with the
+    case-sensitive AddKMers, as maskopt does) are exactly the input's k-mer set (equal size, equal order-free checksums,
+    spot checks both ways); (d) length bounds N + k - 1 <= L <= N + S(k-1); (e) -M has at least as many ones and the
+    same characters."""
+    import hashlib
+    import numpy as np
+    k = 31
+    seq = gen.random_joined(100000, 1030, seed=1)
+    raw = seq.tobytes()
+    r = kc.compute(ctx, raw, k, True, want_mask=True)
+    N, S, L = r.stats["n_kmers"], r.stats["n_simplitigs"], r.length
+    out, mask = r.strings(want_mask=True)
+    r.close()
+    assert 100000 * 1000 - 20 <= N <= 100000 * 1000          # i.i.d. sequence: duplicates are (almost) impossible
+    assert N + k - 1 <= L <= N + S * (k - 1)
+    o = np.frombuffer(out.encode(), dtype=np.uint8)
+    m = np.frombuffer(mask.encode(), dtype=np.uint8)
+    assert int((o < 97).sum()) == N                              # (b)
+    assert int((m < 97).sum()) >= N and np.array_equal(o & 0xDF, m & 0xDF)   # (e)
+    r2 = kc.compute(ctx, raw, k, True, want_mask=False)        # (a)
+    out2, _ = r2.strings()
+    r2.close()
+    assert hashlib.md5(out2.encode()).hexdigest() == hashlib.md5(out.encode()).hexdigest()
+    # (c) round trip through the sets
+    a = kc.KmerSet(ctx, k, True, capacity_hint=len(raw))
+    a.AddKMers(raw)
+    b = kc.KmerSet(ctx, k, True, capacity_hint=len(out))
+    b.AddKMers(out, case_sensitive=True)
+    assert a.size() == N and b.size() == N
+    ka, kb = _export_keys_np(a), _export_keys_np(b)
+    mix = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        assert int(ka.sum(dtype=np.uint64)) == int(kb.sum(dtype=np.uint64))
+        assert int(np.bitwise_xor.reduce(ka * mix)) == int(np.bitwise_xor.reduce(kb * mix))
+    probe = [int(x) for x in ka[:: max(1, N // 500)][:500]]
+    assert all(b.contains(probe)) and all(a.contains([int(x) for x in kb[:: max(1, N // 500)][:500]]))
+    a.close(); b.close()
+
+
 def test_simplitigs_reference_kats(ctx):
     # tests/simplitigs_unittest.h:183-208 (order-tolerant there: sorted by length)
     enc = oracle_lib.encode_kmer
