@@ -333,6 +333,46 @@ static int select_flagged_nosync(OvWork &w, const u64 *in, const u8 *flags, u64 
     return KC_OK;
 }
 
+// Small inputs (most levels: a few hundred to a few thousand hits) are sorted by ONE workgroup in LDS -- a bitonic network
+// over (key, id) rows; ids are ascending in the input, so ordering by (key, id) is the stable order by key.  The library
+// radix sort costs 4-8 launches per call, which is what a level with few hits was spending its time on.
+template <int W>
+__global__ void __launch_bounds__(1024) ov_small_sort_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ ids, u32 n, u32 P,
+                                                             u64 *keys_out, u64 *ids_out) {
+    extern __shared__ u64 kc_srt[];   // P ids, then W planes of P key words
+    u64 *sid = kc_srt;
+    u64 *sk = kc_srt + P;
+    for (u32 i = threadIdx.x; i < P; i += blockDim.x) {
+        sid[i] = i < n ? ids[i] : ~(u64)0;
+        for (int j = 0; j < W; ++j) sk[(u32)j * P + i] = i < n ? keys[(u64)i * W + j] : ~(u64)0;
+    }
+    __syncthreads();
+    auto greater = [&](u32 a, u32 b) -> bool {   // row a sorts after row b
+        for (int j = W - 1; j >= 0; --j) {
+            const u64 x = sk[(u32)j * P + a], y = sk[(u32)j * P + b];
+            if (x != y) return x > y;
+        }
+        return sid[a] > sid[b];
+    };
+    for (u32 size = 2; size <= P; size <<= 1) {
+        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+            for (u32 t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const u32 lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                if (greater(lo, hi) == up) {
+                    u64 tmp = sid[lo]; sid[lo] = sid[hi]; sid[hi] = tmp;
+                    for (int j = 0; j < W; ++j) { tmp = sk[(u32)j * P + lo]; sk[(u32)j * P + lo] = sk[(u32)j * P + hi]; sk[(u32)j * P + hi] = tmp; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        ids_out[i] = sid[i];
+        for (int j = 0; j < W; ++j) keys_out[(u64)i * W + j] = sk[(u32)j * P + i];
+    }
+}
+
 // stable sort of n rows (W-word keys, 2*d significant bits) with their ids; outputs in keys_out / ids_out
 static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, int d, u64 *keys_out, u64 *ids_out, u64 *s0, u64 *s1,
                      u64 *s2, u64 *s3) {
@@ -341,6 +381,19 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
     if (total_bits == 0) {
         KC_HIP(ctx, hipMemcpyAsync(keys_out, keys, n * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemcpyAsync(ids_out, ids, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return KC_OK;
+    }
+    const u64 small_limit = 1024;   // beyond ~1k rows the library radix sort wins (measured); LDS: P * (W + 1) * 8 bytes
+    if (n <= small_limit && !getenv("KC_NO_SMALL_SORT")) {
+        u32 P = 2;
+        while (P < n) P <<= 1;
+        const size_t lds = (size_t)P * (W + 1) * 8;
+        switch (W) {
+            case 1: hipLaunchKernelGGL(ov_small_sort_kernel<1>, dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, keys_out, ids_out); break;
+            case 2: hipLaunchKernelGGL(ov_small_sort_kernel<2>, dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, keys_out, ids_out); break;
+            default: hipLaunchKernelGGL(ov_small_sort_kernel<4>, dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, keys_out, ids_out); break;
+        }
+        KC_HIP(ctx, hipGetLastError());
         return KC_OK;
     }
     if (W == 1) {
