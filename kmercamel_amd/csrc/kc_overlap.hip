@@ -109,7 +109,7 @@ template <int W> __device__ __forceinline__ bool is_representative(const Key<W> 
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, const u64 *__restrict__ actS, u64 nS,
                                                               const u64 *__restrict__ suf, const u64 *__restrict__ pre, int k, int d,
-                                                              int complements, u8 *hitS, u64 *hit_count) {
+                                                              int complements, u8 *hitS, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nS) return;
     u64 v = actS[i];
@@ -121,13 +121,16 @@ __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, c
         if (is_representative(key, d, complements)) hit = 1;
     }
     hitS[i] = hit;
-    if (hit) atomicAdd((ull *)hit_count, 1ULL);
+    if (hit) {   // the first hit_cap hits are also listed (unordered): a level with few hits skips the ordered compaction
+        const u64 pos = atomicAdd((ull *)hit_count, 1ULL);
+        if (pos < hit_cap) hit_list[pos] = v;
+    }
 }
 
 template <int W>
 __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
                                                              const u64 *__restrict__ pre, const u64 *__restrict__ pslot, int k, int d,
-                                                             int complements, u8 *hitP, u64 *hit_count) {
+                                                             int complements, u8 *hitP, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nP) return;
     u8 hit = 0;
@@ -136,7 +139,10 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
         if (is_representative(key, d, complements)) hit = 1;
     }
     hitP[i] = hit;
-    if (hit) atomicAdd((ull *)hit_count, 1ULL);
+    if (hit) {
+        const u64 pos = atomicAdd((ull *)hit_count, 1ULL);
+        if (pos < hit_cap) hit_list[pos] = actP[i];
+    }
 }
 
 template <int W, bool SUFFIX>
@@ -336,15 +342,25 @@ static int select_flagged_nosync(OvWork &w, const u64 *in, const u8 *flags, u64 
 // Small inputs (most levels: a few hundred to a few thousand hits) are sorted by ONE workgroup in LDS -- a bitonic network
 // over (key, id) rows; ids are ascending in the input, so ordering by (key, id) is the stable order by key.  The library
 // radix sort costs 4-8 launches per call, which is what a level with few hits was spending its time on.
-template <int W>
+// MODE 0: keys given; MODE 1 / 2: the key of row i is the d-mer suffix / prefix of ends[ids[i]] (the rows may then come in
+// any order, e.g. straight from the hit list of the probe kernels).
+#define KC_SMALL_ROWS 1024
+template <int W, int MODE>
 __global__ void __launch_bounds__(1024) ov_small_sort_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ ids, u32 n, u32 P,
-                                                             u64 *keys_out, u64 *ids_out) {
+                                                             const u64 *__restrict__ ends, int k, int d, u64 *keys_out, u64 *ids_out) {
     extern __shared__ u64 kc_srt[];   // P ids, then W planes of P key words
     u64 *sid = kc_srt;
     u64 *sk = kc_srt + P;
     for (u32 i = threadIdx.x; i < P; i += blockDim.x) {
-        sid[i] = i < n ? ids[i] : ~(u64)0;
-        for (int j = 0; j < W; ++j) sk[(u32)j * P + i] = i < n ? keys[(u64)i * W + j] : ~(u64)0;
+        const u64 id = i < n ? ids[i] : ~(u64)0;
+        sid[i] = id;
+        Key<W> key;
+        for (int j = 0; j < W; ++j) key.w[j] = ~(u64)0;
+        if (i < n) {
+            if (MODE == 0) key = load_key<W>(keys, i);
+            else { Key<W> e = load_key<W>(ends, id); key = (MODE == 1) ? key_suffix(e, d) : key_prefix(e, k, d); }
+        }
+        for (int j = 0; j < W; ++j) sk[(u32)j * P + i] = key.w[j];
     }
     __syncthreads();
     auto greater = [&](u32 a, u32 b) -> bool {   // row a sorts after row b
@@ -383,15 +399,14 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         KC_HIP(ctx, hipMemcpyAsync(ids_out, ids, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return KC_OK;
     }
-    const u64 small_limit = 1024;   // beyond ~1k rows the library radix sort wins (measured); LDS: P * (W + 1) * 8 bytes
-    if (n <= small_limit && !getenv("KC_NO_SMALL_SORT")) {
+    if (n <= KC_SMALL_ROWS && !getenv("KC_NO_SMALL_SORT")) {   // beyond ~1k rows the library radix sort wins (measured)
         u32 P = 2;
         while (P < n) P <<= 1;
         const size_t lds = (size_t)P * (W + 1) * 8;
         switch (W) {
-            case 1: hipLaunchKernelGGL(ov_small_sort_kernel<1>, dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, keys_out, ids_out); break;
-            case 2: hipLaunchKernelGGL(ov_small_sort_kernel<2>, dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, keys_out, ids_out); break;
-            default: hipLaunchKernelGGL(ov_small_sort_kernel<4>, dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, keys_out, ids_out); break;
+            case 1: hipLaunchKernelGGL((ov_small_sort_kernel<1, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
+            case 2: hipLaunchKernelGGL((ov_small_sort_kernel<2, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
+            default: hipLaunchKernelGGL((ov_small_sort_kernel<4, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
         }
         KC_HIP(ctx, hipGetLastError());
         return KC_OK;
@@ -492,24 +507,44 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                            (const u64 *)pre, k, d, pslot);
         hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
-                           (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1);
+                           (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS);
         hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
-                           (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3);
+                           (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
         KC_TRY(read_back(ctx, hp, cnt, 4));
         const u64 nHS = hp[1], nHP = hp[3];
         if (trace) t_hits = now_us();
         if ((nHS == 0 || nHP == 0) && trace) fprintf(stderr, "[ov] d=%d nS=%llu no hits: %.0f us\n", d, (unsigned long long)nS, t_hits - t_level);
         if (nHS == 0 || nHP == 0) continue;   // no key seen from both sides at this overlap length
-        // 2. compact the hits (ordered); the counts are already known
-        KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
-        KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, nP));
-        hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
-                           (const u64 *)suf, k, d, hs_keys);
-        hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
-                           (const u64 *)pre, k, d, hp_keys);
-        // 3. sort by key (stable: ids ascending inside a key)
-        KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
-        KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3));
+        // 2. compact the hits (ordered; the counts are already known) ...
+        // 3. ... and sort them by key (stable: ids ascending inside a key).  Few hits: the probe kernels have listed them
+        // already (unordered); one workgroup derives the keys and sorts the rows by (key, id) in LDS.
+        const bool small_ok = !getenv("KC_NO_SMALL_SORT");
+        auto small_side = [&](bool suffix_side, const u64 *ids_in, u64 n, u64 *keys_o, u64 *ids_o) {
+            u32 P = 2;
+            while (P < n) P <<= 1;
+            const size_t lds = (size_t)P * (W + 1) * 8;
+            if (suffix_side)
+                hipLaunchKernelGGL((ov_small_sort_kernel<W, 1>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
+                                   (const u64 *)suf, k, d, keys_o, ids_o);
+            else
+                hipLaunchKernelGGL((ov_small_sort_kernel<W, 2>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
+                                   (const u64 *)pre, k, d, keys_o, ids_o);
+        };
+        if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
+        else {
+            KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
+            hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
+                               (const u64 *)suf, k, d, hs_keys);
+            KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
+        }
+        if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
+        else {
+            KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, nP));
+            hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
+                               (const u64 *)pre, k, d, hp_keys);
+            KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3));
+        }
+        KC_HIP(ctx, hipGetLastError());
         if (trace) { (void)hipStreamSynchronize(ctx->stream); t_sorted = now_us(); }
         // 4./5. match, verify, repair
         u64 nNew = 0;
