@@ -959,7 +959,6 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         scope.release(tmp);
     }
     // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
-    const bool k31 = (W == 1 && k == 31 && set->mlen == 15);
     u64 *branch = work_b, *branch_cursor = cnt + 4;   // branch ports of round 1 (work_b is free until round 2)
     // sharded round-1 lists (gathered into `heads` / `branch` right after the kernel)
     u64 *heads_sh = nullptr, *branch_sh = nullptr, *shard_cur = nullptr;
@@ -976,8 +975,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     int per_wg = KC_CHOOSE_PER_WG;
     if (const char *e = getenv("KC_PER_WG")) { int v = atoi(e); if (v >= 256 && v % 256 == 0) per_wg = v; }
     const unsigned cgrid = kc_grid8(N, (unsigned)per_wg);
-    if (k31)
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, (W == 1 ? 31 : 0)>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
+    // compile-time k for the benchmark configurations (k = 31 / 63 / 127 with m = 15): constant trip counts everywhere
+    constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
+    if (k == KSPEC && set->mlen == 15 && !getenv("KC_NO_KSPEC"))
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, KSPEC>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
                            (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
                            stage_words, per_wg);
     else
