@@ -213,13 +213,15 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
 // block -- consecutive k-mers share their minimizer, so a thread reserves space once per RUN of equal blocks; (2) one
 // workgroup per block builds that block's 16384-slot table in LDS (LDS compare-and-swap, no global atomics) and writes it
 // out with coalesced stores; (3) the few keys whose 128 local probes were all taken go through the global insert.
-#define KC_BUCKET_PPT 16
+// (positions per thread: 16 single-word keys, 8 wide ones -- the keys of an open run are staged in LDS)
+template <int W>
 __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
                                                                 const u64 *__restrict__ low, u64 len, int k, int complements,
-                                                                int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters) {
+                                                                int case_sensitive, SetView<W> set, u64 *bucket, u64 *bcursor, u64 *counters,
+                                                                int ppt) {
     extern __shared__ u32 kc_ring[];
     const int win = k - set.m + 1;
-    u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)win * blockDim.x);   // stage[j * blockDim + tid]: keys of the open run
+    u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)win * blockDim.x);   // stage[(j * W + w) * blockDim + tid]: keys of the open run
     const u64 bs = (u64)1 << set.bshift;
     u32 nrun = 0;
     u64 run_blk = 0;
@@ -227,71 +229,101 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
     auto flush = [&]() {
         if (!nrun) return;
         const u64 base = atomicAdd((ull *)&bcursor[run_blk], (ull)nrun);
-        if (base + nrun <= bs) {
-            u64 *dst = bucket + (run_blk << set.bshift) + base;
-            for (u32 j = 0; j < nrun; ++j) dst[j] = stage[j * blockDim.x + threadIdx.x];
-        } else overflow = true;
+        // a bucket that overflows keeps the part of the run that still fits (so that its first `bs` entries are all real
+        // keys for the build kernel) and raises the flag: the caller then re-inserts the whole input through the global path
+        u32 fit = nrun;
+        if (base + nrun > bs) { overflow = true; fit = base < bs ? (u32)(bs - base) : 0; }
+        u64 *dst = bucket + ((run_blk << set.bshift) + base) * W;
+        for (u32 j = 0; j < fit * W; ++j) dst[j] = stage[j * blockDim.x + threadIdx.x];
         nrun = 0;
     };
-    kc_roll_kmers<1>(codes, brk, low, len, k, complements, case_sensitive, set.m, KC_BUCKET_PPT, kc_ring, [&](const Key<1> &key, u32 mmh) {
+    kc_roll_kmers<W>(codes, brk, low, len, k, complements, case_sensitive, set.m, ppt, kc_ring, [&](const Key<W> &key, u32 mmh) {
         const u64 blk = set_block_home(set, mmh, 0) >> set.bshift;
         if (nrun && blk != run_blk) flush();
         run_blk = blk;
-        stage[nrun * blockDim.x + threadIdx.x] = key.w[0];
+        for (int w = 0; w < W; ++w) stage[(nrun * W + w) * blockDim.x + threadIdx.x] = key.w[w];
         ++nrun;
     });
     flush();
     if (overflow) atomicExch((ull *)&counters[3], 1ULL);
 }
 
-// one workgroup per table block; dynamic LDS: (1 << bshift) keys + (1 << bshift) tag bytes
-__global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<1> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
+// one workgroup per table block; dynamic LDS: (1 << bshift) keys of W words + (1 << bshift) tag bytes.  A slot is claimed
+// by an LDS compare-and-swap on its MOST significant key word (never all ones: 2k < 64 W), then the other words and
+// finally the tag byte are written; a lane that finds "its" top word in an unpublished slot looks again in its next loop
+// iteration (nobody waits inside an iteration, so lanes of one wave cannot block each other).
+template <int W>
+__global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
                                                               int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap) {
     extern __shared__ u64 kc_blk[];
     const u32 bs = 1u << set.bshift;
     u64 *lk = kc_blk;
-    u8 *lt = reinterpret_cast<u8 *>(kc_blk + bs);
+    volatile u8 *lt = reinterpret_cast<volatile u8 *>(kc_blk + (size_t)bs * W);
     __shared__ u32 added_s;
     const u64 base = (u64)blockIdx.x << set.bshift;
     if (threadIdx.x == 0) added_s = 0;
-    for (u32 i = threadIdx.x; i < bs; i += blockDim.x) lk[i] = fresh ? ~(u64)0 : set.keys[base + i];
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
-        reinterpret_cast<u64 *>(lt)[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
+        reinterpret_cast<u64 *>(const_cast<u8 *>(lt))[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) {
+        // keys of empty slots are undefined in the wide-key table (their state says so): only the claim word matters here
+        const bool occupied = !fresh && lt[i / W] != 0;
+        lk[i] = occupied ? set.keys[base * W + i] : ~(u64)0;
+    }
     __syncthreads();
     u64 n = bcursor[blockIdx.x];
     if (n > bs) n = bs;   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
     const u32 span = set_block_span(set);
     u32 added = 0;
     for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
-        const u64 kv = bucket[base + j];
-        Key<1> key; key.w[0] = kv;
+        Key<W> key;
+        for (int w = 0; w < W; ++w) key.w[w] = bucket[(base + j) * W + w];
+        const u64 top = key.w[W - 1];
         const u64 ph = key_place_hash(key);
         const u32 off = (u32)(((u64)(u32)ph * span) >> 32);
         bool done = false;
-        for (u32 p = 0; p < set.local_probes && !done; ++p) {
+        u32 p = 0;
+        while (p < set.local_probes && !done) {
             const u32 s = off + p;
-            u64 cur = lk[s];
-            if (cur == ~(u64)0) cur = atomicCAS((ull *)&lk[s], ~0ULL, (ull)kv);
-            if (cur == ~(u64)0) { lt[s] = kc_tag_of(ph); ++added; done = true; }
-            else if (cur == kv) done = true;
+            u64 cur = lk[(size_t)s * W + W - 1];
+            if (cur == ~(u64)0) cur = atomicCAS((ull *)&lk[(size_t)s * W + W - 1], ~0ULL, (ull)top);
+            if (cur == ~(u64)0) {   // claimed: publish
+                for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lt[s] = kc_tag_of(ph);
+                ++added;
+                done = true;
+            } else if (cur == top) {
+                if (W > 1 && lt[s] == 0) continue;   // being published by another lane: look again (p unchanged)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                bool eq = true;
+                for (int w = 0; w < W - 1; ++w) eq = eq && (lk[(size_t)s * W + w] == key.w[w]);
+                if (eq) done = true; else ++p;
+            } else ++p;
         }
         if (!done) {   // block-local run exhausted: the global insert (second home) takes it after all blocks are written
             const u64 pos = atomicAdd((ull *)&counters[2], 1ULL);
-            if (pos < ovf_cap) ovf_list[pos] = kv;
+            if (pos < ovf_cap)
+                for (int w = 0; w < W; ++w) ovf_list[pos * W + w] = key.w[w];
         }
     }
     if (added) atomicAdd(&added_s, added);
     __syncthreads();
-    for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.keys[base + i] = lk[i];
-    for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x) reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(lt)[i];
+    for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
+    for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
+        reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
+    if (W > 1)
+        for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
     if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.cap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at cap
     if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
 }
 
-__global__ void __launch_bounds__(256) kc_insert_list_kernel(SetView<1> set, const u64 *__restrict__ list, u64 n, u64 *counters) {
+template <int W>
+__global__ void __launch_bounds__(256) kc_insert_list_kernel(SetView<W> set, const u64 *__restrict__ list, u64 n, u64 *counters) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    Key<1> key; key.w[0] = list[t];
+    Key<W> key;
+    for (int w = 0; w < W; ++w) key.w[w] = list[t * W + w];
     u64 slot;
     int r = set_insert(set, key, &slot);
     if (r > 0) atomicAdd((ull *)&counters[0], 1ULL);
@@ -353,6 +385,8 @@ int kcs_clean_table(const kc_set *s) {
     return set_fill_table(s->ctx, s->W, s->cap, s->keys, s->state, s->tags);
 }
 
+static int bucketed_max_bshift(int W) { return W == 1 ? 14 : (W == 2 ? 13 : 12); }
+
 extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capacity_hint, kc_set **out) {
     if (!ctx || !out) return KC_E_ARG;
     *out = nullptr;
@@ -361,9 +395,9 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     kc_set *s = new kc_set();
     s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
     s->mlen = k >= 16 ? 15 : 0;
-    // slots per block: large enough that the skewed minimizer popularity does not overflow blocks; single-word keys use
-    // 16384 so that one block (128 KB of keys + 16 KB of tags) fits the LDS of a CU for the bucketed build
-    s->bshift = s->W == 1 ? 14 : 15;
+    // slots per block: as large as the LDS of a CU allows for the bucketed build (128 KB of keys + the tags): 16384 / 8192 /
+    // 4096 for 1 / 2 / 4 key words; large blocks keep the skewed minimizer popularity from overflowing them
+    s->bshift = bucketed_max_bshift(s->W);
     if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v < k) ? v : 0; }   // tuning/ablation knobs
     if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= 20) s->bshift = v; }
     if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
@@ -473,54 +507,66 @@ static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, cons
     return KC_OK;
 }
 
-// bucketed build: see kc_bucket_scatter_kernel.  Needs single-word keys, minimizer blocks whose table fits the LDS of a
-// CU (16384 slots), no occurrence counting; small inputs are not worth the three launches.
+// bucketed build: see kc_bucket_scatter_kernel.  Needs minimizer blocks whose table fits the LDS of a CU (16384 / 8192 /
+// 4096 slots for 1 / 2 / 4 key words), no occurrence counting; small inputs are not worth the three launches.
 static bool bucketed_applies(const kc_set *set, u64 len) {
     u64 min_len = (u64)1 << 20;
     if (const char *e = getenv("KC_BUCKET_MIN")) min_len = (u64)atoll(e);   // tests force either path
-    return set->W == 1 && set->mlen && set->bshift <= 14 && set->bshift >= 9 && !set->counts && len >= min_len &&
+    return set->mlen && set->bshift <= bucketed_max_bshift(set->W) && set->bshift >= 9 && !set->counts && len >= min_len &&
            set->local_probes + 8 < ((u32)1 << set->bshift) / 2;
 }
 
-static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
     kc_ctx *ctx = set->ctx;
     KcScope scope(ctx);
     const u64 bs = (u64)1 << set->bshift;
     const u64 ovf_cap = (u64)1 << 20;
     u64 *bucket = nullptr, *bcursor = nullptr, *ovf = nullptr;
-    KC_TRY(scope.alloc(&bucket, set->cap));
+    KC_TRY(scope.alloc(&bucket, set->cap * W));
     KC_TRY(scope.alloc(&bcursor, set->nblocks));
-    KC_TRY(scope.alloc(&ovf, ovf_cap));
+    KC_TRY(scope.alloc(&ovf, ovf_cap * W));
     KC_HIP(ctx, hipMemsetAsync(bcursor, 0, set->nblocks * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
     const int win = set->k - set->mlen + 1;
-    const size_t lds_scatter = (size_t)win * 256 * 4 + (size_t)KC_BUCKET_PPT * 256 * 8;
-    const u64 nthreads = (len + KC_BUCKET_PPT - 1) / KC_BUCKET_PPT;
-    hipLaunchKernelGGL(kc_bucket_scatter_kernel, dim3(kc_grid(nthreads, 256)), dim3(256), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
-                       set->k, set->complements, case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters);
-    const size_t lds_build = (size_t)bs * 9;
+    const int ppt = W == 1 ? 16 : 8;
+    const unsigned tb = win <= 40 ? 256 : (win <= 80 ? 128 : 64);    // LDS ring: win * tb * 4 bytes (<= 40 KB) + staged run keys
+    const size_t lds_scatter = (size_t)win * tb * 4 + (size_t)ppt * W * tb * 8;
+    const u64 nthreads = (len + ppt - 1) / ppt;
+    hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
+                       set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt);
+    const size_t lds_build = (size_t)bs * (8 * W + 1);
     static bool attr_done = false;
     if (!attr_done) {
-        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         attr_done = true;
     }
     const int fresh = set->size_host == 0 ? 1 : 0;
     if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
-    set->unclean = false;                        // the build kernel writes every slot and tag of every block
-    hipLaunchKernelGGL(kc_block_build_kernel, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<1>(set), (const u64 *)bucket,
+    set->unclean = false;                        // the build kernel writes every slot, state and tag of every block
+    hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
                        (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap);
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (getenv("KC_SET_TRACE"))
+        fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu\n", W,
+                (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3]);
     if (h[3] || h[2] > ovf_cap)   // a bucket (or the spill list) overflowed: the global path inserts whatever is still missing
         return insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);
     if (h[2]) {
-        hipLaunchKernelGGL(kc_insert_list_kernel, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<1>(set), (const u64 *)ovf, h[2],
+        hipLaunchKernelGGL(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)ovf, h[2],
                            set->counters);
         KC_HIP(ctx, hipGetLastError());
     }
     return KC_OK;
+}
+static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+    switch (set->W) {
+        case 1: return insert_bucketed_w<1>(set, d_codes, d_brk, d_low, len, case_sensitive);
+        case 2: return insert_bucketed_w<2>(set, d_codes, d_brk, d_low, len, case_sensitive);
+        default: return insert_bucketed_w<4>(set, d_codes, d_brk, d_low, len, case_sensitive);
+    }
 }
 
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {

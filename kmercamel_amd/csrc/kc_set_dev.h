@@ -150,9 +150,10 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
                     for (int i = 0; i < W; ++i)
                         __hip_atomic_store(&s.keys[slot * W + i], key.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // publish: the key words above are agent-scope (sc1, write-through) stores and every reader uses agent-scope
-                    // loads, so draining them (workgroup-scope release = s_waitcnt only) before the state store is enough; an
-                    // agent-scope RELEASE here would write back the whole L2 on every insert (measured: 214 ms per 10^8 k-mers)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    // loads, so it is enough to drain them before the state store.  An agent-scope RELEASE would write back the
+                    // whole L2 on every insert (measured: 214 ms per 10^8 k-mers); a workgroup-scope fence compiles to nothing and
+                    // lets the state store overtake the keys (seen as a handful of duplicate k-mers) -- hence the explicit wait.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(&s.state[slot], KC_ST_FULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     set_write_tag(s, slot, kc_tag_of(kh));
                     *slot_out = slot;

@@ -168,6 +168,24 @@ def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, mon
             s1.close(); s2.close()
 
 
+@pytest.mark.parametrize("k", [31, 40, 100])
+def test_bucket_overflow_falls_back_to_direct_inserts(ctx, oracle, k, monkeypatch):
+    """A short read repeated thousands of times sends more occurrences to a few table blocks than a bucket holds: the
+    bucketed build keeps what fits, raises its overflow flag, and the direct insert kernel adds the rest (1 / 2 / 4 key words)."""
+    monkeypatch.setenv("KC_BUCKET_MIN", "0")
+    rng = random.Random(900 + k)
+    read = _rand_seq(rng, k + 300)
+    other = [_rand_seq(rng, 400) for _ in range(50)]
+    seq = "\n".join([read] * 4000 + other)
+    want = sorted(set(oracle.kmer_set(read, k, True)) | set(x for o in other for x in oracle.kmer_set(o, k, True)))
+    s = kc.KmerSet(ctx, k, True, capacity_hint=len(seq))
+    s.AddKMers(seq)
+    assert s.size() == len(want) and sorted(s.keys()) == want
+    sim = kc.get_simplitigs(s)
+    assert sim.strings() == oracle.simplitigs_of_sequence(seq.replace("\n", "N"), k, True, mode=1)
+    sim.close(); s.close()
+
+
 def _export_keys_np(s):
     """the set's keys as a numpy array (single-word keys), through the C ABI"""
     import ctypes
