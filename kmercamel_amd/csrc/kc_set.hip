@@ -218,7 +218,7 @@ template <int W>
 __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
                                                                 const u64 *__restrict__ low, u64 len, int k, int complements,
                                                                 int case_sensitive, SetView<W> set, u64 *bucket, u64 *bcursor, u64 *counters,
-                                                                int ppt) {
+                                                                int ppt, u32 stage_cap) {
     extern __shared__ u32 kc_ring[];
     const int win = k - set.m + 1;
     u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)win * blockDim.x);   // stage[(j * W + w) * blockDim + tid]: keys of the open run
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
     };
     kc_roll_kmers<W>(codes, brk, low, len, k, complements, case_sensitive, set.m, ppt, kc_ring, [&](const Key<W> &key, u32 mmh) {
         const u64 blk = set_block_home(set, mmh, 0) >> set.bshift;
-        if (nrun && blk != run_blk) flush();
+        if (nrun && (blk != run_blk || nrun == stage_cap)) flush();   // (a run longer than the staging area is reserved in pieces)
         run_blk = blk;
         for (int w = 0; w < W; ++w) stage[(nrun * W + w) * blockDim.x + threadIdx.x] = key.w[w];
         ++nrun;
@@ -528,12 +528,14 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_HIP(ctx, hipMemsetAsync(bcursor, 0, set->nblocks * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
     const int win = set->k - set->mlen + 1;
-    const int ppt = W == 1 ? 16 : 8;
+    // positions per thread: every thread first rolls over the k-1 bases before its range, so wide k wants long ranges
+    const int ppt = W == 1 ? 16 : (W == 2 ? 32 : 64);
+    const u32 stage_cap = W == 1 ? 16 : 8;                             // staged keys per thread (a longer run is flushed in pieces)
     const unsigned tb = win <= 40 ? 256 : (win <= 80 ? 128 : 64);    // LDS ring: win * tb * 4 bytes (<= 40 KB) + staged run keys
-    const size_t lds_scatter = (size_t)win * tb * 4 + (size_t)ppt * W * tb * 8;
+    const size_t lds_scatter = (size_t)win * tb * 4 + (size_t)stage_cap * W * tb * 8;
     const u64 nthreads = (len + ppt - 1) / ppt;
     hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
-                       set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt);
+                       set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap);
     const size_t lds_build = (size_t)bs * (8 * W + 1);
     static bool attr_done = false;
     if (!attr_done) {
