@@ -590,6 +590,8 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
             if (__hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicExch((ull *)(cursor + 7), 1ULL);
             return;
         }
+        // once any walk has hit the limit the whole pass is void: stop wasting steps (checked every 256 steps)
+        if (limit != ~(u64)0 && (len & 255) == 0 && __hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     }
     Key<W> hk = set_key_at(set, slot);
     bool winner = true;
@@ -616,34 +618,66 @@ __global__ void __launch_bounds__(256) kc_unvisited_kernel(SetView<W> set, const
     if (FILL) list[pos] = slot;
 }
 
-// cycles (rare): one thread, sequential. Cut each cycle at its minimum key, on that node's port L.
+// cycles (rare): one thread, sequential.  Cut each cycle at its minimum key, on that node's port L, and append the cut
+// ends to the head list (cursor[0] = number of heads); the chains are then found by the ordinary discovery pass.
 template <int W>
-__global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, u8 *visited, u64 *chain_head,
-                                 u64 *chain_len, u64 *chain_key, u64 *cursor) {
+__global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, u8 *visited, int complements, u64 *heads,
+                                 u64 *cursor) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    u64 nh = cursor[0];
     for (u64 i = 0; i < nlist; ++i) {
         u64 start = list[i];
         if (visited[start]) continue;
-        u64 cur = start, best = start, len = 0;
+        u64 cur = start, best = start;
         int co = 0;
         Key<W> bk = set_key_at(set, start);
         do {
             visited[cur] = 1;
-            ++len;
             Key<W> ck = set_key_at(set, cur);
             if (key_lt(ck, bk)) { bk = ck; best = cur; }
             u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
             cur = LK_SLOT(w);
             co = LK_PORT(w) == 0 ? 0 : 1;
         } while (cur != start);
-        u64 wl = link[(best << 1) | 0];
-        link[LK_PID(wl)] = LK_DEAD;
-        link[(best << 1) | 0] = LK_DEAD;
-        u64 pos = atomicAdd((ull *)cursor, 1ULL);
-        chain_head[pos] = (best << 1) | 0;
-        chain_len[pos] = len;
-        for (int j = 0; j < W; ++j) chain_key[pos * W + j] = bk.w[j];
+        const u64 wl = link[(best << 1) | 0];
+        const u64 partner = LK_PID(wl);              // the port that faced best's port L
+        link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
+        link[(best << 1) | 0] = LK_DEAD | (wl & LK_SPLIT);
+        heads[nh++] = (best << 1) | 0;                // entry port of orientation o is port o
+        if (complements || !(partner & 1)) { if (partner != ((best << 1) | 0)) heads[nh++] = partner; }
     }
+    cursor[0] = nh;
+}
+
+// the same cut, in parallel: every k-mer left on a cycle walks its cycle (at most `max_steps` steps) and the one holding the
+// cycle's minimum key cuts it.  A cycle longer than max_steps is left alone (cursor[2] = 1): the caller then runs the
+// sequential kernel above in a further pass.  Walkers may meet a link another thread has just cut: they simply stop.
+template <int W>
+__global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, int complements,
+                                                                 u64 *heads, u64 *cursor, u64 max_steps) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlist) return;
+    const u64 start = list[t];
+    u64 cur = start, steps = 0;
+    int co = 0;
+    const Key<W> sk = set_key_at(set, start);
+    do {
+        if (cur != start && key_lt(set_key_at(set, cur), sk)) return;   // not the minimum of its cycle
+        const u64 w = __hip_atomic_load(&link[(cur << 1) | (u64)(co == 0 ? 1 : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!LK_IS_MATCHED(w)) return;                                    // cut under our feet (then start is not the minimum either)
+        cur = LK_SLOT(w);
+        co = LK_PORT(w) == 0 ? 0 : 1;
+        if (++steps > max_steps) { atomicExch((ull *)(cursor + 2), 1ULL); return; }
+    } while (cur != start);
+    // start holds the minimum key of its cycle
+    const u64 wl = link[(start << 1) | 0];
+    const u64 partner = LK_PID(wl);
+    __hip_atomic_store(&link[partner], LK_DEAD | (link[partner] & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&link[(start << 1) | 0], LK_DEAD | (wl & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool two = (complements || !(partner & 1)) && partner != ((start << 1) | 0);
+    const u64 pos = atomicAdd((ull *)cursor, two ? 2ULL : 1ULL);
+    heads[pos] = (start << 1) | 0;
+    if (two) heads[pos + 1] = partner;
 }
 
 __global__ void __launch_bounds__(256) kc_iota_kernel(u64 *a, u64 n) {
@@ -780,22 +814,27 @@ __device__ __forceinline__ u64 kc_find_start(const u64 *starts, u64 n, u64 id) {
 }
 // one thread per start (sorted ascending): nodes until the next splitter (exclusive) or the tail (inclusive)
 __global__ void __launch_bounds__(256) kc_segment_walk_kernel(const u64 *__restrict__ link, const u64 *__restrict__ starts, u64 nstarts,
-                                                              u64 *seg_len, u64 *seg_next, u64 *seg_tail) {
+                                                              u64 *seg_len, u64 *seg_next, u64 *seg_tail, u8 *visited,
+                                                              const u64 *__restrict__ seg_chain) {
+    // visited != nullptr: marking pass -- only the segments that chain_reduce assigned to a chain with ends (seg_chain) mark
+    // their nodes (splitters on cycles start segments too, but no head reaches them), nothing else is written
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nstarts) return;
+    if (visited && seg_chain[j] == KC_SEG_NONE) return;
     u64 cur = starts[j] >> 1;
     int co = (int)(starts[j] & 1);
     u64 len = 1;
     u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
     while (true) {
-        if (!LK_IS_MATCHED(w)) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (cur << 1) | (u64)co; break; }
+        if (visited) visited[cur] = 1;
+        if (!LK_IS_MATCHED(w)) { if (!visited) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (cur << 1) | (u64)co; } break; }
         u64 nxt = LK_SLOT(w);
         int no = LK_PORT(w) == 0 ? 0 : 1;
         u64 wn = link[(nxt << 1) | (u64)(no == 0 ? 1 : 0)];
-        if (wn & LK_SPLIT) { seg_next[j] = kc_find_start(starts, nstarts, (nxt << 1) | (u64)no); seg_tail[j] = KC_SEG_NONE; break; }
+        if (wn & LK_SPLIT) { if (!visited) { seg_next[j] = kc_find_start(starts, nstarts, (nxt << 1) | (u64)no); seg_tail[j] = KC_SEG_NONE; } break; }
         cur = nxt; co = no; w = wn; ++len;
     }
-    seg_len[j] = len;
+    if (!visited) seg_len[j] = len;
 }
 // one thread per start that is a chain head: walk the list of segments
 template <int W>
@@ -1045,133 +1084,143 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         hipLaunchKernelGGL((kc_heads_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
                            cnt);
     }
-    // chain records: at most nheads chains from heads (+ cycles appended later; reallocated if needed)
-    u64 max_chains = nheads + 1;
-    u64 *chain_head = nullptr, *chain_len = nullptr, *chain_key = nullptr;
-    KC_TRY(scope.alloc(&chain_head, max_chains));
-    KC_TRY(scope.alloc(&chain_len, max_chains));
-    KC_TRY(scope.alloc(&chain_key, max_chains * W));
-    // ---- per-chain measure pass with a step limit: read-like inputs (chains of ~1000 nodes) finish here
-    u64 KC_CHAIN_LIMIT = 16384;
+    // ---- chain discovery.  Pass 0 works on the heads round 1..n produced.  K-mers on cycles (every port matched) are
+    // reached from no head: if the pass does not cover all N nodes, the cycles are cut (at their minimum key, on port L),
+    // the cut ends join the head list, and the discovery runs once more -- so long chains keep the segment-parallel path
+    // (and short ones the recorded-stream emit) whether or not the input has cycles.
+    u64 KC_CHAIN_LIMIT = 4096;   // longer chains take the segment-parallel path
     if (const char *e = getenv("KC_CHAIN_LIMIT")) { long v = atol(e); if (v >= 1) KC_CHAIN_LIMIT = (u64)v; }   // tests force the segment path
-    bool seg_ok = false;
-    u64 nstarts = 0;
-    u64 *starts = nullptr, *seg_len = nullptr, *seg_next = nullptr, *seg_tail = nullptr, *seg_chain = nullptr, *seg_off = nullptr;
-    u64 hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-    // recording pool of the measure pass: every walk needs at most steps/1024 + 1 chunks, all walks together make 2N steps
-    KcRec rec{};
+    const bool want_rec = !getenv("KC_NOREC");
     const KcRec no_rec{};
+    u64 *chain_head = nullptr, *chain_len = nullptr, *chain_key = nullptr;
+    u64 *starts = nullptr, *seg_len = nullptr, *seg_next = nullptr, *seg_tail = nullptr, *seg_chain = nullptr, *seg_off = nullptr;
     u32 *chunk_next = nullptr;
     u64 *pool = nullptr, *chain_stream = nullptr, *chain_tail = nullptr;
-    const bool want_rec = !getenv("KC_NOREC");
-    if (want_rec) {
-        rec.pool_cap = 2 * N / (32 * KC_CHUNK_WORDS) + 2 * nheads + 1024;
-        KC_TRY(scope.alloc(&pool, rec.pool_cap * KC_CHUNK_WORDS));
-        KC_TRY(scope.alloc(&chunk_next, rec.pool_cap));
-        KC_TRY(scope.alloc(&chain_stream, max_chains));
-        KC_TRY(scope.alloc(&chain_tail, max_chains));
-        rec.pool = pool; rec.chunk_next = chunk_next; rec.pool_cursor = cnt + 5; rec.chain_stream = chain_stream; rec.chain_tail = chain_tail;
-    }
-    if (nheads) {
-        if (want_rec)
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
-                               compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, KC_CHAIN_LIMIT, rec);
-        else
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
-                               compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, KC_CHAIN_LIMIT, no_rec);
-    }
-    KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, ctx->stream));
-    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const bool too_long = hc[7] != 0;
-    // the recordings are used when this pass was the one that produced the chains: no long chain, no cycles, pool not exhausted
-    const bool use_stream = want_rec && !too_long && hc[3] == N && hc[6] == 0;
-    if (!use_stream) { scope.release(pool); scope.release(chunk_next); scope.release(chain_stream); scope.release(chain_tail); }
-    // ---- some chain is long: segment-parallel path (needs: no cycles, splitter list did not overflow)
-    if (too_long) {
-        const u64 max_starts = nheads + 2 * nsplit_max + 1;
-        u64 *starts_raw = nullptr;
-        KC_TRY(scope.alloc(&starts_raw, max_starts));
-        KC_TRY(scope.alloc(&starts, max_starts));
-        KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                           (const u8 *)set->tags, cap, compl_, starts_raw, cnt + 6);
-        KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
-        {
-            size_t tb = 0;
-            KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
-            u8 *tmp = nullptr;
-            KC_TRY(scope.alloc(&tmp, tb));
-            KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            scope.release(tmp);
-        }
-        scope.release(starts_raw);
-        KC_TRY(scope.alloc(&seg_len, nstarts + 1)); KC_TRY(scope.alloc(&seg_next, nstarts + 1)); KC_TRY(scope.alloc(&seg_tail, nstarts + 1));
-        KC_TRY(scope.alloc(&seg_chain, nstarts + 1)); KC_TRY(scope.alloc(&seg_off, nstarts + 1));
-        KC_HIP(ctx, hipMemsetAsync(seg_chain, 0xff, (nstarts + 1) * 8, ctx->stream));
-        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
-        if (nstarts) {
-            hipLaunchKernelGGL(kc_segment_walk_kernel, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)starts,
-                               nstarts, seg_len, seg_next, seg_tail);
-            hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
-                               (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
-                               seg_off, chain_head, chain_len, chain_key, cnt);
-        }
-        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        seg_ok = (hc[3] == N);
-        hc[1] = 0;
-    }
-    // ---- long chains but the segment path is not applicable (cycles / splitter overflow): unlimited per-chain pass
-    if (too_long && !seg_ok) {
+    bool seg_ok = false, use_stream = false, known_long = false;
+    u64 nstarts = 0, nchains = 0;
+    for (int pass = 0;; ++pass) {
+        const u64 max_chains = nheads + 1;
+        KC_TRY(scope.alloc(&chain_head, max_chains));
+        KC_TRY(scope.alloc(&chain_len, max_chains));
+        KC_TRY(scope.alloc(&chain_key, max_chains * W));
+        // per-chain measure pass with a step limit: read-like inputs (chains of ~1000 nodes) finish here
+        u64 hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        if (nheads)
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
-                               compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
-        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+        // recording pool of the measure pass: every walk needs at most steps/1024 + 1 chunks, all walks together make 2N steps
+        KcRec rec{};
+        if (want_rec) {
+            rec.pool_cap = 2 * N / (32 * KC_CHUNK_WORDS) + 2 * nheads + 1024;
+            KC_TRY(scope.alloc(&pool, rec.pool_cap * KC_CHUNK_WORDS));
+            KC_TRY(scope.alloc(&chunk_next, rec.pool_cap));
+            KC_TRY(scope.alloc(&chain_stream, max_chains));
+            KC_TRY(scope.alloc(&chain_tail, max_chains));
+            rec.pool = pool; rec.chunk_next = chunk_next; rec.pool_cursor = cnt + 5; rec.chain_stream = chain_stream; rec.chain_tail = chain_tail;
+        }
+        if (nheads && !known_long) {
+            if (want_rec)
+                hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
+                                   (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
+                                   KC_CHAIN_LIMIT, rec);
+            else
+                hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
+                                   (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
+                                   KC_CHAIN_LIMIT, no_rec);
+        }
+        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 64, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    u8 *visited = nullptr;
-    if (hc[3] != N) {
-        // some k-mers are on cycles (every port matched, no head reaches them): mark what the chains cover, list the rest
+        const bool too_long = known_long || hc[7] != 0;
+        known_long = too_long;   // (cutting cycles only adds chains: a later pass need not find that out again)
+        // the recordings are used when this pass is the one that produces the chains: no long chain, no cycles, pool not exhausted
+        use_stream = want_rec && !too_long && hc[3] == N && hc[6] == 0;
+        if (!use_stream) {
+            scope.release(pool); scope.release(chunk_next); scope.release(chain_stream); scope.release(chain_tail);
+            pool = nullptr; chunk_next = nullptr; chain_stream = nullptr; chain_tail = nullptr;
+        }
+        nchains = hc[0];
+        if (!too_long && hc[3] == N) break;
+        // ---- some chain is long: segment-parallel path
+        seg_ok = false;
+        if (too_long) {
+            const u64 max_starts = nheads + 2 * nsplit_max + 1;
+            u64 *starts_raw = nullptr;
+            KC_TRY(scope.alloc(&starts_raw, max_starts));
+            KC_TRY(scope.alloc(&starts, max_starts));
+            KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                               (const u8 *)set->tags, cap, compl_, starts_raw, cnt + 6);
+            KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
+            {
+                size_t tb = 0;
+                KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
+                u8 *tmp = nullptr;
+                KC_TRY(scope.alloc(&tmp, tb));
+                KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
+                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                scope.release(tmp);
+            }
+            scope.release(starts_raw);
+            KC_TRY(scope.alloc(&seg_len, nstarts + 1)); KC_TRY(scope.alloc(&seg_next, nstarts + 1)); KC_TRY(scope.alloc(&seg_tail, nstarts + 1));
+            KC_TRY(scope.alloc(&seg_chain, nstarts + 1)); KC_TRY(scope.alloc(&seg_off, nstarts + 1));
+            KC_HIP(ctx, hipMemsetAsync(seg_chain, 0xff, (nstarts + 1) * 8, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
+            if (nstarts) {
+                hipLaunchKernelGGL(kc_segment_walk_kernel, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, (u8 *)nullptr, (const u64 *)nullptr);
+                hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                                   (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
+                                   seg_off, chain_head, chain_len, chain_key, cnt);
+            }
+            KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            seg_ok = (hc[3] == N);
+            nchains = hc[0];
+            if (seg_ok) break;
+        }
+        // ---- not every k-mer is on a chain with ends: cycles.  Mark what the heads reach, cut the rest, go again.
+        if (pass == 2) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not cover the set after cutting the cycles");
+        u8 *visited = nullptr;
         KC_TRY(scope.alloc(&visited, cap));
         KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        if (nheads)
+        if (too_long) {
+            if (nstarts)
+                hipLaunchKernelGGL(kc_segment_walk_kernel, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain);
+        } else if (nheads) {
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
+        }
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
                            (u64 *)nullptr, cnt + 1);
-        KC_HIP(ctx, hipMemcpyAsync(hc, cnt, 32, hipMemcpyDeviceToHost, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    u64 nchains = hc[0], nunvis = hc[1];
-    if (nunvis) {
-        u64 *ulist = nullptr;
+        u64 nunvis = 0;
+        KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
+        if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
+        u64 *ulist = nullptr, *heads2 = nullptr;
         KC_TRY(scope.alloc(&ulist, nunvis));
+        KC_TRY(scope.alloc(&heads2, nheads + 2 * nunvis + 1));   // every cycle adds at most two heads
+        KC_HIP(ctx, hipMemcpyAsync(heads2, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
                            cnt + 1);
-        // room for up to nunvis more chains
-        u64 *ch2 = nullptr, *cl2 = nullptr, *ck2 = nullptr;
-        u64 nmax2 = nchains + nunvis + 1;
-        KC_TRY(scope.alloc(&ch2, nmax2)); KC_TRY(scope.alloc(&cl2, nmax2)); KC_TRY(scope.alloc(&ck2, nmax2 * W));
-        KC_HIP(ctx, hipMemcpyAsync(ch2, chain_head, nchains * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(cl2, chain_len, nchains * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(ck2, chain_key, nchains * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(cnt, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
+        if (pass == 0)   // all cycles of up to 4096 k-mers at once; longer ones (if any) by the sequential kernel in the next pass
+            hipLaunchKernelGGL((kc_cycles_parallel_kernel<W>), dim3(kc_grid(nunvis, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)ulist,
+                               nunvis, compl_, heads2, cnt, (u64)4096);
+        else
+            hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited, compl_, heads2,
+                               cnt);
+        KC_TRY(read_u64(ctx, cnt, &nheads));
+        scope.release(heads); heads = heads2;
+        scope.release(ulist); scope.release(visited);
         scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
-        chain_head = ch2; chain_len = cl2; chain_key = ck2;
-        hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited, chain_head,
-                           chain_len, chain_key, cnt);
-        KC_TRY(read_u64(ctx, cnt, &nchains));
-        scope.release(ulist);
+        scope.release(starts); scope.release(seg_len); scope.release(seg_next); scope.release(seg_tail); scope.release(seg_chain); scope.release(seg_off);
+        starts = seg_len = seg_next = seg_tail = seg_chain = seg_off = nullptr;
+        nstarts = 0;
     }
     KC_HIP(ctx, hipGetLastError());
     scope.release(heads);
-    scope.release(visited);
 
     // order chains by head key, size them, emit
     const u64 S = nchains;
