@@ -254,25 +254,35 @@ __global__ void __launch_bounds__(256) ov_fix_kernel(const u64 *__restrict__ ne,
 
 // cycle repair (rare, one thread): among the cycles left uncovered, find the one whose latest event is earliest, and
 // report that event (u, c).  res = {found, part, u, c}
-__global__ void ov_find_cycle_kernel(const u64 *__restrict__ ne, u64 n, const u64 *__restrict__ first_snap, const u64 *__restrict__ eidx,
-                                     u8 *cov, u64 *res) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    u64 best_part = ~0ull, best_u = ~0ull, best_c = 0, found = 0;
-    for (u64 e = 0; e < n; ++e) {
-        u64 y0 = ne[e * 5 + 1];
-        if (cov[y0]) continue;
-        u64 cur = y0, mp = 0, mu = 0, mc = 0;
-        bool any = false;
-        do {
-            cov[cur] = 1;
-            const u64 *ed = ne + eidx[cur] * 5;
-            u64 part = ed[4], eu = ed[2], ec = ed[3];
-            if (!any || part > mp || (part == mp && eu > mu)) { mp = part; mu = eu; mc = ec; any = true; }
-            cur = first_snap[ed[0]];
-        } while (cur != y0);
-        if (!found || mp < best_part || (mp == best_part && mu < best_u)) { best_part = mp; best_u = mu; best_c = mc; found = 1; }
+// Pass 1, one thread per new edge: an uncovered edge lies on a cycle; the thread whose target vertex is the smallest of its
+// cycle reports the cycle's latest event (part, u) to an atomic minimum.  res[1] = (part << 32) | u, initialised to ~0.
+__global__ void __launch_bounds__(256) ov_find_cycle_kernel(const u64 *__restrict__ ne, u64 n, const u64 *__restrict__ first_snap,
+                                                            const u64 *__restrict__ eidx, const u8 *__restrict__ cov, u64 *res) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const u64 y0 = ne[e * 5 + 1];
+    if (cov[y0]) return;
+    u64 cur = y0, mp = 0, mu = 0;
+    bool any = false;
+    do {
+        if (cur < y0) return;                         // another thread owns this cycle
+        const u64 *ed = ne + eidx[cur] * 5;
+        const u64 part = ed[4], eu = ed[2];
+        if (!any || part > mp || (part == mp && eu > mu)) { mp = part; mu = eu; any = true; }
+        cur = first_snap[ed[0]];
+    } while (cur != y0);
+    atomicMin((ull *)(res + 1), (ull)((mp << 32) | mu));
+}
+// Pass 2: the edge logged by that event supplies c.  res = {found, part, u, c}
+__global__ void __launch_bounds__(256) ov_pick_event_kernel(const u64 *__restrict__ ne, u64 n, u64 *res) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const u64 best = res[1];
+    if (best == ~(u64)0) return;
+    const u64 *ed = ne + e * 5;
+    if (ed[4] == (best >> 32) && ed[2] == (best & 0xffffffffull) && ed[0] == ed[2]) {   // the event's own edge (not its mirror)
+        res[0] = 1; res[2] = ed[2]; res[3] = ed[3];
     }
-    res[0] = found; res[1] = best_part; res[2] = best_u; res[3] = best_c;
 }
 
 __global__ void __launch_bounds__(256) ov_undo_kernel(const u64 *__restrict__ ne, u64 n, u64 *edge_from, u8 *overlaps, u64 *pred, u64 *eidx,
@@ -588,8 +598,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             ++repairs;
             if (h_bl.size() / 2 >= BL_MAX) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap repair list exhausted");
             hipLaunchKernelGGL(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, eidx);
-            hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)ne, nNew, (const u64 *)first_snap,
-                               (const u64 *)eidx, cov, cnt + 4);
+            KC_HIP(ctx, hipMemsetAsync(cnt + 4, 0, 32, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(cnt + 5, 0xff, 8, ctx->stream));
+            hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew,
+                               (const u64 *)first_snap, (const u64 *)eidx, (const u8 *)cov, cnt + 4);
+            hipLaunchKernelGGL(ov_pick_event_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, cnt + 4);
             KC_TRY(read_back(ctx, hp, cnt + 4, 4));
             if (!hp[0]) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap verification failed without a cycle");
             h_bl.push_back(hp[2]); h_bl.push_back(hp[3]);
