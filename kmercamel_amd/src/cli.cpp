@@ -3,6 +3,7 @@
 // log lines and output format, running the hot path on the GPU through the C ABI.  `compute` uses the fused
 // device-resident pipeline (kc_compute); the converters are host-side byte shuffles (conversions.h); everything the
 // hot-path scope leaves out (other algorithms, min-run masks) is rejected explicitly.
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -101,8 +102,16 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
                 int min_frequency) {
     if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
     else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");
+    const bool trace = std::getenv("KC_CLI_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+    };
+    kcamd::warm_context();   // the device comes up while the file is read
     Records recs = load_records(path, assume_simplitigs);
+    mark("records loaded");
     kc_ctx *ctx = kcamd::context();
+    mark("device context ready");
     if (lower_bound) {
         // LowerBoundLength (lower_bound.h:7-36): simplitigs, then the cycle cover of the overlap graph
         kc_simplitigs *s = nullptr;
@@ -151,6 +160,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         return usage_subcommand("compute");
     }
     kcamd::check(rc);
+    mark("kc_compute returned");
     uint64_t st[16];
     kc_result_stats(res, st);
     if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
@@ -162,10 +172,12 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     std::string out(st[2], 'N'), mask(maskf ? st[2] : 0, 'N');
     kcamd::check(kc_result_copy(res, out.data(), maskf ? mask.data() : nullptr));
     kc_result_destroy(res);
+    mark("result copied to the host");
     of->write(out.data(), (std::streamsize)out.size());
     if (maskf != nullptr) { maskf->write(mask.data(), (std::streamsize)mask.size()); (*maskf) << std::endl; }
     WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
     *of << std::endl;   // main.cpp:210
+    mark("output written");
     return 0;
 }
 
@@ -364,9 +376,12 @@ int main(int argc, char **argv) {
     if (argc == 1 || std::string(argv[1]) == "-h") { usage(); return 0; }
     std::string cmd = argv[1];
     if (cmd == "-v" || cmd == "--version") { std::cerr << KC_CLI_VERSION << std::endl; return 0; }
-    if (cmd == "compute") return camel_compute(argc - 1, argv + 1, false);
-    if (cmd == "lowerbound") return camel_compute(argc - 1, argv + 1, true);
-    if (cmd == "maskopt") return camel_optimize(argc - 1, argv + 1);
+    // the device-backed subcommands leave through done(): all output files are closed by then, and tearing the HIP runtime
+    // down at exit costs ~0.1 s that a command-line run has no use for
+    auto done = [](int rc) -> int { std::cout.flush(); std::cerr.flush(); _exit(rc); return rc; };
+    if (cmd == "compute") return done(camel_compute(argc - 1, argv + 1, false));
+    if (cmd == "lowerbound") return done(camel_compute(argc - 1, argv + 1, true));
+    if (cmd == "maskopt") return done(camel_optimize(argc - 1, argv + 1));
     if (cmd == "ms2mssep") return camel_split_ms(argc - 1, argv + 1);
     if (cmd == "mssep2ms") return camel_join_ms(argc - 1, argv + 1);
     if (cmd == "ms2spss") return camel_spss(argc - 1, argv + 1, true);

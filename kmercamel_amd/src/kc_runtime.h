@@ -7,19 +7,27 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <thread>
 #include <zlib.h>
 #include "../../include/kmercamel_amd.h"
 
 namespace kcamd {
 
 inline kc_ctx *context() {
+    static std::once_flag once;
     static kc_ctx *ctx = nullptr;
-    if (!ctx) {
+    static int rc = KC_OK;
+    std::call_once(once, [] {
         const char *g = std::getenv("KMERCAMEL_GPU");
-        int rc = kc_ctx_create(g ? std::atoi(g) : 0, &ctx);
-        if (rc != KC_OK) throw std::runtime_error("kmercamel_amd: no usable MI355X / HIP device (kc_ctx_create returned " + std::to_string(rc) + ")");
-    }
+        rc = kc_ctx_create(g ? std::atoi(g) : 0, &ctx);
+    });
+    if (rc != KC_OK) throw std::runtime_error("kmercamel_amd: no usable MI355X / HIP device (kc_ctx_create returned " + std::to_string(rc) + ")");
     return ctx;
+}
+// Device and context creation takes ~0.1-0.2 s: the CLI starts it in the background and reads the input meanwhile.
+inline void warm_context() {
+    std::thread([] { try { (void)context(); } catch (...) {} }).detach();
 }
 
 // C codes -> the reference's exceptions (global.h:219-221, parser.h:95-97, simplitigs.h:82, masks.h:75-77)
