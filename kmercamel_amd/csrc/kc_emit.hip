@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
     bool rc = v >= S;
     u64 L = lens[sidx], wb = woff[sidx], n = weight[v];
     u64 upper_end = L - (u64)k;   // indices <= upper_end are k-mer starts of the simplitig
-    for (u64 t = lane; t < n; t += 64) {
+    // blockIdx.y splits long vertices (assembled genomes give simplitigs of Mbp) into interleaved 64-character slices
+    for (u64 t = (u64)blockIdx.y * 64 + lane; t < n; t += (u64)gridDim.y * 64) {
         u64 j = rc ? (L - 1 - t) : t;
         u64 b = (words[wb + (j >> 5)] >> (62 - 2 * (j & 31))) & 3;
         if (rc) b = 3 - b;
@@ -113,7 +114,9 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     char *out = nullptr, *mask = nullptr;
     KC_TRY(kc_alloc(ctx, &out, L + 1));
-    hipLaunchKernelGGL(em_emit_kernel, dim3(kc_grid(V * 64, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+    unsigned slices = 1;   // waves per vertex: ~8192 characters each on average, at most 256
+    if (V && L / V > 16384) { u64 y = L / V / 8192; slices = (unsigned)(y > 256 ? 256 : y); }
+    hipLaunchKernelGGL(em_emit_kernel, dim3(kc_grid(V * 64, 256), slices), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
                        (const u64 *)s->lens, S, V, k, (const u64 *)dist, (const u64 *)endv, (const u64 *)weight, h_start, out);
     if (d_mask && set_for_mask) {
         KC_TRY(kc_alloc(ctx, &mask, L + 1));
