@@ -94,58 +94,7 @@ __global__ void __launch_bounds__(256) kc_gather_shards_kernel(const u64 *__rest
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_out = ovf ? dst_cap + 1 : pre[KC_NSHARD];
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Ordered compaction of the occupied slots (tag != 0) into `occ`: per 2048-slot tile a count, an exclusive scan of the
-// tile counts, then every wave ranks its 64 slots with a ballot + popcount prefix and scatters.  Keeps slot order, so
-// a sweep over `occ` still walks the table region by region.
-#define KC_TILE 2048
-__global__ void __launch_bounds__(256) kc_occ_count_kernel(const u8 *__restrict__ tags, u64 cap, u64 *tile_count) {
-    __shared__ u32 wsum[4];
-    u64 base = (u64)blockIdx.x * KC_TILE;
-    u32 c = 0;
-    for (int r = 0; r < KC_TILE / 256 / 8; ++r) {   // 8 tags per thread per round
-        u64 off = base + ((u64)r * 256 + threadIdx.x) * 8;
-        if (off < cap) {
-            u64 w = *reinterpret_cast<const u64 *>(tags + off);
-            c += (u32)__popcll(w & 0x8080808080808080ULL);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = (u64)wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-__global__ void __launch_bounds__(256) kc_occ_fill_kernel(const u8 *__restrict__ tags, u64 cap, const u64 *__restrict__ tile_off, u64 *occ) {
-    __shared__ u32 wcount[4][KC_TILE / 256];
-    u64 base = (u64)blockIdx.x * KC_TILE;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // pass 1: per wave and round, number of occupied slots among its 64
-    u64 masks[KC_TILE / 256];
-#pragma unroll
-    for (int r = 0; r < KC_TILE / 256; ++r) {
-        u64 slot = base + (u64)r * 256 + threadIdx.x;
-        bool occd = slot < cap && tags[slot] != 0;
-        u64 m = __ballot(occd);
-        masks[r] = m;
-        if (lane == 0) wcount[wave][r] = (u32)__popcll(m);
-    }
-    __syncthreads();
-    u64 out = tile_off[blockIdx.x];
-#pragma unroll
-    for (int r = 0; r < KC_TILE / 256; ++r) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            u32 cnt = wcount[w][r];
-            if (w == wave) {
-                u64 m = masks[r];
-                if ((m >> lane) & 1) occ[out + (u64)__popcll(m & (((u64)1 << lane) - 1))] = base + (u64)r * 256 + threadIdx.x;
-            }
-            out += cnt;
-        }
-    }
-}
-
-// Round 1 over the compacted k-mers: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
+// Round 1: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
 // over the m-mer hashes whose prefix/suffix minima give both ports' shared minimizer part).
 // `stage` (LDS) holds the tag bytes of table block `sblk` (+ 8 bytes of the next one) when sblk != ~0: see the kernel below.
 template <int W, int KC>
@@ -327,33 +276,38 @@ __device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *
     }
 }
 
-// The kernel: a workgroup owns KC_CHOOSE_PER_WG consecutive entries of `occ` (slot order, i.e. mostly one table block) and
-// first copies that block's tag bytes into LDS.  ~90 % of the candidate lookups start in that very block (shared
-// minimizer), so their tag windows are read from LDS instead of each dragging a 128-byte line through the L1: the kernel
-// was bound by exactly that L2->L1 fill traffic (8 scattered tag lines per k-mer), not by HBM, ALU work or latency.
-#define KC_CHOOSE_PER_WG 1024
+// The kernel: a workgroup owns KC_CHOOSE_SLOTS consecutive table slots (an eighth of a 16384-slot block) and first copies
+// the tag bytes of the whole block into LDS.  ~90 % of the candidate lookups start in that very block (shared minimizer),
+// so their tag windows are read from LDS instead of each dragging a 128-byte line through the L1: the kernel was bound by
+// exactly that L2->L1 fill traffic (8 scattered tag lines per k-mer), not by HBM, ALU work or latency.  The occupied slots
+// of its range are listed in LDS from the staged tags, so the lanes stay dense without any global list of occupied slots.
+#define KC_CHOOSE_SLOTS 2048
 template <int W, int KC>
-__global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
-                                                              const u64 *__restrict__ occ, u64 nocc, int xcd_aware, u64 *heads,
-                                                              u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
-                                                              u64 branch_shard_cap, u64 *branch_cursors, int stage_words, int per_wg) {
+__global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
+                                                              u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
+                                                              u64 branch_shard_cap, u64 *branch_cursors, int stage_words) {
     extern __shared__ u64 kc_stage[];
-    const u64 t0 = kc_xcd_block_id(xcd_aware) * (u64)per_wg;
-    if (t0 >= nocc) return;
+    __shared__ unsigned short kc_list[KC_CHOOSE_SLOTS];
+    __shared__ u32 kc_nlist;
+    const u64 base = kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_SLOTS;
+    if (base >= set.cap) return;
+    if (threadIdx.x == 0) kc_nlist = 0;
     u64 sblk = ~(u64)0;
     if (stage_words) {
-        sblk = occ[t0] >> set.bshift;
+        sblk = base >> set.bshift;
         const u64 *src = reinterpret_cast<const u64 *>(set.tags + (sblk << set.bshift));
         for (int j = threadIdx.x; j < stage_words; j += 256) kc_stage[j] = src[j];
-        __syncthreads();
     }
+    __syncthreads();
+    const u8 *tg = stage_words ? reinterpret_cast<const u8 *>(kc_stage) + (base & (((u64)1 << set.bshift) - 1)) : set.tags + base;
+    for (u32 i = threadIdx.x; i < KC_CHOOSE_SLOTS; i += 256)
+        if (base + i < set.cap && tg[i] != 0) kc_list[atomicAdd(&kc_nlist, 1u)] = (unsigned short)i;
+    __syncthreads();
+    const u32 n = kc_nlist;
 #pragma unroll 1
-    for (int it = 0; it < per_wg / 256; ++it) {
-        const u64 t = t0 + (u64)it * 256 + threadIdx.x;
-        if (t >= nocc) break;
-        kc_choose_dense_one<W, KC>(set, link, k_rt, complements, occ[t], kc_stage, sblk, heads, heads_shard_cap, heads_cursors, branch,
+    for (u32 t = threadIdx.x; t < n; t += 256)
+        kc_choose_dense_one<W, KC>(set, link, k_rt, complements, base + kc_list[t], kc_stage, sblk, heads, heads_shard_cap, heads_cursors, branch,
                                    branch_shard_cap, branch_cursors);
-    }
 }
 
 // Branch ports re-enumerate their candidates and reject every existing one they did not choose: the rejected port's
@@ -486,10 +440,9 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
 // Fallback for heavily branching graphs (the branch list overflowed): check every round-1 choice against its target
 // directly. FILL = false counts the unreciprocated ports, FILL = true marks them LK_REJ and lists them.
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, const u64 *__restrict__ occ, u64 nocc, u64 *work_out, u64 *cursor) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nocc) return;
-    const u64 slot = occ[t];
+__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, const u8 *__restrict__ tags, u64 cap, u64 *work_out, u64 *cursor) {
+    const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= cap || tags[slot] == 0) return;
     for (int port = 0; port < 2; ++port) {
         const u64 pid = (slot << 1) | (u64)port;
         u64 w = link[pid];
@@ -980,23 +933,6 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_TRY(scope.alloc(&work_a, work_cap));
     KC_TRY(scope.alloc(&work_b, work_cap));
     u64 *heads_cursor = cnt + 2, *work_cursor = cnt;
-    // compacted list of occupied slots (slot order kept)
-    const u64 ntiles = (cap + KC_TILE - 1) / KC_TILE;
-    u64 *tile_cnt = nullptr, *tile_off = nullptr, *occ = nullptr;
-    KC_TRY(scope.alloc(&tile_cnt, ntiles + 1));
-    KC_TRY(scope.alloc(&tile_off, ntiles + 1));
-    KC_TRY(scope.alloc(&occ, N + 1));
-    hipLaunchKernelGGL(kc_occ_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u8 *)set->tags, cap, tile_cnt);
-    {
-        size_t tb = 0;
-        KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, tile_cnt, tile_off, (int)ntiles, ctx->stream));
-        u8 *tmp = nullptr;
-        KC_TRY(scope.alloc(&tmp, tb));
-        KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tb, tile_cnt, tile_off, (int)ntiles, ctx->stream));
-        hipLaunchKernelGGL(kc_occ_fill_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u8 *)set->tags, cap, (const u64 *)tile_off, occ);
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        scope.release(tmp);
-    }
     // round 1 over all k-mers (the dominant kernel of this phase: 8 table probes per k-mer)
     u64 *branch = work_b, *branch_cursor = cnt + 4;   // branch ports of round 1 (work_b is free until round 2)
     // sharded round-1 lists (gathered into `heads` / `branch` right after the kernel)
@@ -1011,19 +947,15 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // tag staging: one table block's tags (+ 8 bytes) in LDS, when the set has minimizer blocks of at most 32 KB
     const int stage_words = (set->mlen && set->bshift <= 15 && !getenv("KC_NOSTAGE")) ? (int)(((u64)1 << set->bshift) / 8 + 1) : 0;
     const size_t stage_lds = (size_t)stage_words * 8;
-    int per_wg = KC_CHOOSE_PER_WG;
-    if (const char *e = getenv("KC_PER_WG")) { int v = atoi(e); if (v >= 256 && v % 256 == 0) per_wg = v; }
-    const unsigned cgrid = kc_grid8(N, (unsigned)per_wg);
+    const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);
     // compile-time k for the benchmark configurations (k = 31 / 63 / 127 with m = 15): constant trip counts everywhere
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
     if (k == KSPEC && set->mlen == 15 && !getenv("KC_NO_KSPEC"))
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, KSPEC>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
-                           stage_words, per_wg);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, KSPEC>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_, xcd_aware,
+                           heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, stage_words);
     else
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_,
-                           (const u64 *)occ, N, xcd_aware, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors,
-                           stage_words, per_wg);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_, xcd_aware,
+                           heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, stage_words);
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
                        (const u64 *)heads_cursors, heads, heads_cap, heads_cursor);
@@ -1041,7 +973,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
         // kc_reject_kernel run may already have set are simply found again
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), dim3(kc_grid(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
         scope.release(work_a); scope.release(work_b);
@@ -1049,11 +981,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&work_a, work_cap));
         KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), dim3(kc_grid(N, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)occ, N, work_a,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
-    scope.release(tile_cnt); scope.release(tile_off); scope.release(occ);
     while (nwork) {
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
