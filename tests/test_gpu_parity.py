@@ -188,6 +188,15 @@ def test_bucket_overflow_falls_back_to_direct_inserts(ctx, oracle, k, monkeypatc
     sim.close(); s.close()
 
 
+def test_randomised_parity_run():
+    """20 s of tools/fuzz_parity.py: random shapes (reads, low complexity, repeats, circles, thousands of copies of one read),
+    random k in 2..127, both strand modes, both set-build paths, forced segment walks -- whole `compute` output vs the oracle."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "20", "7"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "fuzz ok" in p.stdout, p.stdout + p.stderr
+
+
 def _export_keys_np(s):
     """the set's keys as a numpy array (single-word keys), through the C ABI"""
     import ctypes
