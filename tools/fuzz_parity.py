@@ -14,7 +14,10 @@ def rand_seq(rng, n, alphabet="ACGT"):
 
 def make_case(rng, k):
     shape = rng.choice(["reads", "lowc", "repeat", "circle", "copies", "mixed"])
-    if shape == "reads":
+    if rng.random() < 0.02:   # now and then a case beyond 2^20 positions (default bucketed build, larger overlap buckets)
+        shape = "big"
+        recs = [r.decode() for r in gen.stress_reads(rng.randint(200000, 1500000), rng.randint(3000, 12000), rng.randint(max(k, 100), max(k, 100) + 300), seed=rng.randint(0, 1 << 30))]
+    elif shape == "reads":
         recs = [r.decode() for r in gen.stress_reads(rng.randint(500, 30000), rng.randint(20, 400), rng.randint(max(k, 30), max(k, 30) + 300), seed=rng.randint(0, 1 << 30))]
     elif shape == "lowc":
         recs = [rand_seq(rng, rng.randint(k, 5000), rng.choice(["AC", "AT", "ACG", "A"])) for _ in range(rng.randint(1, 20))]
