@@ -108,13 +108,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # KC_BENCH_BACKEND=gloo is for checking the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices and
+    # the two scalars are reduced through the host); the real thing is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("KC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     ctx = kc.Context(local_rank)
     host = gen.random_joined(args.records, read_len, seed=shard_seed(rank))
@@ -143,7 +152,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    elapsed, total_kmers = aggregate(dist, dev, elapsed, stats[-1]["n_kmers"])
+    elapsed, total_kmers = aggregate(dist, red_dev, elapsed, stats[-1]["n_kmers"])
 
     if args.check and rank == 0:
         # size-independent properties of the result at the benchmark's own size (no oracle involved): min-one mask (ones == N),
