@@ -52,21 +52,39 @@ def main():
             with open(fa, "w") as f:
                 for i, r in enumerate(recs):
                     f.write(">r%d\n%s\n" % (i, r))
-            rc, want, wmask, st = orc.compute_file(fa, k, compl, False, mode=1)
+            # which entry: plain compute (canonical order), -S (records are simplitigs; reference order, layout-free), -z
+            entry = rng.choice(["plain", "plain", "plain", "S", "z"])
+            if entry == "S":
+                recs = [r for r in recs if len(r) >= k and set(r) <= set("ACGT")] or [rand_seq(rng, k + 5)]
+                with open(fa, "w") as f:
+                    for i, r in enumerate(recs):
+                        f.write(">r%d\n%s\n" % (i, r))
+                rc, want, wmask, st = orc.compute_file(fa, k, compl, True, mode=0)
+            elif entry == "z":
+                zf = rng.choice([2, 3])
+                rc, want, wmask, st = orc.compute_file_z(fa, k, compl, mode=1, min_frequency=zf)
+            else:
+                rc, want, wmask, st = orc.compute_file(fa, k, compl, False, mode=1)
             try:
-                r = kc.compute_file(ctx, fa, k, compl, want_mask=True)
+                if entry == "S": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, assume_simplitigs=True)
+                elif entry == "z": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, min_frequency=zf)
+                else: r = kc.compute_file(ctx, fa, k, compl, want_mask=True)
             except kc.KcError as e:
-                assert rc != 0, "GPU failed (%s) where the oracle succeeded: k=%d compl=%s shape=%s seed=%d case=%d" % (e, k, compl, shape, seed, n)
+                assert rc != 0, "GPU failed (%s) where the oracle succeeded: %s k=%d compl=%s shape=%s seed=%d case=%d" % (e, entry, k, compl, shape, seed, n)
                 n += 1
                 continue
             out, mask = r.strings(want_mask=True)
             ok = rc == 0 and out == want and mask == wmask and r.stats["n_kmers"] == st[0]
             r.close()
+            if ok and entry == "plain" and rng.random() < 0.3:   # maskopt on the result, both targets
+                for alg, mini in (("max-one", False), ("min-one", True)):
+                    rc2, wopt = orc.maskopt(out, k, compl, mini)
+                    ok = ok and rc2 == 0 and kc.Optimize(ctx, out, k, compl, alg) == wopt
             if not ok:
                 keep = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d.fa" % (seed, n))
                 os.makedirs(os.path.dirname(keep), exist_ok=True)
                 os.replace(fa, keep)
-                print("MISMATCH case %d: k=%d compl=%s shape=%s env=%s -> %s" % (n, k, compl, shape, {e: os.environ.get(e) for e in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT")}, keep))
+                print("MISMATCH case %d (%s): k=%d compl=%s shape=%s env=%s -> %s" % (n, entry, k, compl, shape, {e: os.environ.get(e) for e in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT")}, keep))
                 sys.exit(1)
             shapes[shape] = shapes.get(shape, 0) + 1
             n += 1
