@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
 // ---- bucketed build (single-word keys): global CAS inserts pay a fabric atomic plus two scattered line round trips per
 // k-mer and were the slowest kernel of the path.  Instead (1) scatter the canonical k-mers into one bucket per table
 // block -- consecutive k-mers share their minimizer, so a thread reserves space once per RUN of equal blocks; (2) one
-// workgroup per block builds that block's 16384-slot table in LDS (LDS compare-and-swap, no global atomics) and writes it
+// workgroup per block builds that block's table (16384 / 8192 / 4096 slots for 1 / 2 / 4 key words) in LDS (LDS compare-and-swap, no global atomics) and writes it
 // out with coalesced stores; (3) the few keys whose 128 local probes were all taken go through the global insert.
 // (positions per thread: 16 single-word keys, 8 wide ones -- the keys of an open run are staged in LDS)
 template <int W>
@@ -401,13 +401,16 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v < k) ? v : 0; }   // tuning/ablation knobs
     if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= 20) s->bshift = v; }
     if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
-    // target load 0.5 (shorter tag scans, measured 10 % faster neighbour probes) when table + links + occ list at that load
+    // target load 0.5 (shorter tag scans, measured 10 % faster neighbour probes) when table + links at that load
     // stay below 60 % of the device memory, else 0.66
     double load = 0.5;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
-        double per_slot = 8.0 * s->W + 1 + 16, need = (double)capacity_hint / load * per_slot + (double)capacity_hint * 12;
+        // per slot: keys + tag (+ state word for wide keys) + the larger of the build buckets (8W, freed before phase 1) and
+        // the port links (16)
+        double per_slot = 8.0 * s->W + 1 + (s->W > 1 ? 4 : 0) + (8.0 * s->W > 16 ? 8.0 * s->W : 16);
+        double need = (double)capacity_hint / load * per_slot + (double)capacity_hint * 4;
         if (total_b && need > 0.6 * (double)total_b) load = 0.66;
     }
     if (const char *e = getenv("KC_LOAD")) { double v = atof(e); if (v >= 0.2 && v <= 0.9) load = v; }

@@ -10,7 +10,9 @@
 //   * edges are matched greedily by a symmetric 64-bit priority (locally dominant edges, iterated to a fixpoint:
 //     every open port picks its best still-available edge, an edge is accepted when both of its ports picked it);
 //   * chains start at the end with the smaller key and are ordered by that key; cycles are cut at their minimum key.
-// Kernels: neighbour_choose (4 probes per port), accept, heads, walk (measure), walk (emit packed 2-bit).
+// Kernels: kc_choose_dense_kernel (round 1: 8 batched lookups per k-mer, block tags staged in LDS), kc_reject / kc_choose /
+// kc_accept (later rounds), kc_walk_measure (walk + 2-bit recording), kc_stream_emit, the segment-parallel kernels for long
+// chains and the cycle cutters; host flow in build_simplitigs_w.
 #include "kc_internal.h"
 #include <hipcub/hipcub.hpp>
 
