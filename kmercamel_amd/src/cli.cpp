@@ -83,7 +83,10 @@ struct Records {
 };
 Records load_records(const std::string &path, bool simplitigs) {
     Records r;
-    auto recs = kcamd::read_records(path);
+    const std::string buf = kcamd::slurp_fast(path);
+    if (kcamd::join_fasta(buf, simplitigs, r.joined, r.offsets, r.n)) return r;   // FASTA: one pass, no per-record strings
+    r = Records();
+    auto recs = kcamd::parse_records(buf);
     r.n = recs.size();
     size_t total = 0;
     for (auto &x : recs) total += x.seq.size() + 1;

@@ -2,6 +2,7 @@
 // default 0), C-ABI error codes turned back into the exception types the reference throws, and the record reader.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -60,6 +61,64 @@ inline std::string slurp(const std::string &path) {
     while ((n = gzread(f, tmp.data(), (unsigned)tmp.size())) > 0) buf.append(tmp.data(), (size_t)n);
     gzclose(f);
     return buf;
+}
+
+// Plain (non-gzip) regular files are read with one read into a buffer of the file's size; everything else goes through zlib.
+inline std::string slurp_fast(const std::string &path) {
+    if (path != "-") {
+        FILE *in = fopen(path.c_str(), "rb");
+        if (in == nullptr) throw std::invalid_argument("couldn't open file " + path);
+        unsigned char magic[2] = {0, 0};
+        size_t got = fread(magic, 1, 2, in);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(in, 0, SEEK_END) == 0) {
+            long size = ftell(in);
+            if (size >= 0 && fseek(in, 0, SEEK_SET) == 0) {
+                std::string buf((size_t)size, '\0');
+                size_t n = size ? fread(&buf[0], 1, (size_t)size, in) : 0;
+                fclose(in);
+                buf.resize(n);
+                return buf;
+            }
+        }
+        fclose(in);
+    }
+    return slurp(path);
+}
+
+// FASTA fast path of the tokenizer below, straight into the form the device wants: the record sequences joined by '\n'
+// (or, for -S, concatenated with their offsets).  Same rules (kseq.h:183-224): everything before the first '>' / '@' is
+// skipped, a line starting with '>' or '@' starts a record, empty lines are skipped, a '\r' ending the accumulated
+// sequence is dropped.  Returns false as soon as a '+' line shows that the file is FASTQ (the general parser takes over).
+inline bool join_fasta(const std::string &b, bool concatenate, std::string &joined, std::vector<uint64_t> &offsets, uint64_t &n_records) {
+    const char *p = b.data(), *end = p + b.size();
+    joined.clear(); offsets.clear(); n_records = 0;
+    joined.reserve(b.size() + 16);
+    while (p < end && *p != '>' && *p != '@') ++p;
+    while (p < end) {
+        // p is at a header character (a header character that is the last byte of the file starts no record): skip the line
+        if (p + 1 >= end) break;
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        p = nl ? nl + 1 : end;
+        const size_t start = joined.size();
+        if (concatenate) offsets.push_back(start);
+        bool next_header = false;
+        while (p < end) {
+            const char c = *p;
+            if (c == '>' || c == '@') { next_header = true; break; }
+            if (c == '+') return false;
+            if (c == '\n') { ++p; continue; }
+            nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? nl : end;
+            joined.append(p, (size_t)(le - p));
+            if (joined.size() - start > 1 && joined.back() == '\r') joined.pop_back();
+            p = nl ? nl + 1 : end;
+        }
+        ++n_records;
+        if (!concatenate) joined.push_back('\n');
+        if (!next_header) break;
+    }
+    if (concatenate) offsets.push_back(joined.size());
+    return true;
 }
 
 // Records with the semantics of the reference's tokenizer (kseq.h:183-224): multi-line FASTA and FASTQ, header char

@@ -119,3 +119,13 @@ def test_dropin_templates_all_key_widths():
     p = subprocess.run([SHIM, os.path.join(GOLDEN, "test.fa")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("PASS") == 3
+
+
+def test_fast_fasta_loader_matches_tokenizer(tmp_path):
+    """tests/host/parse_check.cpp: the CLI's one-pass FASTA loader (join_fasta) vs the kseq-semantics tokenizer it
+    shortcuts, on edge cases and 200 000 random byte soups (host-only)."""
+    exe = str(tmp_path / "parse_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "host", "parse_check.cpp"),
+                           "-I" + os.path.join(ROOT, "kmercamel_amd", "src"), "-lz", "-pthread", "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0 and "parse_check ok" in p.stdout, p.stdout
