@@ -301,7 +301,10 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
         for (int j = threadIdx.x; j < stage_words; j += 256) kc_stage[j] = src[j];
     }
     __syncthreads();
-    const u8 *tg = stage_words ? reinterpret_cast<const u8 *>(kc_stage) + (base & (((u64)1 << set.bshift) - 1)) : set.tags + base;
+    // (blocks smaller than the slot range -- only with the KC_BSHIFT knob -- are staged for the window reads of the first
+    // block only; the occupancy of the whole range then comes from global memory)
+    const bool range_in_block = stage_words && ((u64)1 << set.bshift) >= (u64)KC_CHOOSE_SLOTS;
+    const u8 *tg = range_in_block ? reinterpret_cast<const u8 *>(kc_stage) + (base & (((u64)1 << set.bshift) - 1)) : set.tags + base;
     for (u32 i = threadIdx.x; i < KC_CHOOSE_SLOTS; i += 256)
         if (base + i < set.cap && tg[i] != 0) kc_list[atomicAdd(&kc_nlist, 1u)] = (unsigned short)i;
     __syncthreads();

@@ -48,6 +48,11 @@ def main():
             os.environ["KC_BUCKET_MIN"] = rng.choice(["0", "0", "1048576"])
             if rng.random() < 0.15: os.environ["KC_CHAIN_LIMIT"] = str(rng.choice([2, 64, 700]))
             else: os.environ.pop("KC_CHAIN_LIMIT", None)
+            # small blocks / short local probe runs: block-local spills, second homes, bucket overflows
+            if rng.random() < 0.2: os.environ["KC_BSHIFT"] = str(rng.choice([9, 10, 11]))
+            else: os.environ.pop("KC_BSHIFT", None)
+            if rng.random() < 0.2: os.environ["KC_LOCAL_PROBES"] = str(rng.choice([2, 8, 16]))
+            else: os.environ.pop("KC_LOCAL_PROBES", None)
             shape, recs = make_case(rng, k)
             with open(fa, "w") as f:
                 for i, r in enumerate(recs):
@@ -70,7 +75,13 @@ def main():
                 elif entry == "z": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, min_frequency=zf)
                 else: r = kc.compute_file(ctx, fa, k, compl, want_mask=True)
             except kc.KcError as e:
-                assert rc != 0, "GPU failed (%s) where the oracle succeeded: %s k=%d compl=%s shape=%s seed=%d case=%d" % (e, entry, k, compl, shape, seed, n)
+                if rc == 0:
+                    keep = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d.fa" % (seed, n))
+                    os.makedirs(os.path.dirname(keep), exist_ok=True)
+                    os.replace(fa, keep)
+                    print("GPU failed (%s) where the oracle succeeded: %s k=%d compl=%s shape=%s seed=%d case=%d env=%s -> %s" % (
+                        e, entry, k, compl, shape, seed, n, {v: os.environ.get(v) for v in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_BSHIFT", "KC_LOCAL_PROBES")}, keep))
+                    sys.exit(1)
                 n += 1
                 continue
             out, mask = r.strings(want_mask=True)
@@ -84,7 +95,7 @@ def main():
                 keep = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d.fa" % (seed, n))
                 os.makedirs(os.path.dirname(keep), exist_ok=True)
                 os.replace(fa, keep)
-                print("MISMATCH case %d (%s): k=%d compl=%s shape=%s env=%s -> %s" % (n, entry, k, compl, shape, {e: os.environ.get(e) for e in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT")}, keep))
+                print("MISMATCH case %d (%s): k=%d compl=%s shape=%s env=%s -> %s" % (n, entry, k, compl, shape, {e: os.environ.get(e) for e in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_BSHIFT", "KC_LOCAL_PROBES")}, keep))
                 sys.exit(1)
             shapes[shape] = shapes.get(shape, 0) + 1
             n += 1
