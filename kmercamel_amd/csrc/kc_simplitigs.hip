@@ -278,7 +278,7 @@ __device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *
     }
 }
 
-// The kernel: a workgroup owns KC_CHOOSE_SLOTS consecutive table slots (an eighth of a 16384-slot block) and first copies
+// The kernel: a workgroup owns KC_CHOOSE_SLOTS consecutive table slots (a quarter of an 8192-slot block) and first copies
 // the tag bytes of the whole block into LDS.  ~90 % of the candidate lookups start in that very block (shared minimizer),
 // so their tag windows are read from LDS instead of each dragging a 128-byte line through the L1: the kernel was bound by
 // exactly that L2->L1 fill traffic (8 scattered tag lines per k-mer), not by HBM, ALU work or latency.  The occupied slots
