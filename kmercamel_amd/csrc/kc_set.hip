@@ -190,7 +190,10 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
 template <int W>
 __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
                                                         const u64 *__restrict__ low, u64 len, int k, int complements,
-                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt, u32 *occ_counts) {
+                                                        int case_sensitive, SetView<W> set, u64 *counters, int ppt, u32 *occ_counts,
+                                                        const u64 *__restrict__ only_over, u64 over_limit) {
+    // only_over != nullptr: the clean-up pass after a bucketed build whose buckets overflowed -- only the k-mers of blocks
+    // that received more than over_limit occurrences (only_over[block], the scatter kernel's cursors) are inserted
     extern __shared__ u32 kc_ring[];
     u64 added = 0;
     bool overflow = false;
@@ -198,6 +201,7 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
     kc_roll_kmers<W>(codes, brk, low, len, k, complements, case_sensitive, m, ppt, kc_ring, [&](const Key<W> &key, u32 mmh) {
         const u64 kh = key_place_hash(key);
         const u64 home = m ? set_block_home(set, mmh, kh) : kc_mulhi64(kc_mix64(kh), set.cap);
+        if (only_over && only_over[home >> set.bshift] <= over_limit) return;
         u64 slot;
         int r = set_insert_at(set, key, kh, home, &slot);
         if (occ_counts && r >= 0) atomicAdd(&occ_counts[slot], 1u);   // AddKMersWithFrequencies (parser.h:51-85)
@@ -495,7 +499,8 @@ int kcs_reserve(kc_set *set, u64 additional) {
     return kcs_rebuild(set, ncap, nnblocks, nkeys, nstate, ntags, 0);
 }
 
-static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
+static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive,
+                         const u64 *only_over = nullptr, u64 over_limit = 0) {
     kc_ctx *ctx = set->ctx;
     int ppt = set->W == 1 ? 16 : (set->W == 2 ? 32 : 64);
     u64 nthreads = (len + ppt - 1) / ppt;
@@ -504,9 +509,9 @@ static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, cons
     const size_t lds = (size_t)win * bs * 4;
     unsigned g = kc_grid(nthreads, bs);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts); break;
-        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt, set->counts); break;
-        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt, set->counts); break;
+        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
+        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
+        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
     }
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
@@ -559,8 +564,12 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu\n", W,
                 (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3]);
-    if (h[3] || h[2] > ovf_cap)   // a bucket (or the spill list) overflowed: the global path inserts whatever is still missing
+    if (h[2] > ovf_cap)   // the spill list overflowed: the global path inserts whatever is still missing
         return insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);
+    if (h[3]) {           // some buckets overflowed (blocks hit by high-multiplicity repeats): a second sweep inserts only those blocks' k-mers
+        KC_TRY(insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive, bcursor, bs));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (bcursor belongs to this scope)
+    }
     if (h[2]) {
         hipLaunchKernelGGL(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)ovf, h[2],
                            set->counters);
