@@ -23,6 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #define LV_EMPTY (~(u64)0)
+#define KC_CNT_BLOCKS 256
 #define KC_LDS_MIN 12      /* buckets with fewer members are replayed by a single thread straight from global memory */
 #define KC_LDS_MAX 1200    /* 39 B of LDS per member: 46 KB */
 
@@ -457,13 +458,21 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     OvWork w; w.ctx = ctx;
     u64 *pre, *suf, *edge_from, *pred, *first, *last, *first_snap, *last_snap, *actS, *actP, *actS2, *actP2, *eidx;
     u8 *overlaps, *hitS, *hitP, *cov;
-    u64 *pslot, *ne, *cnt, *bl;
+    u64 *pslot, *ne, *cnt, *cnt_pool, *bl;
     KC_TRY(scope.alloc(&pre, V * W)); KC_TRY(scope.alloc(&suf, V * W));
     KC_TRY(kc_alloc(ctx, &edge_from, V)); KC_TRY(kc_alloc(ctx, &pred, V)); KC_TRY(kc_alloc(ctx, &overlaps, V));
     KC_TRY(scope.alloc(&first, V)); KC_TRY(scope.alloc(&last, V)); KC_TRY(scope.alloc(&first_snap, V)); KC_TRY(scope.alloc(&last_snap, V));
     KC_TRY(scope.alloc(&actS, V)); KC_TRY(scope.alloc(&actP, V)); KC_TRY(scope.alloc(&actS2, V)); KC_TRY(scope.alloc(&actP2, V));
     KC_TRY(scope.alloc(&eidx, V)); KC_TRY(scope.alloc(&hitS, V)); KC_TRY(scope.alloc(&hitP, V)); KC_TRY(scope.alloc(&cov, V));
-    KC_TRY(scope.alloc(&pslot, V)); KC_TRY(scope.alloc(&ne, V * 10 + 10)); KC_TRY(scope.alloc(&cnt, 16));  // ne: up to two log entries per event
+    KC_TRY(scope.alloc(&pslot, V)); KC_TRY(scope.alloc(&ne, V * 10 + 10)); KC_TRY(scope.alloc(&cnt_pool, KC_CNT_BLOCKS * 16));  // ne: up to two log entries per event
+    // counter blocks (16 words): every use takes a fresh, already zeroed block instead of clearing one with a fill launch
+    KC_HIP(ctx, hipMemsetAsync(cnt_pool, 0, KC_CNT_BLOCKS * 16 * 8, ctx->stream));
+    u64 cnt_used = 0;
+    auto fresh_cnt = [&]() -> u64 * {
+        if (cnt_used == KC_CNT_BLOCKS) { (void)hipMemsetAsync(cnt_pool, 0, KC_CNT_BLOCKS * 16 * 8, ctx->stream); cnt_used = 0; }
+        return cnt_pool + 16 * cnt_used++;
+    };
+    cnt = fresh_cnt();
     const u64 BL_MAX = 4096;
     KC_TRY(scope.alloc(&bl, BL_MAX * 2));
     KC_TRY(scope.alloc(&w.d_num, 2));
@@ -513,7 +522,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         tab.mask = lcap - 1;
         tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
         KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
-        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 128, ctx->stream));
+        cnt = fresh_cnt();
         hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                            (const u64 *)pre, k, d, pslot);
         hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
@@ -560,7 +569,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         u64 nNew = 0;
         const u64 max_new = (complements ? 2 : 1) * nHS;   // every event logs at most 1 (+1 mirrored) edge
         while (true) {
-            KC_HIP(ctx, hipMemsetAsync(cnt, 0, 128, ctx->stream));
+            cnt = fresh_cnt();
+            g.ne_count = cnt;
             if (!lower_bound) {
                 // path-end entries carry the tag of the bucket that wrote them; every launch draws its tags from a fresh
                 // range, so entries of other levels / replays are simply never trusted (no clearing between launches)
@@ -640,7 +650,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
     scope.release(big);
-    void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt, bl, w.d_num,
+    void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt_pool, bl, w.d_num,
                    tab.slot, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
     for (void *p : rel) scope.release(p);
     return KC_OK;
