@@ -163,7 +163,8 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
     const int win = k - m + 1;
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     u64 cw = codes[s >> 5], bw = brk[s >> 6];
-    for (u64 p = s; p < e1; ++p) {
+    u32 rj = 0;   // ring slot of position p (a running counter: p % win would be a 64-bit division per base)
+    for (u64 p = s; p < e1; ++p, rj = (rj + 1 == (u32)win) ? 0u : rj + 1) {
         if ((p & 31) == 0) cw = codes[p >> 5];
         if ((p & 63) == 0) bw = brk[p >> 6];
         u64 b = (cw >> (62 - 2 * (p & 31))) & 3;
@@ -172,7 +173,7 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
         rc = key_prepend(rc, 3 - b, k);
         if (run < k) ++run;
         if (m && run >= m)
-            ring[(u32)(p % (u64)win) * blockDim.x + threadIdx.x] = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
+            ring[rj * blockDim.x + threadIdx.x] = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
         if (p >= e0 && run >= k) {
             if (case_sensitive) {
                 u64 fp = p - (u64)(k - 1);
