@@ -158,32 +158,56 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
     u64 s = e0 >= (u64)(k - 1) ? e0 - (u64)(k - 1) : 0;
     Key<W> cur = key_zero<W>(), rc = key_zero<W>();
     int run = 0;
-    // minimizer: every base contributes ONE new canonical m-mer hash; the last k-m+1 of them live in a per-thread LDS
-    // ring (ring[j * blockDim + tid], conflict-free), the k-mer's minimizer hash is the minimum over the ring
+    // minimizer = minimum of the last win = k-m+1 canonical m-mer hashes (one new hash per base).  Sliding minimum in O(1) per
+    // base (van Herk / Gil-Werman): the positions are cut into blocks of `win`; a window is a suffix of the previous block
+    // plus a prefix of the current one, so it is min(suffix minimum stored when that block ended, running prefix minimum).
+    // Per thread, in LDS (index j * blockDim + tid, conflict-free): raw[win] hashes of the current block, suf[win] suffix
+    // minima of the previous one.  (For k = 127 the window has 113 hashes: scanning it per k-mer was most of the kernel.)
     const int win = k - m + 1;
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    u32 *raw = ring, *suf = ring + (size_t)win * blockDim.x;
+    u32 pref = ~0u;
     u64 cw = codes[s >> 5], bw = brk[s >> 6];
-    u32 rj = 0;   // ring slot of position p (a running counter: p % win would be a 64-bit division per base)
+    u32 rj = 0;   // position inside the current block (a running counter: p % win would be a 64-bit division per base)
     for (u64 p = s; p < e1; ++p, rj = (rj + 1 == (u32)win) ? 0u : rj + 1) {
         if ((p & 31) == 0) cw = codes[p >> 5];
         if ((p & 63) == 0) bw = brk[p >> 6];
         u64 b = (cw >> (62 - 2 * (p & 31))) & 3;
-        if ((bw >> (p & 63)) & 1) { run = 0; continue; }
-        cur = key_append(cur, b, k);
-        rc = key_prepend(rc, 3 - b, k);
-        if (run < k) ++run;
-        if (m && run >= m)
-            ring[rj * blockDim.x + threadIdx.x] = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
-        if (p >= e0 && run >= k) {
-            if (case_sensitive) {
-                u64 fp = p - (u64)(k - 1);
-                if ((low[fp >> 6] >> (fp & 63)) & 1) continue;
+        if (rj == 0) pref = ~0u;
+        if ((bw >> (p & 63)) & 1) run = 0;
+        else {
+            cur = key_append(cur, b, k);
+            rc = key_prepend(rc, 3 - b, k);
+            if (run < k) ++run;
+            if (m && run >= m) {
+                const u32 h = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
+                raw[rj * blockDim.x + threadIdx.x] = h;
+                pref = h < pref ? h : pref;
             }
-            const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
-            u32 mmh = ~0u;
-            if (m)
-                for (int j = 0; j < win; ++j) { u32 h = ring[j * blockDim.x + threadIdx.x]; mmh = h < mmh ? h : mmh; }
-            emit(key, mmh);
+            if (p >= e0 && run >= k) {
+                bool keep = true;
+                if (case_sensitive) {
+                    u64 fp = p - (u64)(k - 1);
+                    keep = !((low[fp >> 6] >> (fp & 63)) & 1);
+                }
+                if (keep) {
+                    const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
+                    u32 mmh = ~0u;
+                    if (m) {
+                        mmh = pref;
+                        if (rj + 1 < (u32)win) { const u32 sv = suf[(rj + 1) * blockDim.x + threadIdx.x]; mmh = sv < mmh ? sv : mmh; }
+                    }
+                    emit(key, mmh);
+                }
+            }
+        }
+        if (m && rj + 1 == (u32)win) {   // block complete: its suffix minima serve the windows of the next block
+            u32 acc = ~0u;
+            for (int i = win - 1; i >= 0; --i) {
+                const u32 h = raw[i * blockDim.x + threadIdx.x];
+                acc = h < acc ? h : acc;
+                suf[i * blockDim.x + threadIdx.x] = acc;
+            }
         }
     }
 }
@@ -226,7 +250,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
                                                                 int ppt, u32 stage_cap) {
     extern __shared__ u32 kc_ring[];
     const int win = k - set.m + 1;
-    u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)win * blockDim.x);   // stage[(j * W + w) * blockDim + tid]: keys of the open run
+    u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)2 * win * blockDim.x);   // stage[(j * W + w) * blockDim + tid]: keys of the open run
     const u64 bs = (u64)1 << set.bshift;
     u32 nrun = 0;
     u64 run_blk = 0;
@@ -506,8 +530,8 @@ static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, cons
     int ppt = set->W == 1 ? 16 : (set->W == 2 ? 32 : 64);
     u64 nthreads = (len + ppt - 1) / ppt;
     const int win = set->mlen ? set->k - set->mlen + 1 : 1;
-    const unsigned bs = win <= 40 ? 256 : (win <= 80 ? 128 : 64);    // LDS ring: win * bs * 4 bytes (<= 40 KB)
-    const size_t lds = (size_t)win * bs * 4;
+    const unsigned bs = win <= 32 ? 256 : (win <= 64 ? 128 : 64);    // LDS: 2 * win * bs * 4 bytes (<= 64 KB)
+    const size_t lds = (size_t)win * bs * 4 * 2;   // raw + suffix-minimum arrays of kc_roll_kmers
     unsigned g = kc_grid(nthreads, bs);
     switch (set->W) {
         case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
@@ -541,10 +565,15 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     const int win = set->k - set->mlen + 1;
     // positions per thread: every thread first rolls over the k-1 bases before its range, so wide k wants long ranges
     const int ppt = W == 1 ? 16 : (W == 2 ? 32 : 64);
-    const u32 stage_cap = W == 1 ? 16 : 8;                             // staged keys per thread (a longer run is flushed in pieces)
-    const unsigned tb = win <= 40 ? 256 : (win <= 80 ? 128 : 64);    // LDS ring: win * tb * 4 bytes (<= 40 KB) + staged run keys
-    const size_t lds_scatter = (size_t)win * tb * 4 + (size_t)stage_cap * W * tb * 8;
+    const u32 stage_cap = 8;                                           // staged keys per thread (a longer run is flushed in pieces)
+    const unsigned tb = win <= 32 ? 256 : (win <= 64 ? 128 : 64);    // LDS: 2 * win * tb * 4 bytes (<= 64 KB) + staged run keys
+    const size_t lds_scatter = (size_t)win * tb * 4 * 2 + (size_t)stage_cap * W * tb * 8;
     const u64 nthreads = (len + ppt - 1) / ppt;
+    static bool scatter_attr_done = false;
+    if (lds_scatter > 64 * 1024 && !scatter_attr_done) {
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        scatter_attr_done = true;
+    }
     hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
                        set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap);
     const size_t lds_build = (size_t)bs * (8 * W + 1);
