@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
     int mode = KC_MODE_UNI;
     if (g.complements) mode = (g.d == 0 || key_eq(key_rc(key, g.d), key)) ? KC_MODE_PAL : KC_MODE_PAIR;
     const u64 members = (a1 - t) + (b1 - b0);
-    if (members >= KC_LDS_MIN && members <= KC_LDS_MAX) {   // medium buckets: replayed out of LDS by a wavefront of their own
+    if (members >= (u64)g.lds_min && members <= KC_LDS_MAX) {   // medium buckets: replayed out of LDS by a wavefront of their own
         u64 pos = atomicAdd((ull *)big_count, 1ULL);
         if (pos < big_cap) {
             u64 *dsc = big + pos * 5;
@@ -477,7 +477,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     KC_TRY(scope.alloc(&bl, BL_MAX * 2));
     KC_TRY(scope.alloc(&w.d_num, 2));
     u64 *big = nullptr;
-    const u64 big_cap = 2 * V / KC_LDS_MIN + 16;
+    int lds_min = KC_LDS_MIN;
+    if (const char *e = getenv("KC_LDS_MIN")) { int v = atoi(e); if (v >= 2 && v <= KC_LDS_MAX) lds_min = v; }
+    const u64 big_cap = 2 * V / (u64)(lds_min < 4 ? lds_min : 4) + 16;
     KC_TRY(scope.alloc(&big, big_cap * 5));
     u64 tcap = 64;
     while (tcap < 2 * V + 16) tcap <<= 1;
@@ -500,7 +502,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     g.S = S; g.V = V; g.batch = V / 16 + 1; g.complements = complements; g.lower_bound = lower_bound;
     g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
     g.first_snap = first_snap; g.last_snap = last_snap;
-    g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0;
+    g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0; g.lds_min = (u32)lds_min;
     u64 nS = V, nP = V, repairs = 0, tag_base = 0;
     std::vector<u64> h_bl;
     if (!lower_bound) {   // tag 0xffffffff = written by nobody
@@ -582,10 +584,13 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 g.tag_base = (u32)tag_base;
                 tag_base += nHS;
             }
+            // few hits (late levels: a handful of buckets hold everything that is left): even small buckets get a wavefront
+            // and LDS; many hits (tens of thousands of tiny buckets): those stay with one thread each
+            g.lds_min = (u32)((nHS + nHP <= 32768 && !getenv("KC_LDS_MIN")) ? 4 : lds_min);
             hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
                                (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8);
             {
-                u64 nblk = (nHS + nHP) / KC_LDS_MIN + 1;
+                u64 nblk = (nHS + nHP) / (u64)g.lds_min + 1;
                 if (nblk > big_cap) nblk = big_cap;
                 hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
                                    (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8));

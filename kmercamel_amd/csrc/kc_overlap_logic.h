@@ -39,6 +39,7 @@ struct OvArgs {
     const u64 *bl;      // blacklist of (u, c) pairs proven to close a cycle
     u64 nbl;
     u32 tag_base = 0;   // first writer tag of the current launch (tags are never reused between launches)
+    u32 lds_min = 12;   // buckets with at least this many members are replayed out of LDS by a wavefront of their own
 };
 
 #define KC_MODE_UNI 0
