@@ -101,6 +101,8 @@ def test_simplitigs_match_canonical_oracle(ctx, oracle, k, complements):
     cases.append(circ + circ[:k - 1] + circ[: k])      # closes a cycle in the de Bruijn graph
     big = _rand_seq(rng, 6000)
     cases.append(big + big[:k - 1] + "N" + _rand_seq(rng, 500))   # a cycle of 6000 k-mers (beyond the parallel cutter's 4096 steps) + a chain
+    cases.append(big + big[:k - 1])                               # nothing but that cycle: no chain end anywhere
+    cases.append(circ + circ[:k - 1])                             # nothing but a small cycle
     for seq in cases:
         want = oracle.simplitigs_of_sequence(seq.replace("\n", "N"), k, complements, mode=1)
         s = kc.KmerSet(ctx, k, complements, capacity_hint=len(seq))
