@@ -53,14 +53,25 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
     bool rc = v >= S;
     u64 L = lens[sidx], wb = woff[sidx], n = weight[v];
     u64 upper_end = L - (u64)k;   // indices <= upper_end are k-mer starts of the simplitig
-    // blockIdx.y splits long vertices (assembled genomes give simplitigs of Mbp) into interleaved 64-character slices
-    for (u64 t = (u64)blockIdx.y * 64 + lane; t < n; t += (u64)gridDim.y * 64) {
-        u64 j = rc ? (L - 1 - t) : t;
-        u64 b = (words[wb + (j >> 5)] >> (62 - 2 * (j & 31))) & 3;
-        if (rc) b = 3 - b;
-        char c = "ACGT"[b];
-        if (t > upper_end) c = (char)(c + ('a' - 'A'));
-        out[off + t] = c;
+    // every lane spells 8 consecutive characters per step (one 8-byte store); blockIdx.y splits long vertices (assembled
+    // genomes give simplitigs of Mbp) into interleaved 512-character slices
+    for (u64 t0 = ((u64)blockIdx.y * 64 + lane) * 8; t0 < n; t0 += (u64)gridDim.y * 512) {
+        u64 packed = 0;
+        const int cnt = (n - t0 >= 8) ? 8 : (int)(n - t0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const u64 t = t0 + (u64)i;
+            if (i < cnt) {
+                u64 j = rc ? (L - 1 - t) : t;
+                u64 b = (words[wb + (j >> 5)] >> (62 - 2 * (j & 31))) & 3;
+                if (rc) b = 3 - b;
+                u64 c = (u64)(unsigned char)"ACGT"[b];
+                if (t > upper_end) c += (u64)('a' - 'A');
+                packed |= c << (8 * i);
+            }
+        }
+        if (cnt == 8) __builtin_memcpy(out + off + t0, &packed, 8);
+        else for (int i = 0; i < cnt; ++i) out[off + t0 + (u64)i] = (char)(packed >> (8 * i));
     }
 }
 
