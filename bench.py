@@ -1,208 +1,331 @@
 #!/usr/bin/env python3
-"""bench.py -- `compute -k 31` (BIGREEDY) on synthetic FASTA, device-resident input -> device-resident masked superstring.
+"""bench.py -- `compute -k 31` (BIGREEDY) on synthetic FASTA, BASELINE configs[2] by default.
 
 One step = one pass of the whole hot path (pack -> canonical k-mer set -> simplitigs -> greedy overlap path -> emit)
-over one batch of synthetic records already resident in HBM.  N=1 runs BASELINE config[1] (100 000 records x 1 030 bp,
-seed 1 = 100 M 31-mers).  N>1: one process per GPU (torchrun), every rank runs the same-size shard of independent records
-(seed 1+rank) -- weak scaling over records with no data-path collective; value = all ranks' k-mers / max-over-ranks time.
+over the synthetic record set, input resident in HBM when the timed region starts, result resident in HBM when it ends.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant kernel and
-`cpu_baseline` (the reference's own code, oracle/_ref/kcref, on a bounded sample; N=1 only)."""
+N = 1 (default): BASELINE configs[2], the configuration the target is quoted on: 2 500 000 records x 1 030 bp, seed 2
+(2.5 G 31-mers).  `value` is the device-resident rate; the same JSON line also carries
+  * `end_to_end_cli`: SURVEY 8d metric (1) -- wall time of a fresh `kmercamel compute -k 31 -o out in.fa` process from
+    start to exit (FASTA read, H2D, kernels, D2H, output write; tmpfs files), median of --cli-runs runs,
+  * `roofline` for the dominant kernel (HIP events on the library's own stream),
+  * `cpu_baseline`: the reference's own code (oracle/_ref/kcref, 1 thread) on a bounded sample, median of --cpu-runs.
+N > 1: launched by torchrun, one rank per GPU; STRONG scaling on the same record set -- the k-mer set is sharded by
+hash range (block owner), the ranks exchange buckets / neighbour queries / chain fragments over RCCL and emit ONE
+masked superstring (kmercamel_amd/sharded.py).  value = N_kmers / max-over-ranks time.
+
+Prints ONE JSON line on rank 0."""
 import argparse
 import json
 import os
+import shutil
+import statistics
 import subprocess
 import sys
-import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling there: 6.29 TB/s
-# HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/collect_profile.sh ->
-# tools/summarize_profile.py: separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE x2 on gfx950 as calibrated on
-# the pack kernel). Only valid for the default workload it was collected on.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_final_cfg2_traffic.json")
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CHUNK_RECORDS = 100000  # the record set is generated in chunks of this many records, chunk c from default_rng([seed, c])
 
 
-def measured_traffic(kernel_substr, default_workload):
-    if not default_workload or not os.path.exists(TRAFFIC_FILE):
-        return None
+def traffic_from_profile(kernel_substr, records, k):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS workload (separate FETCH_SIZE /
+    WRITE_SIZE passes, tools/collect_profile.sh -> tools/summarize_profile.py); None when no profile of it is committed."""
+    name = {(2500000, 31): "r02_cfg2_2p5G_traffic.json", (100000, 31): "r02_cfg1_traffic.json"}.get((records, k))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return None, None
     try:
-        t = json.load(open(TRAFFIC_FILE))
-        for k, v in t.items():
-            if kernel_substr in k:
-                return int(v["hbm_bytes_per_launch"])
+        t = json.load(open(path))
+        for kn, v in t.items():
+            if kernel_substr in kn:
+                return int(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(k, read_len, sample_records, seed):
-    """Time the CPU path on a bounded sample of the same workload (same generator, fewer records)."""
-    import gen
-    recs = gen.random_records(sample_records, read_len, seed)
-    with tempfile.TemporaryDirectory() as d:
-        fa = os.path.join(d, "sample.fa")
-        with open(fa, "wb") as f:
-            for i, r in enumerate(recs):
-                f.write(b">r%d\n%s\n" % (i, r))
+_LUT32 = None
+
+
+def chunk_joined(seed, chunk, n, length):
+    """records [chunk*CHUNK_RECORDS, +n) of the set: uniform i.i.d. ACGT (2 bits of default_rng([seed, chunk]).bytes() per base,
+    most significant pair first), each followed by '\\n'"""
+    import numpy as np
+    global _LUT32
+    if _LUT32 is None:
+        acgt = b"ACGT"
+        _LUT32 = np.frombuffer(b"".join(bytes([acgt[(b >> 6) & 3], acgt[(b >> 4) & 3], acgt[(b >> 2) & 3], acgt[b & 3]]) for b in range(256)),
+                               dtype=np.uint32).copy()
+    rng = np.random.default_rng([seed, chunk])
+    total = n * length
+    raw = np.frombuffer(rng.bytes((total + 3) // 4), dtype=np.uint8)
+    bases = _LUT32[raw].view(np.uint8)[:total].reshape(n, length)
+    a = np.empty((n, length + 1), dtype=np.uint8)
+    a[:, :length] = bases
+    a[:, length] = 10
+    return a
+
+
+def record_range(records, rank, world):
+    """rank's slice of the record set (whole chunks first, so that every world size generates the same records)"""
+    lo = records * rank // world
+    hi = records * (rank + 1) // world
+    return lo, hi
+
+
+def generate(seed, lo, hi, length, fasta=None):
+    """records [lo, hi) joined by '\\n' as one uint8 array; optionally also written as FASTA (>r<i>) to `fasta`"""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    parts = []
+    f = open(fasta, "wb") if fasta else None
+    chunks = list(range(lo // CHUNK_RECORDS, (hi + CHUNK_RECORDS - 1) // CHUNK_RECORDS))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:   # numpy releases the GIL in the bulk operations
+        for c, a in zip(chunks, pool.map(lambda c: chunk_joined(seed, c, CHUNK_RECORDS, length), chunks)):
+            c_lo = c * CHUNK_RECORDS
+            s, e = max(lo, c_lo) - c_lo, min(hi, c_lo + CHUNK_RECORDS) - c_lo
+            a = a[s:e]
+            parts.append(a.reshape(-1))
+            if f:   # ">r<i>\\n" + sequence + "\\n" per record, written group-wise (records whose index has the same number of digits)
+                idx = np.arange(c_lo + s, c_lo + e, dtype=np.int64)
+                nd = np.where(idx > 0, np.floor(np.log10(np.maximum(idx, 1))).astype(np.int64) + 1, 1)
+                g0 = 0
+                while g0 < len(idx):
+                    d = int(nd[g0])
+                    g1 = g0 + int(np.searchsorted(nd[g0:], d, side="right"))
+                    rows = np.empty((g1 - g0, 3 + d + length + 1), dtype=np.uint8)
+                    rows[:, 0] = ord(">"); rows[:, 1] = ord("r"); rows[:, 2 + d] = 10
+                    rows[:, 2:2 + d] = (idx[g0:g1, None] // (10 ** np.arange(d - 1, -1, -1, dtype=np.int64))[None, :]) % 10 + 48
+                    rows[:, 3 + d:] = a[g0:g1]
+                    rows.tofile(f)
+                    g0 = g1
+    if f:
+        f.close()
+    out = np.concatenate(parts) if len(parts) > 1 else parts[0]
+    return out[:-1]
+
+
+def cpu_baseline(k, read_len, sample_records, seed, runs, full_n):
+    """The reference's CPU path (oracle/_ref/kcref = its own headers compiled in place) on a bounded sample of the same
+    workload (same generator, first `sample_records` records), median of `runs` runs; falls back to the oracle restatement."""
+    tmp = "/dev/shm/kc_bench_cpu_%d" % os.getpid()
+    os.makedirs(tmp, exist_ok=True)
+    try:
+        fa = os.path.join(tmp, "sample.fa")
+        generate(seed, 0, sample_records, read_len, fasta=fa)
         kcref = os.path.join(ROOT, "oracle", "_ref", "kcref")
         if os.path.exists(kcref):
-            t0 = time.time()
-            p = subprocess.run([kcref, "compute", "-k", str(k), "-o", os.path.join(d, "out.txt"), fa], capture_output=True, text=True)
-            dt = time.time() - t0
-            st = json.loads(p.stderr.strip().splitlines()[-1])
-            return {"value": round(st["n_kmers"] / dt / 1e6, 4), "unit": "Mkmers/s", "cores": 1, "kind": "reference",
-                    "sample": "%d records x %d bp (same generator, seed %d): %d k-mers in %.1f s wall incl. FASTA read; phases read %.1f / simplitigs %.1f / path %.1f / emit %.1f s"
-                              % (sample_records, read_len, seed, st["n_kmers"], dt, st["t_read_s"], st["t_simplitigs_s"], st["t_path_s"], st["t_emit_s"])}
+            walls, st = [], None
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                p = subprocess.run([kcref, "compute", "-k", str(k), "-o", os.path.join(tmp, "out.txt"), fa], capture_output=True, text=True)
+                walls.append(time.perf_counter() - t0)
+                st = json.loads(p.stderr.strip().splitlines()[-1])
+            dt = statistics.median(walls)
+            rate = st["n_kmers"] / dt / 1e6
+            return {"value": round(rate, 4), "unit": "Mkmers/s", "cores": 1, "kind": "reference", "runs": runs,
+                    "wall_s": [round(w, 2) for w in walls],
+                    "sample": "first %d records x %d bp of the same set (%d k-mers), process wall incl. FASTA read and output write, median of %d runs; "
+                              "last run's phases: read %.1f / simplitigs %.1f / path %.1f / emit %.1f s; the full %d-k-mer set would take ~%.0f s at this rate "
+                              "(linear extrapolation, not run)" % (sample_records, read_len, st["n_kmers"], runs, st["t_read_s"], st["t_simplitigs_s"],
+                                                                   st["t_path_s"], st["t_emit_s"], full_n, full_n / (rate * 1e6))}
         import oracle_lib
         orc = oracle_lib.Oracle()
-        t0 = time.time()
-        rc, out, _, st = orc.compute_file(fa, k, True, False, mode=0, want_mask=False)
-        dt = time.time() - t0
-        return {"value": round(st[0] / dt / 1e6, 4), "unit": "Mkmers/s", "cores": 1, "kind": "port",
-                "sample": "%d records x %d bp (seed %d): %d k-mers in %.1f s (oracle restatement, reference order)" % (sample_records, read_len, seed, st[0], dt)}
+        walls, st = [], None
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            rc, out, _, st = orc.compute_file(fa, k, True, False, mode=0, want_mask=False)
+            walls.append(time.perf_counter() - t0)
+        dt = statistics.median(walls)
+        return {"value": round(st[0] / dt / 1e6, 4), "unit": "Mkmers/s", "cores": 1, "kind": "port", "runs": runs,
+                "sample": "first %d records x %d bp (%d k-mers), oracle restatement in reference order, median of %d runs" % (sample_records, read_len, st[0], runs)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
-def shard_seed(rank):
-    """records of rank r are generated with seed 1+r (independent shards, weak scaling)"""
-    return 1 + rank
+def cli_end_to_end(fa, k, runs, expect_len, expect_bytes):
+    """SURVEY 8d metric (1): wall of a fresh CLI process, start to exit, files on tmpfs. Returns (dict, ok)."""
+    import numpy as np
+    exe = os.path.join(ROOT, "kmercamel_amd", "bin", "kmercamel")
+    out = os.path.join(os.path.dirname(fa), "out.txt")
+    walls, trace = [], ""
+    env = dict(os.environ, KC_CLI_TRACE="1")
+    for _ in range(runs):
+        if os.path.exists(out):
+            os.unlink(out)
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "compute", "-k", str(k), "-o", out, fa], capture_output=True, text=True, env=env)
+        walls.append(time.perf_counter() - t0)
+        if p.returncode != 0:
+            return {"error": "CLI exited with %d: %s" % (p.returncode, p.stderr[-400:])}, False
+        trace = " | ".join(l[6:] for l in p.stderr.splitlines() if l.startswith("[cli] "))
+    # the file holds the header line, the superstring, '\n'
+    with open(out, "rb") as f:
+        header = f.readline()
+        body = np.fromfile(f, dtype=np.uint8)
+    same = (len(body) == expect_len + 1) and bool(np.array_equal(body[:expect_len], expect_bytes))
+    res = {"wall_s": [round(w, 3) for w in walls], "runs": runs, "median_wall_s": round(statistics.median(walls), 3),
+           "output_identical_to_device_resident_result": same, "header": header.decode(errors="replace").strip()[:120],
+           "phase_trace_ms_last_run": trace, "files": "tmpfs (/dev/shm)"}
+    return res, same
 
 
-def aggregate(dist, dev, elapsed, n_kmers):
-    """(max over ranks of elapsed, sum over ranks of the k-mer counts); identity without a process group"""
-    if dist is None:
-        return float(elapsed), float(n_kmers)
-    import torch
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    nk = torch.tensor([float(n_kmers)], dtype=torch.float64, device=dev)
-    dist.all_reduce(nk, op=dist.ReduceOp.SUM)
-    return float(t.item()), float(nk.item())
+def hbm_copy_ceiling(torch, dev):
+    """device-to-device copy of 4 GiB: (read + write bytes) / time, best of 5 -- the measured streaming ceiling"""
+    n = 1 << 32
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return round(best, 1)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("-k", type=int, default=31)
-    ap.add_argument("--records", type=int, default=100000)
+    ap.add_argument("--records", type=int, default=2500000, help="2 500 000 = BASELINE configs[2] (2.5 G k-mers); 100 000 = configs[1]")
+    ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--read-len", type=int, default=0, help="default k-1+1000 (1030 for k=31)")
+    ap.add_argument("--cli-runs", type=int, default=3)
+    ap.add_argument("--no-cli", action="store_true")
     ap.add_argument("--cpu-sample-records", type=int, default=40000)
+    ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify size-independent properties of the output")
     args = ap.parse_args()
     k = args.k
     read_len = args.read_len or (k - 1 + 1000)
 
-    import numpy as np
-    import torch
-    import gen
-    import kmercamel_amd as kc
-
+    # `--gpus N` without a launcher: start the ranks ourselves, BEFORE anything touches the GPU in this process
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    # KC_BENCH_BACKEND=gloo is for checking the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices and
-    # the two scalars are reduced through the host); the real thing is one rank per GPU over RCCL ("nccl").
-    backend = os.environ.get("KC_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        import bench_sharded
+        sys.exit(bench_sharded.main(args, world, rank, local_rank, read_len))
+
+    import numpy as np
+    import torch
+    import kmercamel_amd as kc
+
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
-
     ctx = kc.Context(local_rank)
-    host = gen.random_joined(args.records, read_len, seed=shard_seed(rank))
-    d_seq = torch.from_numpy(host).to(dev)
-    torch.cuda.synchronize()
-    nbytes = int(d_seq.numel())
-
-    def step():
-        r = kc.compute(ctx, None, k, True, want_mask=False, device_ptr=d_seq.data_ptr(), length=nbytes)
-        st = r.stats
-        r.close()
-        return st
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    tmp = "/dev/shm/kc_bench_%d" % os.getpid()
+    want_cli = not args.no_cli
+    fa = None
+    if want_cli:
+        os.makedirs(tmp, exist_ok=True)
+        fa = os.path.join(tmp, "in.fa")
+    try:
+        t_gen = time.perf_counter()
+        host = generate(args.seed, 0, args.records, read_len, fasta=fa)
+        t_gen = time.perf_counter() - t_gen
+        d_seq = torch.from_numpy(host).to(dev)
         torch.cuda.synchronize()
+        nbytes = int(d_seq.numel())
+        del host
 
-    for _ in range(args.warmup):
-        st = step()
-    barrier()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        stats.append(step())
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    elapsed, total_kmers = aggregate(dist, red_dev, elapsed, stats[-1]["n_kmers"])
+        def step():
+            r = kc.compute(ctx, None, k, True, want_mask=False, device_ptr=d_seq.data_ptr(), length=nbytes)
+            st = r.stats
+            r.close()
+            return st
 
-    if args.check and rank == 0:
-        # size-independent properties of the result at the benchmark's own size (no oracle involved): min-one mask (ones == N),
-        # length bounds, and a sampled round trip -- k-mers read off random upper-case positions of the output are in the
-        # input's set, k-mers read off random input positions are in the set the output represents (same sizes).
-        import ctypes
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = []
+        for _ in range(args.steps):
+            stats.append(step())
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        st = stats[-1]
+        N, S = st["n_kmers"], st["n_simplitigs"]
+
+        # the result once more, on the host: reference for the CLI comparison and for --check
         r = kc.compute(ctx, None, k, True, want_mask=False, device_ptr=d_seq.data_ptr(), length=nbytes)
-        N, S, L = r.stats["n_kmers"], r.stats["n_simplitigs"], r.length
+        L = r.length
+        import ctypes
         o = np.empty(L + 1, dtype=np.uint8)
         ctx.check(ctx.lib.kc_result_copy(r.h, o.ctypes.data_as(ctypes.c_char_p), None))
         r.close()
         o = o[:L]
-        assert int(np.count_nonzero(o < 97)) == N, "mask is not min-one"
-        assert N + k - 1 <= L <= N + S * (k - 1), "superstring length out of bounds"
-        a = kc.KmerSet(ctx, k, True, capacity_hint=nbytes)
-        a.add_device(d_seq.data_ptr(), nbytes)
-        b = kc.KmerSet(ctx, k, True, capacity_hint=L)
-        b.AddKMers(o.tobytes(), case_sensitive=True)
-        assert a.size() == N and b.size() == N, "round trip: set sizes differ (%d, %d, %d)" % (a.size(), b.size(), N)
-        rng = np.random.default_rng(7)
-        code = np.full(256, 255, dtype=np.uint8)
-        for i, ch in enumerate(b"ACGT"):
-            code[ch] = i; code[ch + 32] = i
-        def kmers_at(buf, pos):
-            out = []
-            for p0 in pos:
-                w = code[buf[p0:p0 + k]]
-                if len(w) < k or (w == 255).any():
-                    continue
-                f = 0; rc = 0
-                for j, c in enumerate(w.tolist()):
-                    f = (f << 2) | c
-                    rc |= (3 - c) << (2 * j)
-                out.append(min(f, rc))
-            return out
-        up = np.flatnonzero(o[: min(L, 50_000_000)] < 97)
-        qa = kmers_at(o, rng.choice(up, size=min(2000, len(up)), replace=False))
-        assert qa and all(a.contains(qa)), "round trip: an output k-mer is not in the input set"
-        seq_host = d_seq[: min(nbytes, 50_000_000)].cpu().numpy()
-        qb = kmers_at(seq_host, rng.integers(0, len(seq_host) - k, size=2000))
-        assert qb and all(b.contains(qb)), "round trip: an input k-mer is not represented by the output"
-        a.close(); b.close()
-        print("check ok: N=%d S=%d L=%d, %d + %d sampled k-mers round-tripped" % (N, S, L, len(qa), len(qb)), file=sys.stderr)
+        checks = {}
+        if args.check:
+            # size-independent properties at the benchmark's own size (no oracle involved): min-one mask (ones == N), length
+            # bounds, and a round trip -- the k-mer set read back off the output equals the input's set in size, and sampled
+            # k-mers are found both ways
+            assert int(np.count_nonzero(o < 97)) == N, "mask is not min-one"
+            assert N + k - 1 <= L <= N + S * (k - 1), "superstring length out of bounds"
+            a = kc.KmerSet(ctx, k, True, capacity_hint=nbytes)
+            a.add_device(d_seq.data_ptr(), nbytes)
+            assert a.size() == N
+            rng = np.random.default_rng(7)
+            code = np.full(256, 255, dtype=np.uint8)
+            for i, ch in enumerate(b"ACGT"):
+                code[ch] = i; code[ch + 32] = i
 
-    if rank == 0:
-        st = stats[-1]
+            def kmers_at(buf, pos):
+                out = []
+                for p0 in pos:
+                    w = code[buf[p0:p0 + k]]
+                    if len(w) < k or (w == 255).any():
+                        continue
+                    f = 0; rc = 0
+                    for j, c in enumerate(w.tolist()):
+                        f = (f << 2) | c
+                        rc |= (3 - c) << (2 * j)
+                    out.append(min(f, rc))
+                return out
+            up = np.flatnonzero(o[: min(L, 50_000_000)] < 97)
+            qa = kmers_at(o, rng.choice(up, size=min(2000, len(up)), replace=False))
+            assert qa and all(a.contains(qa)), "round trip: an output k-mer is not in the input set"
+            a.close()
+            b = kc.KmerSet(ctx, k, True, capacity_hint=L)
+            b.AddKMers(o.tobytes(), case_sensitive=True)
+            assert b.size() == N, "round trip: the output represents %d k-mers, the input has %d" % (b.size(), N)
+            seq_host = d_seq[: min(nbytes, 50_000_000)].cpu().numpy()
+            qb = kmers_at(seq_host, rng.integers(0, len(seq_host) - k, size=2000))
+            assert qb and all(b.contains(qb)), "round trip: an input k-mer is not represented by the output"
+            b.close()
+            checks = {"ones_eq_N": True, "set_round_trip": True, "sampled": len(qa) + len(qb)}
+            print("check ok: N=%d S=%d L=%d" % (N, S, L), file=sys.stderr)
+
+        ceiling = hbm_copy_ceiling(torch, dev)
+        # free the device before the CLI child needs it (the pool holds ~60 B per k-mer)
+        del d_seq
+        ctx.close()
+        torch.cuda.empty_cache()
+
         W = 8 * (1 if k < 32 else (2 if k < 64 else 4))
-        N, S = st["n_kmers"], st["n_simplitigs"]
-        # dominant kernel: whichever of the two hash kernels took longer (both timed with HIP events recorded on the
-        # library's own stream around the launch, averaged over the timed steps)
         us_probe = sum(s["us_probe_kernel"] for s in stats) / len(stats)
         us_insert = sum(s["us_insert_kernel"] for s in stats) / len(stats)
         if us_probe >= us_insert:
@@ -214,37 +337,52 @@ def main():
         achieved = alg_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
         phases = {p: round(sum(s[p] for s in stats) / len(stats) / 1000.0, 3) for p in
                   ("us_insert_phase", "us_simplitig_phase", "us_overlap_phase", "us_emit_phase", "us_total")}
+        whole_alg = N * (1.5 + 4 * W + 16) + S * 2 * k * (2 * W + 8)
+        traffic, traffic_src = traffic_from_profile(ksub, args.records, k)
+        cfg_name = {2500000: "BASELINE configs[2]", 100000: "BASELINE configs[1]"}.get(args.records, "custom size")
         line = {
-            "metric": "M distinct k-mers/s end-to-end compute -k %d (device-resident sequence -> masked superstring)" % k,
-            "value": round(total_kmers * args.steps / elapsed / 1e6, 3),
+            "metric": "M distinct k-mers/s, compute -k %d (device-resident FASTA sequence -> device-resident masked superstring)" % k,
+            "value": round(N * args.steps / elapsed / 1e6, 3),
             "unit": "Mkmers/s",
-            "n_gpus": world,
+            "n_gpus": 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1000.0, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u64" if k < 32 else ("u128" if k < 64 else "u256"),
             "data": "synthetic",
-            "config": {"workload": "synthetic FASTA %d records x %d bp per GPU, uniform ACGT, seed 1+rank, k=%d, bidirectional (BASELINE configs[1] at 1 GPU)"
-                                   % (args.records, read_len, k),
-                       "n_kmers_per_gpu": N, "n_simplitigs": S, "superstring_length": st["length"], "sharding": "independent record shards per rank, no collective"},
+            "config": {"workload": "%s: synthetic FASTA %d records x %d bp, uniform ACGT, default_rng([%d, chunk]) per %d records, k=%d, bidirectional"
+                                   % (cfg_name, args.records, read_len, args.seed, CHUNK_RECORDS, k),
+                       "n_kmers": N, "n_simplitigs": S, "superstring_length": L},
             "phases_ms": phases,
             "matching_rounds": st["matching_rounds"], "overlap_repairs": st["overlap_repairs"],
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(ksub, args.records == 100000 and k == 31 and not args.read_len),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(us, 1),
-                         "whole_path_alg_bytes": int(N * (1.5 + 4 * W + 16) + S * 2 * k * (2 * W + 8)),
-                         "whole_path_achieved_GBs": round((N * (1.5 + 4 * W + 16) + S * 2 * k * (2 * W + 8)) / (phases["us_total"] * 1e-3) / 1e9, 2)},
+                         "measured_copy_ceiling_GBs": ceiling,
+                         "whole_path_alg_bytes": int(whole_alg),
+                         "whole_path_achieved_GBs": round(whole_alg / (phases["us_total"] * 1e-3) / 1e9, 2)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(k, read_len, args.cpu_sample_records, seed=1)
+        if checks:
+            line["checks"] = checks
+        if want_cli:
+            e2e, ok = cli_end_to_end(fa, k, args.cli_runs, L, o)
+            if "median_wall_s" in e2e:
+                e2e["value"] = round(N / e2e["median_wall_s"] / 1e6, 3)
+                e2e["unit"] = "Mkmers/s"
+                e2e["definition"] = "N / wall of `kmercamel compute -k %d -o out in.fa`, fresh process start to exit (SURVEY 8d metric 1)" % k
+            line["end_to_end_cli"] = e2e
+            if not ok:
+                print(json.dumps(line), flush=True)
+                print("bench.py: the CLI output differs from the device-resident result", file=sys.stderr)
+                sys.exit(1)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(k, read_len, min(args.cpu_sample_records, args.records), args.seed, args.cpu_runs, N)
         print(json.dumps(line), flush=True)
-    ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

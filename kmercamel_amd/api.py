@@ -88,6 +88,18 @@ def load():
     return lib
 
 
+def _host_bytes(seq):
+    """(void pointer, length, keep-alive object) of a str / bytes / bytearray / contiguous numpy uint8 array, without copying arrays"""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    if isinstance(seq, (bytes, bytearray)):
+        b = bytes(seq)
+        return ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p), len(b), b
+    import numpy as np
+    a = np.ascontiguousarray(seq, dtype=np.uint8)
+    return ctypes.c_void_p(a.ctypes.data), int(a.size), a
+
+
 def words_for_k(k):
     return 1 if k < 32 else (2 if k < 64 else 4)
 
@@ -142,9 +154,8 @@ class KmerSet:
         ctx._adopt(self)
 
     def AddKMers(self, seq, case_sensitive=False):  # parser.h:22-49
-        if isinstance(seq, str):
-            seq = seq.encode()
-        self.ctx.check(self.ctx.lib.kc_set_add_sequence(self.h, seq, len(seq), int(case_sensitive)))
+        ptr, n, _keep = _host_bytes(seq)
+        self.ctx.check(self.ctx.lib.kc_set_add_sequence(self.h, ctypes.cast(ptr, ctypes.c_char_p), n, int(case_sensitive)))
 
     def add_device(self, ptr, length, case_sensitive=False):
         self.ctx.check(self.ctx.lib.kc_set_add_sequence_device(self.h, ctypes.c_void_p(ptr), length, int(case_sensitive)))
@@ -437,6 +448,13 @@ class ComputeResult:
         self.ctx.check(self.ctx.lib.kc_result_copy(self.h, out, mask))
         return out.raw[:self.length].decode(), (mask.raw[:self.length].decode() if want_mask else None)
 
+    def array(self):
+        """the masked superstring as a numpy uint8 array (no Python string in between: usable at 2.5 G characters)"""
+        import numpy as np
+        out = np.empty(self.length + 1, dtype=np.uint8)
+        self.ctx.check(self.ctx.lib.kc_result_copy(self.h, out.ctypes.data_as(ctypes.c_char_p), None))
+        return out[:self.length]
+
     def close(self):
         if self.h:
             self.ctx.lib.kc_result_destroy(self.h)
@@ -465,9 +483,8 @@ def compute(ctx, seq, k, complements=True, want_mask=False, simplitig_offsets=No
         flags |= FLAG_INPUT_ON_DEVICE
         ctx.check(ctx.lib.kc_compute(ctx.h, ctypes.c_void_p(device_ptr), length, off, nrec, k, flags, ctypes.byref(h)))
     else:
-        buf = seq if isinstance(seq, (bytes, bytearray)) else seq.encode()
-        ctx.check(ctx.lib.kc_compute(ctx.h, ctypes.cast(ctypes.c_char_p(bytes(buf)), ctypes.c_void_p), len(buf), off, nrec, k, flags,
-                                     ctypes.byref(h)))
+        ptr, n, _keep = _host_bytes(seq)
+        ctx.check(ctx.lib.kc_compute(ctx.h, ptr, n, off, nrec, k, flags, ctypes.byref(h)))
     return ComputeResult(ctx, h)
 
 

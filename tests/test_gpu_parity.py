@@ -251,6 +251,52 @@ def test_full_size_properties_cfg1(ctx):
     a.close(); b.close()
 
 
+def test_full_size_properties_cfg2(ctx):
+    """BASELINE configs[2] at full size (2 500 000 records x 1 030 bp, k = 31: 2.5 * 10^9 k-mers, the set bench.py runs),
+    through the same oracle-free properties as cfg1: determinism (two runs, identical bytes), ones == N (min-one mask),
+    length bounds, and the round trip -- the k-mers at the upper-case positions of the output are exactly the input's set
+    (equal sizes, equal order-free checksums over all 2.5 G keys, spot checks both ways)."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    k = 31
+    seq = bench.generate(2, 0, 2500000, 1030)
+    r = kc.compute(ctx, seq, k, True, want_mask=False)
+    N, S, L = r.stats["n_kmers"], r.stats["n_simplitigs"], r.length
+    o = r.array()
+    r.close()
+    assert 2500000 * 1000 - 200 <= N <= 2500000 * 1000
+    assert N + k - 1 <= L <= N + S * (k - 1)
+    assert int(np.count_nonzero(o < 97)) == N
+    r2 = kc.compute(ctx, seq, k, True, want_mask=False)
+    o2 = r2.array()
+    r2.close()
+    assert np.array_equal(o, o2)
+    del o2
+    mix = np.uint64(0x9E3779B97F4A7C15)
+
+    def digest(s):
+        keys = _export_keys_np(s)
+        with np.errstate(over="ignore"):
+            d = (len(keys), int(keys.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(keys * mix)))
+        return d, [int(x) for x in keys[:: max(1, len(keys) // 500)][:500]]
+    a = kc.KmerSet(ctx, k, True, capacity_hint=len(seq))
+    a.AddKMers(seq)
+    da, pa = digest(a)
+    a.close()
+    b = kc.KmerSet(ctx, k, True, capacity_hint=L)
+    b.AddKMers(o, case_sensitive=True)
+    db, pb = digest(b)
+    assert da[0] == N and da == db
+    assert all(b.contains(pa))
+    b.close()
+    a = kc.KmerSet(ctx, k, True, capacity_hint=len(seq))
+    a.AddKMers(seq)
+    assert all(a.contains(pb))
+    a.close()
+
+
 def test_simplitigs_reference_kats(ctx):
     # tests/simplitigs_unittest.h:183-208 (order-tolerant there: sorted by length)
     enc = oracle_lib.encode_kmer
