@@ -116,6 +116,36 @@ int kc_result_device_ptrs(kc_result *r, void **d_out, void **d_mask);
 int kc_result_copy(kc_result *r, char *out, char *mask_out);
 void kc_result_destroy(kc_result *r);
 
+/* ---- hash-sharded multi-GPU path (the reference is one thread of one process, main.cpp:122-212, so these
+ * have no reference counterpart): one process (or thread) per GPU, every rank holds a kc_ctx and a kc_comm.  The k-mer
+ * set is partitioned by table-block range (block = hash of the canonical minimizer), the ranks exchange k-mer buckets,
+ * neighbour queries and chain fragments, and together emit ONE masked superstring, byte-identical to kc_compute's on
+ * the union of the inputs; rank r ends up with the r-th contiguous slice of it. ---- */
+typedef struct kc_comm kc_comm;
+/* single rank (world = 1): the sharded code path without a transport */
+int kc_comm_create_self(kc_ctx *ctx, kc_comm **out);
+/* Transport supplied by the caller on HOST buffers (tests: torch.distributed/gloo; any MPI).  all-to-all(v): `send` holds
+ * the bytes for rank 0, 1, ... back to back (send_bytes[p] each), `recv` receives rank 0's, 1's, ... bytes back to back.
+ * all-gather: `out` = every rank's `bytes_per_rank` bytes in rank order.  Return 0 on success. */
+typedef int (*kc_alltoallv_host_fn)(void *user, const void *send, const uint64_t *send_bytes, void *recv, const uint64_t *recv_bytes);
+typedef int (*kc_allgather_host_fn)(void *user, const void *in, void *out, uint64_t bytes_per_rank);
+int kc_comm_create_callbacks(kc_ctx *ctx, int rank, int world, kc_alltoallv_host_fn alltoallv, kc_allgather_host_fn allgather, void *user,
+                             kc_comm **out);
+/* RCCL over xGMI: rank 0 calls kc_rccl_unique_id (128 bytes), hands the id to the other ranks by any means (bench.py:
+ * torch.distributed broadcast), then every rank calls kc_comm_create_rccl.  librccl.so is loaded on first use. */
+int kc_rccl_unique_id(void *id128);
+int kc_comm_create_rccl(kc_ctx *ctx, int rank, int world, const void *id128, kc_comm **out);
+void kc_comm_destroy(kc_comm *comm);
+/* stats[8]: 0 bytes sent, 1 bytes received, 2 collective calls, 3 microseconds spent inside them (host clock) */
+int kc_comm_stats(kc_comm *comm, uint64_t *stats);
+/* The greedy branch of kmercamel<>() over all ranks' records: `seq`/`len` are THIS rank's records (joined by '\n', may be
+ * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE (k >= 16; -S, -M and -z go
+ * through the single-GPU kc_compute).  The result holds this rank's slice; stats as kc_result_stats with global counts. */
+int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out);
+/* position and size of this rank's slice inside the superstring (offset 0 / whole length for kc_compute results);
+ * kc_result_device_ptrs / kc_result_copy address the slice */
+int kc_result_slice(kc_result *r, uint64_t *offset, uint64_t *slice_len);
+
 /* ---- next row 1: maskopt -t max-one / min-one (masks.h:40-78, 239-261) ---- */
 /* ms: one masked superstring (ACGTacgt, else KC_E_INVALID_CHAR after output like the reference). out: len bytes. */
 int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out);

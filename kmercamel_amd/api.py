@@ -54,13 +54,21 @@ SIGNATURES = {
     "kc_result_device_ptrs": (ctypes.c_int, [_vp, _vpp, _vpp]),
     "kc_result_copy": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_char_p]),
     "kc_result_destroy": (None, [_vp]),
+    "kc_comm_create_self": (ctypes.c_int, [_vp, _vpp]),
+    "kc_comm_create_callbacks": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vpp]),
+    "kc_rccl_unique_id": (ctypes.c_int, [_vp]),
+    "kc_comm_create_rccl": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vpp]),
+    "kc_comm_destroy": (None, [_vp]),
+    "kc_comm_stats": (ctypes.c_int, [_vp, _u64p]),
+    "kc_compute_sharded": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
+    "kc_result_slice": (ctypes.c_int, [_vp, _u64p, _u64p]),
     "kc_maskopt_ones": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "kc_version": (ctypes.c_char_p, []),
 }
 
 STAT_NAMES = ["n_kmers", "n_simplitigs", "length", "sparse_branch", "n_vertices", "matching_rounds", "us_insert_phase",
               "us_simplitig_phase", "us_overlap_phase", "us_emit_phase", "us_probe_kernel", "us_insert_kernel", "table_capacity",
-              "overlap_repairs", "us_total", "reserved"]
+              "overlap_repairs", "us_total", "n_kmers_local"]
 
 
 class KcError(RuntimeError):
@@ -448,12 +456,19 @@ class ComputeResult:
         self.ctx.check(self.ctx.lib.kc_result_copy(self.h, out, mask))
         return out.raw[:self.length].decode(), (mask.raw[:self.length].decode() if want_mask else None)
 
+    def slice(self):
+        """(offset, length) of the part of the superstring this result holds (hash-sharded runs: this rank's slice)"""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        self.ctx.check(self.ctx.lib.kc_result_slice(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def array(self):
-        """the masked superstring as a numpy uint8 array (no Python string in between: usable at 2.5 G characters)"""
+        """the masked superstring (or this rank's slice of it) as a numpy uint8 array -- no Python string in between"""
         import numpy as np
-        out = np.empty(self.length + 1, dtype=np.uint8)
+        n = self.slice()[1]
+        out = np.empty(n + 1, dtype=np.uint8)
         self.ctx.check(self.ctx.lib.kc_result_copy(self.h, out.ctypes.data_as(ctypes.c_char_p), None))
-        return out[:self.length]
+        return out[:n]
 
     def close(self):
         if self.h:
@@ -485,6 +500,102 @@ def compute(ctx, seq, k, complements=True, want_mask=False, simplitig_offsets=No
     else:
         ptr, n, _keep = _host_bytes(seq)
         ctx.check(ctx.lib.kc_compute(ctx.h, ptr, n, off, nrec, k, flags, ctypes.byref(h)))
+    return ComputeResult(ctx, h)
+
+
+# ---- hash-sharded multi-GPU path: one process per GPU -------------------------------------------------
+_A2A_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _u64p, ctypes.c_void_p, _u64p)
+_AG_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+
+
+class Comm:
+    """Rank-to-rank transport of the hash-sharded path (kc_comm).
+
+    Comm.self_(ctx)             one rank, no transport;
+    Comm.rccl(ctx, dist)        RCCL over xGMI inside the library (grouped ncclSend/ncclRecv); torch.distributed is only used to
+                                hand rank 0's unique id to the other ranks;
+    Comm.torch_host(ctx, dist)  host-staged through a torch.distributed process group (gloo): tests, boxes without xGMI."""
+
+    def __init__(self, ctx, h, rank, world, keep=None):
+        self.ctx, self.h, self.rank, self.world, self._keep = ctx, h, rank, world, keep
+
+    @classmethod
+    def self_(cls, ctx):
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.kc_comm_create_self(ctx.h, ctypes.byref(h)))
+        return cls(ctx, h, 0, 1)
+
+    @classmethod
+    def rccl(cls, ctx, dist):
+        import torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = (ctypes.c_uint8 * 128)()
+        if rank == 0:
+            ctx.check(ctx.lib.kc_rccl_unique_id(buf))
+        box = [bytes(buf)]
+        dist.broadcast_object_list(box, src=0)
+        idb = (ctypes.c_uint8 * 128).from_buffer_copy(box[0])
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.kc_comm_create_rccl(ctx.h, rank, world, idb, ctypes.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @classmethod
+    def torch_host(cls, ctx, dist, group=None):
+        import torch
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def view(ptr, nbytes):
+            if nbytes == 0:
+                return torch.empty(0, dtype=torch.uint8)
+            return torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+
+        def a2a(user, send, send_bytes, recv, recv_bytes):
+            try:
+                sb = [int(send_bytes[i]) for i in range(world)]
+                rb = [int(recv_bytes[i]) for i in range(world)]
+                dist.all_to_all_single(view(recv, sum(rb)), view(send, sum(sb)), output_split_sizes=rb, input_split_sizes=sb, group=group)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- an exception must not unwind through the C caller
+                print("kmercamel_amd: all-to-all callback failed: %r" % (e,), flush=True)
+                return 1
+
+        def ag(user, inp, out, nbytes):
+            try:
+                n = int(nbytes)
+                dist.all_gather_into_tensor(view(out, n * world), view(inp, n), group=group)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("kmercamel_amd: all-gather callback failed: %r" % (e,), flush=True)
+                return 1
+
+        fa, fg = _A2A_FN(a2a), _AG_FN(ag)
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.kc_comm_create_callbacks(ctx.h, rank, world, ctypes.cast(fa, ctypes.c_void_p), ctypes.cast(fg, ctypes.c_void_p), None,
+                                                   ctypes.byref(h)))
+        return cls(ctx, h, rank, world, keep=(fa, fg))
+
+    def stats(self):
+        st = (ctypes.c_uint64 * 8)()
+        self.ctx.check(self.ctx.lib.kc_comm_stats(self.h, st))
+        return {"bytes_sent": st[0], "bytes_received": st[1], "calls": st[2], "us_in_collectives": st[3]}
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.kc_comm_destroy(self.h)
+            self.h = None
+
+
+def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length=None):
+    """kc_compute_sharded: collective over comm's ranks; `seq` = THIS rank's records joined by '\\n' (may be empty).
+    The ComputeResult holds this rank's slice of the one masked superstring (see .slice(), .array())."""
+    flags = FLAG_COMPLEMENTS if complements else 0
+    h = ctypes.c_void_p()
+    if device_ptr is not None:
+        flags |= FLAG_INPUT_ON_DEVICE
+        ctx.check(ctx.lib.kc_compute_sharded(ctx.h, comm.h, ctypes.c_void_p(device_ptr), length, k, flags, ctypes.byref(h)))
+    else:
+        ptr, n, _keep = _host_bytes(seq)
+        ctx.check(ctx.lib.kc_compute_sharded(ctx.h, comm.h, ptr, n, k, flags, ctypes.byref(h)))
     return ComputeResult(ctx, h)
 
 

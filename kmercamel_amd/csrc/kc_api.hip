@@ -158,6 +158,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     }
     KC_HIP(ctx, hipEventRecord(eend, ctx->stream));
     KC_HIP(ctx, hipEventSynchronize(eend));
+    r->slice_off = 0; r->slice_len = r->length;
     if (rc == KC_OK) {
         r->stats[0] = n_kmers; r->stats[1] = S; r->stats[2] = r->length; r->stats[5] = rounds;
         r->stats[6] = (u64)(1000.0 * ev_ms(e0, e1)); r->stats[7] = (u64)(1000.0 * ev_ms(e1, e2));
@@ -191,9 +192,15 @@ extern "C" int kc_result_copy(kc_result *r, char *out, char *mask_out) {
     if (!r || !out) return KC_E_ARG;
     kc_ctx *ctx = r->ctx;
     KC_HIP(ctx, hipSetDevice(ctx->device));
-    KC_HIP(ctx, hipMemcpyAsync(out, r->d_out, r->length, hipMemcpyDeviceToHost, ctx->stream));
-    if (mask_out && r->d_mask) KC_HIP(ctx, hipMemcpyAsync(mask_out, r->d_mask, r->length, hipMemcpyDeviceToHost, ctx->stream));
+    if (r->slice_len) KC_HIP(ctx, hipMemcpyAsync(out, r->d_out, r->slice_len, hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_out && r->d_mask && r->slice_len) KC_HIP(ctx, hipMemcpyAsync(mask_out, r->d_mask, r->slice_len, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+extern "C" int kc_result_slice(kc_result *r, uint64_t *offset, uint64_t *slice_len) {
+    if (!r) return KC_E_ARG;
+    if (offset) *offset = r->slice_off;
+    if (slice_len) *slice_len = r->slice_len;
     return KC_OK;
 }
 extern "C" void kc_result_destroy(kc_result *r) {

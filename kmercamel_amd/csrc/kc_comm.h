@@ -1,0 +1,39 @@
+// Rank-to-rank exchange layer of the hash-sharded path (one process per GPU).  Not part of the ABI.
+//
+// The sharded pipeline (kc_shard.hip) needs exactly two collectives, neither of them a reduction over the data path:
+//   * all-to-all(v) of device buffers (k-mer buckets, neighbour queries and their answers, chain-fragment pointers,
+//     packed bases on their way to the rank that emits them): every rank sends a different byte range to every peer;
+//   * all-gather of a few host words per rank (counts, flags).
+// Back ends: RCCL (grouped ncclSend/ncclRecv on the context's stream -- over xGMI every peer pair has its own link, so
+// the 7 sends of a rank run concurrently), host callbacks (the caller moves host bytes: torch.distributed/gloo in the
+// tests, MPI elsewhere; device buffers are staged through pinned memory), and the trivial single-rank one.
+#pragma once
+#include "kc_internal.h"
+
+struct kc_comm {
+    kc_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    int kind = 0;   // 0 self, 1 host callbacks, 2 RCCL
+    // host callbacks
+    kc_alltoallv_host_fn a2a_host = nullptr;
+    kc_allgather_host_fn ag_host = nullptr;
+    void *user = nullptr;
+    u8 *stage_send = nullptr, *stage_recv = nullptr;   // pinned
+    size_t stage_send_bytes = 0, stage_recv_bytes = 0;
+    // RCCL
+    void *nccl_comm = nullptr;
+    u64 *d_small = nullptr;   // device scratch for the host-word all-gather
+    // statistics
+    u64 bytes_sent = 0, bytes_received = 0, calls = 0;
+    double seconds = 0;
+};
+
+// All counts / offsets in BYTES, arrays of `world` entries (host).  Send ranges may overlap (an all-gather is an
+// all-to-all whose send ranges coincide).  Enqueued on ctx->stream; returns after the data has arrived for the host
+// back ends, asynchronously for RCCL (stream order).
+int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64 *send_cnt, void *d_recv, const u64 *recv_off, const u64 *recv_cnt);
+// out[world * words] <- every rank's in[words] (host, synchronous)
+int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words);
+// convenience: element-wise sum / max over ranks of a few host words
+int kcc_allreduce_sum(kc_comm *c, u64 *vals, int words);
+int kcc_allreduce_max(kc_comm *c, u64 *vals, int words);

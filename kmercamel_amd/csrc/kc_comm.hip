@@ -1,0 +1,203 @@
+// Exchange layer of the hash-sharded path: see kc_comm.h.  RCCL is reached through dlopen, so that single-GPU users
+// (the CLI measures process wall time) never load it.
+#include "kc_comm.h"
+#include <chrono>
+#include <dlfcn.h>
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- RCCL entry points (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclSend/ncclRecv, ncclGroupStart/End, ncclAllGather)
+struct NcclId { char internal[128]; };
+typedef int (*fn_get_id)(NcclId *);
+typedef int (*fn_init_rank)(void **, int, NcclId, int);
+typedef int (*fn_destroy)(void *);
+typedef int (*fn_sendrecv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_group)();
+typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*fn_errstr)(int);
+struct Rccl {
+    void *lib = nullptr;
+    fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_destroy destroy = nullptr;
+    fn_sendrecv send = nullptr, recv = nullptr; fn_group group_start = nullptr, group_end = nullptr;
+    fn_allgather allgather = nullptr; fn_errstr errstr = nullptr;
+    bool load(std::string &err) {
+        if (lib) return true;
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+        get_id = (fn_get_id)dlsym(lib, "ncclGetUniqueId"); init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
+        destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy"); send = (fn_sendrecv)dlsym(lib, "ncclSend"); recv = (fn_sendrecv)dlsym(lib, "ncclRecv");
+        group_start = (fn_group)dlsym(lib, "ncclGroupStart"); group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
+        allgather = (fn_allgather)dlsym(lib, "ncclAllGather"); errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
+        if (!get_id || !init_rank || !destroy || !send || !recv || !group_start || !group_end || !allgather) { err = "librccl.so lacks an expected symbol"; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+const int kNcclUint8 = 1;   // ncclUint8 (rccl.h ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1)
+
+int nccl_fail(kc_ctx *ctx, const char *what, int rc) {
+    return kc_fail(ctx, KC_E_NO_DEVICE, std::string(what) + ": RCCL error " + std::to_string(rc) + (g_rccl.errstr ? std::string(" (") + g_rccl.errstr(rc) + ")" : ""));
+}
+
+int ensure_stage(kc_comm *c, size_t send_bytes, size_t recv_bytes) {
+    kc_ctx *ctx = c->ctx;
+    if (send_bytes > c->stage_send_bytes) {
+        if (c->stage_send) (void)hipHostFree(c->stage_send);
+        c->stage_send = nullptr; c->stage_send_bytes = 0;
+        size_t want = send_bytes + send_bytes / 4 + 4096;
+        KC_HIP(ctx, hipHostMalloc((void **)&c->stage_send, want, hipHostMallocDefault));
+        c->stage_send_bytes = want;
+    }
+    if (recv_bytes > c->stage_recv_bytes) {
+        if (c->stage_recv) (void)hipHostFree(c->stage_recv);
+        c->stage_recv = nullptr; c->stage_recv_bytes = 0;
+        size_t want = recv_bytes + recv_bytes / 4 + 4096;
+        KC_HIP(ctx, hipHostMalloc((void **)&c->stage_recv, want, hipHostMallocDefault));
+        c->stage_recv_bytes = want;
+    }
+    return KC_OK;
+}
+
+}  // namespace
+
+int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64 *send_cnt, void *d_recv, const u64 *recv_off, const u64 *recv_cnt) {
+    kc_ctx *ctx = c->ctx;
+    const double t0 = now_s();
+    const int G = c->world;
+    u64 tot_s = 0, tot_r = 0;
+    for (int p = 0; p < G; ++p) { tot_s += send_cnt[p]; tot_r += recv_cnt[p]; }
+    c->bytes_sent += tot_s - send_cnt[c->rank]; c->bytes_received += tot_r - recv_cnt[c->rank]; ++c->calls;
+    int rc = KC_OK;
+    if (c->kind == 0) {
+        if (send_cnt[0] != recv_cnt[0]) return kc_fail(ctx, KC_E_ARG, "self exchange with unequal counts");
+        if (send_cnt[0]) KC_HIP(ctx, hipMemcpyAsync((u8 *)d_recv + recv_off[0], (const u8 *)d_send + send_off[0], send_cnt[0], hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (c->kind == 1) {
+        // device -> pinned (packed in rank order) -> caller's transport -> pinned -> device
+        KC_TRY(ensure_stage(c, tot_s, tot_r));
+        u64 o = 0;
+        for (int p = 0; p < G; ++p) {
+            if (send_cnt[p]) KC_HIP(ctx, hipMemcpyAsync(c->stage_send + o, (const u8 *)d_send + send_off[p], send_cnt[p], hipMemcpyDeviceToHost, ctx->stream));
+            o += send_cnt[p];
+        }
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (c->a2a_host(c->user, c->stage_send, send_cnt, c->stage_recv, recv_cnt) != 0) return kc_fail(ctx, KC_E_NO_DEVICE, "the all-to-all callback failed");
+        o = 0;
+        for (int p = 0; p < G; ++p) {
+            if (recv_cnt[p]) KC_HIP(ctx, hipMemcpyAsync((u8 *)d_recv + recv_off[p], c->stage_recv + o, recv_cnt[p], hipMemcpyHostToDevice, ctx->stream));
+            o += recv_cnt[p];
+        }
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        int e = g_rccl.group_start();
+        if (e) return nccl_fail(ctx, "ncclGroupStart", e);
+        for (int p = 0; p < G && !e; ++p) {
+            if (send_cnt[p]) e = g_rccl.send(const_cast<u8 *>((const u8 *)d_send + send_off[p]), send_cnt[p], kNcclUint8, p, c->nccl_comm, ctx->stream);
+            if (!e && recv_cnt[p]) e = g_rccl.recv((u8 *)d_recv + recv_off[p], recv_cnt[p], kNcclUint8, p, c->nccl_comm, ctx->stream);
+        }
+        int e2 = g_rccl.group_end();
+        if (e || e2) rc = nccl_fail(ctx, "grouped ncclSend/ncclRecv", e ? e : e2);
+    }
+    c->seconds += now_s() - t0;
+    return rc;
+}
+
+int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
+    kc_ctx *ctx = c->ctx;
+    const double t0 = now_s();
+    ++c->calls;
+    int rc = KC_OK;
+    if (c->kind == 0) memcpy(out, in, (size_t)words * 8);
+    else if (c->kind == 1) {
+        if (c->ag_host(c->user, in, out, (u64)words * 8) != 0) rc = kc_fail(ctx, KC_E_NO_DEVICE, "the all-gather callback failed");
+    } else {
+        if (words > 64) return kc_fail(ctx, KC_E_ARG, "all-gather of more than 64 words");
+        u64 *d_in = c->d_small, *d_out = c->d_small + 64;
+        KC_HIP(ctx, hipMemcpyAsync(d_in, in, (size_t)words * 8, hipMemcpyHostToDevice, ctx->stream));
+        int e = g_rccl.allgather(d_in, d_out, (size_t)words * 8, kNcclUint8, c->nccl_comm, ctx->stream);
+        if (e) return nccl_fail(ctx, "ncclAllGather", e);
+        KC_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)words * 8 * c->world, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    c->seconds += now_s() - t0;
+    return rc;
+}
+
+int kcc_allreduce_sum(kc_comm *c, u64 *vals, int words) {
+    std::vector<u64> all((size_t)words * c->world);
+    KC_TRY(kcc_allgather_words(c, vals, all.data(), words));
+    for (int w = 0; w < words; ++w) { u64 s = 0; for (int p = 0; p < c->world; ++p) s += all[(size_t)p * words + w]; vals[w] = s; }
+    return KC_OK;
+}
+int kcc_allreduce_max(kc_comm *c, u64 *vals, int words) {
+    std::vector<u64> all((size_t)words * c->world);
+    KC_TRY(kcc_allgather_words(c, vals, all.data(), words));
+    for (int w = 0; w < words; ++w) { u64 s = 0; for (int p = 0; p < c->world; ++p) s = all[(size_t)p * words + w] > s ? all[(size_t)p * words + w] : s; vals[w] = s; }
+    return KC_OK;
+}
+
+extern "C" int kc_comm_create_self(kc_ctx *ctx, kc_comm **out) {
+    if (!ctx || !out) return KC_E_ARG;
+    kc_comm *c = new kc_comm();
+    c->ctx = ctx; c->rank = 0; c->world = 1; c->kind = 0;
+    *out = c;
+    return KC_OK;
+}
+
+extern "C" int kc_comm_create_callbacks(kc_ctx *ctx, int rank, int world, kc_alltoallv_host_fn alltoallv, kc_allgather_host_fn allgather, void *user,
+                                        kc_comm **out) {
+    if (!ctx || !out || !alltoallv || !allgather || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
+    if (world > 64) return kc_fail(ctx, KC_E_ARG, "at most 64 ranks");
+    kc_comm *c = new kc_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 1;
+    c->a2a_host = alltoallv; c->ag_host = allgather; c->user = user;
+    *out = c;
+    return KC_OK;
+}
+
+extern "C" int kc_rccl_unique_id(void *id128) {
+    if (!id128) return KC_E_ARG;
+    std::string err;
+    if (!g_rccl.load(err)) return KC_E_NO_DEVICE;
+    NcclId id;
+    if (g_rccl.get_id(&id) != 0) return KC_E_NO_DEVICE;
+    memcpy(id128, id.internal, 128);
+    return KC_OK;
+}
+
+extern "C" int kc_comm_create_rccl(kc_ctx *ctx, int rank, int world, const void *id128, kc_comm **out) {
+    if (!ctx || !out || !id128 || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
+    if (world > 64) return kc_fail(ctx, KC_E_ARG, "at most 64 ranks");
+    std::string err;
+    if (!g_rccl.load(err)) return kc_fail(ctx, KC_E_NO_DEVICE, err);
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    NcclId id;
+    memcpy(id.internal, id128, 128);
+    void *comm = nullptr;
+    int e = g_rccl.init_rank(&comm, world, id, rank);
+    if (e) return nccl_fail(ctx, "ncclCommInitRank", e);
+    kc_comm *c = new kc_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 2; c->nccl_comm = comm;
+    if (kc_alloc(ctx, &c->d_small, 64 + 64 * 64) != KC_OK) { (void)g_rccl.destroy(comm); delete c; return KC_E_NO_DEVICE; }
+    *out = c;
+    return KC_OK;
+}
+
+extern "C" void kc_comm_destroy(kc_comm *c) {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->stage_send) (void)hipHostFree(c->stage_send);
+    if (c->stage_recv) (void)hipHostFree(c->stage_recv);
+    if (c->d_small) kc_release(c->ctx, c->d_small);
+    if (c->nccl_comm) (void)g_rccl.destroy(c->nccl_comm);
+    delete c;
+}
+
+extern "C" int kc_comm_stats(kc_comm *c, uint64_t *stats) {
+    if (!c || !stats) return KC_E_ARG;
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    stats[0] = c->bytes_sent; stats[1] = c->bytes_received; stats[2] = c->calls; stats[3] = (u64)(c->seconds * 1e6);
+    return KC_OK;
+}

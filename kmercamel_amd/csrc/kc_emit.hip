@@ -43,12 +43,17 @@ __global__ void __launch_bounds__(256) em_rank_step_kernel(const u64 *__restrict
 // one wavefront per vertex on the start path
 __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ words, const u64 *__restrict__ woff,
                                                       const u64 *__restrict__ lens, u64 S, u64 V, int k, const u64 *__restrict__ dist,
-                                                      const u64 *__restrict__ endv, const u64 *__restrict__ weight, u64 start, char *out) {
+                                                      const u64 *__restrict__ endv, const u64 *__restrict__ weight, u64 start, char *out,
+                                                      u64 out_lo, int nranks, int me) {
+    // nranks > 1 (hash-sharded flow): this rank emits the vertices whose block starts in its share of the output, into a
+    // buffer that begins at output offset out_lo
     u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     int lane = threadIdx.x & 63;
     if (v >= V) return;
     if (endv[v] != endv[start]) return;
     u64 off = dist[start] - dist[v];
+    if (nranks > 1 && (int)(((unsigned __int128)off * (unsigned)nranks) / dist[start]) != me) return;
+    off -= out_lo;
     u64 sidx = v < S ? v : v - S;
     bool rc = v >= S;
     u64 L = lens[sidx], wb = woff[sidx], n = weight[v];
@@ -94,11 +99,12 @@ __global__ void __launch_bounds__(256) em_mask_kernel(const char *__restrict__ o
     mask[p] = in ? (char)(c - ('a' - 'A')) : c;
 }
 
-int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc_set *set_for_mask, char **d_out, char **d_mask, u64 *length) {
+// weighted list ranking of the path: dist[v] = characters from v's block to the end of its path, endv[v] = last vertex of
+// v's path, weight[v] = characters v contributes; start = smallest vertex without in-edge; L = dist[start]
+int kce_rank_path(kc_simplitigs *s, const KcPathDev *path, KcRank *r) {
     kc_ctx *ctx = s->ctx;
     KcScope scope(ctx);
     const u64 S = s->n, V = path->V;
-    const int k = s->k;
     u64 *pred = nullptr, *start = nullptr, *nxt, *dist, *endv, *nxt2, *dist2, *endv2, *weight;
     KC_TRY(scope.alloc(&pred, V)); KC_TRY(scope.alloc(&start, 2));
     KC_TRY(scope.alloc(&nxt, V)); KC_TRY(scope.alloc(&dist, V)); KC_TRY(scope.alloc(&endv, V));
@@ -123,25 +129,50 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
     u64 L = 0;
     KC_HIP(ctx, hipMemcpyAsync(&L, dist + h_start, 8, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    char *out = nullptr, *mask = nullptr;
-    KC_TRY(kc_alloc(ctx, &out, L + 1));
+    scope.keep(dist); scope.keep(endv); scope.keep(weight);
+    r->V = V; r->dist = dist; r->endv = endv; r->weight = weight; r->start = h_start; r->L = L;
+    return KC_OK;
+}
+void kce_rank_release(kc_ctx *ctx, KcRank *r) {
+    kc_release(ctx, r->dist); kc_release(ctx, r->endv); kc_release(ctx, r->weight);
+    r->dist = r->endv = r->weight = nullptr;
+}
+// spell the blocks of the start path into `out` (which begins at output offset out_lo; nranks > 1: only this rank's blocks)
+int kce_emit_ranked(kc_simplitigs *s, const KcRank *r, u64 out_lo, int nranks, int me, char *out) {
+    kc_ctx *ctx = s->ctx;
+    const u64 V = r->V, L = r->L;
     unsigned slices = 1;   // waves per vertex: ~8192 characters each on average, at most 256
     if (V && L / V > 16384) { u64 y = L / V / 8192; slices = (unsigned)(y > 256 ? 256 : y); }
     hipLaunchKernelGGL(em_emit_kernel, dim3(kc_grid(V * 64, 256), slices), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
-                       (const u64 *)s->lens, S, V, k, (const u64 *)dist, (const u64 *)endv, (const u64 *)weight, h_start, out);
-    if (d_mask && set_for_mask) {
-        KC_TRY(kc_alloc(ctx, &mask, L + 1));
-        unsigned gm = kc_grid(L, 256);
-        switch (set_for_mask->W) {
-            case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<1>(set_for_mask), mask); break;
-            case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<2>(set_for_mask), mask); break;
-            default: hipLaunchKernelGGL((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<4>(set_for_mask), mask); break;
+                       (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
+    KC_HIP(ctx, hipGetLastError());
+    return KC_OK;
+}
+
+int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc_set *set_for_mask, char **d_out, char **d_mask, u64 *length) {
+    kc_ctx *ctx = s->ctx;
+    const int k = s->k;
+    KcRank rk;
+    KC_TRY(kce_rank_path(s, path, &rk));
+    const u64 L = rk.L;
+    char *out = nullptr, *mask = nullptr;
+    int rc = kc_alloc(ctx, &out, L + 1);
+    if (rc == KC_OK) rc = kce_emit_ranked(s, &rk, 0, 1, 0, out);
+    if (rc == KC_OK && d_mask && set_for_mask) {
+        rc = kc_alloc(ctx, &mask, L + 1);
+        if (rc == KC_OK) {
+            unsigned gm = kc_grid(L, 256);
+            switch (set_for_mask->W) {
+                case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<1>(set_for_mask), mask); break;
+                case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<2>(set_for_mask), mask); break;
+                default: hipLaunchKernelGGL((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<4>(set_for_mask), mask); break;
+            }
+            if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "mask kernel launch failed");
         }
     }
-    KC_HIP(ctx, hipGetLastError());
-    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    void *rel[] = {pred, start, nxt, dist, endv, nxt2, dist2, endv2, weight};
-    for (void *p : rel) scope.release(p);
+    (void)hipStreamSynchronize(ctx->stream);
+    kce_rank_release(ctx, &rk);
+    if (rc != KC_OK) { kc_release(ctx, out); kc_release(ctx, mask); return rc; }
     *d_out = out;
     if (d_mask) *d_mask = mask;
     *length = L;

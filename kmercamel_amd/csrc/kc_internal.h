@@ -48,13 +48,17 @@ struct kc_set {
     u32 *counts = nullptr; // cap entries, only while counting occurrences for -z
     u64 *counters = nullptr;  // device: [0] size, [1] overflow flag
     u64 size_host = 0;
+    u64 rlo = 0, rcap = 0;   // hash-sharded sets: the global slots [rlo, rlo + rcap) live here (rcap == 0: all of them); keys / state / tags / counts
+                             // are then LOCAL arrays of rcap entries
     mutable bool unclean = false;   // table allocated but not filled with EMPTY yet (a bucketed build of a fresh set overwrites every
                                     // slot, so the 9 B/slot fill is deferred until something else needs the table)
 };
 int kcs_clean_table(const kc_set *s);   // kc_set.hip
 
 template <int W> static inline SetView<W> kc_view_raw(const kc_set *s) {
-    return SetView<W>{s->keys, s->state, s->tags, s->cap, s->nblocks, s->bshift, s->mlen, s->k, s->local_probes};
+    const u64 rcap = s->rcap ? s->rcap : s->cap;
+    return SetView<W>{s->keys - s->rlo * W, s->state ? s->state - s->rlo : nullptr, s->tags - s->rlo, s->cap, s->nblocks, s->bshift, s->mlen, s->k,
+                      s->local_probes, s->rlo, rcap};
 }
 // every kernel reaches the table through a view: this is where a deferred fill happens
 template <int W> static inline SetView<W> kc_view(const kc_set *s) {
@@ -75,8 +79,9 @@ struct kc_simplitigs {
 
 struct kc_result {
     kc_ctx *ctx = nullptr;
-    char *d_out = nullptr, *d_mask = nullptr;
-    u64 length = 0;
+    char *d_out = nullptr, *d_mask = nullptr;   // the slice [slice_off, slice_off + slice_len) of the superstring (single GPU: all of it)
+    u64 length = 0;                              // length of the whole superstring
+    u64 slice_off = 0, slice_len = 0;
     u64 stats[16] = {0};
 };
 
@@ -142,12 +147,29 @@ struct KcScope {
 static inline unsigned kc_grid(u64 n, unsigned block) { u64 g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
 static inline unsigned kc_grid8(u64 n, unsigned block) { u64 g = (n + block - 1) / block; g = (g + 7) / 8 * 8; return (unsigned)(g ? g : 8); }  // for kc_xcd_block_id()
 
+// ---- kc_util.hip: scan / ordered compaction / sharded lists / message routing (hand-written, no library calls) ----
+int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n);   // out[0..n], out[n] = total; out may alias in
+int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *out, u64 *d_total);   // stable
+int kcu_compact_shards(kc_ctx *ctx, const u64 *src, u64 shard_cap, const u64 *d_cursors, int nshards, int stride, int E, u64 *dst, u64 *total, bool *overflow);
+struct kc_comm;
+struct KcRoute {
+    u64 n = 0, n_recv = 0;
+    u64 *perm = nullptr;                      // device: send position -> item
+    std::vector<u64> scnt, soff, rcnt, roff;  // items per peer
+};
+int kcr_build(kc_comm *c, const u8 *dest, u64 n, KcRoute *r);
+void kcr_free(kc_ctx *ctx, KcRoute *r);
+int kcr_forward(kc_comm *c, const KcRoute &r, const u64 *items, int E, int stride, u64 **recv_out);
+int kcr_backward(kc_comm *c, const KcRoute &r, const u64 *answers, int A, u64 *out);
+
 // ---- cross-TU host entry points (each dispatches on W internally) ----
 // kc_set.hip
 int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk, u64 **d_low);
 int kcs_reserve(kc_set *set, u64 additional);
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive);
 int kcs_refresh_size(kc_set *set);
+int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out);   // collective
+int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved_bytes);   // collective
 // kc_simplitigs.hip
 int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds);
 int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 len, const u64 *h_offsets, u64 n, int offsets_are_host_positions,
@@ -159,5 +181,9 @@ struct KcPathDev { u64 V = 0; u64 *edge_from = nullptr; u8 *overlaps = nullptr; 
 int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out);
 void kco_path_release(kc_ctx *ctx, KcPathDev *p);
 // kc_emit.hip
+struct KcRank { u64 V = 0; u64 *dist = nullptr, *endv = nullptr, *weight = nullptr; u64 start = 0, L = 0; };
+int kce_rank_path(kc_simplitigs *s, const KcPathDev *path, KcRank *r);
+void kce_rank_release(kc_ctx *ctx, KcRank *r);
+int kce_emit_ranked(kc_simplitigs *s, const KcRank *r, u64 out_lo, int nranks, int me, char *out);
 int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc_set *set_for_mask, char **d_out, char **d_mask, u64 *length);
 int kce_maskopt(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out);

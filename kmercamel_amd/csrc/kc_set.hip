@@ -4,6 +4,7 @@
 // stream (each thread reads its own few words, neighbouring lanes read neighbouring words), the cost is the random
 // 8-byte (W*8-byte) slot access of the insert.
 #include "kc_internal.h"
+#include "kc_comm.h"
 
 // ------------------------------------------------------------------------------------------------- pool / ctx
 hipError_t KcPool::alloc(void **out, size_t bytes) {
@@ -247,7 +248,10 @@ template <int W>
 __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk,
                                                                 const u64 *__restrict__ low, u64 len, int k, int complements,
                                                                 int case_sensitive, SetView<W> set, u64 *bucket, u64 *bcursor, u64 *counters,
-                                                                int ppt, u32 stage_cap) {
+                                                                int ppt, u32 stage_cap, const u64 *__restrict__ boff, int count_only) {
+    // boff == nullptr: one bucket of 2^bshift entries per block (single GPU).  Otherwise (hash-sharded build) the kernel runs
+    // twice: count_only = 1 adds the run lengths to bcursor[block]; then, with boff = exclusive scan of those counts and the
+    // cursors cleared, the keys land at boff[block] + position -- grouped by block, hence contiguous per owner rank.
     extern __shared__ u32 kc_ring[];
     const int win = k - set.m + 1;
     u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)2 * win * blockDim.x);   // stage[(j * W + w) * blockDim + tid]: keys of the open run
@@ -257,7 +261,14 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
     bool overflow = false;
     auto flush = [&]() {
         if (!nrun) return;
+        if (count_only) { atomicAdd((ull *)&bcursor[run_blk], (ull)nrun); nrun = 0; return; }
         const u64 base = atomicAdd((ull *)&bcursor[run_blk], (ull)nrun);
+        if (boff) {
+            u64 *dst = bucket + (boff[run_blk] + base) * W;
+            for (u32 j = 0; j < nrun * W; ++j) dst[j] = stage[j * blockDim.x + threadIdx.x];
+            nrun = 0;
+            return;
+        }
         // a bucket that overflows keeps the part of the run that still fits (so that its first `bs` entries are all real
         // keys for the build kernel) and raises the flag: the caller then re-inserts the whole input through the global path
         u32 fit = nrun;
@@ -270,7 +281,8 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
         const u64 blk = set_block_home(set, mmh, 0) >> set.bshift;
         if (nrun && (blk != run_blk || nrun == stage_cap)) flush();   // (a run longer than the staging area is reserved in pieces)
         run_blk = blk;
-        for (int w = 0; w < W; ++w) stage[(nrun * W + w) * blockDim.x + threadIdx.x] = key.w[w];
+        if (!count_only)
+            for (int w = 0; w < W; ++w) stage[(nrun * W + w) * blockDim.x + threadIdx.x] = key.w[w];
         ++nrun;
     });
     flush();
@@ -281,16 +293,30 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
 // by an LDS compare-and-swap on its MOST significant key word (never all ones: 2k < 64 W), then the other words and
 // finally the tag byte are written; a lane that finds "its" top word in an unpublished slot looks again in its next loop
 // iteration (nobody waits inside an iteration, so lanes of one wave cannot block each other).
+#define KC_MAX_SEG 64
 template <int W>
 __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
-                                                              int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap) {
+                                                              int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap,
+                                                              const u64 *__restrict__ seg_scan, int nseg) {
+    // nseg == 0: the block's keys are bucket[block * 2^bshift ...], bcursor[block] of them (single GPU).  nseg > 0 (hash-sharded
+    // build): the block is LOCAL block blockIdx.x of this rank's range and its keys arrived in nseg segments, one per source
+    // rank: segment q = bucket[seg_scan[q * gridDim.x + block] .. seg_scan[q * gridDim.x + block + 1]).
     extern __shared__ u64 kc_blk[];
+    __shared__ u64 seg_lo[KC_MAX_SEG], seg_pre[KC_MAX_SEG + 1];
     const u32 bs = 1u << set.bshift;
     u64 *lk = kc_blk;
     volatile u8 *lt = reinterpret_cast<volatile u8 *>(kc_blk + (size_t)bs * W);
     __shared__ u32 added_s;
-    const u64 base = (u64)blockIdx.x << set.bshift;
-    if (threadIdx.x == 0) added_s = 0;
+    const u64 base = set.rlo + ((u64)blockIdx.x << set.bshift);
+    if (threadIdx.x == 0) {
+        added_s = 0;
+        u64 a = 0;
+        for (int q = 0; q < nseg; ++q) {
+            const u64 lo = seg_scan[(u64)q * gridDim.x + blockIdx.x], hi = seg_scan[(u64)q * gridDim.x + blockIdx.x + 1];
+            seg_lo[q] = lo; seg_pre[q] = a; a += hi - lo;
+        }
+        seg_pre[nseg] = a;
+    }
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
         reinterpret_cast<u64 *>(const_cast<u8 *>(lt))[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
     __syncthreads();
@@ -300,13 +326,20 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         lk[i] = occupied ? set.keys[base * W + i] : ~(u64)0;
     }
     __syncthreads();
-    u64 n = bcursor[blockIdx.x];
-    if (n > bs) n = bs;   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
+    u64 n;
+    if (nseg) n = seg_pre[nseg];
+    else { n = bcursor[blockIdx.x]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
     const u32 span = set_block_span(set);
     u32 added = 0;
     for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
         Key<W> key;
-        for (int w = 0; w < W; ++w) key.w[w] = bucket[(base + j) * W + w];
+        u64 src = base + j;
+        if (nseg) {
+            int q = 0;
+            while (q + 1 < nseg && j >= seg_pre[q + 1]) ++q;
+            src = seg_lo[q] + (j - seg_pre[q]);
+        }
+        for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
         const u64 top = key.w[W - 1];
         const u64 ph = key_place_hash(key);
         const u32 off = (u32)(((u64)(u32)ph * span) >> 32);
@@ -343,7 +376,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
     if (W > 1)
         for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
-    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.cap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at cap
+    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at the end of the range
     if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
 }
 
@@ -411,7 +444,7 @@ static int set_alloc_table(kc_set *set, u64 cap, u64 **keys, u32 **state, u8 **t
 int kcs_clean_table(const kc_set *s) {
     if (!s->unclean) return KC_OK;
     s->unclean = false;
-    return set_fill_table(s->ctx, s->W, s->cap, s->keys, s->state, s->tags);
+    return set_fill_table(s->ctx, s->W, s->rcap ? s->rcap : s->cap, s->keys, s->state, s->tags);
 }
 
 static int bucketed_max_bshift(int W) { return W == 1 ? 14 : (W == 2 ? 13 : 12); }
@@ -575,7 +608,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
         scatter_attr_done = true;
     }
     hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
-                       set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap);
+                       set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
     const size_t lds_build = (size_t)bs * (8 * W + 1);
     static bool attr_done = false;
     if (!attr_done) {
@@ -586,7 +619,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
     set->unclean = false;                        // the build kernel writes every slot, state and tag of every block
     hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                       (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap);
+                       (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0);
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -612,6 +645,134 @@ static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, co
         case 1: return insert_bucketed_w<1>(set, d_codes, d_brk, d_low, len, case_sensitive);
         case 2: return insert_bucketed_w<2>(set, d_codes, d_brk, d_low, len, case_sensitive);
         default: return insert_bucketed_w<4>(set, d_codes, d_brk, d_low, len, case_sensitive);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- hash-sharded set
+// The table geometry (block size, minimizer length, load) is that of kc_set_create for the TOTAL number of occurrences;
+// the number of blocks is rounded up to a multiple of the world size and rank r owns blocks [r * bpr, (r + 1) * bpr).
+int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out) {
+    *out = nullptr;
+    if (k < 16) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs k >= 16 (minimizer blocks)");
+    u64 occ = occ_local;
+    KC_TRY(kcc_allreduce_sum(c, &occ, 1));
+    kc_set *s = new kc_set();
+    s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
+    s->mlen = 15;
+    s->bshift = s->W == 4 ? 12 : 13;
+    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= bucketed_max_bshift(s->W)) s->bshift = v; }
+    if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
+    if (s->local_probes + 8 >= ((u32)1 << s->bshift) / 2) s->local_probes = ((u32)1 << s->bshift) / 4;
+    double load = 0.5;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+        double per_slot = 8.0 * s->W + 1 + (s->W > 1 ? 4 : 0) + 16 + 8;
+        double need = (double)occ / c->world / load * per_slot + (double)occ / c->world * (16.0 * s->W + 60);
+        if (total_b && need > 0.6 * (double)total_b) load = 0.66;
+    }
+    if (const char *e = getenv("KC_LOAD")) { double v = atof(e); if (v >= 0.2 && v <= 0.9) load = v; }
+    const u64 bs = (u64)1 << s->bshift;
+    u64 cap = (u64)((double)occ / load) + 1024;
+    u64 nblocks = (cap + bs - 1) >> s->bshift;
+    nblocks = (nblocks + c->world - 1) / c->world * c->world;
+    const u64 bpr = nblocks / c->world;
+    s->nblocks = nblocks; s->cap = nblocks << s->bshift;
+    s->rcap = bpr << s->bshift; s->rlo = (u64)c->rank * s->rcap;
+    int rc = kc_alloc(ctx, &s->keys, s->rcap * s->W);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->tags, s->rcap + 8);
+    if (rc == KC_OK && s->W != 1) rc = kc_alloc(ctx, &s->state, s->rcap);
+    s->unclean = true;
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 4);
+    if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    if (rc != KC_OK) { kc_set_destroy(s); return rc; }
+    *out = s;
+    return KC_OK;
+}
+
+// AddKMers over all ranks: count the occurrences per table block, lay the canonical k-mers out block by block (= owner by
+// owner), all-to-all the per-block counts and the keys, build every owned block in LDS from its `world` segments.
+template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved) {
+    kc_ctx *ctx = set->ctx;
+    KcScope scope(ctx);
+    const int G = c->world;
+    const u64 nblocks = set->nblocks, bpr = nblocks / G, bs = (u64)1 << set->bshift;
+    u64 *bcount = nullptr, *boff = nullptr, *bcur = nullptr, *bucket = nullptr, *rcounts = nullptr, *seg_scan = nullptr, *rkeys = nullptr, *ovf = nullptr;
+    KC_TRY(scope.alloc(&bcount, nblocks + 1)); KC_TRY(scope.alloc(&boff, nblocks + 1)); KC_TRY(scope.alloc(&bcur, nblocks + 1));
+    KC_HIP(ctx, hipMemsetAsync(bcount, 0, (nblocks + 1) * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(bcur, 0, (nblocks + 1) * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
+    const int win = set->k - set->mlen + 1;
+    const int ppt = W == 1 ? 16 : (W == 2 ? 32 : 64);
+    const u32 stage_cap = 8;
+    const unsigned tb = win <= 32 ? 256 : (win <= 64 ? 128 : 64);
+    const size_t lds_scatter = (size_t)win * tb * 4 * 2 + (size_t)stage_cap * W * tb * 8;
+    const u64 nthreads = (len + ppt - 1) / ppt;
+    if (lds_scatter > 64 * 1024)
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    const bool have = len >= (u64)set->k;
+    if (have)
+        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                           set->complements, 0, kc_view_raw<W>(set), (u64 *)nullptr, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 1);
+    KC_TRY(kcu_exclusive_scan(ctx, bcount, boff, nblocks));
+    std::vector<u64> h_off(nblocks + 1);
+    KC_HIP(ctx, hipMemcpyAsync(h_off.data(), boff, (nblocks + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const u64 occ_local = h_off[nblocks];
+    KC_TRY(scope.alloc(&bucket, occ_local * W + 1));
+    if (have)
+        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                           set->complements, 0, kc_view_raw<W>(set), bucket, bcur, set->counters, ppt, stage_cap, (const u64 *)boff, 0);
+    KC_HIP(ctx, hipGetLastError());
+    // exchange 1: the per-block counts of every owner's blocks
+    std::vector<u64> so(G), sc(G), ro(G), rcv(G);
+    KC_TRY(scope.alloc(&rcounts, (u64)G * bpr + 1));
+    for (int p = 0; p < G; ++p) { so[p] = (u64)p * bpr * 8; sc[p] = bpr * 8; ro[p] = (u64)p * bpr * 8; rcv[p] = bpr * 8; }
+    KC_TRY(kcc_alltoallv(c, bcount, so.data(), sc.data(), rcounts, ro.data(), rcv.data()));
+    // exchange 2: the keys themselves
+    std::vector<u64> totals(G), all((size_t)G * G);
+    for (int p = 0; p < G; ++p) totals[p] = h_off[(u64)(p + 1) * bpr] - h_off[(u64)p * bpr];
+    KC_TRY(kcc_allgather_words(c, totals.data(), all.data(), G));
+    u64 nrecv = 0;
+    for (int p = 0; p < G; ++p) {
+        so[p] = h_off[(u64)p * bpr] * W * 8; sc[p] = totals[p] * W * 8;
+        ro[p] = nrecv * W * 8; rcv[p] = all[(size_t)p * G + c->rank] * W * 8;
+        nrecv += all[(size_t)p * G + c->rank];
+    }
+    KC_TRY(scope.alloc(&rkeys, nrecv * W + 1));
+    KC_TRY(kcc_alltoallv(c, bucket, so.data(), sc.data(), rkeys, ro.data(), rcv.data()));
+    if (moved) *moved = (occ_local - totals[c->rank]) * W * 8;
+    KC_TRY(scope.alloc(&seg_scan, (u64)G * bpr + 2));
+    KC_TRY(kcu_exclusive_scan(ctx, rcounts, seg_scan, (u64)G * bpr));
+    scope.release(bucket);
+    // build the owned blocks
+    const u64 ovf_cap = (u64)1 << 20;
+    KC_TRY(scope.alloc(&ovf, ovf_cap * W));
+    const size_t lds_build = (size_t)bs * (8 * W + 1);
+    KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    set->unclean = false;
+    hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
+                       (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G);
+    KC_HIP(ctx, hipGetLastError());
+    u64 h[4] = {0, 0, 0, 0};
+    KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (getenv("KC_SET_TRACE"))
+        fprintf(stderr, "[set] rank %d/%d sharded build W=%d: %llu of %llu blocks (2^%d slots), %llu occurrences in, %llu received, size %llu, spills %llu\n", c->rank, G, W,
+                (unsigned long long)bpr, (unsigned long long)nblocks, set->bshift, (unsigned long long)occ_local, (unsigned long long)nrecv, (unsigned long long)h[0],
+                (unsigned long long)h[2]);
+    if (h[2] > ovf_cap) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded build: too many k-mers spilled out of their blocks");
+    if (h[2]) {
+        hipLaunchKernelGGL(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), (const u64 *)ovf, h[2], set->counters);
+        KC_HIP(ctx, hipGetLastError());
+    }
+    return kcs_refresh_size(set);
+}
+int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved) {
+    switch (set->W) {
+        case 1: return build_sharded_w<1>(set, c, d_codes, d_brk, d_low, len, moved);
+        case 2: return build_sharded_w<2>(set, c, d_codes, d_brk, d_low, len, moved);
+        default: return build_sharded_w<4>(set, c, d_codes, d_brk, d_low, len, moved);
     }
 }
 

@@ -30,6 +30,9 @@ template <int W> struct SetView {
     int m;          // minimizer length (0: plain hashing)
     int k;
     u32 local_probes;
+    // hash-sharded tables: this rank holds the global slots [rlo, rlo + rcap) (a whole number of blocks); the three pointers
+    // above are biased by -rlo so that they are indexed with GLOBAL slot numbers.  One GPU: rlo = 0, rcap = cap.
+    u64 rlo, rcap;
 };
 
 // `ph` below is always key_place_hash(key): its low 7 bits give the tag, the offset inside a block is a range reduction
@@ -75,8 +78,10 @@ template <int W> KC_HD u64 set_block_home(const SetView<W> &s, u32 mmh, u64 keyh
     u64 blk = ((u64)u * s.nblocks) >> 32;
     return (blk << s.bshift) | (((u64)(u32)keyhash * set_block_span(s)) >> 32);
 }
+// second, minimizer-independent home of an overfull block's keys: anywhere in the slot range of the rank that owns the
+// block (lookups of a key always run on that rank, so the range is the local one)
 template <int W> KC_HD u64 set_global_home(const SetView<W> &s, u64 keyhash) {
-    return kc_mulhi64(kc_mix64(keyhash ^ 0x6a09e667f3bcc909ULL), s.cap);
+    return s.rlo + kc_mulhi64(kc_mix64(keyhash ^ 0x6a09e667f3bcc909ULL), s.rcap);
 }
 template <int W> KC_HD u64 set_home_kh(const SetView<W> &s, const Key<W> &key, u64 keyhash) {
     if (s.m == 0) return kc_mulhi64(kc_mix64(keyhash), s.cap);
@@ -97,14 +102,14 @@ KC_HD u32 kc_mmer_rc(u32 f, int m) { return (u32)(kc_rc_word((u64)f) >> (64 - 2 
 // i-th slot of the probe sequence that starts at `home`
 template <int W> KC_HD u64 set_probe_slot(const SetView<W> &s, u64 home, u64 ghome, u64 i) {
     u64 p = (s.m != 0 && i >= s.local_probes) ? ghome + (i - s.local_probes) : home + i;
-    return p >= s.cap ? p - s.cap : p;
+    return p >= s.rlo + s.rcap ? p - s.rcap : p;
 }
 
 #if defined(__HIPCC__)
 // tag of a freshly inserted key; the first 8 tags are mirrored behind the table for set_scan's unaligned 8-byte loads
 template <int W> __device__ __forceinline__ void set_write_tag(const SetView<W> &s, u64 slot, u8 tag) {
     s.tags[slot] = tag;
-    if (slot < 8) s.tags[s.cap + slot] = tag;
+    if (slot - s.rlo < 8) s.tags[s.rcap + slot] = tag;
 }
 
 
@@ -118,7 +123,7 @@ template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, 
 // `home` = set_home_kh(s, key, kh) (callers that know the minimizer hash already pass set_block_home(...))
 template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, u64 kh, u64 home, u64 *slot_out) {
     const u64 ghome = set_global_home(s, kh);
-    const u64 limit = s.m ? s.cap + s.local_probes : s.cap;
+    const u64 limit = s.m ? s.rcap + s.local_probes : s.rcap;
     if constexpr (W == 1) {
         unsigned long long *keys = (unsigned long long *)s.keys;
         const unsigned long long kv = key.w[0];
@@ -176,7 +181,7 @@ template <int W> __device__ __forceinline__ u64 set_scan(const SetView<W> &s, co
     const u64 pat = 0x0101010101010101ULL * (u64)tag, hi7 = 0x8080808080808080ULL, lo7 = 0x7f7f7f7f7f7f7f7fULL;
     u64 pos = start;
     while (count) {
-        // 8 tags from `pos` on in one unaligned load (tags[cap..cap+7] mirror tags[0..7], so no wrap handling here)
+        // 8 tags from `pos` on in one unaligned load (the 8 tags behind the range mirror its first 8, so no wrap handling here)
         u64 word;
         __builtin_memcpy(&word, s.tags + pos, 8);
         u64 x = word ^ pat;
@@ -188,7 +193,7 @@ template <int W> __device__ __forceinline__ u64 set_scan(const SetView<W> &s, co
             int b = __builtin_ctzll(cand) >> 3;
             if ((empty >> (8 * b)) & 0x80) return KC_NONE64;
             u64 slot = pos + (u64)b;
-            if (slot >= s.cap) slot -= s.cap;
+            if (slot >= s.rlo + s.rcap) slot -= s.rcap;
             bool eq = true;
             for (int i = 0; i < W; ++i) eq = eq && (s.keys[slot * W + i] == key.w[i]);
             if (eq) return slot;
@@ -197,17 +202,17 @@ template <int W> __device__ __forceinline__ u64 set_scan(const SetView<W> &s, co
         if (count <= 8) break;
         count -= 8;
         pos += 8;
-        if (pos >= s.cap) pos -= s.cap;
+        if (pos >= s.rlo + s.rcap) pos -= s.rcap;
     }
     return KC_SCAN_MORE;
 }
 // `home` must be the key's block home (set_home_kh, or set_block_home with a minimizer hash derived incrementally)
 template <int W> __device__ __forceinline__ u64 set_find_from(const SetView<W> &s, const Key<W> &key, u64 keyhash, u64 home) {
     const u8 tag = kc_tag_of(keyhash);
-    if (s.m == 0) { u64 r = set_scan(s, key, tag, home, s.cap); return r == KC_SCAN_MORE ? KC_NONE64 : r; }
+    if (s.m == 0) { u64 r = set_scan(s, key, tag, home, s.rcap); return r == KC_SCAN_MORE ? KC_NONE64 : r; }
     u64 r = set_scan(s, key, tag, home, (u64)s.local_probes);
     if (r != KC_SCAN_MORE) return r;
-    r = set_scan(s, key, tag, set_global_home(s, keyhash), s.cap);
+    r = set_scan(s, key, tag, set_global_home(s, keyhash), s.rcap);
     return r == KC_SCAN_MORE ? KC_NONE64 : r;
 }
 template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) {

@@ -1,0 +1,980 @@
+// Hash-sharded multi-GPU flow of the BIGREEDY path: one rank per GPU, the k-mer set partitioned by table-block
+// range (block = hash of the canonical minimizer, so ~90 % of a k-mer's de Bruijn neighbours live on its own rank).
+// The reference has no counterpart (single thread, main.cpp:122-212); the contract is: ONE masked superstring,
+// byte-identical to the single-GPU kc_compute on the union of the ranks' records.  That holds by construction: the
+// canonical simplitig rule (kc_simplitigs.hip) is layout- and schedule-free, and phases 2-3 are functions of
+// the ordered simplitig list.
+//
+//   phase 0  kcs_build_sharded (kc_set.hip): k-mers bucketed by block, all-to-all of the buckets, LDS build on the owner.
+//   phase 1a kc_shard_choose_kernel: the 8 neighbour lookups per k-mer; candidates whose home block belongs to another
+//            rank become queries (key + home), all-to-all, kc_shard_answer_kernel on the owner, answers back;
+//            kc_shard_resolve_kernel settles the ports that waited.  Ports with >= 2 existing candidates ("branch
+//            ports") contribute their edges to a small replicated subgraph that every rank settles identically by the
+//            sequential form of the rule (edges by descending priority) -- branch ports are rare on read-like input.
+//   phase 1b chains: every rank contracts the chain pieces that stay inside it ("fragments", kc_shard_walk_kernel, bases
+//            recorded 2 bits per step), fragments are ranked across ranks by pointer jumping (log2 rounds of
+//            request/answer all-to-alls), chain heads gather their tails and decide orientation; the chain records
+//            (head/tail k-mers, length) are all-gathered and sorted by head key on every rank = the simplitig list.
+//   phase 2  overlap path: replicated (it needs only the 2 end k-mers per simplitig; V ~ 2 * 10^-3 N).
+//   phase 3  every simplitig is emitted by the rank that owns the output range it starts in: the winning fragments send
+//            their recorded bases (32 per message) there, the owner assembles the packed simplitigs and runs the ordinary
+//            emit kernel into its slice of the superstring.
+#include "kc_internal.h"
+#include "kc_comm.h"
+#include "kc_simp_dev.h"
+#include "kc_scan_dev.h"
+#include <algorithm>
+#include <unordered_map>
+#include <unordered_set>
+
+#define KC_USH 16       /* cursor shards of the record / query lists */
+#define KC_USTRIDE 16   /* words between two cursors: one 128-byte line each */
+#define KC_GID(rank, idx) (((u64)(rank) << 40) | (u64)(idx))
+#define KC_GID_RANK(g) ((int)((g) >> 40))
+#define KC_GID_IDX(g) ((g) & (((u64)1 << 40) - 1))
+#define KC_FCW 4        /* words per recording chunk of a fragment walk (128 bases) */
+#define KC_MAX_RANKS_SH 64
+
+namespace {
+
+struct ShLists {
+    u64 *rec;        // records {pid, cand[4]}: 5 words, shard s owns [s * rec_scap, ...)
+    u64 rec_scap;
+    u64 *rec_cur;    // KC_USH cursors
+    u64 *qry;        // queries {key[W], home, meta}: W + 2 words
+    u64 qry_scap;
+    u64 *qry_cur;
+    u64 *flags;      // [0] a list overflowed
+};
+
+// ---------------------------------------------------------------------------------------------------- phase 1a
+// Round 1 over this rank's slot range.  Same sweep as kc_choose_dense_kernel (workgroup = 2048 slots of one block, block
+// tags staged in LDS); a port whose 4 candidates are all local and of which at most one exists is settled at once, every
+// other port gets a record, every remote candidate a query.  List space is reserved once per workgroup iteration.
+template <int W, int KC>
+__global__ void __launch_bounds__(256) kc_shard_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
+                                                              ShLists L, int stage_words) {
+    extern __shared__ u64 kc_stage[];
+    __shared__ unsigned short kc_list[KC_CHOOSE_SLOTS];
+    __shared__ u32 kc_nlist, n_rec, n_qry;
+    __shared__ u64 base_rec, base_qry;
+    const u64 base = set.rlo + kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_SLOTS;
+    const u64 end = set.rlo + set.rcap;
+    if (base >= end) return;
+    if (threadIdx.x == 0) { kc_nlist = 0; n_rec = 0; n_qry = 0; }
+    const u64 sblk = base >> set.bshift;
+    {
+        const u64 *src = reinterpret_cast<const u64 *>(set.tags + (sblk << set.bshift));
+        for (int j = threadIdx.x; j < stage_words; j += 256) kc_stage[j] = src[j];
+    }
+    __syncthreads();
+    const u8 *tg = reinterpret_cast<const u8 *>(kc_stage) + (base & (((u64)1 << set.bshift) - 1));
+    for (u32 i = threadIdx.x; i < KC_CHOOSE_SLOTS; i += 256)
+        if (base + i < end && tg[i] != 0) kc_list[atomicAdd(&kc_nlist, 1u)] = (unsigned short)i;
+    __syncthreads();
+    const u32 n = kc_nlist;
+    const u32 shard = (u32)blockIdx.x & (KC_USH - 1);
+    const int QW = W + 2;
+#pragma unroll 1
+    for (u32 t0 = 0; t0 < n; t0 += 256) {
+        const u32 t = t0 + threadIdx.x;
+        const bool active = t < n;
+        KcCand<W> cd;
+        u64 slot = 0;
+        u32 need = 0, nq = 0;   // need: bit p = port p gets a record
+        if (active) {
+            slot = base + kc_list[t];
+            kc_cand_lookup<W, KC, true>(set, k_rt, complements, slot, kc_stage, sblk, cd);
+#pragma unroll
+            for (int port = 0; port < 2; ++port) {
+                const u64 pid = (slot << 1) | (u64)port;
+                if (port == 1 && cd.xpal) { link[pid] = LK_DEAD; continue; }
+                u32 nfound = 0, nrem = 0, bc = 0;
+#pragma unroll
+                for (u32 c = 0; c < 4; ++c) {
+                    const u64 cs = cd.cslot[port * 4 + c];
+                    if (cs == KC_REMOTE) ++nrem;
+                    else if (cs != KC_NONE64) { ++nfound; bc = c; }
+                }
+                if (nrem == 0 && nfound <= 1) {
+                    const int i = port * 4 + (int)bc;
+                    link[pid] = nfound ? LK_MAKE(LK_CHOICE, (cd.qbits >> i) & 1, port ? bc : 3 - bc, cd.cslot[i]) : LK_DEAD;
+                } else { need |= 1u << port; nq += nrem; }
+            }
+        }
+        const u32 nr = (need & 1) + (need >> 1);
+        const u32 my_rec = nr ? atomicAdd(&n_rec, nr) : 0;
+        const u32 my_qry = nq ? atomicAdd(&n_qry, nq) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            base_rec = n_rec ? atomicAdd((ull *)&L.rec_cur[shard * KC_USTRIDE], (ull)n_rec) : 0;
+            base_qry = n_qry ? atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)n_qry) : 0;
+        }
+        __syncthreads();
+        if (nr) {
+            u64 rpos = base_rec + my_rec, qpos = base_qry + my_qry;
+#pragma unroll
+            for (int port = 0; port < 2; ++port) {
+                if (!((need >> port) & 1)) continue;
+                if (rpos >= L.rec_scap) { L.flags[0] = 1; break; }
+                const u64 ri = (u64)shard * L.rec_scap + rpos;
+                u64 *r = L.rec + ri * 5;
+                r[0] = (slot << 1) | (u64)port;
+#pragma unroll
+                for (u32 c = 0; c < 4; ++c) {
+                    const int i = port * 4 + (int)c;
+                    const u64 cs = cd.cslot[i];
+                    const u64 q = (cd.qbits >> i) & 1;
+                    r[1 + c] = (cs == KC_NONE64 || cs == KC_REMOTE) ? cs : ((cs << 1) | q);
+                    if (cs == KC_REMOTE) {
+                        if (qpos >= L.qry_scap) { L.flags[0] = 1; }
+                        else {
+                            u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * QW;
+                            for (int w = 0; w < W; ++w) qq[w] = cd.cy[i].w[w];
+                            qq[W] = cd.chome[i];
+                            qq[W + 1] = (ri << 3) | (q << 2) | (u64)c;
+                        }
+                        ++qpos;
+                    }
+                }
+                ++rpos;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { n_rec = 0; n_qry = 0; }
+        // (the next iteration's LDS atomics come after its own lookups; the barrier at its reservation orders the reset)
+        __syncthreads();
+    }
+}
+
+// destination rank of every query (owner of the home slot)
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_qdest_kernel(const u64 *__restrict__ qry, u64 n, u64 rcap, u8 *dest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dest[t] = (u8)(qry[t * (W + 2) + W] / rcap);
+}
+// the owner's side: queries {key, home} -> slot (global) or KC_NONE64
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_answer_kernel(SetView<W> set, const u64 *__restrict__ q, u64 n, u64 *ans) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    Key<W> key;
+    for (int w = 0; w < W; ++w) key.w[w] = q[t * (W + 1) + w];
+    ans[t] = set_find_from(set, key, key_place_hash(key), q[t * (W + 1) + W]);
+}
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restrict__ qry, const u64 *__restrict__ ans, u64 n, u64 *rec) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 meta = qry[t * (W + 2) + W + 1], a = ans[t];
+    rec[(meta >> 3) * 5 + 1 + (meta & 3)] = a == KC_NONE64 ? KC_NONE64 : ((a << 1) | ((meta >> 2) & 1));
+}
+
+// candidate (port, c) of x: canonical key (the port it is entered on is already in the record)
+template <int W> __device__ __forceinline__ Key<W> kc_neighbour_key(const Key<W> &x, int port, u32 c, int k, int complements) {
+    Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+    if (!complements) return nf;
+    Key<W> r = key_rc(nf, k);
+    return key_lt(r, nf) ? r : nf;
+}
+// settle the recorded ports.  Branch ports (>= 2 existing candidates) choose their best edge here too, and list all their
+// edges {x pid, y pid, priority, base, key x, key y} for the replicated branch matching.
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_resolve_kernel(SetView<W> set, u64 *link, int k, int complements, const u64 *__restrict__ rec, u64 rec_scap,
+                                                               const u64 *__restrict__ rec_cur, u64 *edges, u64 edge_cap, u64 *edge_cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 shard = t / rec_scap, pos = t - shard * rec_scap;
+    if (shard >= KC_USH) return;
+    u64 cnt = rec_cur[shard * KC_USTRIDE];
+    if (pos >= (cnt > rec_scap ? rec_scap : cnt)) return;
+    const u64 *r = rec + t * 5;
+    const u64 pid = r[0];
+    const int port = (int)(pid & 1);
+    u32 nfound = 0, bc = 0;
+    for (u32 c = 0; c < 4; ++c)
+        if (r[1 + c] != KC_NONE64) { ++nfound; bc = c; }
+    if (nfound == 0) { link[pid] = LK_DEAD; return; }
+    if (nfound == 1) { link[pid] = LK_MAKE(LK_CHOICE, r[1 + bc] & 1, port ? bc : 3 - bc, r[1 + bc] >> 1); return; }
+    const Key<W> x = set_key_at(set, pid >> 1);
+    const u64 hx = key_hash(x);
+    Key<W> by = x; int bq = 0; u64 bpr = 0; bool have = false;
+    const u64 e0 = atomicAdd((ull *)edge_cursor, (ull)nfound);
+    u32 ne = 0;
+    for (u32 c = 0; c < 4; ++c) {
+        if (r[1 + c] == KC_NONE64) continue;
+        const Key<W> y = kc_neighbour_key(x, port, c, k, complements);
+        const int q = (int)(r[1 + c] & 1);
+        const u64 pr = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
+        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bc = c; have = true; }
+        if (e0 + ne < edge_cap) {
+            u64 *e = edges + (e0 + ne) * (4 + 2 * W);
+            e[0] = pid; e[1] = r[1 + c]; e[2] = pr; e[3] = port ? c : 3 - c;
+            for (int w = 0; w < W; ++w) { e[4 + w] = x.w[w]; e[4 + W + w] = y.w[w]; }
+        }
+        ++ne;
+    }
+    link[pid] = LK_MAKE(LK_CHOICE, r[1 + bc] & 1, port ? bc : 3 - bc, r[1 + bc] >> 1);   // provisional; the branch matching overrides it
+}
+__global__ void __launch_bounds__(256) kc_shard_apply_fix_kernel(u64 *link, const u64 *__restrict__ fix, u64 n, u64 rlo2, u64 rcap2) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 pid = fix[2 * t];
+    if (pid - rlo2 < rcap2) link[pid] = fix[2 * t + 1];
+}
+
+// ---------------------------------------------------------------------------------------------------- phase 1b: fragments
+// entry = oriented node (slot, o) whose entry port o is dead (a chain head) or matched to a slot of another rank
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_shard_entries_kernel(const u64 *__restrict__ link, const u8 *__restrict__ tags, u64 rlo, u64 rcap, int complements,
+                                                               const u64 *__restrict__ tile_off, u64 *out) {
+    const u64 base = rlo + (u64)blockIdx.x * 2048 + (u64)threadIdx.x * 8;
+    u64 c = 0;
+    u32 m = 0;
+    for (int i = 0; i < 8; ++i) {
+        const u64 slot = base + i;
+        if (slot >= rlo + rcap || tags[slot] == 0) continue;
+        for (int o = 0; o < (complements ? 2 : 1); ++o) {
+            const u64 w = link[(slot << 1) | (u64)o];
+            const bool entry = LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - rlo >= rcap);
+            if (entry) { m |= 1u << (2 * i + o); ++c; }
+        }
+    }
+    u64 tot;
+    const u64 ex = kc_block_excl_scan(c, &tot);
+    if (!FILL) { if (threadIdx.x == 0) out[blockIdx.x] = tot; return; }
+    u64 pos = tile_off[blockIdx.x] + ex;
+    for (int j = 0; j < 16; ++j)
+        if ((m >> j) & 1) out[pos++] = ((base + (u64)(j >> 1)) << 1) | (u64)(j & 1);
+}
+
+struct FragRec {
+    u64 *pool;        // chunks of KC_FCW words
+    u32 *chunk_next;
+    u64 pool_cap;
+    u64 *pool_cursor;
+};
+// one thread per entry: walk the links while they stay on this rank; record the appended bases
+template <bool MARK>
+__global__ void __launch_bounds__(256) kc_shard_walk_kernel(const u64 *__restrict__ link, u64 rlo, u64 rcap, const u64 *__restrict__ entries, u64 n,
+                                                            u64 *f_exit, u64 *f_partner, u64 *f_len, u32 *f_stream, u32 *fidx, FragRec rec, u8 *visited,
+                                                            u64 *flags) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 h = entries[t];
+    u64 cur = h >> 1;
+    int co = (int)(h & 1);
+    u64 len = 1, acc = 0, partner = KC_NONE64;
+    int nacc = 0, wi = 0;
+    u32 chunk = KC_NO_CHUNK, first_chunk = KC_NO_CHUNK;
+    bool ok = true;
+    auto flush_word = [&](u64 word) {
+        if (chunk == KC_NO_CHUNK || wi == KC_FCW) {
+            const u64 nc = atomicAdd((ull *)rec.pool_cursor, 1ULL);
+            if (nc >= rec.pool_cap) { ok = false; return; }
+            if (first_chunk == KC_NO_CHUNK) first_chunk = (u32)nc; else rec.chunk_next[chunk] = (u32)nc;
+            chunk = (u32)nc;
+            wi = 0;
+        }
+        rec.pool[(u64)chunk * KC_FCW + (u64)wi++] = word;
+    };
+    int xp;
+    while (true) {
+        if (MARK) visited[cur - rlo] = 1;
+        xp = co == 0 ? 1 : 0;
+        const u64 w = link[(cur << 1) | (u64)xp];
+        if (!LK_IS_MATCHED(w)) break;
+        if (LK_SLOT(w) - rlo >= rcap) { partner = LK_PID(w); break; }
+        if (!MARK) {
+            acc = (acc << 2) | LK_BASE(w);
+            if (++nacc == 32) { if (ok) flush_word(acc); acc = 0; nacc = 0; }
+        }
+        cur = LK_SLOT(w);
+        co = LK_PORT(w) == 0 ? 0 : 1;
+        ++len;
+    }
+    if (MARK) return;
+    if (nacc && ok) flush_word(acc << (64 - 2 * nacc));
+    if (!ok) flags[0] = 1;
+    f_exit[t] = (cur << 1) | (u64)xp;
+    f_partner[t] = partner;
+    f_len[t] = len;
+    f_stream[t] = first_chunk;
+    fidx[h - 2 * rlo] = (u32)t;
+}
+
+// ---- pointer jumping over fragments.  nxt = global id of the next fragment (KC_NONE64: this one ends the chain);
+// dist = nodes from this fragment's first node up to (not including) nxt's first node, or to the chain end; last = the
+// chain's final fragment once known.
+__global__ void __launch_bounds__(256) kc_shard_jump_init_kernel(const u64 *__restrict__ f_partner, const u64 *__restrict__ f_len, u64 n, int me, u64 *nxt,
+                                                                 u64 *dist, u64 *last) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    nxt[t] = f_partner[t];   // still a port id: resolved to a fragment id by the first request round
+    dist[t] = f_len[t];
+    last[t] = f_partner[t] == KC_NONE64 ? KC_GID(me, t) : KC_NONE64;
+}
+// active = fragments that still have a successor; req = what to ask its owner (round 0: the entry port; later: the fragment index)
+__global__ void __launch_bounds__(256) kc_shard_active_flags_kernel(const u64 *__restrict__ nxt, u64 n, u8 *flags) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) flags[t] = nxt[t] != KC_NONE64;
+}
+__global__ void __launch_bounds__(256) kc_shard_iota_kernel(u64 *a, u64 n) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) a[t] = t;
+}
+__global__ void __launch_bounds__(256) kc_shard_req_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ nxt, int round0, u64 rcap2, u64 *req, u8 *dest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 v = nxt[act[t]];
+    req[t] = v;
+    dest[t] = round0 ? (u8)(v / rcap2) : (u8)KC_GID_RANK(v);
+}
+__global__ void __launch_bounds__(256) kc_shard_ans_port_kernel(const u64 *__restrict__ req, u64 n, const u32 *__restrict__ fidx, u64 rlo2, int me, u64 *ans) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) ans[t] = KC_GID(me, fidx[req[t] - rlo2]);
+}
+__global__ void __launch_bounds__(256) kc_shard_ans_jump_kernel(const u64 *__restrict__ req, u64 n, const u64 *__restrict__ nxt, const u64 *__restrict__ dist,
+                                                                const u64 *__restrict__ last, u64 *ans) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 g = KC_GID_IDX(req[t]);
+    ans[3 * t] = nxt[g]; ans[3 * t + 1] = dist[g]; ans[3 * t + 2] = last[g];
+}
+__global__ void __launch_bounds__(256) kc_shard_apply_port_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ ans, u64 *nxt) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) nxt[act[t]] = ans[t];
+}
+__global__ void __launch_bounds__(256) kc_shard_apply_jump_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ ans, u64 *nxt, u64 *dist, u64 *last) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = act[t];
+    nxt[e] = ans[3 * t];
+    dist[e] += ans[3 * t + 1];
+    if (ans[3 * t] == KC_NONE64) last[e] = ans[3 * t + 2];
+}
+
+// ---- chain heads: fragments whose entry port is dead.  They ask the owner of the chain's final fragment for the tail
+// (oriented tail node + its key) and decide whether their direction is the one that is emitted.
+__global__ void __launch_bounds__(256) kc_shard_head_flags_kernel(const u64 *__restrict__ link, const u64 *__restrict__ entries, u64 n, u8 *flags) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) flags[t] = LK_STATE(link[entries[t]]) == LK_DEAD;
+}
+__global__ void __launch_bounds__(256) kc_shard_tailreq_kernel(const u64 *__restrict__ heads, u64 n, const u64 *__restrict__ last, u64 *req, u8 *dest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 g = last[heads[t]];
+    req[t] = g; dest[t] = (u8)KC_GID_RANK(g);
+}
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_tailans_kernel(SetView<W> set, const u64 *__restrict__ req, u64 n, const u64 *__restrict__ f_exit, u64 *ans) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 x = f_exit[KC_GID_IDX(req[t])];
+    ans[t * (W + 1)] = x;
+    const Key<W> key = set_key_at(set, x >> 1);
+    for (int w = 0; w < W; ++w) ans[t * (W + 1) + 1 + w] = key.w[w];
+}
+// chain record (3 + 3W words): {final fragment id, nodes, head key (canonical), first k-mer (oriented), last k-mer (oriented)}
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_chain_kernel(SetView<W> set, int k, int complements, const u64 *__restrict__ heads, u64 n,
+                                                             const u64 *__restrict__ entries, const u64 *__restrict__ dist, const u64 *__restrict__ last,
+                                                             const u64 *__restrict__ tail, u64 *chains, u64 *cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = heads[t], h = entries[e], len = dist[e];
+    const Key<W> hk = set_key_at(set, h >> 1);
+    Key<W> tk;
+    for (int w = 0; w < W; ++w) tk.w[w] = tail[t * (W + 1) + 1 + w];
+    const u64 tx = tail[t * (W + 1)];   // tail node << 1 | exit port
+    bool winner = true;
+    if (complements) winner = (len == 1) ? ((h & 1) == 0) : key_lt(hk, tk);
+    atomicAdd((ull *)(cursor + 1), (ull)(winner ? len : 0));
+    if (!winner) return;
+    const u64 pos = atomicAdd((ull *)cursor, 1ULL);
+    u64 *c = chains + pos * (3 + 3 * W);
+    c[0] = last[e]; c[1] = len; c[2] = 0;
+    const Key<W> fk = (h & 1) ? key_rc(hk, k) : hk;
+    const Key<W> lk = (tx & 1) ? tk : key_rc(tk, k);   // orientation of the tail node = 1 - exit port; orientation 1 = reverse complement
+    for (int w = 0; w < W; ++w) { c[3 + w] = hk.w[w]; c[3 + W + w] = fk.w[w]; c[3 + 2 * W + w] = lk.w[w]; }
+}
+
+// ---- the replicated simplitig list: chain records sorted by head key (host) -> lens / firstK / lastK / final fragment ids
+// sorted final-fragment ids for the membership test of the fragments
+__device__ __forceinline__ u64 kc_lower_bound64(const u64 *a, u64 n, u64 v) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------------- phase 3: bases to the emitting rank
+// fragment e of the emitted direction of simplitig i covers string positions [p0, p0 + cnt): p0 = 0, cnt = k - 1 + len for
+// the head fragment, p0 = node offset + k - 1, cnt = len otherwise.  One message per 32 bases:
+// {absolute base position in the packed stream | (count - 1) << 58, 32 bases left-aligned}.
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_shard_msg_kernel(int k, const u64 *__restrict__ entries, u64 n, const u64 *__restrict__ f_len, const u64 *__restrict__ dist,
+                                                           const u64 *__restrict__ last, const u32 *__restrict__ f_stream, const u64 *__restrict__ pool,
+                                                           const u32 *__restrict__ chunk_next, const u64 *__restrict__ keys_biased, int W, const u64 *__restrict__ fin_sorted,
+                                                           const u64 *__restrict__ fin_simp, u64 S, const u64 *__restrict__ lens, const u64 *__restrict__ woff,
+                                                           const u8 *__restrict__ simp_dest, u64 *mcount, const u64 *__restrict__ moff, u64 *msgs, u8 *mdest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 fin = last[t];
+    const u64 j = kc_lower_bound64(fin_sorted, S, fin);
+    if (j >= S || fin_sorted[j] != fin) { if (!FILL) mcount[t] = 0; return; }   // the other direction is the emitted one
+    const u64 i = fin_simp[j];
+    const u64 nodes = lens[i] - (u64)(k - 1);
+    const u64 off = nodes - dist[t], len = f_len[t];
+    const bool head = off == 0;
+    const u64 cnt = head ? (u64)(k - 1) + len : len;
+    const u64 nm = (cnt + 31) / 32;
+    if (!FILL) { mcount[t] = nm; return; }
+    const u64 p0 = head ? 0 : off + (u64)(k - 1);
+    // oriented first k-mer of the fragment
+    const u64 h = entries[t];
+    u64 kw[4] = {0, 0, 0, 0};
+    for (int w = 0; w < W; ++w) kw[w] = keys_biased[(h >> 1) * (u64)W + w];
+    auto base_at = [&](int idx) -> u64 {   // idx-th base of the oriented k-mer
+        if (h & 1) {   // reverse complement: base idx = complement of forward base k - 1 - idx
+            const int s = 2 * idx;
+            return 3 - ((kw[s >> 6] >> (s & 63)) & 3);
+        }
+        const int s = 2 * (k - 1 - idx);
+        return (kw[s >> 6] >> (s & 63)) & 3;
+    };
+    u64 m = moff[t], pos = woff[i] * 32 + p0, acc = 0;
+    int nacc = 0;
+    const u8 d = simp_dest[i];
+    auto put = [&](u64 b) {
+        acc = (acc << 2) | b;
+        if (++nacc == 32) { msgs[2 * m] = pos | ((u64)31 << 58); msgs[2 * m + 1] = acc; mdest[m] = d; ++m; pos += 32; acc = 0; nacc = 0; }
+    };
+    if (head) for (int idx = 0; idx < k; ++idx) put(base_at(idx));
+    else put(base_at(k - 1));
+    u32 chunk = f_stream[t];
+    int wi = 0;
+    u64 left = len - 1;
+    while (left) {
+        if (wi == KC_FCW) { chunk = chunk_next[chunk]; wi = 0; }
+        const u64 sw = pool[(u64)chunk * KC_FCW + (u64)wi++];
+        const int nb = left >= 32 ? 32 : (int)left;
+        for (int q = 0; q < nb; ++q) put((sw >> (62 - 2 * q)) & 3);
+        left -= (u64)nb;
+    }
+    if (nacc) { msgs[2 * m] = pos | ((u64)(nacc - 1) << 58); msgs[2 * m + 1] = acc << (64 - 2 * nacc); mdest[m] = d; }
+}
+__global__ void __launch_bounds__(256) kc_shard_place_kernel(const u64 *__restrict__ msgs, u64 n, u64 *words) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 hdr = msgs[2 * t], payload = msgs[2 * t + 1];
+    const u64 pos = hdr & (((u64)1 << 58) - 1);
+    const int cnt = (int)(hdr >> 58) + 1;
+    const u64 wi = pos >> 5;
+    const int sh = (int)(pos & 31) * 2;   // bits already used in word wi
+    atomicOr((ull *)&words[wi], (ull)(payload >> sh));
+    if (sh && sh + 2 * cnt > 64) atomicOr((ull *)&words[wi + 1], (ull)(payload << (64 - sh)));
+}
+
+// per-simplitig destination rank: owner of the output offset at which its on-path vertex starts
+__global__ void __launch_bounds__(256) kc_shard_simp_dest_kernel(const u64 *__restrict__ dist, const u64 *__restrict__ endv, u64 start, u64 S, u64 V, u64 Ltot, int G,
+                                                                 u8 *simp_dest, u64 *rank_lo, u64 *rank_hi, const u64 *__restrict__ weight) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    if (endv[v] != endv[start]) return;
+    const u64 off = dist[start] - dist[v];
+    const int r = (int)(((unsigned __int128)off * (unsigned)G) / Ltot);
+    simp_dest[v < S ? v : v - S] = (u8)r;
+    atomicMin((ull *)&rank_lo[r], (ull)off);
+    atomicMax((ull *)&rank_hi[r], (ull)(off + weight[v]));
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- host flow
+namespace {
+
+int read_words(kc_ctx *ctx, const u64 *d, u64 *h, int n) {
+    KC_HIP(ctx, hipMemcpyAsync(h, d, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ms;
+}
+bool trace_on() { return getenv("KC_SHARD_TRACE") != nullptr; }
+
+// every rank's `n_local` rows of `words` words -> all rows on every rank (device), row counts per rank in `counts`
+int allgather_rows(kc_comm *c, const u64 *d_rows, u64 n_local, int words, u64 **d_all, u64 *n_all, std::vector<u64> *counts) {
+    kc_ctx *ctx = c->ctx;
+    const int G = c->world;
+    std::vector<u64> cnt(G);
+    KC_TRY(kcc_allgather_words(c, &n_local, cnt.data(), 1));
+    std::vector<u64> so(G, 0), sc(G, n_local * words * 8), ro(G), rcv(G);
+    u64 tot = 0;
+    for (int p = 0; p < G; ++p) { ro[p] = tot * words * 8; rcv[p] = cnt[p] * words * 8; tot += cnt[p]; }
+    u64 *all = nullptr;
+    KC_TRY(kc_alloc(ctx, &all, tot * words + 1));
+    int rc = kcc_alltoallv(c, d_rows, so.data(), sc.data(), all, ro.data(), rcv.data());
+    if (rc != KC_OK) { kc_release(ctx, all); return rc; }
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *d_all = all; *n_all = tot;
+    if (counts) *counts = cnt;
+    return KC_OK;
+}
+
+template <int W> bool hkey_lt(const u64 *a, const u64 *b) {
+    for (int i = W - 1; i >= 0; --i) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; }
+    return false;
+}
+template <int W> bool hkey_eq(const u64 *a, const u64 *b) {
+    for (int i = 0; i < W; ++i) if (a[i] != b[i]) return false;
+    return true;
+}
+
+// The branch subgraph, settled the way the canonical rule is defined (oracle restatement: simplitigs_canonical_order):
+// all its edges by descending priority (ties: ordered endpoint tuple), an edge is taken when both ports are free.
+// rows: {x pid, y pid, priority, base, key x, key y} as listed by kc_shard_resolve_kernel (every edge of a branch port; an
+// edge between two branch ports appears twice).  fix: {pid, final link word} for every port whose provisional link changes.
+template <int W> void settle_branches(const std::vector<u64> &rows, u64 n, std::vector<u64> &fix) {
+    const int EW = 4 + 2 * W;
+    struct Edge { u64 pa, pb, pr; const u64 *ka, *kb; };
+    std::vector<Edge> edges;
+    edges.reserve(n);
+    std::unordered_set<u64> branch;
+    for (u64 i = 0; i < n; ++i) {
+        const u64 *e = rows.data() + i * EW;
+        const u64 x = e[0], y = e[1];
+        const u64 *kx = e + 4, *ky = e + 4 + W;
+        branch.insert(x);
+        const bool x_first = hkey_lt<W>(kx, ky) || (hkey_eq<W>(kx, ky) && (x & 1) <= (y & 1));
+        if (x_first) edges.push_back({x, y, e[2], kx, ky}); else edges.push_back({y, x, e[2], ky, kx});
+    }
+    std::sort(edges.begin(), edges.end(), [](const Edge &a, const Edge &b) {
+        if (a.pr != b.pr) return a.pr > b.pr;
+        if (!hkey_eq<W>(a.ka, b.ka)) return hkey_lt<W>(a.ka, b.ka);
+        if ((a.pa & 1) != (b.pa & 1)) return (a.pa & 1) < (b.pa & 1);
+        if (!hkey_eq<W>(a.kb, b.kb)) return hkey_lt<W>(a.kb, b.kb);
+        return (a.pb & 1) < (b.pb & 1);
+    });
+    std::unordered_map<u64, u64> mate;
+    mate.reserve(edges.size() * 2);
+    for (const Edge &e : edges) {
+        if (e.pa == e.pb) continue;
+        if (mate.count(e.pa) || mate.count(e.pb)) continue;
+        mate[e.pa] = e.pb; mate[e.pb] = e.pa;
+    }
+    fix.clear();
+    std::unordered_set<u64> done;
+    for (u64 i = 0; i < n; ++i) {
+        const u64 *e = rows.data() + i * EW;
+        const u64 x = e[0], y = e[1];
+        auto mx = mate.find(x);
+        if (mx == mate.end()) { if (done.insert(x).second) { fix.push_back(x); fix.push_back(LK_DEAD); } }
+        else if (mx->second == y) { fix.push_back(x); fix.push_back(LK_MAKE(LK_MATCHED, y & 1, e[3], y >> 1)); }
+        if (!branch.count(y)) {   // y has this one candidate only: it keeps its choice iff the edge was taken
+            auto my = mate.find(y);
+            if (my == mate.end() && done.insert(y).second) { fix.push_back(y); fix.push_back(LK_DEAD); }
+        }
+    }
+}
+
+template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, int k, int complements, kc_result **out) {
+    KcScope scope(ctx);
+    const int G = c->world, me = c->rank;
+    const bool trace = trace_on();
+    hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1], e2 = ctx->ev[2], e3 = ctx->ev[3];
+    hipEvent_t eend;
+    KC_HIP(ctx, hipEventCreate(&eend));
+    struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } evg{eend};
+    KC_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    // ---------------- phase 0
+    kc_set *set = nullptr;
+    const u64 occ_local = len >= (u64)k ? len - k + 1 : 0;
+    KC_TRY(kcs_create_sharded(ctx, c, k, complements, occ_local, &set));
+    struct SetGuard { kc_set *s; ~SetGuard() { if (s) kc_set_destroy(s); } } setg{set};
+    {
+        u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
+        int rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
+        u64 moved = 0;
+        if (rc == KC_OK) rc = kcs_build_sharded(set, c, codes, brk, low, len, &moved);
+        (void)hipStreamSynchronize(ctx->stream);
+        kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low);
+        KC_TRY(rc);
+    }
+    const u64 N_local = set->size_host;
+    u64 N = N_local;
+    KC_TRY(kcc_allreduce_sum(c, &N, 1));
+    if (N == 0) return kc_fail(ctx, KC_E_NO_KMERS, "input contains no k-mers");
+    KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    SetView<W> sv = kc_view<W>(set);
+    const u64 rlo = set->rlo, rcap = set->rcap;
+    // ---------------- phase 1a: links
+    u64 *link_alloc = nullptr;
+    KC_TRY(scope.alloc(&link_alloc, 2 * rcap));
+    u64 *link = link_alloc - 2 * rlo;   // indexed with global port ids
+    u64 *cur = nullptr;                  // cursors + flags
+    KC_TRY(scope.alloc(&cur, (2 * KC_USH + 4) * KC_USTRIDE));
+    ShLists L{};
+    const int QW = W + 2, EW = 4 + 2 * W;
+    u64 rec_scap = (N_local + N_local / 8) / KC_USH + 4096, qry_scap = (N_local + N_local / 2) / KC_USH + 4096;
+    const int stage_words = (int)(((u64)1 << set->bshift) / 8 + 1);
+    const unsigned cgrid = kc_grid8(rcap, KC_CHOOSE_SLOTS);
+    constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
+    for (int attempt = 0;; ++attempt) {
+        KC_TRY(scope.alloc(&L.rec, rec_scap * KC_USH * 5));
+        KC_TRY(scope.alloc(&L.qry, qry_scap * KC_USH * QW));
+        L.rec_scap = rec_scap; L.qry_scap = qry_scap;
+        L.rec_cur = cur; L.qry_cur = cur + KC_USH * KC_USTRIDE; L.flags = cur + 2 * KC_USH * KC_USTRIDE;
+        KC_HIP(ctx, hipMemsetAsync(cur, 0, (2 * KC_USH + 4) * KC_USTRIDE * 8, ctx->stream));
+        if (k == KSPEC && !getenv("KC_NO_KSPEC"))
+            hipLaunchKernelGGL((kc_shard_choose_kernel<W, KSPEC>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
+        else
+            hipLaunchKernelGGL((kc_shard_choose_kernel<W, 0>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
+        KC_HIP(ctx, hipGetLastError());
+        u64 ovf = 0;
+        KC_TRY(read_words(ctx, L.flags, &ovf, 1));
+        u64 any = ovf;
+        KC_TRY(kcc_allreduce_max(c, &any, 1));   // (the retry is collective: it re-enters no exchange, but keep the ranks in step)
+        if (!any) break;
+        if (attempt == 4) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded probe: record / query lists overflow");
+        scope.release(L.rec); scope.release(L.qry);
+        rec_scap = rec_scap * 2 + 4096; qry_scap = qry_scap * 3 + 4096;
+    }
+    // queries -> owners -> answers
+    u64 nq = 0;
+    {
+        u64 *qc = nullptr;
+        bool ovf = false;
+        std::vector<u64> hc(KC_USH * KC_USTRIDE);
+        KC_TRY(read_words(ctx, L.qry_cur, hc.data(), KC_USH * KC_USTRIDE));
+        for (int s = 0; s < KC_USH; ++s) nq += hc[(size_t)s * KC_USTRIDE];
+        KC_TRY(scope.alloc(&qc, nq * QW + 1));
+        KC_TRY(kcu_compact_shards(ctx, L.qry, qry_scap, L.qry_cur, KC_USH, KC_USTRIDE, QW, qc, &nq, &ovf));
+        scope.release(L.qry); L.qry = nullptr;
+        u8 *dest = nullptr;
+        KC_TRY(scope.alloc(&dest, nq + 1));
+        if (nq) hipLaunchKernelGGL((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcap, dest);
+        KcRoute rt;
+        KC_TRY(kcr_build(c, dest, nq, &rt));
+        u64 *rq = nullptr, *ans = nullptr, *ansb = nullptr;
+        int rc = kcr_forward(c, rt, qc, W + 1, QW, &rq);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
+        if (rc == KC_OK && rt.n_recv)
+            hipLaunchKernelGGL((kc_shard_answer_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, ans);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nq + 1);
+        if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
+        if (rc == KC_OK && nq)
+            hipLaunchKernelGGL((kc_shard_fill_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, L.rec);
+        (void)hipStreamSynchronize(ctx->stream);
+        kcr_free(ctx, &rt);
+        kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
+        scope.release(qc); scope.release(dest);
+        KC_TRY(rc);
+    }
+    // settle the recorded ports; branch ports list their edges
+    u64 n_branch_edges = 0;
+    {
+        u64 edge_cap = 1 << 16, *edges = nullptr, *ecur = cur + (2 * KC_USH + 1) * KC_USTRIDE;
+        for (int attempt = 0;; ++attempt) {
+            KC_TRY(scope.alloc(&edges, edge_cap * EW));
+            KC_HIP(ctx, hipMemsetAsync(ecur, 0, 8, ctx->stream));
+            hipLaunchKernelGGL((kc_shard_resolve_kernel<W>), dim3(kc_grid(rec_scap * KC_USH, 256)), dim3(256), 0, ctx->stream, sv, link, k, complements,
+                               (const u64 *)L.rec, rec_scap, (const u64 *)L.rec_cur, edges, edge_cap, ecur);
+            KC_HIP(ctx, hipGetLastError());
+            KC_TRY(read_words(ctx, ecur, &n_branch_edges, 1));
+            if (n_branch_edges <= edge_cap) break;
+            if (attempt == 2) return kc_fail(ctx, KC_E_CAPACITY, "branch edge list overflow");
+            scope.release(edges);
+            edge_cap = n_branch_edges + 1024;
+        }
+        scope.release(L.rec); L.rec = nullptr;
+        u64 *all = nullptr, n_all = 0;
+        KC_TRY(allgather_rows(c, edges, n_branch_edges, EW, &all, &n_all, nullptr));
+        scope.release(edges);
+        if (n_all) {
+            std::vector<u64> rows(n_all * EW), fix;
+            KC_HIP(ctx, hipMemcpyAsync(rows.data(), all, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            settle_branches<W>(rows, n_all, fix);
+            if (!fix.empty()) {
+                u64 *dfix = nullptr;
+                KC_TRY(scope.alloc(&dfix, fix.size()));
+                KC_HIP(ctx, hipMemcpyAsync(dfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(kc_shard_apply_fix_kernel, dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dfix, (u64)(fix.size() / 2),
+                                   2 * rlo, 2 * rcap);
+                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                scope.release(dfix);
+            }
+            n_branch_edges = n_all;
+        }
+        kc_release(ctx, all);
+    }
+    if (trace) fprintf(stderr, "[shard %d/%d] N_local=%llu N=%llu queries=%llu branch edges (all ranks)=%llu\n", me, G, (unsigned long long)N_local,
+                       (unsigned long long)N, (unsigned long long)nq, (unsigned long long)n_branch_edges);
+    // ---------------- phase 1b: fragments
+    u64 *entries = nullptr, n_ent = 0;
+    {
+        const u64 ntiles = (rcap + 2047) / 2048;
+        u64 *tcount = nullptr;
+        KC_TRY(scope.alloc(&tcount, ntiles + 2));
+        hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                           (const u64 *)nullptr, tcount);
+        KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
+        KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
+        KC_TRY(scope.alloc(&entries, n_ent + 1));
+        hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                           (const u64 *)tcount, entries);
+        KC_HIP(ctx, hipGetLastError());
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        scope.release(tcount);
+    }
+    if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
+    u64 *f_exit = nullptr, *f_partner = nullptr, *f_len = nullptr, *nxt = nullptr, *dist = nullptr, *last = nullptr, *iota = nullptr, *act = nullptr;
+    u32 *f_stream = nullptr, *fidx = nullptr, *chunk_next = nullptr;
+    u64 *pool = nullptr;
+    u8 *flags8 = nullptr;
+    KC_TRY(scope.alloc(&f_exit, n_ent + 1)); KC_TRY(scope.alloc(&f_partner, n_ent + 1)); KC_TRY(scope.alloc(&f_len, n_ent + 1));
+    KC_TRY(scope.alloc(&f_stream, n_ent + 1)); KC_TRY(scope.alloc(&fidx, 2 * rcap));
+    KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1));
+    KC_TRY(scope.alloc(&iota, n_ent + 1)); KC_TRY(scope.alloc(&act, n_ent + 1)); KC_TRY(scope.alloc(&flags8, n_ent + 1));
+    FragRec frec{};
+    frec.pool_cap = n_ent + 2 * N_local / (32 * KC_FCW) + 1024;
+    KC_TRY(scope.alloc(&pool, frec.pool_cap * KC_FCW)); KC_TRY(scope.alloc(&chunk_next, frec.pool_cap));
+    frec.pool = pool; frec.chunk_next = chunk_next; frec.pool_cursor = cur;
+    KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
+    if (n_ent) {
+        hipLaunchKernelGGL((kc_shard_walk_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                           f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE);
+        hipLaunchKernelGGL(kc_shard_jump_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)f_partner, (const u64 *)f_len, n_ent, me, nxt, dist, last);
+        hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
+    }
+    KC_HIP(ctx, hipGetLastError());
+    {
+        u64 pf = 0;
+        KC_TRY(read_words(ctx, cur + KC_USTRIDE, &pf, 1));
+        if (pf) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted");
+    }
+    // pointer jumping
+    u64 rounds = 0, prev_active = ~(u64)0;
+    for (int round = 0;; ++round) {
+        u64 n_act = 0;
+        if (n_ent) {
+            hipLaunchKernelGGL(kc_shard_active_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)nxt, n_ent, flags8);
+            KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
+            KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_act, 1));
+        }
+        u64 tot_act = n_act;
+        KC_TRY(kcc_allreduce_sum(c, &tot_act, 1));
+        if (tot_act == 0) break;
+        if (round > 1 && tot_act >= prev_active)
+            return kc_fail(ctx, KC_E_ARG, "the k-mer set contains cycles that span several ranks: not supported by the hash-sharded path yet");
+        if (round > 0) prev_active = tot_act;
+        u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
+        u8 *dest = nullptr;
+        const int A = round == 0 ? 1 : 3;
+        KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
+        if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, round == 0 ? 1 : 0, 2 * rcap, req, dest);
+        KcRoute rt;
+        KC_TRY(kcr_build(c, dest, n_act, &rt));
+        int rc = kcr_forward(c, rt, req, 1, 1, &rq);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * A + 1);
+        if (rc == KC_OK && rt.n_recv) {
+            if (round == 0) hipLaunchKernelGGL(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
+            else hipLaunchKernelGGL(kc_shard_ans_jump_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u64 *)nxt, (const u64 *)dist, (const u64 *)last, ans);
+        }
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, n_act * A + 1);
+        if (rc == KC_OK) rc = kcr_backward(c, rt, ans, A, ansb);
+        if (rc == KC_OK && n_act) {
+            if (round == 0) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
+            else hipLaunchKernelGGL(kc_shard_apply_jump_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt, dist, last);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        kcr_free(ctx, &rt);
+        kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
+        scope.release(req); scope.release(dest);
+        KC_TRY(rc);
+        ++rounds;
+    }
+    // chain heads gather their tails; winners become chain records
+    const int CW = 3 + 3 * W;
+    u64 *chains = nullptr, n_chains = 0, covered = 0;
+    {
+        u64 *heads = nullptr, n_heads = 0;
+        KC_TRY(scope.alloc(&heads, n_ent + 1));
+        if (n_ent) {
+            hipLaunchKernelGGL(kc_shard_head_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, flags8);
+            KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, heads, cur + 2 * KC_USTRIDE));
+            KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_heads, 1));
+        }
+        u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *tail = nullptr;
+        u8 *dest = nullptr;
+        KC_TRY(scope.alloc(&req, n_heads + 1)); KC_TRY(scope.alloc(&dest, n_heads + 1));
+        if (n_heads) hipLaunchKernelGGL(kc_shard_tailreq_kernel, dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, (const u64 *)heads, n_heads, (const u64 *)last, req, dest);
+        KcRoute rt;
+        KC_TRY(kcr_build(c, dest, n_heads, &rt));
+        int rc = kcr_forward(c, rt, req, 1, 1, &rq);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * (W + 1) + 1);
+        if (rc == KC_OK && rt.n_recv)
+            hipLaunchKernelGGL((kc_shard_tailans_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, (const u64 *)f_exit, ans);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &tail, n_heads * (W + 1) + 1);
+        if (rc == KC_OK) rc = kcr_backward(c, rt, ans, W + 1, tail);
+        if (rc == KC_OK) rc = scope.alloc(&chains, (n_heads + 1) * CW);
+        KC_HIP(ctx, hipMemsetAsync(cur, 0, 2 * 8, ctx->stream));
+        if (rc == KC_OK && n_heads)
+            hipLaunchKernelGGL((kc_shard_chain_kernel<W>), dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, sv, k, complements, (const u64 *)heads, n_heads,
+                               (const u64 *)entries, (const u64 *)dist, (const u64 *)last, (const u64 *)tail, chains, cur);
+        u64 hc[2] = {0, 0};
+        if (rc == KC_OK) rc = read_words(ctx, cur, hc, 2);
+        kcr_free(ctx, &rt);
+        kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, tail);
+        scope.release(req); scope.release(dest); scope.release(heads);
+        KC_TRY(rc);
+        n_chains = hc[0]; covered = hc[1];
+    }
+    {
+        u64 tot = covered;
+        KC_TRY(kcc_allreduce_sum(c, &tot, 1));
+        if (tot != N) return kc_fail(ctx, KC_E_ARG, "the k-mer set contains cycles (" + std::to_string(N - tot) + " k-mers on them): not supported by the hash-sharded path yet");
+    }
+    // ---------------- the replicated simplitig list
+    u64 *all_chains = nullptr, S = 0;
+    KC_TRY(allgather_rows(c, chains, n_chains, CW, &all_chains, &S, nullptr));
+    scope.release(chains);
+    if (S * 5 >= N) { kc_release(ctx, all_chains); return kc_fail(ctx, KC_E_ARG, "too many simplitigs for the dense overlap graph (main.cpp:175): the sparse branch is not part of the hash-sharded path"); }
+    kc_simplitigs *simp = new kc_simplitigs();
+    simp->ctx = ctx; simp->k = k; simp->W = W; simp->n = S;
+    struct SimpGuard { kc_simplitigs *s; ~SimpGuard() { if (s) kc_simplitigs_destroy(s); } } simpg{simp};
+    u64 *fin_sorted = nullptr, *fin_simp = nullptr;
+    {
+        std::vector<u64> rows(S * CW);
+        KC_HIP(ctx, hipMemcpyAsync(rows.data(), all_chains, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        kc_release(ctx, all_chains);
+        std::vector<u64> order(S);
+        for (u64 i = 0; i < S; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](u64 a, u64 b) { return hkey_lt<W>(rows.data() + a * CW + 3, rows.data() + b * CW + 3); });
+        std::vector<u64> lens(S + 1), woff(S + 1), firstK(S * W + 1), lastK(S * W + 1);
+        std::vector<std::pair<u64, u64>> fin(S);
+        u64 wsum = 0, bases = 0;
+        for (u64 i = 0; i < S; ++i) {
+            const u64 *r = rows.data() + order[i] * CW;
+            lens[i] = r[1] + (u64)(k - 1);
+            woff[i] = wsum; wsum += lens[i] / 32 + 1; bases += lens[i];
+            for (int w = 0; w < W; ++w) { firstK[i * W + w] = r[3 + W + w]; lastK[i * W + w] = r[3 + 2 * W + w]; }
+            fin[i] = {r[0], i};
+        }
+        woff[S] = wsum;
+        std::sort(fin.begin(), fin.end());
+        std::vector<u64> fs(S + 1), fi(S + 1);
+        for (u64 i = 0; i < S; ++i) { fs[i] = fin[i].first; fi[i] = fin[i].second; }
+        simp->nwords = wsum; simp->total_bases = bases;
+        KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
+        KC_TRY(kc_alloc(ctx, &simp->firstK, S * W + 1)); KC_TRY(kc_alloc(ctx, &simp->lastK, S * W + 1));
+        KC_TRY(kc_alloc(ctx, &simp->words, wsum + 2));
+        KC_TRY(scope.alloc(&fin_sorted, S + 1)); KC_TRY(scope.alloc(&fin_simp, S + 1));
+        KC_HIP(ctx, hipMemcpyAsync(simp->lens, lens.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(simp->woff, woff.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(simp->firstK, firstK.data(), (S * W + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(simp->lastK, lastK.data(), (S * W + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(fin_sorted, fs.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(fin_simp, fi.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(simp->words, 0, (wsum + 2) * 8, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    KC_HIP(ctx, hipEventRecord(e2, ctx->stream));
+    // ---------------- phase 2 (replicated) and the path ranking of phase 3
+    KcPathDev path;
+    KC_TRY(kco_overlap_path_device(simp, complements, 0, &path));
+    struct PathGuard { kc_ctx *c; KcPathDev *p; ~PathGuard() { kco_path_release(c, p); } } pathg{ctx, &path};
+    KC_HIP(ctx, hipEventRecord(e3, ctx->stream));
+    KcRank rk;
+    KC_TRY(kce_rank_path(simp, &path, &rk));
+    struct RankGuard { kc_ctx *c; KcRank *r; ~RankGuard() { kce_rank_release(c, r); } } rankg{ctx, &rk};
+    const u64 V = path.V, Ltot = rk.L;
+    // ---------------- phase 3: bases to the emitting ranks, emit
+    u8 *simp_dest = nullptr;
+    u64 *rank_rng = nullptr;
+    KC_TRY(scope.alloc(&simp_dest, S + 1)); KC_TRY(scope.alloc(&rank_rng, 2 * KC_MAX_RANKS_SH));
+    KC_HIP(ctx, hipMemsetAsync(rank_rng, 0xff, KC_MAX_RANKS_SH * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(rank_rng + KC_MAX_RANKS_SH, 0, KC_MAX_RANKS_SH * 8, ctx->stream));
+    hipLaunchKernelGGL(kc_shard_simp_dest_kernel, dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)rk.dist, (const u64 *)rk.endv, rk.start, S, V, Ltot, G, simp_dest,
+                       rank_rng, rank_rng + KC_MAX_RANKS_SH, (const u64 *)rk.weight);
+    u64 n_msg = 0;
+    {
+        u64 *mcount = nullptr, *moff = nullptr, *msgs = nullptr, *rmsgs = nullptr;
+        u8 *mdest = nullptr;
+        KC_TRY(scope.alloc(&mcount, n_ent + 2)); KC_TRY(scope.alloc(&moff, n_ent + 2));
+        if (n_ent)
+            hipLaunchKernelGGL((kc_shard_msg_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
+                               (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, W, (const u64 *)fin_sorted,
+                               (const u64 *)fin_simp, S, (const u64 *)simp->lens, (const u64 *)simp->woff, (const u8 *)simp_dest, mcount, (const u64 *)nullptr, (u64 *)nullptr, (u8 *)nullptr);
+        KC_TRY(kcu_exclusive_scan(ctx, mcount, moff, n_ent));
+        KC_TRY(read_words(ctx, moff + n_ent, &n_msg, 1));
+        KC_TRY(scope.alloc(&msgs, 2 * n_msg + 2)); KC_TRY(scope.alloc(&mdest, n_msg + 1));
+        if (n_ent)
+            hipLaunchKernelGGL((kc_shard_msg_kernel<true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
+                               (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, W, (const u64 *)fin_sorted,
+                               (const u64 *)fin_simp, S, (const u64 *)simp->lens, (const u64 *)simp->woff, (const u8 *)simp_dest, mcount, (const u64 *)moff, msgs, mdest);
+        KC_HIP(ctx, hipGetLastError());
+        KcRoute rt;
+        KC_TRY(kcr_build(c, mdest, n_msg, &rt));
+        int rc = kcr_forward(c, rt, msgs, 2, 2, &rmsgs);
+        if (rc == KC_OK && rt.n_recv)
+            hipLaunchKernelGGL(kc_shard_place_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rmsgs, rt.n_recv, simp->words);
+        (void)hipStreamSynchronize(ctx->stream);
+        kcr_free(ctx, &rt);
+        kc_release(ctx, rmsgs);
+        KC_TRY(rc);
+    }
+    u64 h_rng[2 * KC_MAX_RANKS_SH];
+    KC_TRY(read_words(ctx, rank_rng, h_rng, 2 * KC_MAX_RANKS_SH));
+    u64 lo = h_rng[me], hi = h_rng[KC_MAX_RANKS_SH + me];
+    if (lo == ~(u64)0) { lo = 0; hi = 0; }   // no block starts in this rank's share
+    kc_result *r = new kc_result();
+    r->ctx = ctx; r->length = Ltot; r->slice_off = lo; r->slice_len = hi - lo;
+    int rc = kc_alloc(ctx, &r->d_out, r->slice_len + 8);
+    if (rc == KC_OK && r->slice_len) rc = kce_emit_ranked(simp, &rk, lo, G, me, r->d_out);
+    KC_HIP(ctx, hipEventRecord(eend, ctx->stream));
+    KC_HIP(ctx, hipEventSynchronize(eend));
+    if (rc != KC_OK) { kc_result_destroy(r); return rc; }
+    r->stats[0] = N; r->stats[1] = S; r->stats[2] = Ltot; r->stats[4] = V; r->stats[5] = rounds;
+    r->stats[6] = (u64)(1000.0 * ev_ms(e0, e1)); r->stats[7] = (u64)(1000.0 * ev_ms(e1, e2));
+    r->stats[8] = (u64)(1000.0 * ev_ms(e2, e3)); r->stats[9] = (u64)(1000.0 * ev_ms(e3, eend));
+    r->stats[12] = set->cap; r->stats[13] = path.repairs; r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
+    r->stats[15] = N_local;
+    if (trace) fprintf(stderr, "[shard %d/%d] entries=%llu jump rounds=%llu chains(local winners)=%llu S=%llu messages=%llu slice=[%llu,%llu) of %llu\n", me, G,
+                       (unsigned long long)n_ent, (unsigned long long)rounds, (unsigned long long)n_chains, (unsigned long long)S, (unsigned long long)n_msg,
+                       (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)Ltot);
+    *out = r;
+    return KC_OK;
+}
+
+}  // namespace
+
+extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out) {
+    if (!ctx || !comm || !out || (!seq && len)) return KC_E_ARG;
+    *out = nullptr;
+    if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
+    if (k < 16 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 16 <= k <= 127");
+    if (flags & (KC_FLAG_SIMPLITIGS_INPUT | KC_FLAG_WANT_MASK) || ((flags >> 8) & 0xff) > 1)
+        return kc_fail(ctx, KC_E_ARG, "-S, -M and -z are not part of the hash-sharded path (use kc_compute)");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;
+    u8 *d_own = nullptr;
+    const u8 *d_seq = (const u8 *)seq;
+    if (!(flags & KC_FLAG_INPUT_ON_DEVICE)) {
+        KC_TRY(kc_alloc(ctx, &d_own, len + 64));
+        if (len) KC_HIP(ctx, hipMemcpyAsync(d_own, seq, len, hipMemcpyHostToDevice, ctx->stream));
+        d_seq = d_own;
+    }
+    int rc;
+    switch (kc_words_for_k(k)) {
+        case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, out); break;
+        case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, out); break;
+        default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, out); break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, d_own);
+    return rc;
+}

@@ -1,0 +1,350 @@
+// Device code of phase 1 (greedy simplitigs by de Bruijn neighbour lookup) shared by the single-GPU flow
+// (kc_simplitigs.hip) and the hash-sharded flow (kc_shard.hip): port-link words, the edge order of the canonical rule, the
+// batched neighbour lookup of round 1.  See kc_simplitigs.hip for the algorithm.
+#pragma once
+#include "kc_internal.h"
+
+#define LK_OPEN 0ull
+#define LK_CHOICE 1ull
+#define LK_MATCHED 2ull
+#define LK_DEAD 3ull
+#define LK_STATE(w) ((w) & 3ull)
+#define LK_PORT(w) (((w) >> 2) & 1ull)
+#define LK_BASE(w) (((w) >> 3) & 3ull)
+#define LK_REJ 32ull                  /* bit 5: the choice is not (yet) known to be reciprocated */
+#define LK_SPLIT (1ull << 63)          /* the node of this port is a splitter: a segment start for the parallel chain walks */
+#define LK_SLOT(w) (((w) & ~LK_SPLIT) >> 6)
+#define LK_PID(w) ((LK_SLOT(w) << 1) | LK_PORT(w))
+#define LK_MAKE(state, port, base, slot) ((u64)(state) | ((u64)(port) << 2) | ((u64)(base) << 3) | ((u64)(slot) << 6))
+// Round 1 needs no accept pass: the edge relation is symmetric, so a port's choice can only be unreciprocated if its
+// target had at least two candidates; such "branch" ports (rare) are listed by the choose kernel and send explicit
+// rejections (LK_REJ) to the candidates they did not choose.  A round-1 choice without LK_REJ is therefore mutual.
+// Later rounds write their tentative choices WITH LK_REJ and confirm them to LK_MATCHED in kc_accept_kernel.
+#define LK_IS_MATCHED(w) (LK_STATE(w) == LK_MATCHED || (LK_STATE(w) == LK_CHOICE && !((w) & LK_REJ)))
+
+// "edge (x,px)-(y1,q1) is preferred over edge (x,px)-(y2,q2)": higher priority first, ties by the ordered endpoint tuple.
+template <int W>
+__device__ __forceinline__ bool edge_preferred(const Key<W> &x, int px, const Key<W> &y1, int q1, u64 pr1, const Key<W> &y2, int q2,
+                                               u64 pr2) {
+    if (pr1 != pr2) return pr1 > pr2;
+    // tuple (ka,pa,kb,pb) with (ka,pa) <= (kb,pb)
+    bool x_first1 = key_lt(x, y1) || (key_eq(x, y1) && px <= q1);
+    bool x_first2 = key_lt(x, y2) || (key_eq(x, y2) && px <= q2);
+    const Key<W> &a1 = x_first1 ? x : y1; int pa1 = x_first1 ? px : q1;
+    const Key<W> &b1 = x_first1 ? y1 : x; int pb1 = x_first1 ? q1 : px;
+    const Key<W> &a2 = x_first2 ? x : y2; int pa2 = x_first2 ? px : q2;
+    const Key<W> &b2 = x_first2 ? y2 : x; int pb2 = x_first2 ? q2 : px;
+    if (!key_eq(a1, a2)) return key_lt(a1, a2);
+    if (pa1 != pa2) return pa1 < pa2;
+    if (!key_eq(b1, b2)) return key_lt(b1, b2);
+    return pb1 < pb2;
+}
+
+// A port that ends DEAD (no partner left) is the entry port of a directed chain: oriented node (slot, o = port).  Every
+// port ends either MATCHED or DEAD, so the heads are exactly the ports that die (unidirectional mode: the L ports).
+__device__ __forceinline__ void kc_push_head(u64 pid, int complements, u64 *heads, u64 heads_cap, u64 *heads_cursor) {
+    if (!complements && (pid & 1)) return;
+    u64 pos = atomicAdd((ull *)heads_cursor, 1ULL);
+    if (pos < heads_cap) heads[pos] = pid;
+}
+
+// Round 1 lists its heads and branch ports through KC_NSHARD cursors (one 128-byte line each, picked by workgroup): chain
+// heads are sparse (2 per simplitig), so the compiler's wave-level aggregation of the atomic leaves ~1 atomic per event,
+// and ~10^5..10^6 atomics on ONE address serialise at ~13 ns each -- longer than the kernel's real work.  The sharded
+// lists are gathered into one contiguous list afterwards (kc_gather_shards_kernel).
+#define KC_NSHARD 64
+#define KC_SHARD_STRIDE 16
+__device__ __forceinline__ void kc_push_sharded(u64 val, u64 *list, u64 shard_cap, u64 *cursors) {
+    const u64 sh = blockIdx.x & (KC_NSHARD - 1);
+    u64 pos = atomicAdd((ull *)&cursors[sh * KC_SHARD_STRIDE], 1ULL);
+    if (pos < shard_cap) list[sh * shard_cap + pos] = val;
+}
+// grid (x, KC_NSHARD): shard blockIdx.y is copied behind the shards before it; *total_out = total, or dst_cap + 1 when a
+// shard (or the destination) overflowed, which the caller treats like any other list overflow.
+static __global__ void __launch_bounds__(256) kc_gather_shards_kernel(const u64 *__restrict__ src, u64 shard_cap, const u64 *__restrict__ cursors,
+                                                               u64 *dst, u64 dst_cap, u64 *total_out) {
+    __shared__ u64 pre[KC_NSHARD + 1];
+    __shared__ int ovf;
+    if (threadIdx.x == 0) {
+        u64 a = 0;
+        int o = 0;
+        for (int sh = 0; sh < KC_NSHARD; ++sh) {
+            u64 c = cursors[sh * KC_SHARD_STRIDE];
+            if (c > shard_cap) { o = 1; c = shard_cap; }
+            pre[sh] = a;
+            a += c;
+        }
+        pre[KC_NSHARD] = a;
+        ovf = o || a > dst_cap;
+    }
+    __syncthreads();
+    const u64 sh = blockIdx.y, base = pre[sh], n = pre[sh + 1] - pre[sh];
+    if (!ovf)
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[base + i] = src[sh * shard_cap + i];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_out = ovf ? dst_cap + 1 : pre[KC_NSHARD];
+}
+
+// The 8 candidate lookups of one k-mer.  SH (hash-sharded table): a candidate whose home lies outside this rank's slot range is
+// not looked up; its slot comes back as KC_REMOTE and its home in chome[] (the owner answers the query later).
+#define KC_REMOTE (~(u64)1)
+template <int W> struct KcCand {
+    Key<W> x;        // the k-mer itself
+    Key<W> cy[8];    // candidate i = port (i >> 2), extension character (i & 3): canonical key
+    u64 cslot[8];    // its slot, KC_NONE64 (absent or not a legal edge), or KC_REMOTE
+    u64 chome[8];    // home slot of the candidate key
+    u32 qbits;       // bit i: the port on which candidate i is entered
+    bool xpal;       // x is its own reverse complement (links on port L only)
+};
+template <int W, int KC, bool SH>
+__device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, int complements, const u64 slot, const u64 *stage, const u64 sblk,
+                                               KcCand<W> &out) {
+    const int k = KC ? KC : k_rt;
+    const int m = KC ? 15 : set.m;
+    const Key<W> x = set_key_at(set, slot);
+    const Key<W> xr = key_rc(x, k);
+    const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
+    u32 sharedR = ~0u, sharedL = ~0u;   // min over m-mer positions 1..k-m (append side) / 0..k-m-1 (prepend side)
+    u32 f_first = 0, r_first = 0, f_last = 0, r_last = 0;   // first / last m-mer of x, forward and reverse complement
+    if (m) {
+        const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+        const int top = 2 * (m - 1);
+        u32 f = 0, r = 0;
+        if constexpr (W != 1) {
+#pragma unroll
+            for (int j = 0; j < m - 1; ++j) {
+                u32 b = key_at(x, k, j);
+                f = (f << 2) | b;
+                r = (r >> 2) | ((3u - b) << top);
+            }
+        }
+        u32 first = ~0u, mid = ~0u, last = ~0u;
+#pragma unroll
+        for (int i = 0; i <= k - m; ++i) {
+            if constexpr (W == 1) {   // one word: every m-mer is a shift of x / RC(x), no serial dependency between positions
+                f = (u32)(x.w[0] >> (2 * (k - m - i))) & maskm;
+                r = (u32)(xr.w[0] >> (2 * i)) & maskm;
+            } else {
+                u32 b = key_at(x, k, i + m - 1);
+                f = ((f << 2) | b) & maskm;
+                r = (r >> 2) | ((3u - b) << top);
+            }
+            u32 h = kc_mmer_hash(f, r);
+            if (i == 0) { first = h; f_first = f; r_first = r; }
+            if (i == k - m) last = h;
+            if (i != 0 && i != k - m) mid = h < mid ? h : mid;
+        }
+        f_last = f; r_last = r;
+        if (k - m == 0) { sharedR = ~0u; sharedL = ~0u; }
+        else { sharedR = mid < last ? mid : last; sharedL = mid < first ? mid : first; }
+    }
+    // The 8 candidate lookups are independent, so they are issued as a batch: (A) all candidate keys and their homes,
+    // (B) all first tag windows (one unaligned 8-byte load each), (C) the key loads of the tag hits, (D) compares.  A
+    // lookup that the first window does not settle (tag false positive, probe run longer than 8) is rare; those are
+    // redone by the generic scan in ONE loop after the batch, so a wave pays that latency once, not once per candidate.
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const int top = 2 * (m - 1);
+    // candidate (port, c): canonical key y, the port q it is entered on, placement hash and home
+    auto make_cand = [&](const int port, const u32 c, Key<W> &y, int &q, u64 &hy, u64 &home) {
+        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+        y = nf;
+        if (complements) {
+            Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
+            bool pal = (KC & 1) ? false : key_eq(nf, r);
+            bool fwd = !key_lt(r, nf);
+            if (!fwd) y = r;
+            q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
+        } else {
+            q = port ? 0 : 1;
+        }
+        hy = key_place_hash(y);
+        if (m) {
+            // the one m-mer the candidate does not share with x, one shift away from x's last / first m-mer
+            u32 nfw = port ? (((f_last << 2) | c) & maskm) : ((f_first >> 2) | (c << top));
+            u32 nrc = port ? ((r_last >> 2) | ((3u - c) << top)) : (((r_first << 2) | (3u - c)) & maskm);
+            u32 h = kc_mmer_hash(nfw, nrc);
+            const u32 shared = port ? sharedR : sharedL;
+            home = set_block_home(set, h < shared ? h : shared, hy);
+        } else home = kc_mulhi64(kc_mix64(hy), set.cap);
+    };
+    Key<W> (&cy)[8] = out.cy;
+    u64 (&chome)[8] = out.chome, (&cslot)[8] = out.cslot;
+    u64 cph[8], cword[8];
+    u32 live = 0, qbits = 0, remote = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int q;
+        make_cand(i >> 2, (u32)(i & 3), cy[i], q, cph[i], chome[i]);
+        const bool ok = !key_eq(cy[i], x) && !((i >> 2) == 1 && xpal);   // no self edges; palindromes link on port L only
+        live |= (u32)ok << i;
+        qbits |= (u32)q << i;
+    }
+    // first tag window of every candidate: from the staged block (LDS) when the home lies in it, else from global memory
+    u32 inblk = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 in = (chome[i] >> set.bshift) == sblk ? 1u : 0u;
+        inblk |= in << i;
+        if (SH) {   // homes in another rank's range are not addressable here: read x's own tag window instead (harmless), note the candidate
+            const u32 rem = (chome[i] - set.rlo >= set.rcap) ? 1u : 0u;
+            remote |= (rem & (live >> i)) << i;
+            if (rem) live &= ~(1u << i);
+            if (!in) __builtin_memcpy(&cword[i], set.tags + (rem ? slot : chome[i]), 8);
+        } else if (!in) __builtin_memcpy(&cword[i], set.tags + chome[i], 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if ((inblk >> i) & 1) {
+            const u32 o = (u32)chome[i] & ((1u << set.bshift) - 1u);
+            const u64 w0 = stage[o >> 3], w1 = stage[(o >> 3) + 1];
+            const u32 sh = (o & 7u) * 8u;
+            cword[i] = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+        }
+    // branch-free on purpose: a conditional here lets the compiler sink a candidate's load into the branch and wait for it
+    u32 pending = 0, slow = 0, settled2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u64 hi7 = 0x8080808080808080ULL, lo7 = 0x7f7f7f7f7f7f7f7fULL;
+        u32 t32 = kc_tag_of(cph[i]);
+        t32 |= t32 << 8; t32 |= t32 << 16;
+        const u64 xw = cword[i] ^ (((u64)t32 << 32) | t32);
+        const u64 zero = ~(((xw & lo7) + lo7) | xw | lo7);
+        const u64 empty = ~cword[i] & hi7;
+        u64 cand = zero | empty;
+        if (set.local_probes < 8) cand &= ((u64)1 << (8 * set.local_probes)) - 1;   // an empty slot proves a miss only inside the local probe run
+        const u32 lv = (live >> i) & 1u;
+        const u32 none = cand == 0 ? 1u : 0u;                        // window full of other tags: keep scanning (slow path)
+        const int b = __builtin_ctzll(cand | ((u64)1 << 63)) >> 3;
+        const u32 hit = (u32)(((empty >> (8 * b)) & 0x80) == 0) & (none ^ 1u);   // first candidate is a tag match, not an empty slot
+        u64 sl = chome[i] + (u64)b;
+        if (!SH) sl = sl >= set.cap ? sl - set.cap : sl;   // (plain hashing only; block homes keep their window inside the block)
+        const u32 pend = lv & hit;
+        // if that tag match turns out to be another key, the next candidate of the window usually is the empty slot
+        // that proves the miss: note it now, so that a tag false positive does not cost a trip through the slow path
+        const u64 cand2 = cand & (cand - 1);
+        const int b2 = __builtin_ctzll(cand2 | ((u64)1 << 63)) >> 3;
+        const u32 miss2 = (u32)(cand2 != 0) & (u32)(((empty >> (8 * b2)) & 0x80) != 0);
+        slow |= (lv & none) << i;
+        pending |= pend << i;
+        settled2 |= miss2 << i;
+        cslot[i] = pend ? sl : slot;   // non-pending candidates re-read x's own slot: an unconditional, harmless load
+    }
+    Key<W> ck[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ck[i] = set_key_at(set, cslot[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 pend = (pending >> i) & 1u;
+        const u32 eq = key_eq(ck[i], cy[i]) ? 1u : 0u;
+        slow |= (pend & (eq ^ 1u) & (((settled2 >> i) & 1u) ^ 1u)) << i;   // tag false positive, miss not proven yet: slow path
+        cslot[i] = (pend & eq) ? cslot[i] : KC_NONE64;
+    }
+    while (slow) {   // rare per lane, but some lane of nearly every wave gets here: redo only the scan, from the known home
+        const int i = __builtin_ctz(slow);
+        slow &= slow - 1;
+        Key<W> y; int q; u64 hy, home;
+        make_cand(i >> 2, (u32)(i & 3), y, q, hy, home);
+        const u64 ts = set_find_from(set, y, hy, home);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j == i) cslot[j] = ts;
+    }
+    if (SH) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((remote >> i) & 1) cslot[i] = KC_REMOTE;
+    }
+    out.x = x; out.qbits = qbits; out.xpal = xpal;
+}
+
+// Round 1: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
+// over the m-mer hashes whose prefix/suffix minima give both ports' shared minimizer part).
+// `stage` (LDS) holds the tag bytes of table block `sblk` (+ 8 bytes of the next one) when sblk != ~0: see the kernel below.
+template <int W, int KC>
+__device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *__restrict__ link, int k_rt, int complements, const u64 slot,
+                                                    const u64 *stage, const u64 sblk, u64 *heads, u64 heads_shard_cap, u64 *heads_cursors,
+                                                    u64 *branch, u64 branch_shard_cap, u64 *branch_cursors) {
+    KcCand<W> cd;
+    kc_cand_lookup<W, KC, false>(set, k_rt, complements, slot, stage, sblk, cd);
+    const Key<W> &x = cd.x;
+    const Key<W> (&cy)[8] = cd.cy;
+    const u64 (&cslot)[8] = cd.cslot;
+    const u32 qbits = cd.qbits;
+    const bool xpal = cd.xpal;
+    // every ~256th k-mer (by slot) is a splitter: chains are walked segment-wise between splitters
+    const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        const u64 pid = (slot << 1) | (u64)port;
+        if (port == 1 && xpal) {
+            link[pid] = LK_DEAD | splitbit;
+            if (complements) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);
+            continue;
+        }
+        int nfound = 0;
+        Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0, hxk = 0; u32 bbase = 0;
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c) {
+            const int i = port * 4 + (int)c;
+            const u64 tslot = cslot[i];
+            if (tslot == KC_NONE64) continue;
+            const Key<W> y = cy[i];
+            const int q = (int)((qbits >> i) & 1);
+            if (nfound == 0) { by = y; bq = q; bslot = tslot; bbase = port ? c : 3 - c; nfound = 1; continue; }
+            // priorities (the layout-free key hash) are only needed to choose between two existing candidates
+            if (nfound == 1) { hxk = key_hash(x); bpr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(by), bq)); nfound = 2; }
+            u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
+            if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bbase = port ? c : 3 - c; }
+        }
+        link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD) | splitbit;
+        if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+        if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);   // branch port: it has to reject the others
+    }
+}
+
+// The kernel: a workgroup owns KC_CHOOSE_SLOTS consecutive table slots (a quarter of an 8192-slot block) and first copies
+// the tag bytes of the whole block into LDS.  ~90 % of the candidate lookups start in that very block (shared minimizer),
+// so their tag windows are read from LDS instead of each dragging a 128-byte line through the L1: the kernel was bound by
+// exactly that L2->L1 fill traffic (8 scattered tag lines per k-mer), not by HBM, ALU work or latency.  The occupied slots
+// of its range are listed in LDS from the staged tags, so the lanes stay dense without any global list of occupied slots.
+#define KC_CHOOSE_SLOTS 2048
+template <int W, int KC>
+__global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
+                                                              u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
+                                                              u64 branch_shard_cap, u64 *branch_cursors, int stage_words) {
+    extern __shared__ u64 kc_stage[];
+    __shared__ unsigned short kc_list[KC_CHOOSE_SLOTS];
+    __shared__ u32 kc_nlist;
+    const u64 base = kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_SLOTS;
+    if (base >= set.cap) return;
+    if (threadIdx.x == 0) kc_nlist = 0;
+    u64 sblk = ~(u64)0;
+    if (stage_words) {
+        sblk = base >> set.bshift;
+        const u64 *src = reinterpret_cast<const u64 *>(set.tags + (sblk << set.bshift));
+        for (int j = threadIdx.x; j < stage_words; j += 256) kc_stage[j] = src[j];
+    }
+    __syncthreads();
+    // (blocks smaller than the slot range -- only with the KC_BSHIFT knob -- are staged for the window reads of the first
+    // block only; the occupancy of the whole range then comes from global memory)
+    const bool range_in_block = stage_words && ((u64)1 << set.bshift) >= (u64)KC_CHOOSE_SLOTS;
+    const u8 *tg = range_in_block ? reinterpret_cast<const u8 *>(kc_stage) + (base & (((u64)1 << set.bshift) - 1)) : set.tags + base;
+    for (u32 i = threadIdx.x; i < KC_CHOOSE_SLOTS; i += 256)
+        if (base + i < set.cap && tg[i] != 0) kc_list[atomicAdd(&kc_nlist, 1u)] = (unsigned short)i;
+    __syncthreads();
+    const u32 n = kc_nlist;
+#pragma unroll 1
+    for (u32 t = threadIdx.x; t < n; t += 256)
+        kc_choose_dense_one<W, KC>(set, link, k_rt, complements, base + kc_list[t], kc_stage, sblk, heads, heads_shard_cap, heads_cursors, branch,
+                                   branch_shard_cap, branch_cursors);
+}
+
+#define KC_CHUNK_WORDS 32
+#define KC_NO_CHUNK 0xffffffffu
+struct KcRec {
+    u64 *pool;          // chunks of KC_CHUNK_WORDS words
+    u32 *chunk_next;    // next chunk of the same walk
+    u64 pool_cap;       // chunks
+    u64 *pool_cursor;
+    u64 *chain_stream;  // per chain: first chunk (KC_NO_CHUNK if it has a single node)
+    u64 *chain_tail;    // per chain: oriented last node (slot << 1 | orientation)
+};

@@ -1,0 +1,247 @@
+// Small device utilities shared by the translation units: exclusive scan, ordered compaction (wave ballot + prefix scan),
+// and the message routing of the hash-sharded path (bin fixed-size items by destination rank, all-to-all, and the way back).
+// Hand-written for 64-wide wavefronts; no library calls.
+#include "kc_internal.h"
+#include "kc_comm.h"
+#include "kc_scan_dev.h"
+
+// ---------------------------------------------------------------------------------------------------- exclusive scan
+// Three launches per level: per-tile sums (2048 elements per 256-thread workgroup), scan of the tile sums (recursively),
+// tile-local scan with the tile's offset.  out may alias in; out[n] receives the total.
+#define KC_SCAN_TILE 2048
+__global__ void __launch_bounds__(256) kc_scan_sums_kernel(const u64 *__restrict__ in, u64 n, u64 *sums) {
+    const u64 base = (u64)blockIdx.x * KC_SCAN_TILE;
+    u64 s = 0;
+    for (u32 i = threadIdx.x; i < KC_SCAN_TILE; i += 256) if (base + i < n) s += in[base + i];
+    u64 tot;
+    (void)kc_block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) kc_scan_tile_kernel(const u64 *in, u64 n, const u64 *__restrict__ tile_off, u64 *out, u64 ntiles) {
+    const u64 base = (u64)blockIdx.x * KC_SCAN_TILE + (u64)threadIdx.x * 8;
+    u64 v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = base + i < n ? in[base + i] : 0; s += v[i]; }
+    u64 tot;
+    u64 ex = kc_block_excl_scan(s, &tot) + (tile_off ? tile_off[blockIdx.x] : 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
+    if (blockIdx.x == ntiles - 1 && threadIdx.x == 255) out[n] = ex;   // the last thread of the last tile ends at the total
+}
+int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n) {
+    if (n == 0) { KC_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return KC_OK; }
+    const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
+    if (ntiles == 1) {
+        hipLaunchKernelGGL(kc_scan_tile_kernel, dim3(1), dim3(256), 0, ctx->stream, in, n, (const u64 *)nullptr, out, (u64)1);
+        KC_HIP(ctx, hipGetLastError());
+        return KC_OK;
+    }
+    u64 *sums = nullptr;
+    KC_TRY(kc_alloc(ctx, &sums, ntiles + 1));
+    hipLaunchKernelGGL(kc_scan_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, sums);
+    int rc = kcu_exclusive_scan(ctx, sums, sums, ntiles);
+    if (rc == KC_OK) {
+        hipLaunchKernelGGL(kc_scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, (const u64 *)sums, out, ntiles);
+        if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "scan launch failed");
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, sums);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------- ordered compaction
+// out = the elements of `in` whose flag byte is non-zero, in order (stable).  Flags -> per-tile counts (wave ballot +
+// popcount), scan of the counts, then every tile writes its survivors at the tile offset + its in-tile rank.
+__global__ void __launch_bounds__(256) kc_flag_counts_kernel(const u8 *__restrict__ flags, u64 n, u64 *counts) {
+    const u64 base = (u64)blockIdx.x * KC_SCAN_TILE;
+    u64 c = 0;
+    for (u32 i = threadIdx.x; i < KC_SCAN_TILE; i += 256) if (base + i < n && flags[base + i]) ++c;
+    u64 tot;
+    (void)kc_block_excl_scan(c, &tot);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) kc_flag_write_kernel(const u64 *__restrict__ in, const u8 *__restrict__ flags, u64 n,
+                                                            const u64 *__restrict__ tile_off, u64 *out) {
+    // thread t owns the 8 consecutive elements base + 8t .. +7, so that ranks follow the element order
+    const u64 base = (u64)blockIdx.x * KC_SCAN_TILE + (u64)threadIdx.x * 8;
+    u64 c = 0;
+    u32 m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (base + i < n && flags[base + i]) { m |= 1u << i; ++c; }
+    u64 tot;
+    u64 pos = tile_off[blockIdx.x] + kc_block_excl_scan(c, &tot);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if ((m >> i) & 1) out[pos++] = in[base + i];
+}
+// d_total (device, optional) receives the number of survivors
+int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *out, u64 *d_total) {
+    if (n == 0) { if (d_total) KC_HIP(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream)); return KC_OK; }
+    const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
+    u64 *counts = nullptr;
+    KC_TRY(kc_alloc(ctx, &counts, ntiles + 1));
+    hipLaunchKernelGGL(kc_flag_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, flags, n, counts);
+    int rc = kcu_exclusive_scan(ctx, counts, counts, ntiles);
+    if (rc == KC_OK) {
+        hipLaunchKernelGGL(kc_flag_write_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, flags, n, (const u64 *)counts, out);
+        if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "compaction launch failed");
+        if (rc == KC_OK && d_total && hipMemcpyAsync(d_total, counts + ntiles, 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, counts);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------- sharded lists
+// Lists filled through KC_USHARDS cursors (one 128-byte line each): shard s owns the items [s * shard_cap, s * shard_cap + min(count_s, shard_cap)).
+// kcu_compact_shards copies them, E words per item, into one contiguous list and returns the total (or ~0 on overflow of a shard).
+__global__ void __launch_bounds__(256) kc_compact_shards_kernel(const u64 *__restrict__ src, u64 shard_cap, const u64 *__restrict__ cursors, int nshards,
+                                                                int stride, int E, u64 *dst) {
+    __shared__ u64 pre;
+    const int sh = blockIdx.y;
+    if (threadIdx.x == 0) {
+        u64 a = 0;
+        for (int s = 0; s < sh; ++s) { u64 c = cursors[(size_t)s * stride]; a += c > shard_cap ? shard_cap : c; }
+        pre = a;
+    }
+    __syncthreads();
+    u64 n = cursors[(size_t)sh * stride];
+    if (n > shard_cap) n = shard_cap;
+    const u64 words = n * (u64)E;
+    const u64 *s0 = src + (u64)sh * shard_cap * (u64)E;
+    u64 *d0 = dst + pre * (u64)E;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (u64)gridDim.x * blockDim.x) d0[i] = s0[i];
+}
+int kcu_compact_shards(kc_ctx *ctx, const u64 *src, u64 shard_cap, const u64 *d_cursors, int nshards, int stride, int E, u64 *dst, u64 *total, bool *overflow) {
+    std::vector<u64> h((size_t)nshards * stride);
+    KC_HIP(ctx, hipMemcpyAsync(h.data(), d_cursors, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u64 t = 0;
+    bool ovf = false;
+    for (int s = 0; s < nshards; ++s) { u64 c = h[(size_t)s * stride]; if (c > shard_cap) { ovf = true; c = shard_cap; } t += c; }
+    *total = t; *overflow = ovf;
+    if (t == 0 || ovf) return KC_OK;
+    hipLaunchKernelGGL(kc_compact_shards_kernel, dim3(64, nshards), dim3(256), 0, ctx->stream, src, shard_cap, d_cursors, nshards, stride, E, dst);
+    KC_HIP(ctx, hipGetLastError());
+    return KC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- routing
+// n items, item i goes to rank dest[i].  kcr_build bins them (LDS histogram per workgroup, one reservation per
+// destination and workgroup) into a permutation `perm` (send position -> item) and exchanges the counts;
+// kcr_forward moves E-word items to their destinations, kcr_backward brings A-word answers back into item order.
+#define KC_MAX_RANKS 64
+__global__ void __launch_bounds__(256) kc_route_count_kernel(const u8 *__restrict__ dest, u64 n, u64 *counts) {
+    __shared__ u32 h[KC_MAX_RANKS];
+    if (threadIdx.x < KC_MAX_RANKS) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&h[dest[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < KC_MAX_RANKS && h[threadIdx.x]) atomicAdd((ull *)&counts[threadIdx.x], (ull)h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) kc_route_perm_kernel(const u8 *__restrict__ dest, u64 n, const u64 *__restrict__ off, u64 *cursors, u64 *perm) {
+    __shared__ u32 h[KC_MAX_RANKS];
+    __shared__ u64 base[KC_MAX_RANKS];
+    const u64 tile = (u64)blockIdx.x * 2048;
+    if (threadIdx.x < KC_MAX_RANKS) h[threadIdx.x] = 0;
+    __syncthreads();
+    u32 mine[8]; u8 d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 i = tile + (u64)j * 256 + threadIdx.x;
+        d[j] = 0; mine[j] = 0;
+        if (i < n) { d[j] = dest[i]; mine[j] = atomicAdd(&h[d[j]], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < KC_MAX_RANKS && h[threadIdx.x]) base[threadIdx.x] = off[threadIdx.x] + atomicAdd((ull *)&cursors[threadIdx.x], (ull)h[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 i = tile + (u64)j * 256 + threadIdx.x;
+        if (i < n) perm[base[d[j]] + mine[j]] = i;
+    }
+}
+__global__ void __launch_bounds__(256) kc_route_gather_kernel(const u64 *__restrict__ items, const u64 *__restrict__ perm, u64 n, int E, int stride, u64 *send) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 *s = items + perm[t] * (u64)stride;
+    for (int w = 0; w < E; ++w) send[t * (u64)E + w] = s[w];
+}
+__global__ void __launch_bounds__(256) kc_route_scatter_kernel(const u64 *__restrict__ tmp, const u64 *__restrict__ perm, u64 n, int A, u64 *out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 *d = out + perm[t] * (u64)A;
+    for (int w = 0; w < A; ++w) d[w] = tmp[t * (u64)A + w];
+}
+
+int kcr_build(kc_comm *c, const u8 *dest, u64 n, KcRoute *r) {
+    kc_ctx *ctx = c->ctx;
+    const int G = c->world;
+    r->n = n; r->perm = nullptr;
+    r->scnt.assign(G, 0); r->soff.assign(G, 0); r->rcnt.assign(G, 0); r->roff.assign(G, 0);
+    u64 *cnt = nullptr;
+    KC_TRY(kc_alloc(ctx, &cnt, 3 * KC_MAX_RANKS));
+    KC_HIP(ctx, hipMemsetAsync(cnt, 0, 3 * KC_MAX_RANKS * 8, ctx->stream));
+    if (n) {
+        unsigned g = kc_grid(n, 256 * 16);
+        hipLaunchKernelGGL(kc_route_count_kernel, dim3(g), dim3(256), 0, ctx->stream, dest, n, cnt);
+    }
+    u64 h[KC_MAX_RANKS];
+    KC_HIP(ctx, hipMemcpyAsync(h, cnt, (size_t)G * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u64 o = 0;
+    for (int p = 0; p < G; ++p) { r->scnt[p] = h[p]; r->soff[p] = o; o += h[p]; }
+    // every rank learns what it will receive from whom
+    std::vector<u64> all((size_t)G * G);
+    int rc = kcc_allgather_words(c, r->scnt.data(), all.data(), G);
+    if (rc != KC_OK) { kc_release(ctx, cnt); return rc; }
+    o = 0;
+    for (int p = 0; p < G; ++p) { r->rcnt[p] = all[(size_t)p * G + c->rank]; r->roff[p] = o; o += r->rcnt[p]; }
+    r->n_recv = o;
+    if (n) {
+        rc = kc_alloc(ctx, &r->perm, n);
+        if (rc != KC_OK) { kc_release(ctx, cnt); return rc; }
+        KC_HIP(ctx, hipMemcpyAsync(cnt + KC_MAX_RANKS, r->soff.data(), (size_t)G * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(kc_route_perm_kernel, dim3(kc_grid(n, 2048)), dim3(256), 0, ctx->stream, dest, n, (const u64 *)(cnt + KC_MAX_RANKS), cnt + 2 * KC_MAX_RANKS, r->perm);
+        KC_HIP(ctx, hipGetLastError());
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the offsets were copied from a host vector)
+    }
+    kc_release(ctx, cnt);
+    return KC_OK;
+}
+void kcr_free(kc_ctx *ctx, KcRoute *r) { if (r->perm) { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, r->perm); r->perm = nullptr; } }
+
+// items: n rows of `stride` words, the first E of which travel.  *recv_out (n_recv * E words) is allocated here.
+int kcr_forward(kc_comm *c, const KcRoute &r, const u64 *items, int E, int stride, u64 **recv_out) {
+    kc_ctx *ctx = c->ctx;
+    const int G = c->world;
+    u64 *send = nullptr, *recv = nullptr;
+    KC_TRY(kc_alloc(ctx, &send, r.n * (u64)E + 1));
+    int rc = kc_alloc(ctx, &recv, r.n_recv * (u64)E + 1);
+    if (rc != KC_OK) { kc_release(ctx, send); return rc; }
+    if (r.n) hipLaunchKernelGGL(kc_route_gather_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, items, (const u64 *)r.perm, r.n, E, stride, send);
+    std::vector<u64> so(G), sc(G), ro(G), rcv(G);
+    for (int p = 0; p < G; ++p) { so[p] = r.soff[p] * E * 8; sc[p] = r.scnt[p] * E * 8; ro[p] = r.roff[p] * E * 8; rcv[p] = r.rcnt[p] * E * 8; }
+    rc = kcc_alltoallv(c, send, so.data(), sc.data(), recv, ro.data(), rcv.data());
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, send);
+    if (rc != KC_OK) { kc_release(ctx, recv); return rc; }
+    *recv_out = recv;
+    return KC_OK;
+}
+// answers: n_recv rows of A words (in the order the requests arrived); out: n rows of A words in item order
+int kcr_backward(kc_comm *c, const KcRoute &r, const u64 *answers, int A, u64 *out) {
+    kc_ctx *ctx = c->ctx;
+    const int G = c->world;
+    u64 *tmp = nullptr;
+    KC_TRY(kc_alloc(ctx, &tmp, r.n * (u64)A + 1));
+    std::vector<u64> so(G), sc(G), ro(G), rcv(G);
+    for (int p = 0; p < G; ++p) { so[p] = r.roff[p] * A * 8; sc[p] = r.rcnt[p] * A * 8; ro[p] = r.soff[p] * A * 8; rcv[p] = r.scnt[p] * A * 8; }
+    int rc = kcc_alltoallv(c, answers, so.data(), sc.data(), tmp, ro.data(), rcv.data());
+    if (rc == KC_OK && r.n) {
+        hipLaunchKernelGGL(kc_route_scatter_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, (const u64 *)tmp, (const u64 *)r.perm, r.n, A, out);
+        if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "route scatter launch failed");
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, tmp);
+    return rc;
+}

@@ -1,0 +1,67 @@
+"""One rank of a hash-sharded run, started by tests/test_gpu_sharded.py (and usable by hand):
+
+    python -m torch.distributed.run --nproc-per-node G tests/shard_worker.py <input> <k> <bi|uni> <out.npy> [--backend gloo|nccl]
+
+Every rank takes its contiguous share of the input's records, the ranks run kc_compute_sharded together, rank 0 collects
+the slices in rank order and stores the assembled superstring.  With the gloo backend all ranks may share one GPU
+(exchanges are staged through the host): that is how the multi-rank path is exercised on a 1-GPU box."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def split_records(recs, rank, world):
+    lo, hi = len(recs) * rank // world, len(recs) * (rank + 1) // world
+    return recs[lo:hi]
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import kmercamel_amd as kc
+    path, k, mode, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    backend = sys.argv[sys.argv.index("--backend") + 1] if "--backend" in sys.argv else "gloo"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    ndev = torch.cuda.device_count()
+    dev = int(os.environ.get("LOCAL_RANK", "0")) % max(1, ndev)
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo")
+    ctx = kc.Context(dev)
+    comm = kc.Comm.rccl(ctx, dist) if backend == "nccl" else kc.Comm.torch_host(ctx, dist)
+    recs = [r[2] for r in kc.read_records(path)]
+    mine = b"\n".join(split_records(recs, rank, world))
+    r = kc.compute_sharded(ctx, comm, mine, k, mode == "bi")
+    off, n = r.slice()
+    piece = r.array().copy()
+    stats = dict(r.stats)
+    r.close()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((off, n, piece.tobytes(), stats, comm.stats()), gathered, dst=0)
+    if rank == 0:
+        gathered.sort(key=lambda g: (g[0], g[1]))
+        pos, parts = 0, []
+        for off_r, n_r, b, _, _ in gathered:
+            if n_r == 0:
+                continue
+            assert off_r == pos, "slices do not tile the superstring: offset %d, expected %d" % (off_r, pos)
+            parts.append(b)
+            pos += n_r
+        assert pos == stats["length"], "slices cover %d of %d characters" % (pos, stats["length"])
+        np.save(out_path, np.frombuffer(b"".join(parts), dtype=np.uint8))
+        print("sharded ok: world=%d N=%d S=%d L=%d jump_rounds=%d bytes_sent(rank0)=%d" % (world, stats["n_kmers"], stats["n_simplitigs"], stats["length"],
+                                                                                         stats["matching_rounds"], gathered[0][4]["bytes_sent"]), flush=True)
+    comm.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
