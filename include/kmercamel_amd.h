@@ -138,6 +138,11 @@ int kc_comm_create_rccl(kc_ctx *ctx, int rank, int world, const void *id128, kc_
 void kc_comm_destroy(kc_comm *comm);
 /* stats[8]: 0 bytes sent, 1 bytes received, 2 collective calls, 3 microseconds spent inside them (host clock) */
 int kc_comm_stats(kc_comm *comm, uint64_t *stats);
+/* The partition itself, host side only (no GPU needed; the multi-rank CPU tests exercise it): geometry of the table for
+ * `total_occurrences` k-mer occurrences over `world` ranks -- out6 = {table blocks, log2 slots per block, blocks per rank,
+ * first global slot of `rank`, slots per rank, minimizer length} -- and the owner rank of n canonical k-mers (W words each). */
+int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, uint64_t *out6);
+int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner);
 /* The greedy branch of kmercamel<>() over all ranks' records: `seq`/`len` are THIS rank's records (joined by '\n', may be
  * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE (k >= 16; -S, -M and -z go
  * through the single-GPU kc_compute).  The result holds this rank's slice; stats as kc_result_stats with global counts. */

@@ -60,6 +60,8 @@ SIGNATURES = {
     "kc_comm_create_rccl": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vpp]),
     "kc_comm_destroy": (None, [_vp]),
     "kc_comm_stats": (ctypes.c_int, [_vp, _u64p]),
+    "kc_shard_geometry": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
+    "kc_shard_owner_of": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64, _u8p]),
     "kc_compute_sharded": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
     "kc_result_slice": (ctypes.c_int, [_vp, _u64p, _u64p]),
     "kc_maskopt_ones": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
@@ -508,6 +510,63 @@ _A2A_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _u64p
 _AG_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
 
 
+def host_transport(dist, group=None):
+    """The two host-buffer collectives kc_comm_create_callbacks asks for, over a torch.distributed process group (gloo):
+    (alltoallv(user, send, send_bytes, recv, recv_bytes), allgather(user, in, out, bytes_per_rank)), raw pointers in, 0 = ok.
+    `send` holds the bytes for rank 0, 1, ... back to back; `recv` receives rank 0's, 1's, ... bytes back to back."""
+    import torch
+    world = dist.get_world_size(group)
+
+    def view(ptr, nbytes):
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8)
+        return torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+
+    def a2a(user, send, send_bytes, recv, recv_bytes):
+        try:
+            sb = [int(send_bytes[i]) for i in range(world)]
+            rb = [int(recv_bytes[i]) for i in range(world)]
+            dist.all_to_all_single(view(recv, sum(rb)), view(send, sum(sb)), output_split_sizes=rb, input_split_sizes=sb, group=group)
+            return 0
+        except Exception as e:  # noqa: BLE001 -- an exception must not unwind through the C caller
+            print("kmercamel_amd: all-to-all callback failed: %r" % (e,), flush=True)
+            return 1
+
+    def ag(user, inp, out, nbytes):
+        try:
+            n = int(nbytes)
+            dist.all_gather_into_tensor(view(out, n * world), view(inp, n), group=group)
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("kmercamel_amd: all-gather callback failed: %r" % (e,), flush=True)
+            return 1
+
+    return a2a, ag
+
+
+def shard_geometry(k, total_occurrences, world, rank):
+    """kc_shard_geometry (host side, no GPU): dict of the table partition for `world` ranks"""
+    lib = load()
+    out = (ctypes.c_uint64 * 6)()
+    rc = lib.kc_shard_geometry(k, total_occurrences, world, rank, out)
+    if rc != KC_OK:
+        raise KcError(rc, "kc_shard_geometry")
+    return dict(zip(("nblocks", "bshift", "blocks_per_rank", "first_slot", "slots_per_rank", "minimizer_length"), [int(x) for x in out]))
+
+
+def shard_owner_of(k, total_occurrences, world, keys):
+    """kc_shard_owner_of (host side, no GPU): owner rank of canonical k-mers given as a numpy uint64 array of shape (n, W)"""
+    import numpy as np
+    lib = load()
+    a = np.ascontiguousarray(keys, dtype=np.uint64)
+    n = a.shape[0] if a.ndim == 2 else a.size // words_for_k(k)
+    out = np.empty(max(1, n), dtype=np.uint8)
+    rc = lib.kc_shard_owner_of(k, total_occurrences, world, a.ctypes.data_as(_u64p), n, out.ctypes.data_as(_u8p))
+    if rc != KC_OK:
+        raise KcError(rc, "kc_shard_owner_of")
+    return out[:n]
+
+
 class Comm:
     """Rank-to-rank transport of the hash-sharded path (kc_comm).
 
@@ -541,33 +600,8 @@ class Comm:
 
     @classmethod
     def torch_host(cls, ctx, dist, group=None):
-        import torch
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-
-        def view(ptr, nbytes):
-            if nbytes == 0:
-                return torch.empty(0, dtype=torch.uint8)
-            return torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
-
-        def a2a(user, send, send_bytes, recv, recv_bytes):
-            try:
-                sb = [int(send_bytes[i]) for i in range(world)]
-                rb = [int(recv_bytes[i]) for i in range(world)]
-                dist.all_to_all_single(view(recv, sum(rb)), view(send, sum(sb)), output_split_sizes=rb, input_split_sizes=sb, group=group)
-                return 0
-            except Exception as e:  # noqa: BLE001 -- an exception must not unwind through the C caller
-                print("kmercamel_amd: all-to-all callback failed: %r" % (e,), flush=True)
-                return 1
-
-        def ag(user, inp, out, nbytes):
-            try:
-                n = int(nbytes)
-                dist.all_gather_into_tensor(view(out, n * world), view(inp, n), group=group)
-                return 0
-            except Exception as e:  # noqa: BLE001
-                print("kmercamel_amd: all-gather callback failed: %r" % (e,), flush=True)
-                return 1
-
+        a2a, ag = host_transport(dist, group)
         fa, fg = _A2A_FN(a2a), _AG_FN(ag)
         h = ctypes.c_void_p()
         ctx.check(ctx.lib.kc_comm_create_callbacks(ctx.h, rank, world, ctypes.cast(fa, ctypes.c_void_p), ctypes.cast(fg, ctypes.c_void_p), None,

@@ -294,6 +294,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
 // finally the tag byte are written; a lane that finds "its" top word in an unpublished slot looks again in its next loop
 // iteration (nobody waits inside an iteration, so lanes of one wave cannot block each other).
 #define KC_MAX_SEG 64
+#define KC_MAX_DYN_LDS (160 * 1024 - 4096)   /* dynamic LDS limit requested for the build kernels (their static LDS is ~1 KB) */
 template <int W>
 __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
                                                               int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap,
@@ -602,19 +603,13 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     const unsigned tb = win <= 32 ? 256 : (win <= 64 ? 128 : 64);    // LDS: 2 * win * tb * 4 bytes (<= 64 KB) + staged run keys
     const size_t lds_scatter = (size_t)win * tb * 4 * 2 + (size_t)stage_cap * W * tb * 8;
     const u64 nthreads = (len + ppt - 1) / ppt;
-    static bool scatter_attr_done = false;
-    if (lds_scatter > 64 * 1024 && !scatter_attr_done) {
-        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        scatter_attr_done = true;
-    }
+    // (set on every call: the attribute belongs to the current device's copy of the kernel, and the call is cheap)
+    if (lds_scatter > 64 * 1024)
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
                        set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
     const size_t lds_build = (size_t)bs * (8 * W + 1);
-    static bool attr_done = false;
-    if (!attr_done) {
-        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_done = true;
-    }
+    KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     const int fresh = set->size_host == 0 ? 1 : 0;
     if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
     set->unclean = false;                        // the build kernel writes every slot, state and tag of every block
@@ -651,6 +646,50 @@ static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, co
 // ------------------------------------------------------------------------------------------------- hash-sharded set
 // The table geometry (block size, minimizer length, load) is that of kc_set_create for the TOTAL number of occurrences;
 // the number of blocks is rounded up to a multiple of the world size and rank r owns blocks [r * bpr, (r + 1) * bpr).
+struct ShardGeom { int W, mlen, bshift; u32 local_probes; u64 nblocks, bpr; };
+static ShardGeom shard_geometry(int k, u64 occ, int world, double load) {
+    ShardGeom g;
+    g.W = kc_words_for_k(k); g.mlen = 15; g.bshift = g.W == 4 ? 12 : 13; g.local_probes = 128;
+    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= bucketed_max_bshift(g.W)) g.bshift = v; }
+    if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) g.local_probes = (u32)v; }
+    if (g.local_probes + 8 >= ((u32)1 << g.bshift) / 2) g.local_probes = ((u32)1 << g.bshift) / 4;
+    const u64 bs = (u64)1 << g.bshift;
+    const u64 cap = (u64)((double)occ / load) + 1024;
+    u64 nblocks = (cap + bs - 1) >> g.bshift;
+    nblocks = (nblocks + world - 1) / world * world;
+    g.nblocks = nblocks; g.bpr = nblocks / world;
+    return g;
+}
+// Host-side description of the partition (needs no GPU): out[0] = table blocks in total, [1] = log2 slots per block,
+// [2] = blocks per rank, [3] = first global slot of `rank`, [4] = slots per rank, [5] = minimizer length.
+extern "C" int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, uint64_t *out6) {
+    if (!out6 || k < 16 || k > 127 || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
+    const ShardGeom g = shard_geometry(k, total_occurrences, world, 0.5);
+    out6[0] = g.nblocks; out6[1] = (u64)g.bshift; out6[2] = g.bpr; out6[3] = ((u64)rank * g.bpr) << g.bshift; out6[4] = g.bpr << g.bshift; out6[5] = (u64)g.mlen;
+    return KC_OK;
+}
+// owner rank of n canonical k-mers (W words each): the rank that holds the table block of the k-mer's canonical minimizer
+template <int W> static void owner_of_w(int k, const ShardGeom &g, const u64 *keys, u64 n, u8 *owner) {
+    SetView<W> v{nullptr, nullptr, nullptr, g.nblocks << g.bshift, g.nblocks, g.bshift, g.mlen, k, g.local_probes, 0, g.nblocks << g.bshift};
+    for (u64 i = 0; i < n; ++i) {
+        Key<W> key;
+        for (int w = 0; w < W; ++w) key.w[w] = keys[i * W + w];
+        const u64 home = set_block_home(v, key_min_mmh(key, k, g.mlen, 0, k - g.mlen), 0);
+        owner[i] = (u8)((home >> g.bshift) / g.bpr);
+    }
+}
+extern "C" int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner) {
+    if ((!keys || !owner) && n) return KC_E_ARG;
+    if (k < 16 || k > 127 || world < 1) return KC_E_ARG;
+    const ShardGeom g = shard_geometry(k, total_occurrences, world, 0.5);
+    switch (g.W) {
+        case 1: owner_of_w<1>(k, g, keys, n, owner); break;
+        case 2: owner_of_w<2>(k, g, keys, n, owner); break;
+        default: owner_of_w<4>(k, g, keys, n, owner); break;
+    }
+    return KC_OK;
+}
+
 int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out) {
     *out = nullptr;
     if (k < 16) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs k >= 16 (minimizer blocks)");
@@ -658,11 +697,6 @@ int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_
     KC_TRY(kcc_allreduce_sum(c, &occ, 1));
     kc_set *s = new kc_set();
     s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
-    s->mlen = 15;
-    s->bshift = s->W == 4 ? 12 : 13;
-    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= bucketed_max_bshift(s->W)) s->bshift = v; }
-    if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
-    if (s->local_probes + 8 >= ((u32)1 << s->bshift) / 2) s->local_probes = ((u32)1 << s->bshift) / 4;
     double load = 0.5;
     {
         size_t free_b = 0, total_b = 0;
@@ -672,11 +706,9 @@ int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_
         if (total_b && need > 0.6 * (double)total_b) load = 0.66;
     }
     if (const char *e = getenv("KC_LOAD")) { double v = atof(e); if (v >= 0.2 && v <= 0.9) load = v; }
-    const u64 bs = (u64)1 << s->bshift;
-    u64 cap = (u64)((double)occ / load) + 1024;
-    u64 nblocks = (cap + bs - 1) >> s->bshift;
-    nblocks = (nblocks + c->world - 1) / c->world * c->world;
-    const u64 bpr = nblocks / c->world;
+    const ShardGeom g = shard_geometry(k, occ, c->world, load);
+    s->mlen = g.mlen; s->bshift = g.bshift; s->local_probes = g.local_probes;
+    const u64 nblocks = g.nblocks, bpr = g.bpr;
     s->nblocks = nblocks; s->cap = nblocks << s->bshift;
     s->rcap = bpr << s->bshift; s->rlo = (u64)c->rank * s->rcap;
     int rc = kc_alloc(ctx, &s->keys, s->rcap * s->W);
@@ -709,7 +741,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     const size_t lds_scatter = (size_t)win * tb * 4 * 2 + (size_t)stage_cap * W * tb * 8;
     const u64 nthreads = (len + ppt - 1) / ppt;
     if (lds_scatter > 64 * 1024)
-        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     const bool have = len >= (u64)set->k;
     if (have)
         hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
@@ -749,7 +781,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     const u64 ovf_cap = (u64)1 << 20;
     KC_TRY(scope.alloc(&ovf, ovf_cap * W));
     const size_t lds_build = (size_t)bs * (8 * W + 1);
-    KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     set->unclean = false;
     hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
                        (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G);
