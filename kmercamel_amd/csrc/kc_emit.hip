@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
 // -M: every lower-case position p <= L-k is switched on iff the k-mer starting at p is in the set (global.h:185-195)
 template <int W>
 __global__ void __launch_bounds__(256) em_mask_kernel(const char *__restrict__ out, u64 L, int k, int complements, SetView<W> set, char *mask) {
-    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 p = kc_gtid();
     if (p >= L) return;
     char c = out[p];
     if (c <= 'Z' || p + (u64)k > L) { mask[p] = c; return; }
@@ -161,7 +161,7 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
     if (rc == KC_OK && d_mask && set_for_mask) {
         rc = kc_alloc(ctx, &mask, L + 1);
         if (rc == KC_OK) {
-            unsigned gm = kc_grid(L, 256);
+            const dim3 gm = kc_grid2(L, 256);
             switch (set_for_mask->W) {
                 case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<1>(set_for_mask), mask); break;
                 case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<2>(set_for_mask), mask); break;
@@ -186,7 +186,7 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
 template <int W, int PASS>
 __global__ void __launch_bounds__(256) mo_kernel(const char *__restrict__ ms, u64 len, int k, int complements, int minimize, SetView<W> set,
                                                  u64 *firstpos, char *out, u64 *bad) {
-    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 p = kc_gtid();
     if (p >= len) return;
     char c = ms[p];
     bool upper = c <= 'Z';
@@ -230,7 +230,7 @@ template <int W> static int maskopt_w(kc_ctx *ctx, const char *ms, u64 len, int 
     KC_HIP(ctx, hipMemsetAsync(firstpos, 0xff, set->cap * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
     SetView<W> sv = kc_view<W>(set);
-    unsigned g = kc_grid(len, 256);
+    const dim3 g = kc_grid2(len, 256);
     hipLaunchKernelGGL((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
     hipLaunchKernelGGL((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
     KC_HIP(ctx, hipGetLastError());

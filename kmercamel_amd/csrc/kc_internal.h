@@ -144,7 +144,23 @@ struct KcScope {
     }
 };
 
-static inline unsigned kc_grid(u64 n, unsigned block) { u64 g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
+// A dispatch carries its size in work-items as 32 bits per dimension: a 1-D launch of 2^32 or more threads is silently
+// truncated.  kc_grid refuses such a launch loudly; kernels that sweep table-sized ranges (> 2^32 slots at 2.5 G k-mers)
+// are launched on kc_grid2's 2-D grid and number their threads with kc_gtid().
+static inline unsigned kc_grid(u64 n, unsigned block) {
+    u64 g = (n + block - 1) / block;
+    if (g * block >= ((u64)1 << 32)) { fprintf(stderr, "kmercamel_amd: internal error: 1-D launch of %llu threads\n", (unsigned long long)(g * block)); abort(); }
+    return (unsigned)(g ? g : 1);
+}
+static inline dim3 kc_grid2(u64 n, unsigned block) {
+    u64 g = (n + block - 1) / block;
+    if (!g) g = 1;
+    const unsigned gx = g > ((u64)1 << 22) ? (1u << 22) : (unsigned)g;
+    return dim3(gx, (unsigned)((g + gx - 1) / gx));
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ u64 kc_gtid() { return ((u64)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; }
+#endif
 static inline unsigned kc_grid8(u64 n, unsigned block) { u64 g = (n + block - 1) / block; g = (g + 7) / 8 * 8; return (unsigned)(g ? g : 8); }  // for kc_xcd_block_id()
 
 // ---- kc_util.hip: scan / ordered compaction / sharded lists / message routing (hand-written, no library calls) ----

@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) kc_insert_list_kernel(SetView<W> set, con
 template <int W>
 __global__ void __launch_bounds__(256) kc_rehash_kernel(SetView<W> from, SetView<W> to, u64 *counters, const u32 *from_counts,
                                                         u32 *to_counts, u32 min_count) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 t = kc_gtid();
     if (t >= from.cap) return;
     if (!set_slot_full(from, t)) return;
     if (from_counts && from_counts[t] < min_count) return;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(256) kc_rehash_kernel(SetView<W> from, SetView
 
 template <int W>
 __global__ void __launch_bounds__(256) kc_export_kernel(SetView<W> set, u64 *out, u64 *cursor) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 t = kc_gtid();
     if (t >= set.cap) return;
     if (!set_slot_full(set, t)) return;
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256) kc_export_kernel(SetView<W> set, u64 *out
 
 template <int W>
 __global__ void __launch_bounds__(256) kc_contains_kernel(SetView<W> set, const u64 *keys, u64 n, u8 *out) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 t = kc_gtid();
     if (t >= n) return;
     Key<W> key;
     for (int i = 0; i < W; ++i) key.w[i] = keys[t * W + i];
@@ -526,7 +526,7 @@ static int kcs_rebuild(kc_set *set, u64 ncap, u64 nnblocks, u64 *nkeys, u32 *nst
         KC_HIP(ctx, hipMemsetAsync(ncounts, 0, ncap * 4, ctx->stream));
     }
     if (set->size_host) {
-        unsigned g = kc_grid(set->cap, 256);
+        const dim3 g = kc_grid2(set->cap, 256);
         switch (set->W) {
             case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), view_of<1>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
             case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), view_of<2>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
@@ -902,7 +902,7 @@ extern "C" int kc_set_export(kc_set *set, uint64_t *out_words) {
     KC_TRY(kc_alloc(ctx, &d_out, n * set->W));
     KC_TRY(kc_alloc(ctx, &cursor, 1));
     KC_HIP(ctx, hipMemsetAsync(cursor, 0, 8, ctx->stream));
-    unsigned g = kc_grid(set->cap, 256);
+    const dim3 g = kc_grid2(set->cap, 256);
     switch (set->W) {
         case 1: hipLaunchKernelGGL(kc_export_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_out, cursor); break;
         case 2: hipLaunchKernelGGL(kc_export_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_out, cursor); break;
@@ -924,7 +924,7 @@ extern "C" int kc_set_contains(kc_set *set, const uint64_t *key_words, uint64_t 
     KC_TRY(kc_alloc(ctx, &d_keys, n * set->W));
     KC_TRY(kc_alloc(ctx, &d_out, n));
     KC_HIP(ctx, hipMemcpyAsync(d_keys, key_words, n * set->W * 8, hipMemcpyHostToDevice, ctx->stream));
-    unsigned g = kc_grid(n, 256);
+    const dim3 g = kc_grid2(n, 256);
     switch (set->W) {
         case 1: hipLaunchKernelGGL(kc_contains_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_keys, n, d_out); break;
         case 2: hipLaunchKernelGGL(kc_contains_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_keys, n, d_out); break;

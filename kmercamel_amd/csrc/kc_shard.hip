@@ -182,7 +182,7 @@ template <int W> __device__ __forceinline__ Key<W> kc_neighbour_key(const Key<W>
 template <int W>
 __global__ void __launch_bounds__(256) kc_shard_resolve_kernel(SetView<W> set, u64 *link, int k, int complements, const u64 *__restrict__ rec, u64 rec_scap,
                                                                const u64 *__restrict__ rec_cur, u64 *edges, u64 edge_cap, u64 *edge_cursor) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = kc_gtid();
     const u64 shard = t / rec_scap, pos = t - shard * rec_scap;
     if (shard >= KC_USH) return;
     u64 cnt = rec_cur[shard * KC_USTRIDE];
@@ -351,6 +351,65 @@ __global__ void __launch_bounds__(256) kc_shard_apply_jump_kernel(const u64 *__r
     nxt[e] = ans[3 * t];
     dist[e] += ans[3 * t + 1];
     if (ans[3 * t] == KC_NONE64) last[e] = ans[3 * t + 2];
+}
+
+// ---- cycles.  K-mers all of whose ports are matched and that no entry reaches lie on cycles inside this rank: they are
+// listed here and cut by kc_cycles_parallel_kernel / kc_cycles_kernel (kc_simp_dev.h).  Fragments that never reach a chain
+// end lie on cycles that span ranks: each reports its smallest key, the ranks agree on every cycle's minimum (host, the
+// cycles are few) and the owner cuts it on that k-mer's port L -- the same cut as the single-GPU flow and the oracle.
+__global__ void __launch_bounds__(256) kc_shard_sum_kernel(const u64 *__restrict__ a, u64 n, u64 *out) {
+    u64 s = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += a[i];
+    u64 tot;
+    (void)kc_block_excl_scan(s, &tot);
+    if (threadIdx.x == 0 && tot) atomicAdd((ull *)out, (ull)tot);
+}
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_shard_unvisited_kernel(const u8 *__restrict__ tags, const u8 *__restrict__ visited, u64 rlo, u64 rcap, u64 *list, u64 *cursor) {
+    const u64 t = kc_gtid();
+    if (t >= rcap || tags[rlo + t] == 0 || visited[t]) return;
+    const u64 pos = atomicAdd((ull *)cursor, 1ULL);
+    if (FILL) list[pos] = rlo + t;
+}
+// rows {fragment id, successor id, slot of the smallest key, that key} of the fragments in `act`
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_cycle_rows_kernel(SetView<W> set, const u64 *__restrict__ link, u64 rlo, u64 rcap, const u64 *__restrict__ act, u64 n,
+                                                                  const u64 *__restrict__ entries, const u64 *__restrict__ succ0, int me, u64 *rows) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = act[t], h = entries[e];
+    u64 cur = h >> 1, best = cur;
+    int co = (int)(h & 1);
+    Key<W> bk = set_key_at(set, cur);
+    while (true) {
+        const u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+        if (!LK_IS_MATCHED(w) || LK_SLOT(w) - rlo >= rcap) break;
+        cur = LK_SLOT(w);
+        co = LK_PORT(w) == 0 ? 0 : 1;
+        const Key<W> ck = set_key_at(set, cur);
+        if (key_lt(ck, bk)) { bk = ck; best = cur; }
+    }
+    u64 *r = rows + t * (3 + W);
+    r[0] = KC_GID(me, e); r[1] = succ0[e]; r[2] = best;
+    for (int w = 0; w < W; ++w) r[3 + w] = bk.w[w];
+}
+// cut the listed k-mers (those on this rank) on their port L; partner[i] = the port that faced it (KC_NONE64 for foreign slots)
+__global__ void __launch_bounds__(256) kc_shard_cut_kernel(u64 *link, const u64 *__restrict__ slots, u64 n, u64 rlo, u64 rcap, u64 *partner) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    partner[t] = KC_NONE64;
+    const u64 slot = slots[t];
+    if (slot - rlo >= rcap) return;
+    const u64 w = link[slot << 1];
+    if (!LK_IS_MATCHED(w)) return;
+    partner[t] = LK_PID(w);
+    link[slot << 1] = LK_DEAD;
+}
+__global__ void __launch_bounds__(256) kc_shard_kill_kernel(u64 *link, const u64 *__restrict__ pids, u64 n, u64 rlo2, u64 rcap2) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 pid = pids[t];
+    if (pid != KC_NONE64 && pid - rlo2 < rcap2) link[pid] = LK_DEAD;
 }
 
 // ---- chain heads: fragments whose entry port is dead.  They ask the owner of the chain's final fragment for the tail
@@ -627,11 +686,13 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         L.rec_scap = rec_scap; L.qry_scap = qry_scap;
         L.rec_cur = cur; L.qry_cur = cur + KC_USH * KC_USTRIDE; L.flags = cur + 2 * KC_USH * KC_USTRIDE;
         KC_HIP(ctx, hipMemsetAsync(cur, 0, (2 * KC_USH + 4) * KC_USTRIDE * 8, ctx->stream));
+        KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
         if (k == KSPEC && !getenv("KC_NO_KSPEC"))
             hipLaunchKernelGGL((kc_shard_choose_kernel<W, KSPEC>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
         else
             hipLaunchKernelGGL((kc_shard_choose_kernel<W, 0>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
         KC_HIP(ctx, hipGetLastError());
+        KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
         u64 ovf = 0;
         KC_TRY(read_words(ctx, L.flags, &ovf, 1));
         u64 any = ovf;
@@ -679,7 +740,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         for (int attempt = 0;; ++attempt) {
             KC_TRY(scope.alloc(&edges, edge_cap * EW));
             KC_HIP(ctx, hipMemsetAsync(ecur, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_shard_resolve_kernel<W>), dim3(kc_grid(rec_scap * KC_USH, 256)), dim3(256), 0, ctx->stream, sv, link, k, complements,
+            hipLaunchKernelGGL((kc_shard_resolve_kernel<W>), kc_grid2(rec_scap * KC_USH, 256), dim3(256), 0, ctx->stream, sv, link, k, complements,
                                (const u64 *)L.rec, rec_scap, (const u64 *)L.rec_cur, edges, edge_cap, ecur);
             KC_HIP(ctx, hipGetLastError());
             KC_TRY(read_words(ctx, ecur, &n_branch_edges, 1));
@@ -712,89 +773,175 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     }
     if (trace) fprintf(stderr, "[shard %d/%d] N_local=%llu N=%llu queries=%llu branch edges (all ranks)=%llu\n", me, G, (unsigned long long)N_local,
                        (unsigned long long)N, (unsigned long long)nq, (unsigned long long)n_branch_edges);
-    // ---------------- phase 1b: fragments
+    // ---------------- phase 1b: fragments (the discovery restarts after a cycle has been cut)
     u64 *entries = nullptr, n_ent = 0;
-    {
-        const u64 ntiles = (rcap + 2047) / 2048;
-        u64 *tcount = nullptr;
-        KC_TRY(scope.alloc(&tcount, ntiles + 2));
-        hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
-                           (const u64 *)nullptr, tcount);
-        KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
-        KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
-        KC_TRY(scope.alloc(&entries, n_ent + 1));
-        hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
-                           (const u64 *)tcount, entries);
-        KC_HIP(ctx, hipGetLastError());
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        scope.release(tcount);
-    }
-    if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
-    u64 *f_exit = nullptr, *f_partner = nullptr, *f_len = nullptr, *nxt = nullptr, *dist = nullptr, *last = nullptr, *iota = nullptr, *act = nullptr;
+    u64 *f_exit = nullptr, *f_partner = nullptr, *f_len = nullptr, *nxt = nullptr, *dist = nullptr, *last = nullptr, *iota = nullptr, *act = nullptr, *succ0 = nullptr;
     u32 *f_stream = nullptr, *fidx = nullptr, *chunk_next = nullptr;
     u64 *pool = nullptr;
     u8 *flags8 = nullptr;
-    KC_TRY(scope.alloc(&f_exit, n_ent + 1)); KC_TRY(scope.alloc(&f_partner, n_ent + 1)); KC_TRY(scope.alloc(&f_len, n_ent + 1));
-    KC_TRY(scope.alloc(&f_stream, n_ent + 1)); KC_TRY(scope.alloc(&fidx, 2 * rcap));
-    KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1));
-    KC_TRY(scope.alloc(&iota, n_ent + 1)); KC_TRY(scope.alloc(&act, n_ent + 1)); KC_TRY(scope.alloc(&flags8, n_ent + 1));
-    FragRec frec{};
-    frec.pool_cap = n_ent + 2 * N_local / (32 * KC_FCW) + 1024;
-    KC_TRY(scope.alloc(&pool, frec.pool_cap * KC_FCW)); KC_TRY(scope.alloc(&chunk_next, frec.pool_cap));
-    frec.pool = pool; frec.chunk_next = chunk_next; frec.pool_cursor = cur;
-    KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
-    if (n_ent) {
-        hipLaunchKernelGGL((kc_shard_walk_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
-                           f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE);
-        hipLaunchKernelGGL(kc_shard_jump_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)f_partner, (const u64 *)f_len, n_ent, me, nxt, dist, last);
-        hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
-    }
-    KC_HIP(ctx, hipGetLastError());
-    {
-        u64 pf = 0;
-        KC_TRY(read_words(ctx, cur + KC_USTRIDE, &pf, 1));
-        if (pf) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted");
-    }
-    // pointer jumping
-    u64 rounds = 0, prev_active = ~(u64)0;
-    for (int round = 0;; ++round) {
-        u64 n_act = 0;
+    KC_TRY(scope.alloc(&fidx, 2 * rcap));
+    u64 rounds = 0, cycles_cut = 0;
+    for (int pass = 0;; ++pass) {
+        if (pass == 64) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not settle after cutting cycles");
+        // entries, fragment walks; cycles inside this rank are cut on the spot (no exchange involved)
+        for (int lpass = 0;; ++lpass) {
+            const u64 ntiles = (rcap + 2047) / 2048;
+            u64 *tcount = nullptr;
+            KC_TRY(scope.alloc(&tcount, ntiles + 2));
+            hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                               (const u64 *)nullptr, tcount);
+            KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
+            KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
+            if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
+            KC_TRY(scope.alloc(&entries, n_ent + 1));
+            hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                               (const u64 *)tcount, entries);
+            KC_HIP(ctx, hipGetLastError());
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            scope.release(tcount);
+            KC_TRY(scope.alloc(&f_exit, n_ent + 1)); KC_TRY(scope.alloc(&f_partner, n_ent + 1)); KC_TRY(scope.alloc(&f_len, n_ent + 1));
+            KC_TRY(scope.alloc(&f_stream, n_ent + 1));
+            FragRec frec{};
+            frec.pool_cap = n_ent + 2 * N_local / (32 * KC_FCW) + 1024;
+            KC_TRY(scope.alloc(&pool, frec.pool_cap * KC_FCW)); KC_TRY(scope.alloc(&chunk_next, frec.pool_cap));
+            frec.pool = pool; frec.chunk_next = chunk_next; frec.pool_cursor = cur;
+            KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
+            if (n_ent) {
+                hipLaunchKernelGGL((kc_shard_walk_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                                   f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE);
+                hipLaunchKernelGGL(kc_shard_sum_kernel, dim3(256), dim3(256), 0, ctx->stream, (const u64 *)f_len, n_ent, cur + 2 * KC_USTRIDE);
+            }
+            KC_HIP(ctx, hipGetLastError());
+            u64 hw[3 * KC_USTRIDE];
+            KC_TRY(read_words(ctx, cur, hw, 3 * KC_USTRIDE));
+            if (hw[KC_USTRIDE]) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted");
+            const u64 walked = hw[2 * KC_USTRIDE] / (complements ? 2 : 1);
+            if (walked == N_local) break;
+            // some k-mers are reached by no fragment: cycles that stay inside this rank
+            if (lpass == 3) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
+            u8 *visited = nullptr;
+            u64 *ulist = nullptr, *dummy_heads = nullptr, nunvis = 0;
+            KC_TRY(scope.alloc(&visited, rcap));
+            KC_HIP(ctx, hipMemsetAsync(visited, 0, rcap, ctx->stream));
+            if (n_ent)
+                hipLaunchKernelGGL((kc_shard_walk_kernel<true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                                   f_exit, f_partner, f_len, f_stream, fidx, frec, visited, cur + KC_USTRIDE);
+            KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
+            hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
+            KC_TRY(read_words(ctx, cur + 3 * KC_USTRIDE, &nunvis, 1));
+            if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree");
+            KC_TRY(scope.alloc(&ulist, nunvis)); KC_TRY(scope.alloc(&dummy_heads, 2 * nunvis + 2));
+            KC_HIP(ctx, hipMemsetAsync(cur + 3 * KC_USTRIDE, 0, 8, ctx->stream));
+            hipLaunchKernelGGL((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
+            if (lpass == 0)
+                hipLaunchKernelGGL((kc_cycles_parallel_kernel<W>), dim3(kc_grid(nunvis, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, complements, dummy_heads, cur, (u64)4096);
+            else
+                hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited - rlo, complements, dummy_heads, cur);
+            KC_HIP(ctx, hipGetLastError());
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ++cycles_cut;
+            scope.release(visited); scope.release(ulist); scope.release(dummy_heads);
+            scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
+        }
+        KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1)); KC_TRY(scope.alloc(&succ0, n_ent + 1));
+        KC_TRY(scope.alloc(&iota, n_ent + 1)); KC_TRY(scope.alloc(&act, n_ent + 1)); KC_TRY(scope.alloc(&flags8, n_ent + 1));
         if (n_ent) {
-            hipLaunchKernelGGL(kc_shard_active_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)nxt, n_ent, flags8);
-            KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
-            KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_act, 1));
+            hipLaunchKernelGGL(kc_shard_jump_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)f_partner, (const u64 *)f_len, n_ent, me, nxt, dist, last);
+            hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
         }
-        u64 tot_act = n_act;
-        KC_TRY(kcc_allreduce_sum(c, &tot_act, 1));
-        if (tot_act == 0) break;
-        if (round > 1 && tot_act >= prev_active)
-            return kc_fail(ctx, KC_E_ARG, "the k-mer set contains cycles that span several ranks: not supported by the hash-sharded path yet");
-        if (round > 0) prev_active = tot_act;
-        u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
-        u8 *dest = nullptr;
-        const int A = round == 0 ? 1 : 3;
-        KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
-        if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, round == 0 ? 1 : 0, 2 * rcap, req, dest);
-        KcRoute rt;
-        KC_TRY(kcr_build(c, dest, n_act, &rt));
-        int rc = kcr_forward(c, rt, req, 1, 1, &rq);
-        if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * A + 1);
-        if (rc == KC_OK && rt.n_recv) {
-            if (round == 0) hipLaunchKernelGGL(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
-            else hipLaunchKernelGGL(kc_shard_ans_jump_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u64 *)nxt, (const u64 *)dist, (const u64 *)last, ans);
+        KC_HIP(ctx, hipGetLastError());
+        // pointer jumping
+        u64 prev_active = ~(u64)0, n_act = 0;
+        bool stalled = false;
+        for (int round = 0;; ++round) {
+            n_act = 0;
+            if (n_ent) {
+                hipLaunchKernelGGL(kc_shard_active_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)nxt, n_ent, flags8);
+                KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
+                KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_act, 1));
+            }
+            u64 tot_act = n_act;
+            KC_TRY(kcc_allreduce_sum(c, &tot_act, 1));
+            if (tot_act == 0) break;
+            if (round > 1 && tot_act >= prev_active) { stalled = true; break; }   // only fragments on cycles are left
+            if (round > 0) prev_active = tot_act;
+            u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
+            u8 *dest = nullptr;
+            const int A = round == 0 ? 1 : 3;
+            KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
+            if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, round == 0 ? 1 : 0, 2 * rcap, req, dest);
+            KcRoute rt;
+            KC_TRY(kcr_build(c, dest, n_act, &rt));
+            int rc = kcr_forward(c, rt, req, 1, 1, &rq);
+            if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * A + 1);
+            if (rc == KC_OK && rt.n_recv) {
+                if (round == 0) hipLaunchKernelGGL(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
+                else hipLaunchKernelGGL(kc_shard_ans_jump_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u64 *)nxt, (const u64 *)dist, (const u64 *)last, ans);
+            }
+            if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, n_act * A + 1);
+            if (rc == KC_OK) rc = kcr_backward(c, rt, ans, A, ansb);
+            if (rc == KC_OK && n_act) {
+                if (round == 0) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
+                else hipLaunchKernelGGL(kc_shard_apply_jump_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt, dist, last);
+            }
+            if (rc == KC_OK && round == 0 && n_ent && hipMemcpyAsync(succ0, nxt, n_ent * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+            (void)hipStreamSynchronize(ctx->stream);
+            kcr_free(ctx, &rt);
+            kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
+            scope.release(req); scope.release(dest);
+            KC_TRY(rc);
+            ++rounds;
         }
-        if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, n_act * A + 1);
-        if (rc == KC_OK) rc = kcr_backward(c, rt, ans, A, ansb);
-        if (rc == KC_OK && n_act) {
-            if (round == 0) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
-            else hipLaunchKernelGGL(kc_shard_apply_jump_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt, dist, last);
+        if (!stalled) break;
+        // cycles that span ranks: agree on every cycle's smallest k-mer, cut there, start over
+        {
+            const int RW = 3 + W;
+            u64 *rows = nullptr, *all = nullptr, n_all = 0;
+            KC_TRY(scope.alloc(&rows, (n_act + 1) * RW));
+            if (n_act)
+                hipLaunchKernelGGL((kc_shard_cycle_rows_kernel<W>), dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, rlo, rcap, (const u64 *)act, n_act,
+                                   (const u64 *)entries, (const u64 *)succ0, me, rows);
+            KC_TRY(allgather_rows(c, rows, n_act, RW, &all, &n_all, nullptr));
+            scope.release(rows);
+            std::vector<u64> h(n_all * RW), cuts;
+            KC_HIP(ctx, hipMemcpyAsync(h.data(), all, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            kc_release(ctx, all);
+            std::unordered_map<u64, u64> at;
+            at.reserve(n_all * 2);
+            for (u64 i = 0; i < n_all; ++i) at[h[i * RW]] = i;
+            std::vector<u8> seen(n_all, 0);
+            std::unordered_set<u64> cut_set;
+            for (u64 i = 0; i < n_all; ++i) {
+                if (seen[i]) continue;
+                u64 j = i, best = i, steps = 0;
+                bool closed = false;
+                while (!seen[j]) {
+                    seen[j] = 1;
+                    if (hkey_lt<W>(h.data() + j * RW + 3, h.data() + best * RW + 3)) best = j;
+                    auto it = at.find(h[j * RW + 1]);
+                    if (it == at.end()) break;          // leads to a fragment that did terminate: not a cycle after all
+                    j = it->second;
+                    if (j == i) { closed = true; break; }
+                    if (++steps > n_all) break;
+                }
+                if (closed && cut_set.insert(h[best * RW + 2]).second) cuts.push_back(h[best * RW + 2]);
+            }
+            if (cuts.empty()) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle");
+            u64 *dcuts = nullptr, *partner = nullptr, *allp = nullptr, n_allp = 0;
+            KC_TRY(scope.alloc(&dcuts, cuts.size())); KC_TRY(scope.alloc(&partner, cuts.size()));
+            KC_HIP(ctx, hipMemcpyAsync(dcuts, cuts.data(), cuts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(kc_shard_cut_kernel, dim3(kc_grid(cuts.size(), 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dcuts, (u64)cuts.size(), rlo, rcap, partner);
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            KC_TRY(allgather_rows(c, partner, cuts.size(), 1, &allp, &n_allp, nullptr));
+            if (n_allp) hipLaunchKernelGGL(kc_shard_kill_kernel, dim3(kc_grid(n_allp, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)allp, n_allp, 2 * rlo, 2 * rcap);
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            kc_release(ctx, allp);
+            scope.release(dcuts); scope.release(partner);
+            cycles_cut += cuts.size();
         }
-        (void)hipStreamSynchronize(ctx->stream);
-        kcr_free(ctx, &rt);
-        kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
-        scope.release(req); scope.release(dest);
-        KC_TRY(rc);
-        ++rounds;
+        scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
+        scope.release(nxt); scope.release(dist); scope.release(last); scope.release(succ0); scope.release(iota); scope.release(act); scope.release(flags8);
     }
     // chain heads gather their tails; winners become chain records
     const int CW = 3 + 3 * W;
@@ -835,7 +982,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     {
         u64 tot = covered;
         KC_TRY(kcc_allreduce_sum(c, &tot, 1));
-        if (tot != N) return kc_fail(ctx, KC_E_ARG, "the k-mer set contains cycles (" + std::to_string(N - tot) + " k-mers on them): not supported by the hash-sharded path yet");
+        if (tot != N) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery covers " + std::to_string(tot) + " of " + std::to_string(N) + " k-mers");
     }
     // ---------------- the replicated simplitig list
     u64 *all_chains = nullptr, S = 0;
@@ -941,8 +1088,11 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     r->stats[0] = N; r->stats[1] = S; r->stats[2] = Ltot; r->stats[4] = V; r->stats[5] = rounds;
     r->stats[6] = (u64)(1000.0 * ev_ms(e0, e1)); r->stats[7] = (u64)(1000.0 * ev_ms(e1, e2));
     r->stats[8] = (u64)(1000.0 * ev_ms(e2, e3)); r->stats[9] = (u64)(1000.0 * ev_ms(e3, eend));
+    r->stats[10] = (u64)(1000.0 * ev_ms(ctx->ev[4], ctx->ev[5]));   // neighbour-probe kernel (kc_shard_choose_kernel)
+    r->stats[11] = nq;                                              // neighbour queries this rank sent
     r->stats[12] = set->cap; r->stats[13] = path.repairs; r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
     r->stats[15] = N_local;
+    r->stats[3] = cycles_cut;
     if (trace) fprintf(stderr, "[shard %d/%d] entries=%llu jump rounds=%llu chains(local winners)=%llu S=%llu messages=%llu slice=[%llu,%llu) of %llu\n", me, G,
                        (unsigned long long)n_ent, (unsigned long long)rounds, (unsigned long long)n_chains, (unsigned long long)S, (unsigned long long)n_msg,
                        (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)Ltot);

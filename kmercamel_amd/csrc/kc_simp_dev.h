@@ -348,3 +348,65 @@ struct KcRec {
     u64 *chain_stream;  // per chain: first chunk (KC_NO_CHUNK if it has a single node)
     u64 *chain_tail;    // per chain: oriented last node (slot << 1 | orientation)
 };
+
+// cycles (rare): one thread, sequential.  Cut each cycle at its minimum key, on that node's port L, and append the cut
+// ends to the head list (cursor[0] = number of heads); the chains are then found by the ordinary discovery pass.
+template <int W>
+__global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, u8 *visited, int complements, u64 *heads,
+                                 u64 *cursor) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    u64 nh = cursor[0];
+    for (u64 i = 0; i < nlist; ++i) {
+        u64 start = list[i];
+        if (visited[start]) continue;
+        u64 cur = start, best = start;
+        int co = 0;
+        Key<W> bk = set_key_at(set, start);
+        do {
+            visited[cur] = 1;
+            Key<W> ck = set_key_at(set, cur);
+            if (key_lt(ck, bk)) { bk = ck; best = cur; }
+            u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+            cur = LK_SLOT(w);
+            co = LK_PORT(w) == 0 ? 0 : 1;
+        } while (cur != start);
+        const u64 wl = link[(best << 1) | 0];
+        const u64 partner = LK_PID(wl);              // the port that faced best's port L
+        link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
+        link[(best << 1) | 0] = LK_DEAD | (wl & LK_SPLIT);
+        heads[nh++] = (best << 1) | 0;                // entry port of orientation o is port o
+        if (complements || !(partner & 1)) { if (partner != ((best << 1) | 0)) heads[nh++] = partner; }
+    }
+    cursor[0] = nh;
+}
+
+// the same cut, in parallel: every k-mer left on a cycle walks its cycle (at most `max_steps` steps) and the one holding the
+// cycle's minimum key cuts it.  A cycle longer than max_steps is left alone (cursor[2] = 1): the caller then runs the
+// sequential kernel above in a further pass.  Walkers may meet a link another thread has just cut: they simply stop.
+template <int W>
+__global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, int complements,
+                                                                 u64 *heads, u64 *cursor, u64 max_steps) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlist) return;
+    const u64 start = list[t];
+    u64 cur = start, steps = 0;
+    int co = 0;
+    const Key<W> sk = set_key_at(set, start);
+    do {
+        if (cur != start && key_lt(set_key_at(set, cur), sk)) return;   // not the minimum of its cycle
+        const u64 w = __hip_atomic_load(&link[(cur << 1) | (u64)(co == 0 ? 1 : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!LK_IS_MATCHED(w)) return;                                    // cut under our feet (then start is not the minimum either)
+        cur = LK_SLOT(w);
+        co = LK_PORT(w) == 0 ? 0 : 1;
+        if (++steps > max_steps) { atomicExch((ull *)(cursor + 2), 1ULL); return; }
+    } while (cur != start);
+    // start holds the minimum key of its cycle
+    const u64 wl = link[(start << 1) | 0];
+    const u64 partner = LK_PID(wl);
+    __hip_atomic_store(&link[partner], LK_DEAD | (link[partner] & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&link[(start << 1) | 0], LK_DEAD | (wl & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool two = (complements || !(partner & 1)) && partner != ((start << 1) | 0);
+    const u64 pos = atomicAdd((ull *)cursor, two ? 2ULL : 1ULL);
+    heads[pos] = (start << 1) | 0;
+    if (two) heads[pos + 1] = partner;
+}

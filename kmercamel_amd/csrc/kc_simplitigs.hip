@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
 // directly. FILL = false counts the unreciprocated ports, FILL = true marks them LK_REJ and lists them.
 template <bool FILL>
 __global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, const u8 *__restrict__ tags, u64 cap, u64 *work_out, u64 *cursor) {
-    const u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 slot = kc_gtid();
     if (slot >= cap || tags[slot] == 0) return;
     for (int port = 0; port < 2; ++port) {
         const u64 pid = (slot << 1) | (u64)port;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
 template <int W, bool FILL>
 __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, u64 *heads,
                                                        u64 *cursor) {
-    u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 slot = kc_gtid();
     if (slot >= set.cap) return;
     if (!set_slot_full(set, slot)) return;
     int no = complements ? 2 : 1;
@@ -262,73 +262,11 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
 
 template <int W, bool FILL>
 __global__ void __launch_bounds__(256) kc_unvisited_kernel(SetView<W> set, const u8 *__restrict__ visited, u64 *list, u64 *cursor) {
-    u64 slot = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 slot = kc_gtid();
     if (slot >= set.cap) return;
     if (!set_slot_full(set, slot) || visited[slot]) return;
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
     if (FILL) list[pos] = slot;
-}
-
-// cycles (rare): one thread, sequential.  Cut each cycle at its minimum key, on that node's port L, and append the cut
-// ends to the head list (cursor[0] = number of heads); the chains are then found by the ordinary discovery pass.
-template <int W>
-__global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, u8 *visited, int complements, u64 *heads,
-                                 u64 *cursor) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    u64 nh = cursor[0];
-    for (u64 i = 0; i < nlist; ++i) {
-        u64 start = list[i];
-        if (visited[start]) continue;
-        u64 cur = start, best = start;
-        int co = 0;
-        Key<W> bk = set_key_at(set, start);
-        do {
-            visited[cur] = 1;
-            Key<W> ck = set_key_at(set, cur);
-            if (key_lt(ck, bk)) { bk = ck; best = cur; }
-            u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
-            cur = LK_SLOT(w);
-            co = LK_PORT(w) == 0 ? 0 : 1;
-        } while (cur != start);
-        const u64 wl = link[(best << 1) | 0];
-        const u64 partner = LK_PID(wl);              // the port that faced best's port L
-        link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
-        link[(best << 1) | 0] = LK_DEAD | (wl & LK_SPLIT);
-        heads[nh++] = (best << 1) | 0;                // entry port of orientation o is port o
-        if (complements || !(partner & 1)) { if (partner != ((best << 1) | 0)) heads[nh++] = partner; }
-    }
-    cursor[0] = nh;
-}
-
-// the same cut, in parallel: every k-mer left on a cycle walks its cycle (at most `max_steps` steps) and the one holding the
-// cycle's minimum key cuts it.  A cycle longer than max_steps is left alone (cursor[2] = 1): the caller then runs the
-// sequential kernel above in a further pass.  Walkers may meet a link another thread has just cut: they simply stop.
-template <int W>
-__global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, int complements,
-                                                                 u64 *heads, u64 *cursor, u64 max_steps) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nlist) return;
-    const u64 start = list[t];
-    u64 cur = start, steps = 0;
-    int co = 0;
-    const Key<W> sk = set_key_at(set, start);
-    do {
-        if (cur != start && key_lt(set_key_at(set, cur), sk)) return;   // not the minimum of its cycle
-        const u64 w = __hip_atomic_load(&link[(cur << 1) | (u64)(co == 0 ? 1 : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!LK_IS_MATCHED(w)) return;                                    // cut under our feet (then start is not the minimum either)
-        cur = LK_SLOT(w);
-        co = LK_PORT(w) == 0 ? 0 : 1;
-        if (++steps > max_steps) { atomicExch((ull *)(cursor + 2), 1ULL); return; }
-    } while (cur != start);
-    // start holds the minimum key of its cycle
-    const u64 wl = link[(start << 1) | 0];
-    const u64 partner = LK_PID(wl);
-    __hip_atomic_store(&link[partner], LK_DEAD | (link[partner] & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&link[(start << 1) | 0], LK_DEAD | (wl & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool two = (complements || !(partner & 1)) && partner != ((start << 1) | 0);
-    const u64 pos = atomicAdd((ull *)cursor, two ? 2ULL : 1ULL);
-    heads[pos] = (start << 1) | 0;
-    if (two) heads[pos + 1] = partner;
 }
 
 __global__ void __launch_bounds__(256) kc_iota_kernel(u64 *a, u64 n) {
@@ -671,7 +609,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
         // kc_reject_kernel run may already have set are simply found again
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
         scope.release(work_a); scope.release(work_b);
@@ -679,7 +617,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&work_a, work_cap));
         KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap, work_a,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
@@ -705,12 +643,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+        hipLaunchKernelGGL((kc_heads_kernel<W, false>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                            (u64 *)nullptr, cnt);
         KC_TRY(read_u64(ctx, cnt, &nheads));
         KC_TRY(scope.alloc(&heads, nheads + 1));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
+        hipLaunchKernelGGL((kc_heads_kernel<W, true>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
                            cnt);
     }
     // ---- chain discovery.  Pass 0 works on the heads round 1..n produced.  K-mers on cycles (every port matched) are
@@ -821,7 +759,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
+        hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
                            (u64 *)nullptr, cnt + 1);
         u64 nunvis = 0;
         KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
@@ -831,7 +769,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&heads2, nheads + 2 * nunvis + 1));   // every cycle adds at most two heads
         KC_HIP(ctx, hipMemcpyAsync(heads2, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), dim3(kc_grid(cap, 256)), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
+        hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
                            cnt + 1);
         KC_HIP(ctx, hipMemcpyAsync(cnt, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
         if (pass == 0)   // all cycles of up to 4096 k-mers at once; longer ones (if any) by the sequential kernel in the next pass

@@ -78,3 +78,26 @@ def test_ranks_wide_keys_and_branching_reads(ctx, tmp_path, k):
     write_fasta(fa, recs)
     got = run_ranks(2, fa, k, "bi", str(tmp_path / "out.npy"))
     assert np.array_equal(got, single(ctx, fa, k, True))
+
+
+@pytest.mark.parametrize("world,k,mode", [(2, 31, "bi"), (3, 31, "uni"), (4, 23, "bi"), (2, 63, "bi")])
+def test_ranks_real_genome_with_cycles(ctx, golden_dir, tmp_path, world, k, mode):
+    """S. pneumoniae (the reference's data/spneumoniae.fa): chains of > 10^5 k-mers, branch ports, and a few cycles -- cut at
+    their smallest k-mer whether they stay on one rank or span several.  One record, so some ranks hold no input at all."""
+    fa = os.path.join(golden_dir, "spneumoniae.fa.gz")
+    got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), timeout=900)
+    assert np.array_equal(got, single(ctx, fa, k, mode == "bi")), (world, k, mode)
+
+
+def test_ranks_cfg1_full_size(ctx, tmp_path):
+    """BASELINE configs[1] (10^8 31-mers) over 4 ranks == single GPU, byte for byte"""
+    sys.path.insert(0, ROOT)
+    import bench
+    seq = bench.generate(1, 0, 100000, 1030)
+    fa = str(tmp_path / "cfg1.fa")
+    bench.generate(1, 0, 100000, 1030, fasta=fa)
+    want = kc.compute(ctx, seq, 31, True)
+    w = want.array().copy()
+    want.close()
+    got = run_ranks(4, fa, 31, "bi", str(tmp_path / "out.npy"), timeout=1200)
+    assert np.array_equal(got, w)
