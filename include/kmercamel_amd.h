@@ -62,6 +62,11 @@ int kc_set_export(kc_set *set, uint64_t *out_words);
 /* kh_get != kh_end for n keys of W words each (khash.h:232-246); exact-key membership (no RC lookup) */
 int kc_set_contains(kc_set *set, const uint64_t *key_words, uint64_t n, uint8_t *out);
 
+/* kh_del (khash.h:353-359) for n exact keys (W words each): *n_erased (may be NULL) = how many were present.  The table has
+ * no tombstones (the simplitig phase consumes k-mers through port links instead); erasing rebuilds it without the keys,
+ * O(table) per call -- it exists for the element-wise compatibility API (eraseKMer, next_simplitig, khash_utils.h:105-118). */
+int kc_set_erase(kc_set *set, const uint64_t *key_words, uint64_t n, uint64_t *n_erased);
+
 /* ---- simplitigs: replaces std::vector<simplitig_t> (simplitigs.h:11) as a packed, device-resident collection ---- */
 /* get_simplitigs (simplitigs.h:191-205): greedy simplitigs of the set by de Bruijn neighbour lookup. The reference
  * consumes the set; here the set stays intact (it is reused for the -M mask). Order/orientation follow the

@@ -38,6 +38,7 @@ SIGNATURES = {
     "kc_set_size": (ctypes.c_int, [_vp, _u64p]),
     "kc_set_export": (ctypes.c_int, [_vp, _u64p]),
     "kc_set_contains": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint64, _u8p]),
+    "kc_set_erase": (ctypes.c_int, [_vp, _u64p, ctypes.c_uint64, _u64p]),
     "kc_simplitigs_build": (ctypes.c_int, [_vp, _vpp]),
     "kc_simplitigs_from_strings": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_char_p, _u64p, ctypes.c_uint64, _vpp]),
     "kc_simplitigs_destroy": (None, [_vp]),

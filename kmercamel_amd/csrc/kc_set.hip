@@ -884,6 +884,65 @@ extern "C" int kc_set_filter_min_frequency(kc_set *set, int min_frequency) {
     return KC_OK;
 }
 
+// kh_del for a list of keys: flag the slots that hold them, then move every unflagged k-mer into a fresh table of the
+// same size (the same rebuild as the -z filter: keep[slot] plays the occurrence counter, threshold 1).
+template <int W>
+__global__ void __launch_bounds__(256) kc_flag_erase_kernel(SetView<W> set, const u64 *__restrict__ keys, u64 n, u32 *keep, u64 *counter) {
+    u64 t = kc_gtid();
+    if (t >= n) return;
+    Key<W> key;
+    for (int i = 0; i < W; ++i) key.w[i] = keys[t * W + i];
+    const u64 slot = set_find(set, key);
+    if (slot == KC_NONE64) return;
+    if (atomicExch(&keep[slot], 0u) == 1u) atomicAdd((ull *)counter, 1ULL);
+}
+__global__ void __launch_bounds__(256) kc_fill_u32_kernel(u32 *a, u64 n, u32 v) {
+    u64 t = kc_gtid();
+    if (t < n) a[t] = v;
+}
+extern "C" int kc_set_erase(kc_set *set, const uint64_t *key_words, uint64_t n, uint64_t *n_erased) {
+    if (!set || (!key_words && n)) return KC_E_ARG;
+    kc_ctx *ctx = set->ctx;
+    if (n_erased) *n_erased = 0;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    if (set->rcap) return kc_fail(ctx, KC_E_ARG, "kc_set_erase on a hash-sharded set");
+    if (set->counts) return kc_fail(ctx, KC_E_ARG, "kc_set_erase while occurrences are being counted");
+    KC_TRY(kcs_refresh_size(set));
+    if (!n || !set->size_host) return KC_OK;
+    u64 *d_keys = nullptr;
+    u32 *keep = nullptr;
+    KC_TRY(kc_alloc(ctx, &d_keys, n * set->W));
+    int rc = kc_alloc(ctx, &keep, set->cap);
+    if (rc != KC_OK) { kc_release(ctx, d_keys); return rc; }
+    KC_HIP(ctx, hipMemcpyAsync(d_keys, key_words, n * set->W * 8, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(kc_fill_u32_kernel, kc_grid2(set->cap, 256), dim3(256), 0, ctx->stream, keep, set->cap, 1u);
+    const dim3 g = kc_grid2(n, 256);
+    switch (set->W) {
+        case 1: hipLaunchKernelGGL(kc_flag_erase_kernel<1>, g, dim3(256), 0, ctx->stream, view_of<1>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
+        case 2: hipLaunchKernelGGL(kc_flag_erase_kernel<2>, g, dim3(256), 0, ctx->stream, view_of<2>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
+        default: hipLaunchKernelGGL(kc_flag_erase_kernel<4>, g, dim3(256), 0, ctx->stream, view_of<4>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
+    }
+    KC_HIP(ctx, hipGetLastError());
+    u64 h[4];
+    KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, d_keys);
+    const u64 erased = h[3];
+    if (n_erased) *n_erased = erased;
+    if (!erased) { kc_release(ctx, keep); return KC_OK; }
+    u64 *nkeys = nullptr; u32 *nstate = nullptr; u8 *ntags = nullptr;
+    rc = set_alloc_table(set, set->cap, &nkeys, &nstate, &ntags);
+    if (rc != KC_OK) { kc_release(ctx, keep); return rc; }
+    set->counts = keep;   // released by the rebuild
+    KC_TRY(kcs_rebuild(set, set->cap, set->nblocks, nkeys, nstate, ntags, 1u));
+    h[0] -= erased; h[1] = 0; h[2] = 0; h[3] = 0;
+    KC_HIP(ctx, hipMemcpyAsync(set->counters, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    set->size_host = h[0];
+    return KC_OK;
+}
+
 extern "C" int kc_set_size(kc_set *set, uint64_t *n) {
     if (!set || !n) return KC_E_ARG;
     KC_TRY(kcs_refresh_size(set));

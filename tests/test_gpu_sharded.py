@@ -101,3 +101,29 @@ def test_ranks_cfg1_full_size(ctx, tmp_path):
     want.close()
     got = run_ranks(4, fa, 31, "bi", str(tmp_path / "out.npy"), timeout=1200)
     assert np.array_equal(got, w)
+
+
+def test_rccl_transport_single_rank(ctx, tmp_path):
+    """the RCCL back end (grouped ncclSend/ncclRecv inside the library, id handed over through torch.distributed) with the one
+    rank a 1-GPU box allows: librccl loads, the communicator comes up, every exchange of the flow runs through it"""
+    recs = gen.random_records(300, 400, seed=8)
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "shard_worker.py"), fa, "31", "bi", str(tmp_path / "out.npy"), "--backend", "nccl"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert np.array_equal(np.load(str(tmp_path / "out.npy")), single(ctx, fa, 31, True))
+
+
+def test_bench_gpus2_line(tmp_path):
+    """bench.py --gpus 2 (its own launcher, host-staged transport because the box has one GPU): a strong-scaling line on one record set"""
+    import json
+    env = dict(os.environ, KC_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--records", "20000", "--steps", "2", "--warmup", "1", "--check"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["n_kmers"] == 20000 * 1000
+    assert line["checks"]["ones_eq_N"] and len(line["per_rank"]) == 2
