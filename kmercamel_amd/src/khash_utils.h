@@ -1,7 +1,8 @@
 // Drop-in for the reference's src/khash_utils.h on the hot path: the k-mer set types kh_S64_t/kh_S128_t/kh_S256_t and
 // the by-value wrapper tags kmer_dict64_t/128_t/256_t (khash_utils.h:28-95), backed by the device-resident set of
 // libkmercamel_amd.so instead of khash.  Only what the greedy path and its callers use is provided:
-// kh_init_set / kh_destroy_set / kh_put_to_set / kh_get_from_set, kh_size, kh_end, containsKMer, kMersToVec.
+// kh_init_set / kh_destroy_set / kh_put_to_set / kh_get_from_set / kh_del_from_set, kh_size, kh_end, containsKMer, eraseKMer,
+// nextKMer, kMersToVec, kMersFromVec.
 // Element-wise calls (kh_put_to_set, kh_get_from_set) cross the ABI once per call -- they exist for compatibility; bulk
 // ingestion goes through AddKMers / ReadKMers (parser.h) which hand whole records to one kernel.
 #pragma once
@@ -18,6 +19,9 @@ template <typename kmer_t> struct kc_hset {
     bool complements = true;
     uint64_t size = 0;
     std::vector<kmer_t> pending;   // keys put one by one before k is known
+    kmer_t last_get = kmer_t(0);   // key of the last successful kh_get_from_set (what a following kh_del_from_set removes)
+    std::vector<kmer_t> order;     // nextKMer: the keys in the order the set was first iterated
+    bool have_order = false;
 };
 typedef kc_hset<kmer64_t> kh_S64_t;
 typedef kc_hset<kmer128_t> kh_S128_t;
@@ -65,7 +69,16 @@ template <typename kmer_t> void refresh(kc_hset<kmer_t> *s) { check(kc_set_size(
             kcamd::to_words(key, w);                                                                                        \
             uint8_t present = 0;                                                                                            \
             kcamd::check(kc_set_contains(set->h, w, 1, &present));                                                          \
+            if (present) set->last_get = key;                                                                               \
             return present ? 0 : kh_end(set);                                                                               \
+        }                                                                                                                   \
+        /* kh_del (khash.h:353-359): `it` is what kh_get_from_set just returned for the key to remove */                   \
+        inline void kh_del_from_set(kh_S##type##_t *set, khint_t it) {                                                      \
+            if (!set->h || it == kh_end(set)) return;                                                                       \
+            uint64_t w[4] = {0, 0, 0, 0};                                                                                   \
+            kcamd::to_words(set->last_get, w);                                                                              \
+            kcamd::check(kc_set_erase(set->h, w, 1, nullptr));                                                              \
+            kcamd::refresh(set);                                                                                            \
         }                                                                                                                   \
     };
 KC_INIT_WRAPPER(64)
@@ -78,6 +91,49 @@ inline bool containsKMer(kh_S_t *kMers, kh_wrapper_t wrapper, kmer_t kMer, int k
     bool ret = wrapper.kh_get_from_set(kMers, kMer) != kh_end(kMers);
     if (complements) ret |= wrapper.kh_get_from_set(kMers, ReverseComplement(kMer, k)) != kh_end(kMers);
     return ret;
+}
+
+/// Remove the k-mer and its reverse complement (khash_utils.h:105-118).
+template <typename kmer_t, typename kh_S_t, typename kh_wrapper_t>
+void eraseKMer(kh_S_t *kMers, kh_wrapper_t, kmer_t kMer, int k, bool complements) {
+    if (!kMers->h) return;
+    uint64_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int W = kcamd::words_of<kmer_t>::value;
+    kcamd::to_words(kMer, w);
+    if (complements) kcamd::to_words(ReverseComplement(kMer, k), w + W);
+    kcamd::check(kc_set_erase(kMers->h, w, complements ? 2 : 1, nullptr));
+    kcamd::refresh(kMers);
+}
+
+/// Return the next k-mer of the set and update the index; kmer_t(-1) when exhausted (khash_utils.h:120-129).  The
+/// reference scans its buckets upward from lastIndex; here the iteration order is the order of the first export of the
+/// set (any fixed order serves: callers erase while they iterate and only need every live key exactly once).
+template <typename kmer_t, typename kh_S_t>
+kmer_t nextKMer(kh_S_t *kMers, kmer_t, size_t &lastIndex) {
+    if (!kMers->h) return ~kmer_t(0);
+    if (!kMers->have_order) {
+        kcamd::refresh(kMers);
+        const int W = kcamd::words_of<kmer_t>::value;
+        std::vector<uint64_t> buf(std::max<uint64_t>(1, kMers->size * W));
+        kcamd::check(kc_set_export(kMers->h, buf.data()));
+        kMers->order.resize(kMers->size);
+        for (uint64_t i = 0; i < kMers->size; ++i) kcamd::from_words(buf.data() + i * W, kMers->order[i]);
+        kMers->have_order = true;
+    }
+    for (; lastIndex < kMers->order.size(); ++lastIndex) {
+        uint64_t w[4] = {0, 0, 0, 0};
+        kcamd::to_words(kMers->order[lastIndex], w);
+        uint8_t present = 0;
+        kcamd::check(kc_set_contains(kMers->h, w, 1, &present));
+        if (present) return kMers->order[lastIndex];
+    }
+    return ~kmer_t(0);
+}
+
+/// Insert the k-mers of the vector (khash_utils.h:154-159).
+template <typename kmer_t, typename kh_S_t, typename kh_wrapper_t>
+void kMersFromVec(kh_S_t *kMers, kh_wrapper_t wrapper, std::vector<kmer_t> &kMerVec) {
+    for (kmer_t kMer : kMerVec) { int ret; wrapper.kh_put_to_set(kMers, kMer, &ret); }
 }
 
 /// Construct a vector of the k-mer set in an arbitrary order (khash_utils.h:131-141).

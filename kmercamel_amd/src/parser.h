@@ -32,6 +32,23 @@ void ReadKMers(kh_S_t *kMers, kh_wrapper_t wrapper, kmer_t _, std::string &path,
     AddKMers(kMers, wrapper, _, joined.size(), joined.data(), k, complements, case_sensitive);
 }
 
+/// Load the k-mers that occur at least min_frequency times (parser.h:51-85, 122-141): occurrence counters on the device
+/// while the records are added, then the filtered rebuild.
+template <typename kmer_t, typename kh_S_t, typename kh_wrapper_t>
+void ReadKMersFiltered(kh_S_t *kMers, kh_wrapper_t, kmer_t, std::string &path, int k, bool complements, uint16_t min_frequency) {
+    auto recs = kcamd::read_records(path);
+    std::string joined;
+    size_t total = 0;
+    for (auto &r : recs) total += r.seq.size() + 1;
+    joined.reserve(total);
+    for (auto &r : recs) { joined += r.seq; joined.push_back('\n'); }
+    kcamd::ensure(kMers, k, complements);
+    kcamd::check(kc_set_enable_counting(kMers->h));
+    kcamd::check(kc_set_add_sequence(kMers->h, joined.data(), joined.size(), 0));
+    kcamd::check(kc_set_filter_min_frequency(kMers->h, min_frequency < 1 ? 1 : (min_frequency > 255 ? 255 : (int)min_frequency)));
+    kcamd::refresh(kMers);
+}
+
 inline void WriteLog(const std::string message) {   // parser.h:159-164
     auto snapshot = std::chrono::system_clock::now();
     std::time_t time = std::chrono::system_clock::to_time_t(snapshot);

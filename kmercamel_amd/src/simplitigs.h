@@ -1,5 +1,5 @@
-// Drop-in for the reference's src/simplitigs.h entry points: simplitig_t, get_simplitigs, simplitigs_from_fasta and the
-// small accessors (simplitigs.h:11-103, 191-205).  std::vector<bool> simplitigs are converted to / from the packed
+// Drop-in for the reference's src/simplitigs.h entry points: simplitig_t, get_simplitigs, next_simplitig,
+// simplitigs_to_kmer_vec, simplitigs_from_fasta and the small accessors (simplitigs.h:11-103, 142-205).  std::vector<bool> simplitigs are converted to / from the packed
 // device collection at this boundary only; the CLI's fused path never materialises them.
 #pragma once
 #include <vector>
@@ -75,6 +75,62 @@ inline std::vector<simplitig_t> simplitigs_from_fasta(std::string &path) {   // 
     std::vector<simplitig_t> simplitigs;
     for (auto &r : kcamd::read_records(path)) simplitigs.push_back(simplitig_from_string(r.seq));
     return simplitigs;
+}
+
+/// All k-mers of the simplitigs, in order (simplitigs.h:53-65).
+template <typename kmer_t>
+std::vector<kmer_t> simplitigs_to_kmer_vec(kmer_t kmer_type, std::vector<simplitig_t> simplitigs, int k, size_t length_estimate) {
+    std::vector<kmer_t> result;
+    result.reserve(length_estimate);
+    for (auto &s : simplitigs)
+        for (size_t i = 0, n = kmers_in_simplitig(s, k); i < n; ++i) result.push_back(kmer_at_simplitig_index(kmer_type, s, k, i));
+    return result;
+}
+
+/// One seed-and-extend simplitig in the reference's own sequential manner (simplitigs.h:105-189): the seed and every
+/// k-mer the walk takes are removed from the set; the right end tries T, G, C, A, the left end A, C, G, T.  This is the
+/// element-wise compatibility entry point -- every step is a handful of single-key device lookups; whole sets go through
+/// get_simplitigs, which computes all simplitigs in a few kernels.
+namespace kcamd {
+// one step at the end whose outward-reading k-mer is `fw` (and `bw` its reverse complement; uni-directional walks keep only
+// the strand they move on and mark the other with all ones): returns the extension code 0..3 or 0xFF
+template <bool complements, typename kmer_t, typename kh_S_t, typename kh_wrapper_t>
+inline uint8_t step_outwards(kmer_t &fw, kmer_t &bw, kh_S_t *kMers, kh_wrapper_t &wrapper, int k) {
+    const bool on_forward = complements || bw == ~kmer_t(0);
+    const kmer_t mask = (kmer_t(1) << (2 * k)) - kmer_t(1);
+    for (int ext = 0; ext < 4; ++ext) {
+        const kmer_t nf = ((fw << 2) & mask) | kmer_t((uint64_t)(3 ^ ext));
+        const kmer_t nb = (bw >> 2) | (kmer_t((uint64_t)ext) << (2 * (k - 1)));
+        const kmer_t probe = complements ? (nf <= nb ? nf : nb) : (on_forward ? nf : nb);
+        const khint_t it = wrapper.kh_get_from_set(kMers, probe);
+        if (it == kh_end(kMers)) continue;
+        if (complements) { fw = nf; bw = nb; }
+        else if (on_forward) fw = nf;
+        else bw = nb;
+        wrapper.kh_del_from_set(kMers, it);
+        return (uint8_t)ext;
+    }
+    return 0xFF;
+}
+}  // namespace kcamd
+template <bool complements, typename kmer_t, typename kh_S_t, typename kh_wrapper_t>
+simplitig_t next_simplitig(kh_S_t *kMers, kh_wrapper_t wrapper, kmer_t begin, int k) {
+    kmer_t last = begin, first = begin;
+    kmer_t last_rc = complements ? ReverseComplement(begin, k) : ~kmer_t(0), first_rc = last_rc;
+    simplitig_t right(2 * k), left;
+    for (int i = 0; i < 2 * k; ++i) right[2 * k - 1 - i] = (kcamd::low64(begin >> i) & 1) != 0;
+    eraseKMer(kMers, wrapper, begin, k, complements);
+    for (uint8_t e; (e = kcamd::step_outwards<complements>(last, last_rc, kMers, wrapper, k)) != 0xFF;) {
+        right.push_back(!(e & 2));   // the appended nucleotide is 3 ^ e
+        right.push_back(!(e & 1));
+    }
+    for (uint8_t e; (e = kcamd::step_outwards<complements>(first_rc, first, kMers, wrapper, k)) != 0xFF;) {
+        left.push_back(e & 1);       // the prepended nucleotide is e; pushed low bit first, the whole prefix is reversed below
+        left.push_back(e & 2);
+    }
+    simplitig_t res(left.rbegin(), left.rend());
+    res.insert(res.end(), right.begin(), right.end());
+    return res;
 }
 
 /// Greedy simplitigs of the k-mer set (simplitigs.h:191-205).  Unlike the reference the set is left intact.
