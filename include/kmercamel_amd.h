@@ -156,6 +156,17 @@ int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len
  * kc_result_device_ptrs / kc_result_copy address the slice */
 int kc_result_slice(kc_result *r, uint64_t *offset, uint64_t *slice_len);
 
+/* ---- streamed I/O of the CLI path (ReadKMers' kseq loop, parser.h:88-118 + kseq.h:183-234; the output stream of
+ * main.cpp:164-210): a reader thread feeds pinned chunks, the device tokenises the FASTA (header lines and line breaks cut
+ * out, records joined by '\n') while the next chunk is read; the result leaves through pinned chunks, copy overlapping write. */
+/* path: plain / gzip file, or "-" for stdin.  *d_seq: device buffer with the joined record sequences (free with
+ * kc_device_free), ready for kc_compute(..., KC_FLAG_INPUT_ON_DEVICE).  *is_fastq = 1 (and nothing returned) when the input
+ * is FASTQ: use the host parser.  KC_E_IO when the file cannot be opened (parser.h:95-97). */
+int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *len, int *is_fastq);
+void kc_device_free(kc_ctx *ctx, void *d_ptr);
+/* write the result's characters (which = 0) or its -M mask (which = 1) to a file descriptor */
+int kc_result_write_fd(kc_result *r, int fd, int which);
+
 /* ---- next row 1: maskopt -t max-one / min-one (masks.h:40-78, 239-261) ---- */
 /* ms: one masked superstring (ACGTacgt, else KC_E_INVALID_CHAR after output like the reference). out: len bytes. */
 int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out);

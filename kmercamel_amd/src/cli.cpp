@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <unistd.h>
+#include <fcntl.h>
 #include "global.h"
 #include "parser.h"
 #include "conversions.h"
@@ -101,8 +102,17 @@ Records load_records(const std::string &path, bool simplitigs) {
 }
 
 // greedy branch of kmercamel<>() (main.cpp:122-212)
+// all of `data` to a file descriptor
+static void write_all(int fd, const char *data, size_t n) {
+    while (n) {
+        ssize_t w = ::write(fd, data, n);
+        if (w < 0) throw std::runtime_error("write failed");
+        data += w; n -= (size_t)w;
+    }
+}
+
 int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
-                int min_frequency) {
+                int min_frequency, const std::string &out_path, const std::string &mask_path) {
     if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
     else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");
     const bool trace = std::getenv("KC_CLI_TRACE") != nullptr;
@@ -111,10 +121,28 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
     };
     kcamd::warm_context();   // the device comes up while the file is read
-    Records recs = load_records(path, assume_simplitigs);
-    mark("records loaded");
-    kc_ctx *ctx = kcamd::context();
-    mark("device context ready");
+    Records recs;
+    kc_ctx *ctx = nullptr;
+    void *d_seq = nullptr;
+    uint64_t d_len = 0;
+    bool streamed = false;
+    if (!assume_simplitigs && !lower_bound && !std::getenv("KC_CLI_NOSTREAM")) {
+        // FASTA goes to the device in pinned chunks and is tokenised there while the next chunk is read (no joined host copy)
+        ctx = kcamd::context();
+        mark("device context ready");
+        int is_fastq = 0;
+        int rc = kc_read_fasta_device(ctx, path.c_str(), &d_seq, &d_len, &is_fastq);
+        if (rc == KC_E_IO) throw std::invalid_argument("couldn't open file " + path);
+        kcamd::check(rc);
+        streamed = !is_fastq;
+        if (streamed) mark("input on the device");
+    }
+    if (!streamed) {
+        recs = load_records(path, assume_simplitigs);
+        mark("records loaded");
+        ctx = kcamd::context();
+        mark("device context ready");
+    }
     if (lower_bound) {
         // LowerBoundLength (lower_bound.h:7-36): simplitigs, then the cycle cover of the overlap graph
         kc_simplitigs *s = nullptr;
@@ -157,7 +185,9 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     uint32_t flags = (complements ? KC_FLAG_COMPLEMENTS : 0) | (assume_simplitigs ? KC_FLAG_SIMPLITIGS_INPUT : 0) | (maskf ? KC_FLAG_WANT_MASK : 0) |
                      KC_FLAG_MIN_FREQUENCY(min_frequency);
     kc_result *res = nullptr;
-    int rc = kc_compute(ctx, recs.joined.data(), recs.joined.size(), assume_simplitigs ? recs.offsets.data() : nullptr, recs.n, k, flags, &res);
+    int rc = streamed ? kc_compute(ctx, d_seq, d_len, nullptr, 0, k, flags | KC_FLAG_INPUT_ON_DEVICE, &res)
+                      : kc_compute(ctx, recs.joined.data(), recs.joined.size(), assume_simplitigs ? recs.offsets.data() : nullptr, recs.n, k, flags, &res);
+    if (streamed) kc_device_free(ctx, d_seq);
     if (rc == KC_E_NO_KMERS) {
         std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
         return usage_subcommand("compute");
@@ -172,14 +202,26 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
     if (st[3]) WriteLog("2. part: Number of simplitigs over threshold, computing directly from k-mers.");
     WriteLog("Finished 2. part: Hamiltonian path.");
-    std::string out(st[2], 'N'), mask(maskf ? st[2] : 0, 'N');
-    kcamd::check(kc_result_copy(res, out.data(), maskf ? mask.data() : nullptr));
+    // the characters leave through pinned chunks, device-to-host copy overlapping the write (kc_result_write_fd); the
+    // streams only carry the header lines, so they are flushed first and the data follows through the descriptor
+    of->flush();
+    if (maskf) maskf->flush();
+    auto emit = [&](const std::string &p, int which) {
+        int fd = p.empty() ? 1 : ::open(p.c_str(), O_WRONLY | O_APPEND);
+        if (fd < 0) throw std::runtime_error("cannot reopen " + p);
+        kcamd::check(kc_result_write_fd(res, fd, which));
+        if (which == 1) write_all(fd, "\n", 1);   // global.h:206-208
+        if (!p.empty()) ::close(fd);
+    };
+    emit(out_path, 0);
+    if (maskf != nullptr) emit(mask_path, 1);
     kc_result_destroy(res);
-    mark("result copied to the host");
-    of->write(out.data(), (std::streamsize)out.size());
-    if (maskf != nullptr) { maskf->write(mask.data(), (std::streamsize)mask.size()); (*maskf) << std::endl; }
+    mark("result written");
     WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
-    *of << std::endl;   // main.cpp:210
+    {
+        int fd = out_path.empty() ? 1 : ::open(out_path.c_str(), O_WRONLY | O_APPEND);
+        if (fd >= 0) { write_all(fd, "\n", 1); if (!out_path.empty()) ::close(fd); }   // main.cpp:210
+    }
     mark("output written");
     return 0;
 }
@@ -191,19 +233,19 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     int k = 0, d_max = 5, opt;
     std::ofstream output, maskOutput;
     std::ostream *of = &std::cout, *maskf = nullptr;
-    std::string algorithm = "greedy";
+    std::string algorithm = "greedy", out_path, mask_path;
     bool complements = true, d_set = false, assume_simplitigs = false;
     int min_frequency = 1;
     try {
         while ((opt = getopt(argc, argv, lowerbound ? "k:huxSz:" : "k:d:a:o:huxM:Sz:")) != -1) {
             switch (opt) {
-                case 'o': output.open(optarg); of = &output; break;
+                case 'o': output.open(optarg); of = &output; out_path = optarg; break;
                 case 'k': k = std::stoi(optarg); break;
                 case 'd': d_set = true; d_max = std::stoi(optarg); break;
                 case 'a': algorithm = optarg; break;
                 case 'u': complements = false; break;
                 case 'x': std::cerr << "Warning: The parameter -x currently has no effect due to the improvement in the underlying algorithm." << std::endl; break;
-                case 'M': maskOutput.open(optarg); maskf = &maskOutput; break;
+                case 'M': maskOutput.open(optarg); maskf = &maskOutput; mask_path = optarg; break;
                 case 'S': assume_simplitigs = true; break;
                 case 'h': usage_subcommand(subcommand); return 0;
                 case 'z': min_frequency = std::stoi(optarg); break;
@@ -228,7 +270,7 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     if (min_frequency >= 256 || min_frequency < 1) return fail("Minimum frequency '-z' must be between 1 and 255.");
     if (min_frequency != 1 && assume_simplitigs) return fail("Inputting simplitigs is not compatible with frequency filterring.");
     if (algorithm != "greedy") return fail("Algorithm '" + algorithm + "' not supported by the MI355X build (greedy only).");
-    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency);
+    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency, out_path, mask_path);
 }
 
 // Optimize (masks.h:239-261) for max-one / min-one

@@ -129,3 +129,67 @@ def test_fast_fasta_loader_matches_tokenizer(tmp_path):
                            "-I" + os.path.join(ROOT, "kmercamel_amd", "src"), "-lz", "-pthread", "-o", exe])
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 0 and "parse_check ok" in p.stdout, p.stdout
+
+
+@pytest.mark.gpu
+def test_cli_streamed_fasta_tokeniser_equals_host_parser(tmp_path):
+    """compute reads FASTA through the device-side tokeniser (kc_read_fasta_device: pinned chunks, header lines and line breaks
+    cut out on the GPU); KC_CLI_NOSTREAM=1 takes the host tokenizer with kseq's semantics (kseq.h:183-224).  Same bytes out on
+    awkward inputs: multi-line records, CRLF, empty lines, junk before the first header, '>' inside a line, header at the very
+    end, no trailing newline, '@' headers, gzip, stdin, and random mixtures of all of that."""
+    import gzip
+    import random
+    rng = random.Random(17)
+
+    def seq(n):
+        return "".join(rng.choice("ACGTacgtNn") if rng.random() < 0.03 else rng.choice("ACGT") for _ in range(n))
+
+    cases = {
+        "multiline.fa": ">a desc\n" + "\n".join(seq(60) for _ in range(40)) + "\n>b\n" + seq(75) + "\n" + seq(3) + "\n",
+        "crlf.fa": ">a\r\n" + "\r\n".join(seq(50) for _ in range(30)) + "\r\n>b\r\n" + seq(200) + "\r\n",
+        "blank_lines.fa": "\n\n>a\n\n" + seq(100) + "\n\n\n" + seq(100) + "\n>b\n\n>c\n" + seq(150),
+        "junk_before.fa": "this is not fasta\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n>a\n" + seq(300) + "\n",
+        "gt_inside.fa": ">a\n" + seq(80) + ">" + seq(80) + "\n" + seq(40) + "@" + seq(40) + "\n>b\n" + seq(120) + "\n",
+        "header_last.fa": ">a\n" + seq(300) + "\n>",
+        "at_headers.fa": ">a\n" + seq(200) + "\n@b looks like fastq but has no plus line\n" + seq(200) + "\n",
+    }
+    soup = []
+    for r in range(300):
+        soup.append((">" if rng.random() < 0.8 else "@") + "r%d %s" % (r, "x" * rng.randrange(0, 30)))
+        for _ in range(rng.randrange(0, 6)):
+            soup.append(seq(rng.randrange(0, 90)) + ("\r" if rng.random() < 0.1 else ""))
+    cases["soup.fa"] = "\n".join(soup) + ("\n" if rng.random() < 0.5 else "")
+    big = []
+    for r in range(3000):   # > 32 MB: several chunks, records cut by chunk borders
+        big.append(">big%d" % r)
+        s = seq(12000)
+        big.extend(s[i:i + 70] for i in range(0, len(s), 70))
+    cases["big.fa"] = "\n".join(big) + "\n"
+    for name, text in cases.items():
+        path = str(tmp_path / name)
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        for k in (("31",) if name == "big.fa" else ("31", "17")):
+            a = run("compute", "-k", k, path)
+            env = dict(os.environ, KC_CLI_NOSTREAM="1")
+            b = subprocess.run([BIN, "compute", "-k", k, path], capture_output=True, text=True, env=env)
+            assert a.returncode == b.returncode == 0, (name, a.stderr[-500:], b.stderr[-500:])
+            assert a.stdout == b.stdout, (name, k)
+            assert a.stdout.count("\n") == 2
+    # gzip and stdin go through the same reader
+    path = str(tmp_path / "multiline.fa")
+    with open(path, "rb") as f:
+        raw = f.read()
+    with gzip.open(path + ".gz", "wb") as f:
+        f.write(raw)
+    want = run("compute", "-k", "31", path).stdout.split("\n")[1]
+    assert run("compute", "-k", "31", path + ".gz").stdout.split("\n")[1] == want
+    p = subprocess.run([BIN, "compute", "-k", "31", "-"], input=raw, capture_output=True)
+    assert p.returncode == 0 and p.stdout.decode().split("\n")[1] == want
+    # -o / -M files: header line, data, newline -- through the descriptor path
+    o, m = str(tmp_path / "o.fa"), str(tmp_path / "m.fa")
+    p = run("compute", "-k", "31", "-o", o, "-M", m, path)
+    assert p.returncode == 0
+    lo, lm = open(o).read().split("\n"), open(m).read().split("\n")
+    assert lo[0].startswith(">maskedsuperstring") and lo[1] == want and lo[2] == "" and len(lo) == 3
+    assert "mask=max-one" in lm[0] and lm[1].upper() == want.upper() and lm[2] == "" and len(lm) == 3
