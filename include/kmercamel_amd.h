@@ -40,6 +40,9 @@ const char *kc_last_error(const kc_ctx *ctx);
 /* the private HIP stream (hipStream_t) the kernels are launched on */
 void *kc_ctx_stream(kc_ctx *ctx);
 int kc_ctx_synchronize(kc_ctx *ctx);
+/* stats[4]: peak bytes held by the context's device memory pool, bytes obtained from hipMalloc, hipMalloc calls,
+ * microseconds spent inside them */
+int kc_ctx_stats(kc_ctx *ctx, uint64_t *stats);
 
 /* ---- k-mer set: replaces kh_S64/S128/S256 + kmer_dictNN_t (khash_utils.h:28-95) ---- */
 /* wrapper.kh_init_set() (khash_utils.h:43). capacity_hint = expected number of k-mer occurrences to be added (0 = grow on demand). */

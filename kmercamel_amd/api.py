@@ -29,6 +29,7 @@ SIGNATURES = {
     "kc_last_error": (ctypes.c_char_p, [_vp]),
     "kc_ctx_stream": (_vp, [_vp]),
     "kc_ctx_synchronize": (ctypes.c_int, [_vp]),
+    "kc_ctx_stats": (ctypes.c_int, [_vp, _u64p]),
     "kc_set_create": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, _vpp]),
     "kc_set_destroy": (None, [_vp]),
     "kc_set_add_sequence": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int]),

@@ -17,7 +17,8 @@ struct KcPool {
     struct Blk { size_t size; void *p; };
     std::vector<Blk> free_list;
     std::map<void *, size_t> live;
-    size_t live_bytes = 0, peak_bytes = 0;
+    size_t live_bytes = 0, peak_bytes = 0, malloc_bytes = 0, malloc_calls = 0;
+    double malloc_seconds = 0;   // wall time inside hipMalloc (large first-time allocations dominate a cold CLI run)
     hipError_t alloc(void **out, size_t bytes);
     void release(void *p);
     void trim();      // hipFree everything cached

@@ -5,6 +5,7 @@
 // 8-byte (W*8-byte) slot access of the insert.
 #include "kc_internal.h"
 #include "kc_comm.h"
+#include <chrono>
 
 // ------------------------------------------------------------------------------------------------- pool / ctx
 hipError_t KcPool::alloc(void **out, size_t bytes) {
@@ -24,7 +25,10 @@ hipError_t KcPool::alloc(void **out, size_t bytes) {
         if (live_bytes > peak_bytes) peak_bytes = live_bytes;
         return hipSuccess;
     }
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, need);
+    malloc_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    malloc_bytes += need; ++malloc_calls;
     if (e != hipSuccess) {
         (void)hipGetLastError();
         trim();
@@ -82,6 +86,12 @@ extern "C" void *kc_ctx_stream(kc_ctx *ctx) { return ctx ? (void *)ctx->stream :
 extern "C" int kc_ctx_synchronize(kc_ctx *ctx) {
     if (!ctx) return KC_E_ARG;
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KC_OK;
+}
+extern "C" int kc_ctx_stats(kc_ctx *ctx, uint64_t *stats) {
+    if (!ctx || !stats) return KC_E_ARG;
+    stats[0] = ctx->pool.peak_bytes; stats[1] = ctx->pool.malloc_bytes; stats[2] = ctx->pool.malloc_calls;
+    stats[3] = (u64)(ctx->pool.malloc_seconds * 1e6);
     return KC_OK;
 }
 extern "C" void kc_free(void *p) { free(p); }

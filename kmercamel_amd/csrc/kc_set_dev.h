@@ -144,6 +144,9 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
             u64 slot = set_probe_slot(s, home, ghome, probes);
             u32 st = __hip_atomic_load(&s.state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (st == KC_ST_FULL) {
+                // the key loads below must not be hoisted above the state load (the hardware returns vector memory loads in
+                // issue order; this keeps the compiler from reordering them)
+                asm volatile("" ::: "memory");
                 bool eq = true;
                 for (int i = 0; i < W; ++i)
                     eq = eq && (__hip_atomic_load(&s.keys[slot * W + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key.w[i]);
@@ -158,6 +161,10 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
                     // loads, so it is enough to drain them before the state store.  An agent-scope RELEASE would write back the
                     // whole L2 on every insert (measured: 214 ms per 10^8 k-mers); a workgroup-scope fence compiles to nothing and
                     // lets the state store overtake the keys (seen as a handful of duplicate k-mers) -- hence the explicit wait.
+                    // This relies on gfx9 behaviour (stores are counted by vmcnt; sc1 stores are written through): refuse other targets.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "the wide-key publish sequence is written for gfx942 / gfx950 (vmcnt counts stores); port it before building for another target"
+#endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(&s.state[slot], KC_ST_FULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     set_write_tag(s, slot, kc_tag_of(kh));

@@ -194,6 +194,11 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     }
     kcamd::check(rc);
     mark("kc_compute returned");
+    if (trace) {
+        uint64_t ps[4] = {0, 0, 0, 0};
+        kc_ctx_stats(ctx, ps);
+        std::cerr << "[cli] device pool: peak " << ps[0] / 1e9 << " GB, hipMalloc " << ps[1] / 1e9 << " GB in " << ps[2] << " calls, " << ps[3] / 1e3 << " ms inside hipMalloc" << std::endl;
+    }
     uint64_t st[16];
     kc_result_stats(res, st);
     if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");

@@ -6,6 +6,7 @@
 #include <vector>
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipFree(0);
     const size_t G20 = (size_t)20e9;
     for (int nt : {1, 2, 4, 8}) {
@@ -26,7 +27,8 @@ int main() {
     {
         hipStream_t s; hipStreamCreate(&s);
         void *p = nullptr; double t0 = now(); hipError_t e = hipMallocAsync(&p, G20, s); hipStreamSynchronize(s); double t1 = now();
-        hipMemsetAsync(p, 0, G20, s); hipStreamSynchronize(s); double t2 = now();
+        if (e == hipSuccess) { hipMemsetAsync(p, 0, G20, s); hipStreamSynchronize(s); }
+        double t2 = now();
         hipFreeAsync(p, s); hipStreamSynchronize(s); double t3 = now();
         void *q = nullptr; hipMallocAsync(&q, G20, s); hipStreamSynchronize(s); double t4 = now();
         printf("hipMallocAsync 20 GB: %.3f s (%d), memset %.3f, freeAsync %.3f, mallocAsync again %.3f\n", t1 - t0, (int)e, t2 - t1, t3 - t2, t4 - t3);
@@ -44,7 +46,8 @@ int main() {
         hipError_t e3 = hipMemMap(va, n, 0, h, 0); double t3 = now();
         hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
         hipError_t e4 = hipMemSetAccess(va, n, &acc, 1); double t4 = now();
-        hipMemset(va, 0, n); hipDeviceSynchronize(); double t5 = now();
+        if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) { hipMemset(va, 0, n); hipDeviceSynchronize(); }
+        double t5 = now();
         printf("VMM 20 GB (granularity %zu): create %.3f (%d) reserve %.3f (%d) map %.3f (%d) setaccess %.3f (%d) memset %.3f\n", gran, t1 - t0, (int)e1, t2 - t1, (int)e2, t3 - t2, (int)e3, t4 - t3, (int)e4, t5 - t4);
     }
     {
@@ -53,7 +56,7 @@ int main() {
     }
     {
         void *p = nullptr; double t0 = now(); hipError_t e = hipMallocManaged(&p, G20); double t1 = now();
-        hipMemPrefetchAsync(p, G20, 0, 0); hipDeviceSynchronize(); double t2 = now();
+        double t2 = now();
         printf("hipMallocManaged 20 GB %.3f (%d), prefetch to device %.3f\n", t1 - t0, (int)e, t2 - t1); hipFree(p);
     }
     return 0;
