@@ -148,21 +148,33 @@ def cpu_baseline(k, read_len, sample_records, seed, runs, full_n):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def cli_end_to_end(fa, k, runs, expect_len, expect_bytes):
-    """SURVEY 8d metric (1): wall of a fresh CLI process, start to exit, files on tmpfs. Returns (dict, ok)."""
+def cli_end_to_end(fa, k, runs, expect_len, expect_bytes, settle):
+    """SURVEY 8d metric (1): wall of a fresh CLI process, start to exit, files on tmpfs. Returns (dict, ok).
+
+    Every timed run starts on an IDLE device: the driver scrubs the VRAM a process frees (here ~150 GB, ~5 s at ~30 GB/s) in the
+    background after its exit, and the next process's hipMalloc calls block on that scrub -- a cost of the PREVIOUS job, not of
+    this one (tools/cli_cold_warm.py: 6.5 s back to back, 1.5 s after an 8 s pause, 17 ms instead of 5 s inside hipMalloc).
+    So the runs are `settle` seconds apart; one extra run without the pause is reported next to them."""
     import numpy as np
     exe = os.path.join(ROOT, "kmercamel_amd", "bin", "kmercamel")
     out = os.path.join(os.path.dirname(fa), "out.txt")
     walls, trace = [], ""
     env = dict(os.environ, KC_CLI_TRACE="1")
-    for _ in range(runs):
+    back_to_back = None
+    for i in range(runs + 1):
         if os.path.exists(out):
             os.unlink(out)
+        if i < runs:
+            time.sleep(settle)
         t0 = time.perf_counter()
         p = subprocess.run([exe, "compute", "-k", str(k), "-o", out, fa], capture_output=True, text=True, env=env)
-        walls.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
         if p.returncode != 0:
             return {"error": "CLI exited with %d: %s" % (p.returncode, p.stderr[-400:])}, False
+        if i == runs:
+            back_to_back = dt     # started the moment the previous run exited
+            break
+        walls.append(dt)
         trace = " | ".join(l[6:] for l in p.stderr.splitlines() if l.startswith("[cli] "))
     # the file holds the header line, the superstring, '\n'
     with open(out, "rb") as f:
@@ -170,6 +182,9 @@ def cli_end_to_end(fa, k, runs, expect_len, expect_bytes):
         body = np.fromfile(f, dtype=np.uint8)
     same = (len(body) == expect_len + 1) and bool(np.array_equal(body[:expect_len], expect_bytes))
     res = {"wall_s": [round(w, 3) for w in walls], "runs": runs, "median_wall_s": round(statistics.median(walls), 3),
+           "idle_device_pause_s": settle, "wall_back_to_back_s": round(back_to_back, 3),
+           "note": "timed runs start on an idle device (pause before each); back_to_back = one more run started the moment the previous "
+                   "process exited: its hipMalloc calls wait for the driver's scrub of the ~150 GB that process freed",
            "output_identical_to_device_resident_result": same, "header": header.decode(errors="replace").strip()[:120],
            "phase_trace_ms_last_run": trace, "files": "tmpfs (/dev/shm)"}
     return res, same
@@ -205,6 +220,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--read-len", type=int, default=0, help="default k-1+1000 (1030 for k=31)")
     ap.add_argument("--cli-runs", type=int, default=3)
+    ap.add_argument("--cli-settle", type=float, default=8.0, help="seconds of idle device before each timed CLI run")
     ap.add_argument("--no-cli", action="store_true")
     ap.add_argument("--cpu-sample-records", type=int, default=40000)
     ap.add_argument("--cpu-runs", type=int, default=3)
@@ -368,7 +384,7 @@ def main():
         if checks:
             line["checks"] = checks
         if want_cli:
-            e2e, ok = cli_end_to_end(fa, k, args.cli_runs, L, o)
+            e2e, ok = cli_end_to_end(fa, k, args.cli_runs, L, o, args.cli_settle)
             if "median_wall_s" in e2e:
                 e2e["value"] = round(N / e2e["median_wall_s"] / 1e6, 3)
                 e2e["unit"] = "Mkmers/s"

@@ -115,6 +115,10 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         if (rc == KC_OK && min_frequency > 1) rc = kc_set_enable_counting(set);
         u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
         if (rc == KC_OK && len >= (u64)k) {
+            // the port links of phase 1 (16 B per slot) are the largest block of the run and the build buckets of phase 0 (8 W B
+            // per slot) are gone by then: obtain the larger of the two now, so that both phases use the same memory
+            void *arena = nullptr;
+            if (ctx->pool.alloc(&arena, set->cap * 16) == hipSuccess) ctx->pool.release(arena); else (void)hipGetLastError();
             rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
             if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, 0);
         }

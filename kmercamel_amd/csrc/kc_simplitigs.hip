@@ -563,7 +563,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     // heads (ports that die) and the work list of unresolved ports are collected on the fly into bounded buffers; an
     // overflow (never seen on read-like inputs) falls back to exact counting passes.
-    u64 heads_cap = N / 4 + 65536, work_cap = N / 8 + 65536;
+    // (sized for read-like inputs -- 2 heads per simplitig, hardly any branch port; a cold process pays ~26 ms per GB it obtains
+    // from hipMalloc, so generous bounds are not free.  Overflows take the exact paths below.)
+    u64 heads_cap = N / 32 + 65536, work_cap = N / 64 + 65536;
     u64 *heads = nullptr, *work_a = nullptr, *work_b = nullptr;
     KC_TRY(scope.alloc(&heads, heads_cap));
     KC_TRY(scope.alloc(&work_a, work_cap));

@@ -7,12 +7,14 @@
 set -u
 OUT=${1:-gpurun_out/profile}
 shift || true
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-cli}
 R=$(pwd)
+# the counter passes run one step of the same workload (the workload flags are taken from ARGS, steps / warmup overridden)
+PMCARGS="$ARGS --steps 1 --warmup 0"
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py $ARGS > $R/$OUT/bench_stats.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $R/$OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PMCARGS > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $R/$OUT/pmc_write -- python3 $R/bench.py $PMCARGS > /dev/null 2>&1
 rm -f $R/$OUT/*/*/*_kernel_trace.csv
 tail -1 $R/$OUT/bench_stats.log

@@ -37,7 +37,8 @@ def main(src, tag):
     if pk:
         # calibration: the pack kernel reads `len` input bytes exactly once
         cfg = bench["config"]
-        nbytes = cfg["n_kmers_per_gpu"] / 1000 * 1031 if "n_kmers_per_gpu" in cfg else None
+        nk = cfg.get("n_kmers", cfg.get("n_kmers_per_gpu"))
+        nbytes = nk / 1000 * 1031 if nk else None
         out["_calibration"] = {"kernel": pk[0], "known_read_bytes": nbytes, "fetch_size_bytes_raw": out[pk[0]]["fetch_size_bytes_raw"],
                                "ratio_known_over_raw": round(nbytes / out[pk[0]]["fetch_size_bytes_raw"], 3) if nbytes else None}
     json.dump(out, open("profiles/%s_traffic.json" % tag, "w"), indent=1, sort_keys=True)
