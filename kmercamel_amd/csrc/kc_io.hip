@@ -14,6 +14,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <chrono>
 #include <thread>
 #include <mutex>
@@ -362,9 +363,10 @@ extern "C" void kc_device_free(kc_ctx *ctx, void *d_ptr) {
     kc_release(ctx, d_ptr);
 }
 
-// result -> file descriptor.  Regular files: NW writer threads, each with its own pinned chunk, take 64 MB pieces in turn
-// (device-to-host copy on a private stream, then pwrite at the piece's offset) -- a single memcpy-bound write() stream is what
-// limits a tmpfs or page-cache target.  Pipes / terminals: two pinned chunks, the copy of piece i+1 overlapping the write of i.
+// result -> file descriptor.  Regular files are extended to their final size and mapped; NW worker threads, each with its
+// own pinned chunk and stream, take 64 MB pieces in turn: device-to-host copy, then a memcpy into the mapping (the page
+// allocation behind a buffered write() holds the inode lock, so concurrent write() calls would queue up; faults on a
+// shared mapping do not).  Pipes / terminals: two pinned chunks, the copy of piece i+1 overlapping the write of piece i.
 extern "C" int kc_result_write_fd(kc_result *r, int fd, int which) {
     if (!r || fd < 0) return KC_E_ARG;
     kc_ctx *ctx = r->ctx;
@@ -374,30 +376,27 @@ extern "C" int kc_result_write_fd(kc_result *r, int fd, int which) {
     const u64 total = r->slice_len;
     const size_t CH = (size_t)64 << 20;
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const off_t base = lseek(fd, 0, SEEK_CUR);
     struct stat st;
-    const bool seekable = base >= 0 && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && total > CH;
-    if (seekable) {
-        off_t start = base;
+    if (total > CH && fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
         const int fl = fcntl(fd, F_GETFL);
+        off_t start = lseek(fd, 0, SEEK_CUR);
         if (fl >= 0 && (fl & O_APPEND)) start = st.st_size;   // append mode: the data goes behind what is there
-        const int NW = 4;
-        std::atomic<u64> next{0};
-        std::atomic<int> bad{0};
-        std::vector<std::thread> th;
-        const u64 pieces = (total + CH - 1) / CH;
-        int fd2 = fd;
-        // pwrite ignores O_APPEND only on some systems (Linux appends regardless of the offset): write through a second descriptor
         char linkpath[64];
         snprintf(linkpath, sizeof linkpath, "/proc/self/fd/%d", fd);
-        if (fl >= 0 && (fl & O_APPEND)) { fd2 = ::open(linkpath, O_WRONLY); if (fd2 < 0) fd2 = fd; }
-        if (fd2 == fd && fl >= 0 && (fl & O_APPEND)) {
-            // could not get a plain descriptor: fall through to the sequential path below
-        } else {
-            if (ftruncate(fd2, start + (off_t)total) != 0) { /* not fatal: pwrite extends the file */ }
+        const int fd2 = start >= 0 ? ::open(linkpath, O_RDWR) : -1;   // (a mapping needs a readable descriptor)
+        char *map = nullptr;
+        if (fd2 >= 0 && ftruncate(fd2, start + (off_t)total) == 0) {
+            void *m = mmap(nullptr, (size_t)start + total, PROT_READ | PROT_WRITE, MAP_SHARED, fd2, 0);
+            if (m != MAP_FAILED) map = (char *)m;
+        }
+        if (map) {
+            const int NW = 8;
+            std::atomic<u64> next{0};
+            std::atomic<int> bad{0};
+            std::vector<std::thread> th;
+            const u64 pieces = (total + CH - 1) / CH;
             for (int w = 0; w < NW; ++w)
-                th.emplace_back([&, w] {
-                    (void)w;
+                th.emplace_back([&] {
                     if (hipSetDevice(ctx->device) != hipSuccess) { bad = 1; return; }
                     hipStream_t s = nullptr;
                     char *hb = nullptr;
@@ -407,23 +406,19 @@ extern "C" int kc_result_write_fd(kc_result *r, int fd, int which) {
                         if (i >= pieces || bad) break;
                         const u64 off = i * CH, n = total - off < CH ? total - off : CH;
                         if (hipMemcpyAsync(hb, src + off, n, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { bad = 1; break; }
-                        u64 done = 0;
-                        while (done < n) {
-                            const ssize_t wr = pwrite(fd2, hb + done, n - done, start + (off_t)(off + done));
-                            if (wr < 0) { bad = 2; break; }
-                            done += (u64)wr;
-                        }
+                        memcpy(map + start + off, hb, n);
                     }
                     (void)hipHostFree(hb);
                     (void)hipStreamDestroy(s);
                 });
             for (auto &t : th) t.join();
-            if (fd2 != fd) ::close(fd2);
-            else (void)lseek(fd, start + (off_t)total, SEEK_SET);
-            if (bad == 2) return kc_fail(ctx, KC_E_IO, "write failed");
+            munmap(map, (size_t)start + total);
+            ::close(fd2);
+            if (!(fl >= 0 && (fl & O_APPEND))) (void)lseek(fd, start + (off_t)total, SEEK_SET);
             if (bad) return kc_fail(ctx, KC_E_NO_DEVICE, "device-to-host copy failed");
             return KC_OK;
         }
+        if (fd2 >= 0) { (void)ftruncate(fd2, st.st_size); ::close(fd2); }
     }
     char *hb[2] = {nullptr, nullptr};
     hipEvent_t ev[2];

@@ -20,7 +20,6 @@
 #include "kc_internal.h"
 #include "kc_overlap_logic.h"
 #include "kc_overlap_lds.h"
-#include <hipcub/hipcub.hpp>
 
 #define LV_EMPTY (~(u64)0)
 #define KC_CNT_BLOCKS 256
@@ -330,24 +329,17 @@ struct OvWork {
     }
 };
 
+// ordered (stable) compaction by wave ballot / prefix scan: kcu_select_flagged (kc_util.hip)
 static int select_flagged(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u64 n, u64 *h_count) {
     kc_ctx *ctx = w.ctx;
-    size_t bytes = 0;
-    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
-    KC_TRY(w.ensure_tmp(bytes));
-    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(w.tmp, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
+    KC_TRY(kcu_select_flagged(ctx, in, flags, n, out, w.d_num));
     KC_HIP(ctx, hipMemcpyAsync(h_count, w.d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KC_OK;
 }
 
 static int select_flagged_nosync(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u64 n) {
-    kc_ctx *ctx = w.ctx;
-    size_t bytes = 0;
-    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(nullptr, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
-    KC_TRY(w.ensure_tmp(bytes));
-    KC_HIP(ctx, hipcub::DeviceSelect::Flagged(w.tmp, bytes, in, flags, out, w.d_num, (int)n, ctx->stream));
-    return KC_OK;
+    return kcu_select_flagged(w.ctx, in, flags, n, out, w.d_num);
 }
 
 // Small inputs (most levels: a few hundred to a few thousand hits) are sorted by ONE workgroup in LDS -- a bitonic network
@@ -422,13 +414,7 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         KC_HIP(ctx, hipGetLastError());
         return KC_OK;
     }
-    if (W == 1) {
-        size_t bytes = 0;
-        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys_out, ids, ids_out, (int)n, 0, total_bits, ctx->stream));
-        KC_TRY(w.ensure_tmp(bytes));
-        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(w.tmp, bytes, keys, keys_out, ids, ids_out, (int)n, 0, total_bits, ctx->stream));
-        return KC_OK;
-    }
+    if (W == 1) return kcu_sort_pairs(ctx, keys, keys_out, ids, ids_out, n, 0, total_bits);
     u64 *perm = s0, *perm2 = s1, *kw = s2, *kw2 = s3;
     hipLaunchKernelGGL(ov_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
     for (int word = 0; word < W; ++word) {
@@ -436,10 +422,7 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         if (bits <= 0) break;
         if (bits > 64) bits = 64;
         hipLaunchKernelGGL(ov_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, (const u64 *)perm, n, W, word, kw);
-        size_t bytes = 0;
-        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kw, kw2, perm, perm2, (int)n, 0, bits, ctx->stream));
-        KC_TRY(w.ensure_tmp(bytes));
-        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(w.tmp, bytes, kw, kw2, perm, perm2, (int)n, 0, bits, ctx->stream));
+        KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, n, 0, bits));
         std::swap(perm, perm2);
     }
     hipLaunchKernelGGL(ov_gather_rows_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, (const u64 *)perm, n, W, keys_out,
@@ -454,7 +437,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     const int k = s->k;
     const u64 S = s->n, V = S * (complements ? 2 : 1);
     if (S == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
-    if (V >= ((u64)1 << 31)) return kc_fail(ctx, KC_E_ARG, "more than 2^31 overlap-graph vertices are not supported yet");
+    if (V >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_ARG, "more than 2^32 overlap-graph vertices are not supported (32-bit writer tags of the path-end entries)");
     OvWork w; w.ctx = ctx;
     u64 *pre, *suf, *edge_from, *pred, *first, *last, *first_snap, *last_snap, *actS, *actP, *actS2, *actP2, *eidx;
     u8 *overlaps, *hitS, *hitP, *cov;

@@ -14,7 +14,6 @@
 // kc_accept (later rounds), kc_walk_measure (walk + 2-bit recording), kc_stream_emit, the segment-parallel kernels for long
 // chains and the cycle cutters; host flow in build_simplitigs_w.
 #include "kc_internal.h"
-#include <hipcub/hipcub.hpp>
 
 #include "kc_simp_dev.h"
 
@@ -522,16 +521,12 @@ static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k
     KC_TRY(scope.alloc(&kw, n));
     KC_TRY(scope.alloc(&kw2, n));
     hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
-    size_t tmp_bytes = 0;
-    KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, kw, kw2, perm, perm2, n, 0, 64, ctx->stream));
-    void *tmp = nullptr;
-    KC_TRY(scope.alloc((u8 **)&tmp, tmp_bytes));
     for (int word = 0; word < W; ++word) {
         int bits = 2 * k - 64 * word;
         if (bits <= 0) break;
         if (bits > 64) bits = 64;
         hipLaunchKernelGGL(kc_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, d_keys, perm, n, W, word, kw);
-        KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kw, kw2, perm, perm2, n, 0, bits, ctx->stream));
+        KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, n, 0, bits));
         std::swap(perm, perm2);
     }
     KC_HIP(ctx, hipGetLastError());
@@ -719,15 +714,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
                                (const u8 *)set->tags, cap, compl_, starts_raw, cnt + 6);
             KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
-            {
-                size_t tb = 0;
-                KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
-                u8 *tmp = nullptr;
-                KC_TRY(scope.alloc(&tmp, tb));
-                KC_HIP(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tb, starts_raw, starts, (int)nstarts, 0, 64, ctx->stream));
-                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                scope.release(tmp);
-            }
+            KC_TRY(kcu_sort_pairs(ctx, starts_raw, starts, nullptr, nullptr, nstarts, 0, 64));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             scope.release(starts_raw);
             KC_TRY(scope.alloc(&seg_len, nstarts + 1)); KC_TRY(scope.alloc(&seg_next, nstarts + 1)); KC_TRY(scope.alloc(&seg_tail, nstarts + 1));
             KC_TRY(scope.alloc(&seg_chain, nstarts + 1)); KC_TRY(scope.alloc(&seg_off, nstarts + 1));
@@ -805,12 +793,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
     hipLaunchKernelGGL(kc_chain_sizes_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)chain_len, (const u64 *)perm, S, k,
                        s->lens, nwords);
-    size_t tmp_bytes = 0;
-    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, nwords, s->woff, S, ctx->stream));
-    u8 *tmp = nullptr;
-    KC_TRY(scope.alloc(&tmp, tmp_bytes));
-    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, nwords, s->woff, S, ctx->stream));
-    hipLaunchKernelGGL(kc_finish_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, s->woff, (const u64 *)nwords, S);
+    KC_TRY(kcu_exclusive_scan(ctx, nwords, s->woff, S));   // (woff[S] = total)
     KC_TRY(read_u64(ctx, s->woff + S, &s->nwords));
     s->total_bases = N + S * (u64)(k - 1);
     rc = kc_alloc(ctx, &s->words, s->nwords + 1);
@@ -837,7 +820,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     scope.release(seg_off);
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    scope.release(tmp); scope.release(nwords); kc_release(ctx, perm);
+    scope.release(nwords); kc_release(ctx, perm);
     scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
     scope.release(link); scope.release(cnt);
     *out = s;
@@ -1115,15 +1098,10 @@ template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
     KC_TRY(kc_alloc(ctx, &cnt, n + 1));
     KC_TRY(kc_alloc(ctx, &koff, n + 1));
     hipLaunchKernelGGL(kc_kmer_counts_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->lens, n, k, cnt);
-    size_t tmp_bytes = 0;
-    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt, koff, n, ctx->stream));
-    u8 *tmp = nullptr;
-    KC_TRY(kc_alloc(ctx, &tmp, tmp_bytes));
-    KC_HIP(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, cnt, koff, n, ctx->stream));
-    hipLaunchKernelGGL(kc_finish_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, koff, (const u64 *)cnt, n);
+    KC_TRY(kcu_exclusive_scan(ctx, cnt, koff, n));   // (koff[n] = total)
     u64 nk = 0;
     KC_TRY(read_u64(ctx, koff + n, &nk));
-    kc_release(ctx, tmp);
+    if (nk >= ((u64)1 << 31)) return kc_fail(ctx, KC_E_ARG, "more than 2^31 k-mers in the sparse branch (main.cpp:175-181) are not supported");
     u64 *kmers = nullptr, *sk = nullptr, *sk2 = nullptr, *perm = nullptr, *perm2 = nullptr;
     KC_TRY(kc_alloc(ctx, &kmers, nk * W));
     KC_TRY(kc_alloc(ctx, &sk, nk)); KC_TRY(kc_alloc(ctx, &sk2, nk));
@@ -1131,9 +1109,7 @@ template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
     hipLaunchKernelGGL((kc_expand_kmers_kernel<W>), dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words,
                        (const u64 *)s->woff, (const u64 *)s->lens, (const u64 *)koff, n, k, nk, kmers, sk);
     hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, perm, nk);
-    KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, sk, sk2, perm, perm2, nk, 0, 8, ctx->stream));
-    KC_TRY(kc_alloc(ctx, &tmp, tmp_bytes));
-    KC_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, sk, sk2, perm, perm2, nk, 0, 8, ctx->stream));
+    KC_TRY(kcu_sort_pairs(ctx, sk, sk2, perm, perm2, nk, 0, 8));
     kc_simplitigs *r = new kc_simplitigs();
     int wpk = k / 32 + 1;
     r->ctx = ctx; r->k = k; r->W = W; r->n = nk; r->total_bases = nk * (u64)k; r->nwords = nk * (u64)wpk;
@@ -1147,7 +1123,7 @@ template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
                        (const u64 *)perm2, nk, k, wpk, r->lens, r->woff, r->words, r->firstK, r->lastK);
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    kc_release(ctx, tmp); kc_release(ctx, cnt); kc_release(ctx, koff); kc_release(ctx, kmers);
+    kc_release(ctx, cnt); kc_release(ctx, koff); kc_release(ctx, kmers);
     kc_release(ctx, sk); kc_release(ctx, sk2); kc_release(ctx, perm); kc_release(ctx, perm2);
     *out = r;
     return KC_OK;

@@ -91,6 +91,96 @@ int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------- stable radix sort
+// LSD radix sort of (key, value) pairs on the bits [begin_bit, end_bit) of 64-bit keys, 4 bits per pass: per-tile digit
+// counts, one exclusive scan over (digit, tile), stable scatter (every thread owns 8 consecutive elements, its 16 counters
+// live in registers, the cross-thread offsets come from workgroup prefix sums).  Used for the simplitig order, the hit
+// lists of the overlap levels and the sparse branch; sizes are 10^3..10^7, far from the hot path.
+__global__ void __launch_bounds__(256) kc_radix_hist_kernel(const u64 *__restrict__ keys, u64 n, int shift, u64 ntiles, u64 *counts) {
+    __shared__ u32 h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * KC_SCAN_TILE + (u64)threadIdx.x * 8;
+    u32 c[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) c[b] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (base + i < n) {
+            const u32 d = (u32)(keys[base + i] >> shift) & 15u;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) c[b] += d == (u32)b;
+        }
+#pragma unroll
+    for (int b = 0; b < 16; ++b) if (c[b]) atomicAdd(&h[b], c[b]);
+    __syncthreads();
+    if (threadIdx.x < 16) counts[(u64)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) kc_radix_scatter_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ vals, u64 n, int shift, u64 ntiles,
+                                                               const u64 *__restrict__ offsets, u64 *keys_out, u64 *vals_out) {
+    const u64 base = (u64)blockIdx.x * KC_SCAN_TILE + (u64)threadIdx.x * 8;
+    u64 k[8];
+    u32 d[8], c[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) c[b] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        d[i] = 16;
+        if (base + i < n) {
+            k[i] = keys[base + i];
+            d[i] = (u32)(k[i] >> shift) & 15u;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) c[b] += d[i] == (u32)b;
+        }
+    }
+    u64 pos[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+        u64 tot;
+        pos[b] = offsets[(u64)b * ntiles + blockIdx.x] + kc_block_excl_scan((u64)c[b], &tot);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (d[i] == 16) continue;
+        u64 p = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) if (d[i] == (u32)b) { p = pos[b]; pos[b] = p + 1; }
+        keys_out[p] = k[i];
+        if (vals) vals_out[p] = vals[base + i];
+    }
+}
+// keys_in / vals_in are left intact; the sorted pairs end in keys_out / vals_out (vals may be null: keys only).
+int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *vals_in, u64 *vals_out, u64 n, int begin_bit, int end_bit) {
+    if (n == 0) return KC_OK;
+    const int passes = (end_bit - begin_bit + 3) / 4;
+    if (passes <= 0) {
+        KC_HIP(ctx, hipMemcpyAsync(keys_out, keys_in, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (vals_in) KC_HIP(ctx, hipMemcpyAsync(vals_out, vals_in, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return KC_OK;
+    }
+    const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
+    u64 *counts = nullptr, *tk = nullptr, *tv = nullptr;
+    KC_TRY(kc_alloc(ctx, &counts, 16 * ntiles + 1));
+    int rc = kc_alloc(ctx, &tk, n);
+    if (rc == KC_OK && vals_in) rc = kc_alloc(ctx, &tv, n);
+    // ping-pong so that the last pass lands in the caller's output buffers
+    const u64 *sk = keys_in, *sv = vals_in;
+    for (int p = 0; p < passes && rc == KC_OK; ++p) {
+        const bool to_out = ((passes - 1 - p) & 1) == 0;
+        u64 *dk = to_out ? keys_out : tk, *dv = to_out ? vals_out : tv;
+        const int shift = begin_bit + 4 * p;
+        hipLaunchKernelGGL(kc_radix_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, n, shift, ntiles, counts);
+        rc = kcu_exclusive_scan(ctx, counts, counts, 16 * ntiles);
+        if (rc != KC_OK) break;
+        hipLaunchKernelGGL(kc_radix_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, sv, n, shift, ntiles, (const u64 *)counts, dk, dv);
+        if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "radix sort launch failed");
+        sk = dk; sv = dv;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, counts); kc_release(ctx, tk); kc_release(ctx, tv);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------- sharded lists
 // Lists filled through KC_USHARDS cursors (one 128-byte line each): shard s owns the items [s * shard_cap, s * shard_cap + min(count_s, shard_cap)).
 // kcu_compact_shards copies them, E words per item, into one contiguous list and returns the total (or ~0 on overflow of a shard).
