@@ -23,13 +23,14 @@ extern "C" int kc_superstring_from_path(kc_simplitigs *s, const uint64_t *edge_f
     KC_HIP(ctx, hipSetDevice(ctx->device));
     if (s->n == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
     KcPathDev p;
+    char *d_out = nullptr, *d_mask = nullptr;
+    u64 L = 0;
+    auto cleanup = kc_defer([&] { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, d_out); kc_release(ctx, d_mask); kco_path_release(ctx, &p); });
     p.V = s->n * (complements ? 2 : 1);
     KC_TRY(kc_alloc(ctx, &p.edge_from, p.V));
     KC_TRY(kc_alloc(ctx, &p.overlaps, p.V));
     KC_HIP(ctx, hipMemcpyAsync(p.edge_from, edge_from, p.V * 8, hipMemcpyHostToDevice, ctx->stream));
     KC_HIP(ctx, hipMemcpyAsync(p.overlaps, overlaps, p.V, hipMemcpyHostToDevice, ctx->stream));
-    char *d_out = nullptr, *d_mask = nullptr;
-    u64 L = 0;
     int rc = kce_superstring(s, &p, complements ? 1 : 0, mask_out ? set : nullptr, &d_out, mask_out ? &d_mask : nullptr, &L);
     if (rc == KC_OK) rc = copy_out_string(ctx, d_out, L, out);
     if (rc == KC_OK && mask_out) {
@@ -37,8 +38,6 @@ extern "C" int kc_superstring_from_path(kc_simplitigs *s, const uint64_t *edge_f
         else *mask_out = nullptr;
     }
     if (length) *length = L;
-    kc_release(ctx, d_out); kc_release(ctx, d_mask);
-    kco_path_release(ctx, &p);
     return rc;
 }
 
@@ -94,16 +93,30 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     hipEvent_t eend;
     KC_HIP(ctx, hipEventCreate(&eend));
     u8 *d_own = nullptr;
+    kc_result *r = nullptr;
+    kc_set *set = nullptr;
+    kc_simplitigs *simp = nullptr, *sparse = nullptr;
+    bool done = false;
+    KcPathDev p;
+    // whatever the exit path: the event, the intermediate objects and (unless the call succeeds) the result go back
+    auto cleanup = kc_defer([&] {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipEventDestroy(eend);
+        kco_path_release(ctx, &p);
+        if (sparse) kc_simplitigs_destroy(sparse);
+        if (simp) kc_simplitigs_destroy(simp);
+        if (set) kc_set_destroy(set);
+        kc_release(ctx, d_own);
+        if (!done && r) kc_result_destroy(r);
+    });
     const u8 *d_seq = (const u8 *)seq;
     if (!on_device) {
         KC_TRY(kc_alloc(ctx, &d_own, len + 64));
         KC_HIP(ctx, hipMemcpyAsync(d_own, seq, len, hipMemcpyHostToDevice, ctx->stream));
         d_seq = d_own;
     }
-    kc_result *r = new kc_result();
+    r = new kc_result();
     r->ctx = ctx;
-    kc_set *set = nullptr;
-    kc_simplitigs *simp = nullptr, *sparse = nullptr;
     u64 rounds = 0, n_kmers = 0;
     int rc = KC_OK;
     double dom_us = 0;
@@ -152,7 +165,6 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
             if (rc == KC_OK) { use = sparse; r->stats[3] = 1; }
         }
     }
-    KcPathDev p;
     if (rc == KC_OK) rc = kco_overlap_path_device(use, complements, 0, &p);
     KC_HIP(ctx, hipEventRecord(e3, ctx->stream));
     if (rc == KC_OK) {
@@ -171,12 +183,8 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         r->stats[12] = set ? set->cap : 0;
         r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
     }
-    (void)hipEventDestroy(eend);
-    if (sparse) kc_simplitigs_destroy(sparse);
-    if (simp) kc_simplitigs_destroy(simp);
-    if (set) kc_set_destroy(set);
-    kc_release(ctx, d_own);
-    if (rc != KC_OK) { kc_result_destroy(r); return rc; }
+    if (rc != KC_OK) return rc;
+    done = true;
     *out = r;
     return KC_OK;
 }

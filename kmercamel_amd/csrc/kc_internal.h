@@ -63,7 +63,8 @@ template <int W> static inline SetView<W> kc_view_raw(const kc_set *s) {
 }
 // every kernel reaches the table through a view: this is where a deferred fill happens
 template <int W> static inline SetView<W> kc_view(const kc_set *s) {
-    if (s->unclean) (void)kcs_clean_table(s);
+    // (a failed fill leaves its message in the context and keeps the flag set: the next call that checks HIP errors reports it)
+    if (s->unclean && kcs_clean_table(s) != KC_OK) s->unclean = true;
     return kc_view_raw<W>(s);
 }
 
@@ -162,6 +163,10 @@ static inline dim3 kc_grid2(u64 n, unsigned block) {
 #if defined(__HIPCC__)
 __device__ __forceinline__ u64 kc_gtid() { return ((u64)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; }
 #endif
+// run something on every exit path of a scope (early error returns included)
+template <typename F> struct KcDefer { F f; ~KcDefer() { f(); } };
+template <typename F> static inline KcDefer<F> kc_defer(F f) { return KcDefer<F>{f}; }
+
 static inline unsigned kc_grid8(u64 n, unsigned block) { u64 g = (n + block - 1) / block; g = (g + 7) / 8 * 8; return (unsigned)(g ? g : 8); }  // for kc_xcd_block_id()
 
 // ---- kc_util.hip: scan / ordered compaction / sharded lists / message routing (hand-written, no library calls) ----

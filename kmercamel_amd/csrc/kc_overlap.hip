@@ -443,6 +443,13 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u8 *overlaps, *hitS, *hitP, *cov;
     u64 *pslot, *ne, *cnt, *cnt_pool, *bl;
     KC_TRY(scope.alloc(&pre, V * W)); KC_TRY(scope.alloc(&suf, V * W));
+    edge_from = pred = nullptr; overlaps = nullptr;
+    u64 *hp = nullptr;   // pinned readback buffer
+    bool ok = false;
+    auto cleanup = kc_defer([&] {   // on failure the three output arrays go back too
+        if (hp) (void)hipHostFree(hp);
+        if (!ok) { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, edge_from); kc_release(ctx, pred); kc_release(ctx, overlaps); }
+    });
     KC_TRY(kc_alloc(ctx, &edge_from, V)); KC_TRY(kc_alloc(ctx, &pred, V)); KC_TRY(kc_alloc(ctx, &overlaps, V));
     KC_TRY(scope.alloc(&first, V)); KC_TRY(scope.alloc(&last, V)); KC_TRY(scope.alloc(&first_snap, V)); KC_TRY(scope.alloc(&last_snap, V));
     KC_TRY(scope.alloc(&actS, V)); KC_TRY(scope.alloc(&actP, V)); KC_TRY(scope.alloc(&actS2, V)); KC_TRY(scope.alloc(&actP2, V));
@@ -493,7 +500,6 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
     }
 
-    u64 *hp = nullptr;   // pinned readback buffer
     KC_HIP(ctx, hipHostMalloc((void **)&hp, 128, hipHostMallocDefault));
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
         g.d = d;
@@ -634,8 +640,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         }
         std::swap(actS, actS2); std::swap(actP, actP2);
     }
-    (void)hipHostFree(hp);
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ok = true;
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
     scope.release(big);
     void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt_pool, bl, w.d_num,

@@ -783,6 +783,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     const u64 S = nchains;
     kc_simplitigs *s = new kc_simplitigs();
     s->ctx = ctx; s->k = k; s->W = W; s->n = S;
+    bool built = false;
+    auto cleanup = kc_defer([&] { if (!built) kc_simplitigs_destroy(s); });
     u64 *perm = nullptr, *nwords = nullptr;
     int rc = sort_perm_by_keys(ctx, chain_key, S, W, k, &perm);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->lens, S + 1);
@@ -790,14 +792,14 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rc == KC_OK) rc = scope.alloc(&nwords, S + 1);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->firstK, S * W);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->lastK, S * W);
-    if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
+    if (rc != KC_OK) return rc;
     hipLaunchKernelGGL(kc_chain_sizes_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)chain_len, (const u64 *)perm, S, k,
                        s->lens, nwords);
     KC_TRY(kcu_exclusive_scan(ctx, nwords, s->woff, S));   // (woff[S] = total)
     KC_TRY(read_u64(ctx, s->woff + S, &s->nwords));
     s->total_bases = N + S * (u64)(k - 1);
     rc = kc_alloc(ctx, &s->words, s->nwords + 1);
-    if (rc != KC_OK) { kc_simplitigs_destroy(s); return rc; }
+    if (rc != KC_OK) return rc;
     if (seg_ok) {
         u64 *rank = nullptr;
         KC_TRY(scope.alloc(&rank, S + 1));
@@ -823,6 +825,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     scope.release(nwords); kc_release(ctx, perm);
     scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
     scope.release(link); scope.release(cnt);
+    built = true;
     *out = s;
     return KC_OK;
 }
