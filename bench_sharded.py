@@ -70,7 +70,7 @@ def main(args, world, rank, local_rank, read_len):
     elapsed = float(t.item())
     per_rank = [None] * world
     st = stats[-1]
-    mine = {"n_kmers_local": st["n_kmers_local"], "us_probe_kernel": st["us_probe_kernel"], "queries": st["us_insert_kernel"],
+    mine = {"n_kmers_local": st["n_kmers_rank"], "us_probe_kernel": st["us_probe_kernel"], "queries": st["queries_sent"],
             "bytes_sent_per_step": (c1["bytes_sent"] - c0["bytes_sent"]) // max(1, args.steps),
             "us_in_collectives_per_step": (c1["us_in_collectives"] - c0["us_in_collectives"]) // max(1, args.steps),
             "phases_ms": [round(st[p] / 1000.0, 3) for p in ("us_insert_phase", "us_simplitig_phase", "us_overlap_phase", "us_emit_phase", "us_total")]}

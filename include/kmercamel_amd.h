@@ -118,6 +118,10 @@ int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offse
  *            kernel), 11 k-mer insert kernel time (us, summed over its launches), 12 table capacity,
  *            13 overlap repair rounds, 14 total device us, 15 reserved */
 int kc_result_stats(kc_result *r, uint64_t *stats);
+/* the same followed by more: stats[16] cycles the simplitig rule had to cut (every k-mer of such a cycle has both ports
+ * matched; the reference's delete-as-you-go walk cannot close a cycle, so this bounds how many more simplitigs than the
+ * reference there can be), [17] k-mers held by this rank, [18] neighbour queries this rank sent (sharded runs); n <= 32 */
+int kc_result_stats_ext(kc_result *r, uint64_t *stats, int n);
 /* device pointers to the output characters (length bytes each; mask NULL unless requested) */
 int kc_result_device_ptrs(kc_result *r, void **d_out, void **d_mask);
 /* copy to host buffers of `length` bytes (mask may be NULL) */

@@ -53,6 +53,7 @@ SIGNATURES = {
     "kc_free": (None, [_vp]),
     "kc_compute": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
     "kc_result_stats": (ctypes.c_int, [_vp, _u64p]),
+    "kc_result_stats_ext": (ctypes.c_int, [_vp, _u64p, ctypes.c_int]),
     "kc_result_device_ptrs": (ctypes.c_int, [_vp, _vpp, _vpp]),
     "kc_result_copy": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_char_p]),
     "kc_result_destroy": (None, [_vp]),
@@ -75,7 +76,7 @@ SIGNATURES = {
 
 STAT_NAMES = ["n_kmers", "n_simplitigs", "length", "sparse_branch", "n_vertices", "matching_rounds", "us_insert_phase",
               "us_simplitig_phase", "us_overlap_phase", "us_emit_phase", "us_probe_kernel", "us_insert_kernel", "table_capacity",
-              "overlap_repairs", "us_total", "n_kmers_local"]
+              "overlap_repairs", "us_total", "reserved"]
 
 
 class KcError(RuntimeError):
@@ -447,9 +448,9 @@ class ComputeResult:
     def __init__(self, ctx, h):
         self.ctx, self.h = ctx, h
         ctx._adopt(self)
-        st = (ctypes.c_uint64 * 16)()
-        ctx.check(ctx.lib.kc_result_stats(h, st))
-        self.stats = dict(zip(STAT_NAMES, list(st)))
+        st = (ctypes.c_uint64 * 19)()
+        ctx.check(ctx.lib.kc_result_stats_ext(h, st, 19))
+        self.stats = dict(zip(STAT_NAMES + ["cycles_cut", "n_kmers_rank", "queries_sent"], list(st)))
         self.length = self.stats["length"]
 
     def device_ptrs(self):

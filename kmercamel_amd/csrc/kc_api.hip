@@ -117,7 +117,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     }
     r = new kc_result();
     r->ctx = ctx;
-    u64 rounds = 0, n_kmers = 0;
+    u64 rounds = 0, n_kmers = 0, cycles = 0;
     int rc = KC_OK;
     double dom_us = 0;
     KC_HIP(ctx, hipEventRecord(e0, ctx->stream));
@@ -142,7 +142,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         if (rc == KC_OK) { n_kmers = set->size_host; dom_us += 1000.0 * ev_ms(ctx->ev[6], ctx->ev[7]); }
         KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
         // phase 1: get_simplitigs (simplitigs.h:191-205)
-        if (rc == KC_OK) rc = kcp_build_simplitigs(set, &simp, &rounds);
+        if (rc == KC_OK) rc = kcp_build_simplitigs(set, &simp, &rounds, &cycles);
         if (rc == KC_OK) r->stats[10] = (u64)(1000.0 * ev_ms(ctx->ev[4], ctx->ev[5]));   // neighbour-probe kernel
     } else {
         KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -182,6 +182,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         r->stats[11] = (u64)dom_us;   // insert kernel
         r->stats[12] = set ? set->cap : 0;
         r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
+        r->stats_ext[0] = cycles; r->stats_ext[1] = n_kmers;
     }
     if (rc != KC_OK) return rc;
     done = true;
@@ -192,6 +193,11 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
 extern "C" int kc_result_stats(kc_result *r, uint64_t *stats) {
     if (!r || !stats) return KC_E_ARG;
     memcpy(stats, r->stats, sizeof r->stats);
+    return KC_OK;
+}
+extern "C" int kc_result_stats_ext(kc_result *r, uint64_t *stats, int n) {
+    if (!r || !stats || n < 0) return KC_E_ARG;
+    for (int i = 0; i < n; ++i) stats[i] = i < 16 ? r->stats[i] : (i < 32 ? r->stats_ext[i - 16] : 0);
     return KC_OK;
 }
 extern "C" int kc_result_device_ptrs(kc_result *r, void **d_out, void **d_mask) {

@@ -85,6 +85,7 @@ struct kc_result {
     u64 length = 0;                              // length of the whole superstring
     u64 slice_off = 0, slice_len = 0;
     u64 stats[16] = {0};
+    u64 stats_ext[16] = {0};   // [0] cycles cut by the simplitig rule, [1] k-mers on this rank, [2] neighbour queries sent (sharded runs)
 };
 
 #define KC_HIP(ctx, call)                                                                                  \
@@ -194,7 +195,7 @@ int kcs_refresh_size(kc_set *set);
 int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out);   // collective
 int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved_bytes);   // collective
 // kc_simplitigs.hip
-int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds);
+int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds, u64 *cycles_cut);
 int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 len, const u64 *h_offsets, u64 n, int offsets_are_host_positions,
                                      kc_simplitigs **out);
 int kcp_to_sparse(kc_simplitigs *s, kc_simplitigs **out);

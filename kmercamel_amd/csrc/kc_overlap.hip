@@ -25,6 +25,7 @@
 #define KC_CNT_BLOCKS 256
 #define KC_LDS_MIN 12      /* buckets with fewer members are replayed by a single thread straight from global memory */
 #define KC_LDS_MAX 1200    /* 39 B of LDS per member: 46 KB */
+#define KC_LDS_HUGE 3800   /* the few buckets beyond that (d <= 2: one or two buckets hold every vertex that is left) get a CU's whole LDS: 145 KB */
 
 template <int W> struct LevelTable {
     u64 *slot;     // W==1: the d-mer key; W>1: a representative prefix vertex (its key is re-derived from pre[])
@@ -183,7 +184,7 @@ template <int W> __device__ __forceinline__ int cmp_rows(const u64 *a, u64 i, co
 template <int W>
 __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__restrict__ hsk, const u64 *__restrict__ hsv, u64 nHS,
                                                       const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP, u64 *scrS, u64 *scrP,
-                                                      u64 *big, u64 big_cap, u64 *big_count) {
+                                                      u64 *big, u64 big_cap, u64 *big_count, u64 *huge, u64 huge_cap, u64 *huge_count) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHS) return;
     Key<W> key = load_key<W>(hsk, t);
@@ -206,6 +207,14 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
         u64 pos = atomicAdd((ull *)big_count, 1ULL);
         if (pos < big_cap) {
             u64 *dsc = big + pos * 5;
+            dsc[0] = t; dsc[1] = a1; dsc[2] = b0; dsc[3] = b1; dsc[4] = (u64)mode;
+            return;
+        }
+    }
+    if (members > KC_LDS_MAX && members <= KC_LDS_HUGE) {
+        u64 pos = atomicAdd((ull *)huge_count, 1ULL);
+        if (pos < huge_cap) {
+            u64 *dsc = huge + pos * 5;
             dsc[0] = t; dsc[1] = a1; dsc[2] = b0; dsc[3] = b1; dsc[4] = (u64)mode;
             return;
         }
@@ -471,6 +480,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     if (const char *e = getenv("KC_LDS_MIN")) { int v = atoi(e); if (v >= 2 && v <= KC_LDS_MAX) lds_min = v; }
     const u64 big_cap = 2 * V / (u64)(lds_min < 4 ? lds_min : 4) + 16;
     KC_TRY(scope.alloc(&big, big_cap * 5));
+    u64 *huge = nullptr;
+    const u64 huge_cap = 2 * V / KC_LDS_MAX + 16;
+    KC_TRY(scope.alloc(&huge, huge_cap * 5));
+    KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ov_match_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kc_lds_bytes_bound(KC_LDS_HUGE)));
     u64 tcap = 64;
     while (tcap < 2 * V + 16) tcap <<= 1;
     LevelTable<W> tab;
@@ -577,12 +590,18 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             // and LDS; many hits (tens of thousands of tiny buckets): those stay with one thread each
             g.lds_min = (u32)((nHS + nHP <= 32768 && !getenv("KC_LDS_MIN")) ? 4 : lds_min);
             hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
-                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8);
+                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8, huge, huge_cap, cnt + 9);
             {
                 u64 nblk = (nHS + nHP) / (u64)g.lds_min + 1;
                 if (nblk > big_cap) nblk = big_cap;
                 hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
                                    (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8));
+                if (nHS + nHP > KC_LDS_MAX) {   // only then can a bucket be that large
+                    u64 nh = (nHS + nHP) / KC_LDS_MAX + 1;
+                    if (nh > huge_cap) nh = huge_cap;
+                    hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nh), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g,
+                                       (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)huge, huge_cap, (const u64 *)(cnt + 9));
+                }
             }
             if (!lower_bound)
                 hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
@@ -643,7 +662,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ok = true;
     out->V = V; out->edge_from = edge_from; out->overlaps = overlaps; out->pred = pred; out->repairs = repairs;
-    scope.release(big);
+    scope.release(big); scope.release(huge);
     void *rel[] = {pre, suf, first, last, first_snap, last_snap, actS, actP, actS2, actP2, eidx, hitS, hitP, cov, pslot, ne, cnt_pool, bl, w.d_num,
                    tab.slot, hs_ids, hp_ids, hs_ids2, hp_ids2, hs_keys, hp_keys, hs_keys2, hp_keys2, sc0, sc1, sc2, sc3, w.tmp};
     for (void *p : rel) scope.release(p);

@@ -1089,10 +1089,8 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     r->stats[6] = (u64)(1000.0 * ev_ms(e0, e1)); r->stats[7] = (u64)(1000.0 * ev_ms(e1, e2));
     r->stats[8] = (u64)(1000.0 * ev_ms(e2, e3)); r->stats[9] = (u64)(1000.0 * ev_ms(e3, eend));
     r->stats[10] = (u64)(1000.0 * ev_ms(ctx->ev[4], ctx->ev[5]));   // neighbour-probe kernel (kc_shard_choose_kernel)
-    r->stats[11] = nq;                                              // neighbour queries this rank sent
     r->stats[12] = set->cap; r->stats[13] = path.repairs; r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
-    r->stats[15] = N_local;
-    r->stats[3] = cycles_cut;
+    r->stats_ext[0] = cycles_cut; r->stats_ext[1] = N_local; r->stats_ext[2] = nq;
     if (trace) fprintf(stderr, "[shard %d/%d] entries=%llu jump rounds=%llu chains(local winners)=%llu S=%llu messages=%llu slice=[%llu,%llu) of %llu\n", me, G,
                        (unsigned long long)n_ent, (unsigned long long)rounds, (unsigned long long)n_chains, (unsigned long long)S, (unsigned long long)n_msg,
                        (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)Ltot);

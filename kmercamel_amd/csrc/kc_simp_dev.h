@@ -374,6 +374,7 @@ __global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restric
         const u64 partner = LK_PID(wl);              // the port that faced best's port L
         link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
         link[(best << 1) | 0] = LK_DEAD | (wl & LK_SPLIT);
+        ++cursor[4];                                  // cycles cut
         heads[nh++] = (best << 1) | 0;                // entry port of orientation o is port o
         if (complements || !(partner & 1)) { if (partner != ((best << 1) | 0)) heads[nh++] = partner; }
     }
@@ -407,6 +408,7 @@ __global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set,
     __hip_atomic_store(&link[(start << 1) | 0], LK_DEAD | (wl & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool two = (complements || !(partner & 1)) && partner != ((start << 1) | 0);
     const u64 pos = atomicAdd((ull *)cursor, two ? 2ULL : 1ULL);
+    atomicAdd((ull *)(cursor + 4), 1ULL);             // cycles cut
     heads[pos] = (start << 1) | 0;
     if (two) heads[pos + 1] = partner;
 }

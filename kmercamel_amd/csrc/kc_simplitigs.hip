@@ -541,7 +541,8 @@ static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h) {
     return KC_OK;
 }
 
-template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out) {
+template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out, u64 *cycles_out) {
+    u64 cycles_cut = 0;
     kc_ctx *ctx = set->ctx;
     KcScope scope(ctx);
     const int k = set->k, compl_ = set->complements;
@@ -768,7 +769,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         else
             hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited, compl_, heads2,
                                cnt);
-        KC_TRY(read_u64(ctx, cnt, &nheads));
+        {
+            u64 hcyc[5] = {0, 0, 0, 0, 0};
+            KC_HIP(ctx, hipMemcpyAsync(hcyc, cnt, 40, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            nheads = hcyc[0]; cycles_cut += hcyc[4];
+        }
         scope.release(heads); heads = heads2;
         scope.release(ulist); scope.release(visited);
         scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
@@ -826,15 +832,16 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     scope.release(chain_head); scope.release(chain_len); scope.release(chain_key);
     scope.release(link); scope.release(cnt);
     built = true;
+    if (cycles_out) *cycles_out = cycles_cut;
     *out = s;
     return KC_OK;
 }
 
-int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds) {
+int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds, u64 *cycles) {
     switch (set->W) {
-        case 1: return build_simplitigs_w<1>(set, out, rounds);
-        case 2: return build_simplitigs_w<2>(set, out, rounds);
-        default: return build_simplitigs_w<4>(set, out, rounds);
+        case 1: return build_simplitigs_w<1>(set, out, rounds, cycles);
+        case 2: return build_simplitigs_w<2>(set, out, rounds, cycles);
+        default: return build_simplitigs_w<4>(set, out, rounds, cycles);
     }
 }
 
@@ -842,7 +849,7 @@ extern "C" int kc_simplitigs_build(kc_set *set, kc_simplitigs **out) {
     if (!set || !out) return KC_E_ARG;
     *out = nullptr;
     KC_HIP(set->ctx, hipSetDevice(set->ctx->device));
-    return kcp_build_simplitigs(set, out, nullptr);
+    return kcp_build_simplitigs(set, out, nullptr, nullptr);
 }
 
 extern "C" void kc_simplitigs_destroy(kc_simplitigs *s) {
