@@ -195,16 +195,114 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fragment contraction.  A chain walk costs one scattered 128-byte line per step for 8 useful bytes (measured: the walk
+// kernel moves 16x its algorithmic bytes and sits at the HBM transaction ceiling), but ~90 % of its steps stay inside one
+// table block (consecutive k-mers share their minimizer).  So every block first contracts the chain pieces that lie inside
+// it: one workgroup loads the block's port links (16 B per slot) into LDS, walks every in-block run ("fragment") there from
+// both of its ends, and replaces the INWARD link word of each end node by a shortcut: far end node, the number of nodes, and
+// the appended bases of the run (up to 19 inline, longer runs through a word pool).  The chain walk then hops from fragment
+// to fragment: two scattered lines per fragment instead of one per node.  The inward words are not restored -- if the hop
+// walk finds a chain beyond the limit or a cycle, the matching is recomputed and the classic flow takes over (rare on
+// read-like inputs; inputs whose chains are long on average skip the contraction in the first place).
+//
+// shortcut word: bits 0-1 = 0 (LK_OPEN, not a state of a finished port) and bit 5 (LK_REJ) set; bit 2: the bases are in the
+// pool; bits 6-19 far node (slot offset in the block); bit 20 orientation at the far node; inline: bits 21-25 number of bases,
+// bits 26-63 the bases (first one in the highest pair); pool: bits 21-34 nodes - 1, bits 35-63 first pool word (relative to
+// the block's pool base).
+#define KC_SC_IS(w) ((((w) & 3ull) == 0ull) && ((w) & LK_REJ))
+#define KC_SC_EXT 4ull
+#define KC_SC_INLINE_MAX 19
+template <int W>
+__global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
+                                                                u64 *blk_pool_base, u64 *flags) {
+    extern __shared__ u64 kc_fl[];           // the block's link words, then the list of long fragments
+    __shared__ u32 n_long, n_words;
+    __shared__ u64 pbase;
+    const u32 bs = 1u << set.bshift;
+    const u64 base = (u64)blockIdx.x << set.bshift;
+    u32 *longs = reinterpret_cast<u32 *>(kc_fl + 2 * (size_t)bs);   // (local port id of the entry, first pool word)
+    const u32 long_cap = 2048;
+    if (threadIdx.x == 0) { n_long = 0; n_words = 0; }
+    for (u32 i = threadIdx.x; i < 2 * bs; i += blockDim.x) kc_fl[i] = link[base * 2 + i];
+    __syncthreads();
+    const u64 blk = blockIdx.x;
+    auto walk = [&](u32 s, int o, u32 &far, int &fo, u32 &len, u64 &bases, u64 *ext, bool fill) {
+        // from the oriented node (s, o) along the links that stay in this block; bases = the appended bases, first one highest
+        u32 cur = s;
+        int co = o;
+        len = 1; bases = 0;
+        u64 acc = 0; int nacc = 0; u32 wi = 0;
+        while (true) {
+            const u64 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
+            if (!LK_IS_MATCHED(w) || (LK_SLOT(w) >> set.bshift) != blk) break;
+            const u64 b = LK_BASE(w);
+            if (len <= KC_SC_INLINE_MAX) bases |= b << (36 - 2 * (len - 1));
+            if (fill) { acc = (acc << 2) | b; if (++nacc == 32) { ext[wi++] = acc; acc = 0; nacc = 0; } }
+            cur = (u32)LK_SLOT(w) & (bs - 1);
+            co = LK_PORT(w) == 0 ? 0 : 1;
+            ++len;
+        }
+        if (fill && nacc) ext[wi] = acc << (64 - 2 * nacc);
+        far = cur; fo = co;
+    };
+    for (u32 s = threadIdx.x; s < bs; s += blockDim.x) {
+        if (set.tags[base + s] == 0) continue;
+        for (int o = 0; o < (complements ? 2 : 1); ++o) {
+            const u64 we = kc_fl[2 * s + o];
+            if (LK_IS_MATCHED(we) && (LK_SLOT(we) >> set.bshift) == blk) continue;   // entered from inside the block: not a fragment end
+            u32 far, len; int fo; u64 bases;
+            walk(s, o, far, fo, len, bases, nullptr, false);
+            if (len == 1) continue;
+            const u32 xp = o == 0 ? 1u : 0u;
+            if (len - 1 <= KC_SC_INLINE_MAX) {
+                link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
+            } else {
+                const u32 nw = (len - 1 + 31) / 32;
+                const u32 at = atomicAdd(&n_long, 1u);
+                const u32 rel = atomicAdd(&n_words, nw);
+                if (at < long_cap && len - 1 < (1u << 14)) { longs[2 * at] = 2 * s + (u32)o; longs[2 * at + 1] = rel; }
+                else flags[0] = 1;   // (more long runs than the list holds, or a run of 2^14 nodes: the caller falls back)
+            }
+        }
+    }
+    __syncthreads();
+    if (n_long == 0) return;
+    if (threadIdx.x == 0) {
+        pbase = atomicAdd((ull *)&pool_cursors[(blockIdx.x & 63) * 16], (ull)n_words);
+        blk_pool_base[blk] = pbase;
+    }
+    __syncthreads();
+    // pool shard s owns the words [s * pool_cap / 64, (s + 1) * pool_cap / 64)
+    const u64 shard_cap = pool_cap / 64, shard_lo = (u64)(blockIdx.x & 63) * shard_cap;
+    if (pbase + n_words > shard_cap) { if (threadIdx.x == 0) flags[0] = 1; return; }
+    const u32 nl = n_long < long_cap ? n_long : long_cap;
+    for (u32 i = threadIdx.x; i < nl; i += blockDim.x) {
+        const u32 pid = longs[2 * i], rel = longs[2 * i + 1];
+        const u32 s = pid >> 1; const int o = (int)(pid & 1);
+        u32 far, len; int fo; u64 bases;
+        walk(s, o, far, fo, len, bases, pool + shard_lo + pbase + rel, true);
+        const u32 xp = o == 0 ? 1u : 0u;
+        link[(base + s) * 2 + xp] = LK_REJ | KC_SC_EXT | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | ((u64)rel << 35);
+    }
+}
+
 // measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a
 // chain is emitted (bi: the one starting at the smaller key) and records the winners.
 // MARK: also flag visited nodes (only needed when the node count shows that cycles exist).
 // REC: also record the bases appended along the walk (32 per word, first base in bits 63:62) into 32-word chunks drawn
 // from `pool`, so that the winning direction is later emitted by copying its recording instead of walking the chain a
 // third time (every step of a walk is a scattered 128-byte line fetch; the recording is 2 bits per step).
-template <int W, bool MARK, bool REC>
+struct KcFrag {          // fragment shortcuts in the link words (kc_frag_contract_kernel); pool == nullptr: none
+    const u64 *pool;
+    const u64 *blk_pool_base;
+    u64 shard_cap;
+};
+template <int W, bool MARK, bool REC, bool FRAG = false>
 __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
                                                               const u64 *__restrict__ heads, u64 nheads, u8 *visited,
-                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit, KcRec rec) {
+                                                              u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit, KcRec rec,
+                                                              KcFrag frag = KcFrag{nullptr, nullptr, 0}) {
     // limit: give up (cursor[7] = 1) on a chain longer than this; the caller then switches to the segment-parallel path
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nheads) return;
@@ -226,14 +324,41 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         }
         rec.pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++] = word;
     };
+    auto push_base = [&](u64 b) {
+        acc = (acc << 2) | b;
+        if (++nacc == 32) { if (rec_ok) flush_word(acc); acc = 0; nacc = 0; }
+    };
     while (true) {
         if (MARK) visited[cur] = 1;
         u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
-        if (!LK_IS_MATCHED(w)) break;
-        if (REC) {
-            acc = (acc << 2) | LK_BASE(w);
-            if (++nacc == 32) { if (rec_ok) flush_word(acc); acc = 0; nacc = 0; }
+        if (FRAG && KC_SC_IS(w)) {
+            // a contracted run: take its bases, continue at its far end
+            const u64 blk = cur >> set.bshift;
+            u64 nb;
+            if (w & KC_SC_EXT) {
+                nb = (w >> 21) & 0x3fff;
+                const u64 *src = frag.pool + (blk & 63) * frag.shard_cap + frag.blk_pool_base[blk] + (w >> 35);
+                if (REC)
+                    for (u64 i = 0; i < nb; i += 32) {
+                        const u64 word = src[i >> 5];
+                        const int m = nb - i >= 32 ? 32 : (int)(nb - i);
+                        for (int j = 0; j < m; ++j) push_base((word >> (62 - 2 * j)) & 3);
+                    }
+            } else {
+                nb = (w >> 21) & 31;
+                if (REC) for (u64 i = 0; i < nb; ++i) push_base((w >> (62 - 2 * i)) & 3);
+            }
+            len += nb;
+            cur = (blk << set.bshift) | ((w >> 6) & 0x3fff);
+            co = (int)((w >> 20) & 1);
+            if (len > limit) {
+                if (__hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicExch((ull *)(cursor + 7), 1ULL);
+                return;
+            }
+            w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         }
+        if (!LK_IS_MATCHED(w)) break;
+        if (REC) push_base(LK_BASE(w));
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
         if (++len > limit) {
@@ -541,7 +666,8 @@ static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h) {
     return KC_OK;
 }
 
-template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out, u64 *cycles_out) {
+#define KC_RETRY_NOFRAG 1000   /* internal: the fragment hop walk met a long chain or a cycle; redo without contraction */
+template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out, u64 *cycles_out, bool allow_frag) {
     u64 cycles_cut = 0;
     kc_ctx *ctx = set->ctx;
     KcScope scope(ctx);
@@ -681,7 +807,32 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_TRY(scope.alloc(&chain_tail, max_chains));
             rec.pool = pool; rec.chunk_next = chunk_next; rec.pool_cursor = cnt + 5; rec.chain_stream = chain_stream; rec.chain_tail = chain_tail;
         }
-        if (nheads && !known_long) {
+        // fragment contraction (see kc_frag_contract_kernel): worth it when the chains are short on average (read-like input)
+        const bool use_frag = allow_frag && pass == 0 && want_rec && !known_long && nheads && set->mlen && set->bshift <= 13 && !getenv("KC_NOFRAG") &&
+                              2 * N / nheads <= KC_CHAIN_LIMIT / 2;
+        u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr;
+        if (use_frag) {
+            const u64 pool_cap = (N / 16 + 65536) / 64 * 64;
+            KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, set->nblocks)); KC_TRY(scope.alloc(&fcur, 64 * 16 + 16));
+            KC_HIP(ctx, hipMemsetAsync(fcur, 0, (64 * 16 + 16) * 8, ctx->stream));
+            const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 8 + 2048 * 8;
+            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
+                               fcur + 64 * 16);
+            const KcFrag fr{fpool, fbase, pool_cap / 64};
+            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
+                               (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
+                               KC_CHAIN_LIMIT, rec, fr);
+            KC_HIP(ctx, hipGetLastError());
+            u64 hf[8] = {0}, fflag = 0;
+            KC_HIP(ctx, hipMemcpyAsync(hf, cnt, 64, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipMemcpyAsync(&fflag, fcur + 64 * 16, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            // the inward links of the fragment ends are shortcuts now: anything but a clean result means starting over without them
+            if (fflag || hf[7] || hf[6] || hf[3] != N) return KC_RETRY_NOFRAG;
+            scope.release(fpool); scope.release(fbase); scope.release(fcur);
+        }
+        if (nheads && !known_long && !use_frag) {
             if (want_rec)
                 hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                    (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
@@ -838,11 +989,16 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
 }
 
 int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds, u64 *cycles) {
-    switch (set->W) {
-        case 1: return build_simplitigs_w<1>(set, out, rounds, cycles);
-        case 2: return build_simplitigs_w<2>(set, out, rounds, cycles);
-        default: return build_simplitigs_w<4>(set, out, rounds, cycles);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc;
+        switch (set->W) {
+            case 1: rc = build_simplitigs_w<1>(set, out, rounds, cycles, attempt == 0); break;
+            case 2: rc = build_simplitigs_w<2>(set, out, rounds, cycles, attempt == 0); break;
+            default: rc = build_simplitigs_w<4>(set, out, rounds, cycles, attempt == 0); break;
+        }
+        if (rc != KC_RETRY_NOFRAG) return rc;
     }
+    return kc_fail(set->ctx, KC_E_NO_DEVICE, "simplitig build did not settle");
 }
 
 extern "C" int kc_simplitigs_build(kc_set *set, kc_simplitigs **out) {
