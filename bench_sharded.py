@@ -33,7 +33,26 @@ def main(args, world, rank, local_rank, read_len):
         red_dev = torch.device("cpu")
     dev = torch.device("cuda", local_rank)
     ctx = kc.Context(local_rank)
-    comm = kc.Comm.rccl(ctx, dist) if backend == "nccl" else kc.Comm.torch_host(ctx, dist)
+    transport = "RCCL grouped ncclSend/ncclRecv (xGMI)"
+    if backend == "nccl":
+        # the library's own RCCL communicator; should it not come up on this node (all ranks decide together), fall back to the
+        # host-staged transport over a gloo group rather than lose the measurement -- the line says which one ran
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            comm = kc.Comm.rccl(ctx, dist)
+        except Exception as e:  # noqa: BLE001
+            print("bench_sharded: RCCL communicator failed on rank %d: %r" % (rank, e), file=sys.stderr, flush=True)
+            comm = None
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = kc.Comm.torch_host(ctx, dist, group=dist.new_group(backend="gloo"))
+            transport = "host-staged gloo (the RCCL communicator did not come up)"
+    else:
+        comm = kc.Comm.torch_host(ctx, dist)
+        transport = "host-staged " + backend
     lo, hi = bench.record_range(args.records, rank, world)
     host = bench.generate(args.seed, lo, hi, read_len)
     d_seq = torch.from_numpy(host).to(dev)
@@ -122,7 +141,7 @@ def main(args, world, rank, local_rank, read_len):
                                    % (cfg_name, args.records, read_len, args.seed, bench.CHUNK_RECORDS, k),
                        "n_kmers": N, "n_simplitigs": S, "superstring_length": st["length"],
                        "sharding": "k-mer set by table-block range (hash of the canonical minimizer); exchanges: k-mer buckets, neighbour queries + answers, fragment pointer jumping, packed bases to the emitting rank",
-                       "transport": "RCCL grouped ncclSend/ncclRecv (xGMI)" if backend == "nccl" else "host-staged " + backend},
+                       "transport": transport},
             "fragment_jump_rounds": st["matching_rounds"], "overlap_repairs": st["overlap_repairs"],
             "per_rank": per_rank,
             "roofline": {"bound": "hbm", "kernel": "kc_shard_choose_kernel<W,K> (neighbour probe of the slowest rank's shard)", "achieved": round(achieved, 2),

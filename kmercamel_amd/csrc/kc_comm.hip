@@ -91,9 +91,14 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
         }
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     } else {
+        // the part a rank keeps for itself is a device-to-device copy; the rest goes out as one group of sends and receives
+        if (send_cnt[c->rank] != recv_cnt[c->rank]) return kc_fail(ctx, KC_E_ARG, "all-to-all: a rank's send and receive counts for itself differ");
+        if (send_cnt[c->rank])
+            KC_HIP(ctx, hipMemcpyAsync((u8 *)d_recv + recv_off[c->rank], (const u8 *)d_send + send_off[c->rank], send_cnt[c->rank], hipMemcpyDeviceToDevice, ctx->stream));
         int e = g_rccl.group_start();
         if (e) return nccl_fail(ctx, "ncclGroupStart", e);
         for (int p = 0; p < G && !e; ++p) {
+            if (p == c->rank) continue;
             if (send_cnt[p]) e = g_rccl.send(const_cast<u8 *>((const u8 *)d_send + send_off[p]), send_cnt[p], kNcclUint8, p, c->nccl_comm, ctx->stream);
             if (!e && recv_cnt[p]) e = g_rccl.recv((u8 *)d_recv + recv_off[p], recv_cnt[p], kNcclUint8, p, c->nccl_comm, ctx->stream);
         }

@@ -206,6 +206,13 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 // walk finds a chain beyond the limit or a cycle, the matching is recomputed and the classic flow takes over (rare on
 // read-like inputs; inputs whose chains are long on average skip the contraction in the first place).
 //
+// MEASURED (MI355X, k = 31): the hop walk touches 4.5x fewer lines, yet at 2.5e9 k-mers it takes 124 ms against 114 ms for the
+// plain walk, and the contraction itself costs 43 ms more (10^8 k-mers: 1.8 + 2.7 ms against 4.7 ms).  Both walks make the same
+// number of BLOCK CHANGES (0.22 per k-mer and direction), i.e. of jumps to a random 128 KB region of an 80 GB array, and their
+// time follows that number, not the number of lines: the dependent chain is bound by the address-translation misses of those
+// jumps (~5 G/s with every resident walker waiting on one), not by HBM line fetches.  The contraction is therefore an
+// experiment kept behind KC_FRAG=1 (tests run it); it is off by default.
+//
 // shortcut word: bits 0-1 = 0 (LK_OPEN, not a state of a finished port) and bit 5 (LK_REJ) set; bit 2: the bases are in the
 // pool; bits 6-19 far node (slot offset in the block); bit 20 orientation at the far node; inline: bits 21-25 number of bases,
 // bits 26-63 the bases (first one in the highest pair); pool: bits 21-34 nodes - 1, bits 35-63 first pool word (relative to
@@ -213,20 +220,30 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 #define KC_SC_IS(w) ((((w) & 3ull) == 0ull) && ((w) & LK_REJ))
 #define KC_SC_EXT 4ull
 #define KC_SC_INLINE_MAX 19
+#define KC_FRAG_LONGS 512       /* runs of more than 20 nodes per block that get pool space (expected ~100) */
+#define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
 template <int W>
 __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
                                                                 u64 *blk_pool_base, u64 *flags) {
-    extern __shared__ u64 kc_fl[];           // the block's link words, then the list of long fragments
-    __shared__ u32 n_long, n_words;
+    // LDS: per port of the block one 32-bit word -- bit 31: matched to a slot of this block; then bits 0-13 that slot's offset,
+    // bit 14 the port entered there, bits 15-16 the appended base -- then the list of long runs and the list of fragment ends.
+    // (76 KB for 8192-slot blocks: two workgroups share a CU.)
+    extern __shared__ u32 kc_fl[];
+    __shared__ u32 n_long, n_words, n_ent;
     __shared__ u64 pbase;
     const u32 bs = 1u << set.bshift;
     const u64 base = (u64)blockIdx.x << set.bshift;
-    u32 *longs = reinterpret_cast<u32 *>(kc_fl + 2 * (size_t)bs);   // (local port id of the entry, first pool word)
-    const u32 long_cap = 2048;
-    if (threadIdx.x == 0) { n_long = 0; n_words = 0; }
-    for (u32 i = threadIdx.x; i < 2 * bs; i += blockDim.x) kc_fl[i] = link[base * 2 + i];
-    __syncthreads();
     const u64 blk = blockIdx.x;
+    u32 *longs = kc_fl + 2 * (size_t)bs;                            // (local port id of the entry, first pool word)
+    const u32 long_cap = KC_FRAG_LONGS, ent_cap = KC_FRAG_ENTRIES;
+    unsigned short *ents = reinterpret_cast<unsigned short *>(longs + 2 * long_cap);   // local port ids of the fragment ends
+    if (threadIdx.x == 0) { n_long = 0; n_words = 0; n_ent = 0; }
+    for (u32 i = threadIdx.x; i < 2 * bs; i += blockDim.x) {
+        const u64 w = link[base * 2 + i];
+        const bool in = set.tags[base + (i >> 1)] != 0 && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
+        kc_fl[i] = in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15)) : 0u;
+    }
+    __syncthreads();
     auto walk = [&](u32 s, int o, u32 &far, int &fo, u32 &len, u64 &bases, u64 *ext, bool fill) {
         // from the oriented node (s, o) along the links that stay in this block; bases = the appended bases, first one highest
         u32 cur = s;
@@ -234,36 +251,53 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         len = 1; bases = 0;
         u64 acc = 0; int nacc = 0; u32 wi = 0;
         while (true) {
-            const u64 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
-            if (!LK_IS_MATCHED(w) || (LK_SLOT(w) >> set.bshift) != blk) break;
-            const u64 b = LK_BASE(w);
+            const u32 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
+            if (!(w >> 31)) break;
+            const u64 b = (w >> 15) & 3;
             if (len <= KC_SC_INLINE_MAX) bases |= b << (36 - 2 * (len - 1));
             if (fill) { acc = (acc << 2) | b; if (++nacc == 32) { ext[wi++] = acc; acc = 0; nacc = 0; } }
-            cur = (u32)LK_SLOT(w) & (bs - 1);
-            co = LK_PORT(w) == 0 ? 0 : 1;
+            cur = w & 0x3fffu;
+            co = (int)((w >> 14) & 1);
             ++len;
         }
         if (fill && nacc) ext[wi] = acc << (64 - 2 * nacc);
         far = cur; fo = co;
     };
-    for (u32 s = threadIdx.x; s < bs; s += blockDim.x) {
-        if (set.tags[base + s] == 0) continue;
+    // The fragment ends first go into a list (one LDS atomic per wavefront and sweep step: ballot + popcount), so that the walks
+    // below run with every lane busy -- walking straight from the slot sweep kept ~3 of 64 lanes active.
+    const int lane = threadIdx.x & 63;
+    for (u32 s0 = 0; s0 < bs; s0 += blockDim.x) {
+        const u32 s = s0 + threadIdx.x;
         for (int o = 0; o < (complements ? 2 : 1); ++o) {
-            const u64 we = kc_fl[2 * s + o];
-            if (LK_IS_MATCHED(we) && (LK_SLOT(we) >> set.bshift) == blk) continue;   // entered from inside the block: not a fragment end
-            u32 far, len; int fo; u64 bases;
-            walk(s, o, far, fo, len, bases, nullptr, false);
-            if (len == 1) continue;
-            const u32 xp = o == 0 ? 1u : 0u;
-            if (len - 1 <= KC_SC_INLINE_MAX) {
-                link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
-            } else {
-                const u32 nw = (len - 1 + 31) / 32;
-                const u32 at = atomicAdd(&n_long, 1u);
-                const u32 rel = atomicAdd(&n_words, nw);
-                if (at < long_cap && len - 1 < (1u << 14)) { longs[2 * at] = 2 * s + (u32)o; longs[2 * at + 1] = rel; }
-                else flags[0] = 1;   // (more long runs than the list holds, or a run of 2^14 nodes: the caller falls back)
+            // an end of a run of >= 2 nodes: occupied, not entered from inside the block, left towards a slot of the block
+            const bool is_end = set.tags[base + s] != 0 && !(kc_fl[2 * s + o] >> 31) && (kc_fl[2 * s + (o == 0 ? 1 : 0)] >> 31);
+            const unsigned long long m = __ballot(is_end);
+            if (!m) continue;
+            u32 at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&n_ent, (u32)__popcll(m));
+            at0 = __shfl(at0, 0, 64);
+            if (is_end) {
+                const u32 at = at0 + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1));
+                if (at < ent_cap) ents[at] = (unsigned short)(2 * s + (u32)o); else flags[0] = 1;
             }
+        }
+    }
+    __syncthreads();
+    const u32 ne = n_ent < ent_cap ? n_ent : ent_cap;
+    for (u32 e = threadIdx.x; e < ne; e += blockDim.x) {
+        const u32 s = ents[e] >> 1;
+        const int o = (int)(ents[e] & 1);
+        u32 far, len; int fo; u64 bases;
+        walk(s, o, far, fo, len, bases, nullptr, false);
+        const u32 xp = o == 0 ? 1u : 0u;
+        if (len - 1 <= KC_SC_INLINE_MAX) {
+            link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
+        } else {
+            const u32 nw = (len - 1 + 31) / 32;
+            const u32 at = atomicAdd(&n_long, 1u);
+            const u32 rel = atomicAdd(&n_words, nw);
+            if (at < long_cap && len - 1 < (1u << 14)) { longs[2 * at] = 2 * s + (u32)o; longs[2 * at + 1] = rel; }
+            else flags[0] = 1;   // (more long runs than the list holds, or a run of 2^14 nodes: the caller falls back)
         }
     }
     __syncthreads();
@@ -808,14 +842,15 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             rec.pool = pool; rec.chunk_next = chunk_next; rec.pool_cursor = cnt + 5; rec.chain_stream = chain_stream; rec.chain_tail = chain_tail;
         }
         // fragment contraction (see kc_frag_contract_kernel): worth it when the chains are short on average (read-like input)
-        const bool use_frag = allow_frag && pass == 0 && want_rec && !known_long && nheads && set->mlen && set->bshift <= 13 && !getenv("KC_NOFRAG") &&
+        // OFF by default (KC_FRAG=1 turns it on): measured on MI355X it does not pay -- see the note at kc_frag_contract_kernel.
+        const bool use_frag = allow_frag && pass == 0 && want_rec && !known_long && nheads && set->mlen && set->bshift <= 13 && getenv("KC_FRAG") &&
                               2 * N / nheads <= KC_CHAIN_LIMIT / 2;
         u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr;
         if (use_frag) {
             const u64 pool_cap = (N / 16 + 65536) / 64 * 64;
             KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, set->nblocks)); KC_TRY(scope.alloc(&fcur, 64 * 16 + 16));
             KC_HIP(ctx, hipMemsetAsync(fcur, 0, (64 * 16 + 16) * 8, ctx->stream));
-            const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 8 + 2048 * 8;
+            const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
                                fcur + 64 * 16);
@@ -829,6 +864,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_HIP(ctx, hipMemcpyAsync(&fflag, fcur + 64 * 16, 8, hipMemcpyDeviceToHost, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             // the inward links of the fragment ends are shortcuts now: anything but a clean result means starting over without them
+            if (getenv("KC_SIMP_TRACE"))
+                fprintf(stderr, "[simp] fragment walk: flag %llu, too long %llu, recording overflow %llu, covered %llu of %llu, chains %llu\n", (unsigned long long)fflag,
+                        (unsigned long long)hf[7], (unsigned long long)hf[6], (unsigned long long)hf[3], (unsigned long long)N, (unsigned long long)hf[0]);
             if (fflag || hf[7] || hf[6] || hf[3] != N) return KC_RETRY_NOFRAG;
             scope.release(fpool); scope.release(fbase); scope.release(fcur);
         }

@@ -11,6 +11,7 @@ import json
 import os
 import random
 
+import numpy as np
 import pytest
 
 import gen
@@ -138,8 +139,9 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [{"KC_BUCKET_MIN": "0"}, {"KC_BUCKET_MIN": "1000000000"}, {"KC_NOREC": "1"}, {"KC_NOSTAGE": "1"},
-                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}],
-                         ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills"])
+                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_FRAG": "1"}, {"KC_FRAG": "1", "KC_CHAIN_LIMIT": "600"}],
+                         ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "fragment-contraction",
+                              "fragment-contraction-then-fallback"])
 def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
     """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
     walk, LDS tag staging) must give the same set and the same simplitigs; KC_LOCAL_PROBES=2 makes block-local probe runs
@@ -170,6 +172,27 @@ def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, mon
                 assert sim.strings() == want
                 sim.close()
             s1.close(); s2.close()
+
+
+@pytest.mark.parametrize("k", [21, 31, 63, 127])
+def test_fragment_contraction_path(ctx, k, monkeypatch):
+    """KC_FRAG=1: in-block chain runs are contracted into shortcuts in LDS and the measure walk hops from fragment to fragment
+    (kc_frag_contract_kernel).  Same bytes as the default walk on read-like input (chains of ~500 nodes, every fragment length
+    incl. runs beyond the 19 inline bases), both strand modes; a chain limit below the chain length takes the
+    recompute-and-fall-back route."""
+    seq = gen.random_joined(3000, 500 + k, seed=900 + k)
+    for complements in (True, False):
+        want = kc.compute(ctx, seq, k, complements)
+        w = want.array().copy()
+        want.close()
+        for env in ({"KC_FRAG": "1"}, {"KC_FRAG": "1", "KC_CHAIN_LIMIT": "1100"}, {"KC_FRAG": "1", "KC_BSHIFT": "10"}):
+            for name, value in env.items():
+                monkeypatch.setenv(name, value)
+            got = kc.compute(ctx, seq, k, complements)
+            assert np.array_equal(got.array(), w), (k, complements, env)
+            got.close()
+            for name in env:
+                monkeypatch.delenv(name)
 
 
 @pytest.mark.parametrize("k", [31, 40, 100])
