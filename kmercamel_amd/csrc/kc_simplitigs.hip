@@ -358,9 +358,16 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         }
         rec.pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++] = word;
     };
-    auto push_base = [&](u64 b) {
-        acc = (acc << 2) | b;
-        if (++nacc == 32) { if (rec_ok) flush_word(acc); acc = 0; nacc = 0; }
+    // append n (1..32) bases given right-aligned in `bits` (first base in the highest pair) to the recording
+    auto push_group = [&](u64 bits, int n) {
+        const int room = 32 - nacc;
+        if (n < room) { acc = (acc << (2 * n)) | bits; nacc += n; return; }
+        const int rest = n - room;                                   // `room` bases complete the pending word
+        const u64 hi = rest ? (bits >> (2 * rest)) : bits;
+        const u64 word = room == 32 ? hi : ((acc << (2 * room)) | hi);
+        if (rec_ok) flush_word(word);
+        acc = rest ? (bits & (((u64)1 << (2 * rest)) - 1)) : 0;
+        nacc = rest;
     };
     while (true) {
         if (MARK) visited[cur] = 1;
@@ -374,13 +381,12 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
                 const u64 *src = frag.pool + (blk & 63) * frag.shard_cap + frag.blk_pool_base[blk] + (w >> 35);
                 if (REC)
                     for (u64 i = 0; i < nb; i += 32) {
-                        const u64 word = src[i >> 5];
                         const int m = nb - i >= 32 ? 32 : (int)(nb - i);
-                        for (int j = 0; j < m; ++j) push_base((word >> (62 - 2 * j)) & 3);
+                        push_group(src[i >> 5] >> (64 - 2 * m), m);
                     }
             } else {
                 nb = (w >> 21) & 31;
-                if (REC) for (u64 i = 0; i < nb; ++i) push_base((w >> (62 - 2 * i)) & 3);
+                if (REC && nb) push_group(w >> (64 - 2 * nb), (int)nb);
             }
             len += nb;
             cur = (blk << set.bshift) | ((w >> 6) & 0x3fff);
@@ -392,7 +398,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
             w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         }
         if (!LK_IS_MATCHED(w)) break;
-        if (REC) push_base(LK_BASE(w));
+        if (REC) push_group(LK_BASE(w), 1);
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
         if (++len > limit) {

@@ -180,12 +180,13 @@ def test_fragment_contraction_path(ctx, k, monkeypatch):
     (kc_frag_contract_kernel).  Same bytes as the default walk on read-like input (chains of ~500 nodes, every fragment length
     incl. runs beyond the 19 inline bases), both strand modes; a chain limit below the chain length takes the
     recompute-and-fall-back route."""
-    seq = gen.random_joined(3000, 500 + k, seed=900 + k)
+    seq = np.concatenate([gen.random_joined(3000, 500 + k, seed=900 + k), np.array([10], dtype=np.uint8),
+                          gen.random_joined(60, 2500 + k, seed=901 + k)])   # a few chains beyond the limit of the second setting
     for complements in (True, False):
         want = kc.compute(ctx, seq, k, complements)
         w = want.array().copy()
         want.close()
-        for env in ({"KC_FRAG": "1"}, {"KC_FRAG": "1", "KC_CHAIN_LIMIT": "1100"}, {"KC_FRAG": "1", "KC_BSHIFT": "10"}):
+        for env in ({"KC_FRAG": "1"}, {"KC_FRAG": "1", "KC_CHAIN_LIMIT": "1200"}, {"KC_FRAG": "1", "KC_BSHIFT": "10"}):
             for name, value in env.items():
                 monkeypatch.setenv(name, value)
             got = kc.compute(ctx, seq, k, complements)
