@@ -206,12 +206,10 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 // walk finds a chain beyond the limit or a cycle, the matching is recomputed and the classic flow takes over (rare on
 // read-like inputs; inputs whose chains are long on average skip the contraction in the first place).
 //
-// MEASURED (MI355X, k = 31): the hop walk touches 4.5x fewer lines, yet at 2.5e9 k-mers it takes 124 ms against 114 ms for the
-// plain walk, and the contraction itself costs 43 ms more (10^8 k-mers: 1.8 + 2.7 ms against 4.7 ms).  Both walks make the same
-// number of BLOCK CHANGES (0.22 per k-mer and direction), i.e. of jumps to a random 128 KB region of an 80 GB array, and their
-// time follows that number, not the number of lines: the dependent chain is bound by the address-translation misses of those
-// jumps (~5 G/s with every resident walker waiting on one), not by HBM line fetches.  The contraction is therefore an
-// experiment kept behind KC_FRAG=1 (tests run it); it is off by default.
+// MEASURED (MI355X, k = 31, 2.5e9 k-mers): contraction 43 ms + hop walk 71 ms = the plain walk's 114 ms.  The hop walk
+// touches 4.5x fewer lines but runs at 15 G lines/s against the plain walk's 44 G lines/s: every hop is a dependent jump to a
+// random 128 KB region of an 80 GB array, and both walks make the same number of those jumps (0.22 per k-mer and direction).
+// The contraction is therefore an experiment kept behind KC_FRAG=1 (the tests run it); it is off by default.
 //
 // shortcut word: bits 0-1 = 0 (LK_OPEN, not a state of a finished port) and bit 5 (LK_REJ) set; bit 2: the bases are in the
 // pool; bits 6-19 far node (slot offset in the block); bit 20 orientation at the far node; inline: bits 21-25 number of bases,
