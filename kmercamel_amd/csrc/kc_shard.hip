@@ -457,8 +457,22 @@ __global__ void __launch_bounds__(256) kc_shard_chain_kernel(SetView<W> set, int
     for (int w = 0; w < W; ++w) { c[3 + w] = hk.w[w]; c[3 + W + w] = fk.w[w]; c[3 + 2 * W + w] = lk.w[w]; }
 }
 
-// ---- the replicated simplitig list: chain records sorted by head key (host) -> lens / firstK / lastK / final fragment ids
-// sorted final-fragment ids for the membership test of the fragments
+// ---- the replicated simplitig list: chain records sorted by head key (device radix sort over the key words) -> lens / word
+// counts / firstK / lastK / final fragment ids; the final-fragment ids sorted once more for the fragments' membership test
+__global__ void __launch_bounds__(256) kc_shard_row_word_kernel(const u64 *__restrict__ rows, const u64 *__restrict__ perm, u64 n, int CW, int word, u64 *out) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = rows[perm[t] * (u64)CW + word];
+}
+__global__ void __launch_bounds__(256) kc_shard_simp_fill_kernel(const u64 *__restrict__ rows, const u64 *__restrict__ perm, u64 S, int CW, int W, int k, u64 *lens,
+                                                                 u64 *nwords, u64 *firstK, u64 *lastK, u64 *fin, u64 *idx) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const u64 *r = rows + perm[i] * (u64)CW;
+    const u64 L = r[1] + (u64)(k - 1);
+    lens[i] = L; nwords[i] = L / 32 + 1;
+    for (int w = 0; w < W; ++w) { firstK[i * W + w] = r[3 + W + w]; lastK[i * W + w] = r[3 + 2 * W + w]; }
+    fin[i] = r[0]; idx[i] = i;
+}
 __device__ __forceinline__ u64 kc_lower_bound64(const u64 *a, u64 n, u64 v) {
     u64 lo = 0, hi = n;
     while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
@@ -994,40 +1008,35 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     struct SimpGuard { kc_simplitigs *s; ~SimpGuard() { if (s) kc_simplitigs_destroy(s); } } simpg{simp};
     u64 *fin_sorted = nullptr, *fin_simp = nullptr;
     {
-        std::vector<u64> rows(S * CW);
-        KC_HIP(ctx, hipMemcpyAsync(rows.data(), all_chains, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        kc_release(ctx, all_chains);
-        std::vector<u64> order(S);
-        for (u64 i = 0; i < S; ++i) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](u64 a, u64 b) { return hkey_lt<W>(rows.data() + a * CW + 3, rows.data() + b * CW + 3); });
-        std::vector<u64> lens(S + 1), woff(S + 1), firstK(S * W + 1), lastK(S * W + 1);
-        std::vector<std::pair<u64, u64>> fin(S);
-        u64 wsum = 0, bases = 0;
-        for (u64 i = 0; i < S; ++i) {
-            const u64 *r = rows.data() + order[i] * CW;
-            lens[i] = r[1] + (u64)(k - 1);
-            woff[i] = wsum; wsum += lens[i] / 32 + 1; bases += lens[i];
-            for (int w = 0; w < W; ++w) { firstK[i * W + w] = r[3 + W + w]; lastK[i * W + w] = r[3 + 2 * W + w]; }
-            fin[i] = {r[0], i};
+        // order by head key: stable LSD radix sort over the key words, least significant word first (as the single-GPU flow)
+        u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr, *nw = nullptr, *fin = nullptr, *idx = nullptr;
+        KC_TRY(scope.alloc(&perm, S + 1)); KC_TRY(scope.alloc(&perm2, S + 1)); KC_TRY(scope.alloc(&kw, S + 1)); KC_TRY(scope.alloc(&kw2, S + 1));
+        KC_TRY(scope.alloc(&nw, S + 1)); KC_TRY(scope.alloc(&fin, S + 1)); KC_TRY(scope.alloc(&idx, S + 1));
+        hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, perm, S);
+        for (int word = 0; word < W; ++word) {
+            int bits = 2 * k - 64 * word;
+            if (bits <= 0) break;
+            if (bits > 64) bits = 64;
+            hipLaunchKernelGGL(kc_shard_row_word_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, 3 + word, kw);
+            KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, S, 0, bits));
+            std::swap(perm, perm2);
         }
-        woff[S] = wsum;
-        std::sort(fin.begin(), fin.end());
-        std::vector<u64> fs(S + 1), fi(S + 1);
-        for (u64 i = 0; i < S; ++i) { fs[i] = fin[i].first; fi[i] = fin[i].second; }
-        simp->nwords = wsum; simp->total_bases = bases;
         KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
         KC_TRY(kc_alloc(ctx, &simp->firstK, S * W + 1)); KC_TRY(kc_alloc(ctx, &simp->lastK, S * W + 1));
-        KC_TRY(kc_alloc(ctx, &simp->words, wsum + 2));
         KC_TRY(scope.alloc(&fin_sorted, S + 1)); KC_TRY(scope.alloc(&fin_simp, S + 1));
-        KC_HIP(ctx, hipMemcpyAsync(simp->lens, lens.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(simp->woff, woff.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(simp->firstK, firstK.data(), (S * W + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(simp->lastK, lastK.data(), (S * W + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(fin_sorted, fs.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        KC_HIP(ctx, hipMemcpyAsync(fin_simp, fi.data(), (S + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(kc_shard_simp_fill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, W, k, simp->lens, nw,
+                           simp->firstK, simp->lastK, fin, idx);
+        KC_HIP(ctx, hipGetLastError());
+        KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S));                       // woff[S] = words in total
+        KC_TRY(kcu_sort_pairs(ctx, fin, fin_sorted, idx, fin_simp, S, 0, 64));     // final fragment id -> simplitig
+        u64 wsum = 0;
+        KC_TRY(read_words(ctx, simp->woff + S, &wsum, 1));
+        simp->nwords = wsum; simp->total_bases = N + S * (u64)(k - 1);
+        KC_TRY(kc_alloc(ctx, &simp->words, wsum + 2));
         KC_HIP(ctx, hipMemsetAsync(simp->words, 0, (wsum + 2) * 8, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        kc_release(ctx, all_chains);
+        scope.release(perm); scope.release(perm2); scope.release(kw); scope.release(kw2); scope.release(nw); scope.release(fin); scope.release(idx);
     }
     KC_HIP(ctx, hipEventRecord(e2, ctx->stream));
     // ---------------- phase 2 (replicated) and the path ranking of phase 3
