@@ -690,7 +690,8 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     KC_TRY(scope.alloc(&cur, (2 * KC_USH + 4) * KC_USTRIDE));
     ShLists L{};
     const int QW = W + 2, EW = 4 + 2 * W;
-    u64 rec_scap = (N_local + N_local / 8) / KC_USH + 4096, qry_scap = (N_local + N_local / 2) / KC_USH + 4096;
+    // expected: ~0.5 records and ~0.8 queries per k-mer at 8 ranks, fewer at 2 or 4; an overflow doubles the lists and repeats the sweep
+    u64 rec_scap = (N_local - N_local / 4) / KC_USH + 4096, qry_scap = N_local / KC_USH + 4096;
     const int stage_words = (int)(((u64)1 << set->bshift) / 8 + 1);
     const unsigned cgrid = kc_grid8(rcap, KC_CHOOSE_SLOTS);
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
