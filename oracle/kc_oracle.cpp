@@ -494,21 +494,7 @@ std::vector<Simplitig> simplitigs_canonical_order(std::vector<K> keys, int k, bo
             }
         }
     }
-    // static port degrees (number of distinct edges at the port)
-    std::vector<uint8_t> deg(2 * n, 0);
-    {
-        std::vector<std::pair<uint64_t, uint64_t>> uniq;
-        uniq.reserve(edges.size());
-        for (auto &e : edges) uniq.emplace_back(2ull * e.ia + e.pa, 2ull * e.ib + e.pb);
-        std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-        for (auto &u : uniq) { if (u.first == u.second) continue; ++deg[u.first]; ++deg[u.second]; }
-    }
-    const bool ks = getenv("KC_ORACLE_KS") != nullptr;
-    auto cls = [&](const Edge<K> &e) -> int { return ks && (deg[2 * e.ia + e.pa] == 1 || deg[2 * e.ib + e.pb] == 1) ? 1 : 0; };
-    auto edge_less = [&](const Edge<K> &a, const Edge<K> &b) {  // "a is preferred over b"
-        const int ca = cls(a), cb = cls(b);
-        if (ca != cb) return ca > cb;
+    auto edge_less = [](const Edge<K> &a, const Edge<K> &b) {  // "a is preferred over b"
         if (a.pr != b.pr) return a.pr > b.pr;
         if (!(a.ka == b.ka)) return a.ka < b.ka;
         if (a.pa != b.pa) return a.pa < b.pa;
@@ -516,12 +502,6 @@ std::vector<Simplitig> simplitigs_canonical_order(std::vector<K> keys, int k, bo
         return a.pb < b.pb;
     };
     std::sort(edges.begin(), edges.end(), edge_less);
-    if (getenv("KC_ORACLE_DEBUG")) {
-        size_t c1 = 0, d1 = 0, d2 = 0, d3 = 0;
-        for (auto &e : edges) c1 += cls(e);
-        for (size_t i = 0; i < 2 * n; ++i) { d1 += deg[i] == 1; d2 += deg[i] == 2; d3 += deg[i] >= 3; }
-        fprintf(stderr, "[oracle] edges %zu class1 %zu; ports deg1 %zu deg2 %zu deg3+ %zu ks=%d\n", edges.size(), c1, d1, d2, d3, (int)ks);
-    }
     // (in bi mode every edge was generated from both endpoints; duplicates are adjacent and harmless to greedy)
     const uint32_t NONE = 0xffffffffu;
     std::vector<uint32_t> link(2 * n, NONE);      // link[2*i+port] = 2*j+port' of the matched port
