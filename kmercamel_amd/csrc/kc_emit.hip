@@ -21,23 +21,29 @@ __global__ void __launch_bounds__(256) em_start_kernel(const u64 *__restrict__ p
     if (v >= V) return;
     if (pred[v] == KC_NONE64) atomicMin((ull *)start, (ull)v);
 }
+// pointer-jumping state of a vertex in ONE 32-byte record: a jump reads the successor's record with a single scattered access
+// (three separate arrays cost three lines per vertex and round: 265 -> ~100 us per round at V = 5e6)
+struct __attribute__((aligned(32))) EmRank { u64 nxt, dist, endv, pad; };
 __global__ void __launch_bounds__(256) em_rank_init_kernel(const u64 *__restrict__ edge_from, const u8 *__restrict__ overlaps,
-                                                           const u64 *__restrict__ lens, u64 S, u64 V, u64 *nxt, u64 *dist, u64 *endv,
-                                                           u64 *weight) {
+                                                           const u64 *__restrict__ lens, u64 S, u64 V, EmRank *st, u64 *weight) {
     u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     u64 e = edge_from[v];
     u64 L = lens[v < S ? v : v - S];
     u64 w = L - (e != KC_NONE64 ? (u64)overlaps[v] : 0);
-    nxt[v] = e; dist[v] = w; endv[v] = v; weight[v] = w;
+    st[v] = EmRank{e, w, v, 0};
+    weight[v] = w;
 }
-__global__ void __launch_bounds__(256) em_rank_step_kernel(const u64 *__restrict__ nxt, const u64 *__restrict__ dist,
-                                                           const u64 *__restrict__ endv, u64 V, u64 *nxt2, u64 *dist2, u64 *endv2) {
+__global__ void __launch_bounds__(256) em_rank_step_kernel(const EmRank *__restrict__ a, u64 V, EmRank *b) {
     u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
-    u64 n = nxt[v];
-    if (n == KC_NONE64) { nxt2[v] = n; dist2[v] = dist[v]; endv2[v] = endv[v]; }
-    else { nxt2[v] = nxt[n]; dist2[v] = dist[v] + dist[n]; endv2[v] = endv[n]; }
+    EmRank x = a[v];
+    if (x.nxt != KC_NONE64) { const EmRank y = a[x.nxt]; x.nxt = y.nxt; x.dist += y.dist; x.endv = y.endv; }
+    b[v] = x;
+}
+__global__ void __launch_bounds__(256) em_rank_split_kernel(const EmRank *__restrict__ a, u64 V, u64 *dist, u64 *endv) {
+    u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < V) { dist[v] = a[v].dist; endv[v] = a[v].endv; }
 }
 
 // one wavefront per vertex on the start path
@@ -105,22 +111,23 @@ int kce_rank_path(kc_simplitigs *s, const KcPathDev *path, KcRank *r) {
     kc_ctx *ctx = s->ctx;
     KcScope scope(ctx);
     const u64 S = s->n, V = path->V;
-    u64 *pred = nullptr, *start = nullptr, *nxt, *dist, *endv, *nxt2, *dist2, *endv2, *weight;
+    u64 *pred = nullptr, *start = nullptr, *dist, *endv, *weight;
+    EmRank *ra = nullptr, *rb = nullptr;
     KC_TRY(scope.alloc(&pred, V)); KC_TRY(scope.alloc(&start, 2));
-    KC_TRY(scope.alloc(&nxt, V)); KC_TRY(scope.alloc(&dist, V)); KC_TRY(scope.alloc(&endv, V));
-    KC_TRY(scope.alloc(&nxt2, V)); KC_TRY(scope.alloc(&dist2, V)); KC_TRY(scope.alloc(&endv2, V)); KC_TRY(scope.alloc(&weight, V));
+    KC_TRY(scope.alloc(&ra, V + 1)); KC_TRY(scope.alloc(&rb, V + 1));
+    KC_TRY(scope.alloc(&dist, V)); KC_TRY(scope.alloc(&endv, V)); KC_TRY(scope.alloc(&weight, V));
     KC_HIP(ctx, hipMemsetAsync(pred, 0xff, V * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(start, 0xff, 16, ctx->stream));
     unsigned g = kc_grid(V, 256);
     hipLaunchKernelGGL(em_pred_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, V, pred);
     hipLaunchKernelGGL(em_start_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)pred, V, start);
     hipLaunchKernelGGL(em_rank_init_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, (const u8 *)path->overlaps,
-                       (const u64 *)s->lens, S, V, nxt, dist, endv, weight);
+                       (const u64 *)s->lens, S, V, ra, weight);
     for (u64 span = 1; span < V; span <<= 1) {
-        hipLaunchKernelGGL(em_rank_step_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)nxt, (const u64 *)dist, (const u64 *)endv, V, nxt2,
-                           dist2, endv2);
-        std::swap(nxt, nxt2); std::swap(dist, dist2); std::swap(endv, endv2);
+        hipLaunchKernelGGL(em_rank_step_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)ra, V, rb);
+        std::swap(ra, rb);
     }
+    hipLaunchKernelGGL(em_rank_split_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)ra, V, dist, endv);
     KC_HIP(ctx, hipGetLastError());
     u64 h_start = 0;
     KC_HIP(ctx, hipMemcpyAsync(&h_start, start, 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -608,7 +608,10 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
     const int win = set->k - set->mlen + 1;
     // positions per thread: every thread first rolls over the k-1 bases before its range, so wide k wants long ranges
-    const int ppt = W == 1 ? 16 : (W == 2 ? 32 : 64);
+    // (every thread first rolls over the k - 1 bases before its range: longer ranges waste less of that, shorter ones give
+    // small inputs more threads; measured at 2.5e9 31-mers: 64.0 / 60.5 / 59.2 ms for 16 / 32 / 64 positions)
+    int ppt = W == 1 ? (len >= ((u64)1 << 28) ? 32 : 16) : (W == 2 ? 32 : 64);
+    if (const char *e = getenv("KC_PPT")) { int v = atoi(e); if (v >= 8 && v <= 512) ppt = v; }   // tuning knob
     const u32 stage_cap = 8;                                           // staged keys per thread (a longer run is flushed in pieces)
     const unsigned tb = win <= 32 ? 256 : (win <= 64 ? 128 : 64);    // LDS: 2 * win * tb * 4 bytes (<= 64 KB) + staged run keys
     const size_t lds_scatter = (size_t)win * tb * 4 * 2 + (size_t)stage_cap * W * tb * 8;
