@@ -35,7 +35,7 @@ CHUNK_RECORDS = 100000  # the record set is generated in chunks of this many rec
 def traffic_from_profile(kernel_substr, records, k):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS workload (separate FETCH_SIZE /
     WRITE_SIZE passes, tools/collect_profile.sh -> tools/summarize_profile.py); None when no profile of it is committed."""
-    name = {(2500000, 31): "r02_cfg2_2p5G_traffic.json", (100000, 31): "r02_cfg1_traffic.json"}.get((records, k))
+    name = {(2500000, 31): "r02_final_cfg2_2p5G_traffic.json", (100000, 31): "r02_final_cfg1_traffic.json"}.get((records, k))
     path = os.path.join(ROOT, "profiles", name) if name else None
     if not path or not os.path.exists(path):
         return None, None

@@ -202,14 +202,18 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 // it: one workgroup loads the block's port links (16 B per slot) into LDS, walks every in-block run ("fragment") there from
 // both of its ends, and replaces the INWARD link word of each end node by a shortcut: far end node, the number of nodes, and
 // the appended bases of the run (up to 19 inline, longer runs through a word pool).  The chain walk then hops from fragment
-// to fragment: two scattered lines per fragment instead of one per node.  The inward words are not restored -- if the hop
-// walk finds a chain beyond the limit or a cycle, the matching is recomputed and the classic flow takes over (rare on
-// read-like inputs; inputs whose chains are long on average skip the contraction in the first place).
+// to fragment: two scattered lines per fragment instead of one per node.  Every replaced word is logged first (8 B per
+// fragment end): if the hop walk finds a chain beyond the limit or misses k-mers (cycles), kc_frag_restore_kernel puts the
+// words back and the classic flow takes over on the original links; inputs whose chains are long on average skip the
+// contraction in the first place.  An end that finds no room in a list or pool simply keeps its plain link (the walk then
+// steps through that fragment node by node from this side).
 //
-// MEASURED (MI355X, k = 31, 2.5e9 k-mers): contraction 43 ms + hop walk 71 ms = the plain walk's 114 ms.  The hop walk
-// touches 4.5x fewer lines but runs at 15 G lines/s against the plain walk's 44 G lines/s: every hop is a dependent jump to a
-// random 128 KB region of an 80 GB array, and both walks make the same number of those jumps (0.22 per k-mer and direction).
-// The contraction is therefore an experiment kept behind KC_FRAG=1 (the tests run it); it is off by default.
+// MEASURED (MI355X, k = 31, 2.5e9 k-mers): contraction 43 ms + hop walk 32 ms against the plain walk's 111 ms.  (The hop walk
+// first ran at 71 ms -- not for its memory accesses: scattered 8-byte reads run at ~49 G/s on this GPU whatever the footprint,
+// tools/rand_probe.hip -- but because every walk reserved its first recording chunk with an atomic on one shared cursor and,
+// once walks hop over runs of different lengths, the lanes of a wave reach that point in different loop trips, so the
+// compiler's wave-level aggregation of the atomic no longer applied: ~5e6 same-address atomics at ~13 ns each.  The first
+// chunk of walk t is now chunk t.)
 //
 // shortcut word: bits 0-1 = 0 (LK_OPEN, not a state of a finished port) and bit 5 (LK_REJ) set; bit 2: the bases are in the
 // pool; bits 6-19 far node (slot offset in the block); bit 20 orientation at the far node; inline: bits 21-25 number of bases,
@@ -222,13 +226,14 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 #define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
 template <int W>
 __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
-                                                                u64 *blk_pool_base, u64 *flags) {
+                                                                u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log) {
     // LDS: per port of the block one 32-bit word -- bit 31: matched to a slot of this block; then bits 0-13 that slot's offset,
     // bit 14 the port entered there, bits 15-16 the appended base -- then the list of long runs and the list of fragment ends.
     // (76 KB for 8192-slot blocks: two workgroups share a CU.)
     extern __shared__ u32 kc_fl[];
     __shared__ u32 n_long, n_words, n_ent;
-    __shared__ u64 pbase;
+    __shared__ u64 pbase, lbase;
+    __shared__ int log_ok;
     const u32 bs = 1u << set.bshift;
     const u64 base = (u64)blockIdx.x << set.bshift;
     const u64 blk = blockIdx.x;
@@ -236,10 +241,18 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     const u32 long_cap = KC_FRAG_LONGS, ent_cap = KC_FRAG_ENTRIES;
     unsigned short *ents = reinterpret_cast<unsigned short *>(longs + 2 * long_cap);   // local port ids of the fragment ends
     if (threadIdx.x == 0) { n_long = 0; n_words = 0; n_ent = 0; }
-    for (u32 i = threadIdx.x; i < 2 * bs; i += blockDim.x) {
-        const u64 w = link[base * 2 + i];
-        const bool in = set.tags[base + (i >> 1)] != 0 && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
-        kc_fl[i] = in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15)) : 0u;
+    // one 16-byte load per slot (both port words) and one tag byte; bit 30 of the digest = the slot is occupied
+    for (u32 s = threadIdx.x; s < bs; s += blockDim.x) {
+        const bool occ = set.tags[base + s] != 0;
+        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(link + (base + s) * 2);
+        const u64 w2[2] = {ww.x, ww.y};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const u64 w = w2[p];
+            const bool in = occ && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
+            kc_fl[2 * s + p] = (occ ? 0x40000000u : 0u) |
+                               (in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15)) : 0u);
+        }
     }
     __syncthreads();
     auto walk = [&](u32 s, int o, u32 &far, int &fo, u32 &len, u64 &bases, u64 *ext, bool fill) {
@@ -248,7 +261,7 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         int co = o;
         len = 1; bases = 0;
         u64 acc = 0; int nacc = 0; u32 wi = 0;
-        while (true) {
+        while (len <= bs) {   // (a run has at most bs nodes; the bound only guards against a corrupt table)
             const u32 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
             if (!(w >> 31)) break;
             const u64 b = (w >> 15) & 3;
@@ -268,7 +281,8 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         const u32 s = s0 + threadIdx.x;
         for (int o = 0; o < (complements ? 2 : 1); ++o) {
             // an end of a run of >= 2 nodes: occupied, not entered from inside the block, left towards a slot of the block
-            const bool is_end = set.tags[base + s] != 0 && !(kc_fl[2 * s + o] >> 31) && (kc_fl[2 * s + (o == 0 ? 1 : 0)] >> 31);
+            const u32 f_in = s < bs ? kc_fl[2 * s + o] : 0u, f_out = s < bs ? kc_fl[2 * s + (o == 0 ? 1 : 0)] : 0u;   // (blocks of < 1024 slots: KC_BSHIFT)
+            const bool is_end = (f_in & 0x40000000u) && !(f_in >> 31) && (f_out >> 31);
             const unsigned long long m = __ballot(is_end);
             if (!m) continue;
             u32 at0 = 0;
@@ -276,26 +290,38 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
             at0 = __shfl(at0, 0, 64);
             if (is_end) {
                 const u32 at = at0 + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1));
-                if (at < ent_cap) ents[at] = (unsigned short)(2 * s + (u32)o); else flags[0] = 1;
+                if (at < ent_cap) ents[at] = (unsigned short)(2 * s + (u32)o);   // (an end beyond the list keeps its plain link)
             }
         }
     }
     __syncthreads();
     const u32 ne = n_ent < ent_cap ? n_ent : ent_cap;
+    // every word about to be replaced is logged first (kc_frag_restore_kernel puts it back if the hop walk has to be abandoned):
+    // the original word with the local port id in its unused bits 46-59.  No log space: the block keeps its plain links.
+    if (threadIdx.x == 0) {
+        const u64 lshard = log_cap / 64;
+        const u64 b = ne ? atomicAdd((ull *)&log_cursors[(blockIdx.x & 63) * 16], (ull)ne) : 0;
+        log_ok = b + ne <= lshard;
+        lbase = (u64)(blockIdx.x & 63) * lshard + b;
+        blk_log[blk] = log_ok ? ((lbase << 16) | (u64)ne) : 0;
+    }
+    __syncthreads();
+    if (!log_ok) return;
     for (u32 e = threadIdx.x; e < ne; e += blockDim.x) {
         const u32 s = ents[e] >> 1;
         const int o = (int)(ents[e] & 1);
         u32 far, len; int fo; u64 bases;
         walk(s, o, far, fo, len, bases, nullptr, false);
         const u32 xp = o == 0 ? 1u : 0u;
+        log[lbase + e] = link[(base + s) * 2 + xp] | ((u64)(2 * s + xp) << 46);
         if (len - 1 <= KC_SC_INLINE_MAX) {
             link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
         } else {
             const u32 nw = (len - 1 + 31) / 32;
             const u32 at = atomicAdd(&n_long, 1u);
             const u32 rel = atomicAdd(&n_words, nw);
+            // (more long runs than the list holds, or a run of 2^14 nodes: that end keeps its plain link)
             if (at < long_cap && len - 1 < (1u << 14)) { longs[2 * at] = 2 * s + (u32)o; longs[2 * at + 1] = rel; }
-            else flags[0] = 1;   // (more long runs than the list holds, or a run of 2^14 nodes: the caller falls back)
         }
     }
     __syncthreads();
@@ -307,7 +333,7 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     __syncthreads();
     // pool shard s owns the words [s * pool_cap / 64, (s + 1) * pool_cap / 64)
     const u64 shard_cap = pool_cap / 64, shard_lo = (u64)(blockIdx.x & 63) * shard_cap;
-    if (pbase + n_words > shard_cap) { if (threadIdx.x == 0) flags[0] = 1; return; }
+    if (pbase + n_words > shard_cap) return;   // no pool space: the long runs of this block keep their plain links
     const u32 nl = n_long < long_cap ? n_long : long_cap;
     for (u32 i = threadIdx.x; i < nl; i += blockDim.x) {
         const u32 pid = longs[2 * i], rel = longs[2 * i + 1];
@@ -316,6 +342,19 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         walk(s, o, far, fo, len, bases, pool + shard_lo + pbase + rel, true);
         const u32 xp = o == 0 ? 1u : 0u;
         link[(base + s) * 2 + xp] = LK_REJ | KC_SC_EXT | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | ((u64)rel << 35);
+    }
+}
+
+// puts the logged link words back (the hop walk met a chain beyond the limit, or the input has cycles: the classic flow
+// takes over on the original links)
+__global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, const u64 *__restrict__ log, const u64 *__restrict__ blk_log, int bshift) {
+    const u64 blk = blockIdx.x;
+    const u64 e = blk_log[blk];
+    const u32 n = (u32)(e & 0xffffu);
+    const u64 lb = e >> 16;
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 w = log[lb + i];
+        link[((blk << bshift) << 1) + ((w >> 46) & 0x3fffu)] = w & ~(0x3fffull << 46);
     }
 }
 
@@ -347,10 +386,15 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     u32 chunk = KC_NO_CHUNK, first_chunk = KC_NO_CHUNK;
     bool rec_ok = true;
     auto flush_word = [&](u64 word) {
-        if (chunk == KC_NO_CHUNK || wi == KC_CHUNK_WORDS) {
-            const u64 nc = atomicAdd((ull *)rec.pool_cursor, 1ULL);
+        if (chunk == KC_NO_CHUNK) {
+            // the first chunk of walk t is chunk t: no reservation.  (Lanes of a wave reach their first flush at different loop
+            // trips once walks hop over fragments, so a shared cursor here meant ~one same-address atomic per walk, ~13 ns each.)
+            chunk = first_chunk = (u32)t;
+            wi = 0;
+        } else if (wi == KC_CHUNK_WORDS) {
+            const u64 nc = nheads + atomicAdd((ull *)rec.pool_cursor, 1ULL);
             if (nc >= rec.pool_cap) { rec_ok = false; return; }
-            if (first_chunk == KC_NO_CHUNK) first_chunk = (u32)nc; else rec.chunk_next[chunk] = (u32)nc;
+            rec.chunk_next[chunk] = (u32)nc;
             chunk = (u32)nc;
             wi = 0;
         }
@@ -704,8 +748,7 @@ static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h) {
     return KC_OK;
 }
 
-#define KC_RETRY_NOFRAG 1000   /* internal: the fragment hop walk met a long chain or a cycle; redo without contraction */
-template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out, u64 *cycles_out, bool allow_frag) {
+template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out, u64 *rounds_out, u64 *cycles_out) {
     u64 cycles_cut = 0;
     kc_ctx *ctx = set->ctx;
     KcScope scope(ctx);
@@ -845,34 +888,44 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_TRY(scope.alloc(&chain_tail, max_chains));
             rec.pool = pool; rec.chunk_next = chunk_next; rec.pool_cursor = cnt + 5; rec.chain_stream = chain_stream; rec.chain_tail = chain_tail;
         }
-        // fragment contraction (see kc_frag_contract_kernel): worth it when the chains are short on average (read-like input)
-        // OFF by default (KC_FRAG=1 turns it on): measured on MI355X it does not pay -- see the note at kc_frag_contract_kernel.
-        const bool use_frag = allow_frag && pass == 0 && want_rec && !known_long && nheads && set->mlen && set->bshift <= 13 && getenv("KC_FRAG") &&
-                              2 * N / nheads <= KC_CHAIN_LIMIT / 2;
-        u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr;
+        // fragment contraction (see kc_frag_contract_kernel): pays when the chains are short on average (read-like input);
+        // KC_NOFRAG=1 turns it off
+        bool use_frag = pass == 0 && want_rec && !known_long && nheads && set->mlen && set->bshift <= 13 && !getenv("KC_NOFRAG") &&
+                        2 * N / nheads <= KC_CHAIN_LIMIT / 2;
         if (use_frag) {
+            u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr, *flog = nullptr, *fblog = nullptr;
             const u64 pool_cap = (N / 16 + 65536) / 64 * 64;
-            KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, set->nblocks)); KC_TRY(scope.alloc(&fcur, 64 * 16 + 16));
-            KC_HIP(ctx, hipMemsetAsync(fcur, 0, (64 * 16 + 16) * 8, ctx->stream));
+            const u64 log_cap = (N / 3 + 65536) / 64 * 64;     // two ends per in-block run, ~N/10 runs
+            KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, set->nblocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16));
+            KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, set->nblocks));
+            KC_HIP(ctx, hipMemsetAsync(fcur, 0, 2 * 64 * 16 * 8, ctx->stream));
             const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
-                               fcur + 64 * 16);
+                               flog, log_cap, fcur + 64 * 16, fblog);
             const KcFrag fr{fpool, fbase, pool_cap / 64};
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                KC_CHAIN_LIMIT, rec, fr);
             KC_HIP(ctx, hipGetLastError());
-            u64 hf[8] = {0}, fflag = 0;
+            u64 hf[8] = {0};
             KC_HIP(ctx, hipMemcpyAsync(hf, cnt, 64, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipMemcpyAsync(&fflag, fcur + 64 * 16, 8, hipMemcpyDeviceToHost, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            // the inward links of the fragment ends are shortcuts now: anything but a clean result means starting over without them
+            const bool clean = !hf[7] && !hf[6] && hf[3] == N;
             if (getenv("KC_SIMP_TRACE"))
-                fprintf(stderr, "[simp] fragment walk: flag %llu, too long %llu, recording overflow %llu, covered %llu of %llu, chains %llu\n", (unsigned long long)fflag,
-                        (unsigned long long)hf[7], (unsigned long long)hf[6], (unsigned long long)hf[3], (unsigned long long)N, (unsigned long long)hf[0]);
-            if (fflag || hf[7] || hf[6] || hf[3] != N) return KC_RETRY_NOFRAG;
-            scope.release(fpool); scope.release(fbase); scope.release(fcur);
+                fprintf(stderr, "[simp] fragment walk: too long %llu, recording overflow %llu, covered %llu of %llu, chains %llu -> %s\n",
+                        (unsigned long long)hf[7], (unsigned long long)hf[6], (unsigned long long)hf[3], (unsigned long long)N, (unsigned long long)hf[0],
+                        clean ? "kept" : "links restored, classic flow");
+            if (!clean) {
+                // a chain beyond the limit, or k-mers on cycles (reached from no head): put the replaced link words back and
+                // let the classic flow below run on the original links
+                hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog,
+                                   (const u64 *)fblog, set->bshift);
+                KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+                if (hf[7]) known_long = true;
+                use_frag = false;
+            }
+            scope.release(fpool); scope.release(fbase); scope.release(fcur); scope.release(flog); scope.release(fblog);
         }
         if (nheads && !known_long && !use_frag) {
             if (want_rec)
@@ -1031,16 +1084,11 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
 }
 
 int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds, u64 *cycles) {
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        int rc;
-        switch (set->W) {
-            case 1: rc = build_simplitigs_w<1>(set, out, rounds, cycles, attempt == 0); break;
-            case 2: rc = build_simplitigs_w<2>(set, out, rounds, cycles, attempt == 0); break;
-            default: rc = build_simplitigs_w<4>(set, out, rounds, cycles, attempt == 0); break;
-        }
-        if (rc != KC_RETRY_NOFRAG) return rc;
+    switch (set->W) {
+        case 1: return build_simplitigs_w<1>(set, out, rounds, cycles);
+        case 2: return build_simplitigs_w<2>(set, out, rounds, cycles);
+        default: return build_simplitigs_w<4>(set, out, rounds, cycles);
     }
-    return kc_fail(set->ctx, KC_E_NO_DEVICE, "simplitig build did not settle");
 }
 
 extern "C" int kc_simplitigs_build(kc_set *set, kc_simplitigs **out) {

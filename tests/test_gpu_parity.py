@@ -139,9 +139,9 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [{"KC_BUCKET_MIN": "0"}, {"KC_BUCKET_MIN": "1000000000"}, {"KC_NOREC": "1"}, {"KC_NOSTAGE": "1"},
-                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_FRAG": "1"}, {"KC_FRAG": "1", "KC_CHAIN_LIMIT": "600"}],
-                         ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "fragment-contraction",
-                              "fragment-contraction-then-fallback"])
+                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_NOFRAG": "1"}, {"KC_CHAIN_LIMIT": "600"}],
+                         ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "plain-walk",
+                              "fragment-contraction-then-restore"])
 def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
     """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
     walk, LDS tag staging) must give the same set and the same simplitigs; KC_LOCAL_PROBES=2 makes block-local probe runs
@@ -176,24 +176,36 @@ def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, mon
 
 @pytest.mark.parametrize("k", [21, 31, 63, 127])
 def test_fragment_contraction_path(ctx, k, monkeypatch):
-    """KC_FRAG=1: in-block chain runs are contracted into shortcuts in LDS and the measure walk hops from fragment to fragment
-    (kc_frag_contract_kernel).  Same bytes as the default walk on read-like input (chains of ~500 nodes, every fragment length
-    incl. runs beyond the 19 inline bases), both strand modes; a chain limit below the chain length takes the
-    recompute-and-fall-back route."""
-    seq = np.concatenate([gen.random_joined(3000, 500 + k, seed=900 + k), np.array([10], dtype=np.uint8),
-                          gen.random_joined(60, 2500 + k, seed=901 + k)])   # a few chains beyond the limit of the second setting
-    for complements in (True, False):
-        want = kc.compute(ctx, seq, k, complements)
-        w = want.array().copy()
-        want.close()
-        for env in ({"KC_FRAG": "1"}, {"KC_FRAG": "1", "KC_CHAIN_LIMIT": "1200"}, {"KC_FRAG": "1", "KC_BSHIFT": "10"}):
-            for name, value in env.items():
-                monkeypatch.setenv(name, value)
-            got = kc.compute(ctx, seq, k, complements)
-            assert np.array_equal(got.array(), w), (k, complements, env)
-            got.close()
-            for name in env:
-                monkeypatch.delenv(name)
+    """Read-like input takes the fragment path by default: in-block chain runs are contracted into shortcuts in LDS and the
+    measure walk hops from fragment to fragment (kc_frag_contract_kernel).  Same bytes as the plain walk (KC_NOFRAG=1) on
+    chains of ~500 nodes (every fragment length incl. runs beyond the 19 inline bases), both strand modes; with a chain limit
+    below some chain's length, and with records whose k-mers form cycles, the hop walk is abandoned, the logged link words
+    are put back (kc_frag_restore_kernel) and the classic flow (segment-parallel walk / cycle cut) takes over."""
+    rng = np.random.default_rng(77 + k)
+    unit = rng.integers(0, 4, size=3 * k + 40)
+    cyc = np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate([unit, unit, unit[:k]])]   # the k-mers of this record form a cycle
+    reads = gen.random_joined(3000, 500 + k, seed=900 + k)
+    long_reads = gen.random_joined(60, 2500 + k, seed=901 + k)   # a few chains beyond the limit of the second setting
+    nl = np.array([10], dtype=np.uint8)
+    inputs = {"reads": np.concatenate([reads, nl, long_reads]), "reads+cycles": np.concatenate([reads, nl, cyc, nl, cyc[::-1].copy()])}
+    for name, seq in inputs.items():
+        for complements in (True, False):
+            monkeypatch.setenv("KC_NOFRAG", "1")
+            want = kc.compute(ctx, seq, k, complements)
+            w = want.array().copy()
+            cycles = want.stats["cycles_cut"]
+            want.close()
+            monkeypatch.delenv("KC_NOFRAG")
+            assert (cycles > 0) == (name == "reads+cycles")
+            for env in ({}, {"KC_CHAIN_LIMIT": "1200"}, {"KC_BSHIFT": "10"}):
+                for var, value in env.items():
+                    monkeypatch.setenv(var, value)
+                got = kc.compute(ctx, seq, k, complements)
+                assert np.array_equal(got.array(), w), (k, name, complements, env)
+                assert got.stats["cycles_cut"] == cycles
+                got.close()
+                for var in env:
+                    monkeypatch.delenv(var)
 
 
 @pytest.mark.parametrize("k", [31, 40, 100])

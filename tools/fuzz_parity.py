@@ -70,6 +70,11 @@ def main():
                 rc, want, wmask, st = orc.compute_file_z(fa, k, compl, mode=1, min_frequency=zf)
             else:
                 rc, want, wmask, st = orc.compute_file(fa, k, compl, False, mode=1)
+            if os.environ.get("KC_FUZZ_VERBOSE"):   # leave a trace (and the input) in case the device call never returns
+                import shutil
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                shutil.copy(fa, os.path.join(ROOT, "gpurun_out", "fuzz_last.fa"))
+                print("case %d: %s k=%d compl=%s shape=%s env=%s" % (n, entry, k, compl, shape, {v: os.environ.get(v) for v in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_BSHIFT", "KC_LOCAL_PROBES")}), flush=True)
             try:
                 if entry == "S": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, assume_simplitigs=True)
                 elif entry == "z": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, min_frequency=zf)
