@@ -107,25 +107,47 @@ template <int W> __device__ __forceinline__ bool is_representative(const Key<W> 
     return !key_lt(r, key);
 }
 
+// Counts the hits of a level and lists the first hit_cap of them (unordered; a level with few hits then skips the ordered
+// compaction).  One global atomic per WORKGROUP: with one per wavefront (what the compiler makes of a plain atomicAdd on a
+// uniform address) the ~80 000 same-address atomics of a 5e6-vertex level cost ~1 ms at ~13 ns each.
+// Called by every thread of the workgroup (256 threads).
+__device__ __forceinline__ void ov_list_hit(u8 hit, u64 v, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
+    __shared__ u32 wcount[4];
+    __shared__ u64 wbase;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(hit != 0);
+    if (lane == 0) wcount[wv] = (u32)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        wbase = tot ? atomicAdd((ull *)hit_count, (ull)tot) : 0;
+    }
+    __syncthreads();
+    if (hit) {
+        u64 pos = wbase + (u64)__popcll(m & (((unsigned long long)1 << lane) - 1));
+        for (int j = 0; j < wv; ++j) pos += wcount[j];
+        if (pos < hit_cap) hit_list[pos] = v;
+    }
+}
+
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, const u64 *__restrict__ actS, u64 nS,
                                                               const u64 *__restrict__ suf, const u64 *__restrict__ pre, int k, int d,
                                                               int complements, u8 *hitS, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nS) return;
-    u64 v = actS[i];
-    Key<W> key = key_suffix(load_key<W>(suf, v), d);
-    u64 s = level_find(t, key, pre, k, d);
     u8 hit = 0;
-    if (s != KC_NONE64) {
-        atomicAnd(&t.flags[s], ~2u);
-        if (is_representative(key, d, complements)) hit = 1;
+    u64 v = 0;
+    if (i < nS) {
+        v = actS[i];
+        Key<W> key = key_suffix(load_key<W>(suf, v), d);
+        u64 s = level_find(t, key, pre, k, d);
+        if (s != KC_NONE64) {
+            atomicAnd(&t.flags[s], ~2u);
+            if (is_representative(key, d, complements)) hit = 1;
+        }
+        hitS[i] = hit;
     }
-    hitS[i] = hit;
-    if (hit) {   // the first hit_cap hits are also listed (unordered): a level with few hits skips the ordered compaction
-        const u64 pos = atomicAdd((ull *)hit_count, 1ULL);
-        if (pos < hit_cap) hit_list[pos] = v;
-    }
+    ov_list_hit(hit, v, hit_count, hit_list, hit_cap);
 }
 
 template <int W>
@@ -133,17 +155,15 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
                                                              const u64 *__restrict__ pre, const u64 *__restrict__ pslot, int k, int d,
                                                              int complements, u8 *hitP, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nP) return;
     u8 hit = 0;
-    if (!(t.flags[pslot[i]] & 2u)) {
-        Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
-        if (is_representative(key, d, complements)) hit = 1;
+    if (i < nP) {
+        if (!(t.flags[pslot[i]] & 2u)) {
+            Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
+            if (is_representative(key, d, complements)) hit = 1;
+        }
+        hitP[i] = hit;
     }
-    hitP[i] = hit;
-    if (hit) {
-        const u64 pos = atomicAdd((ull *)hit_count, 1ULL);
-        if (pos < hit_cap) hit_list[pos] = actP[i];
-    }
+    ov_list_hit(hit, hit ? actP[i] : 0, hit_count, hit_list, hit_cap);
 }
 
 template <int W, bool SUFFIX>
