@@ -179,6 +179,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 struct Reader {
     int fd = -1;
     gzFile gz = nullptr;
+    off_t pos = 0, size = -1;   // regular files: chunks are read by a few threads at once (pread on disjoint ranges)
     bool open(const std::string &path, std::string &err) {
         if (path == "-") { gz = gzdopen(0, "r"); return gz != nullptr; }
         fd = ::open(path.c_str(), O_RDONLY);
@@ -186,10 +187,33 @@ struct Reader {
         unsigned char magic[2] = {0, 0};
         const ssize_t got = pread(fd, magic, 2, 0);
         if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { gz = gzdopen(fd, "r"); fd = -1; if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr; }
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) size = st.st_size;
         return true;
     }
     long read_some(u8 *dst, size_t cap) {
         if (gz) return gzread(gz, dst, (unsigned)cap);
+        if (size >= 0 && !getenv("KC_IO_SERIAL")) {
+            // page-cache / tmpfs reads are memory copies in the kernel: one thread moves ~5 GB/s, four move the chunk in a quarter of the time
+            const size_t want = (size_t)std::min<off_t>((off_t)cap, size > pos ? size - pos : 0);
+            const int T = want >= ((size_t)8 << 20) ? 4 : 1;
+            std::atomic<bool> bad{false};
+            auto part = [&](int t) {
+                size_t lo = want * (size_t)t / (size_t)T, hi = want * (size_t)(t + 1) / (size_t)T;
+                while (lo < hi) {
+                    const ssize_t r = pread(fd, dst + lo, hi - lo, pos + (off_t)lo);
+                    if (r <= 0) { bad = true; return; }   // (a file that shrinks under us is an error)
+                    lo += (size_t)r;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+            part(0);
+            for (auto &x : th) x.join();
+            if (bad) return -1;
+            pos += (off_t)want;
+            return (long)want;
+        }
         size_t have = 0;
         while (have < cap) {
             const ssize_t r = ::read(fd, dst + have, cap - have);

@@ -143,12 +143,13 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
     // redone by the generic scan in ONE loop after the batch, so a wave pays that latency once, not once per candidate.
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     const int top = 2 * (m - 1);
-    // candidate (port, c): canonical key y, the port q it is entered on, placement hash and home
-    auto make_cand = [&](const int port, const u32 c, Key<W> &y, int &q, u64 &hy, u64 &home) {
-        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+    // candidate (port, c) of the k-mer described by cx: canonical key y, the port q it is entered on, placement hash and home
+    struct Ctx { Key<W> x, xr; u32 f_first, r_first, f_last, r_last, sharedR, sharedL; };
+    auto make_cand_of = [&](const Ctx &cx, const int port, const u32 c, Key<W> &y, int &q, u64 &hy, u64 &home) {
+        Key<W> nf = port ? key_append(cx.x, (u64)c, k) : key_prepend(cx.x, (u64)c, k);
         y = nf;
         if (complements) {
-            Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
+            Key<W> r = port ? key_prepend(cx.xr, (u64)(3 - c), k) : key_append(cx.xr, (u64)(3 - c), k);   // RC(nf)
             bool pal = (KC & 1) ? false : key_eq(nf, r);
             bool fwd = !key_lt(r, nf);
             if (!fwd) y = r;
@@ -159,13 +160,15 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
         hy = key_place_hash(y);
         if (m) {
             // the one m-mer the candidate does not share with x, one shift away from x's last / first m-mer
-            u32 nfw = port ? (((f_last << 2) | c) & maskm) : ((f_first >> 2) | (c << top));
-            u32 nrc = port ? ((r_last >> 2) | ((3u - c) << top)) : (((r_first << 2) | (3u - c)) & maskm);
+            u32 nfw = port ? (((cx.f_last << 2) | c) & maskm) : ((cx.f_first >> 2) | (c << top));
+            u32 nrc = port ? ((cx.r_last >> 2) | ((3u - c) << top)) : (((cx.r_first << 2) | (3u - c)) & maskm);
             u32 h = kc_mmer_hash(nfw, nrc);
-            const u32 shared = port ? sharedR : sharedL;
+            const u32 shared = port ? cx.sharedR : cx.sharedL;
             home = set_block_home(set, h < shared ? h : shared, hy);
         } else home = kc_mulhi64(kc_mix64(hy), set.cap);
     };
+    const Ctx own{x, xr, f_first, r_first, f_last, r_last, sharedR, sharedL};
+    auto make_cand = [&](const int port, const u32 c, Key<W> &y, int &q, u64 &hy, u64 &home) { make_cand_of(own, port, c, y, q, hy, home); };
     Key<W> (&cy)[8] = out.cy;
     u64 (&chome)[8] = out.chome, (&cslot)[8] = out.cslot;
     u64 cph[8], cword[8];
@@ -194,10 +197,9 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if ((inblk >> i) & 1) {
+            // one unaligned 8-byte LDS read (gfx950 reads LDS at any byte offset; the stage has 8 bytes of slack at its end)
             const u32 o = (u32)chome[i] & ((1u << set.bshift) - 1u);
-            const u64 w0 = stage[o >> 3], w1 = stage[(o >> 3) + 1];
-            const u32 sh = (o & 7u) * 8u;
-            cword[i] = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+            __builtin_memcpy(&cword[i], reinterpret_cast<const u8 *>(stage) + o, 8);
         }
     // branch-free on purpose: a conditional here lets the compiler sink a candidate's load into the branch and wait for it
     u32 pending = 0, slow = 0, settled2 = 0;
@@ -238,15 +240,58 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
         slow |= (pend & (eq ^ 1u) & (((settled2 >> i) & 1u) ^ 1u)) << i;   // tag false positive, miss not proven yet: slow path
         cslot[i] = (pend & eq) ? cslot[i] : KC_NONE64;
     }
-    while (slow) {   // rare per lane, but some lane of nearly every wave gets here: redo only the scan, from the known home
-        const int i = __builtin_ctz(slow);
-        slow &= slow - 1;
-        Key<W> y; int q; u64 hy, home;
-        make_cand(i >> 2, (u32)(i & 3), y, q, hy, home);
-        const u64 ts = set_find_from(set, y, hy, home);
+    // Lookups the first window did not settle (3.5 % of them, i.e. ~18 per wavefront and sweep step: nearly every wave has
+    // some, few lanes have more than one).  A per-lane redo loop made the whole wave pay for its unluckiest lane, once per
+    // trip; instead the wave pools them: every lane lists its unsettled (lane, candidate) pairs in LDS, lane e redoes entry e
+    // -- it pulls the owner's k-mer context with shuffles, rebuilds the candidate and runs the generic scan from the known
+    // home -- and the owners read the slots back.  One dense trip per 64 unsettled lookups.
+    // (The lanes that are active here are a prefix of the wave: the sweep loops run over t = t0 + threadIdx.x < n.)
+    if (__ballot(slow != 0)) {
+        __shared__ unsigned short kc_sq_ent[4][512];
+        __shared__ u64 kc_sq_res[4][512];
+        const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+        const u32 nact = (u32)__popcll(__ballot(1));
+        const u32 cnt = (u32)__popc(slow);
+        const unsigned long long lt = ((unsigned long long)1 << lane) - 1;
+        u32 pre = 0, total = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j == i) cslot[j] = ts;
+        for (int j = 0; j < 4; ++j) {   // exclusive prefix sum of cnt (0..8) over the active lanes, by bit planes
+            const unsigned long long mj = __ballot((cnt >> j) & 1u);
+            pre += (u32)__popcll(mj & lt) << j;
+            total += (u32)__popcll(mj) << j;
+        }
+        {
+            u32 sl = slow, at = pre;
+            while (sl) {
+                const int i = __builtin_ctz(sl);
+                sl &= sl - 1;
+                kc_sq_ent[wv][at++] = (unsigned short)((lane << 3) | i);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 r0 = 0; r0 < total; r0 += nact) {
+            const u32 e = r0 + (u32)lane;
+            const bool has = e < total;
+            const u32 ent = kc_sq_ent[wv][has ? e : 0];
+            const int ol = (int)(ent >> 3);
+            Ctx cx;   // the owner's context: every active lane takes part in the shuffles, the owners are among them
+#pragma unroll
+            for (int w = 0; w < W; ++w) { cx.x.w[w] = __shfl(x.w[w], ol, 64); cx.xr.w[w] = __shfl(xr.w[w], ol, 64); }
+            cx.f_first = __shfl(f_first, ol, 64); cx.r_first = __shfl(r_first, ol, 64);
+            cx.f_last = __shfl(f_last, ol, 64); cx.r_last = __shfl(r_last, ol, 64);
+            cx.sharedR = __shfl(sharedR, ol, 64); cx.sharedL = __shfl(sharedL, ol, 64);
+            if (has) {
+                Key<W> y; int q; u64 hy, home;
+                make_cand_of(cx, (int)((ent >> 2) & 1), ent & 3u, y, q, hy, home);
+                kc_sq_res[wv][ent] = set_find_from(set, y, hy, home);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((slow >> i) & 1u) cslot[i] = kc_sq_res[wv][(lane << 3) | i];
     }
     if (SH) {
 #pragma unroll

@@ -11,7 +11,7 @@ ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-cli}
 R=$(pwd)
 # the counter passes run one step of the same workload (the workload flags are taken from ARGS, steps / warmup overridden)
 PMCARGS="$ARGS --steps 1 --warmup 0"
-mkdir -p $R/$OUT
+rm -rf $R/$OUT; mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats -- python3 $R/bench.py $ARGS > $R/$OUT/bench_stats.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $R/$OUT/pmc_fetch -- python3 $R/bench.py $PMCARGS > /dev/null 2>&1
