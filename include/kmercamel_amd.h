@@ -173,6 +173,9 @@ int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *
 void kc_device_free(kc_ctx *ctx, void *d_ptr);
 /* write the result's characters (which = 0) or its -M mask (which = 1) to a file descriptor */
 int kc_result_write_fd(kc_result *r, int fd, int which);
+/* the same into host memory (e.g. a shared mapping of the output file whose pages are already there): pinned chunks, each
+ * moved on by several threads while the next one arrives from the device.  dst must hold the slice (kc_result_slice). */
+int kc_result_write_mem(kc_result *r, void *dst, int which);
 
 /* ---- next row 1: maskopt -t max-one / min-one (masks.h:40-78, 239-261) ---- */
 /* ms: one masked superstring (ACGTacgt, else KC_E_INVALID_CHAR after output like the reference). out: len bytes. */

@@ -70,6 +70,7 @@ SIGNATURES = {
     "kc_read_fasta_device": (ctypes.c_int, [_vp, ctypes.c_char_p, _vpp, _u64p, ctypes.POINTER(ctypes.c_int)]),
     "kc_device_free": (None, [_vp, _vp]),
     "kc_result_write_fd": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    "kc_result_write_mem": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     "kc_maskopt_ones": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "kc_version": (ctypes.c_char_p, []),
 }

@@ -11,6 +11,7 @@
 #include "kc_internal.h"
 #include "kc_scan_dev.h"
 #include <zlib.h>
+#include <cstring>
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
@@ -405,6 +406,17 @@ extern "C" int kc_result_write_fd(kc_result *r, int fd, int which) {
         if (hipHostMalloc((void **)&hb[i], CH, hipHostMallocDefault) != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
         if (rc == KC_OK && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = KC_E_NO_DEVICE;
     }
+    // A regular file whose blocks are already allocated up to the end of this write (the CLI preallocates the output while the
+    // GPU computes) takes its chunks through four pwrite()s at once: into allocated pages a write is a plain memory copy and
+    // scales with threads; where pages still have to be allocated, parallel writers only contend (measured: slower than one).
+    off_t fpos = -1;
+    {
+        struct stat st;
+        if (!getenv("KC_IO_SERIAL") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(fcntl(fd, F_GETFL) & O_APPEND)) {
+            const off_t cur = lseek(fd, 0, SEEK_CUR);
+            if (cur >= 0 && (u64)st.st_blocks * 512 >= (u64)cur + total) fpos = cur;
+        }
+    }
     u64 sent = 0, written = 0;
     int slot = 0;
     u64 len_in[2] = {0, 0};
@@ -421,13 +433,87 @@ extern "C" int kc_result_write_fd(kc_result *r, int fd, int which) {
             sent += len_in[nxt];
         }
         if (hipEventSynchronize(ev[slot]) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
-        u64 off = 0;
-        while (off < len_in[slot]) {
-            const ssize_t w = ::write(fd, hb[slot] + off, len_in[slot] - off);
-            if (w < 0) { rc = kc_fail(ctx, KC_E_IO, "write failed"); break; }
-            off += (u64)w;
+        if (fpos >= 0) {
+            const int T = len_in[slot] >= ((u64)8 << 20) ? 4 : 1;
+            std::atomic<bool> bad{false};
+            const char *buf = hb[slot];
+            const u64 n = len_in[slot];
+            const off_t at = fpos + (off_t)written;
+            auto part = [&](int t) {
+                u64 lo = n * (u64)t / (u64)T, hi = n * (u64)(t + 1) / (u64)T;
+                while (lo < hi) {
+                    const ssize_t w = pwrite(fd, buf + lo, hi - lo, at + (off_t)lo);
+                    if (w <= 0) { bad = true; return; }
+                    lo += (u64)w;
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+            part(0);
+            for (auto &x : th) x.join();
+            if (bad) { rc = kc_fail(ctx, KC_E_IO, "write failed"); break; }
+        } else {
+            u64 off = 0;
+            while (off < len_in[slot]) {
+                const ssize_t w = ::write(fd, hb[slot] + off, len_in[slot] - off);
+                if (w < 0) { rc = kc_fail(ctx, KC_E_IO, "write failed"); break; }
+                off += (u64)w;
+            }
         }
         written += len_in[slot];
+        slot = nxt;
+    }
+    if (fpos >= 0 && rc == KC_OK) (void)lseek(fd, fpos + (off_t)total, SEEK_SET);   // the caller goes on writing behind the string
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; ++i) { if (hb[i]) (void)hipHostFree(hb[i]); (void)hipEventDestroy(ev[i]); }
+    return rc;
+}
+
+// Same pipeline, destination = host memory: chunk i is copied on by four threads while chunk i+1 arrives.  For a pageable
+// destination this beats one big hipMemcpy (which stages through a single thread's copies), and it is what the CLI uses to
+// fill the (prefaulted) shared mapping of its output file -- stores into a mapping take no inode lock, so they scale.
+extern "C" int kc_result_write_mem(kc_result *r, void *dst_v, int which) {
+    if (!r || !dst_v) return KC_E_ARG;
+    kc_ctx *ctx = r->ctx;
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    const char *src = which ? r->d_mask : r->d_out;
+    if (!src) return kc_fail(ctx, KC_E_ARG, "the result holds no such string");
+    char *dst = static_cast<char *>(dst_v);
+    const u64 total = r->slice_len;
+    const size_t CH = (size_t)32 << 20;
+    char *hb[2] = {nullptr, nullptr};
+    hipEvent_t ev[2];
+    int rc = KC_OK;
+    for (int i = 0; i < 2 && rc == KC_OK; ++i) {
+        if (hipHostMalloc((void **)&hb[i], CH, hipHostMallocDefault) != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
+        if (rc == KC_OK && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = KC_E_NO_DEVICE;
+    }
+    u64 sent = 0, done = 0;
+    int slot = 0;
+    u64 len_in[2] = {0, 0};
+    if (rc == KC_OK && total) {
+        len_in[0] = total < CH ? total : CH;
+        if (hipMemcpyAsync(hb[0], src, len_in[0], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[0], ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+        sent = len_in[0];
+    }
+    while (rc == KC_OK && done < total) {
+        const int nxt = slot ^ 1;
+        if (sent < total) {
+            len_in[nxt] = total - sent < CH ? total - sent : CH;
+            if (hipMemcpyAsync(hb[nxt], src + sent, len_in[nxt], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[nxt], ctx->stream) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
+            sent += len_in[nxt];
+        }
+        if (hipEventSynchronize(ev[slot]) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
+        const u64 n = len_in[slot];
+        const int T = (n >= ((u64)8 << 20) && !getenv("KC_IO_SERIAL")) ? 4 : 1;
+        const char *buf = hb[slot];
+        char *at = dst + done;
+        auto part = [&](int t) { const u64 lo = n * (u64)t / (u64)T, hi = n * (u64)(t + 1) / (u64)T; memcpy(at + lo, buf + lo, hi - lo); };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+        part(0);
+        for (auto &x : th) x.join();
+        done += n;
         slot = nxt;
     }
     (void)hipStreamSynchronize(ctx->stream);

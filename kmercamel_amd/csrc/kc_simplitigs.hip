@@ -221,7 +221,9 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64
 // the block's pool base).
 #define KC_SC_IS(w) ((((w) & 3ull) == 0ull) && ((w) & LK_REJ))
 #define KC_SC_EXT 4ull
+#define KC_SC_NEXT 8ull
 #define KC_SC_INLINE_MAX 19
+#define KC_SC_NEXT_MAX 7
 #define KC_FRAG_LONGS 512       /* runs of more than 20 nodes per block that get pool space (expected ~100) */
 #define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
 template <int W>
@@ -314,7 +316,14 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         walk(s, o, far, fo, len, bases, nullptr, false);
         const u32 xp = o == 0 ? 1u : 0u;
         log[lbase + e] = link[(base + s) * 2 + xp] | ((u64)(2 * s + xp) << 46);
-        if (len - 1 <= KC_SC_INLINE_MAX) {
+        // runs of up to 8 nodes whose far end is matched onwards also carry that onward link (the walk then skips the far end's
+        // line altogether): bit 3 set, bits 6-41 next slot, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
+        // inside the run, bits 48-61 those bases
+        const u64 wfar = (len - 1 <= KC_SC_NEXT_MAX) ? link[(base + far) * 2 + (fo == 0 ? 1u : 0u)] : 0;
+        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && LK_SLOT(wfar) < ((u64)1 << 36)) {
+            link[(base + s) * 2 + xp] = LK_REJ | KC_SC_NEXT | (LK_SLOT(wfar) << 6) | (LK_PORT(wfar) << 42) | (LK_BASE(wfar) << 43) | ((u64)(len - 1) << 45) |
+                                        ((bases >> 24) << 48);
+        } else if (len - 1 <= KC_SC_INLINE_MAX) {
             link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
         } else {
             const u32 nw = (len - 1 + 31) / 32;
@@ -416,6 +425,19 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         if (FRAG && KC_SC_IS(w)) {
             // a contracted run: take its bases, continue at its far end
+            if (w & KC_SC_NEXT) {
+                // the run and the step out of it in one word: no look at the far end
+                const u64 nb1 = ((w >> 45) & 7) + 1;
+                if (REC) push_group(((((w >> 48) & 0x3fffull) >> (14 - 2 * (nb1 - 1))) << 2) | ((w >> 43) & 3), (int)nb1);
+                len += nb1;
+                cur = (w >> 6) & (((u64)1 << 36) - 1);
+                co = (int)((w >> 42) & 1);
+                if (len > limit) {
+                    if (__hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicExch((ull *)(cursor + 7), 1ULL);
+                    return;
+                }
+                continue;
+            }
             const u64 blk = cur >> set.bshift;
             u64 nb;
             if (w & KC_SC_EXT) {

@@ -3,7 +3,13 @@
 // log lines and output format, running the hot path on the GPU through the C ABI.  `compute` uses the fused
 // device-resident pipeline (kc_compute); the converters are host-side byte shuffles (conversions.h); everything the
 // hot-path scope leaves out (other algorithms, min-run masks) is rejected explicitly.
+#include <algorithm>
 #include <chrono>
+#include <thread>
+#include <sys/stat.h>
+#include <sys/mman.h>
+#include <sstream>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -121,6 +127,55 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
     };
     kcamd::warm_context();   // the device comes up while the file is read
+    // The output file is sized (about the input's length), mapped and its pages are faulted in by four threads while the GPU
+    // computes; the result then goes straight into the page cache through the mapping (kc_result_write_mem: stores into a
+    // mapping take no inode lock, so several threads move each chunk) and the file is cut to its final length.  A single
+    // write() stream to tmpfs / the page cache moves ~6 GB/s, page allocation included; this way the allocation is off the
+    // critical path and the copy is parallel.  Anything unusual (not a regular file, small input, mapping refused, result
+    // longer than estimated) falls back to the plain descriptor path below.
+    struct OutMap {
+        int fd = -1; char *map = nullptr; size_t cap = 0; bool ok = false, committed = false;
+        std::thread th;
+        void settle() { if (th.joinable()) th.join(); }
+        ~OutMap() {
+            settle();
+            if (map) ::munmap(map, cap);
+            if (fd >= 0) { if (!committed && ::ftruncate(fd, 0) != 0) {} ::close(fd); }
+        }
+    } om;
+    std::string hdr;
+    if (!lower_bound && !out_path.empty() && !std::getenv("KC_CLI_NOPREALLOC")) {
+        struct stat sti, sto;
+        if (::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode) && sti.st_size > (off_t)(64 << 20) && ::stat(out_path.c_str(), &sto) == 0 &&
+            S_ISREG(sto.st_mode)) {
+            std::ostringstream hs;
+            WriteName(path, "greedy", k, false, !complements, hs);
+            hdr = hs.str();
+            om.cap = hdr.size() + (size_t)sti.st_size + 4096;
+            om.th = std::thread([&om, out_path] {
+                const int fd = ::open(out_path.c_str(), O_RDWR);
+                if (fd < 0) return;
+                if (::ftruncate(fd, (off_t)om.cap) != 0) { ::close(fd); return; }
+                void *m = ::mmap(nullptr, om.cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                om.fd = fd;   // (from here on the destructor restores the empty file unless the result is committed)
+                if (m == MAP_FAILED) return;
+                om.map = static_cast<char *>(m);
+                const int T = 4;
+                auto part = [&](int t) {
+                    const size_t lo = (om.cap * (size_t)t / T) & ~(size_t)4095, hi = t + 1 == T ? om.cap : ((om.cap * (size_t)(t + 1) / T) & ~(size_t)4095);
+#ifdef MADV_POPULATE_WRITE
+                    if (::madvise(om.map + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+#endif
+                    for (size_t p = lo; p < hi; p += 4096) reinterpret_cast<volatile char *>(om.map)[p] = 0;
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+                part(0);
+                for (auto &x : th) x.join();
+                om.ok = true;
+            });
+        }
+    }
     Records recs;
     kc_ctx *ctx = nullptr;
     void *d_seq = nullptr;
@@ -202,7 +257,11 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     uint64_t st[16];
     kc_result_stats(res, st);
     if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
-    WriteName(path, "greedy", k, false, !complements, *of);
+    om.settle();
+    if (om.fd >= 0) mark("output mapping ready");
+    const bool mapped = om.ok && hdr.size() + st[2] + 1 <= om.cap;
+    if (!mapped && om.fd >= 0) { if (om.map) { ::munmap(om.map, om.cap); om.map = nullptr; } if (::ftruncate(om.fd, 0) != 0) {} ::close(om.fd); om.fd = -1; }
+    if (!mapped) WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
     if (st[3]) WriteLog("2. part: Number of simplitigs over threshold, computing directly from k-mers.");
@@ -218,12 +277,20 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (which == 1) write_all(fd, "\n", 1);   // global.h:206-208
         if (!p.empty()) ::close(fd);
     };
-    emit(out_path, 0);
+    if (mapped) {
+        memcpy(om.map, hdr.data(), hdr.size());
+        kcamd::check(kc_result_write_mem(res, om.map + hdr.size(), 0));
+        mark("result in the mapping");
+        om.map[hdr.size() + st[2]] = '\n';   // main.cpp:210
+        ::munmap(om.map, om.cap); om.map = nullptr;
+        if (::ftruncate(om.fd, (off_t)(hdr.size() + st[2] + 1)) != 0) throw std::runtime_error("cannot size " + out_path);
+        om.committed = true;
+    } else emit(out_path, 0);
     if (maskf != nullptr) emit(mask_path, 1);
     kc_result_destroy(res);
     mark("result written");
     WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
-    {
+    if (!mapped) {
         int fd = out_path.empty() ? 1 : ::open(out_path.c_str(), O_WRONLY | O_APPEND);
         if (fd >= 0) { write_all(fd, "\n", 1); if (!out_path.empty()) ::close(fd); }   // main.cpp:210
     }
