@@ -361,14 +361,14 @@ struct OvWork {
 // ordered (stable) compaction by wave ballot / prefix scan: kcu_select_flagged (kc_util.hip)
 static int select_flagged(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u64 n, u64 *h_count) {
     kc_ctx *ctx = w.ctx;
-    KC_TRY(kcu_select_flagged(ctx, in, flags, n, out, w.d_num));
+    KC_TRY(kcu_select_flagged(ctx, in, flags, n, out, w.d_num, false));
     KC_HIP(ctx, hipMemcpyAsync(h_count, w.d_num, 8, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KC_OK;
 }
 
 static int select_flagged_nosync(OvWork &w, const u64 *in, const u8 *flags, u64 *out, u64 n) {
-    return kcu_select_flagged(w.ctx, in, flags, n, out, w.d_num);
+    return kcu_select_flagged(w.ctx, in, flags, n, out, w.d_num, false);
 }
 
 // Small inputs (most levels: a few hundred to a few thousand hits) are sorted by ONE workgroup in LDS -- a bitonic network
@@ -443,7 +443,7 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         KC_HIP(ctx, hipGetLastError());
         return KC_OK;
     }
-    if (W == 1) return kcu_sort_pairs(ctx, keys, keys_out, ids, ids_out, n, 0, total_bits);
+    if (W == 1) return kcu_sort_pairs(ctx, keys, keys_out, ids, ids_out, n, 0, total_bits, false);
     u64 *perm = s0, *perm2 = s1, *kw = s2, *kw2 = s3;
     hipLaunchKernelGGL(ov_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
     for (int word = 0; word < W; ++word) {
@@ -451,7 +451,7 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         if (bits <= 0) break;
         if (bits > 64) bits = 64;
         hipLaunchKernelGGL(ov_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, (const u64 *)perm, n, W, word, kw);
-        KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, n, 0, bits));
+        KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, n, 0, bits, false));
         std::swap(perm, perm2);
     }
     hipLaunchKernelGGL(ov_gather_rows_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, (const u64 *)perm, n, W, keys_out,

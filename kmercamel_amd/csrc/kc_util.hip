@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) kc_scan_tile_kernel(const u64 *in, u64 n,
     for (int i = 0; i < 8; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
     if (blockIdx.x == ntiles - 1 && threadIdx.x == 255) out[n] = ex;   // the last thread of the last tile ends at the total
 }
-int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n) {
+int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n, bool sync) {
     if (n == 0) { KC_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return KC_OK; }
     const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
     if (ntiles == 1) {
@@ -39,12 +39,13 @@ int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n) {
     u64 *sums = nullptr;
     KC_TRY(kc_alloc(ctx, &sums, ntiles + 1));
     hipLaunchKernelGGL(kc_scan_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, sums);
-    int rc = kcu_exclusive_scan(ctx, sums, sums, ntiles);
+    int rc = kcu_exclusive_scan(ctx, sums, sums, ntiles, sync);
     if (rc == KC_OK) {
         hipLaunchKernelGGL(kc_scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, (const u64 *)sums, out, ntiles);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "scan launch failed");
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    // (sync = false: the temporaries go back to the pool at once; whoever gets them next works on the same stream, behind us)
+    if (sync) (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, sums);
     return rc;
 }
@@ -74,19 +75,19 @@ __global__ void __launch_bounds__(256) kc_flag_write_kernel(const u64 *__restric
     for (int i = 0; i < 8; ++i) if ((m >> i) & 1) out[pos++] = in[base + i];
 }
 // d_total (device, optional) receives the number of survivors
-int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *out, u64 *d_total) {
+int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *out, u64 *d_total, bool sync) {
     if (n == 0) { if (d_total) KC_HIP(ctx, hipMemsetAsync(d_total, 0, 8, ctx->stream)); return KC_OK; }
     const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
     u64 *counts = nullptr;
     KC_TRY(kc_alloc(ctx, &counts, ntiles + 1));
     hipLaunchKernelGGL(kc_flag_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, flags, n, counts);
-    int rc = kcu_exclusive_scan(ctx, counts, counts, ntiles);
+    int rc = kcu_exclusive_scan(ctx, counts, counts, ntiles, sync);
     if (rc == KC_OK) {
         hipLaunchKernelGGL(kc_flag_write_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, flags, n, (const u64 *)counts, out);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "compaction launch failed");
         if (rc == KC_OK && d_total && hipMemcpyAsync(d_total, counts + ntiles, 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    if (sync) (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, counts);
     return rc;
 }
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(256) kc_radix_scatter_kernel(const u64 *__rest
     }
 }
 // keys_in / vals_in are left intact; the sorted pairs end in keys_out / vals_out (vals may be null: keys only).
-int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *vals_in, u64 *vals_out, u64 n, int begin_bit, int end_bit) {
+int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *vals_in, u64 *vals_out, u64 n, int begin_bit, int end_bit, bool sync) {
     if (n == 0) return KC_OK;
     const int passes = (end_bit - begin_bit + 3) / 4;
     if (passes <= 0) {
@@ -170,13 +171,13 @@ int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *va
         u64 *dk = to_out ? keys_out : tk, *dv = to_out ? vals_out : tv;
         const int shift = begin_bit + 4 * p;
         hipLaunchKernelGGL(kc_radix_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, n, shift, ntiles, counts);
-        rc = kcu_exclusive_scan(ctx, counts, counts, 16 * ntiles);
+        rc = kcu_exclusive_scan(ctx, counts, counts, 16 * ntiles, sync);
         if (rc != KC_OK) break;
         hipLaunchKernelGGL(kc_radix_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, sv, n, shift, ntiles, (const u64 *)counts, dk, dv);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "radix sort launch failed");
         sk = dk; sv = dv;
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    if (sync) (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, counts); kc_release(ctx, tk); kc_release(ctx, tv);
     return rc;
 }
