@@ -347,6 +347,7 @@ struct OvWork {
     kc_ctx *ctx;
     void *tmp = nullptr; size_t tmp_bytes = 0;
     u64 *d_num = nullptr;
+    u64 *d_flag = nullptr, *h_flag = nullptr;   // bucketed sort: overflow flag (device word, pinned host word)
     int ensure_tmp(size_t bytes) {
         if (bytes <= tmp_bytes) return KC_OK;
         kc_release(ctx, tmp);
@@ -443,6 +444,16 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         KC_HIP(ctx, hipGetLastError());
         return KC_OK;
     }
+    // mid-size and large lists: one MSD bucket pass + one-workgroup LDS sorts (4 launches); skewed keys overflow a bucket and
+    // take the LSD radix sort below (5 launches per 4 key bits) instead
+    if (!getenv("KC_NO_BUCKET_SORT")) {
+        const int brc = kcu_sort_rows_bucketed(ctx, keys, ids, n, W, total_bits, keys_out, ids_out, w.d_flag);
+        if (brc == KC_OK) {
+            KC_HIP(ctx, hipMemcpyAsync(w.h_flag, w.d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (*w.h_flag == 0) return KC_OK;
+        } else if (brc != KC_E_ARG) return brc;
+    }
     if (W == 1) return kcu_sort_pairs(ctx, keys, keys_out, ids, ids_out, n, 0, total_bits, false);
     u64 *perm = s0, *perm2 = s1, *kw = s2, *kw2 = s3;
     hipLaunchKernelGGL(ov_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
@@ -494,7 +505,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     cnt = fresh_cnt();
     const u64 BL_MAX = 4096;
     KC_TRY(scope.alloc(&bl, BL_MAX * 2));
-    KC_TRY(scope.alloc(&w.d_num, 2));
+    KC_TRY(scope.alloc(&w.d_num, 4));
+    w.d_flag = w.d_num + 2;
     u64 *big = nullptr;
     int lds_min = KC_LDS_MIN;
     if (const char *e = getenv("KC_LDS_MIN")) { int v = atoi(e); if (v >= 2 && v <= KC_LDS_MAX) lds_min = v; }
@@ -534,6 +546,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     }
 
     KC_HIP(ctx, hipHostMalloc((void **)&hp, 128, hipHostMallocDefault));
+    w.h_flag = hp + 15;   // (the level loop reads back at most 9 words)
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
         g.d = d;
         const bool trace = getenv("KC_OV_TRACE") != nullptr;

@@ -182,6 +182,136 @@ int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *va
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------- bucketed row sort
+// Rows = (W-word key with `total_bits` significant bits, id); wanted: ascending by (key, id).  One MSD pass on the top NB bits
+// (histogram, single-workgroup scan, scatter) splits the rows into ~n/300 buckets, then one workgroup per bucket sorts its
+// rows by (key, id) in LDS (bitonic network): four launches, where the LSD radix sort needs 5 per 4 bits of key.  A bucket
+// beyond what a workgroup holds (skewed keys: repeats, low-complexity sequence) raises *d_flag and the output is void --
+// the caller then falls back to the LSD sort.  ids must be unique (they break ties).
+#define KC_BKT_THREADS 256
+__device__ __forceinline__ u32 kc_row_bucket(const u64 *__restrict__ row, int W, int total_bits, int nb_bits) {
+    const int lo = total_bits - nb_bits, w0 = lo >> 6, off = lo & 63;
+    u64 v = row[w0] >> off;
+    if (off + nb_bits > 64 && w0 + 1 < W) v |= row[w0 + 1] << (64 - off);
+    return (u32)v & ((1u << nb_bits) - 1u);
+}
+// (cstride: with few buckets every counter sits on a line of its own -- atomics on one 128-byte line serialise at ~4 ns each,
+// which made the two atomic passes of a 16 000-row sort cost more than the sort)
+__global__ void __launch_bounds__(256) kc_bkt_hist_kernel(const u64 *__restrict__ keys, u64 n, int W, int total_bits, int nb_bits, u32 *counts, u32 cstride) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[(size_t)kc_row_bucket(keys + i * (u64)W, W, total_bits, nb_bits) * cstride], 1u);
+}
+// one workgroup: offsets[b] = rows before bucket b (offsets[nb] = n), cursors = a copy to scatter through; *flag |= a bucket exceeds cap
+__global__ void __launch_bounds__(1024) kc_bkt_scan_kernel(const u32 *__restrict__ counts, u32 nb, u32 cap, u32 *offsets, u32 *cursors, u64 *flag, u32 cstride) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 over;
+    const u32 per = (nb + 1023u) / 1024u, lo = threadIdx.x * per;
+    if (threadIdx.x == 0) over = 0;
+    __syncthreads();
+    u32 s = 0, big = 0;
+    for (u32 i = lo; i < lo + per && i < nb; ++i) { const u32 c = counts[(size_t)i * cstride]; s += c; big |= c > cap; }
+    if (big) over = 1;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u32 inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 base = 0;
+    for (int i = 0; i < wv; ++i) base += wsum[i];
+    u32 run = base + inc - s;
+    for (u32 i = lo; i < lo + per && i < nb; ++i) { offsets[i] = run; cursors[(size_t)i * cstride] = run; run += counts[(size_t)i * cstride]; }
+    if (threadIdx.x == 1023) offsets[nb] = run;
+    if (threadIdx.x == 0 && over) *flag = 1;
+}
+__global__ void __launch_bounds__(256) kc_bkt_scatter_kernel(const u64 *__restrict__ keys, const u64 *__restrict__ ids, u64 n, int W, int total_bits,
+                                                             int nb_bits, u32 *cursors, u64 *tk, u64 *tv, u32 cstride) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 *row = keys + i * (u64)W;
+    const u32 pos = atomicAdd(&cursors[(size_t)kc_row_bucket(row, W, total_bits, nb_bits) * cstride], 1u);
+    for (int j = 0; j < W; ++j) tk[(u64)pos * W + j] = row[j];
+    tv[pos] = ids[i];
+}
+__global__ void __launch_bounds__(KC_BKT_THREADS) kc_bkt_sort_kernel(const u64 *__restrict__ tk, const u64 *__restrict__ tv, const u32 *__restrict__ offsets,
+                                                                     int W, u32 cap, const u64 *__restrict__ flag, u64 *keys_out, u64 *ids_out) {
+    extern __shared__ u64 kc_bkt[];   // cap ids, then W planes of cap key words
+    const u32 lo = offsets[blockIdx.x], m = offsets[blockIdx.x + 1] - lo;
+    if (m == 0 || *flag) return;
+    if (m == 1) {
+        if (threadIdx.x == 0) { ids_out[lo] = tv[lo]; for (int j = 0; j < W; ++j) keys_out[(u64)lo * W + j] = tk[(u64)lo * W + j]; }
+        return;
+    }
+    u32 P = 2;
+    while (P < m) P <<= 1;
+    u64 *sid = kc_bkt, *sk = kc_bkt + cap;
+    for (u32 i = threadIdx.x; i < P; i += blockDim.x) {
+        sid[i] = i < m ? tv[lo + i] : ~(u64)0;
+        for (int j = 0; j < W; ++j) sk[(u32)j * cap + i] = i < m ? tk[(u64)(lo + i) * W + j] : ~(u64)0;
+    }
+    __syncthreads();
+    auto greater = [&](u32 a, u32 b) -> bool {   // row a sorts after row b
+        for (int j = W - 1; j >= 0; --j) {
+            const u64 x = sk[(u32)j * cap + a], y = sk[(u32)j * cap + b];
+            if (x != y) return x > y;
+        }
+        return sid[a] > sid[b];
+    };
+    for (u32 size = 2; size <= P; size <<= 1) {
+        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+            for (u32 t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const u32 a = ((t / stride) * (stride << 1)) + (t % stride), b = a + stride;
+                const bool up = ((a & size) == 0);
+                if (greater(a, b) == up) {
+                    u64 tmp = sid[a]; sid[a] = sid[b]; sid[b] = tmp;
+                    for (int j = 0; j < W; ++j) { tmp = sk[(u32)j * cap + a]; sk[(u32)j * cap + a] = sk[(u32)j * cap + b]; sk[(u32)j * cap + b] = tmp; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (u32 i = threadIdx.x; i < m; i += blockDim.x) {
+        ids_out[lo + i] = sid[i];
+        for (int j = 0; j < W; ++j) keys_out[(u64)(lo + i) * W + j] = sk[(u32)j * cap + i];
+    }
+}
+// returns KC_E_ARG when the shape does not suit the method (the caller then uses the LSD sort right away); otherwise the sort
+// is enqueued and *d_flag (device word, zeroed here) tells afterwards whether a bucket overflowed.  No stream sync.
+int kcu_sort_rows_bucketed(kc_ctx *ctx, const u64 *keys, const u64 *ids, u64 n, int W, int total_bits, u64 *keys_out, u64 *ids_out, u64 *d_flag) {
+    if (n < 1024 || n >= ((u64)1 << 31)) return KC_E_ARG;
+    int lg = 0;
+    while (((u64)1 << lg) < n) ++lg;
+    int nb_bits = lg - 8;   // ~256-512 rows per bucket when the keys are spread evenly
+    if (nb_bits < 3) nb_bits = 3;
+    if (nb_bits > 16) nb_bits = 16;
+    if (total_bits < nb_bits + 4) return KC_E_ARG;   // (few key bits: the LSD sort needs few passes anyway)
+    const u32 nb = 1u << nb_bits;
+    const u32 cap = W == 4 ? 1024u : 2048u;
+    const size_t lds = (size_t)cap * (size_t)(W + 1) * 8;
+    u32 *counts = nullptr, *offsets = nullptr, *cursors = nullptr;
+    u64 *tk = nullptr, *tv = nullptr;
+    const u32 cstride = nb <= 2048 ? 32u : 1u;
+    int rc = kc_alloc(ctx, &counts, (size_t)nb * cstride);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &offsets, nb + 1);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &cursors, (size_t)nb * cstride);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &tk, n * (u64)W);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &tv, n);
+    // (the temporaries go back to the pool without a stream sync: their next user queues behind these kernels)
+    auto done = [&](int r) { kc_release(ctx, counts); kc_release(ctx, offsets); kc_release(ctx, cursors); kc_release(ctx, tk); kc_release(ctx, tv); return r; };
+    if (rc != KC_OK) return done(rc);
+    if (hipMemsetAsync(counts, 0, (size_t)nb * cstride * 4, ctx->stream) != hipSuccess || hipMemsetAsync(d_flag, 0, 8, ctx->stream) != hipSuccess)
+        return done(kc_fail(ctx, KC_E_NO_DEVICE, "memset failed"));
+    hipLaunchKernelGGL(kc_bkt_hist_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, n, W, total_bits, nb_bits, counts, cstride);
+    hipLaunchKernelGGL(kc_bkt_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)counts, nb, cap, offsets, cursors, d_flag, cstride);
+    hipLaunchKernelGGL(kc_bkt_scatter_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, n, W, total_bits, nb_bits, cursors, tk, tv, cstride);
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bkt_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return done(kc_fail(ctx, KC_E_NO_DEVICE, "LDS size refused"));
+    hipLaunchKernelGGL(kc_bkt_sort_kernel, dim3(nb), dim3(KC_BKT_THREADS), lds, ctx->stream, (const u64 *)tk, (const u64 *)tv, (const u32 *)offsets, W, cap,
+                       (const u64 *)d_flag, keys_out, ids_out);
+    if (hipGetLastError() != hipSuccess) return done(kc_fail(ctx, KC_E_NO_DEVICE, "bucketed sort launch failed"));
+    return done(KC_OK);
+}
+
 // ---------------------------------------------------------------------------------------------------- sharded lists
 // Lists filled through KC_USHARDS cursors (one 128-byte line each): shard s owns the items [s * shard_cap, s * shard_cap + min(count_s, shard_cap)).
 // kcu_compact_shards copies them, E words per item, into one contiguous list and returns the total (or ~0 on overflow of a shard).
