@@ -741,6 +741,7 @@ __global__ void __launch_bounds__(256) kc_segment_emit_kernel(SetView<W> set, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
+static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h);
 static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out) {
     // LSD over the key words (least significant word first), each pass a stable radix sort of (word, perm).
     u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr;
@@ -750,6 +751,20 @@ static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k
     KC_TRY(scope.alloc(&kw, n));
     KC_TRY(scope.alloc(&kw2, n));
     hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
+    // many keys (read sets: one chain per read): one MSD bucket pass + LDS sorts (kcu_sort_rows_bucketed); the LSD passes
+    // below remain for small inputs and for key sets so skewed that a bucket overflows
+    if (n >= 1024 && !getenv("KC_NO_BUCKET_SORT")) {
+        u64 *kout = nullptr, *flag = nullptr;
+        KC_TRY(scope.alloc(&kout, n * (u64)W));
+        KC_TRY(scope.alloc(&flag, 1));
+        const int brc = kcu_sort_rows_bucketed(ctx, d_keys, perm, n, W, 2 * k, kout, perm2, flag);
+        if (brc == KC_OK) {
+            u64 ovf = 1;
+            KC_TRY(read_u64(ctx, flag, &ovf));
+            if (!ovf) { scope.keep(perm2); *perm_out = perm2; return KC_OK; }
+        } else if (brc != KC_E_ARG) return brc;
+        scope.release(kout);
+    }
     for (int word = 0; word < W; ++word) {
         int bits = 2 * k - 64 * word;
         if (bits <= 0) break;
