@@ -201,30 +201,35 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
             const u32 o = (u32)chome[i] & ((1u << set.bshift) - 1u);
             __builtin_memcpy(&cword[i], reinterpret_cast<const u8 *>(stage) + o, 8);
         }
-    // branch-free on purpose: a conditional here lets the compiler sink a candidate's load into the branch and wait for it
+    // branch-free on purpose: a conditional here lets the compiler sink a candidate's load into the branch and wait for it.
+    // The 8 tag bytes of a window are searched in 32-bit halves: "byte equals the tag" and "byte is empty" each become one bit
+    // per byte (bit 7), and a multiply gathers the four bits of a half into a nibble -- (h * 0x204081) >> 28 -- so that
+    // everything after that (first candidate, is it a match, is the next one an empty slot) works on two 8-bit masks.
     u32 pending = 0, slow = 0, settled2 = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const u64 hi7 = 0x8080808080808080ULL, lo7 = 0x7f7f7f7f7f7f7f7fULL;
-        u32 t32 = kc_tag_of(cph[i]);
-        t32 |= t32 << 8; t32 |= t32 << 16;
-        const u64 xw = cword[i] ^ (((u64)t32 << 32) | t32);
-        const u64 zero = ~(((xw & lo7) + lo7) | xw | lo7);
-        const u64 empty = ~cword[i] & hi7;
-        u64 cand = zero | empty;
-        if (set.local_probes < 8) cand &= ((u64)1 << (8 * set.local_probes)) - 1;   // an empty slot proves a miss only inside the local probe run
+        const u32 lo7 = 0x7f7f7f7fu, hi7 = 0x80808080u, gather = 0x204081u;
+        const u32 pat = (u32)kc_tag_of(cph[i]) * 0x01010101u;
+        const u32 wl = (u32)cword[i], wh = (u32)(cword[i] >> 32);
+        const u32 xl = wl ^ pat, xh = wh ^ pat;
+        const u32 ml = ~(((xl & lo7) + lo7) | xl) & hi7, mh = ~(((xh & lo7) + lo7) | xh) & hi7;   // bit 7 of the bytes that equal the tag
+        const u32 el = ~wl & hi7, eh = ~wh & hi7;                                                  // bit 7 of the empty bytes (tag 0)
+        const u32 M8 = ((ml * gather) >> 28) | (((mh * gather) >> 28) << 4);
+        const u32 E8 = ((el * gather) >> 28) | (((eh * gather) >> 28) << 4);
+        u32 C = M8 | E8;
+        if (set.local_probes < 8) C &= (1u << set.local_probes) - 1u;   // an empty slot proves a miss only inside the local probe run
         const u32 lv = (live >> i) & 1u;
-        const u32 none = cand == 0 ? 1u : 0u;                        // window full of other tags: keep scanning (slow path)
-        const int b = __builtin_ctzll(cand | ((u64)1 << 63)) >> 3;
-        const u32 hit = (u32)(((empty >> (8 * b)) & 0x80) == 0) & (none ^ 1u);   // first candidate is a tag match, not an empty slot
+        const u32 none = C == 0 ? 1u : 0u;                          // window full of other tags: keep scanning (pooled redo)
+        const u32 b = (u32)__builtin_ctz(C | 0x100u);
+        const u32 hit = (M8 >> b) & 1u;                             // first candidate is a tag match, not an empty slot (0 when none)
         u64 sl = chome[i] + (u64)b;
         if (!SH) sl = sl >= set.cap ? sl - set.cap : sl;   // (plain hashing only; block homes keep their window inside the block)
         const u32 pend = lv & hit;
         // if that tag match turns out to be another key, the next candidate of the window usually is the empty slot
-        // that proves the miss: note it now, so that a tag false positive does not cost a trip through the slow path
-        const u64 cand2 = cand & (cand - 1);
-        const int b2 = __builtin_ctzll(cand2 | ((u64)1 << 63)) >> 3;
-        const u32 miss2 = (u32)(cand2 != 0) & (u32)(((empty >> (8 * b2)) & 0x80) != 0);
+        // that proves the miss: note it now, so that a tag false positive does not cost a trip through the redo
+        const u32 C2 = C & (C - 1u);
+        const u32 b2 = (u32)__builtin_ctz(C2 | 0x100u);
+        const u32 miss2 = (E8 >> b2) & 1u;                          // (0 when there is no second candidate)
         slow |= (lv & none) << i;
         pending |= pend << i;
         settled2 |= miss2 << i;
