@@ -208,6 +208,52 @@ def test_fragment_contraction_path(ctx, k, monkeypatch):
                     monkeypatch.delenv(var)
 
 
+@pytest.mark.parametrize("k", [21, 45])
+def test_overlap_hit_lists_bucketed_sort_and_its_fallback(ctx, oracle, k, monkeypatch):
+    """Hit lists beyond 1024 rows are ordered by an MSD bucket pass + one-workgroup LDS sorts (kcu_sort_rows_bucketed); keys
+    that share their leading characters (here: unidirectional runs over a two-letter alphabet, so the top key bits take few
+    values) overflow a bucket and the level falls back to the LSD radix sort.  Both routes, and the LSD sort alone
+    (KC_NO_BUCKET_SORT=1), must give the same bytes; the smaller case is also checked against the oracle."""
+    rng = np.random.default_rng(500 + k)
+    def reads(n, length, alphabet):
+        a = np.frombuffer(alphabet.encode(), dtype=np.uint8)[rng.integers(0, len(alphabet), size=(n, length + 1))]
+        a[:, length] = 10
+        return a.reshape(-1)[:-1].copy()
+    cases = {"skewed": reads(40000, k + 25, "AC"), "even": reads(30000, k + 40, "ACGT")}
+    for name, seq in cases.items():
+        for complements in (False, True):
+            got = kc.compute(ctx, seq, k, complements)
+            g = got.array().copy(); got.close()
+            monkeypatch.setenv("KC_NO_BUCKET_SORT", "1")
+            ref = kc.compute(ctx, seq, k, complements)
+            r = ref.array().copy(); ref.close()
+            monkeypatch.delenv("KC_NO_BUCKET_SORT")
+            assert np.array_equal(g, r), (name, k, complements)
+    small = reads(3000, k + 25, "AC")
+    text = small.tobytes().decode()
+    for complements in (False, True):
+        want = oracle.simplitigs_of_sequence(text.replace("\n", "N"), k, complements, mode=1)
+        rc, wout, wmask = oracle.global_(want, k, complements, want_mask=True)
+        got = kc.compute(ctx, small, k, complements)
+        assert rc == 0 and got.array().tobytes().decode() == wout
+        got.close()
+
+
+def test_result_write_mem_equals_copy(ctx):
+    """kc_result_write_mem (pinned chunks moved on by several threads; what the CLI fills its output mapping with) gives the
+    bytes of kc_result_copy, for the superstring and for the -M mask, at a size beyond one 32 MB chunk."""
+    import ctypes
+    seq = gen.random_joined(60000, 700, seed=77)
+    res = kc.compute(ctx, seq, 31, True, want_mask=True)
+    want = res.strings(want_mask=True)
+    assert res.length > (32 << 20)
+    for which in (0, 1):
+        buf = np.zeros(res.length, dtype=np.uint8)
+        ctx.check(ctx.lib.kc_result_write_mem(res.h, buf.ctypes.data_as(ctypes.c_void_p), which))
+        assert buf.tobytes().decode() == want[which]
+    res.close()
+
+
 @pytest.mark.parametrize("k", [31, 40, 100])
 def test_bucket_overflow_falls_back_to_direct_inserts(ctx, oracle, k, monkeypatch):
     """A short read repeated thousands of times sends more occurrences to a few table blocks than a bucket holds: the
