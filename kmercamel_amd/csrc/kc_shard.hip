@@ -50,18 +50,17 @@ struct ShLists {
 // ---------------------------------------------------------------------------------------------------- phase 1a
 // Round 1 over this rank's slot range.  Same sweep as kc_choose_dense_kernel (workgroup = 2048 slots of one block, block
 // tags staged in LDS); a port whose 4 candidates are all local and of which at most one exists is settled at once, every
-// other port gets a record, every remote candidate a query.  List space is reserved once per workgroup iteration.
+// other port gets a record, every remote candidate a query.  List space is reserved once per wavefront and sweep step.
 template <int W, int KC>
-__global__ void __launch_bounds__(256) kc_shard_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
+__global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
                                                               ShLists L, int stage_words) {
     extern __shared__ u64 kc_stage[];
     __shared__ unsigned short kc_list[KC_CHOOSE_SLOTS];
-    __shared__ u32 kc_nlist, n_rec, n_qry;
-    __shared__ u64 base_rec, base_qry;
+    __shared__ u32 kc_nlist;
     const u64 base = set.rlo + kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_SLOTS;
     const u64 end = set.rlo + set.rcap;
     if (base >= end) return;
-    if (threadIdx.x == 0) { kc_nlist = 0; n_rec = 0; n_qry = 0; }
+    if (threadIdx.x == 0) kc_nlist = 0;
     const u64 sblk = base >> set.bshift;
     {
         const u64 *src = reinterpret_cast<const u64 *>(set.tags + (sblk << set.bshift));
@@ -73,7 +72,7 @@ __global__ void __launch_bounds__(256) kc_shard_choose_kernel(SetView<W> set, u6
         if (base + i < end && tg[i] != 0) kc_list[atomicAdd(&kc_nlist, 1u)] = (unsigned short)i;
     __syncthreads();
     const u32 n = kc_nlist;
-    const u32 shard = (u32)blockIdx.x & (KC_USH - 1);
+    const u32 shard = ((u32)blockIdx.x * 4u + (threadIdx.x >> 6)) & (KC_USH - 1);
     const int QW = W + 2;
 #pragma unroll 1
     for (u32 t0 = 0; t0 < n; t0 += 256) {
@@ -89,28 +88,36 @@ __global__ void __launch_bounds__(256) kc_shard_choose_kernel(SetView<W> set, u6
             for (int port = 0; port < 2; ++port) {
                 const u64 pid = (slot << 1) | (u64)port;
                 if (port == 1 && cd.xpal) { link[pid] = LK_DEAD; continue; }
-                u32 nfound = 0, nrem = 0, bc = 0;
+                u32 nfound = 0, nrem = 0, bc = 0, bq = 0;
+                u64 bslot = 0;   // (kept by selects: indexing cslot[] with a run-time index sends the array to scratch memory)
 #pragma unroll
                 for (u32 c = 0; c < 4; ++c) {
                     const u64 cs = cd.cslot[port * 4 + c];
                     if (cs == KC_REMOTE) ++nrem;
-                    else if (cs != KC_NONE64) { ++nfound; bc = c; }
+                    else if (cs != KC_NONE64) { ++nfound; bc = c; bslot = cs; bq = (cd.qbits >> (port * 4 + c)) & 1u; }
                 }
                 if (nrem == 0 && nfound <= 1) {
-                    const int i = port * 4 + (int)bc;
-                    link[pid] = nfound ? LK_MAKE(LK_CHOICE, (cd.qbits >> i) & 1, port ? bc : 3 - bc, cd.cslot[i]) : LK_DEAD;
+                    link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD;
                 } else { need |= 1u << port; nq += nrem; }
             }
         }
+        // list space is reserved once per wavefront and sweep step (every lane runs every step, so all 64 take part): exclusive
+        // prefix sums of the record count (0..2) and the query count (0..8) by ballots over their bit planes, one atomic each.
+        // (Reserving per workgroup took four barriers per step, which cost more than the lookups: 2x the single-GPU kernel.)
         const u32 nr = (need & 1) + (need >> 1);
-        const u32 my_rec = nr ? atomicAdd(&n_rec, nr) : 0;
-        const u32 my_qry = nq ? atomicAdd(&n_qry, nq) : 0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            base_rec = n_rec ? atomicAdd((ull *)&L.rec_cur[shard * KC_USTRIDE], (ull)n_rec) : 0;
-            base_qry = n_qry ? atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)n_qry) : 0;
+        const unsigned long long lt = ((unsigned long long)1 << (threadIdx.x & 63)) - 1;
+        u32 my_rec = 0, tot_rec = 0, my_qry = 0, tot_qry = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const unsigned long long m = __ballot((nr >> j) & 1u); my_rec += (u32)__popcll(m & lt) << j; tot_rec += (u32)__popcll(m) << j; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const unsigned long long m = __ballot((nq >> j) & 1u); my_qry += (u32)__popcll(m & lt) << j; tot_qry += (u32)__popcll(m) << j; }
+        u64 base_rec = 0, base_qry = 0;
+        if ((threadIdx.x & 63) == 0) {
+            if (tot_rec) base_rec = atomicAdd((ull *)&L.rec_cur[shard * KC_USTRIDE], (ull)tot_rec);
+            if (tot_qry) base_qry = atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)tot_qry);
         }
-        __syncthreads();
+        base_rec = __shfl(base_rec, 0, 64);
+        base_qry = __shfl(base_qry, 0, 64);
         if (nr) {
             u64 rpos = base_rec + my_rec, qpos = base_qry + my_qry;
 #pragma unroll
@@ -140,10 +147,6 @@ __global__ void __launch_bounds__(256) kc_shard_choose_kernel(SetView<W> set, u6
                 ++rpos;
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { n_rec = 0; n_qry = 0; }
-        // (the next iteration's LDS atomics come after its own lookups; the barrier at its reservation orders the reset)
-        __syncthreads();
     }
 }
 
@@ -224,20 +227,26 @@ __global__ void __launch_bounds__(256) kc_shard_apply_fix_kernel(u64 *link, cons
 
 // ---------------------------------------------------------------------------------------------------- phase 1b: fragments
 // entry = oriented node (slot, o) whose entry port o is dead (a chain head) or matched to a slot of another rank
+// (two passes: count, then fill at the scanned offsets.  The count pass keeps every thread's 16-bit entry mask, so the fill pass
+// does not sweep the 16 bytes per slot of link words a second time.)
 template <bool FILL>
 __global__ void __launch_bounds__(256) kc_shard_entries_kernel(const u64 *__restrict__ link, const u8 *__restrict__ tags, u64 rlo, u64 rcap, int complements,
-                                                               const u64 *__restrict__ tile_off, u64 *out) {
+                                                               const u64 *__restrict__ tile_off, u64 *out, unsigned short *masks) {
     const u64 base = rlo + (u64)blockIdx.x * 2048 + (u64)threadIdx.x * 8;
     u64 c = 0;
     u32 m = 0;
-    for (int i = 0; i < 8; ++i) {
-        const u64 slot = base + i;
-        if (slot >= rlo + rcap || tags[slot] == 0) continue;
-        for (int o = 0; o < (complements ? 2 : 1); ++o) {
-            const u64 w = link[(slot << 1) | (u64)o];
-            const bool entry = LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - rlo >= rcap);
-            if (entry) { m |= 1u << (2 * i + o); ++c; }
+    if (FILL) { m = masks[(u64)blockIdx.x * 256 + threadIdx.x]; c = (u64)__popc(m); }
+    else {
+        for (int i = 0; i < 8; ++i) {
+            const u64 slot = base + i;
+            if (slot >= rlo + rcap || tags[slot] == 0) continue;
+            for (int o = 0; o < (complements ? 2 : 1); ++o) {
+                const u64 w = link[(slot << 1) | (u64)o];
+                const bool entry = LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - rlo >= rcap);
+                if (entry) { m |= 1u << (2 * i + o); ++c; }
+            }
         }
+        masks[(u64)blockIdx.x * 256 + threadIdx.x] = (unsigned short)m;
     }
     u64 tot;
     const u64 ex = kc_block_excl_scan(c, &tot);
@@ -550,14 +559,22 @@ __global__ void __launch_bounds__(256) kc_shard_place_kernel(const u64 *__restri
 // per-simplitig destination rank: owner of the output offset at which its on-path vertex starts
 __global__ void __launch_bounds__(256) kc_shard_simp_dest_kernel(const u64 *__restrict__ dist, const u64 *__restrict__ endv, u64 start, u64 S, u64 V, u64 Ltot, int G,
                                                                  u8 *simp_dest, u64 *rank_lo, u64 *rank_hi, const u64 *__restrict__ weight) {
+    // the ranks' output ranges are reduced per workgroup in LDS first: one atomicMin / atomicMax per vertex on G global words
+    // serialised at ~6 ns each (12 ms per 10^6 simplitigs, on every rank)
+    __shared__ u64 lo_s[64], hi_s[64];   // (at most 64 ranks: KC_MAX_RANKS of the routing code)
+    for (int i = threadIdx.x; i < G; i += blockDim.x) { lo_s[i] = ~(u64)0; hi_s[i] = 0; }
+    __syncthreads();
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    if (endv[v] != endv[start]) return;
-    const u64 off = dist[start] - dist[v];
-    const int r = (int)(((unsigned __int128)off * (unsigned)G) / Ltot);
-    simp_dest[v < S ? v : v - S] = (u8)r;
-    atomicMin((ull *)&rank_lo[r], (ull)off);
-    atomicMax((ull *)&rank_hi[r], (ull)(off + weight[v]));
+    if (v < V && endv[v] == endv[start]) {
+        const u64 off = dist[start] - dist[v];
+        const int r = (int)(((unsigned __int128)off * (unsigned)G) / Ltot);
+        simp_dest[v < S ? v : v - S] = (u8)r;
+        atomicMin((ull *)&lo_s[r], (ull)off);
+        atomicMax((ull *)&hi_s[r], (ull)(off + weight[v]));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < G; i += blockDim.x)
+        if (hi_s[i]) { atomicMin((ull *)&rank_lo[i], (ull)lo_s[i]); atomicMax((ull *)&rank_hi[i], (ull)hi_s[i]); }
 }
 
 }  // namespace
@@ -690,8 +707,13 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     KC_TRY(scope.alloc(&cur, (2 * KC_USH + 4) * KC_USTRIDE));
     ShLists L{};
     const int QW = W + 2, EW = 4 + 2 * W;
-    // expected: ~0.5 records and ~0.8 queries per k-mer at 8 ranks, fewer at 2 or 4; an overflow doubles the lists and repeats the sweep
-    u64 rec_scap = (N_local - N_local / 4) / KC_USH + 4096, qry_scap = N_local / KC_USH + 4096;
+    // List capacities from the expected counts (+15 %): a candidate leaves its source's block ~12 % of the time and is then
+    // remote with probability (G-1)/G; a port with a remote candidate needs a record, every remote candidate a query.  (At 2
+    // ranks that is ~0.5 records and ~0.55 queries per k-mer, at 8 ranks ~0.8 and ~1.0 -- 40 and 8(W+2) bytes each, the
+    // largest temporaries of the rank.)  An overflow doubles the lists and repeats the sweep, collectively.
+    const double p_rem = 0.12 * (double)(G - 1) / (double)G, keep4 = (1 - p_rem) * (1 - p_rem) * (1 - p_rem) * (1 - p_rem);
+    u64 rec_scap = (u64)(1.15 * 2.0 * (1.0 - keep4) * (double)N_local) / KC_USH + 4096;
+    u64 qry_scap = (u64)(1.15 * 8.0 * p_rem * (double)N_local) / KC_USH + 4096;
     const int stage_words = (int)(((u64)1 << set->bshift) / 8 + 1);
     const unsigned cgrid = kc_grid8(rcap, KC_CHOOSE_SLOTS);
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
@@ -802,18 +824,20 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         for (int lpass = 0;; ++lpass) {
             const u64 ntiles = (rcap + 2047) / 2048;
             u64 *tcount = nullptr;
+            unsigned short *emasks = nullptr;
             KC_TRY(scope.alloc(&tcount, ntiles + 2));
+            KC_TRY(scope.alloc(&emasks, ntiles * 256));
             hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
-                               (const u64 *)nullptr, tcount);
+                               (const u64 *)nullptr, tcount, emasks);
             KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
             KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
             if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
             KC_TRY(scope.alloc(&entries, n_ent + 1));
             hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
-                               (const u64 *)tcount, entries);
+                               (const u64 *)tcount, entries, emasks);
             KC_HIP(ctx, hipGetLastError());
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            scope.release(tcount);
+            scope.release(tcount); scope.release(emasks);
             KC_TRY(scope.alloc(&f_exit, n_ent + 1)); KC_TRY(scope.alloc(&f_partner, n_ent + 1)); KC_TRY(scope.alloc(&f_len, n_ent + 1));
             KC_TRY(scope.alloc(&f_stream, n_ent + 1));
             FragRec frec{};
