@@ -156,14 +156,14 @@ __global__ void __launch_bounds__(256) kc_shard_qdest_kernel(const u64 *__restri
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) dest[t] = (u8)(qry[t * (W + 2) + W] / rcap);
 }
-// the owner's side: queries {key, home} -> slot (global) or KC_NONE64
+// the owner's side: queries {key} -> slot (global) or KC_NONE64
 template <int W>
 __global__ void __launch_bounds__(256) kc_shard_answer_kernel(SetView<W> set, const u64 *__restrict__ q, u64 n, u64 *ans) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     Key<W> key;
-    for (int w = 0; w < W; ++w) key.w[w] = q[t * (W + 1) + w];
-    ans[t] = set_find_from(set, key, key_place_hash(key), q[t * (W + 1) + W]);
+    for (int w = 0; w < W; ++w) key.w[w] = q[t * W + w];
+    ans[t] = set_find(set, key);
 }
 template <int W>
 __global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restrict__ qry, const u64 *__restrict__ ans, u64 n, u64 *rec) {
@@ -756,7 +756,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         KcRoute rt;
         KC_TRY(kcr_build(c, dest, nq, &rt));
         u64 *rq = nullptr, *ans = nullptr, *ansb = nullptr;
-        int rc = kcr_forward(c, rt, qc, W + 1, QW, &rq);
+        int rc = kcr_forward(c, rt, qc, W, QW, &rq);   // only the key travels: the owner derives the home (one minimizer pass, ~2 ms per 1e9 queries)
         if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
         if (rc == KC_OK && rt.n_recv)
             hipLaunchKernelGGL((kc_shard_answer_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, ans);
