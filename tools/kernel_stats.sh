@@ -1,8 +1,7 @@
 #!/bin/bash
-# per-kernel times of one benchmark configuration with the fragment contraction on (KC_FRAG=1)
+# per-kernel times (top of the rocprofv3 summary) of one benchmark configuration: tools/kernel_stats.sh [bench flags]
 set -u
-R=$(pwd); OUT=$R/gpurun_out/frag_stats; rm -rf $OUT; mkdir -p $OUT
-export KC_FRAG=1
+R=$(pwd); OUT=$R/gpurun_out/kernel_stats; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cli "$@" > $OUT/bench.log 2>&1
 rm -f $OUT/*/*_kernel_trace.csv
