@@ -203,7 +203,8 @@ int kcp_to_sparse(kc_simplitigs *s, kc_simplitigs **out);
 int kcp_insert_simplitig_kmers(kc_set *set, kc_simplitigs *s);
 // kc_overlap.hip
 struct KcPathDev { u64 V = 0; u64 *edge_from = nullptr; u8 *overlaps = nullptr; u64 *pred = nullptr; u64 repairs = 0; };
-int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out);
+struct kc_comm;
+int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out, kc_comm *comm = nullptr);   // comm: keys of a level divided among the ranks
 void kco_path_release(kc_ctx *ctx, KcPathDev *p);
 // kc_emit.hip
 struct KcRank { u64 V = 0; u64 *dist = nullptr, *endv = nullptr, *weight = nullptr; u64 start = 0, L = 0; };

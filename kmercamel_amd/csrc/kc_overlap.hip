@@ -18,6 +18,7 @@
 // Levels without hits (almost all d > log4 V) cost two streaming kernels.
 #include <chrono>
 #include "kc_internal.h"
+#include "kc_comm.h"
 #include "kc_overlap_logic.h"
 #include "kc_overlap_lds.h"
 
@@ -88,13 +89,20 @@ __global__ void __launch_bounds__(256) ov_init_kernel(const u64 *__restrict__ fi
     actS[v] = v; actP[v] = v; eidx[v] = KC_NONE64;
 }
 
+// Hash-sharded flow: the overlap keys of a level are divided among the G ranks by their hash (a bucket = all suffix / prefix
+// vertices with one key, so every bucket is replayed by exactly one rank); the ranks exchange the edges they found (see
+// overlap_path_w).  G == 1: everything is ours.
+template <int W> __device__ __forceinline__ bool ov_key_is_ours(const Key<W> &key, u32 G, u32 me) {
+    return G <= 1 || (u32)(((key_hash(key) >> 32) * (u64)G) >> 32) == me;
+}
 template <int W>
 __global__ void __launch_bounds__(256) ov_insert_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
-                                                               const u64 *__restrict__ pre, int k, int d, u64 *pslot) {
+                                                               const u64 *__restrict__ pre, int k, int d, u64 *pslot, u32 G, u32 me) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nP) return;
     u64 j = actP[i];
     Key<W> key = key_prefix(load_key<W>(pre, j), k, d);
+    if (!ov_key_is_ours(key, G, me)) { pslot[i] = KC_NONE64; return; }
     u64 s = level_insert(t, key, j, pre, k, d);
     atomicAnd(&t.flags[s], ~1u);
     pslot[i] = s;
@@ -133,14 +141,14 @@ __device__ __forceinline__ void ov_list_hit(u8 hit, u64 v, u64 *hit_count, u64 *
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, const u64 *__restrict__ actS, u64 nS,
                                                               const u64 *__restrict__ suf, const u64 *__restrict__ pre, int k, int d,
-                                                              int complements, u8 *hitS, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
+                                                              int complements, u8 *hitS, u64 *hit_count, u64 *hit_list, u64 hit_cap, u32 G, u32 me) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u8 hit = 0;
     u64 v = 0;
     if (i < nS) {
         v = actS[i];
         Key<W> key = key_suffix(load_key<W>(suf, v), d);
-        u64 s = level_find(t, key, pre, k, d);
+        u64 s = ov_key_is_ours(key, G, me) ? level_find(t, key, pre, k, d) : KC_NONE64;
         if (s != KC_NONE64) {
             atomicAnd(&t.flags[s], ~2u);
             if (is_representative(key, d, complements)) hit = 1;
@@ -157,7 +165,7 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u8 hit = 0;
     if (i < nP) {
-        if (!(t.flags[pslot[i]] & 2u)) {
+        if (pslot[i] != KC_NONE64 && !(t.flags[pslot[i]] & 2u)) {   // (KC_NONE64: the key belongs to another rank)
             Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
             if (is_representative(key, d, complements)) hit = 1;
         }
@@ -327,6 +335,15 @@ __global__ void __launch_bounds__(256) ov_clear_cov_kernel(const u64 *__restrict
 }
 
 
+// hash-sharded flow: the edges the other ranks found at this level (log entries outside [own_lo, own_hi))
+__global__ void __launch_bounds__(256) ov_apply_remote_kernel(const u64 *__restrict__ ne, u64 n, u64 own_lo, u64 own_hi, int d, u64 *edge_from, u8 *overlaps,
+                                                              u64 *pred) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || (t >= own_lo && t < own_hi)) return;
+    const u64 x = ne[t * 5], y = ne[t * 5 + 1];
+    edge_from[x] = y; overlaps[x] = (u8)d; pred[y] = x;
+}
+
 template <bool SUFFIX>
 __global__ void __launch_bounds__(256) ov_still_active_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ edge_from,
                                                               const u64 *__restrict__ pred, u8 *keep) {
@@ -471,9 +488,16 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
     return KC_OK;
 }
 
-template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out) {
+template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out, kc_comm *comm) {
     kc_ctx *ctx = s->ctx;
     KcScope scope(ctx);
+    // Hash-sharded flow (comm with more than one rank): every rank holds all vertices, but the KEYS of a level are divided by
+    // hash -- a rank builds the level table, finds the hits and replays the buckets of its keys only, then the ranks
+    // all-gather the edges they logged and apply the others'; verification, repair and the shrinking of the active lists run
+    // on the combined log, identically everywhere.  Exactness is untouched: buckets of one level never shared state except
+    // through the verified path ends (that is what the verify / repair step is for), whether they run on one GPU or on eight.
+    const bool split = comm && comm->world > 1 && !lower_bound && !getenv("KC_SHARD_REPLICATE_PHASE2");
+    const u32 PG = split ? (u32)comm->world : 1u, pme = split ? (u32)comm->rank : 0u;
     const int k = s->k;
     const u64 S = s->n, V = S * (complements ? 2 : 1);
     if (S == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
@@ -545,8 +569,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
     }
 
-    KC_HIP(ctx, hipHostMalloc((void **)&hp, 128, hipHostMallocDefault));
-    w.h_flag = hp + 15;   // (the level loop reads back at most 9 words)
+    KC_HIP(ctx, hipHostMalloc((void **)&hp, 512, hipHostMallocDefault));
+    w.h_flag = hp + 15;   // (the level loop reads back at most 9 words; hp[32..] are staging words of the sharded flow)
+    u64 *ne_all = nullptr;
+    if (split) KC_TRY(scope.alloc(&ne_all, V * 10 + 10));
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
         g.d = d;
         const bool trace = getenv("KC_OV_TRACE") != nullptr;
@@ -555,22 +581,26 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         if (trace) { (void)hipStreamSynchronize(ctx->stream); t_level = now_us(); }
         // 1. bucket: cnt[1] = suffix hits, cnt[3] = prefix hits
         u64 lcap = 64;
-        while (lcap < 2 * nP + 16) lcap <<= 1;
+        const u64 tab_keys = split ? nP / PG + nP / (4 * PG) + 512 : nP;   // (our share of the keys, with room for an uneven split)
+        while (lcap < 2 * tab_keys + 16) lcap <<= 1;
         tab.mask = lcap - 1;
         tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
         KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
         cnt = fresh_cnt();
         hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
-                           (const u64 *)pre, k, d, pslot);
+                           (const u64 *)pre, k, d, pslot, PG, pme);
         hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
-                           (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS);
+                           (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
         hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                            (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
         KC_TRY(read_back(ctx, hp, cnt, 4));
         const u64 nHS = hp[1], nHP = hp[3];
+        const bool local_any = !(nHS == 0 || nHP == 0);
+        // (sharded flow: whether any rank has hits shows in the all-gather of the edge counts below -- one collective per level)
+        const bool any = local_any || split;
         if (trace) t_hits = now_us();
-        if ((nHS == 0 || nHP == 0) && trace) fprintf(stderr, "[ov] d=%d nS=%llu no hits: %.0f us\n", d, (unsigned long long)nS, t_hits - t_level);
-        if (nHS == 0 || nHP == 0) continue;   // no key seen from both sides at this overlap length
+        if (!any && trace) fprintf(stderr, "[ov] d=%d nS=%llu no hits: %.0f us\n", d, (unsigned long long)nS, t_hits - t_level);
+        if (!any) continue;   // no key seen from both sides at this overlap length
         // 2. compact the hits (ordered; the counts are already known) ...
         // 3. ... and sort them by key (stable: ids ascending inside a key).  Few hits: the probe kernels have listed them
         // already (unordered); one workgroup derives the keys and sorts the rows by (key, id) in LDS.
@@ -586,14 +616,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 hipLaunchKernelGGL((ov_small_sort_kernel<W, 2>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
                                    (const u64 *)pre, k, d, keys_o, ids_o);
         };
-        if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
+        if (!local_any) { /* nothing of ours at this level: only the exchange below */ }
+        else if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
         else {
             KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
             hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
                                (const u64 *)suf, k, d, hs_keys);
             KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
         }
-        if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
+        if (!local_any) { }
+        else if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
         else {
             KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, nP));
             hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
@@ -622,9 +654,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             // few hits (late levels: a handful of buckets hold everything that is left): even small buckets get a wavefront
             // and LDS; many hits (tens of thousands of tiny buckets): those stay with one thread each
             g.lds_min = (u32)((nHS + nHP <= 32768 && !getenv("KC_LDS_MIN")) ? 4 : lds_min);
-            hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
-                               (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8, huge, huge_cap, cnt + 9);
-            {
+            if (local_any) {
+                hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
+                                   (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8, huge, huge_cap, cnt + 9);
                 u64 nblk = (nHS + nHP) / (u64)g.lds_min + 1;
                 if (nblk > big_cap) nblk = big_cap;
                 hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
@@ -636,36 +668,65 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                                        (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)huge, huge_cap, (const u64 *)(cnt + 9));
                 }
             }
-            if (!lower_bound)
-                hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
-                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
-            KC_HIP(ctx, hipGetLastError());
-            KC_TRY(read_back(ctx, hp, cnt, 9));
-            nNew = hp[0];
-            const u64 covered = hp[2];
+            const u64 *LOG = ne;   // the log the verification works on, and the counter block whose word 0 holds its length
+            u64 *CNT = cnt;
+            u64 covered = 0;
+            if (!split) {
+                if (!lower_bound)
+                    hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
+                                       (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
+                KC_HIP(ctx, hipGetLastError());
+                KC_TRY(read_back(ctx, hp, cnt, 9));
+                nNew = hp[0];
+                covered = hp[2];
+            } else {
+                // the ranks' logs are concatenated in rank order (the same everywhere); the others' edges are applied here
+                u64 nloc = 0, counts[64], off_mine = 0;
+                KC_HIP(ctx, hipGetLastError());
+                if (local_any) { KC_TRY(read_back(ctx, hp, cnt, 9)); nloc = hp[0]; }
+                KC_TRY(kcc_allgather_words(comm, &nloc, counts, 1));
+                nNew = 0;
+                for (u32 r = 0; r < PG; ++r) { if (r == pme) off_mine = nNew; nNew += counts[r]; }
+                if (nNew) {
+                    u64 so[64], sc[64], ro[64], rcv[64], a = 0;
+                    for (u32 r = 0; r < PG; ++r) { so[r] = 0; sc[r] = nloc * 40; ro[r] = a * 40; rcv[r] = counts[r] * 40; a += counts[r]; }
+                    KC_TRY(kcc_alltoallv(comm, ne, so, sc, ne_all, ro, rcv));
+                    hipLaunchKernelGGL(ov_apply_remote_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne_all, nNew, off_mine,
+                                       off_mine + nloc, d, edge_from, overlaps, pred);
+                    CNT = fresh_cnt();
+                    hp[32] = nNew;
+                    KC_HIP(ctx, hipMemcpyAsync(CNT, hp + 32, 8, hipMemcpyHostToDevice, ctx->stream));
+                    LOG = ne_all;
+                    hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
+                                       (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, CNT + 2);
+                    KC_HIP(ctx, hipGetLastError());
+                    KC_TRY(read_back(ctx, hp + 40, CNT, 3));
+                    covered = hp[42];
+                }
+            }
             if (nNew == 0 || lower_bound) break;
             if (covered == nNew) {
-                hipLaunchKernelGGL((ov_fix_kernel<true>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
-                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
-                hipLaunchKernelGGL(ov_clear_cov_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, cov);
+                hipLaunchKernelGGL((ov_fix_kernel<true>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
+                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, CNT + 2);
+                hipLaunchKernelGGL(ov_clear_cov_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, cov);
                 break;
             }
             // a cycle slipped through a stale path-end test: blacklist its earliest closing event, undo, replay
             ++repairs;
             if (h_bl.size() / 2 >= BL_MAX) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap repair list exhausted");
-            hipLaunchKernelGGL(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, eidx);
-            KC_HIP(ctx, hipMemsetAsync(cnt + 4, 0, 32, ctx->stream));
-            KC_HIP(ctx, hipMemsetAsync(cnt + 5, 0xff, 8, ctx->stream));
-            hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew,
-                               (const u64 *)first_snap, (const u64 *)eidx, (const u8 *)cov, cnt + 4);
-            hipLaunchKernelGGL(ov_pick_event_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, cnt + 4);
-            KC_TRY(read_back(ctx, hp, cnt + 4, 4));
+            hipLaunchKernelGGL(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, eidx);
+            KC_HIP(ctx, hipMemsetAsync(CNT + 4, 0, 32, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(CNT + 5, 0xff, 8, ctx->stream));
+            hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew,
+                               (const u64 *)first_snap, (const u64 *)eidx, (const u8 *)cov, CNT + 4);
+            hipLaunchKernelGGL(ov_pick_event_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, CNT + 4);
+            KC_TRY(read_back(ctx, hp, CNT + 4, 4));
             if (!hp[0]) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap verification failed without a cycle");
             h_bl.push_back(hp[2]); h_bl.push_back(hp[3]);
             KC_HIP(ctx, hipMemcpyAsync(bl, h_bl.data(), h_bl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             g.nbl = h_bl.size() / 2;
-            hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nNew, edge_from, overlaps, pred,
+            hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, edge_from, overlaps, pred,
                                eidx, cov);
         }
         if (trace) {
@@ -702,11 +763,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     return KC_OK;
 }
 
-int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out) {
+int kco_overlap_path_device(kc_simplitigs *s, int complements, int lower_bound, KcPathDev *out, kc_comm *comm) {
     switch (s->W) {
-        case 1: return overlap_path_w<1>(s, complements, lower_bound, out);
-        case 2: return overlap_path_w<2>(s, complements, lower_bound, out);
-        default: return overlap_path_w<4>(s, complements, lower_bound, out);
+        case 1: return overlap_path_w<1>(s, complements, lower_bound, out, comm);
+        case 2: return overlap_path_w<2>(s, complements, lower_bound, out, comm);
+        default: return overlap_path_w<4>(s, complements, lower_bound, out, comm);
     }
 }
 void kco_path_release(kc_ctx *ctx, KcPathDev *p) {

@@ -1066,7 +1066,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     KC_HIP(ctx, hipEventRecord(e2, ctx->stream));
     // ---------------- phase 2 (replicated) and the path ranking of phase 3
     KcPathDev path;
-    KC_TRY(kco_overlap_path_device(simp, complements, 0, &path));
+    KC_TRY(kco_overlap_path_device(simp, complements, 0, &path, c));
     struct PathGuard { kc_ctx *c; KcPathDev *p; ~PathGuard() { kco_path_release(c, p); } } pathg{ctx, &path};
     KC_HIP(ctx, hipEventRecord(e3, ctx->stream));
     KcRank rk;
