@@ -346,8 +346,12 @@ __global__ void __launch_bounds__(256) kc_shard_ans_jump_kernel(const u64 *__res
                                                                 const u64 *__restrict__ last, u64 *ans) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    // two words: {successor, distance}; a fragment that has reached its chain's end sends the final fragment in place of the
+    // successor, marked by bit 63 (ids use 46 bits)
     const u64 g = KC_GID_IDX(req[t]);
-    ans[3 * t] = nxt[g]; ans[3 * t + 1] = dist[g]; ans[3 * t + 2] = last[g];
+    const u64 nx = nxt[g];
+    ans[2 * t] = nx == KC_NONE64 ? (last[g] | ((u64)1 << 63)) : nx;
+    ans[2 * t + 1] = dist[g];
 }
 __global__ void __launch_bounds__(256) kc_shard_apply_port_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ ans, u64 *nxt) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,9 +361,11 @@ __global__ void __launch_bounds__(256) kc_shard_apply_jump_kernel(const u64 *__r
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 e = act[t];
-    nxt[e] = ans[3 * t];
-    dist[e] += ans[3 * t + 1];
-    if (ans[3 * t] == KC_NONE64) last[e] = ans[3 * t + 2];
+    const u64 a = ans[2 * t];
+    const bool ended = (a >> 63) != 0;
+    nxt[e] = ended ? KC_NONE64 : a;
+    dist[e] += ans[2 * t + 1];
+    if (ended) last[e] = a & ~((u64)1 << 63);
 }
 
 // ---- cycles.  K-mers all of whose ports are matched and that no entry reaches lie on cycles inside this rank: they are
@@ -906,7 +912,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             if (round > 0) prev_active = tot_act;
             u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
             u8 *dest = nullptr;
-            const int A = round == 0 ? 1 : 3;
+            const int A = round == 0 ? 1 : 2;
             KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
             if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, round == 0 ? 1 : 0, 2 * rcap, req, dest);
             KcRoute rt;
