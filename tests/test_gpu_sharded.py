@@ -72,12 +72,15 @@ def test_ranks_emit_one_identical_superstring_random_reads(ctx, tmp_path, world)
 
 @pytest.mark.parametrize("k", [23, 63, 127])
 def test_ranks_wide_keys_and_branching_reads(ctx, tmp_path, k):
-    """overlapping reads from both strands with errors: branch ports, chains that span many reads"""
+    """overlapping reads from both strands with errors: branch ports, chains that span many reads; phase 2 with the overlap
+    keys divided among the ranks (default) and with every rank doing all of it (KC_SHARD_REPLICATE_PHASE2=1)"""
     recs = [r for r in gen.stress_reads(genome_len=30000, n_reads=600, read_len=max(200, 2 * k), seed=k, n_frac=0.002, lower_frac=0.05) if len(r) >= k]
     fa = str(tmp_path / "in.fa")
     write_fasta(fa, recs)
-    got = run_ranks(2, fa, k, "bi", str(tmp_path / "out.npy"))
-    assert np.array_equal(got, single(ctx, fa, k, True))
+    want = single(ctx, fa, k, True)
+    for world, env in ((2, None), (3, None), (2, {"KC_SHARD_REPLICATE_PHASE2": "1"})):
+        got = run_ranks(world, fa, k, "bi", str(tmp_path / "out.npy"), extra_env=env)
+        assert np.array_equal(got, want), (world, env)
 
 
 @pytest.mark.parametrize("world,k,mode", [(2, 31, "bi"), (3, 31, "uni"), (4, 23, "bi"), (2, 63, "bi")])
