@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
                                                       u64 *big, u64 big_cap, u64 *big_count, u64 *huge, u64 huge_cap, u64 *huge_count) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHS) return;
+    if (g.abort2 && (g.abort2[0] | g.abort2[1])) return;   // a bucketed sort overflowed: the host redoes the level's sorts
     Key<W> key = load_key<W>(hsk, t);
     if (t > 0 && key_eq(load_key<W>(hsk, t - 1), key)) return;
     // bucket ends by binary search (a linear scan is one dependent global load per member: 0.3 ms for the single bucket of d = 0)
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(64) ov_match_lds_kernel(OvArgs g, const u64 *_
     extern __shared__ __attribute__((aligned(16))) unsigned char kc_lds[];
     u64 nb = *big_count;
     if (nb > big_cap) nb = big_cap;
-    if ((u64)blockIdx.x >= nb) return;
+    if ((u64)blockIdx.x >= nb) return;   // (no descriptors when the match kernel stood down: abort2)
     const u64 *dsc = big + (u64)blockIdx.x * 5;
     kc_match_bucket_lds(g, hsv + dsc[0], (u32)(dsc[1] - dsc[0]), hpv + dsc[2], (u32)(dsc[3] - dsc[2]), (int)dsc[4], kc_lds);
 }
@@ -440,8 +441,12 @@ __global__ void __launch_bounds__(1024) ov_small_sort_kernel(const u64 *__restri
 }
 
 // stable sort of n rows (W-word keys, 2*d significant bits) with their ids; outputs in keys_out / ids_out
+// side (0 suffix / 1 prefix) selects the overflow word of the bucketed sort; *bucketed tells the caller that the result is only
+// valid if that word is still zero (it is read back together with the match counters: no sync of its own);
+// allow_bucketed = false: the LSD sort right away
 static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, int d, u64 *keys_out, u64 *ids_out, u64 *s0, u64 *s1,
-                     u64 *s2, u64 *s3) {
+                     u64 *s2, u64 *s3, int side, bool allow_bucketed, bool *bucketed) {
+    *bucketed = false;
     kc_ctx *ctx = w.ctx;
     int total_bits = 2 * d;
     if (total_bits == 0) {
@@ -463,13 +468,10 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
     }
     // mid-size and large lists: one MSD bucket pass + one-workgroup LDS sorts (4 launches); skewed keys overflow a bucket and
     // take the LSD radix sort below (5 launches per 4 key bits) instead
-    if (!getenv("KC_NO_BUCKET_SORT")) {
-        const int brc = kcu_sort_rows_bucketed(ctx, keys, ids, n, W, total_bits, keys_out, ids_out, w.d_flag);
-        if (brc == KC_OK) {
-            KC_HIP(ctx, hipMemcpyAsync(w.h_flag, w.d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (*w.h_flag == 0) return KC_OK;
-        } else if (brc != KC_E_ARG) return brc;
+    if (allow_bucketed && !getenv("KC_NO_BUCKET_SORT")) {
+        const int brc = kcu_sort_rows_bucketed(ctx, keys, ids, n, W, total_bits, keys_out, ids_out, w.d_flag + side);
+        if (brc == KC_OK) { *bucketed = true; return KC_OK; }
+        if (brc != KC_E_ARG) return brc;
     }
     if (W == 1) return kcu_sort_pairs(ctx, keys, keys_out, ids, ids_out, n, 0, total_bits, false);
     u64 *perm = s0, *perm2 = s1, *kw = s2, *kw2 = s3;
@@ -530,7 +532,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     const u64 BL_MAX = 4096;
     KC_TRY(scope.alloc(&bl, BL_MAX * 2));
     KC_TRY(scope.alloc(&w.d_num, 4));
-    w.d_flag = w.d_num + 2;
+    w.d_flag = w.d_num + 2;   // two words: overflow of the suffix-side / prefix-side bucketed sort of the current level
     u64 *big = nullptr;
     int lds_min = KC_LDS_MIN;
     if (const char *e = getenv("KC_LDS_MIN")) { int v = atoi(e); if (v >= 2 && v <= KC_LDS_MAX) lds_min = v; }
@@ -561,7 +563,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     g.S = S; g.V = V; g.batch = V / 16 + 1; g.complements = complements; g.lower_bound = lower_bound;
     g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
     g.first_snap = first_snap; g.last_snap = last_snap;
-    g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0; g.lds_min = (u32)lds_min;
+    g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0; g.lds_min = (u32)lds_min; g.abort2 = nullptr;
     u64 nS = V, nP = V, repairs = 0, tag_base = 0;
     std::vector<u64> h_bl;
     if (!lower_bound) {   // tag 0xffffffff = written by nobody
@@ -616,13 +618,17 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 hipLaunchKernelGGL((ov_small_sort_kernel<W, 2>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
                                    (const u64 *)pre, k, d, keys_o, ids_o);
         };
+        // a bucketed sort that overflows (skewed keys) leaves its flag word set and its output void; the match kernels then
+        // stand down, the flag comes back with their counters, and the side is sorted again by the LSD sort (no sync of its own)
+        bool bkS = false, bkP = false;
+        KC_HIP(ctx, hipMemsetAsync(w.d_flag, 0, 16, ctx->stream));
         if (!local_any) { /* nothing of ours at this level: only the exchange below */ }
         else if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
         else {
             KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
             hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
                                (const u64 *)suf, k, d, hs_keys);
-            KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3));
+            KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3, 0, true, &bkS));
         }
         if (!local_any) { }
         else if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
@@ -630,7 +636,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, nP));
             hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
                                (const u64 *)pre, k, d, hp_keys);
-            KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3));
+            KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3, 1, true, &bkP));
         }
         KC_HIP(ctx, hipGetLastError());
         if (trace) { (void)hipStreamSynchronize(ctx->stream); t_sorted = now_us(); }
@@ -654,6 +660,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             // few hits (late levels: a handful of buckets hold everything that is left): even small buckets get a wavefront
             // and LDS; many hits (tens of thousands of tiny buckets): those stay with one thread each
             g.lds_min = (u32)((nHS + nHP <= 32768 && !getenv("KC_LDS_MIN")) ? 4 : lds_min);
+            g.abort2 = (bkS || bkP) ? w.d_flag : nullptr;
+            // after a read-back that carried the overflow words (hp[16], hp[17]): sort the overflowed side(s) again, LSD this time
+            auto resort_overflowed = [&]() -> int {
+                bool dummy;
+                if (hp[16]) KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3, 0, false, &dummy));
+                if (hp[17]) KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3, 1, false, &dummy));
+                KC_HIP(ctx, hipMemsetAsync(w.d_flag, 0, 16, ctx->stream));
+                bkS = bkP = false;
+                return KC_OK;
+            };
             if (local_any) {
                 hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
                                    (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8, huge, huge_cap, cnt + 9);
@@ -676,14 +692,21 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                     hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
                                        (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
                 KC_HIP(ctx, hipGetLastError());
+                if (bkS || bkP) KC_HIP(ctx, hipMemcpyAsync(hp + 16, w.d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
                 KC_TRY(read_back(ctx, hp, cnt, 9));
+                if ((bkS || bkP) && (hp[16] | hp[17])) { KC_TRY(resort_overflowed()); continue; }   // (nothing was logged: the kernels stood down)
                 nNew = hp[0];
                 covered = hp[2];
             } else {
                 // the ranks' logs are concatenated in rank order (the same everywhere); the others' edges are applied here
                 u64 nloc = 0, counts[64], off_mine = 0;
                 KC_HIP(ctx, hipGetLastError());
-                if (local_any) { KC_TRY(read_back(ctx, hp, cnt, 9)); nloc = hp[0]; }
+                if (local_any) {
+                    if (bkS || bkP) KC_HIP(ctx, hipMemcpyAsync(hp + 16, w.d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
+                    KC_TRY(read_back(ctx, hp, cnt, 9));
+                    if ((bkS || bkP) && (hp[16] | hp[17])) { KC_TRY(resort_overflowed()); continue; }   // (local redo: no collective was entered yet)
+                    nloc = hp[0];
+                }
                 KC_TRY(kcc_allgather_words(comm, &nloc, counts, 1));
                 nNew = 0;
                 for (u32 r = 0; r < PG; ++r) { if (r == pme) off_mine = nNew; nNew += counts[r]; }

@@ -36,6 +36,7 @@ struct OvArgs {
     const u64 *first_snap; const u64 *last_snap;  // exact path ends at the start of the level
     u64 *ne;            // new-edge log: 5 words per edge {x, y, event_u, event_c, part}
     u64 *ne_count;
+    const u64 *abort2;  // two device words (or null): non-zero = the sorted hit lists are void (a bucketed sort overflowed): do nothing
     const u64 *bl;      // blacklist of (u, c) pairs proven to close a cycle
     u64 nbl;
     u32 tag_base = 0;   // first writer tag of the current launch (tags are never reused between launches)
