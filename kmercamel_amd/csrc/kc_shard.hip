@@ -1049,7 +1049,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             if (bits <= 0) break;
             if (bits > 64) bits = 64;
             hipLaunchKernelGGL(kc_shard_row_word_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, 3 + word, kw);
-            KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, S, 0, bits));
+            KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, S, 0, bits, false));   // (no sync of its own: everything below queues behind it)
             std::swap(perm, perm2);
         }
         KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
@@ -1058,8 +1058,8 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         hipLaunchKernelGGL(kc_shard_simp_fill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, W, k, simp->lens, nw,
                            simp->firstK, simp->lastK, fin, idx);
         KC_HIP(ctx, hipGetLastError());
-        KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S));                       // woff[S] = words in total
-        KC_TRY(kcu_sort_pairs(ctx, fin, fin_sorted, idx, fin_simp, S, 0, 64));     // final fragment id -> simplitig
+        KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S, false));                       // woff[S] = words in total
+        KC_TRY(kcu_sort_pairs(ctx, fin, fin_sorted, idx, fin_simp, S, 0, 46, false));     // final fragment id (46 bits) -> simplitig
         u64 wsum = 0;
         KC_TRY(read_words(ctx, simp->woff + S, &wsum, 1));
         simp->nwords = wsum; simp->total_bases = N + S * (u64)(k - 1);
