@@ -239,6 +239,24 @@ def test_overlap_hit_lists_bucketed_sort_and_its_fallback(ctx, oracle, k, monkey
         got.close()
 
 
+def test_sampled_path_ranking_equals_pointer_jumping(ctx, monkeypatch):
+    """Phase 3 ranks the path by pointer jumping over all vertices (small inputs) or over sampled splitters with one walk per
+    segment (from 2^20 vertices on; KC_SAMPLED_RANK_MIN=0 forces it): both must place every block at the same offset --
+    read sets (thousands of short blocks), a few long records (one-vertex paths among them) and both strand modes."""
+    cases = [gen.random_joined(4000, 300, seed=31), gen.random_joined(3, 20000, seed=32),
+             np.concatenate([gen.random_joined(500, 90, seed=33), np.array([10], dtype=np.uint8), gen.random_joined(1, 50000, seed=34)])]
+    for seq in cases:
+        for k in (31, 63):
+            for complements in (True, False):
+                a = kc.compute(ctx, seq, k, complements, want_mask=True)
+                want = a.strings(want_mask=True); a.close()
+                monkeypatch.setenv("KC_SAMPLED_RANK_MIN", "0")
+                b = kc.compute(ctx, seq, k, complements, want_mask=True)
+                got = b.strings(want_mask=True); b.close()
+                monkeypatch.delenv("KC_SAMPLED_RANK_MIN")
+                assert got == want, (len(seq), k, complements)
+
+
 def test_result_write_mem_equals_copy(ctx):
     """kc_result_write_mem (pinned chunks moved on by several threads; what the CLI fills its output mapping with) gives the
     bytes of kc_result_copy, for the superstring and for the -M mask, at a size beyond one 32 MB chunk."""
