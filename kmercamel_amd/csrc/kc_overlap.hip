@@ -174,6 +174,70 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
     ov_list_hit(hit, hit ? actP[i] : 0, hit_count, hit_list, hit_cap);
 }
 
+// ---- levels d >= 16 through ONE table (large inputs).  A hit at level d >= 16 needs the first 16 bases of the prefix to
+// equal the 16 bases of the suffix vertex's k-mer that start k-d from its end, so one table of the prefix ends' first
+// 16-mers (built once; equal 16-mers chained through `next`) serves every such level: a level is then one sweep over the
+// active suffixes (window lookup, exact d-mer compare with the few chained candidates) instead of table fill + 5e6 CAS
+// inserts + probe sweep + flag sweep.  Most of these levels have no hit at all.  Same hit sets as the per-level table.
+struct T16 { u64 *key; u32 *head; u32 *next; u64 mask; };   // key: the 16-mer (32 bits), ~0 = empty; head / next: 0xffffffff = none
+#define KC_T16_CHAIN_MAX 64   /* longer chains (a 16-mer shared by many simplitig ends): the level falls back to its own table */
+template <int W>
+__global__ void __launch_bounds__(256) ov_t16_build_kernel(T16 t, const u64 *__restrict__ pre, u64 V, int k) {
+    const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const u64 k16 = key_prefix(load_key<W>(pre, v), k, 16).w[0] & 0xffffffffull;
+    u64 s = kc_mix64(k16) & t.mask;
+    while (true) {
+        u64 cur = __hip_atomic_load(&t.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == ~(u64)0) { const u64 prev = atomicCAS((ull *)&t.key[s], ~0ULL, (ull)k16); cur = prev == ~(u64)0 ? k16 : prev; }
+        if (cur == k16) break;
+        s = (s + 1) & t.mask;
+    }
+    t.next[v] = atomicExch(&t.head[s], (u32)v);
+}
+template <int W>
+__global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__restrict__ actS, u64 nS, const u64 *__restrict__ suf, const u64 *__restrict__ pre,
+                                                         const u64 *__restrict__ pred, int k, int d, int complements, u8 *hitS, u32 *markP, u64 *cnt, u64 *hs_list,
+                                                         u64 *hp_list, u64 hit_cap, u32 G, u32 me) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u8 hit = 0;
+    u64 u = 0;
+    if (i < nS) {
+        u = actS[i];
+        const Key<W> key = key_suffix(load_key<W>(suf, u), d);
+        if (ov_key_is_ours(key, G, me)) {
+            const u64 k16 = key_prefix(key, d, 16).w[0] & 0xffffffffull;
+            u64 s = kc_mix64(k16) & t.mask;
+            u64 cur;
+            while ((cur = t.key[s]) != ~(u64)0 && cur != k16) s = (s + 1) & t.mask;
+            if (cur == k16) {
+                const bool rep = is_representative(key, d, complements);
+                bool found = false;
+                int steps = 0;
+                for (u32 v = t.head[s]; v != 0xffffffffu; v = t.next[v]) {
+                    if (++steps > KC_T16_CHAIN_MAX) { cnt[4] = 1; break; }
+                    if (pred[v] != KC_NONE64) continue;   // no longer an active prefix vertex
+                    if (!key_eq(key_prefix(load_key<W>(pre, v), k, d), key)) continue;
+                    found = true;
+                    if (rep && atomicExch(&markP[v], 1u) == 0u) {   // first suffix to reach this prefix vertex: list it
+                        const u64 pos = atomicAdd((ull *)(cnt + 3), 1ULL);
+                        if (pos < hit_cap) hp_list[pos] = v;
+                    }
+                }
+                hit = (found && rep) ? 1 : 0;
+            }
+        }
+        hitS[i] = hit;
+    }
+    ov_list_hit(hit, u, cnt + 1, hs_list, hit_cap);
+}
+
+// hitP (by position in actP) from the per-vertex marks of ov_probe16_kernel: only needed when the prefix hits outgrow their list
+__global__ void __launch_bounds__(256) ov_marks_to_hits_kernel(const u64 *__restrict__ actP, u64 nP, const u32 *__restrict__ markP, u8 *hitP) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nP) hitP[i] = markP[actP[i]] ? 1 : 0;
+}
+
 template <int W, bool SUFFIX>
 __global__ void __launch_bounds__(256) ov_hit_keys_kernel(const u64 *__restrict__ ids, u64 n, const u64 *__restrict__ ends, int k, int d,
                                                           u64 *keys) {
@@ -559,6 +623,23 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                        pre, suf, edge_from, overlaps, pred, first, last, first_snap, last_snap, actS, actP, eidx);
     KC_HIP(ctx, hipGetLastError());
 
+    // the 16-mer table of the prefix ends for the levels d >= 16 (large inputs; KC_T16_MIN = vertex count from which it is used)
+    T16 t16{};
+    u32 *markP = nullptr;
+    u64 t16_min = (u64)1 << 16;
+    if (const char *e = getenv("KC_T16_MIN")) { const long long v = atoll(e); if (v >= 0) t16_min = (u64)v; }
+    const bool t16_on = k - 1 >= 16 && V >= t16_min && V < ((u64)1 << 32) - 1;
+    if (t16_on) {
+        u64 c16 = 64;
+        while (c16 < 2 * V + 16) c16 <<= 1;
+        t16.mask = c16 - 1;
+        KC_TRY(scope.alloc(&t16.key, c16)); KC_TRY(scope.alloc(&t16.head, c16)); KC_TRY(scope.alloc(&t16.next, V)); KC_TRY(scope.alloc(&markP, V));
+        KC_HIP(ctx, hipMemsetAsync(t16.key, 0xff, c16 * 8, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(t16.head, 0xff, c16 * 4, ctx->stream));
+        KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
+        hipLaunchKernelGGL((ov_t16_build_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)pre, V, k);
+        KC_HIP(ctx, hipGetLastError());
+    }
     OvArgs g;
     g.S = S; g.V = V; g.batch = V / 16 + 1; g.complements = complements; g.lower_bound = lower_bound;
     g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
@@ -582,20 +663,38 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         double t_level = 0, t_hits = 0, t_sorted = 0, t_matched = 0;
         if (trace) { (void)hipStreamSynchronize(ctx->stream); t_level = now_us(); }
         // 1. bucket: cnt[1] = suffix hits, cnt[3] = prefix hits
-        u64 lcap = 64;
-        const u64 tab_keys = split ? nP / PG + nP / (4 * PG) + 512 : nP;   // (our share of the keys, with room for an uneven split)
-        while (lcap < 2 * tab_keys + 16) lcap <<= 1;
-        tab.mask = lcap - 1;
-        tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
-        KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
-        cnt = fresh_cnt();
-        hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
-                           (const u64 *)pre, k, d, pslot, PG, pme);
-        hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
-                           (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
-        hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
-                           (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
-        KC_TRY(read_back(ctx, hp, cnt, 4));
+        auto own_table_probe = [&]() -> int {   // the level builds a table of its own prefix keys
+            u64 lcap = 64;
+            const u64 tab_keys = split ? nP / PG + nP / (4 * PG) + 512 : nP;   // (our share of the keys, with room for an uneven split)
+            while (lcap < 2 * tab_keys + 16) lcap <<= 1;
+            tab.mask = lcap - 1;
+            tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
+            KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
+            cnt = fresh_cnt();
+            hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
+                               (const u64 *)pre, k, d, pslot, PG, pme);
+            hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
+                               (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
+            hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
+                               (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
+            KC_TRY(read_back(ctx, hp, cnt, 4));
+            return KC_OK;
+        };
+        if (t16_on && d >= 16) {
+            // one sweep over the active suffixes through the 16-mer table of the prefix ends (see ov_probe16_kernel)
+            cnt = fresh_cnt();
+            hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, nS, (const u64 *)suf,
+                               (const u64 *)pre, (const u64 *)pred, k, d, complements, hitS, markP, cnt, hs_ids, hp_ids, (u64)KC_SMALL_ROWS, PG, pme);
+            KC_TRY(read_back(ctx, hp, cnt, 5));
+            if (hp[4]) {   // a chain beyond the limit (repetitive ends): this level takes the table of its own
+                KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
+                KC_TRY(own_table_probe());
+            } else if (hp[3]) {
+                if (hp[3] > KC_SMALL_ROWS || getenv("KC_NO_SMALL_SORT"))   // (the ordered compaction of the prefix hits reads hitP)
+                    hipLaunchKernelGGL(ov_marks_to_hits_kernel, dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP, (const u32 *)markP, hitP);
+                KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
+            }
+        } else KC_TRY(own_table_probe());
         const u64 nHS = hp[1], nHP = hp[3];
         const bool local_any = !(nHS == 0 || nHP == 0);
         // (sharded flow: whether any rank has hits shows in the all-gather of the edge counts below -- one collective per level)

@@ -239,6 +239,31 @@ def test_overlap_hit_lists_bucketed_sort_and_its_fallback(ctx, oracle, k, monkey
         got.close()
 
 
+@pytest.mark.parametrize("k", [23, 31, 63])
+def test_high_levels_through_the_16mer_table(ctx, k, monkeypatch):
+    """Levels d >= 16 of phase 2 run through one table of the prefix ends' first 16-mers from 2^16 vertices on
+    (KC_T16_MIN=0 forces it, a huge value turns it off): same bytes on read sets with overlapping reads (many hits at high
+    levels), and on ends that share their first 16 bases thousands of times (chains beyond the limit: those levels fall
+    back to a table of their own)."""
+    rng = np.random.default_rng(900 + k)
+    stem = rng.integers(0, 4, size=40)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rep = []
+    for _ in range(400):   # 400 records that all start with the same 40 bases
+        rep.append(acgt[np.concatenate([stem, rng.integers(0, 4, size=k + 20)])])
+        rep.append(np.array([10], dtype=np.uint8))
+    repetitive = np.concatenate(rep)[:-1]
+    reads = np.frombuffer("\n".join(r.decode() for r in gen.stress_reads(30000, 900, max(150, 2 * k), seed=k, n_frac=0.0, lower_frac=0.0)).encode(), dtype=np.uint8)
+    for seq in (reads, repetitive):
+        for complements in (True, False):
+            monkeypatch.setenv("KC_T16_MIN", "1000000000000")
+            a = kc.compute(ctx, seq, k, complements); want = a.array().copy(); a.close()
+            monkeypatch.setenv("KC_T16_MIN", "0")
+            b = kc.compute(ctx, seq, k, complements); got = b.array().copy(); b.close()
+            monkeypatch.delenv("KC_T16_MIN")
+            assert np.array_equal(got, want), (k, complements, len(seq))
+
+
 def test_sampled_path_ranking_equals_pointer_jumping(ctx, monkeypatch):
     """Phase 3 ranks the path by pointer jumping over all vertices (small inputs) or over sampled splitters with one walk per
     segment (from 2^20 vertices on; KC_SAMPLED_RANK_MIN=0 forces it): both must place every block at the same offset --
