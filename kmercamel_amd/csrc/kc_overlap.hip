@@ -219,9 +219,14 @@ __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__res
                     if (pred[v] != KC_NONE64) continue;   // no longer an active prefix vertex
                     if (!key_eq(key_prefix(load_key<W>(pre, v), k, d), key)) continue;
                     found = true;
-                    if (rep && atomicExch(&markP[v], 1u) == 0u) {   // first suffix to reach this prefix vertex: list it
-                        const u64 pos = atomicAdd((ull *)(cnt + 3), 1ULL);
-                        if (pos < hit_cap) hp_list[pos] = v;
+                    if (rep && atomicExch(&markP[v], 1u) == 0u) {   // first suffix to reach this prefix vertex
+                        // few hits (the usual case at these levels): list and count them here.  Many (overlapping reads): one add per
+                        // hit on one word would serialise at ~12 ns each, so past the list's capacity only a flag is raised and the
+                        // host counts the marks in a sweep of their own (ov_marks_to_hits_kernel).
+                        if (__hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hit_cap) {
+                            const u64 pos = atomicAdd((ull *)(cnt + 3), 1ULL);
+                            if (pos < hit_cap) hp_list[pos] = v;
+                        } else cnt[5] = 1;
                     }
                 }
                 hit = (found && rep) ? 1 : 0;
@@ -232,10 +237,15 @@ __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__res
     ov_list_hit(hit, u, cnt + 1, hs_list, hit_cap);
 }
 
-// hitP (by position in actP) from the per-vertex marks of ov_probe16_kernel: only needed when the prefix hits outgrow their list
-__global__ void __launch_bounds__(256) ov_marks_to_hits_kernel(const u64 *__restrict__ actP, u64 nP, const u32 *__restrict__ markP, u8 *hitP) {
+// hitP (by position in actP) and the exact number of prefix hits from the per-vertex marks of ov_probe16_kernel: only needed
+// when the prefix hits outgrow their list
+__global__ void __launch_bounds__(256) ov_marks_to_hits_kernel(const u64 *__restrict__ actP, u64 nP, const u32 *__restrict__ markP, u8 *hitP, u64 *count,
+                                                               u64 *hp_list, u64 hit_cap) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nP) hitP[i] = markP[actP[i]] ? 1 : 0;
+    u8 hit = 0;
+    u64 v = 0;
+    if (i < nP) { v = actP[i]; hit = markP[v] ? 1 : 0; hitP[i] = hit; }
+    ov_list_hit(hit, v, count, hp_list, hit_cap);
 }
 
 template <int W, bool SUFFIX>
@@ -685,13 +695,19 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             cnt = fresh_cnt();
             hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, nS, (const u64 *)suf,
                                (const u64 *)pre, (const u64 *)pred, k, d, complements, hitS, markP, cnt, hs_ids, hp_ids, (u64)KC_SMALL_ROWS, PG, pme);
-            KC_TRY(read_back(ctx, hp, cnt, 5));
+            KC_TRY(read_back(ctx, hp, cnt, 6));
             if (hp[4]) {   // a chain beyond the limit (repetitive ends): this level takes the table of its own
                 KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
                 KC_TRY(own_table_probe());
             } else if (hp[3]) {
-                if (hp[3] > KC_SMALL_ROWS || getenv("KC_NO_SMALL_SORT"))   // (the ordered compaction of the prefix hits reads hitP)
-                    hipLaunchKernelGGL(ov_marks_to_hits_kernel, dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP, (const u32 *)markP, hitP);
+                if (hp[5] || hp[3] >= KC_SMALL_ROWS || getenv("KC_NO_SMALL_SORT")) {
+                    // many prefix hits: their exact number and hitP (read by the ordered compaction) come from a sweep over the marks
+                    u64 *c2 = fresh_cnt();
+                    hipLaunchKernelGGL(ov_marks_to_hits_kernel, dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP, (const u32 *)markP, hitP,
+                                       c2, hp_ids, (u64)KC_SMALL_ROWS);
+                    KC_TRY(read_back(ctx, hp + 48, c2, 1));
+                    hp[3] = hp[48];
+                }
                 KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
             }
         } else KC_TRY(own_table_probe());
