@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
 // active suffixes (window lookup, exact d-mer compare with the few chained candidates) instead of table fill + 5e6 CAS
 // inserts + probe sweep + flag sweep.  Most of these levels have no hit at all.  Same hit sets as the per-level table.
 struct T16 { u64 *key; u32 *head; u32 *next; u64 mask; };   // key: the 16-mer (32 bits), ~0 = empty; head / next: 0xffffffff = none
-#define KC_T16_CHAIN_MAX 64   /* longer chains (a 16-mer shared by many simplitig ends): the level falls back to its own table */
+#define KC_T16_CHAIN_MAX 16   /* longer chains (a 16-mer shared by many simplitig ends): this and the later levels build tables of their own */
 template <int W>
 __global__ void __launch_bounds__(256) ov_t16_build_kernel(T16 t, const u64 *__restrict__ pre, u64 V, int k) {
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -639,6 +639,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u64 t16_min = (u64)1 << 16;
     if (const char *e = getenv("KC_T16_MIN")) { const long long v = atoll(e); if (v >= 0) t16_min = (u64)v; }
     const bool t16_on = k - 1 >= 16 && V >= t16_min && V < ((u64)1 << 32) - 1;
+    bool t16_dead = false;
     if (t16_on) {
         u64 c16 = 64;
         while (c16 < 2 * V + 16) c16 <<= 1;
@@ -690,13 +691,14 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             KC_TRY(read_back(ctx, hp, cnt, 4));
             return KC_OK;
         };
-        if (t16_on && d >= 16) {
+        if (t16_on && !t16_dead && d >= 16) {
             // one sweep over the active suffixes through the 16-mer table of the prefix ends (see ov_probe16_kernel)
             cnt = fresh_cnt();
             hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, nS, (const u64 *)suf,
                                (const u64 *)pre, (const u64 *)pred, k, d, complements, hitS, markP, cnt, hs_ids, hp_ids, (u64)KC_SMALL_ROWS, PG, pme);
             KC_TRY(read_back(ctx, hp, cnt, 6));
-            if (hp[4]) {   // a chain beyond the limit (repetitive ends): this level takes the table of its own
+            if (hp[4]) {   // a chain beyond the limit (repetitive ends; chains never shrink): this level and the later ones take tables of their own
+                t16_dead = true;
                 KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
                 KC_TRY(own_table_probe());
             } else if (hp[3]) {
