@@ -410,6 +410,23 @@ __global__ void __launch_bounds__(256) ov_clear_cov_kernel(const u64 *__restrict
 }
 
 
+// the 64 shards of the new-edge log -> the dense log `ne`; cnt[0] = number of entries (what the verification kernels read)
+__global__ void __launch_bounds__(256) ov_gather_log_kernel(const u64 *__restrict__ ne_sh, const u64 *__restrict__ shcur, u64 shcap, u64 *ne, u64 *cnt) {
+    __shared__ u64 pre[65];
+    if (threadIdx.x == 0) {
+        u64 a = 0;
+        for (int s = 0; s < 64; ++s) { u64 c = shcur[s * 16]; if (c > shcap) c = shcap; pre[s] = a; a += c; }
+        pre[64] = a;
+    }
+    __syncthreads();
+    const int sh = blockIdx.y;
+    const u64 n = (pre[sh + 1] - pre[sh]) * 5;
+    const u64 *src = ne_sh + (u64)sh * shcap * 5;
+    u64 *dst = ne + pre[sh] * 5;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) cnt[0] = pre[64];
+}
+
 // hash-sharded flow: the edges the other ranks found at this level (log entries outside [own_lo, own_hi))
 __global__ void __launch_bounds__(256) ov_apply_remote_kernel(const u64 *__restrict__ ne, u64 n, u64 own_lo, u64 own_hi, int d, u64 *edge_from, u8 *overlaps,
                                                               u64 *pred) {
@@ -656,6 +673,12 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
     g.first_snap = first_snap; g.last_snap = last_snap;
     g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0; g.lds_min = (u32)lds_min; g.abort2 = nullptr;
+    // sharded new-edge log (see ov_add_event): every shard could hold a whole level's edges of an evenly spread load four times over
+    u64 *ne_sh = nullptr, *ne_shcur = nullptr;
+    const u64 ne_shcap = (2 * V) / 16 + 1024;
+    const bool log_sharded = V >= ((u64)1 << 16) && !getenv("KC_NO_SHARDED_LOG");
+    if (log_sharded) { KC_TRY(scope.alloc(&ne_sh, 64 * ne_shcap * 5)); KC_TRY(scope.alloc(&ne_shcur, 65 * 16)); }
+    g.ne_sh = nullptr; g.ne_shcur = ne_shcur; g.ne_shcap = ne_shcap;
     u64 nS = V, nP = V, repairs = 0, tag_base = 0;
     std::vector<u64> h_bl;
     if (!lower_bound) {   // tag 0xffffffff = written by nobody
@@ -778,6 +801,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             // and LDS; many hits (tens of thousands of tiny buckets): those stay with one thread each
             g.lds_min = (u32)((nHS + nHP <= 32768 && !getenv("KC_LDS_MIN")) ? 4 : lds_min);
             g.abort2 = (bkS || bkP) ? w.d_flag : nullptr;
+            // many events (the mid levels of a read set): the log goes through 64 cursors and is gathered afterwards
+            const bool shlog = log_sharded && local_any && nHS >= 4096;
+            g.ne_sh = shlog ? ne_sh : nullptr;
+            if (shlog) KC_HIP(ctx, hipMemsetAsync(ne_shcur, 0, 65 * 16 * 8, ctx->stream));
             // after a read-back that carried the overflow words (hp[16], hp[17]): sort the overflowed side(s) again, LSD this time
             auto resort_overflowed = [&]() -> int {
                 bool dummy;
@@ -801,6 +828,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                                        (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)huge, huge_cap, (const u64 *)(cnt + 9));
                 }
             }
+            if (shlog) {
+                const u64 per_shard_blocks = (2 * nHS / 64 * 5) / (256 * 8) + 1;
+                hipLaunchKernelGGL(ov_gather_log_kernel, dim3((unsigned)(per_shard_blocks > 1024 ? 1024 : per_shard_blocks), 64), dim3(256), 0, ctx->stream,
+                                   (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, cnt);
+            }
             const u64 *LOG = ne;   // the log the verification works on, and the counter block whose word 0 holds its length
             u64 *CNT = cnt;
             u64 covered = 0;
@@ -810,7 +842,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                                        (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
                 KC_HIP(ctx, hipGetLastError());
                 if (bkS || bkP) KC_HIP(ctx, hipMemcpyAsync(hp + 16, w.d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
+                if (shlog) KC_HIP(ctx, hipMemcpyAsync(hp + 20, ne_shcur + 64 * 16, 8, hipMemcpyDeviceToHost, ctx->stream));
                 KC_TRY(read_back(ctx, hp, cnt, 9));
+                if (shlog && hp[20]) return kc_fail(ctx, KC_E_NO_DEVICE, "a shard of the new-edge log overflowed");
                 if ((bkS || bkP) && (hp[16] | hp[17])) { KC_TRY(resort_overflowed()); continue; }   // (nothing was logged: the kernels stood down)
                 nNew = hp[0];
                 covered = hp[2];
@@ -820,7 +854,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 KC_HIP(ctx, hipGetLastError());
                 if (local_any) {
                     if (bkS || bkP) KC_HIP(ctx, hipMemcpyAsync(hp + 16, w.d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
+                    if (shlog) KC_HIP(ctx, hipMemcpyAsync(hp + 20, ne_shcur + 64 * 16, 8, hipMemcpyDeviceToHost, ctx->stream));
                     KC_TRY(read_back(ctx, hp, cnt, 9));
+                    if (shlog && hp[20]) return kc_fail(ctx, KC_E_NO_DEVICE, "a shard of the new-edge log overflowed");
                     if ((bkS || bkP) && (hp[16] | hp[17])) { KC_TRY(resort_overflowed()); continue; }   // (local redo: no collective was entered yet)
                     nloc = hp[0];
                 }

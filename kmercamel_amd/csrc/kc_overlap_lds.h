@@ -205,9 +205,24 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
     const u32 nev = nev_shared;
     if (nev == 0) return;
     __shared__ u64 base_shared;
-    if (lane == 0) base_shared = atomicAdd((unsigned long long *)g.ne_count, (unsigned long long)nev * (bi ? 2 : 1));
+    __shared__ u64 *log_shared;
+    if (lane == 0) {
+        const u64 want = (u64)nev * (bi ? 2 : 1);
+        if (g.ne_sh) {   // sharded log (see ov_add_event)
+            const u32 sh = ((u32)blockIdx.x * 0x9E3779B1u) >> 26;   // (one bucket per workgroup)
+            const u64 pos = atomicAdd((unsigned long long *)&g.ne_shcur[sh * 16], (unsigned long long)want);
+            const bool fits = pos + want <= g.ne_shcap;
+            if (!fits) g.ne_shcur[64 * 16] = 1;
+            log_shared = fits ? g.ne_sh + ((u64)sh * g.ne_shcap + pos) * 5 : nullptr;
+            base_shared = 0;
+        } else {
+            base_shared = atomicAdd((unsigned long long *)g.ne_count, (unsigned long long)want);
+            log_shared = g.ne;
+        }
+    }
     __syncthreads();
     const u64 base = base_shared;
+    u64 *const logp = log_shared;
     for (u32 e = lane; e < nev; e += 64) {
         const u32 ev = b.evU[e], eidx = ev & 0x7fffffffu, ci = b.evC[e];
         const bool from2 = (ev >> 31) != 0;
@@ -215,12 +230,12 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
         const u64 c = from2 ? ov_mirror(b.A[ci], S) : b.B[ci];
         const u64 part = b.evPart[e];
         g.edge_from[u] = c; g.overlaps[u] = (u8)g.d; g.pred[c] = u;
-        u64 *le = g.ne + (base + (u64)e * (bi ? 2 : 1)) * 5;
-        le[0] = u; le[1] = c; le[2] = u; le[3] = c; le[4] = part;
+        u64 *le = logp ? logp + (base + (u64)e * (bi ? 2 : 1)) * 5 : nullptr;
+        if (le) { le[0] = u; le[1] = c; le[2] = u; le[3] = c; le[4] = part; }
         if (bi) {
             const u64 x2 = ov_mirror(c, S), y2 = ov_mirror(u, S);
             g.edge_from[x2] = y2; g.overlaps[x2] = (u8)g.d; g.pred[y2] = x2;
-            le[5] = x2; le[6] = y2; le[7] = u; le[8] = c; le[9] = part;
+            if (le) { le[5] = x2; le[6] = y2; le[7] = u; le[8] = c; le[9] = part; }
         }
     }
 }

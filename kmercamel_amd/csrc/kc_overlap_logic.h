@@ -36,6 +36,8 @@ struct OvArgs {
     const u64 *first_snap; const u64 *last_snap;  // exact path ends at the start of the level
     u64 *ne;            // new-edge log: 5 words per edge {x, y, event_u, event_c, part}
     u64 *ne_count;
+    u64 *ne_sh;         // sharded new-edge log (device replay only; null: log straight into ne): 64 shards of ne_shcap entries, cursors 16 words apart
+    u64 *ne_shcur; u64 ne_shcap;
     const u64 *abort2;  // two device words (or null): non-zero = the sorted hit lists are void (a bucketed sort overflowed): do nothing
     const u64 *bl;      // blacklist of (u, c) pairs proven to close a cycle
     u64 nbl;
@@ -92,17 +94,29 @@ KC_HD void ov_add_event(const OvArgs &g, u64 u, u64 c, u64 firstU, u64 part, u32
         lastY2 = ((u32)(l3 >> 32) == tag) ? (l3 & 0xffffffffull) : s3;
     }
     u64 pos = 0;
+    u64 *e = nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
-    pos = atomicAdd((unsigned long long *)g.ne_count, two ? 2ULL : 1ULL);
+    if (g.ne_sh) {
+        // one add per event on ONE word serialises at ~12 ns (5e5 events of a level: several ms): the log is written through 64
+        // cursors (the bucket's tag picks one) and gathered into the dense log afterwards (ov_gather_log_kernel)
+        const u32 sh = (tag * 0x9E3779B1u) >> 26;
+        pos = atomicAdd((unsigned long long *)&g.ne_shcur[sh * 16], two ? 2ULL : 1ULL);
+        e = pos + 2 <= g.ne_shcap ? g.ne_sh + ((u64)sh * g.ne_shcap + pos) * 5 : nullptr;
+        if (!e) g.ne_shcur[64 * 16] = 1;   // a shard ran full (cannot happen with the caller's sizing): the caller sees the flag
+    } else {
+        pos = atomicAdd((unsigned long long *)g.ne_count, two ? 2ULL : 1ULL);
+        e = g.ne + pos * 5;
+    }
 #else
     pos = *g.ne_count; *g.ne_count += two ? 2 : 1;
+    e = g.ne + pos * 5;
 #endif
     g.edge_from[u] = c; g.overlaps[u] = (u8)g.d; g.pred[c] = u;
     if (!g.lower_bound) {
         g.first[lastC] = ((u64)tag << 32) | firstU;
         g.last[firstU] = ((u64)tag << 32) | lastC;
     }
-    u64 *e = g.ne + pos * 5;
+    if (!e) return;
     e[0] = u; e[1] = c; e[2] = u; e[3] = c; e[4] = part;
     if (two) {
         g.edge_from[x2] = y2; g.overlaps[x2] = (u8)g.d; g.pred[y2] = x2;
