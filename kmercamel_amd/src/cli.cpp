@@ -152,28 +152,35 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
             WriteName(path, "greedy", k, false, !complements, hs);
             hdr = hs.str();
             om.cap = hdr.size() + (size_t)sti.st_size + 4096;
-            om.th = std::thread([&om, out_path] {
-                const int fd = ::open(out_path.c_str(), O_RDWR);
-                if (fd < 0) return;
-                if (::ftruncate(fd, (off_t)om.cap) != 0) { ::close(fd); return; }
-                void *m = ::mmap(nullptr, om.cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            const int fd = ::open(out_path.c_str(), O_RDWR);
+            if (fd >= 0 && ::ftruncate(fd, (off_t)om.cap) == 0) {
                 om.fd = fd;   // (from here on the destructor restores the empty file unless the result is committed)
-                if (m == MAP_FAILED) return;
-                om.map = static_cast<char *>(m);
-                const int T = 8;   // (page allocation scales less than linearly; 8 threads fault 2.6 GB in ~0.4 s)
-                auto part = [&](int t) {
-                    const size_t lo = (om.cap * (size_t)t / T) & ~(size_t)4095, hi = t + 1 == T ? om.cap : ((om.cap * (size_t)(t + 1) / T) & ~(size_t)4095);
+                void *m = ::mmap(nullptr, om.cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                if (m != MAP_FAILED) {
+                    om.map = static_cast<char *>(m);
+                    om.ok = true;
+                    // the pages are faulted in by eight threads, front of the file first (piece i goes to thread i mod 8), and
+                    // without changing a byte: the result may already be arriving in the front while the back is still being
+                    // populated (the copy then meets a populated page nearly everywhere, and simply faults where it does not)
+                    om.th = std::thread([&om] {
+                        const int T = 8;
+                        const size_t PIECE = (size_t)8 << 20;
+                        auto part = [&](int t) {
+                            for (size_t lo = (size_t)t * PIECE; lo < om.cap; lo += (size_t)T * PIECE) {
+                                const size_t hi = lo + PIECE < om.cap ? lo + PIECE : om.cap;
 #ifdef MADV_POPULATE_WRITE
-                    if (::madvise(om.map + lo, hi - lo, MADV_POPULATE_WRITE) == 0) return;
+                                if (::madvise(om.map + lo, hi - lo, MADV_POPULATE_WRITE) == 0) continue;
 #endif
-                    for (size_t p = lo; p < hi; p += 4096) reinterpret_cast<volatile char *>(om.map)[p] = 0;
-                };
-                std::vector<std::thread> th;
-                for (int t = 1; t < T; ++t) th.emplace_back(part, t);
-                part(0);
-                for (auto &x : th) x.join();
-                om.ok = true;
-            });
+                                for (size_t p = lo; p < hi; p += 4096) __atomic_fetch_or(om.map + p, (char)0, __ATOMIC_RELAXED);
+                            }
+                        };
+                        std::vector<std::thread> th;
+                        for (int t = 1; t < T; ++t) th.emplace_back(part, t);
+                        part(0);
+                        for (auto &x : th) x.join();
+                    });
+                }
+            } else if (fd >= 0) ::close(fd);
         }
     }
     Records recs;
@@ -257,10 +264,8 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     uint64_t st[16];
     kc_result_stats(res, st);
     if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
-    om.settle();
-    if (om.fd >= 0) mark("output mapping ready");
     const bool mapped = om.ok && hdr.size() + st[2] + 1 <= om.cap;
-    if (!mapped && om.fd >= 0) { if (om.map) { ::munmap(om.map, om.cap); om.map = nullptr; } if (::ftruncate(om.fd, 0) != 0) {} ::close(om.fd); om.fd = -1; }
+    if (!mapped && om.fd >= 0) { om.settle(); if (om.map) { ::munmap(om.map, om.cap); om.map = nullptr; } if (::ftruncate(om.fd, 0) != 0) {} ::close(om.fd); om.fd = -1; }
     if (!mapped) WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
@@ -281,6 +286,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         memcpy(om.map, hdr.data(), hdr.size());
         kcamd::check(kc_result_write_mem(res, om.map + hdr.size(), 0));
         mark("result in the mapping");
+        om.settle();   // (the populating threads are through, or nearly: every page has been touched by the copy)
         om.map[hdr.size() + st[2]] = '\n';   // main.cpp:210
         ::munmap(om.map, om.cap); om.map = nullptr;
         if (::ftruncate(om.fd, (off_t)(hdr.size() + st[2] + 1)) != 0) throw std::runtime_error("cannot size " + out_path);
