@@ -376,6 +376,55 @@ def test_full_size_properties_cfg1(ctx):
     a.close(); b.close()
 
 
+def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
+    """The shape real sequencing data has and the benchmark's i.i.d. reads do not: 10x coverage of a 5 Mbp genome by 150 bp
+    reads from both strands with 1 % substitution errors -- every k-mer many times over, millions of branch ports, overlaps
+    at every level from k-1 down, cycles.  ~2 * 10^7 distinct 31-mers: too many for the oracle, so (a) the oracle-free
+    properties (ones == N, length bounds, round trip of the k-mer set) and (b) byte-identity of the default device paths
+    with their alternatives (plain walk, per-level tables only, LSD sorts only, single-cursor edge log, plain path ranking)."""
+    rng = np.random.default_rng(20260)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    G, n_reads, rl, k = 5_000_000, 330_000, 150, 31
+    genome = rng.integers(0, 4, size=G, dtype=np.uint8)
+    pos = rng.integers(0, G - rl, size=n_reads)
+    codes = genome[pos[:, None] + np.arange(rl)[None, :]]
+    rev = rng.random(n_reads) < 0.5
+    codes[rev] = 3 - codes[rev][:, ::-1]
+    err = rng.random(codes.shape) < 0.01
+    codes[err] = (codes[err] + rng.integers(1, 4, size=int(err.sum()), dtype=np.uint8)) & 3
+    a = np.empty((n_reads, rl + 1), dtype=np.uint8)
+    a[:, :rl] = acgt[codes]
+    a[:, rl] = 10
+    seq = a.reshape(-1)[:-1].copy()
+    r = kc.compute(ctx, seq, k, True)
+    N, S, L = r.stats["n_kmers"], r.stats["n_simplitigs"], r.length
+    o = r.array().copy()
+    rounds = r.stats["matching_rounds"] if "matching_rounds" in r.stats else None
+    r.close()
+    assert 10_000_000 < N < 40_000_000 and S > 100_000          # genome k-mers + ~30 per error
+    assert N + k - 1 <= L <= N + S * (k - 1)
+    assert int(np.count_nonzero(o < 97)) == N
+    sa = kc.KmerSet(ctx, k, True, capacity_hint=len(seq)); sa.AddKMers(seq)
+    sb = kc.KmerSet(ctx, k, True, capacity_hint=len(o)); sb.AddKMers(o, case_sensitive=True)
+    assert sa.size() == N and sb.size() == N
+    ka, kb = _export_keys_np(sa), _export_keys_np(sb)
+    mix = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        assert int(ka.sum(dtype=np.uint64)) == int(kb.sum(dtype=np.uint64))
+        assert int(np.bitwise_xor.reduce(ka * mix)) == int(np.bitwise_xor.reduce(kb * mix))
+    sa.close(); sb.close()
+    for env in ({"KC_NOFRAG": "1"}, {"KC_T16_MIN": "1000000000000"}, {"KC_NO_BUCKET_SORT": "1"}, {"KC_NO_SHARDED_LOG": "1"},
+                {"KC_SAMPLED_RANK_MIN": "1000000000000"}, {"KC_SAMPLED_RANK_MIN": "0"}):
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
+        r2 = kc.compute(ctx, seq, k, True)
+        same = np.array_equal(r2.array(), o)
+        r2.close()
+        for name in env:
+            monkeypatch.delenv(name)
+        assert same, env
+
+
 def test_full_size_properties_cfg2(ctx):
     """BASELINE configs[2] at full size (2 500 000 records x 1 030 bp, k = 31: 2.5 * 10^9 k-mers, the set bench.py runs),
     through the same oracle-free properties as cfg1: determinism (two runs, identical bytes), ones == N (min-one mask),
