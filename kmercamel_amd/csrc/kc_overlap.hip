@@ -182,18 +182,21 @@ __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, co
 struct T16 { u64 *key; u32 *head; u32 *next; u64 mask; };   // key: the 16-mer (32 bits), ~0 = empty; head / next: 0xffffffff = none
 #define KC_T16_CHAIN_MAX 16   /* longer chains (a 16-mer shared by many simplitig ends): this and the later levels build tables of their own */
 template <int W>
-__global__ void __launch_bounds__(256) ov_t16_build_kernel(T16 t, const u64 *__restrict__ pre, u64 V, int k) {
+__global__ void __launch_bounds__(256) ov_t16_build_kernel(T16 t, const u64 *__restrict__ pre, u64 V, int k, u64 *distinct) {
     const u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= V) return;
-    const u64 k16 = key_prefix(load_key<W>(pre, v), k, 16).w[0] & 0xffffffffull;
-    u64 s = kc_mix64(k16) & t.mask;
-    while (true) {
-        u64 cur = __hip_atomic_load(&t.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == ~(u64)0) { const u64 prev = atomicCAS((ull *)&t.key[s], ~0ULL, (ull)k16); cur = prev == ~(u64)0 ? k16 : prev; }
-        if (cur == k16) break;
-        s = (s + 1) & t.mask;
+    u8 fresh = 0;   // this vertex brought a 16-mer the table did not have yet
+    if (v < V) {
+        const u64 k16 = key_prefix(load_key<W>(pre, v), k, 16).w[0] & 0xffffffffull;
+        u64 s = kc_mix64(k16) & t.mask;
+        while (true) {
+            u64 cur = __hip_atomic_load(&t.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == ~(u64)0) { const u64 prev = atomicCAS((ull *)&t.key[s], ~0ULL, (ull)k16); if (prev == ~(u64)0) { fresh = 1; cur = k16; } else cur = prev; }
+            if (cur == k16) break;
+            s = (s + 1) & t.mask;
+        }
+        t.next[v] = atomicExch(&t.head[s], (u32)v);
     }
-    t.next[v] = atomicExch(&t.head[s], (u32)v);
+    ov_list_hit(fresh, 0, distinct, nullptr, 0);   // number of distinct 16-mers: the host decides from it whether the table pays
 }
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__restrict__ actS, u64 nS, const u64 *__restrict__ suf, const u64 *__restrict__ pre,
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__res
                 bool found = false;
                 int steps = 0;
                 for (u32 v = t.head[s]; v != 0xffffffffu; v = t.next[v]) {
-                    if (++steps > KC_T16_CHAIN_MAX) { cnt[4] = 1; break; }
+                    if (++steps > KC_T16_CHAIN_MAX) { if (__hip_atomic_load(cnt + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) cnt[4] = 1; break; }
                     if (pred[v] != KC_NONE64) continue;   // no longer an active prefix vertex
                     if (!key_eq(key_prefix(load_key<W>(pre, v), k, d), key)) continue;
                     found = true;
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__res
                         if (__hip_atomic_load(cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hit_cap) {
                             const u64 pos = atomicAdd((ull *)(cnt + 3), 1ULL);
                             if (pos < hit_cap) hp_list[pos] = v;
-                        } else cnt[5] = 1;
+                        } else if (__hip_atomic_load(cnt + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) cnt[5] = 1;   // (millions of plain stores to one word serialise too)
                     }
                 }
                 hit = (found && rep) ? 1 : 0;
@@ -656,7 +659,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u64 t16_min = (u64)1 << 16;
     if (const char *e = getenv("KC_T16_MIN")) { const long long v = atoll(e); if (v >= 0) t16_min = (u64)v; }
     const bool t16_on = k - 1 >= 16 && V >= t16_min && V < ((u64)1 << 32) - 1;
-    bool t16_dead = false;
+    bool t16_dead = false;   // the table is not (or no longer) worth using
     if (t16_on) {
         u64 c16 = 64;
         while (c16 < 2 * V + 16) c16 <<= 1;
@@ -665,8 +668,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         KC_HIP(ctx, hipMemsetAsync(t16.key, 0xff, c16 * 8, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(t16.head, 0xff, c16 * 4, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
-        hipLaunchKernelGGL((ov_t16_build_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)pre, V, k);
+        u64 *dcnt = fresh_cnt();
+        hipLaunchKernelGGL((ov_t16_build_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)pre, V, k, dcnt);
         KC_HIP(ctx, hipGetLastError());
+        // ends that share their first 16 bases (coverage: many simplitigs begin inside the same stretch of genome) make every
+        // lookup compare several candidates exactly; measured, the per-level tables win from ~1.3 vertices per 16-mer on
+        u64 distinct = 0;
+        KC_HIP(ctx, hipMemcpyAsync(&distinct, dcnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (distinct * 13 < V * 10 && !getenv("KC_T16_FORCE")) t16_dead = true;
+        if (getenv("KC_OV_TRACE")) fprintf(stderr, "[ov] 16-mer table: %llu vertices, %llu distinct 16-mers -> %s\n", (unsigned long long)V, (unsigned long long)distinct, t16_dead ? "not used" : "used");
     }
     OvArgs g;
     g.S = S; g.V = V; g.batch = V / 16 + 1; g.complements = complements; g.lower_bound = lower_bound;
@@ -734,6 +745,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                     hp[3] = hp[48];
                 }
                 KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
+                // many hits at a high level (overlapping reads): every hit costs three scattered accesses here, and measured the
+                // per-level tables are ~3x faster on such data -- the later levels use them
+                if (hp[3] > V / 64 && !getenv("KC_T16_FORCE")) t16_dead = true;
             }
         } else KC_TRY(own_table_probe());
         const u64 nHS = hp[1], nHP = hp[3];

@@ -3,6 +3,7 @@
 // batched neighbour lookup of round 1.  See kc_simplitigs.hip for the algorithm.
 #pragma once
 #include "kc_internal.h"
+#include "kc_scan_dev.h"
 
 #define LK_OPEN 0ull
 #define LK_CHOICE 1ull

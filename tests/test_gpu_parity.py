@@ -259,8 +259,9 @@ def test_high_levels_through_the_16mer_table(ctx, k, monkeypatch):
             monkeypatch.setenv("KC_T16_MIN", "1000000000000")
             a = kc.compute(ctx, seq, k, complements); want = a.array().copy(); a.close()
             monkeypatch.setenv("KC_T16_MIN", "0")
+            monkeypatch.setenv("KC_T16_FORCE", "1")   # (also where the table would be judged not to pay: many ends per 16-mer)
             b = kc.compute(ctx, seq, k, complements); got = b.array().copy(); b.close()
-            monkeypatch.delenv("KC_T16_MIN")
+            monkeypatch.delenv("KC_T16_MIN"); monkeypatch.delenv("KC_T16_FORCE")
             assert np.array_equal(got, want), (k, complements, len(seq))
 
 
@@ -413,7 +414,7 @@ def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
         assert int(ka.sum(dtype=np.uint64)) == int(kb.sum(dtype=np.uint64))
         assert int(np.bitwise_xor.reduce(ka * mix)) == int(np.bitwise_xor.reduce(kb * mix))
     sa.close(); sb.close()
-    for env in ({"KC_NOFRAG": "1"}, {"KC_T16_MIN": "1000000000000"}, {"KC_NO_BUCKET_SORT": "1"}, {"KC_NO_SHARDED_LOG": "1"},
+    for env in ({"KC_NOFRAG": "1"}, {"KC_T16_MIN": "1000000000000"}, {"KC_T16_FORCE": "1"}, {"KC_NO_BUCKET_SORT": "1"}, {"KC_NO_SHARDED_LOG": "1"},
                 {"KC_SAMPLED_RANK_MIN": "1000000000000"}, {"KC_SAMPLED_RANK_MIN": "0"}):
         for name, value in env.items():
             monkeypatch.setenv(name, value)
