@@ -148,29 +148,31 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
 // directly. FILL = false counts the unreciprocated ports, FILL = true marks them LK_REJ and lists them.
 template <bool FILL>
 __global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, const u8 *__restrict__ tags, u64 cap, u64 *work_out, u64 *cursor) {
-    // a thread takes 8 slots (one 8-byte load of their tag bytes): the table is sized by k-mer OCCURRENCES, so inputs with
+    // a thread takes 32 slots (8-byte loads of their tag bytes): the table is sized by k-mer OCCURRENCES, so inputs with
     // coverage leave most slots empty and the sweep, not the work, was the cost (36 ms per 10^9 slots with one thread per slot)
-    const u64 slot0 = kc_gtid() * 8;
-    u32 m = 0;   // bit 2i+p: port p of slot0+i is an unreciprocated choice
-    if (slot0 < cap) {
+    const u64 slot0 = kc_gtid() * 32;   // 32 slots per thread: four 8-byte loads of tag bytes
+    u64 m = 0;   // bit 2i+p: port p of slot0+i is an unreciprocated choice
+    for (int g8 = 0; g8 < 4; ++g8) {
+        const u64 s8 = slot0 + 8 * (u64)g8;
+        if (s8 >= cap) break;
         u64 tg = 0;
-        if (slot0 + 8 <= cap) tg = *reinterpret_cast<const u64 *>(tags + slot0);
-        else for (u64 i = 0; slot0 + i < cap; ++i) tg |= (u64)tags[slot0 + i] << (8 * i);
+        if (s8 + 8 <= cap) tg = *reinterpret_cast<const u64 *>(tags + s8);
+        else for (u64 i = 0; s8 + i < cap; ++i) tg |= (u64)tags[s8 + i] << (8 * i);
         for (int i = 0; tg != 0 && i < 8; ++i) {
             if (!((tg >> (8 * i)) & 0xff)) continue;
             for (int port = 0; port < 2; ++port) {
-                const u64 pid = ((slot0 + (u64)i) << 1) | (u64)port;
+                const u64 pid = ((s8 + (u64)i) << 1) | (u64)port;
                 u64 w = link[pid];
                 if (LK_STATE(w) != LK_CHOICE) continue;
                 u64 wt = link[LK_PID(w)];   // only LK_REJ bits change concurrently
                 if (LK_STATE(wt) == LK_CHOICE && LK_PID(wt) == pid) continue;
-                m |= 1u << (2 * i + port);
+                m |= (u64)1 << (16 * g8 + 2 * i + port);
             }
         }
     }
-    u64 pos = kc_block_reserve((u32)__popc(m), cursor);   // (branching inputs list 10^7 ports here: one add per workgroup, not per port)
+    u64 pos = kc_block_reserve((u32)__popcll(m), cursor);   // (branching inputs list 10^7 ports here: one add per workgroup, not per port)
     if (FILL)
-        for (int j = 0; m != 0 && j < 16; ++j)
+        for (int j = 0; m != 0 && j < 64; ++j)
             if ((m >> j) & 1) { const u64 pid = (slot0 << 1) + (u64)j; atomicOr((ull *)&link[pid], (ull)LK_REJ); work_out[pos++] = pid; }
 }
 
@@ -198,24 +200,26 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
 template <int W, bool FILL>
 __global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, u64 *heads,
                                                        u64 *cursor) {
-    const u64 slot0 = kc_gtid() * 8;   // 8 slots per thread, found through one load of their tag bytes (see kc_mutual_scan_kernel)
-    u32 m = 0;   // bit 2i+o: (slot0+i, o) is a head
-    if (slot0 < set.cap) {
+    const u64 slot0 = kc_gtid() * 32;   // 32 slots per thread, found through four loads of their tag bytes (see kc_mutual_scan_kernel)
+    u64 m = 0;   // bit 2i+o: (slot0+i, o) is a head
+    const int no = complements ? 2 : 1;
+    for (int g8 = 0; g8 < 4; ++g8) {
+        const u64 s8 = slot0 + 8 * (u64)g8;
+        if (s8 >= set.cap) break;
         u64 tg = 0;
-        if (slot0 + 8 <= set.cap) tg = *reinterpret_cast<const u64 *>(set.tags + slot0);
-        else for (u64 i = 0; slot0 + i < set.cap; ++i) tg |= (u64)set.tags[slot0 + i] << (8 * i);
-        const int no = complements ? 2 : 1;
+        if (s8 + 8 <= set.cap) tg = *reinterpret_cast<const u64 *>(set.tags + s8);
+        else for (u64 i = 0; s8 + i < set.cap; ++i) tg |= (u64)set.tags[s8 + i] << (8 * i);
         for (int i = 0; tg != 0 && i < 8; ++i) {
             if (!((tg >> (8 * i)) & 0xff)) continue;
             for (int o = 0; o < no; ++o) {
-                u64 w = link[((slot0 + (u64)i) << 1) | (u64)(o == 0 ? 0 : 1)];
-                if (!LK_IS_MATCHED(w)) m |= 1u << (2 * i + o);
+                u64 w = link[((s8 + (u64)i) << 1) | (u64)(o == 0 ? 0 : 1)];
+                if (!LK_IS_MATCHED(w)) m |= (u64)1 << (16 * g8 + 2 * i + o);
             }
         }
     }
-    u64 pos = kc_block_reserve((u32)__popc(m), cursor);
+    u64 pos = kc_block_reserve((u32)__popcll(m), cursor);
     if (FILL)
-        for (int j = 0; m != 0 && j < 16; ++j)
+        for (int j = 0; m != 0 && j < 64; ++j)
             if ((m >> j) & 1) heads[pos++] = (slot0 << 1) + (u64)j;
 }
 
@@ -875,7 +879,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
         // kc_reject_kernel run may already have set are simply found again
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((cap + 7) / 8, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
         scope.release(work_a); scope.release(work_b);
@@ -883,7 +887,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&work_a, work_cap));
         KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((cap + 7) / 8, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap, work_a,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
@@ -909,12 +913,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<W, false>), kc_grid2((cap + 7) / 8, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+        hipLaunchKernelGGL((kc_heads_kernel<W, false>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                            (u64 *)nullptr, cnt);
         KC_TRY(read_u64(ctx, cnt, &nheads));
         KC_TRY(scope.alloc(&heads, nheads + 1));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<W, true>), kc_grid2((cap + 7) / 8, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
+        hipLaunchKernelGGL((kc_heads_kernel<W, true>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
                            cnt);
     }
     // ---- chain discovery.  Pass 0 works on the heads round 1..n produced.  K-mers on cycles (every port matched) are
