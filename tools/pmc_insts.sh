@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/pmc_insts}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY -d $R/$OUT -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_WAIT_ANY -d $R/$OUT -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-cli > /dev/null 2>&1
 cd $R
 python3 - "$OUT" <<'PY'
 import csv,collections,glob,sys
