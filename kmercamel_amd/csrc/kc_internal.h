@@ -59,7 +59,7 @@ int kcs_clean_table(const kc_set *s);   // kc_set.hip
 template <int W> static inline SetView<W> kc_view_raw(const kc_set *s) {
     const u64 rcap = s->rcap ? s->rcap : s->cap;
     return SetView<W>{s->keys - s->rlo * W, s->state ? s->state - s->rlo : nullptr, s->tags - s->rlo, s->cap, s->nblocks, s->bshift, s->mlen, s->k,
-                      s->local_probes, s->rlo, rcap};
+                      s->local_probes, s->rlo, rcap, s->complements};
 }
 // every kernel reaches the table through a view: this is where a deferred fill happens
 template <int W> static inline SetView<W> kc_view(const kc_set *s) {

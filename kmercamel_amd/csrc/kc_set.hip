@@ -158,6 +158,7 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
 // inserts the canonical k-mer (parser.h:44) of every window that holds k valid bases (and, if case_sensitive, whose
 // first base is upper case, parser.h:41-42).
 // kc_roll_kmers walks one thread's window run and hands every k-mer to `emit(key, minimizer hash, first position)`.
+static inline __host__ __device__ int kc_roll_win(int k, int m) { return (m && k - m - 1 >= 1) ? k - m - 1 : 1; }
 template <int W, typename F>
 __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len,
                                               int k, int complements, int case_sensitive, int m, int ppt, u32 *ring, F &&emit) {
@@ -169,15 +170,17 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
     u64 s = e0 >= (u64)(k - 1) ? e0 - (u64)(k - 1) : 0;
     Key<W> cur = key_zero<W>(), rc = key_zero<W>();
     int run = 0;
-    // minimizer = minimum of the last win = k-m+1 canonical m-mer hashes (one new hash per base).  Sliding minimum in O(1) per
+    // minimizer of the k-mer's MIDDLE (positions 1..k-2; kc_set_dev.h) = minimum of the win = k-m-1 canonical m-mer hashes that end
+    // before the current base (one new hash per base).  Sliding minimum in O(1) per
     // base (van Herk / Gil-Werman): the positions are cut into blocks of `win`; a window is a suffix of the previous block
     // plus a prefix of the current one, so it is min(suffix minimum stored when that block ended, running prefix minimum).
     // Per thread, in LDS (index j * blockDim + tid, conflict-free): raw[win] hashes of the current block, suf[win] suffix
     // minima of the previous one.  (For k = 127 the window has 113 hashes: scanning it per k-mer was most of the kernel.)
-    const int win = k - m + 1;
+    const int win = kc_roll_win(k, m);
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     u32 *raw = ring, *suf = ring + (size_t)win * blockDim.x;
     u32 pref = ~0u;
+    u32 prev_min = ~0u;   // minimum of the `win` m-mer hashes that end before the current base = those inside the middle of the k-mer ending here
     u64 cw = codes[s >> 5], bw = brk[s >> 6];
     u32 rj = 0;   // position inside the current block (a running counter: p % win would be a 64-bit division per base)
     for (u64 p = s; p < e1; ++p, rj = (rj + 1 == (u32)win) ? 0u : rj + 1) {
@@ -190,11 +193,6 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
             cur = key_append(cur, b, k);
             rc = key_prepend(rc, 3 - b, k);
             if (run < k) ++run;
-            if (m && run >= m) {
-                const u32 h = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
-                raw[rj * blockDim.x + threadIdx.x] = h;
-                pref = h < pref ? h : pref;
-            }
             if (p >= e0 && run >= k) {
                 bool keep = true;
                 if (case_sensitive) {
@@ -203,21 +201,26 @@ __device__ __forceinline__ void kc_roll_kmers(const u64 *__restrict__ codes, con
                 }
                 if (keep) {
                     const Key<W> &key = (!complements || key_lt(cur, rc)) ? cur : rc;
-                    u32 mmh = ~0u;
-                    if (m) {
-                        mmh = pref;
-                        if (rj + 1 < (u32)win) { const u32 sv = suf[(rj + 1) * blockDim.x + threadIdx.x]; mmh = sv < mmh ? sv : mmh; }
-                    }
-                    emit(key, mmh);
+                    emit(key, prev_min);
                 }
             }
+            if (m && run >= m) {
+                const u32 h = kc_mmer_hash((u32)cur.w[0] & maskm, (u32)key_shr(rc, 2 * (k - m)).w[0]);
+                raw[rj * blockDim.x + threadIdx.x] = h;
+                pref = h < pref ? h : pref;
+            }
         }
-        if (m && rj + 1 == (u32)win) {   // block complete: its suffix minima serve the windows of the next block
-            u32 acc = ~0u;
-            for (int i = win - 1; i >= 0; --i) {
-                const u32 h = raw[i * blockDim.x + threadIdx.x];
-                acc = h < acc ? h : acc;
-                suf[i * blockDim.x + threadIdx.x] = acc;
+        if (m) {
+            // window minimum of the `win` hashes ending HERE: prefix of the current block, suffix of the previous one
+            prev_min = pref;
+            if (rj + 1 < (u32)win) { const u32 sv = suf[(rj + 1) * blockDim.x + threadIdx.x]; prev_min = sv < prev_min ? sv : prev_min; }
+            if (rj + 1 == (u32)win) {   // block complete: its suffix minima serve the windows of the next block
+                u32 acc = ~0u;
+                for (int i = win - 1; i >= 0; --i) {
+                    const u32 h = raw[i * blockDim.x + threadIdx.x];
+                    acc = h < acc ? h : acc;
+                    suf[i * blockDim.x + threadIdx.x] = acc;
+                }
             }
         }
     }
@@ -235,11 +238,10 @@ __global__ void __launch_bounds__(256) kc_insert_kernel(const u64 *__restrict__ 
     bool overflow = false;
     const int m = set.m;
     kc_roll_kmers<W>(codes, brk, low, len, k, complements, case_sensitive, m, ppt, kc_ring, [&](const Key<W> &key, u32 mmh) {
-        const u64 kh = key_place_hash(key);
-        const u64 home = m ? set_block_home(set, mmh, kh) : kc_mulhi64(kc_mix64(kh), set.cap);
-        if (only_over && only_over[home >> set.bshift] <= over_limit) return;
+        const KcPlace pl = m ? set_place_mmh(set, key, mmh) : set_place(set, key);
+        if (only_over && only_over[pl.home >> set.bshift] <= over_limit) return;
         u64 slot;
-        int r = set_insert_at(set, key, kh, home, &slot);
+        int r = set_insert_at(set, key, pl, &slot);
         if (occ_counts && r >= 0) atomicAdd(&occ_counts[slot], 1u);   // AddKMersWithFrequencies (parser.h:51-85)
         if (r > 0) ++added;
         else if (r < 0) overflow = true;
@@ -263,7 +265,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
     // twice: count_only = 1 adds the run lengths to bcursor[block]; then, with boff = exclusive scan of those counts and the
     // cursors cleared, the keys land at boff[block] + position -- grouped by block, hence contiguous per owner rank.
     extern __shared__ u32 kc_ring[];
-    const int win = k - set.m + 1;
+    const int win = kc_roll_win(k, set.m);
     u64 *stage = reinterpret_cast<u64 *>(kc_ring + (size_t)2 * win * blockDim.x);   // stage[(j * W + w) * blockDim + tid]: keys of the open run
     const u64 bs = (u64)1 << set.bshift;
     u32 nrun = 0;
@@ -340,7 +342,6 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     u64 n;
     if (nseg) n = seg_pre[nseg];
     else { n = bcursor[blockIdx.x]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
-    const u32 span = set_block_span(set);
     u32 added = 0;
     for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
         Key<W> key;
@@ -352,8 +353,8 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         }
         for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
         const u64 top = key.w[W - 1];
-        const u64 ph = key_place_hash(key);
-        const u32 off = (u32)(((u64)(u32)ph * span) >> 32);
+        u32 off; u8 tag;
+        set_place_local(set, key, &off, &tag);
         bool done = false;
         u32 p = 0;
         while (p < set.local_probes && !done) {
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
             if (cur == ~(u64)0) {   // claimed: publish
                 for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                lt[s] = kc_tag_of(ph);
+                lt[s] = tag;
                 ++added;
                 done = true;
             } else if (cur == top) {
@@ -467,14 +468,14 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     KC_HIP(ctx, hipSetDevice(ctx->device));
     kc_set *s = new kc_set();
     s->ctx = ctx; s->k = k; s->W = kc_words_for_k(k); s->complements = complements ? 1 : 0;
-    s->mlen = k >= 16 ? 15 : 0;
+    s->mlen = kc_default_mlen(k);
     // slots per block: as large as the LDS of a CU allows for the bucketed build (128 KB of keys + the tags): 16384 / 8192 /
     // 4096 for 1 / 2 / 4 key words; large blocks keep the skewed minimizer popularity from overflowing them
     s->bshift = bucketed_max_bshift(s->W);
     if (s->W == 1) s->bshift = 13;   // 8192-slot blocks (72 KB of LDS): two build workgroups per CU overlap their load / insert / store
                                     // phases; measured +5 % end to end at 2.5 G k-mers, no difference at 100 M
-    if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v < k) ? v : 0; }   // tuning/ablation knobs
-    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= 20) s->bshift = v; }
+    if (const char *e = getenv("KC_MLEN")) { int v = atoi(e); s->mlen = (v > 0 && v <= 16 && v + 2 <= k) ? v : 0; }   // tuning/ablation knobs
+    if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= 15) s->bshift = v; }   // (the probe kernel stages a block's tags in LDS)
     if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) s->local_probes = (u32)v; }
     // target load 0.5 (shorter tag scans, measured 10 % faster neighbour probes) when table + links at that load
     // stay below 60 % of the device memory, else 0.66
@@ -573,7 +574,7 @@ static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, cons
     kc_ctx *ctx = set->ctx;
     int ppt = set->W == 1 ? 16 : (set->W == 2 ? 32 : 64);
     u64 nthreads = (len + ppt - 1) / ppt;
-    const int win = set->mlen ? set->k - set->mlen + 1 : 1;
+    const int win = kc_roll_win(set->k, set->mlen);
     const unsigned bs = win <= 32 ? 256 : (win <= 64 ? 128 : 64);    // LDS: 2 * win * bs * 4 bytes (<= 64 KB)
     const size_t lds = (size_t)win * bs * 4 * 2;   // raw + suffix-minimum arrays of kc_roll_kmers
     unsigned g = kc_grid(nthreads, bs);
@@ -606,7 +607,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_TRY(scope.alloc(&ovf, ovf_cap * W));
     KC_HIP(ctx, hipMemsetAsync(bcursor, 0, set->nblocks * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
-    const int win = set->k - set->mlen + 1;
+    const int win = kc_roll_win(set->k, set->mlen);
     // positions per thread: every thread first rolls over the k-1 bases before its range, so wide k wants long ranges
     // (every thread first rolls over the k - 1 bases before its range: longer ranges waste less of that, shorter ones give
     // small inputs more threads; measured at 2.5e9 31-mers: 64.0 / 60.5 / 59.2 ms for 16 / 32 / 64 positions)
@@ -676,24 +677,24 @@ static ShardGeom shard_geometry(int k, u64 occ, int world, double load) {
 // Host-side description of the partition (needs no GPU): out[0] = table blocks in total, [1] = log2 slots per block,
 // [2] = blocks per rank, [3] = first global slot of `rank`, [4] = slots per rank, [5] = minimizer length.
 extern "C" int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, uint64_t *out6) {
-    if (!out6 || k < 16 || k > 127 || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
+    if (!out6 || k < 17 || k > 127 || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
     const ShardGeom g = shard_geometry(k, total_occurrences, world, 0.5);
     out6[0] = g.nblocks; out6[1] = (u64)g.bshift; out6[2] = g.bpr; out6[3] = ((u64)rank * g.bpr) << g.bshift; out6[4] = g.bpr << g.bshift; out6[5] = (u64)g.mlen;
     return KC_OK;
 }
 // owner rank of n canonical k-mers (W words each): the rank that holds the table block of the k-mer's canonical minimizer
 template <int W> static void owner_of_w(int k, const ShardGeom &g, const u64 *keys, u64 n, u8 *owner) {
-    SetView<W> v{nullptr, nullptr, nullptr, g.nblocks << g.bshift, g.nblocks, g.bshift, g.mlen, k, g.local_probes, 0, g.nblocks << g.bshift};
+    SetView<W> v{nullptr, nullptr, nullptr, g.nblocks << g.bshift, g.nblocks, g.bshift, g.mlen, k, g.local_probes, 0, g.nblocks << g.bshift, 1};
     for (u64 i = 0; i < n; ++i) {
         Key<W> key;
         for (int w = 0; w < W; ++w) key.w[w] = keys[i * W + w];
-        const u64 home = set_block_home(v, key_min_mmh(key, k, g.mlen, 0, k - g.mlen), 0);
+        const u64 home = set_block_home(v, key_min_mmh(key, k, g.mlen, 1, k - g.mlen - 1), 0);
         owner[i] = (u8)((home >> g.bshift) / g.bpr);
     }
 }
 extern "C" int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner) {
     if ((!keys || !owner) && n) return KC_E_ARG;
-    if (k < 16 || k > 127 || world < 1) return KC_E_ARG;
+    if (k < 17 || k > 127 || world < 1) return KC_E_ARG;
     const ShardGeom g = shard_geometry(k, total_occurrences, world, 0.5);
     switch (g.W) {
         case 1: owner_of_w<1>(k, g, keys, n, owner); break;
@@ -705,7 +706,7 @@ extern "C" int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, c
 
 int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out) {
     *out = nullptr;
-    if (k < 16) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs k >= 16 (minimizer blocks)");
+    if (k < 17) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs k >= 17 (minimizer blocks)");
     u64 occ = occ_local;
     KC_TRY(kcc_allreduce_sum(c, &occ, 1));
     kc_set *s = new kc_set();
@@ -747,7 +748,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     KC_HIP(ctx, hipMemsetAsync(bcount, 0, (nblocks + 1) * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(bcur, 0, (nblocks + 1) * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
-    const int win = set->k - set->mlen + 1;
+    const int win = kc_roll_win(set->k, set->mlen);
     const int ppt = W == 1 ? 16 : (W == 2 ? 32 : 64);
     const u32 stage_cap = 8;
     const unsigned tb = win <= 32 ? 256 : (win <= 64 ? 128 : 64);

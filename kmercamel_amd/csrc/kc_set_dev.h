@@ -4,12 +4,17 @@
 // simplitig phase marks k-mers as consumed through port links instead of tombstones, so the table stays probe-able
 // for the -M mask pass).
 //
-// Home slot = locality-preserving: block = fastrange(hash of the k-mer's canonical minimizer (m-mer with the smallest
-// hash over both strands)), offset inside the block = key hash.  Overlapping k-mers -- in particular the 8 de Bruijn
-// neighbours the simplitig phase probes -- share their minimizer ~90 % of the time, so their slots lie in the same
-// 32 KB region that the probing workgroup (and its XCD's L2) is streaming anyway: random HBM line fetches become L2
-// hits.  Probe sequence: `local_probes` linear steps from the block home, then (overfull block, e.g. a low-complexity
-// minimizer) linear probing from a second, minimizer-independent home.  m = 0 (k < 16) falls back to the plain home.
+// Home slot = a function of the k-mer's MIDDLE (k-2)-mer (positions 1..k-2), taken in its canonical orientation:
+// block = fastrange(hash of the middle's canonical minimizer (m-mer with the smallest hash over both strands)), offset
+// inside the block = hash of the canonical middle.  The 4 candidate neighbours of one side of a k-mer x (x[1..k)+c, resp.
+// c+x[0..k-1)) differ only in their outer character, i.e. they share their middle: they share ONE home, so a port of x is
+// looked up with one hash, one home and one tag window instead of four.  The tag byte of a slot holds the two outer
+// characters of its k-mer (in the middle's canonical orientation) next to 3 hash bits, so the window search tells which of
+// the four extensions exist before any key is touched.  Overlapping k-mers share the minimizer of their middles ~90 % of the
+// time, so both homes of a k-mer usually lie in its own block (a block can be staged in LDS and probed there).
+// Probe sequence: `local_probes` linear steps from the block home, then (overfull block, e.g. a low-complexity
+// minimizer) linear probing from a second, minimizer-independent home.  m = 0 (k < 17) falls back to plain hashing of the
+// key (tag = 7 hash bits).
 // W == 1: the slot is the 64-bit key itself, EMPTY = all ones (never a k-mer: the top bit pair is
 // spare for k <= 31), claimed with one 64-bit CAS.  W > 1: a 32-bit state word per slot (EMPTY/BUSY/FULL) is
 // claimed by CAS, the key words are then written with agent-scope stores and published by the FULL store.
@@ -23,7 +28,8 @@
 template <int W> struct SetView {
     u64 *keys;
     u32 *state;
-    u8 *tags;       // 0 = empty, else 0x80 | 7 hash bits: lookups scan 8 slots per 8-byte load and touch a key only on a tag hit
+    u8 *tags;       // 0 = empty, else 0x80 | a << 5 | b << 3 | 3 hash bits (m != 0; a, b = outer characters) or 0x80 | 7 hash bits (m == 0):
+                    // lookups scan 8 slots per 8-byte load and touch a key only on a tag hit
     u64 cap;        // nblocks << bshift
     u64 nblocks;
     int bshift;     // log2(slots per block)
@@ -33,11 +39,14 @@ template <int W> struct SetView {
     // hash-sharded tables: this rank holds the global slots [rlo, rlo + rcap) (a whole number of blocks); the three pointers
     // above are biased by -rlo so that they are indexed with GLOBAL slot numbers.  One GPU: rlo = 0, rcap = cap.
     u64 rlo, rcap;
+    int complements;   // strand mode of the set (the canonical orientation of a middle is the smaller of it and its reverse complement)
 };
 
-// `ph` below is always key_place_hash(key): its low 7 bits give the tag, the offset inside a block is a range reduction
-// of all 32 bits (i.e. mostly the high ones).
+// plain hashing (m == 0): `ph` = key_place_hash(key); its low 7 bits give the tag
 KC_HD u8 kc_tag_of(u64 ph) { return (u8)(0x80u | ((u32)ph & 0x7fu)); }
+// minimizer blocks (m != 0): outer characters a, b of the k-mer in the canonical orientation of its middle + 3 bits of the
+// middle's hash (the offset inside a block is a range reduction of all 32 hash bits, i.e. mostly the high ones)
+KC_HD u8 kc_tag_mid(u32 a, u32 b, u64 mh) { return (u8)(0x80u | (a << 5) | (b << 3) | ((u32)mh & 7u)); }
 // Homes are confined to the first (block size - local probes - 8) slots of a block: a key's local probe run and the 8-tag
 // window of a lookup then never leave the block, so a block can be built or scanned on its own (in LDS).
 template <int W> KC_HD u32 set_block_span(const SetView<W> &s) {
@@ -83,10 +92,47 @@ template <int W> KC_HD u64 set_block_home(const SetView<W> &s, u32 mmh, u64 keyh
 template <int W> KC_HD u64 set_global_home(const SetView<W> &s, u64 keyhash) {
     return s.rlo + kc_mulhi64(kc_mix64(keyhash ^ 0x6a09e667f3bcc909ULL), s.rcap);
 }
-template <int W> KC_HD u64 set_home_kh(const SetView<W> &s, const Key<W> &key, u64 keyhash) {
-    if (s.m == 0) return kc_mulhi64(kc_mix64(keyhash), s.cap);
-    return set_block_home(s, key_min_mmh(key, s.k, s.m, 0, s.k - s.m), keyhash);
+// Canonical middle of a k-mer (k >= 3): M = the smaller of key[1..k-2] and its reverse complement (unidirectional sets: the
+// forward one), and the outer characters (a, b) of the k-mer read in M's orientation.  A palindromic middle has two readings
+// with the same M: the lexicographically smaller pair is taken, so that the result does not depend on the strand the k-mer
+// is given in.
+template <int W> KC_HD void key_middle(const Key<W> &key, int k, int complements, Key<W> &M, u32 &a, u32 &b) {
+    const Key<W> mf = key_and(key_shr(key, 2), key_lowmask<W>(2 * (k - 2)));
+    const u32 c0 = key_at(key, k, 0), c1 = (u32)(key.w[0] & 3);
+    M = mf; a = c0; b = c1;
+    if (complements) {
+        const Key<W> mr = key_rc(mf, k - 2);
+        bool rev = key_lt(mr, mf);
+        if (key_eq(mr, mf)) rev = (4u * (3u - c1) + (3u - c0)) < (4u * c0 + c1);
+        if (rev) { M = mr; a = 3u - c1; b = 3u - c0; }
+    }
 }
+// Where a key lives: home slot, the hash its second home derives from, tag byte.
+struct KcPlace { u64 home, kh; u8 tag; };
+// m != 0, `mmh` = smallest canonical m-mer hash inside the middle (m-mer starts 1..k-m-1)
+template <int W> KC_HD KcPlace set_place_mmh(const SetView<W> &s, const Key<W> &key, u32 mmh) {
+    Key<W> M; u32 a, b;
+    key_middle(key, s.k, s.complements, M, a, b);
+    const u64 mh = key_place_hash(M);
+    return KcPlace{set_block_home(s, mmh, mh), mh, kc_tag_mid(a, b, mh)};
+}
+template <int W> KC_HD KcPlace set_place(const SetView<W> &s, const Key<W> &key) {
+    if (s.m == 0) {
+        const u64 kh = key_place_hash(key);
+        return KcPlace{kc_mulhi64(kc_mix64(kh), s.cap), kh, kc_tag_of(kh)};
+    }
+    return set_place_mmh(s, key, key_min_mmh(key, s.k, s.m, 1, s.k - s.m - 1));
+}
+// the part of set_place a block-local build needs (m != 0): offset of the home inside its block, tag
+template <int W> KC_HD void set_place_local(const SetView<W> &s, const Key<W> &key, u32 *off, u8 *tag) {
+    Key<W> M; u32 a, b;
+    key_middle(key, s.k, s.complements, M, a, b);
+    const u64 mh = key_place_hash(M);
+    *off = (u32)(((u64)(u32)mh * set_block_span(s)) >> 32);
+    *tag = kc_tag_mid(a, b, mh);
+}
+// minimizer length for k (0 = plain hashing): the middle must hold at least one m-mer
+static inline int kc_default_mlen(int k) { return k >= 17 ? 15 : 0; }
 // XCD-aware workgroup order for kernels that sweep the table: workgroups are dealt round-robin over the 8 XCDs, so give
 // XCD j the j-th contiguous eighth of the sweep -- the workgroups resident on one XCD then work on neighbouring table
 // regions and share them through that XCD's L2 (speed only; correctness never depends on placement). Grid = multiple of 8.
@@ -114,15 +160,15 @@ template <int W> __device__ __forceinline__ void set_write_tag(const SetView<W> 
 
 
 // Insert during the build kernel (concurrent with other inserts). Returns 1 if this call added the key, 0 if it was
-// present, -1 if the table is full. *slot_out receives the slot.
-template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, u64 kh, u64 home, u64 *slot_out);
+// present, -1 if the table is full. *slot_out receives the slot.  `pl` = set_place(s, key) (callers that know the minimizer
+// hash of the middle already pass set_place_mmh(...)).
+template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, const KcPlace &pl, u64 *slot_out);
 template <int W> __device__ __forceinline__ int set_insert(const SetView<W> &s, const Key<W> &key, u64 *slot_out) {
-    const u64 kh = key_place_hash(key);
-    return set_insert_at(s, key, kh, set_home_kh(s, key, kh), slot_out);
+    return set_insert_at(s, key, set_place(s, key), slot_out);
 }
-// `home` = set_home_kh(s, key, kh) (callers that know the minimizer hash already pass set_block_home(...))
-template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, u64 kh, u64 home, u64 *slot_out) {
-    const u64 ghome = set_global_home(s, kh);
+template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &s, const Key<W> &key, const KcPlace &pl, u64 *slot_out) {
+    const u64 home = pl.home;
+    const u64 ghome = set_global_home(s, pl.kh);
     const u64 limit = s.m ? s.rcap + s.local_probes : s.rcap;
     if constexpr (W == 1) {
         unsigned long long *keys = (unsigned long long *)s.keys;
@@ -133,7 +179,7 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
             if (cur == kv) { *slot_out = slot; return 0; }
             if (cur == ~0ULL) {
                 unsigned long long prev = atomicCAS(&keys[slot], ~0ULL, kv);
-                if (prev == ~0ULL) { set_write_tag(s, slot, kc_tag_of(kh)); *slot_out = slot; return 1; }
+                if (prev == ~0ULL) { set_write_tag(s, slot, pl.tag); *slot_out = slot; return 1; }
                 if (prev == kv) { *slot_out = slot; return 0; }
             }
         }
@@ -167,7 +213,7 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
 #endif
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_store(&s.state[slot], KC_ST_FULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    set_write_tag(s, slot, kc_tag_of(kh));
+                    set_write_tag(s, slot, pl.tag);
                     *slot_out = slot;
                     return 1;
                 }
@@ -213,19 +259,15 @@ template <int W> __device__ __forceinline__ u64 set_scan(const SetView<W> &s, co
     }
     return KC_SCAN_MORE;
 }
-// `home` must be the key's block home (set_home_kh, or set_block_home with a minimizer hash derived incrementally)
-template <int W> __device__ __forceinline__ u64 set_find_from(const SetView<W> &s, const Key<W> &key, u64 keyhash, u64 home) {
-    const u8 tag = kc_tag_of(keyhash);
-    if (s.m == 0) { u64 r = set_scan(s, key, tag, home, s.rcap); return r == KC_SCAN_MORE ? KC_NONE64 : r; }
-    u64 r = set_scan(s, key, tag, home, (u64)s.local_probes);
+// `pl` = set_place(s, key)
+template <int W> __device__ __forceinline__ u64 set_find_at(const SetView<W> &s, const Key<W> &key, const KcPlace &pl) {
+    if (s.m == 0) { u64 r = set_scan(s, key, pl.tag, pl.home, s.rcap); return r == KC_SCAN_MORE ? KC_NONE64 : r; }
+    u64 r = set_scan(s, key, pl.tag, pl.home, (u64)s.local_probes);
     if (r != KC_SCAN_MORE) return r;
-    r = set_scan(s, key, tag, set_global_home(s, keyhash), s.rcap);
+    r = set_scan(s, key, pl.tag, set_global_home(s, pl.kh), s.rcap);
     return r == KC_SCAN_MORE ? KC_NONE64 : r;
 }
-template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) {
-    const u64 kh = key_place_hash(key);
-    return set_find_from(s, key, kh, set_home_kh(s, key, kh));
-}
+template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) { return set_find_at(s, key, set_place(s, key)); }
 
 template <int W> __device__ __forceinline__ bool set_slot_full(const SetView<W> &s, u64 slot) {
     if constexpr (W == 1) return s.keys[slot] != ~(u64)0;

@@ -78,12 +78,12 @@ __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set,
     for (u32 t0 = 0; t0 < n; t0 += 256) {
         const u32 t = t0 + threadIdx.x;
         const bool active = t < n;
-        KcCand<W> cd;
+        KcCand2<W> cd;
         u64 slot = 0;
         u32 need = 0, nq = 0;   // need: bit p = port p gets a record
         if (active) {
             slot = base + kc_list[t];
-            kc_cand_lookup<W, KC, true>(set, k_rt, complements, slot, kc_stage, sblk, cd);
+            kc_cand_lookup_mid<W, KC, true, false>(set, k_rt, complements, slot, reinterpret_cast<const u8 *>(kc_stage), nullptr, sblk, cd);
 #pragma unroll
             for (int port = 0; port < 2; ++port) {
                 const u64 pid = (slot << 1) | (u64)port;
@@ -131,15 +131,16 @@ __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set,
                 for (u32 c = 0; c < 4; ++c) {
                     const int i = port * 4 + (int)c;
                     const u64 cs = cd.cslot[i];
-                    const u64 q = (cd.qbits >> i) & 1;
-                    r[1 + c] = (cs == KC_NONE64 || cs == KC_REMOTE) ? cs : ((cs << 1) | q);
+                    r[1 + c] = (cs == KC_NONE64 || cs == KC_REMOTE) ? cs : ((cs << 1) | (u64)((cd.qbits >> i) & 1));
                     if (cs == KC_REMOTE) {
                         if (qpos >= L.qry_scap) { L.flags[0] = 1; }
                         else {
+                            int q;   // the port the candidate is entered on travels with the query
+                            const Key<W> y = kc_neighbour_key_q(cd.x, cd.xr, port, c, KC ? KC : k_rt, complements, q);
                             u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * QW;
-                            for (int w = 0; w < W; ++w) qq[w] = cd.cy[i].w[w];
-                            qq[W] = cd.chome[i];
-                            qq[W + 1] = (ri << 3) | (q << 2) | (u64)c;
+                            for (int w = 0; w < W; ++w) qq[w] = y.w[w];
+                            qq[W] = cd.phome[port];
+                            qq[W + 1] = (ri << 3) | ((u64)q << 2) | (u64)c;
                         }
                         ++qpos;
                     }
@@ -173,13 +174,6 @@ __global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restric
     rec[(meta >> 3) * 5 + 1 + (meta & 3)] = a == KC_NONE64 ? KC_NONE64 : ((a << 1) | ((meta >> 2) & 1));
 }
 
-// candidate (port, c) of x: canonical key (the port it is entered on is already in the record)
-template <int W> __device__ __forceinline__ Key<W> kc_neighbour_key(const Key<W> &x, int port, u32 c, int k, int complements) {
-    Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
-    if (!complements) return nf;
-    Key<W> r = key_rc(nf, k);
-    return key_lt(r, nf) ? r : nf;
-}
 // settle the recorded ports.  Branch ports (>= 2 existing candidates) choose their best edge here too, and list all their
 // edges {x pid, y pid, priority, base, key x, key y} for the replicated branch matching.
 template <int W>
@@ -1144,7 +1138,7 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     if (!ctx || !comm || !out || (!seq && len)) return KC_E_ARG;
     *out = nullptr;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
-    if (k < 16 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 16 <= k <= 127");
+    if (k < 17 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 17 <= k <= 127");
     if (flags & (KC_FLAG_SIMPLITIGS_INPUT | KC_FLAG_WANT_MASK) || ((flags >> 8) & 0xff) > 1)
         return kc_fail(ctx, KC_E_ARG, "-S, -M and -z are not part of the hash-sharded path (use kc_compute)");
     KC_HIP(ctx, hipSetDevice(ctx->device));

@@ -85,8 +85,8 @@ static __global__ void __launch_bounds__(256) kc_gather_shards_kernel(const u64 
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_out = ovf ? dst_cap + 1 : pre[KC_NSHARD];
 }
 
-// The 8 candidate lookups of one k-mer.  SH (hash-sharded table): a candidate whose home lies outside this rank's slot range is
-// not looked up; its slot comes back as KC_REMOTE and its home in chome[] (the owner answers the query later).
+// The 8 candidate lookups of one k-mer on a table with PLAIN hashing (set.m == 0, i.e. k < 17: every candidate has a home of
+// its own; tables with minimizer blocks go through kc_cand_lookup_mid below).
 #define KC_REMOTE (~(u64)1)
 template <int W> struct KcCand {
     Key<W> x;        // the k-mer itself
@@ -290,7 +290,7 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
             if (has) {
                 Key<W> y; int q; u64 hy, home;
                 make_cand_of(cx, (int)((ent >> 2) & 1), ent & 3u, y, q, hy, home);
-                kc_sq_res[wv][ent] = set_find_from(set, y, hy, home);
+                kc_sq_res[wv][ent] = set_find_at(set, y, KcPlace{home, hy, kc_tag_of(hy)});   // (this lookup only serves tables with plain hashing)
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -305,6 +305,191 @@ __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, 
             if ((remote >> i) & 1) cslot[i] = KC_REMOTE;
     }
     out.x = x; out.qbits = qbits; out.xpal = xpal;
+}
+
+// candidate (port, c) of x: canonical key and the port q it is entered on (c = the character appended on port R / prepended on port L)
+template <int W> __device__ __forceinline__ Key<W> kc_neighbour_key_q(const Key<W> &x, const Key<W> &xr, int port, u32 c, int k, int complements, int &q) {
+    const Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
+    if (!complements) { q = port ? 0 : 1; return nf; }
+    const Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
+    const bool pal = key_eq(nf, r), fwd = !key_lt(r, nf);
+    q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));   // append: entering y on L if y == nf else R; prepend: the other way round; palindromes: L
+    return fwd ? nf : r;
+}
+template <int W> __device__ __forceinline__ Key<W> kc_neighbour_key(const Key<W> &x, int port, u32 c, int k, int complements) {
+    int q;
+    return kc_neighbour_key_q(x, complements ? key_rc(x, k) : x, port, c, k, complements, q);
+}
+
+// ---- Neighbour lookup on a table with middle-based homes (set.m != 0; kc_set_dev.h).  The 4 candidates of a port share their
+// middle (k-2)-mer, hence ONE home, one placement hash and one tag window; the tag bytes carry the outer characters, so the
+// window search says which extensions can exist and only those keys are compared.  Per k-mer: one pass over the k-m+1 m-mer
+// hashes (the minimizers of both candidate middles are a suffix / a prefix minimum of them), two placement hashes, two
+// homes, two window searches -- against eight of each with per-key homes.
+//   stage_tags: the tag bytes of table block `sblk`, staged in LDS (+ 8 bytes of slack), or nullptr
+//   SK: the keys of block `sblk` are staged too (stage_keys, W words per slot)
+//   SH (hash-sharded table): a port whose home lies in another rank's slot range is not looked up: its four candidates come
+//   back as KC_REMOTE and the owner answers the queries later.
+template <int W> struct KcCand2 {
+    Key<W> x, xr;    // the k-mer and its reverse complement
+    u64 cslot[8];    // candidate i = port (i >> 2), extension character (i & 3): its slot, KC_NONE64 (absent or not a legal edge), or KC_REMOTE
+    u64 phome[2];    // the home the 4 candidates of port L (0) / R (1) share
+    u32 qbits;       // bit i: the port on which candidate i is entered (set for the candidates that were found)
+    bool xpal;       // x is its own reverse complement (links on port L only)
+};
+template <int W, int KC, bool SH, bool SK>
+__device__ __forceinline__ void kc_cand_lookup_mid(const SetView<W> &set, int k_rt, int complements, const u64 slot, const u8 *stage_tags,
+                                                   const u64 *stage_keys, const u64 sblk, KcCand2<W> &out) {
+    const int k = KC ? KC : k_rt;
+    const int m = KC ? 15 : set.m;
+    const u32 bmask = (1u << set.bshift) - 1u;
+    auto load_key = [&](u64 s) {
+        Key<W> r;
+        if (SK && (s >> set.bshift) == sblk) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) r.w[w] = stage_keys[(size_t)((u32)s & bmask) * W + w];
+        } else r = set_key_at(set, s);
+        return r;
+    };
+    const Key<W> x = load_key(slot);
+    const Key<W> xr = key_rc(x, k);
+    const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
+    // minimizers of the two candidate middles: m-mer starts 2..k-m (append side) and 0..k-m-2 (prepend side) of x
+    u32 minR = ~0u, minL = ~0u;
+    {
+        const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+        const int top = 2 * (m - 1);
+        u32 f = 0, r = 0;
+        if constexpr (W != 1) {
+#pragma unroll
+            for (int j = 0; j < m - 1; ++j) {
+                u32 b = key_at(x, k, j);
+                f = (f << 2) | b;
+                r = (r >> 2) | ((3u - b) << top);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i <= k - m; ++i) {
+            if constexpr (W == 1) {   // one word: every m-mer is a shift of x / RC(x), no serial dependency between positions
+                f = (u32)(x.w[0] >> (2 * (k - m - i))) & maskm;
+                r = (u32)(xr.w[0] >> (2 * i)) & maskm;
+            } else {
+                u32 b = key_at(x, k, i + m - 1);
+                f = ((f << 2) | b) & maskm;
+                r = (r >> 2) | ((3u - b) << top);
+            }
+            const u32 h = kc_mmer_hash(f, r);
+            if (i >= 2) minR = h < minR ? h : minR;
+            if (i <= k - m - 2) minL = h < minL ? h : minL;
+        }
+    }
+    u64 (&cslot)[8] = out.cslot;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cslot[i] = KC_NONE64;
+    u32 qbits = 0;
+    const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+    // per port: canonical middle of its candidates, home, search pattern
+    u64 home[2], word[2];
+    u32 pat[2], msk[2], revf[2], fixa[2], inb[2], slowp = 0, rem = 0;
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        const Key<W> mf = port ? key_and(x, lm) : key_shr(x, 4);
+        const Key<W> mr = port ? key_shr(xr, 4) : key_and(xr, lm);
+        const bool rev = complements && key_lt(mr, mf);
+        if (!(KC & 1) && complements && key_eq(mr, mf)) slowp |= 1u << port;   // palindromic middle (even k only): the tags say nothing, generic lookups
+        const Key<W> M = rev ? mr : mf;
+        const u64 mh = key_place_hash(M);
+        home[port] = set_block_home(set, port ? minR : minL, mh);
+        // the character the candidates share next to the middle: x[1] (append side) / x[k-2] (prepend side); reading the
+        // candidate in the middle's canonical orientation it is the FIRST outer character (field a) for append & forward or
+        // prepend & reversed, else the last one (field b); a reversed reading complements it.  The other field is the extension.
+        const u32 fx = port ? key_at(x, k, 1) : (u32)((x.w[0] >> 2) & 3);
+        const bool fa = port ? !rev : rev;
+        const u32 fval = rev ? 3u - fx : fx;
+        pat[port] = 0x80u | ((u32)mh & 7u) | (fa ? fval << 5 : fval << 3);
+        msk[port] = fa ? 0xE7u : 0x9Fu;
+        revf[port] = rev ? 1u : 0u;
+        fixa[port] = fa ? 1u : 0u;
+        inb[port] = (home[port] >> set.bshift) == sblk ? 1u : 0u;
+        if (SH && home[port] - set.rlo >= set.rcap) rem |= 1u << port;
+        out.phome[port] = home[port];
+    }
+    if (xpal) slowp &= 1u;   // port R of a palindrome is dead: nothing to look up
+    // first tag windows of both ports (LDS for in-block homes, one unaligned 8-byte global load otherwise), issued together
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        const bool skip = ((rem >> port) & 1u) || (port == 1 && xpal);
+        if (inb[port] && stage_tags) __builtin_memcpy(&word[port], stage_tags + ((u32)home[port] & bmask), 8);   // (gfx950 reads LDS at any byte offset)
+        else __builtin_memcpy(&word[port], set.tags + (skip ? slot : home[port]), 8);                          // skipped ports read x's own window: harmless
+    }
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        if (port == 1 && xpal) continue;
+        if ((rem >> port) & 1u) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cslot[port * 4 + c] = KC_REMOTE;
+            continue;
+        }
+        if ((slowp >> port) & 1u) continue;
+        const u32 lo7 = 0x7f7f7f7fu, hi7 = 0x80808080u, gather = 0x204081u;
+        const u32 pat4 = pat[port] * 0x01010101u, msk4 = msk[port] * 0x01010101u;
+        u64 wd = word[port];
+        u32 off = 0;
+        while (true) {
+            // "byte matches the pattern on the masked bits" and "byte is empty" become one bit per byte (bit 7), and a multiply gathers
+            // the four bits of a half into a nibble -- (h * 0x204081) >> 28 -- so that everything else works on two 8-bit masks
+            const u32 wl = (u32)wd, wh = (u32)(wd >> 32);
+            const u32 xl = (wl ^ pat4) & msk4, xh = (wh ^ pat4) & msk4;
+            const u32 ml = ~(((xl & lo7) + lo7) | xl) & hi7, mh4 = ~(((xh & lo7) + lo7) | xh) & hi7;
+            const u32 el = ~wl & hi7, eh = ~wh & hi7;
+            const u32 M8 = ((ml * gather) >> 28) | (((mh4 * gather) >> 28) << 4);
+            u32 E8 = ((el * gather) >> 28) | (((eh * gather) >> 28) << 4);
+            const u32 left = set.local_probes - off;                 // slots of the local probe run still ahead
+            if (left < 8) E8 |= 1u << left;                           // (the run ends inside this window: treated like an empty slot, see below)
+            const u32 fe = (u32)__builtin_ctz(E8 | 0x100u);          // first empty slot of the window (8: none)
+            u32 H = M8 & ((1u << fe) - 1u);                           // no deletions: a key lies before the first empty slot after its home
+            while (H) {
+                const u32 j = (u32)__builtin_ctz(H);
+                H &= H - 1u;
+                const u32 tb = (u32)(wd >> (8 * j)) & 0xffu;
+                const u32 v = fixa[port] ? (tb >> 3) & 3u : (tb >> 5) & 3u;
+                const u32 c = revf[port] ? 3u - v : v;
+                const u64 sl = home[port] + (u64)(off + j);
+                if (sl == slot) continue;                             // x itself (no self edges)
+                const Key<W> kk = load_key(sl);
+                int q;
+                const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+                if (key_eq(kk, y)) {
+#pragma unroll
+                    for (u32 cc = 0; cc < 4; ++cc)
+                        if (c == cc) cslot[port * 4 + cc] = sl;       // (selects: a run-time index would send the array to scratch memory)
+                    qbits |= (u32)q << (port * 4 + c);
+                }
+            }
+            if (fe < 8 && !(left < 8 && fe == left)) break;          // a real empty slot: every candidate of this home has been seen
+            if (left <= 8) { slowp |= 1u << port; break; }            // local run exhausted: the rest may sit at the second home
+            off += 8;
+            if (inb[port] && stage_tags) __builtin_memcpy(&wd, stage_tags + ((u32)home[port] & bmask) + off, 8);
+            else __builtin_memcpy(&wd, set.tags + home[port] + off, 8);
+        }
+    }
+    if (slowp) {   // palindromic middles, overfull blocks: one generic lookup per candidate (finds what the window search found again)
+#pragma unroll
+        for (int port = 0; port < 2; ++port) {
+            if (!((slowp >> port) & 1u)) continue;
+            for (u32 c = 0; c < 4; ++c) {
+                int q;
+                const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+                if (key_eq(y, x)) continue;
+                const u64 sl = set_find(set, y);
+#pragma unroll
+                for (u32 cc = 0; cc < 4; ++cc)
+                    if (c == cc) cslot[port * 4 + cc] = sl;
+                if (sl != KC_NONE64) qbits |= (u32)q << (port * 4 + c);
+            }
+        }
+    }
+    out.x = x; out.xr = xr; out.qbits = qbits; out.xpal = xpal;
 }
 
 // Round 1: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
@@ -387,6 +572,102 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
     for (u32 t = threadIdx.x; t < n; t += 256)
         kc_choose_dense_one<W, KC>(set, link, k_rt, complements, base + kc_list[t], kc_stage, sblk, heads, heads_shard_cap, heads_cursors, branch,
                                    branch_shard_cap, branch_cursors);
+}
+
+// ---- round 1 on a table with middle-based homes: one workgroup per table block.  The block's tag bytes and (single-word keys)
+// its keys are staged in LDS with coalesced 16-byte loads; ~90 % of the lookups of the block's k-mers start and end in that
+// very block, so they touch LDS only.  The block is swept in quarters: the occupied slots of a quarter are listed in LDS
+// (so that the lanes stay dense), then every listed k-mer looks up both of its ports (kc_cand_lookup_mid) and writes its
+// two link words.  LDS: tags + keys + the list = 78 KB for 8192-slot blocks of 64-bit keys, two workgroups per CU.
+template <int W>
+__device__ __forceinline__ void kc_choose_write(const SetView<W> &set, u64 *__restrict__ link, int k, int complements, const u64 slot, const KcCand2<W> &cd,
+                                                u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch, u64 branch_shard_cap,
+                                                u64 *branch_cursors) {
+    const Key<W> &x = cd.x;
+    const u64 (&cslot)[8] = cd.cslot;
+    // every ~256th k-mer (by slot) is a splitter: chains are walked segment-wise between splitters
+    const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        const u64 pid = (slot << 1) | (u64)port;
+        if (port == 1 && cd.xpal) {
+            link[pid] = LK_DEAD | splitbit;
+            if (complements) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);
+            continue;
+        }
+        int nfound = 0;
+        u32 bc = 0, bq = 0;
+        u64 bslot = 0;
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c) {
+            const int i = port * 4 + (int)c;
+            if (cslot[i] == KC_NONE64) continue;
+            ++nfound; bc = c; bslot = cslot[i]; bq = (cd.qbits >> i) & 1u;
+        }
+        if (nfound >= 2) {   // a branch port (rare): the best edge by the layout-free priority; the port will reject the others
+            const u64 hxk = key_hash(x);
+            Key<W> by = x; u64 bpr = 0; bool have = false;
+            for (u32 c = 0; c < 4; ++c) {
+                u64 ts = KC_NONE64;
+#pragma unroll
+                for (u32 cc = 0; cc < 4; ++cc) ts = (c == cc) ? cslot[port * 4 + cc] : ts;
+                if (ts == KC_NONE64) continue;
+                int q;
+                const Key<W> y = kc_neighbour_key_q(x, cd.xr, port, c, k, complements, q);
+                const u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
+                if (!have || edge_preferred(x, port, y, q, pr, by, (int)bq, bpr)) { by = y; bq = (u32)q; bpr = pr; bslot = ts; bc = c; have = true; }
+            }
+        }
+        link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD) | splitbit;
+        if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+        if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);
+    }
+}
+
+#define KC_PROBE_THREADS 512
+#define KC_PROBE_QUARTER 2048
+template <int W, int KC, bool SK>
+__global__ void __launch_bounds__(KC_PROBE_THREADS) kc_probe_block_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
+                                                                         u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
+                                                                         u64 branch_shard_cap, u64 *branch_cursors) {
+    // dynamic LDS: [tags: bs + 8 bytes, rounded up to 16][keys: bs * W words, if SK][list: min(bs, KC_PROBE_QUARTER) u16]
+    extern __shared__ ulonglong2 kc_pb[];
+    __shared__ u32 nlist;
+    const u64 blk = kc_xcd_block_id(xcd_aware);
+    if (blk >= set.nblocks) return;
+    const u32 bs = 1u << set.bshift;
+    const u64 base = blk << set.bshift;
+    u8 *st = reinterpret_cast<u8 *>(kc_pb);
+    const u32 tag_bytes = (bs + 8u + 15u) & ~15u;
+    u64 *sk = reinterpret_cast<u64 *>(st + tag_bytes);
+    unsigned short *list = reinterpret_cast<unsigned short *>(st + tag_bytes + (SK ? (size_t)bs * W * 8 : 0));
+    {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(set.tags + base);
+        for (u32 j = threadIdx.x; j < bs / 16; j += KC_PROBE_THREADS) kc_pb[j] = src[j];
+        if (threadIdx.x == 0) *reinterpret_cast<u64 *>(st + bs) = *reinterpret_cast<const u64 *>(set.tags + base + bs);   // (the table has 8 bytes of slack)
+        if (SK) {
+            const ulonglong2 *ksrc = reinterpret_cast<const ulonglong2 *>(set.keys + base * W);
+            ulonglong2 *kdst = reinterpret_cast<ulonglong2 *>(sk);
+            for (u32 j = threadIdx.x; j < bs * W / 2; j += KC_PROBE_THREADS) kdst[j] = ksrc[j];
+        }
+    }
+    const u32 qn = bs < KC_PROBE_QUARTER ? bs : KC_PROBE_QUARTER;
+    for (u32 q0 = 0; q0 < bs; q0 += qn) {
+        if (threadIdx.x == 0) nlist = 0;
+        __syncthreads();   // (first trip: also the staging above)
+        for (u32 i = threadIdx.x; i < qn; i += KC_PROBE_THREADS)
+            if (st[q0 + i] != 0) list[atomicAdd(&nlist, 1u)] = (unsigned short)(q0 + i);
+        __syncthreads();
+        const u32 n = nlist;
+#pragma unroll 1
+        for (u32 t = threadIdx.x; t < n; t += KC_PROBE_THREADS) {
+            const u64 slot = base + list[t];
+            KcCand2<W> cd;
+            kc_cand_lookup_mid<W, KC, false, SK>(set, k_rt, complements, slot, st, sk, blk, cd);
+            kc_choose_write<W>(set, link, KC ? KC : k_rt, complements, slot, cd, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+        }
+        __syncthreads();
+    }
 }
 
 #define KC_CHUNK_WORDS 32

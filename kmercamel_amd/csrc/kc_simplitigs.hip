@@ -55,17 +55,13 @@ __global__ void __launch_bounds__(256) kc_reject_kernel(SetView<W> set, u64 *lin
 }
 
 // One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
-// yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports.
-// The 4 candidate neighbours of a port share k-1 bases with x, hence all m-mers but one: their minimizer (= their table
-// region) is min(shared part, one new m-mer), computed once per port; their reverse complements are one shift away from
-// RC(x).  KC != 0 fixes k = KC and m = 15 at compile time: every loop below then has a constant trip count and is fully
-// unrolled -- the kernel is otherwise bound by scalar loop-control / exec-mask instructions, not by memory.
+// yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports
+// (later rounds: few ports, generic lookups).
 template <int W, bool FIRST, int KC>
 __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
                                                         const u64 *__restrict__ work, u64 nwork, int xcd_aware, u64 *heads,
                                                         u64 heads_cap, u64 *heads_cursor) {
     const int k = KC ? KC : k_rt;
-    const int m = KC ? 15 : set.m;
     u64 t = (FIRST ? kc_xcd_block_id(xcd_aware) : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= nwork) return;
     u64 pid = FIRST ? t : work[t];
@@ -78,28 +74,6 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         link[pid] = LK_DEAD | (link[pid] & LK_SPLIT);
         kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
         return;
-    }
-    u32 shared = ~0u;
-    if (m) {
-        // min over the m-mers the candidates share with x: positions 1..k-m (append side) or 0..k-m-1 (prepend side)
-        const int i0 = port ? 1 : 0;
-        const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
-        const int top = 2 * (m - 1);
-        u32 f = 0, r = 0;
-#pragma unroll
-        for (int j = 0; j < m - 1; ++j) {
-            u32 b = key_at(x, k, i0 + j);
-            f = (f << 2) | b;
-            r = (r >> 2) | ((3u - b) << top);
-        }
-#pragma unroll
-        for (int i = 0; i < k - m; ++i) {
-            u32 b = key_at(x, k, i0 + i + m - 1);
-            f = ((f << 2) | b) & maskm;
-            r = (r >> 2) | ((3u - b) << top);
-            u32 h = kc_mmer_hash(f, r);
-            shared = h < shared ? h : shared;
-        }
     }
     const u64 hxk = key_hash(x);
     int nfound = 0;
@@ -120,14 +94,7 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
             q = port ? 0 : 1;
         }
         if (key_eq(y, x)) continue;
-        const u64 hy = key_place_hash(y);
-        u64 home;
-        if (m) {
-            u32 f = port ? (u32)(nf.w[0] & ((m >= 16) ? ~0u : ((1u << (2 * m)) - 1u))) : (u32)key_prefix(nf, k, m).w[0];
-            u32 h = kc_mmer_hash(f, kc_mmer_rc(f, m));
-            home = set_block_home(set, h < shared ? h : shared, hy);
-        } else home = kc_mulhi64(kc_mix64(hy), set.cap);
-        u64 tslot = set_find_from(set, y, hy, home);
+        u64 tslot = set_find(set, y);
         if (tslot == KC_NONE64) continue;
         if (!FIRST) {
             u64 wt = link[(tslot << 1) | (u64)q];
@@ -850,18 +817,29 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_HIP(ctx, hipMemsetAsync(shard_cur, 0, 2 * KC_NSHARD * KC_SHARD_STRIDE * 8, ctx->stream));
     u64 *heads_cursors = shard_cur, *branch_cursors = shard_cur + KC_NSHARD * KC_SHARD_STRIDE;
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    // tag staging: one table block's tags (+ 8 bytes) in LDS, when the set has minimizer blocks of at most 32 KB
-    const int stage_words = (set->mlen && set->bshift <= 15 && !getenv("KC_NOSTAGE")) ? (int)(((u64)1 << set->bshift) / 8 + 1) : 0;
-    const size_t stage_lds = (size_t)stage_words * 8;
-    const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);
     // compile-time k for the benchmark configurations (k = 31 / 63 / 127 with m = 15): constant trip counts everywhere
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
-    if (k == KSPEC && set->mlen == 15 && !getenv("KC_NO_KSPEC"))
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, KSPEC>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_, xcd_aware,
-                           heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, stage_words);
-    else
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), stage_lds, ctx->stream, sv, link, k, compl_, xcd_aware,
-                           heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, stage_words);
+    const bool kspec = k == KSPEC && set->mlen == 15 && !getenv("KC_NO_KSPEC");
+    if (set->mlen) {
+        // middle-based homes: one workgroup per block, tags (and single-word keys of blocks up to 8192 slots) staged in LDS
+        const u32 bs = 1u << set->bshift;
+        const bool stage_keys = W == 1 && set->bshift <= 13 && !getenv("KC_NOSTAGE");
+        const size_t lds = ((bs + 8 + 15) & ~(size_t)15) + (stage_keys ? (size_t)bs * W * 8 : 0) + (size_t)(bs < KC_PROBE_QUARTER ? bs : KC_PROBE_QUARTER) * 2;
+        const unsigned pgrid = (unsigned)((set->nblocks + 7) / 8 * 8);
+        auto launch = [&](auto kern) -> int {
+            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(KC_PROBE_THREADS), lds, ctx->stream, sv, link, k, compl_, xcd_aware, heads_sh, heads_shard_cap,
+                               heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
+            return KC_OK;
+        };
+        if (stage_keys) { if constexpr (W == 1) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true>) : launch(kc_probe_block_kernel<W, 0, true>)); }
+        else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false>) : launch(kc_probe_block_kernel<W, 0, false>));
+    } else {
+        // plain hashing (k < 17): per-key homes, 8 lookups per k-mer
+        const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);
+        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), 0, ctx->stream, sv, link, k, compl_, xcd_aware,
+                           heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, 0);
+    }
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
                        (const u64 *)heads_cursors, heads, heads_cap, heads_cursor);
