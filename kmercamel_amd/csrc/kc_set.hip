@@ -663,7 +663,7 @@ static int insert_bucketed(kc_set *set, const u64 *d_codes, const u64 *d_brk, co
 struct ShardGeom { int W, mlen, bshift; u32 local_probes; u64 nblocks, bpr; };
 static ShardGeom shard_geometry(int k, u64 occ, int world, double load) {
     ShardGeom g;
-    g.W = kc_words_for_k(k); g.mlen = 15; g.bshift = g.W == 4 ? 12 : 13; g.local_probes = 128;
+    g.W = kc_words_for_k(k); g.mlen = kc_default_mlen(k); g.bshift = g.W == 4 ? 12 : 13; g.local_probes = 128;
     if (const char *e = getenv("KC_BSHIFT")) { int v = atoi(e); if (v >= 9 && v <= bucketed_max_bshift(g.W)) g.bshift = v; }
     if (const char *e = getenv("KC_LOCAL_PROBES")) { int v = atoi(e); if (v >= 1) g.local_probes = (u32)v; }
     if (g.local_probes + 8 >= ((u32)1 << g.bshift) / 2) g.local_probes = ((u32)1 << g.bshift) / 4;
@@ -677,7 +677,7 @@ static ShardGeom shard_geometry(int k, u64 occ, int world, double load) {
 // Host-side description of the partition (needs no GPU): out[0] = table blocks in total, [1] = log2 slots per block,
 // [2] = blocks per rank, [3] = first global slot of `rank`, [4] = slots per rank, [5] = minimizer length.
 extern "C" int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, uint64_t *out6) {
-    if (!out6 || k < 17 || k > 127 || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
+    if (!out6 || k < 18 || k > 127 || world < 1 || rank < 0 || rank >= world) return KC_E_ARG;
     const ShardGeom g = shard_geometry(k, total_occurrences, world, 0.5);
     out6[0] = g.nblocks; out6[1] = (u64)g.bshift; out6[2] = g.bpr; out6[3] = ((u64)rank * g.bpr) << g.bshift; out6[4] = g.bpr << g.bshift; out6[5] = (u64)g.mlen;
     return KC_OK;
@@ -694,7 +694,7 @@ template <int W> static void owner_of_w(int k, const ShardGeom &g, const u64 *ke
 }
 extern "C" int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner) {
     if ((!keys || !owner) && n) return KC_E_ARG;
-    if (k < 17 || k > 127 || world < 1) return KC_E_ARG;
+    if (k < 18 || k > 127 || world < 1) return KC_E_ARG;
     const ShardGeom g = shard_geometry(k, total_occurrences, world, 0.5);
     switch (g.W) {
         case 1: owner_of_w<1>(k, g, keys, n, owner); break;
@@ -706,7 +706,7 @@ extern "C" int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, c
 
 int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out) {
     *out = nullptr;
-    if (k < 17) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs k >= 17 (minimizer blocks)");
+    if (k < 18) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs k >= 18 (minimizer blocks)");
     u64 occ = occ_local;
     KC_TRY(kcc_allreduce_sum(c, &occ, 1));
     kc_set *s = new kc_set();

@@ -13,7 +13,7 @@
 // the four extensions exist before any key is touched.  Overlapping k-mers share the minimizer of their middles ~90 % of the
 // time, so both homes of a k-mer usually lie in its own block (a block can be staged in LDS and probed there).
 // Probe sequence: `local_probes` linear steps from the block home, then (overfull block, e.g. a low-complexity
-// minimizer) linear probing from a second, minimizer-independent home.  m = 0 (k < 17) falls back to plain hashing of the
+// minimizer) linear probing from a second, minimizer-independent home.  m = 0 (k < 18) falls back to plain hashing of the
 // key (tag = 7 hash bits).
 // W == 1: the slot is the 64-bit key itself, EMPTY = all ones (never a k-mer: the top bit pair is
 // spare for k <= 31), claimed with one 64-bit CAS.  W > 1: a 32-bit state word per slot (EMPTY/BUSY/FULL) is
@@ -57,7 +57,8 @@ template <int W> KC_HD u32 set_block_span(const SetView<W> &s) {
 // hash of a canonical m-mer (f forward, r its reverse complement), 32 bit
 KC_HD u32 kc_mmer_hash(u32 f, u32 r) {
     u32 c = f < r ? f : r;
-    c *= 0x9E3779B1u; c ^= c >> 15;   // one multiply: this runs once per base in the insert kernel and 25x per k-mer in the probe kernel
+    c *= 0x9E3779B1u;   // one multiply (a bijection; the minimum looks at the well-mixed high bits first, and set_block_home re-mixes
+                        // the winner): this runs once per base in the insert kernel and 17x per k-mer in the probe kernel
     return c;
 }
 // smallest canonical m-mer hash over the m-mers starting at positions i0..i1 (inclusive) of the k-mer x
@@ -132,7 +133,7 @@ template <int W> KC_HD void set_place_local(const SetView<W> &s, const Key<W> &k
     *tag = kc_tag_mid(a, b, mh);
 }
 // minimizer length for k (0 = plain hashing): the middle must hold at least one m-mer
-static inline int kc_default_mlen(int k) { return k >= 17 ? 15 : 0; }
+static inline int kc_default_mlen(int k) { return k >= 18 ? 16 : 0; }   // 16: an m-mer is exactly one 32-bit word, no masking
 // XCD-aware workgroup order for kernels that sweep the table: workgroups are dealt round-robin over the 8 XCDs, so give
 // XCD j the j-th contiguous eighth of the sweep -- the workgroups resident on one XCD then work on neighbouring table
 // regions and share them through that XCD's L2 (speed only; correctness never depends on placement). Grid = multiple of 8.

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set,
         u32 need = 0, nq = 0;   // need: bit p = port p gets a record
         if (active) {
             slot = base + kc_list[t];
-            kc_cand_lookup_mid<W, KC, true, false>(set, k_rt, complements, slot, reinterpret_cast<const u8 *>(kc_stage), nullptr, sblk, cd);
+            kc_cand_lookup_mid<W, KC, true>(set, k_rt, complements, slot, reinterpret_cast<const u8 *>(kc_stage), sblk, cd);
 #pragma unroll
             for (int port = 0; port < 2; ++port) {
                 const u64 pid = (slot << 1) | (u64)port;
@@ -1138,7 +1138,7 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     if (!ctx || !comm || !out || (!seq && len)) return KC_E_ARG;
     *out = nullptr;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
-    if (k < 17 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 17 <= k <= 127");
+    if (k < 18 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
     if (flags & (KC_FLAG_SIMPLITIGS_INPUT | KC_FLAG_WANT_MASK) || ((flags >> 8) & 0xff) > 1)
         return kc_fail(ctx, KC_E_ARG, "-S, -M and -z are not part of the hash-sharded path (use kc_compute)");
     KC_HIP(ctx, hipSetDevice(ctx->device));

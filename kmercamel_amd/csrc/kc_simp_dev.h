@@ -5,6 +5,7 @@
 #include "kc_internal.h"
 #include "kc_scan_dev.h"
 
+#define KC_MSPEC 16   /* minimizer length the k = 31 / 63 / 127 specialisations are compiled for (= kc_default_mlen) */
 #define LK_OPEN 0ull
 #define LK_CHOICE 1ull
 #define LK_MATCHED 2ull
@@ -85,7 +86,7 @@ static __global__ void __launch_bounds__(256) kc_gather_shards_kernel(const u64 
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *total_out = ovf ? dst_cap + 1 : pre[KC_NSHARD];
 }
 
-// The 8 candidate lookups of one k-mer on a table with PLAIN hashing (set.m == 0, i.e. k < 17: every candidate has a home of
+// The 8 candidate lookups of one k-mer on a table with PLAIN hashing (set.m == 0, i.e. k < 18: every candidate has a home of
 // its own; tables with minimizer blocks go through kc_cand_lookup_mid below).
 #define KC_REMOTE (~(u64)1)
 template <int W> struct KcCand {
@@ -100,7 +101,7 @@ template <int W, int KC, bool SH>
 __device__ __forceinline__ void kc_cand_lookup(const SetView<W> &set, int k_rt, int complements, const u64 slot, const u64 *stage, const u64 sblk,
                                                KcCand<W> &out) {
     const int k = KC ? KC : k_rt;
-    const int m = KC ? 15 : set.m;
+    const int m = KC ? KC_MSPEC : set.m;
     const Key<W> x = set_key_at(set, slot);
     const Key<W> xr = key_rc(x, k);
     const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
@@ -326,117 +327,90 @@ template <int W> __device__ __forceinline__ Key<W> kc_neighbour_key(const Key<W>
 // window search says which extensions can exist and only those keys are compared.  Per k-mer: one pass over the k-m+1 m-mer
 // hashes (the minimizers of both candidate middles are a suffix / a prefix minimum of them), two placement hashes, two
 // homes, two window searches -- against eight of each with per-key homes.
-//   stage_tags: the tag bytes of table block `sblk`, staged in LDS (+ 8 bytes of slack), or nullptr
-//   SK: the keys of block `sblk` are staged too (stage_keys, W words per slot)
-//   SH (hash-sharded table): a port whose home lies in another rank's slot range is not looked up: its four candidates come
-//   back as KC_REMOTE and the owner answers the queries later.
-template <int W> struct KcCand2 {
-    Key<W> x, xr;    // the k-mer and its reverse complement
-    u64 cslot[8];    // candidate i = port (i >> 2), extension character (i & 3): its slot, KC_NONE64 (absent or not a legal edge), or KC_REMOTE
-    u64 phome[2];    // the home the 4 candidates of port L (0) / R (1) share
-    u32 qbits;       // bit i: the port on which candidate i is entered (set for the candidates that were found)
-    bool xpal;       // x is its own reverse complement (links on port L only)
+struct KcPortDesc {
+    u64 home;        // the home the 4 candidates of the port share
+    u32 pat, msk;    // tag pattern of the candidates and the bits of it that are fixed (the free field is the extension)
+    u32 flags;       // bit 0: the middle is read reversed; bit 1: the fixed outer character is field a; bit 2: palindromic middle (generic lookups)
 };
-template <int W, int KC, bool SH, bool SK>
-__device__ __forceinline__ void kc_cand_lookup_mid(const SetView<W> &set, int k_rt, int complements, const u64 slot, const u8 *stage_tags,
-                                                   const u64 *stage_keys, const u64 sblk, KcCand2<W> &out) {
-    const int k = KC ? KC : k_rt;
-    const int m = KC ? 15 : set.m;
-    const u32 bmask = (1u << set.bshift) - 1u;
-    auto load_key = [&](u64 s) {
-        Key<W> r;
-        if (SK && (s >> set.bshift) == sblk) {
-#pragma unroll
-            for (int w = 0; w < W; ++w) r.w[w] = stage_keys[(size_t)((u32)s & bmask) * W + w];
-        } else r = set_key_at(set, s);
-        return r;
-    };
-    const Key<W> x = load_key(slot);
-    const Key<W> xr = key_rc(x, k);
-    const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
-    // minimizers of the two candidate middles: m-mer starts 2..k-m (append side) and 0..k-m-2 (prepend side) of x
-    u32 minR = ~0u, minL = ~0u;
-    {
-        const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
-        const int top = 2 * (m - 1);
-        u32 f = 0, r = 0;
-        if constexpr (W != 1) {
-#pragma unroll
-            for (int j = 0; j < m - 1; ++j) {
-                u32 b = key_at(x, k, j);
-                f = (f << 2) | b;
-                r = (r >> 2) | ((3u - b) << top);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i <= k - m; ++i) {
-            if constexpr (W == 1) {   // one word: every m-mer is a shift of x / RC(x), no serial dependency between positions
-                f = (u32)(x.w[0] >> (2 * (k - m - i))) & maskm;
-                r = (u32)(xr.w[0] >> (2 * i)) & maskm;
-            } else {
-                u32 b = key_at(x, k, i + m - 1);
-                f = ((f << 2) | b) & maskm;
-                r = (r >> 2) | ((3u - b) << top);
-            }
-            const u32 h = kc_mmer_hash(f, r);
-            if (i >= 2) minR = h < minR ? h : minR;
-            if (i <= k - m - 2) minL = h < minL ? h : minL;
-        }
-    }
-    u64 (&cslot)[8] = out.cslot;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) cslot[i] = KC_NONE64;
-    u32 qbits = 0;
+// descriptor of port `port` (0 = L / prepend side, 1 = R / append side) of x; mmh = minimizer hash of the candidates' middle
+template <int W, int KC>
+__device__ __forceinline__ KcPortDesc kc_port_desc(const SetView<W> &set, const Key<W> &x, const Key<W> &xr, int k, int complements, int port, u32 mmh) {
     const Key<W> lm = key_lowmask<W>(2 * (k - 2));
-    // per port: canonical middle of its candidates, home, search pattern
-    u64 home[2], word[2];
-    u32 pat[2], msk[2], revf[2], fixa[2], inb[2], slowp = 0, rem = 0;
+    const Key<W> mf = port ? key_and(x, lm) : key_shr(x, 4);
+    const Key<W> mr = port ? key_shr(xr, 4) : key_and(xr, lm);
+    const bool rev = complements && key_lt(mr, mf);
+    const bool tie = !(KC & 1) && complements && key_eq(mr, mf);   // palindromic middle (even k only): the tags say nothing
+    const Key<W> M = rev ? mr : mf;
+    const u64 mh = key_place_hash(M);
+    // the character the candidates share next to the middle: x[1] (append side) / x[k-2] (prepend side); reading the candidate in
+    // the middle's canonical orientation it is the FIRST outer character (field a) for append & forward or prepend & reversed,
+    // else the last one (field b); a reversed reading complements it.  The other field is the extension.
+    const u32 fx = port ? key_at(x, k, 1) : (u32)((x.w[0] >> 2) & 3);
+    const bool fa = port ? !rev : rev;
+    const u32 fval = rev ? 3u - fx : fx;
+    KcPortDesc d;
+    d.home = set_block_home(set, mmh, mh);
+    d.pat = 0x80u | ((u32)mh & 7u) | (fa ? fval << 5 : fval << 3);
+    d.msk = fa ? 0xE7u : 0x9Fu;
+    d.flags = (rev ? 1u : 0u) | (fa ? 2u : 0u) | (tie ? 4u : 0u);
+    return d;
+}
+// minimizer hash of a middle given forward (mid) and reverse complement (midr), both (k-2)-mers
+template <int W, int KC>
+__device__ __forceinline__ u32 kc_mid_min(const Key<W> &mid, const Key<W> &midr, int k, int m) {
+    const int k2 = k - 2;
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    u32 best = ~0u;
+    if constexpr (W == 1) {
 #pragma unroll
-    for (int port = 0; port < 2; ++port) {
-        const Key<W> mf = port ? key_and(x, lm) : key_shr(x, 4);
-        const Key<W> mr = port ? key_shr(xr, 4) : key_and(xr, lm);
-        const bool rev = complements && key_lt(mr, mf);
-        if (!(KC & 1) && complements && key_eq(mr, mf)) slowp |= 1u << port;   // palindromic middle (even k only): the tags say nothing, generic lookups
-        const Key<W> M = rev ? mr : mf;
-        const u64 mh = key_place_hash(M);
-        home[port] = set_block_home(set, port ? minR : minL, mh);
-        // the character the candidates share next to the middle: x[1] (append side) / x[k-2] (prepend side); reading the
-        // candidate in the middle's canonical orientation it is the FIRST outer character (field a) for append & forward or
-        // prepend & reversed, else the last one (field b); a reversed reading complements it.  The other field is the extension.
-        const u32 fx = port ? key_at(x, k, 1) : (u32)((x.w[0] >> 2) & 3);
-        const bool fa = port ? !rev : rev;
-        const u32 fval = rev ? 3u - fx : fx;
-        pat[port] = 0x80u | ((u32)mh & 7u) | (fa ? fval << 5 : fval << 3);
-        msk[port] = fa ? 0xE7u : 0x9Fu;
-        revf[port] = rev ? 1u : 0u;
-        fixa[port] = fa ? 1u : 0u;
-        inb[port] = (home[port] >> set.bshift) == sblk ? 1u : 0u;
-        if (SH && home[port] - set.rlo >= set.rcap) rem |= 1u << port;
-        out.phome[port] = home[port];
-    }
-    if (xpal) slowp &= 1u;   // port R of a palindrome is dead: nothing to look up
-    // first tag windows of both ports (LDS for in-block homes, one unaligned 8-byte global load otherwise), issued together
-#pragma unroll
-    for (int port = 0; port < 2; ++port) {
-        const bool skip = ((rem >> port) & 1u) || (port == 1 && xpal);
-        if (inb[port] && stage_tags) __builtin_memcpy(&word[port], stage_tags + ((u32)home[port] & bmask), 8);   // (gfx950 reads LDS at any byte offset)
-        else __builtin_memcpy(&word[port], set.tags + (skip ? slot : home[port]), 8);                          // skipped ports read x's own window: harmless
-    }
-#pragma unroll
-    for (int port = 0; port < 2; ++port) {
-        if (port == 1 && xpal) continue;
-        if ((rem >> port) & 1u) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cslot[port * 4 + c] = KC_REMOTE;
-            continue;
+        for (int i = 0; i <= k2 - m; ++i) {
+            const u32 f = (u32)(mid.w[0] >> (2 * (k2 - m - i))) & maskm, r = (u32)(midr.w[0] >> (2 * i)) & maskm;
+            const u32 h = kc_mmer_hash(f, r);
+            best = h < best ? h : best;
         }
-        if ((slowp >> port) & 1u) continue;
+    } else {
+        best = key_min_mmh(mid, k2, m, 0, k2 - m);
+        (void)midr;
+    }
+    return best;
+}
+// generic lookups of the 4 candidates of a port (palindromic middles, overfull blocks whose keys went to their second home)
+template <int W>
+__device__ __forceinline__ void kc_port_search_generic(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, int port,
+                                                       u64 (&cs)[4], u32 &qb) {
+    qb = 0;
+#pragma unroll
+    for (u32 c = 0; c < 4; ++c) {
+        int q;
+        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+        cs[c] = KC_NONE64;
+        if (key_eq(y, x)) continue;
+        const u64 sl = set_find(set, y);
+        cs[c] = sl;
+        if (sl != KC_NONE64) qb |= (u32)q << c;
+    }
+}
+// Search the probe run of one port.  cs[c] = slot of the candidate with extension c (appended on port R, prepended on port L) or
+// KC_NONE64; bit c of qb = the port that candidate is entered on.  Returns false when the window search cannot settle the port
+// (palindromic middle, local probe run exhausted): the caller then uses kc_port_search_generic, or hands the port on.
+//   LT: the home lies in block `sblk` whose tags are staged in LDS (stage_tags); SK: that block's keys are staged too.
+template <int W, bool LT, bool SK>
+__device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, const u64 slot, int port,
+                                               const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, u64 (&cs)[4], u32 &qb) {
+    const u32 bmask = (1u << set.bshift) - 1u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cs[c] = KC_NONE64;
+    qb = 0;
+    bool slow = (d.flags & 4u) != 0;
+    if (!slow) {
         const u32 lo7 = 0x7f7f7f7fu, hi7 = 0x80808080u, gather = 0x204081u;
-        const u32 pat4 = pat[port] * 0x01010101u, msk4 = msk[port] * 0x01010101u;
-        u64 wd = word[port];
+        const u32 pat4 = d.pat * 0x01010101u, msk4 = d.msk * 0x01010101u;
+        const u8 *tg = LT ? stage_tags + ((u32)d.home & bmask) : set.tags + d.home;
         u32 off = 0;
         while (true) {
-            // "byte matches the pattern on the masked bits" and "byte is empty" become one bit per byte (bit 7), and a multiply gathers
+            u64 wd;
+            __builtin_memcpy(&wd, tg + off, 8);   // 8 tags in one unaligned load (gfx950 reads LDS at any byte offset too)
+            // "byte matches the pattern on the fixed bits" and "byte is empty" become one bit per byte (bit 7), and a multiply gathers
             // the four bits of a half into a nibble -- (h * 0x204081) >> 28 -- so that everything else works on two 8-bit masks
             const u32 wl = (u32)wd, wh = (u32)(wd >> 32);
             const u32 xl = (wl ^ pat4) & msk4, xh = (wh ^ pat4) & msk4;
@@ -445,51 +419,175 @@ __device__ __forceinline__ void kc_cand_lookup_mid(const SetView<W> &set, int k_
             const u32 M8 = ((ml * gather) >> 28) | (((mh4 * gather) >> 28) << 4);
             u32 E8 = ((el * gather) >> 28) | (((eh * gather) >> 28) << 4);
             const u32 left = set.local_probes - off;                 // slots of the local probe run still ahead
-            if (left < 8) E8 |= 1u << left;                           // (the run ends inside this window: treated like an empty slot, see below)
+            if (left < 8) E8 |= 1u << left;                           // the run ends inside this window: treated like an empty slot, see below
             const u32 fe = (u32)__builtin_ctz(E8 | 0x100u);          // first empty slot of the window (8: none)
             u32 H = M8 & ((1u << fe) - 1u);                           // no deletions: a key lies before the first empty slot after its home
             while (H) {
                 const u32 j = (u32)__builtin_ctz(H);
                 H &= H - 1u;
-                const u32 tb = (u32)(wd >> (8 * j)) & 0xffu;
-                const u32 v = fixa[port] ? (tb >> 3) & 3u : (tb >> 5) & 3u;
-                const u32 c = revf[port] ? 3u - v : v;
-                const u64 sl = home[port] + (u64)(off + j);
+                const u64 sl = d.home + (u64)(off + j);
                 if (sl == slot) continue;                             // x itself (no self edges)
-                const Key<W> kk = load_key(sl);
-                int q;
-                const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
-                if (key_eq(kk, y)) {
+                Key<W> kk;
+                if (LT && SK) {
+#pragma unroll
+                    for (int w = 0; w < W; ++w) kk.w[w] = stage_keys[(size_t)((u32)sl & bmask) * W + w];
+                } else kk = set_key_at(set, sl);
+                u32 c, q;
+                if (kc_neighbour_match(kk, x, xr, port, k, complements, c, q)) {
 #pragma unroll
                     for (u32 cc = 0; cc < 4; ++cc)
-                        if (c == cc) cslot[port * 4 + cc] = sl;       // (selects: a run-time index would send the array to scratch memory)
-                    qbits |= (u32)q << (port * 4 + c);
+                        if (c == cc) cs[cc] = sl;                     // (selects: a run-time index would send the array to scratch memory)
+                    qb |= q << c;
                 }
             }
             if (fe < 8 && !(left < 8 && fe == left)) break;          // a real empty slot: every candidate of this home has been seen
-            if (left <= 8) { slowp |= 1u << port; break; }            // local run exhausted: the rest may sit at the second home
+            if (left <= 8) { slow = true; break; }                    // local run exhausted: the rest may sit at the second home
             off += 8;
-            if (inb[port] && stage_tags) __builtin_memcpy(&wd, stage_tags + ((u32)home[port] & bmask) + off, 8);
-            else __builtin_memcpy(&wd, set.tags + home[port] + off, 8);
         }
     }
-    if (slowp) {   // palindromic middles, overfull blocks: one generic lookup per candidate (finds what the window search found again)
+    return !slow;
+}
+
+// Is the stored key kk a neighbour of x on `port`?  A neighbour is x shifted by one character with the extension c at the free
+// end, or the reverse complement of that: kk XOR (the shifted x, or the shifted RC(x)) is then zero outside the extension
+// position.  (Stored keys are canonical, so a match with either strand is the canonical candidate; no candidate key is built.)
+// Returns found, the extension character c (appended on port R / prepended on port L) and the port q that kk is entered on.
+template <int W>
+__device__ __forceinline__ bool kc_neighbour_match(const Key<W> &kk, const Key<W> &x, const Key<W> &xr, int port, int k, int complements, u32 &c, u32 &q) {
+    const Key<W> lowm = key_lowmask<W>(2 * k);
+    // the strand whose extension sits at the LOW end: x (append side) / RC(x) (prepend side); the other strand has it at the top
+    const Key<W> &sl = port ? x : xr, &sh = port ? xr : x;
+    Key<W> dl = key_and(key_shl(sl, 2), lowm), dh = key_shr(sh, 2);
 #pragma unroll
-        for (int port = 0; port < 2; ++port) {
-            if (!((slowp >> port) & 1u)) continue;
-            for (u32 c = 0; c < 4; ++c) {
-                int q;
-                const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
-                if (key_eq(y, x)) continue;
-                const u64 sl = set_find(set, y);
+    for (int w = 0; w < W; ++w) { dl.w[w] ^= kk.w[w]; dh.w[w] ^= kk.w[w]; }
+    const u32 cl = (u32)dl.w[0] & 3u;
+    const int ts = 2 * (k - 1), tw = ts >> 6;
+    u64 hv = dh.w[0];
 #pragma unroll
-                for (u32 cc = 0; cc < 4; ++cc)
-                    if (c == cc) cslot[port * 4 + cc] = sl;
-                if (sl != KC_NONE64) qbits |= (u32)q << (port * 4 + c);
-            }
+    for (int w = 1; w < W; ++w) hv = (tw == w) ? dh.w[w] : hv;
+    const u32 ch = (u32)(hv >> (ts & 63)) & 3u;
+    dl.w[0] &= ~(u64)3;
+    bool lz = true, hz = true;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        lz = lz && dl.w[w] == 0;
+        hz = hz && (dh.w[w] & ~((tw == w) ? ((u64)3 << (ts & 63)) : (u64)0)) == 0;
+    }
+    // append side: forward = low match (c = cl), reverse = high match (c = 3 - ch); prepend side: forward = high match (c = ch),
+    // reverse = low match (c = 3 - cl)
+    const bool fwd = port ? lz : hz, rev = complements && (port ? hz : lz);
+    const u32 cf = port ? cl : ch, cr = 3u - (port ? ch : cl);
+    c = fwd ? cf : cr;
+    q = (fwd && rev) ? 0u : (fwd ? (port ? 0u : 1u) : (port ? 1u : 0u));   // entering y on L if it is the forward strand of an append (...); palindromes: L
+    return fwd || rev;
+}
+
+// The common case of kc_port_search for a home in the staged block, without loops: ONE window, settled iff it holds an empty slot
+// with at most one tag match before it (then that key decides).  Anything else -- no empty slot among the 8, a second match (a tag
+// false positive or a branch), a palindromic middle -- returns false and the port is looked up by the loop version later, pooled
+// with the ports of other k-mers: inside the sweep a second loop trip for 2 of 64 lanes costs the whole wave a trip.
+template <int W, bool SK>
+__device__ __forceinline__ bool kc_port_search_one(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, const u64 slot, int port,
+                                                   const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, bool &found, u32 &c, u32 &q, u64 &sl) {
+    const u32 bmask = (1u << set.bshift) - 1u;
+    const u32 lo7 = 0x7f7f7f7fu, hi7 = 0x80808080u, gather = 0x204081u;
+    const u32 pat4 = d.pat * 0x01010101u, msk4 = d.msk * 0x01010101u;
+    u64 wd;
+    __builtin_memcpy(&wd, stage_tags + ((u32)d.home & bmask), 8);
+    const u32 wl = (u32)wd, wh = (u32)(wd >> 32);
+    const u32 xl = (wl ^ pat4) & msk4, xh = (wh ^ pat4) & msk4;
+    const u32 ml = ~(((xl & lo7) + lo7) | xl) & hi7, mh4 = ~(((xh & lo7) + lo7) | xh) & hi7;
+    const u32 el = ~wl & hi7, eh = ~wh & hi7;
+    const u32 M8 = ((ml * gather) >> 28) | (((mh4 * gather) >> 28) << 4);
+    u32 E8 = ((el * gather) >> 28) | (((eh * gather) >> 28) << 4);
+    if (set.local_probes < 8) E8 = 0;                               // (test knob: short local runs always take the loop version)
+    const u32 fe = (u32)__builtin_ctz(E8 | 0x100u);                // first empty slot of the window (8: none)
+    const u32 H = M8 & ((1u << fe) - 1u);
+    found = false; c = 0; q = 0; sl = slot;
+    if ((d.flags & 4u) || fe == 8 || (H & (H - 1u))) return false;
+    const u32 j = (u32)__builtin_ctz(H | 0x100u);                  // the one match, if any (8: none -- then x's own key is read: harmless)
+    sl = H ? d.home + (u64)j : slot;
+    Key<W> kk;
+    if (SK) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) kk.w[w] = stage_keys[(size_t)((u32)sl & bmask) * W + w];
+    } else kk = set_key_at(set, sl);
+    found = kc_neighbour_match(kk, x, xr, port, k, complements, c, q) && H != 0 && sl != slot;   // (sl == slot: x itself, no self edges)
+    return true;
+}
+
+// The two ports of one k-mer in one go (hash-sharded flow).  SH: a port whose home lies in another rank's slot range is not
+// looked up: its four candidates come back as KC_REMOTE and the owner answers the queries later.
+template <int W> struct KcCand2 {
+    Key<W> x, xr;    // the k-mer and its reverse complement
+    u64 cslot[8];    // candidate i = port (i >> 2), extension character (i & 3): its slot, KC_NONE64 (absent or not a legal edge), or KC_REMOTE
+    u64 phome[2];    // the home the 4 candidates of port L (0) / R (1) share
+    u32 qbits;       // bit i: the port on which candidate i is entered (set for the candidates that were found)
+    bool xpal;       // x is its own reverse complement (links on port L only)
+};
+// x, RC(x) and the minimizer hashes of the two candidate middles: m-mer starts 2..k-m (append side) / 0..k-m-2 (prepend side) of x
+template <int W, int KC>
+__device__ __forceinline__ void kc_kmer_mins(const Key<W> &x, const Key<W> &xr, int k, int m, u32 &minL, u32 &minR) {
+    minR = ~0u; minL = ~0u;
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const int top = 2 * (m - 1);
+    u32 f = 0, r = 0;
+    if constexpr (W != 1) {
+#pragma unroll
+        for (int j = 0; j < m - 1; ++j) {
+            u32 b = key_at(x, k, j);
+            f = (f << 2) | b;
+            r = (r >> 2) | ((3u - b) << top);
         }
     }
-    out.x = x; out.xr = xr; out.qbits = qbits; out.xpal = xpal;
+#pragma unroll
+    for (int i = 0; i <= k - m; ++i) {
+        if constexpr (W == 1) {   // one word: every m-mer is a shift of x / RC(x), no serial dependency between positions
+            f = (u32)(x.w[0] >> (2 * (k - m - i))) & maskm;
+            r = (u32)(xr.w[0] >> (2 * i)) & maskm;
+        } else {
+            u32 b = key_at(x, k, i + m - 1);
+            f = ((f << 2) | b) & maskm;
+            r = (r >> 2) | ((3u - b) << top);
+        }
+        const u32 h = kc_mmer_hash(f, r);
+        if (i >= 2) minR = h < minR ? h : minR;
+        if (i <= k - m - 2) minL = h < minL ? h : minL;
+    }
+}
+template <int W, int KC, bool SH>
+__device__ __forceinline__ void kc_cand_lookup_mid(const SetView<W> &set, int k_rt, int complements, const u64 slot, const u8 *stage_tags, const u64 sblk,
+                                                   KcCand2<W> &out) {
+    const int k = KC ? KC : k_rt;
+    const int m = KC ? KC_MSPEC : set.m;
+    const Key<W> x = set_key_at(set, slot);
+    const Key<W> xr = key_rc(x, k);
+    out.x = x; out.xr = xr;
+    out.xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
+    u32 minL, minR;
+    kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
+    u32 qbits = 0;
+#pragma unroll
+    for (int port = 0; port < 2; ++port) {
+        u64 cs[4] = {KC_NONE64, KC_NONE64, KC_NONE64, KC_NONE64};
+        u32 qb = 0;
+        const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, port ? minR : minL);
+        out.phome[port] = d.home;
+        if (port == 1 && out.xpal) {
+        } else if (SH && d.home - set.rlo >= set.rcap) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cs[c] = KC_REMOTE;
+        } else {
+            bool ok;
+            if (stage_tags && (d.home >> set.bshift) == sblk) ok = kc_port_search<W, true, false>(set, k, complements, x, xr, slot, port, d, stage_tags, nullptr, cs, qb);
+            else ok = kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb);
+            if (!ok) kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out.cslot[port * 4 + c] = cs[c];
+        qbits |= qb << (port * 4);
+    }
+    out.qbits = qbits;
 }
 
 // Round 1: one thread per k-mer handles both ports (they share x, RC(x), hash(x) and one pass
@@ -575,98 +673,231 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
 }
 
 // ---- round 1 on a table with middle-based homes: one workgroup per table block.  The block's tag bytes and (single-word keys)
-// its keys are staged in LDS with coalesced 16-byte loads; ~90 % of the lookups of the block's k-mers start and end in that
-// very block, so they touch LDS only.  The block is swept in quarters: the occupied slots of a quarter are listed in LDS
-// (so that the lanes stay dense), then every listed k-mer looks up both of its ports (kc_cand_lookup_mid) and writes its
-// two link words.  LDS: tags + keys + the list = 78 KB for 8192-slot blocks of 64-bit keys, two workgroups per CU.
+// its keys are staged in LDS with coalesced 16-byte loads; ~90 % of the ports of the block's k-mers have their home in that
+// very block, so they are settled out of LDS.  The block is swept in quarters: the occupied slots of a quarter are listed in
+// LDS (so that the lanes stay dense), every listed k-mer settles its in-block ports and lists the others; the listed
+// ("external") ports are then looked up in global memory with every lane busy -- handled inline they made each sweep step of
+// every wave wait for two dependent global round trips on behalf of a few lanes (measured: waves waited 70 % of their cycles).
+// LDS: tags + keys + the two lists = 76 KB for 8192-slot blocks of 64-bit keys, two workgroups per CU (80 KB each did not fit twice).
 template <int W>
-__device__ __forceinline__ void kc_choose_write(const SetView<W> &set, u64 *__restrict__ link, int k, int complements, const u64 slot, const KcCand2<W> &cd,
-                                                u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch, u64 branch_shard_cap,
-                                                u64 *branch_cursors) {
-    const Key<W> &x = cd.x;
-    const u64 (&cslot)[8] = cd.cslot;
+__device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 slot, const int port, const Key<W> &x,
+                                               const Key<W> &xr, const u64 (&cs)[4], const u32 qb, u64 *heads, u64 heads_shard_cap, u64 *heads_cursors,
+                                               u64 *branch, u64 branch_shard_cap, u64 *branch_cursors) {
     // every ~256th k-mer (by slot) is a splitter: chains are walked segment-wise between splitters
     const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;
+    const u64 pid = (slot << 1) | (u64)port;
+    int nfound = 0;
+    u32 bc = 0, bq = 0;
+    u64 bslot = 0;
 #pragma unroll
-    for (int port = 0; port < 2; ++port) {
-        const u64 pid = (slot << 1) | (u64)port;
-        if (port == 1 && cd.xpal) {
-            link[pid] = LK_DEAD | splitbit;
-            if (complements) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);
-            continue;
-        }
-        int nfound = 0;
-        u32 bc = 0, bq = 0;
-        u64 bslot = 0;
-#pragma unroll
-        for (u32 c = 0; c < 4; ++c) {
-            const int i = port * 4 + (int)c;
-            if (cslot[i] == KC_NONE64) continue;
-            ++nfound; bc = c; bslot = cslot[i]; bq = (cd.qbits >> i) & 1u;
-        }
-        if (nfound >= 2) {   // a branch port (rare): the best edge by the layout-free priority; the port will reject the others
-            const u64 hxk = key_hash(x);
-            Key<W> by = x; u64 bpr = 0; bool have = false;
-            for (u32 c = 0; c < 4; ++c) {
-                u64 ts = KC_NONE64;
-#pragma unroll
-                for (u32 cc = 0; cc < 4; ++cc) ts = (c == cc) ? cslot[port * 4 + cc] : ts;
-                if (ts == KC_NONE64) continue;
-                int q;
-                const Key<W> y = kc_neighbour_key_q(x, cd.xr, port, c, k, complements, q);
-                const u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
-                if (!have || edge_preferred(x, port, y, q, pr, by, (int)bq, bpr)) { by = y; bq = (u32)q; bpr = pr; bslot = ts; bc = c; have = true; }
-            }
-        }
-        link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD) | splitbit;
-        if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
-        if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);
+    for (u32 c = 0; c < 4; ++c) {
+        if (cs[c] == KC_NONE64) continue;
+        ++nfound; bc = c; bslot = cs[c]; bq = (qb >> c) & 1u;
     }
+    if (nfound >= 2) {   // a branch port (rare): the best edge by the layout-free priority; the port will reject the others
+        const u64 hxk = key_hash(x);
+        Key<W> by = x; u64 bpr = 0; bool have = false;
+        for (u32 c = 0; c < 4; ++c) {
+            u64 ts = KC_NONE64;
+#pragma unroll
+            for (u32 cc = 0; cc < 4; ++cc) ts = (c == cc) ? cs[cc] : ts;
+            if (ts == KC_NONE64) continue;
+            int q;
+            const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+            const u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
+            if (!have || edge_preferred(x, port, y, q, pr, by, (int)bq, bpr)) { by = y; bq = (u32)q; bpr = pr; bslot = ts; bc = c; have = true; }
+        }
+    }
+    if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+    if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);
+    return (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD) | splitbit;
 }
 
 #define KC_PROBE_THREADS 512
-#define KC_PROBE_QUARTER 2048
+#define KC_PROBE_WAVES (KC_PROBE_THREADS / 64)
+#define KC_PROBE_SSTACK 128   /* per wave: occupied slots waiting for a full step (< 64 left over + 64 new) */
+#define KC_PROBE_ESTACK 120   /* per wave: listed ports waiting for a full step (< 64 left over + up to 64 new per port; more go to the spill list) */
+static inline size_t kc_probe_lds_bytes(int bshift, int W, bool stage_keys) {
+    const size_t bs = (size_t)1 << bshift;
+    return bs + (stage_keys ? bs * W * 8 : 0) + (size_t)KC_PROBE_WAVES * (KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK * 6);
+}
 template <int W, int KC, bool SK>
 __global__ void __launch_bounds__(KC_PROBE_THREADS) kc_probe_block_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
                                                                          u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
-                                                                         u64 branch_shard_cap, u64 *branch_cursors) {
-    // dynamic LDS: [tags: bs + 8 bytes, rounded up to 16][keys: bs * W words, if SK][list: min(bs, KC_PROBE_QUARTER) u16]
+                                                                         u64 branch_shard_cap, u64 *branch_cursors, u64 *spill, u64 spill_cap,
+                                                                         u64 *spill_cursor) {
+    // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
+    // [w bs/8, (w+1) bs/8) in rows of 64, pushes the occupied ones on its own stack and takes 64 off it whenever that many wait, so
+    // every step runs with all lanes busy and no wave ever waits for another (with block-wide lists and barriers every stretch
+    // ended in a nearly empty step that the other seven waves sat out: 4.1 ms against 3.6 ms per 10^8 k-mers).  A port that the
+    // one-window search does not settle (home in another block: ~10 %; second match or no empty slot in the window: ~5 %) goes on
+    // the wave's second stack with the minimizer hash of its middle, and is looked up in global memory 64 at a time.
+    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][per wave: slot stack u16 x 128, port stack u16 x 120 + u32 x 120]
     extern __shared__ ulonglong2 kc_pb[];
-    __shared__ u32 nlist;
+    const int k = KC ? KC : k_rt;
+    const int m = KC ? KC_MSPEC : set.m;
     const u64 blk = kc_xcd_block_id(xcd_aware);
     if (blk >= set.nblocks) return;
     const u32 bs = 1u << set.bshift;
     const u64 base = blk << set.bshift;
     u8 *st = reinterpret_cast<u8 *>(kc_pb);
-    const u32 tag_bytes = (bs + 8u + 15u) & ~15u;
-    u64 *sk = reinterpret_cast<u64 *>(st + tag_bytes);
-    unsigned short *list = reinterpret_cast<unsigned short *>(st + tag_bytes + (SK ? (size_t)bs * W * 8 : 0));
+    u64 *sk = reinterpret_cast<u64 *>(st + bs);
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    u8 *wbase = st + bs + (SK ? (size_t)bs * W * 8 : 0) + (size_t)wv * (KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK * 6);
+    unsigned short *sstack = reinterpret_cast<unsigned short *>(wbase);
+    u32 *emmh = reinterpret_cast<u32 *>(wbase + KC_PROBE_SSTACK * 2);
+    unsigned short *epid = reinterpret_cast<unsigned short *>(wbase + KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK * 4);
     {
         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(set.tags + base);
         for (u32 j = threadIdx.x; j < bs / 16; j += KC_PROBE_THREADS) kc_pb[j] = src[j];
-        if (threadIdx.x == 0) *reinterpret_cast<u64 *>(st + bs) = *reinterpret_cast<const u64 *>(set.tags + base + bs);   // (the table has 8 bytes of slack)
         if (SK) {
             const ulonglong2 *ksrc = reinterpret_cast<const ulonglong2 *>(set.keys + base * W);
             ulonglong2 *kdst = reinterpret_cast<ulonglong2 *>(sk);
             for (u32 j = threadIdx.x; j < bs * W / 2; j += KC_PROBE_THREADS) kdst[j] = ksrc[j];
         }
     }
-    const u32 qn = bs < KC_PROBE_QUARTER ? bs : KC_PROBE_QUARTER;
-    for (u32 q0 = 0; q0 < bs; q0 += qn) {
-        if (threadIdx.x == 0) nlist = 0;
-        __syncthreads();   // (first trip: also the staging above)
-        for (u32 i = threadIdx.x; i < qn; i += KC_PROBE_THREADS)
-            if (st[q0 + i] != 0) list[atomicAdd(&nlist, 1u)] = (unsigned short)(q0 + i);
-        __syncthreads();
-        const u32 n = nlist;
+    __syncthreads();
+    auto load_x = [&](u32 so) {
+        Key<W> r;
+        if (SK) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) r.w[w] = sk[(size_t)so * W + w];
+        } else r = set_key_at(set, base + so);
+        return r;
+    };
+    auto to_spill = [&](u64 pid) {
+        const u64 at = atomicAdd((ull *)spill_cursor, 1ULL);
+        if (at < spill_cap) spill[at] = pid;
+    };
+    const unsigned long long ltm = ((unsigned long long)1 << lane) - 1;
+    auto wave_sync = [&]() {   // LDS traffic between the lanes of this wave: the hardware keeps a wave's LDS instructions in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    u32 scnt = 0, ecnt = 0;   // entries on the two stacks (wave-uniform)
+    const u32 per_wave = bs / KC_PROBE_WAVES, rows = (per_wave + 63) / 64;
 #pragma unroll 1
-        for (u32 t = threadIdx.x; t < n; t += KC_PROBE_THREADS) {
-            const u64 slot = base + list[t];
-            KcCand2<W> cd;
-            kc_cand_lookup_mid<W, KC, false, SK>(set, k_rt, complements, slot, st, sk, blk, cd);
-            kc_choose_write<W>(set, link, KC ? KC : k_rt, complements, slot, cd, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+    for (u32 row = 0; row <= rows; ++row) {
+        const bool drain = row == rows;
+        if (!drain) {
+            const u32 off = row * 64 + (u32)lane, so = (u32)wv * per_wave + off;
+            const bool occ = off < per_wave && st[so] != 0;
+            const unsigned long long mk = __ballot(occ);
+            if (occ) sstack[scnt + (u32)__popcll(mk & ltm)] = (unsigned short)so;
+            scnt += (u32)__popcll(mk);
+            wave_sync();
         }
-        __syncthreads();
+#pragma unroll 1
+        while (scnt >= 64 || ecnt >= 64 || (drain && (scnt | ecnt))) {
+            if (ecnt >= 64 || (drain && scnt == 0)) {
+                // ---- 64 listed ports (fewer when draining): generic window search in global memory
+                const u32 take = ecnt < 64 ? ecnt : 64;
+                ecnt -= take;
+                if ((u32)lane < take) {
+                    const u32 e = epid[ecnt + lane], so = e >> 1;
+                    const int port = (int)(e & 1u);
+                    const u64 slot = base + so;
+                    const Key<W> x = load_x(so);
+                    const Key<W> xr = key_rc(x, k);
+                    const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, emmh[ecnt + lane]);
+                    u64 cs[4]; u32 qb;
+                    if (!kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb)) to_spill((slot << 1) | (u64)port);
+                    else link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors,
+                                                                           branch, branch_shard_cap, branch_cursors);
+                }
+                wave_sync();
+                continue;
+            }
+            // ---- 64 k-mers (fewer when draining)
+            const u32 take = scnt < 64 ? scnt : 64;
+            scnt -= take;
+            const bool active = (u32)lane < take;
+            const u32 so = active ? sstack[scnt + lane] : 0u;
+            const u64 slot = base + so;
+            const Key<W> x = load_x(so);
+            const Key<W> xr = key_rc(x, k);
+            const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
+            const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;           // every ~256th k-mer (by slot) is a splitter of the segment-parallel walks
+            u32 minL, minR;
+            kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
+            u64 wd0 = 0, wd1 = 0;
+            u32 have = 0;
+#pragma unroll 1
+            for (int port = 0; port < 2; ++port) {
+                bool defer = false, done = false;
+                u64 word = 0;
+                const u32 mmh = port ? minR : minL;
+                if (active) {
+                    if (port == 1 && xpal) {   // palindromes link on port L only
+                        word = LK_DEAD | splitbit;
+                        done = true;
+                        if (complements) kc_push_sharded((slot << 1) | 1, heads, heads_shard_cap, heads_cursors);
+                    } else {
+                        const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
+                        bool found; u32 c, q; u64 sl;
+                        if ((d.home >> set.bshift) == blk && kc_port_search_one<W, SK>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl)) {
+                            word = (found ? LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) : LK_DEAD) | splitbit;
+                            done = true;
+                            if (!found && (complements || port == 0)) kc_push_sharded((slot << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+                        } else defer = true;
+                    }
+                }
+                const unsigned long long dm = __ballot(defer);
+                if (dm) {
+                    const u32 nd = (u32)__popcll(dm);
+                    if (ecnt + nd <= KC_PROBE_ESTACK) {
+                        if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); emmh[at] = mmh; }
+                        ecnt += nd;
+                    } else if (defer) to_spill((slot << 1) | (u64)port);
+                }
+                if (done) { if (port) wd1 = word; else wd0 = word; have |= 1u << port; }
+            }
+            // both words of a slot in one 16-byte store whenever both ports were settled here
+            if (have == 3u) *reinterpret_cast<ulonglong2 *>(link + (slot << 1)) = make_ulonglong2(wd0, wd1);
+            else if (have == 1u) link[slot << 1] = wd0;
+            else if (have == 2u) link[(slot << 1) | 1] = wd1;
+            wave_sync();
+        }
+    }
+}
+// the ports the block kernel handed on (rare): generic lookups, one thread per port, grid-stride over the device-side count
+template <int W>
+__global__ void __launch_bounds__(256) kc_probe_spill_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ spill,
+                                                             u64 spill_cap, const u64 *__restrict__ spill_cursor, u64 *heads, u64 heads_shard_cap,
+                                                             u64 *heads_cursors, u64 *branch, u64 branch_shard_cap, u64 *branch_cursors) {
+    u64 n = *spill_cursor;
+    if (n > spill_cap) n = spill_cap;   // (overflow: the caller redoes round 1 with the generic kernel)
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
+        const u64 pid = spill[t], slot = pid >> 1;
+        const int port = (int)(pid & 1);
+        const Key<W> x = set_key_at(set, slot);
+        const Key<W> xr = key_rc(x, k);
+        u64 cs[4]; u32 qb;
+        kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+        link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+    }
+}
+
+// round 1 by generic lookups over the whole table, one thread per slot: the fallback when the spill list of the block kernel
+// overflows (tables with many overfull blocks)
+template <int W>
+__global__ void __launch_bounds__(256) kc_probe_generic_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements, u64 *heads, u64 heads_shard_cap,
+                                                               u64 *heads_cursors, u64 *branch, u64 branch_shard_cap, u64 *branch_cursors) {
+    const u64 slot = kc_gtid();
+    if (slot >= set.cap || set.tags[slot] == 0) return;
+    const Key<W> x = set_key_at(set, slot);
+    const Key<W> xr = key_rc(x, k);
+    const bool xpal = complements && key_eq(x, xr);
+    for (int port = 0; port < 2; ++port) {
+        if (port == 1 && xpal) {
+            link[(slot << 1) | 1] = LK_DEAD | (((slot & 0xffull) == 0) ? LK_SPLIT : 0);
+            if (complements) kc_push_sharded((slot << 1) | 1, heads, heads_shard_cap, heads_cursors);
+            continue;
+        }
+        u64 cs[4]; u32 qb;
+        kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+        link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
     }
 }
 

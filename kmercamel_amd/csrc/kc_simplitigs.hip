@@ -819,28 +819,50 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
     // compile-time k for the benchmark configurations (k = 31 / 63 / 127 with m = 15): constant trip counts everywhere
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
-    const bool kspec = k == KSPEC && set->mlen == 15 && !getenv("KC_NO_KSPEC");
+    const bool kspec = k == KSPEC && set->mlen == KC_MSPEC && !getenv("KC_NO_KSPEC");
+    u64 *spill = nullptr, *spill_cursor = cnt + 6;
+    const u64 spill_cap = N / 64 + 65536;
     if (set->mlen) {
+        KC_TRY(scope.alloc(&spill, spill_cap));
         // middle-based homes: one workgroup per block, tags (and single-word keys of blocks up to 8192 slots) staged in LDS
-        const u32 bs = 1u << set->bshift;
         const bool stage_keys = W == 1 && set->bshift <= 13 && !getenv("KC_NOSTAGE");
-        const size_t lds = ((bs + 8 + 15) & ~(size_t)15) + (stage_keys ? (size_t)bs * W * 8 : 0) + (size_t)(bs < KC_PROBE_QUARTER ? bs : KC_PROBE_QUARTER) * 2;
+        const size_t lds = kc_probe_lds_bytes(set->bshift, W, stage_keys) + (getenv("KC_PROBE_PAD") ? (size_t)atoi(getenv("KC_PROBE_PAD")) : 0);
         const unsigned pgrid = (unsigned)((set->nblocks + 7) / 8 * 8);
         auto launch = [&](auto kern) -> int {
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (getenv("KC_SIMP_TRACE")) {
+                int nb = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), KC_PROBE_THREADS, lds);
+                fprintf(stderr, "[simp] probe kernel: %zu bytes of LDS per workgroup, %d workgroups per CU\n", lds, nb);
+            }
             hipLaunchKernelGGL(kern, dim3(pgrid), dim3(KC_PROBE_THREADS), lds, ctx->stream, sv, link, k, compl_, xcd_aware, heads_sh, heads_shard_cap,
-                               heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
+                               heads_cursors, branch_sh, branch_shard_cap, branch_cursors, spill, spill_cap, spill_cursor);
             return KC_OK;
         };
         if (stage_keys) { if constexpr (W == 1) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true>) : launch(kc_probe_block_kernel<W, 0, true>)); }
         else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false>) : launch(kc_probe_block_kernel<W, 0, false>));
     } else {
-        // plain hashing (k < 17): per-key homes, 8 lookups per k-mer
+        // plain hashing (k < 18): per-key homes, 8 lookups per k-mer
         const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);
         hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), 0, ctx->stream, sv, link, k, compl_, xcd_aware,
                            heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, 0);
     }
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    if (set->mlen) {
+        // the ports the block kernel handed on (window search not applicable, external list full); if even their list overflowed,
+        // round 1 is redone by generic lookups
+        hipLaunchKernelGGL((kc_probe_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)spill, spill_cap,
+                           (const u64 *)spill_cursor, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
+        u64 nspill = 0;
+        KC_TRY(read_u64(ctx, spill_cursor, &nspill));
+        if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] round 1: %llu ports handed to the generic lookups\n", (unsigned long long)nspill);
+        if (nspill > spill_cap) {
+            KC_HIP(ctx, hipMemsetAsync(shard_cur, 0, 2 * KC_NSHARD * KC_SHARD_STRIDE * 8, ctx->stream));
+            hipLaunchKernelGGL((kc_probe_generic_kernel<W>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, link, k, compl_, heads_sh, heads_shard_cap,
+                               heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
+        }
+        scope.release(spill);
+    }
     hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
                        (const u64 *)heads_cursors, heads, heads_cap, heads_cursor);
     hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)branch_sh, branch_shard_cap,

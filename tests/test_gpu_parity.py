@@ -149,7 +149,7 @@ def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, mon
     for name, value in knobs.items():
         monkeypatch.setenv(name, value)
     rng = random.Random(4242)
-    for k in (16, 17, 23, 31):      # single-word keys: plain hashing (16) and minimizer blocks (k >= 17)
+    for k in (16, 18, 23, 31):      # single-word keys: plain hashing (16) and minimizer blocks (k >= 18)
         reads = [r.decode() for r in gen.stress_reads(20000, 200, 250, seed=500 + k)]
         seq = "\n".join(reads)
         for complements in (True, False):

@@ -16,8 +16,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
     agg[r["Kernel_Name"][:40]][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in agg.items():
-    if "choose_dense" not in k and "frag_contract" not in k and "walk_measure" not in k: continue
+    if not any(t in k for t in ("choose_dense", "probe_block", "frag_contract", "walk_measure", "bucket_scatter", "block_build")): continue
     w = d["SQ_WAVES"]
+    print("  per k-mer (1e8): VALU %.0f SALU %.0f LDS %.1f VMEM_RD %.2f" % (d["SQ_INSTS_VALU"] * 64 / 1e8, d["SQ_INSTS_SALU"] * 64 / 1e8, d["SQ_INSTS_LDS"] * 64 / 1e8, d["SQ_INSTS_VMEM_RD"] * 64 / 1e8))
     print(k.ljust(40), "waves %d per wave: VALU %.0f SALU %.0f LDS %.0f VMEM_RD %.1f | wave cycles %.0f, wait %.2f, VALU active %.2f" % (
         w, d["SQ_INSTS_VALU"] / w, d["SQ_INSTS_SALU"] / w, d["SQ_INSTS_LDS"] / w, d["SQ_INSTS_VMEM_RD"] / w, d["SQ_WAVE_CYCLES"] / w,
         d["SQ_WAIT_ANY"] / max(1, d["SQ_WAVE_CYCLES"]), d["SQ_ACTIVE_INST_VALU"] / max(1, d["SQ_WAVE_CYCLES"])))
