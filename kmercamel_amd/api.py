@@ -460,10 +460,12 @@ class ComputeResult:
         return a.value, b.value
 
     def strings(self, want_mask=False):
-        out = ctypes.create_string_buffer(self.length + 1)
-        mask = ctypes.create_string_buffer(self.length + 1) if want_mask else None
+        """(-o line, -M line) held by this result: the whole superstring, or -- hash-sharded runs -- this rank's slice of it"""
+        n = self.slice()[1]
+        out = ctypes.create_string_buffer(n + 1)
+        mask = ctypes.create_string_buffer(n + 1) if want_mask else None
         self.ctx.check(self.ctx.lib.kc_result_copy(self.h, out, mask))
-        return out.raw[:self.length].decode(), (mask.raw[:self.length].decode() if want_mask else None)
+        return out.raw[:n].decode(), (mask.raw[:n].decode() if want_mask else None)
 
     def slice(self):
         """(offset, length) of the part of the superstring this result holds (hash-sharded runs: this rank's slice)"""

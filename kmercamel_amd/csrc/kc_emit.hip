@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
                                                       u64 out_lo, int nranks, int me) {
     // nranks > 1 (hash-sharded flow): this rank emits the vertices whose block starts in its share of the output, into a
     // buffer that begins at output offset out_lo
-    u64 v = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    u64 v = (((u64)blockIdx.z * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) >> 6;   // (x, z): vertices; y: slices of long vertices
     int lane = threadIdx.x & 63;
     if (v >= V) return;
     if (endv[v] != endv[start]) return;
@@ -224,7 +224,10 @@ int kce_emit_ranked(kc_simplitigs *s, const KcRank *r, u64 out_lo, int nranks, i
     const u64 V = r->V, L = r->L;
     unsigned slices = 1;   // waves per vertex: ~8192 characters each on average, at most 256
     if (V && L / V > 16384) { u64 y = L / V / 8192; slices = (unsigned)(y > 256 ? 256 : y); }
-    hipLaunchKernelGGL(em_emit_kernel, dim3(kc_grid(V * 64, 256), slices), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+    // one wavefront per vertex: from 2^26 vertices on the block count no longer fits one grid dimension's 2^32 work-items
+    const u64 gv = (V * 64 + 255) / 256 ? (V * 64 + 255) / 256 : 1;
+    const unsigned gx = gv > ((u64)1 << 22) ? (1u << 22) : (unsigned)gv, gz = (unsigned)((gv + gx - 1) / gx);
+    hipLaunchKernelGGL(em_emit_kernel, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
                        (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;

@@ -290,7 +290,9 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
                 }
                 cv.notify_all();
                 if (got <= 0 || (size_t)got < CH - off) {
-                    if (got > 0) { std::lock_guard<std::mutex> lk(mu); ready.emplace_back(-1, 0); cv.notify_all(); }
+                    // the last chunk: followed by the end marker unless the chunk itself says "end" (0 bytes) or "error" (< 0).  (A chunk
+                    // that holds only the '\r' kept back from a full chunk before EOF has 1 byte and got == 0: it needs the marker too.)
+                    if (total > 0) { std::lock_guard<std::mutex> lk(mu); ready.emplace_back(-1, 0); cv.notify_all(); }
                     return;
                 }
             }

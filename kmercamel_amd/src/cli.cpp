@@ -188,13 +188,24 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     void *d_seq = nullptr;
     uint64_t d_len = 0;
     bool streamed = false;
-    if (!assume_simplitigs && !lower_bound && !std::getenv("KC_CLI_NOSTREAM")) {
+    // the device tokeniser consumes the input before it can say "this is FASTQ, use the host parser": only inputs that can be opened a
+    // second time go through it (regular files); stdin, FIFOs and process substitutions are read once, by the host parser
+    bool reopenable = false;
+    {
+        struct stat sti;
+        reopenable = path != "-" && ::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode);
+    }
+    if (!assume_simplitigs && !lower_bound && reopenable && !std::getenv("KC_CLI_NOSTREAM")) {
         // FASTA goes to the device in pinned chunks and is tokenised there while the next chunk is read (no joined host copy)
         ctx = kcamd::context();
         mark("device context ready");
         int is_fastq = 0;
         int rc = kc_read_fasta_device(ctx, path.c_str(), &d_seq, &d_len, &is_fastq);
-        if (rc == KC_E_IO) throw std::invalid_argument("couldn't open file " + path);
+        if (rc == KC_E_IO) {   // parser.h:95-97 for a file that cannot be opened; a read / gzip error further in says so
+            const std::string e = kc_last_error(ctx);
+            if (e.find("read error") != std::string::npos) throw std::runtime_error(e);
+            throw std::invalid_argument("couldn't open file " + path);
+        }
         kcamd::check(rc);
         streamed = !is_fastq;
         if (streamed) mark("input on the device");

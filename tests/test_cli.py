@@ -186,6 +186,32 @@ def test_cli_streamed_fasta_tokeniser_equals_host_parser(tmp_path):
     assert run("compute", "-k", "31", path + ".gz").stdout.split("\n")[1] == want
     p = subprocess.run([BIN, "compute", "-k", "31", "-"], input=raw, capture_output=True)
     assert p.returncode == 0 and p.stdout.decode().split("\n")[1] == want
+    # FASTQ on stdin / through a FIFO (parser.h:88-101 + kseq.h:212-223): inputs that cannot be opened twice never go through the
+    # device tokeniser (it consumes the stream before it can say "FASTQ")
+    reads = [seq(150) for _ in range(200)]
+    fq = "".join("@q%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads)).encode()
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "w") as f:
+        f.write("".join(">q%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
+    want_q = run("compute", "-k", "31", fa).stdout.split("\n")[1]
+    p = subprocess.run([BIN, "compute", "-k", "31", "-"], input=fq, capture_output=True)
+    assert p.returncode == 0 and p.stdout.decode().split("\n")[1] == want_q, p.stderr.decode()[-300:]
+    fifo = str(tmp_path / "reads.fifo")
+    os.mkfifo(fifo)
+    import threading
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(fq)
+    t = threading.Thread(target=feed)
+    t.start()
+    p = subprocess.run([BIN, "compute", "-k", "31", fifo], capture_output=True)
+    t.join()
+    assert p.returncode == 0 and p.stdout.decode().split("\n")[1] == want_q, p.stderr.decode()[-300:]
+    fqf = str(tmp_path / "reads.fq")
+    with open(fqf, "wb") as f:
+        f.write(fq)
+    assert run("compute", "-k", "31", fqf).stdout.split("\n")[1] == want_q   # a regular FASTQ file: tokeniser says FASTQ, host parser re-opens it
     # -o / -M files: header line, data, newline -- through the descriptor path
     o, m = str(tmp_path / "o.fa"), str(tmp_path / "m.fa")
     p = run("compute", "-k", "31", "-o", o, "-M", m, path)
