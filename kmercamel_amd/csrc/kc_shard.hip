@@ -38,25 +38,68 @@
 namespace {
 
 struct ShLists {
-    u64 *rec;        // records {pid, cand[4]}: 5 words, shard s owns [s * rec_scap, ...)
-    u64 rec_scap;
-    u64 *rec_cur;    // KC_USH cursors
-    u64 *qry;        // queries {key[W], home, meta}: W + 2 words
+    u64 *qry;        // queries {key[W], pid, home}: W + 2 words, shard s owns [s * qry_scap, ...)
     u64 qry_scap;
-    u64 *qry_cur;
+    u64 *qry_cur;    // KC_USH cursors
+    u64 *edges;      // branch ports list their edges {x pid, y pid, priority, base, key x, key y}: 4 + 2 W words
+    u64 edge_cap;
+    u64 *edge_cur;
     u64 *flags;      // [0] a list overflowed
 };
 
+// Settle one port from the slots of its candidates (cs[c], entered on port bit c of qb): the link word.  A branch port (>= 2
+// existing candidates) chooses its best edge here too -- provisionally -- and lists all its edges for the replicated branch
+// matching, which overrides the choice where the sequential rule says so.
+template <int W>
+__device__ __forceinline__ u64 kc_shard_settle_port(int k, int complements, const u64 pid, const Key<W> &x, const Key<W> &xr, const u64 (&cs)[4], const u32 qb,
+                                                    const ShLists &L) {
+    const int port = (int)(pid & 1);
+    u32 nfound = 0, bc = 0;
+#pragma unroll
+    for (u32 c = 0; c < 4; ++c)
+        if (cs[c] != KC_NONE64) { ++nfound; bc = c; }
+    if (nfound == 0) return LK_DEAD;
+    u64 bslot = 0;
+#pragma unroll
+    for (u32 c = 0; c < 4; ++c) bslot = (c == bc) ? cs[c] : bslot;
+    if (nfound == 1) return LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, bslot);
+    const u64 hx = key_hash(x);
+    Key<W> by = x; int bq = 0; u64 bpr = 0; bool have = false;
+    const u64 e0 = atomicAdd((ull *)L.edge_cur, (ull)nfound);
+    if (e0 + nfound > L.edge_cap) L.flags[0] = 1;
+    u32 ne = 0;
+    for (u32 c = 0; c < 4; ++c) {
+        u64 ts = KC_NONE64;
+#pragma unroll
+        for (u32 cc = 0; cc < 4; ++cc) ts = (c == cc) ? cs[cc] : ts;
+        if (ts == KC_NONE64) continue;
+        int q;
+        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+        const u64 pr = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
+        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bc = c; bslot = ts; have = true; }
+        if (e0 + ne < L.edge_cap) {
+            u64 *e = L.edges + (e0 + ne) * (4 + 2 * W);
+            e[0] = pid; e[1] = (ts << 1) | (u64)q; e[2] = pr; e[3] = port ? c : 3 - c;
+            for (int w = 0; w < W; ++w) { e[4 + w] = x.w[w]; e[4 + W + w] = y.w[w]; }
+        }
+        ++ne;
+    }
+    return LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot);   // provisional; the branch matching overrides it
+}
+
 // ---------------------------------------------------------------------------------------------------- phase 1a
-// Round 1 over this rank's slot range.  Same sweep as kc_choose_dense_kernel (workgroup = 2048 slots of one block, block
-// tags staged in LDS); a port whose 4 candidates are all local and of which at most one exists is settled at once, every
-// other port gets a record, every remote candidate a query.  List space is reserved once per wavefront and sweep step.
+// Round 1 over this rank's slot range.  Same sweep as the single-GPU round 1 (workgroup = 2048 slots of one block, block tags
+// staged in LDS).  The 4 candidates of a port share their home (kc_set_dev.h), hence their owner: a port is either settled here
+// or, when that home lies in another rank's range, becomes ONE query {x, port} that the owner answers with the finished link
+// word (24 bytes out, 8 back per remote port, where per-candidate queries cost 4 x 16).  List space is reserved once per
+// wavefront and sweep step.
 template <int W, int KC>
 __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
                                                               ShLists L, int stage_words) {
     extern __shared__ u64 kc_stage[];
     __shared__ unsigned short kc_list[KC_CHOOSE_SLOTS];
     __shared__ u32 kc_nlist;
+    const int k = KC ? KC : k_rt;
     const u64 base = set.rlo + kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_SLOTS;
     const u64 end = set.rlo + set.rcap;
     if (base >= end) return;
@@ -80,7 +123,7 @@ __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set,
         const bool active = t < n;
         KcCand2<W> cd;
         u64 slot = 0;
-        u32 need = 0, nq = 0;   // need: bit p = port p gets a record
+        u32 rem = 0;   // bit p = port p is answered by another rank
         if (active) {
             slot = base + kc_list[t];
             kc_cand_lookup_mid<W, KC, true>(set, k_rt, complements, slot, reinterpret_cast<const u8 *>(kc_stage), sblk, cd);
@@ -88,64 +131,32 @@ __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set,
             for (int port = 0; port < 2; ++port) {
                 const u64 pid = (slot << 1) | (u64)port;
                 if (port == 1 && cd.xpal) { link[pid] = LK_DEAD; continue; }
-                u32 nfound = 0, nrem = 0, bc = 0, bq = 0;
-                u64 bslot = 0;   // (kept by selects: indexing cslot[] with a run-time index sends the array to scratch memory)
-#pragma unroll
-                for (u32 c = 0; c < 4; ++c) {
-                    const u64 cs = cd.cslot[port * 4 + c];
-                    if (cs == KC_REMOTE) ++nrem;
-                    else if (cs != KC_NONE64) { ++nfound; bc = c; bslot = cs; bq = (cd.qbits >> (port * 4 + c)) & 1u; }
-                }
-                if (nrem == 0 && nfound <= 1) {
-                    link[pid] = nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD;
-                } else { need |= 1u << port; nq += nrem; }
+                if (cd.cslot[port * 4] == KC_REMOTE) { rem |= 1u << port; continue; }
+                const u64 cs[4] = {cd.cslot[port * 4], cd.cslot[port * 4 + 1], cd.cslot[port * 4 + 2], cd.cslot[port * 4 + 3]};
+                link[pid] = kc_shard_settle_port<W>(k, complements, pid, cd.x, cd.xr, cs, (cd.qbits >> (port * 4)) & 15u, L);
             }
         }
-        // list space is reserved once per wavefront and sweep step (every lane runs every step, so all 64 take part): exclusive
-        // prefix sums of the record count (0..2) and the query count (0..8) by ballots over their bit planes, one atomic each.
-        // (Reserving per workgroup took four barriers per step, which cost more than the lookups: 2x the single-GPU kernel.)
-        const u32 nr = (need & 1) + (need >> 1);
+        // query space is reserved once per wavefront and sweep step (every lane runs every step, so all 64 take part): exclusive
+        // prefix sums of the query count (0..2) by ballots over its bit planes, one atomic.
+        const u32 nq = (rem & 1) + (rem >> 1);
         const unsigned long long lt = ((unsigned long long)1 << (threadIdx.x & 63)) - 1;
-        u32 my_rec = 0, tot_rec = 0, my_qry = 0, tot_qry = 0;
+        u32 my_qry = 0, tot_qry = 0;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const unsigned long long m = __ballot((nr >> j) & 1u); my_rec += (u32)__popcll(m & lt) << j; tot_rec += (u32)__popcll(m) << j; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const unsigned long long m = __ballot((nq >> j) & 1u); my_qry += (u32)__popcll(m & lt) << j; tot_qry += (u32)__popcll(m) << j; }
-        u64 base_rec = 0, base_qry = 0;
-        if ((threadIdx.x & 63) == 0) {
-            if (tot_rec) base_rec = atomicAdd((ull *)&L.rec_cur[shard * KC_USTRIDE], (ull)tot_rec);
-            if (tot_qry) base_qry = atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)tot_qry);
-        }
-        base_rec = __shfl(base_rec, 0, 64);
+        for (int j = 0; j < 2; ++j) { const unsigned long long m = __ballot((nq >> j) & 1u); my_qry += (u32)__popcll(m & lt) << j; tot_qry += (u32)__popcll(m) << j; }
+        u64 base_qry = 0;
+        if ((threadIdx.x & 63) == 0 && tot_qry) base_qry = atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)tot_qry);
         base_qry = __shfl(base_qry, 0, 64);
-        if (nr) {
-            u64 rpos = base_rec + my_rec, qpos = base_qry + my_qry;
+        if (nq) {
+            u64 qpos = base_qry + my_qry;
 #pragma unroll
             for (int port = 0; port < 2; ++port) {
-                if (!((need >> port) & 1)) continue;
-                if (rpos >= L.rec_scap) { L.flags[0] = 1; break; }
-                const u64 ri = (u64)shard * L.rec_scap + rpos;
-                u64 *r = L.rec + ri * 5;
-                r[0] = (slot << 1) | (u64)port;
-#pragma unroll
-                for (u32 c = 0; c < 4; ++c) {
-                    const int i = port * 4 + (int)c;
-                    const u64 cs = cd.cslot[i];
-                    r[1 + c] = (cs == KC_NONE64 || cs == KC_REMOTE) ? cs : ((cs << 1) | (u64)((cd.qbits >> i) & 1));
-                    if (cs == KC_REMOTE) {
-                        if (qpos >= L.qry_scap) { L.flags[0] = 1; }
-                        else {
-                            int q;   // the port the candidate is entered on travels with the query
-                            const Key<W> y = kc_neighbour_key_q(cd.x, cd.xr, port, c, KC ? KC : k_rt, complements, q);
-                            u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * QW;
-                            for (int w = 0; w < W; ++w) qq[w] = y.w[w];
-                            qq[W] = cd.phome[port];
-                            qq[W + 1] = (ri << 3) | ((u64)q << 2) | (u64)c;
-                        }
-                        ++qpos;
-                    }
-                }
-                ++rpos;
+                if (!((rem >> port) & 1)) continue;
+                if (qpos >= L.qry_scap) { L.flags[0] = 1; break; }
+                u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * QW;
+                for (int w = 0; w < W; ++w) qq[w] = cd.x.w[w];
+                qq[W] = (slot << 1) | (u64)port;
+                qq[W + 1] = cd.phome[port];
+                ++qpos;
             }
         }
     }
@@ -155,62 +166,29 @@ __global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set,
 template <int W>
 __global__ void __launch_bounds__(256) kc_shard_qdest_kernel(const u64 *__restrict__ qry, u64 n, u64 rcap, u8 *dest) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) dest[t] = (u8)(qry[t * (W + 2) + W] / rcap);
+    if (t < n) dest[t] = (u8)(qry[t * (W + 2) + W + 1] / rcap);
 }
-// the owner's side: queries {key} -> slot (global) or KC_NONE64
+// the owner's side: query {x, pid of the asking port} -> that port's link word (lookups of its 4 candidates here, where they live)
 template <int W>
-__global__ void __launch_bounds__(256) kc_shard_answer_kernel(SetView<W> set, const u64 *__restrict__ q, u64 n, u64 *ans) {
+__global__ void __launch_bounds__(256) kc_shard_answer_kernel(SetView<W> set, int k, int complements, const u64 *__restrict__ q, u64 n, u64 *ans, ShLists L) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    Key<W> key;
-    for (int w = 0; w < W; ++w) key.w[w] = q[t * W + w];
-    ans[t] = set_find(set, key);
-}
-template <int W>
-__global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restrict__ qry, const u64 *__restrict__ ans, u64 n, u64 *rec) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const u64 meta = qry[t * (W + 2) + W + 1], a = ans[t];
-    rec[(meta >> 3) * 5 + 1 + (meta & 3)] = a == KC_NONE64 ? KC_NONE64 : ((a << 1) | ((meta >> 2) & 1));
-}
-
-// settle the recorded ports.  Branch ports (>= 2 existing candidates) choose their best edge here too, and list all their
-// edges {x pid, y pid, priority, base, key x, key y} for the replicated branch matching.
-template <int W>
-__global__ void __launch_bounds__(256) kc_shard_resolve_kernel(SetView<W> set, u64 *link, int k, int complements, const u64 *__restrict__ rec, u64 rec_scap,
-                                                               const u64 *__restrict__ rec_cur, u64 *edges, u64 edge_cap, u64 *edge_cursor) {
-    const u64 t = kc_gtid();
-    const u64 shard = t / rec_scap, pos = t - shard * rec_scap;
-    if (shard >= KC_USH) return;
-    u64 cnt = rec_cur[shard * KC_USTRIDE];
-    if (pos >= (cnt > rec_scap ? rec_scap : cnt)) return;
-    const u64 *r = rec + t * 5;
-    const u64 pid = r[0];
+    Key<W> x;
+    for (int w = 0; w < W; ++w) x.w[w] = q[t * (W + 1) + w];
+    const u64 pid = q[t * (W + 1) + W];
     const int port = (int)(pid & 1);
-    u32 nfound = 0, bc = 0;
-    for (u32 c = 0; c < 4; ++c)
-        if (r[1 + c] != KC_NONE64) { ++nfound; bc = c; }
-    if (nfound == 0) { link[pid] = LK_DEAD; return; }
-    if (nfound == 1) { link[pid] = LK_MAKE(LK_CHOICE, r[1 + bc] & 1, port ? bc : 3 - bc, r[1 + bc] >> 1); return; }
-    const Key<W> x = set_key_at(set, pid >> 1);
-    const u64 hx = key_hash(x);
-    Key<W> by = x; int bq = 0; u64 bpr = 0; bool have = false;
-    const u64 e0 = atomicAdd((ull *)edge_cursor, (ull)nfound);
-    u32 ne = 0;
-    for (u32 c = 0; c < 4; ++c) {
-        if (r[1 + c] == KC_NONE64) continue;
-        const Key<W> y = kc_neighbour_key(x, port, c, k, complements);
-        const int q = (int)(r[1 + c] & 1);
-        const u64 pr = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
-        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bc = c; have = true; }
-        if (e0 + ne < edge_cap) {
-            u64 *e = edges + (e0 + ne) * (4 + 2 * W);
-            e[0] = pid; e[1] = r[1 + c]; e[2] = pr; e[3] = port ? c : 3 - c;
-            for (int w = 0; w < W; ++w) { e[4 + w] = x.w[w]; e[4 + W + w] = y.w[w]; }
-        }
-        ++ne;
-    }
-    link[pid] = LK_MAKE(LK_CHOICE, r[1 + bc] & 1, port ? bc : 3 - bc, r[1 + bc] >> 1);   // provisional; the branch matching overrides it
+    const Key<W> xr = key_rc(x, k);
+    const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+    const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+    const KcPortDesc d = kc_port_desc<W, 0>(set, x, xr, k, complements, port, kc_mid_min<W, 0>(mid, midr, k, set.m));
+    u64 cs[4]; u32 qb;
+    if (!kc_port_search<W, false, false>(set, k, complements, x, xr, KC_NONE64, port, d, nullptr, nullptr, cs, qb))
+        kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+    ans[t] = kc_shard_settle_port<W>(k, complements, pid, x, xr, cs, qb, L);
+}
+__global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restrict__ qry, const u64 *__restrict__ ans, u64 n, int QW, u64 *link) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) link[qry[t * (u64)QW + QW - 2]] = ans[t];
 }
 __global__ void __launch_bounds__(256) kc_shard_apply_fix_kernel(u64 *link, const u64 *__restrict__ fix, u64 n, u64 rlo2, u64 rcap2) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,89 +685,88 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     KC_TRY(scope.alloc(&cur, (2 * KC_USH + 4) * KC_USTRIDE));
     ShLists L{};
     const int QW = W + 2, EW = 4 + 2 * W;
-    // List capacities from the expected counts (+15 %): a candidate leaves its source's block ~12 % of the time and is then
-    // remote with probability (G-1)/G; a port with a remote candidate needs a record, every remote candidate a query.  (At 2
-    // ranks that is ~0.5 records and ~0.55 queries per k-mer, at 8 ranks ~0.8 and ~1.0 -- 40 and 8(W+2) bytes each, the
-    // largest temporaries of the rank.)  An overflow doubles the lists and repeats the sweep, collectively.
-    const double p_rem = 0.12 * (double)(G - 1) / (double)G, keep4 = (1 - p_rem) * (1 - p_rem) * (1 - p_rem) * (1 - p_rem);
-    u64 rec_scap = (u64)(1.15 * 2.0 * (1.0 - keep4) * (double)N_local) / KC_USH + 4096;
-    u64 qry_scap = (u64)(1.15 * 8.0 * p_rem * (double)N_local) / KC_USH + 4096;
+    // List capacities from the expected counts (+15 %): the home of a port's candidates leaves its source's block ~13 % of the
+    // time and is then remote with probability (G-1)/G -- ~0.23 queries per k-mer at 8 ranks, 8(W+2) bytes each in the list.
+    // An overflow doubles the lists and repeats the sweep, collectively.
+    const double p_rem = 2.0 / (double)(k - set->mlen) * (double)(G - 1) / (double)G;   // (a middle holds k - m - 1 m-mers: its neighbour's minimizer differs with probability ~2 / (k - m))
+    u64 qry_scap = (u64)(1.15 * 2.0 * p_rem * (double)N_local) / KC_USH + 4096;
+    u64 edge_cap = N_local / 64 + ((u64)1 << 16);
     const int stage_words = (int)(((u64)1 << set->bshift) / 8 + 1);
     const unsigned cgrid = kc_grid8(rcap, KC_CHOOSE_SLOTS);
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
+    u64 nq = 0, n_branch_edges = 0;
     for (int attempt = 0;; ++attempt) {
-        KC_TRY(scope.alloc(&L.rec, rec_scap * KC_USH * 5));
         KC_TRY(scope.alloc(&L.qry, qry_scap * KC_USH * QW));
-        L.rec_scap = rec_scap; L.qry_scap = qry_scap;
-        L.rec_cur = cur; L.qry_cur = cur + KC_USH * KC_USTRIDE; L.flags = cur + 2 * KC_USH * KC_USTRIDE;
+        KC_TRY(scope.alloc(&L.edges, edge_cap * EW + 1));
+        L.qry_scap = qry_scap; L.edge_cap = edge_cap;
+        L.qry_cur = cur + KC_USH * KC_USTRIDE; L.flags = cur + 2 * KC_USH * KC_USTRIDE; L.edge_cur = cur + (2 * KC_USH + 1) * KC_USTRIDE;
         KC_HIP(ctx, hipMemsetAsync(cur, 0, (2 * KC_USH + 4) * KC_USTRIDE * 8, ctx->stream));
         KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-        if (k == KSPEC && !getenv("KC_NO_KSPEC"))
+        if (k == KSPEC && set->mlen == KC_MSPEC && !getenv("KC_NO_KSPEC"))
             hipLaunchKernelGGL((kc_shard_choose_kernel<W, KSPEC>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
         else
             hipLaunchKernelGGL((kc_shard_choose_kernel<W, 0>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+        if (trace) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[shard %d/%d] probe sweep done (%s), N_local=%llu\n", me, G, hipGetErrorString(e), (unsigned long long)N_local); }
+        auto grow = [&]() { scope.release(L.qry); scope.release(L.edges); qry_scap = qry_scap * 3 + 4096; edge_cap = edge_cap * 4 + n_branch_edges; };
+        {   // a list overflowed during the sweep: every rank repeats it with larger lists (nothing has been exchanged yet)
+            u64 any = 0;
+            KC_TRY(read_words(ctx, L.flags, &any, 1));
+            KC_TRY(kcc_allreduce_max(c, &any, 1));
+            if (any) {
+                if (attempt == 4) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded probe: query / branch edge lists overflow");
+                KC_TRY(read_words(ctx, L.edge_cur, &n_branch_edges, 1));
+                grow();
+                continue;
+            }
+        }
+        // queries -> owners -> link words back
+        nq = 0;
+        {
+            u64 *qc = nullptr;
+            bool ovf = false;
+            std::vector<u64> hc(KC_USH * KC_USTRIDE);
+            KC_TRY(read_words(ctx, L.qry_cur, hc.data(), KC_USH * KC_USTRIDE));
+            for (int sh = 0; sh < KC_USH; ++sh) nq += hc[(size_t)sh * KC_USTRIDE] > qry_scap ? qry_scap : hc[(size_t)sh * KC_USTRIDE];
+            KC_TRY(scope.alloc(&qc, nq * QW + 1));
+            KC_TRY(kcu_compact_shards(ctx, L.qry, qry_scap, L.qry_cur, KC_USH, KC_USTRIDE, QW, qc, &nq, &ovf));
+            u8 *dest = nullptr;
+            KC_TRY(scope.alloc(&dest, nq + 1));
+            if (nq) hipLaunchKernelGGL((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcap, dest);
+            KcRoute rt;
+            KC_TRY(kcr_build(c, dest, nq, &rt));
+            u64 *rq = nullptr, *ans = nullptr, *ansb = nullptr;
+            int rc = kcr_forward(c, rt, qc, W + 1, QW, &rq);   // the k-mer and the asking port travel; the owner derives the home (one minimizer pass)
+            if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
+            if (rc == KC_OK && rt.n_recv)
+                hipLaunchKernelGGL((kc_shard_answer_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, k, complements, (const u64 *)rq, rt.n_recv, ans, L);
+            if (trace) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[shard %d/%d] %llu queries out, %llu answered here (%s)\n", me, G, (unsigned long long)nq, (unsigned long long)rt.n_recv, hipGetErrorString(e)); }
+            if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nq + 1);
+            if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
+            if (rc == KC_OK && nq)
+                hipLaunchKernelGGL(kc_shard_fill_kernel, dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, QW, link);
+            (void)hipStreamSynchronize(ctx->stream);
+            kcr_free(ctx, &rt);
+            kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
+            scope.release(qc); scope.release(dest);
+            KC_TRY(rc);
+        }
         u64 ovf = 0;
         KC_TRY(read_words(ctx, L.flags, &ovf, 1));
+        KC_TRY(read_words(ctx, L.edge_cur, &n_branch_edges, 1));
         u64 any = ovf;
-        KC_TRY(kcc_allreduce_max(c, &any, 1));   // (the retry is collective: it re-enters no exchange, but keep the ranks in step)
+        KC_TRY(kcc_allreduce_max(c, &any, 1));   // (the retry is collective: every rank repeats sweep and exchange)
         if (!any) break;
-        if (attempt == 4) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded probe: record / query lists overflow");
-        scope.release(L.rec); scope.release(L.qry);
-        rec_scap = rec_scap * 2 + 4096; qry_scap = qry_scap * 3 + 4096;
+        if (attempt == 4) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded probe: query / branch edge lists overflow");
+        grow();   // (the owners' branch edge lists overflowed while answering: sweep and exchange once more)
     }
-    // queries -> owners -> answers
-    u64 nq = 0;
+    scope.release(L.qry); L.qry = nullptr;
+    // the branch subgraph: every rank's edges to every rank, settled identically everywhere
     {
-        u64 *qc = nullptr;
-        bool ovf = false;
-        std::vector<u64> hc(KC_USH * KC_USTRIDE);
-        KC_TRY(read_words(ctx, L.qry_cur, hc.data(), KC_USH * KC_USTRIDE));
-        for (int s = 0; s < KC_USH; ++s) nq += hc[(size_t)s * KC_USTRIDE];
-        KC_TRY(scope.alloc(&qc, nq * QW + 1));
-        KC_TRY(kcu_compact_shards(ctx, L.qry, qry_scap, L.qry_cur, KC_USH, KC_USTRIDE, QW, qc, &nq, &ovf));
-        scope.release(L.qry); L.qry = nullptr;
-        u8 *dest = nullptr;
-        KC_TRY(scope.alloc(&dest, nq + 1));
-        if (nq) hipLaunchKernelGGL((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcap, dest);
-        KcRoute rt;
-        KC_TRY(kcr_build(c, dest, nq, &rt));
-        u64 *rq = nullptr, *ans = nullptr, *ansb = nullptr;
-        int rc = kcr_forward(c, rt, qc, W, QW, &rq);   // only the key travels: the owner derives the home (one minimizer pass, ~2 ms per 1e9 queries)
-        if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
-        if (rc == KC_OK && rt.n_recv)
-            hipLaunchKernelGGL((kc_shard_answer_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, ans);
-        if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nq + 1);
-        if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
-        if (rc == KC_OK && nq)
-            hipLaunchKernelGGL((kc_shard_fill_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, L.rec);
-        (void)hipStreamSynchronize(ctx->stream);
-        kcr_free(ctx, &rt);
-        kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
-        scope.release(qc); scope.release(dest);
-        KC_TRY(rc);
-    }
-    // settle the recorded ports; branch ports list their edges
-    u64 n_branch_edges = 0;
-    {
-        u64 edge_cap = 1 << 16, *edges = nullptr, *ecur = cur + (2 * KC_USH + 1) * KC_USTRIDE;
-        for (int attempt = 0;; ++attempt) {
-            KC_TRY(scope.alloc(&edges, edge_cap * EW));
-            KC_HIP(ctx, hipMemsetAsync(ecur, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_shard_resolve_kernel<W>), kc_grid2(rec_scap * KC_USH, 256), dim3(256), 0, ctx->stream, sv, link, k, complements,
-                               (const u64 *)L.rec, rec_scap, (const u64 *)L.rec_cur, edges, edge_cap, ecur);
-            KC_HIP(ctx, hipGetLastError());
-            KC_TRY(read_words(ctx, ecur, &n_branch_edges, 1));
-            if (n_branch_edges <= edge_cap) break;
-            if (attempt == 2) return kc_fail(ctx, KC_E_CAPACITY, "branch edge list overflow");
-            scope.release(edges);
-            edge_cap = n_branch_edges + 1024;
-        }
-        scope.release(L.rec); L.rec = nullptr;
         u64 *all = nullptr, n_all = 0;
-        KC_TRY(allgather_rows(c, edges, n_branch_edges, EW, &all, &n_all, nullptr));
-        scope.release(edges);
+        KC_TRY(allgather_rows(c, L.edges, n_branch_edges, EW, &all, &n_all, nullptr));
+        scope.release(L.edges); L.edges = nullptr;
         if (n_all) {
             std::vector<u64> rows(n_all * EW), fix;
             KC_HIP(ctx, hipMemcpyAsync(rows.data(), all, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
