@@ -27,6 +27,7 @@ extern "C" {
 #define KC_E_CAPACITY (-5)    /* hash set capacity exhausted (kh_put's ret=-1, khash.h:314-321) */
 #define KC_E_IO (-6)          /* "couldn't open file" (parser.h:95-97) */
 #define KC_E_NO_KMERS (-7)    /* input holds no k-mers (main.cpp:155-158) */
+#define KC_E_TRANSPORT (-8)   /* an exchange of the hash-sharded path failed (RCCL error, transport callback, peer copy) */
 
 typedef struct kc_ctx kc_ctx;
 typedef struct kc_set kc_set;
@@ -147,6 +148,13 @@ int kc_comm_create_callbacks(kc_ctx *ctx, int rank, int world, kc_alltoallv_host
  * torch.distributed broadcast), then every rank calls kc_comm_create_rccl.  librccl.so is loaded on first use. */
 int kc_rccl_unique_id(void *id128);
 int kc_comm_create_rccl(kc_ctx *ctx, int rank, int world, const void *id128, kc_comm **out);
+/* Ranks that are threads of ONE process (kmercamel compute --gpus N): create the group once, then one communicator per rank
+ * thread; exchanges are device-to-device copies out of the peers' buffers (peer DMA between GPUs, plain copies when ranks
+ * share a GPU).  Destroy the communicators first, then the group. */
+typedef struct kc_thread_group kc_thread_group;
+int kc_thread_group_create(int world, kc_thread_group **out);
+void kc_thread_group_destroy(kc_thread_group *group);
+int kc_comm_create_threads(kc_ctx *ctx, kc_thread_group *group, int rank, kc_comm **out);
 void kc_comm_destroy(kc_comm *comm);
 /* stats[8]: 0 bytes sent, 1 bytes received, 2 collective calls, 3 microseconds spent inside them (host clock) */
 int kc_comm_stats(kc_comm *comm, uint64_t *stats);
@@ -181,6 +189,8 @@ int kc_result_write_mem(kc_result *r, void *dst, int which);
 /* ms: one masked superstring (ACGTacgt, else KC_E_INVALID_CHAR after output like the reference). out: len bytes. */
 int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out);
 
+/* number of HIP devices visible to the process (0 when there is none) */
+int kc_device_count(void);
 /* library/ABI version string */
 const char *kc_version(void);
 

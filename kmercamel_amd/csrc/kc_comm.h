@@ -10,10 +10,32 @@
 #pragma once
 #include "kc_internal.h"
 
+#include <mutex>
+#include <condition_variable>
+// Ranks that are THREADS of one process (the CLI's --gpus): a rank posts where its outgoing bytes lie on its device, and after a
+// barrier every rank copies what is meant for it straight out of its peers' buffers (device-to-device: peer DMA over xGMI when
+// the ranks sit on different GPUs, a plain copy when they share one).
+struct kc_thread_group {
+    int world = 1;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    u64 generation = 0;
+    bool failed = false;
+    struct Post { const void *d_send; const u64 *send_off, *send_cnt; int device; const u64 *words; } post[64];
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const u64 gen = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
 struct kc_comm {
     kc_ctx *ctx = nullptr;
     int rank = 0, world = 1;
-    int kind = 0;   // 0 self, 1 host callbacks, 2 RCCL
+    int kind = 0;   // 0 self, 1 host callbacks, 2 RCCL, 3 threads of one process
+    kc_thread_group *group = nullptr;
     // host callbacks
     kc_alltoallv_host_fn a2a_host = nullptr;
     kc_allgather_host_fn ag_host = nullptr;

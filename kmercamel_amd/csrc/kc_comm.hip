@@ -39,7 +39,7 @@ Rccl g_rccl;
 const int kNcclUint8 = 1;   // ncclUint8 (rccl.h ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1)
 
 int nccl_fail(kc_ctx *ctx, const char *what, int rc) {
-    return kc_fail(ctx, KC_E_NO_DEVICE, std::string(what) + ": RCCL error " + std::to_string(rc) + (g_rccl.errstr ? std::string(" (") + g_rccl.errstr(rc) + ")" : ""));
+    return kc_fail(ctx, KC_E_TRANSPORT, std::string(what) + ": RCCL error " + std::to_string(rc) + (g_rccl.errstr ? std::string(" (") + g_rccl.errstr(rc) + ")" : ""));
 }
 
 int ensure_stage(kc_comm *c, size_t send_bytes, size_t recv_bytes) {
@@ -83,13 +83,30 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
             o += send_cnt[p];
         }
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (c->a2a_host(c->user, c->stage_send, send_cnt, c->stage_recv, recv_cnt) != 0) return kc_fail(ctx, KC_E_NO_DEVICE, "the all-to-all callback failed");
+        if (c->a2a_host(c->user, c->stage_send, send_cnt, c->stage_recv, recv_cnt) != 0) return kc_fail(ctx, KC_E_TRANSPORT, "the all-to-all callback failed");
         o = 0;
         for (int p = 0; p < G; ++p) {
             if (recv_cnt[p]) KC_HIP(ctx, hipMemcpyAsync((u8 *)d_recv + recv_off[p], c->stage_recv + o, recv_cnt[p], hipMemcpyHostToDevice, ctx->stream));
             o += recv_cnt[p];
         }
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (c->kind == 3) {
+        kc_thread_group *g = c->group;
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // what this rank sends is complete before anybody reads it
+        g->post[c->rank] = kc_thread_group::Post{d_send, send_off, send_cnt, ctx->device, nullptr};
+        g->barrier();
+        for (int p = 0; p < G && rc == KC_OK; ++p) {
+            const kc_thread_group::Post &q = g->post[p];
+            const u64 n = q.send_cnt[c->rank];
+            if (n != recv_cnt[p]) { rc = kc_fail(ctx, KC_E_ARG, "thread transport: send and receive counts disagree"); break; }
+            if (!n) continue;
+            const u8 *src = (const u8 *)q.d_send + q.send_off[c->rank];
+            hipError_t e = q.device == ctx->device ? hipMemcpyAsync((u8 *)d_recv + recv_off[p], src, n, hipMemcpyDeviceToDevice, ctx->stream)
+                                                   : hipMemcpyPeerAsync((u8 *)d_recv + recv_off[p], ctx->device, src, q.device, n, ctx->stream);
+            if (e != hipSuccess) rc = kc_fail(ctx, KC_E_TRANSPORT, std::string("thread transport copy: ") + hipGetErrorString(e));
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == KC_OK) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: copy failed");
+        g->barrier();   // the senders may reuse their buffers
     } else {
         // the part a rank keeps for itself is a device-to-device copy; the rest goes out as one group of sends and receives
         if (send_cnt[c->rank] != recv_cnt[c->rank]) return kc_fail(ctx, KC_E_ARG, "all-to-all: a rank's send and receive counts for itself differ");
@@ -116,15 +133,26 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
     int rc = KC_OK;
     if (c->kind == 0) memcpy(out, in, (size_t)words * 8);
     else if (c->kind == 1) {
-        if (c->ag_host(c->user, in, out, (u64)words * 8) != 0) rc = kc_fail(ctx, KC_E_NO_DEVICE, "the all-gather callback failed");
+        if (c->ag_host(c->user, in, out, (u64)words * 8) != 0) rc = kc_fail(ctx, KC_E_TRANSPORT, "the all-gather callback failed");
+    } else if (c->kind == 3) {
+        kc_thread_group *g = c->group;
+        g->post[c->rank].words = in;
+        g->barrier();
+        for (int p = 0; p < c->world; ++p) memcpy(out + (size_t)p * words, g->post[p].words, (size_t)words * 8);
+        g->barrier();
     } else {
-        if (words > 64) return kc_fail(ctx, KC_E_ARG, "all-gather of more than 64 words");
-        u64 *d_in = c->d_small, *d_out = c->d_small + 64;
-        KC_HIP(ctx, hipMemcpyAsync(d_in, in, (size_t)words * 8, hipMemcpyHostToDevice, ctx->stream));
-        int e = g_rccl.allgather(d_in, d_out, (size_t)words * 8, kNcclUint8, c->nccl_comm, ctx->stream);
-        if (e) return nccl_fail(ctx, "ncclAllGather", e);
-        KC_HIP(ctx, hipMemcpyAsync(out, d_out, (size_t)words * 8 * c->world, hipMemcpyDeviceToHost, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // through a 64-word device window per rank; longer vectors go in pieces
+        std::vector<u64> piece((size_t)64 * c->world);
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int nw = words - w0 < 64 ? words - w0 : 64;
+            u64 *d_in = c->d_small, *d_out = c->d_small + 64;
+            KC_HIP(ctx, hipMemcpyAsync(d_in, in + w0, (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
+            int e = g_rccl.allgather(d_in, d_out, (size_t)nw * 8, kNcclUint8, c->nccl_comm, ctx->stream);
+            if (e) return nccl_fail(ctx, "ncclAllGather", e);
+            KC_HIP(ctx, hipMemcpyAsync(piece.data(), d_out, (size_t)nw * 8 * c->world, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (int p = 0; p < c->world; ++p) memcpy(out + (size_t)p * words + w0, piece.data() + (size_t)p * nw, (size_t)nw * 8);
+        }
     }
     c->seconds += now_s() - t0;
     return rc;
@@ -158,6 +186,28 @@ extern "C" int kc_comm_create_callbacks(kc_ctx *ctx, int rank, int world, kc_all
     kc_comm *c = new kc_comm();
     c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 1;
     c->a2a_host = alltoallv; c->ag_host = allgather; c->user = user;
+    *out = c;
+    return KC_OK;
+}
+
+extern "C" int kc_thread_group_create(int world, kc_thread_group **out) {
+    if (!out || world < 1 || world > 64) return KC_E_ARG;
+    kc_thread_group *g = new kc_thread_group();
+    g->world = world;
+    *out = g;
+    return KC_OK;
+}
+extern "C" void kc_thread_group_destroy(kc_thread_group *g) { delete g; }
+extern "C" int kc_comm_create_threads(kc_ctx *ctx, kc_thread_group *group, int rank, kc_comm **out) {
+    if (!ctx || !group || !out || rank < 0 || rank >= group->world) return KC_E_ARG;
+    kc_comm *c = new kc_comm();
+    c->ctx = ctx; c->rank = rank; c->world = group->world; c->kind = 3; c->group = group;
+    // ranks on different GPUs read each other's buffers: peer access both ways (already enabled is fine)
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess)
+        for (int d = 0; d < ndev; ++d)
+            if (d != ctx->device) { int can = 0; if (hipDeviceCanAccessPeer(&can, ctx->device, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0); (void)hipGetLastError(); }
     *out = c;
     return KC_OK;
 }

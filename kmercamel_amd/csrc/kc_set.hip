@@ -95,6 +95,11 @@ extern "C" int kc_ctx_stats(kc_ctx *ctx, uint64_t *stats) {
     return KC_OK;
 }
 extern "C" void kc_free(void *p) { free(p); }
+extern "C" int kc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
 extern "C" const char *kc_version(void) { return "kmercamel_amd 0.1 (gfx950; path of KmerCamel v2.3.0 compute/greedy)"; }
 
 // ------------------------------------------------------------------------------------------------- pack2bit

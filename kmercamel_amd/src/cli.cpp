@@ -16,6 +16,10 @@
 #include <vector>
 #include <unistd.h>
 #include <fcntl.h>
+#include <getopt.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include "global.h"
 #include "parser.h"
 #include "conversions.h"
@@ -33,6 +37,7 @@ const Opt OPTIONS[] = {
     {"-a", "STR ", "the algorithm to be run [greedy (default); the MI355X build implements greedy only]", "c"},
     {"-t", "STR ", "the target mask type to be run [max-one (default), min-one]", "m"},
     {"-o", "FILE", "output for the (min-one) masked superstring; if not specified, printed to stdout", "cmjrp"},
+    {"--gpus", "INT", "number of GPUs (ranks) the k-mer set is hash-sharded over [1 (default); also KMERCAMEL_GPUS]", "c"},
     {"-M", "FILE", "if given, print also ms with mask maximizing ones (only with greedy)", "c"},
     {"-S", "    ", "optimize for the input being pre-computed simplitigs or unitigs (only with greedy)", "cl"},
     {"-u", "    ", "treat k-mer and its reverse complement as distinct", "cml"},
@@ -117,8 +122,89 @@ static void write_all(int fd, const char *data, size_t n) {
     }
 }
 
+// `compute` over several GPUs (--gpus N / KMERCAMEL_GPUS; the reference is one thread, main.cpp:122-212): one rank thread per GPU (ranks
+// beyond the number of devices share them round robin), each with its own context and a communicator of the in-process
+// thread transport; the records are cut into N contiguous parts, kc_compute_sharded builds ONE masked superstring --
+// byte-identical to the single-GPU result -- and every rank copies its slice into place.
+static int run_compute_sharded(const std::string &path, int k, std::ostream *of, bool complements, int gpus) {
+    WriteLog("Started computation of a masked superstring from '" + path + "'.");
+    Records recs = load_records(path, false);
+    const std::string &j = recs.joined;
+    // part r = the records from the first line start at or after byte len * r / N
+    std::vector<size_t> cut(gpus + 1, j.size());
+    cut[0] = 0;
+    for (int r = 1; r < gpus; ++r) {
+        size_t p = j.size() / gpus * r;
+        if (p < cut[r - 1]) p = cut[r - 1];
+        while (p < j.size() && p > 0 && j[p - 1] != '\n') ++p;
+        cut[r] = p;
+    }
+    const int ndev = kc_device_count();
+    if (ndev <= 0) throw std::runtime_error("kmercamel_amd: no usable MI355X / HIP device");
+    kc_thread_group *group = nullptr;
+    if (kc_thread_group_create(gpus, &group) != KC_OK) throw std::runtime_error("kmercamel_amd: cannot create the rank group");
+    std::vector<kc_result *> res(gpus, nullptr);
+    std::vector<std::string> err(gpus);
+    std::vector<int> rcs(gpus, KC_OK);
+    std::vector<uint64_t> st(16, 0);
+    std::string out;
+    std::mutex out_mu;
+    std::condition_variable out_cv;
+    bool out_ready = false;
+    auto rank_main = [&](int r) {
+        kc_ctx *ctx = nullptr;
+        kc_comm *comm = nullptr;
+        int rc = kc_ctx_create(r % ndev, &ctx);
+        if (rc == KC_OK) rc = kc_comm_create_threads(ctx, group, r, &comm);
+        if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; _exit(1); }   // (the others would wait for it forever)
+        const uint64_t len = cut[r + 1] > cut[r] ? cut[r + 1] - cut[r] - (cut[r + 1] == j.size() ? 0 : 1) : 0;   // (the separator after the part is not part of it)
+        rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, complements ? KC_FLAG_COMPLEMENTS : 0, &res[r]);
+        rcs[r] = rc;
+        if (rc != KC_OK) err[r] = kc_last_error(ctx);
+        if (rc != KC_OK && rc != KC_E_NO_KMERS) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
+        if (rc == KC_OK) {
+            if (r == 0) {
+                kc_result_stats(res[0], st.data());
+                { std::lock_guard<std::mutex> lk(out_mu); out.resize(st[2]); out_ready = true; }
+                out_cv.notify_all();
+            } else {
+                std::unique_lock<std::mutex> lk(out_mu);
+                out_cv.wait(lk, [&] { return out_ready; });
+            }
+            uint64_t off = 0, n = 0;
+            kc_result_slice(res[r], &off, &n);
+            if (n && kc_result_copy(res[r], &out[off], nullptr) != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot copy its slice" << std::endl; _exit(1); }
+            kc_result_destroy(res[r]);
+        }
+        kc_comm_destroy(comm);
+        kc_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < gpus; ++r) th.emplace_back(rank_main, r);
+    rank_main(0);
+    for (auto &t : th) t.join();
+    kc_thread_group_destroy(group);
+    if (rcs[0] == KC_E_NO_KMERS) {
+        std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
+        return usage_subcommand("compute");
+    }
+    WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
+    WriteName(path, "greedy", k, false, !complements, *of);
+    WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
+    WriteLog("Finished 2. part: Hamiltonian path.");
+    of->write(out.data(), (std::streamsize)out.size());
+    WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
+    *of << std::endl;
+    return 0;
+}
+
 int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
-                int min_frequency, const std::string &out_path, const std::string &mask_path) {
+                int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1) {
+    if (gpus > 1) {
+        // what the hash-sharded path does not cover runs on one GPU, as without the option
+        if (!lower_bound && !assume_simplitigs && maskf == nullptr && min_frequency == 1 && k >= 18) return run_compute_sharded(path, k, of, complements, gpus);
+        std::cerr << "Note: --gpus applies to plain `compute -k K` with K >= 18 (no -S, -M, -z); running on one GPU." << std::endl;
+    }
     if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
     else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");
     const bool trace = std::getenv("KC_CLI_TRACE") != nullptr;
@@ -325,9 +411,14 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     std::string algorithm = "greedy", out_path, mask_path;
     bool complements = true, d_set = false, assume_simplitigs = false;
     int min_frequency = 1;
+    int gpus = 1;
+    if (const char *e = std::getenv("KMERCAMEL_GPUS")) gpus = std::atoi(e);
+    // the reference's options are short ones (main.cpp:234); the multi-GPU opt-in is a NEW long option, existing command lines are unchanged
+    static const struct option long_opts[] = {{"gpus", required_argument, nullptr, 1000}, {nullptr, 0, nullptr, 0}};
     try {
-        while ((opt = getopt(argc, argv, lowerbound ? "k:huxSz:" : "k:d:a:o:huxM:Sz:")) != -1) {
+        while ((opt = getopt_long(argc, argv, lowerbound ? "k:huxSz:" : "k:d:a:o:huxM:Sz:", long_opts, nullptr)) != -1) {
             switch (opt) {
+                case 1000: gpus = std::stoi(optarg); break;
                 case 'o': output.open(optarg); of = &output; out_path = optarg; break;
                 case 'k': k = std::stoi(optarg); break;
                 case 'd': d_set = true; d_max = std::stoi(optarg); break;
@@ -359,7 +450,8 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     if (min_frequency >= 256 || min_frequency < 1) return fail("Minimum frequency '-z' must be between 1 and 255.");
     if (min_frequency != 1 && assume_simplitigs) return fail("Inputting simplitigs is not compatible with frequency filterring.");
     if (algorithm != "greedy") return fail("Algorithm '" + algorithm + "' not supported by the MI355X build (greedy only).");
-    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency, out_path, mask_path);
+    if (gpus < 1 || gpus > 64) return fail("--gpus must be between 1 and 64.");
+    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency, out_path, mask_path, gpus);
 }
 
 // Optimize (masks.h:239-261) for max-one / min-one

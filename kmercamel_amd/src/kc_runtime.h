@@ -11,6 +11,7 @@
 #include <mutex>
 #include <thread>
 #include <zlib.h>
+#include <sys/stat.h>
 #include "../../include/kmercamel_amd.h"
 
 namespace kcamd {
@@ -68,6 +69,17 @@ inline std::string slurp_fast(const std::string &path) {
     if (path != "-") {
         FILE *in = fopen(path.c_str(), "rb");
         if (in == nullptr) throw std::invalid_argument("couldn't open file " + path);
+        struct stat sti;   // only a regular file can be sized and read in one piece; a FIFO must not even be peeked at (it cannot be re-opened)
+        const bool regular = fstat(fileno(in), &sti) == 0 && S_ISREG(sti.st_mode);
+        if (!regular) {
+            gzFile f = gzdopen(fileno(in), "r");
+            std::string buf;
+            std::vector<char> tmp(1 << 20);
+            int n;
+            while ((n = gzread(f, tmp.data(), (unsigned)tmp.size())) > 0) buf.append(tmp.data(), (size_t)n);
+            gzclose(f);
+            return buf;
+        }
         unsigned char magic[2] = {0, 0};
         size_t got = fread(magic, 1, 2, in);
         if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(in, 0, SEEK_END) == 0) {

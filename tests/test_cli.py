@@ -5,6 +5,7 @@ import os
 import subprocess
 
 import pytest
+import gen
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "kmercamel_amd", "bin", "kmercamel")
@@ -219,3 +220,43 @@ def test_cli_streamed_fasta_tokeniser_equals_host_parser(tmp_path):
     lo, lm = open(o).read().split("\n"), open(m).read().split("\n")
     assert lo[0].startswith(">maskedsuperstring") and lo[1] == want and lo[2] == "" and len(lo) == 3
     assert "mask=max-one" in lm[0] and lm[1].upper() == want.upper() and lm[2] == "" and len(lm) == 3
+
+
+@pytest.mark.gpu
+def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
+    """`compute --gpus N` (new long option / KMERCAMEL_GPUS): N rank threads in one process, the k-mer set
+    hash-sharded over them, exchanges through the in-process thread transport (ranks beyond the device count share the GPU).
+    Same bytes as without the option: random reads, branching reads, a genome with cycles (one record: some ranks get no
+    input); option combinations the sharded path does not cover run on one GPU and say so."""
+    import gzip
+    recs = gen.random_records(3000, 400, seed=21)
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d\n%s\n" % (i, r))
+    br = str(tmp_path / "branching.fa")
+    with open(br, "wb") as f:
+        for i, r in enumerate(gen.stress_reads(4000, 150, 250, seed=77)):
+            f.write(b">b%d\n%s\n" % (i, r))
+    genome = str(tmp_path / "sp.fa")
+    with gzip.open(os.path.join(golden_dir, "spneumoniae.fa.gz"), "rb") as g, open(genome, "wb") as f:
+        f.write(g.read())
+    for path, ks in ((fa, ("31", "21")), (br, ("23",)), (genome, ("31",))):
+        for k in ks:
+            for extra in ((), ("-u",)):
+                want = run("compute", "-k", k, *extra, path)
+                assert want.returncode == 0, want.stderr[-400:]
+                for n in (("2", "3") if path != genome else ("2",)):
+                    got = run("compute", "-k", k, *extra, "--gpus", n, path)
+                    assert got.returncode == 0, got.stderr[-600:]
+                    assert got.stdout == want.stdout, (path, k, extra, n)
+    # through the environment, into a file
+    o1, o2 = str(tmp_path / "a.fa"), str(tmp_path / "b.fa")
+    assert run("compute", "-k", "31", "-o", o1, fa).returncode == 0
+    p = subprocess.run([BIN, "compute", "-k", "31", "-o", o2, fa], capture_output=True, text=True, env=dict(os.environ, KMERCAMEL_GPUS="2"))
+    assert p.returncode == 0 and open(o1).read() == open(o2).read()
+    # -M / -z / -S / small k: one GPU, with a note
+    m = str(tmp_path / "m.fa")
+    p = run("compute", "-k", "31", "-M", m, "--gpus", "2", fa)
+    assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "31", fa).stdout
+    assert run("compute", "-k", "31", "--gpus", "0", fa).returncode == 1
