@@ -56,8 +56,13 @@ def main():
             pos += n_r
         assert pos == stats["length"], "slices cover %d of %d characters" % (pos, stats["length"])
         np.save(out_path, np.frombuffer(b"".join(parts), dtype=np.uint8))
-        print("sharded ok: world=%d N=%d S=%d L=%d jump_rounds=%d bytes_sent(rank0)=%d" % (world, stats["n_kmers"], stats["n_simplitigs"], stats["length"],
-                                                                                         stats["matching_rounds"], gathered[0][4]["bytes_sent"]), flush=True)
+        per_rank = [g[4]["bytes_sent"] / max(1, g[3]["n_kmers_rank"]) for g in gathered]
+        print("sharded ok: world=%d N=%d S=%d L=%d jump_rounds=%d bytes_sent(rank0)=%d max bytes sent per owned k-mer=%.2f collectives=%d" % (
+            world, stats["n_kmers"], stats["n_simplitigs"], stats["length"], stats["matching_rounds"], gathered[0][4]["bytes_sent"], max(per_rank),
+            gathered[0][4]["calls"]), flush=True)
+        import json
+        with open(out_path + ".stats.json", "w") as f:
+            json.dump({"world": world, "n_kmers": stats["n_kmers"], "bytes_sent_per_owned_kmer": per_rank, "collectives": gathered[0][4]["calls"]}, f)
     comm.close()
     ctx.close()
     dist.destroy_process_group()

@@ -130,3 +130,22 @@ def test_bench_gpus2_line(tmp_path):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["n_kmers"] == 20000 * 1000
     assert line["checks"]["ones_eq_N"] and len(line["per_rank"]) == 2
+
+
+def test_exchange_volume_per_kmer(ctx, tmp_path):
+    """Bytes a rank sends per k-mer it owns (kc_comm_stats), 4 ranks, 2*10^6 31-mers of random reads.  Measured after the
+    per-port queries (one query per remote port, answered with the finished link word): 37.9 B at 4 ranks -- k-mer buckets 6,
+    port queries and answers ~4, output messages ~0.4, the rest is the log-round pointer jumping over chain fragments
+    (DESIGN.md section 7 has the break-down and what would replace it).  The bound keeps the volume from creeping back up."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    fa = str(tmp_path / "reads.fa")
+    seq = bench.generate(5, 0, 2000, 1030, fasta=fa)
+    out = str(tmp_path / "out.npy")
+    got = run_ranks(4, fa, 31, "bi", out)
+    want = kc.compute(ctx, seq, 31, True)
+    assert np.array_equal(got, want.array())
+    want.close()
+    st = json.load(open(out + ".stats.json"))
+    assert st["world"] == 4 and max(st["bytes_sent_per_owned_kmer"]) <= 42.0, st
