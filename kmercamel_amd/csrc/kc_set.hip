@@ -315,22 +315,35 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
 template <int W>
 __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
                                                               int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap,
-                                                              const u64 *__restrict__ seg_scan, int nseg) {
+                                                              const u64 *__restrict__ seg_scan, int nseg, int merge_r, int sample_stride) {
     // nseg == 0: the block's keys are bucket[block * 2^bshift ...], bcursor[block] of them (single GPU).  nseg > 0 (hash-sharded
     // build): the block is LOCAL block blockIdx.x of this rank's range and its keys arrived in nseg segments, one per source
     // rank: segment q = bucket[seg_scan[q * gridDim.x + block] .. seg_scan[q * gridDim.x + block + 1]).
+    // merge_r > 0 (the scatter ran with merge_r times as many blocks as the table now has -- the table was sized by k-mer
+    // OCCURRENCES and is now sized by distinct k-mers): block b is built from the merge_r scatter buckets b * merge_r ... (the
+    // block index is a range reduction of the minimizer hash, so dividing the number of blocks by r maps bucket i to block i / r).
+    // sample_stride > 0: count only -- workgroup i inserts scatter bucket i * sample_stride into LDS and adds the number of
+    // distinct keys to counters[2] and the bucket's occurrences to counters[3]; nothing is written to the table.
     extern __shared__ u64 kc_blk[];
     __shared__ u64 seg_lo[KC_MAX_SEG], seg_pre[KC_MAX_SEG + 1];
     const u32 bs = 1u << set.bshift;
     u64 *lk = kc_blk;
     volatile u8 *lt = reinterpret_cast<volatile u8 *>(kc_blk + (size_t)bs * W);
     __shared__ u32 added_s;
-    const u64 base = set.rlo + ((u64)blockIdx.x << set.bshift);
+    const u64 src_blk = sample_stride ? (u64)blockIdx.x * (u64)sample_stride : (u64)blockIdx.x;
+    const u64 base = set.rlo + (src_blk << set.bshift);
+    if (merge_r) nseg = merge_r;
     if (threadIdx.x == 0) {
         added_s = 0;
         u64 a = 0;
         for (int q = 0; q < nseg; ++q) {
-            const u64 lo = seg_scan[(u64)q * gridDim.x + blockIdx.x], hi = seg_scan[(u64)q * gridDim.x + blockIdx.x + 1];
+            u64 lo, hi;
+            if (merge_r) {
+                const u64 sb = (u64)blockIdx.x * (u64)merge_r + (u64)q;
+                u64 c = bcursor[sb];
+                if (c > bs) c = bs;
+                lo = sb << set.bshift; hi = lo + c;
+            } else { lo = seg_scan[(u64)q * gridDim.x + blockIdx.x]; hi = seg_scan[(u64)q * gridDim.x + blockIdx.x + 1]; }
             seg_lo[q] = lo; seg_pre[q] = a; a += hi - lo;
         }
         seg_pre[nseg] = a;
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     __syncthreads();
     u64 n;
     if (nseg) n = seg_pre[nseg];
-    else { n = bcursor[blockIdx.x]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
+    else { n = bcursor[src_blk]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
     u32 added = 0;
     for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
         Key<W> key;
@@ -380,7 +393,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
                 if (eq) done = true; else ++p;
             } else ++p;
         }
-        if (!done) {   // block-local run exhausted: the global insert (second home) takes it after all blocks are written
+        if (!done && !sample_stride) {   // block-local run exhausted: the global insert (second home) takes it after all blocks are written
             const u64 pos = atomicAdd((ull *)&counters[2], 1ULL);
             if (pos < ovf_cap)
                 for (int w = 0; w < W; ++w) ovf_list[pos * W + w] = key.w[w];
@@ -388,6 +401,10 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     }
     if (added) atomicAdd(&added_s, added);
     __syncthreads();
+    if (sample_stride) {
+        if (threadIdx.x == 0) { atomicAdd((ull *)&counters[2], (ull)added_s); atomicAdd((ull *)&counters[3], (ull)n); }
+        return;
+    }
     for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
         reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
@@ -497,6 +514,7 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     if (const char *e = getenv("KC_LOAD")) { double v = atof(e); if (v >= 0.2 && v <= 0.9) load = v; }
     u64 cap = (u64)((double)capacity_hint / load) + 1024;
     s->nblocks = (cap + (((u64)1 << s->bshift) - 1)) >> s->bshift;
+    if (s->nblocks >= 4096) s->nblocks = (s->nblocks + 63) / 64 * 64;   // (a table sized by occurrences can later be rebuilt with 2, 4, ... 64 times fewer blocks)
     cap = s->nblocks << s->bshift;
     s->cap = cap;
     int rc = set_alloc_table(s, cap, &s->keys, &s->state, &s->tags, false);   // filled on first use (kc_view), or never (bucketed build)
@@ -630,14 +648,52 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     const size_t lds_build = (size_t)bs * (8 * W + 1);
     KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     const int fresh = set->size_host == 0 ? 1 : 0;
+    // The table was sized by k-mer OCCURRENCES (the number of distinct k-mers is unknown before the build; khash grows with the
+    // distinct keys, khash.h:314-321).  On a fresh set, count the distinct keys of a sample of the scatter buckets (a bucket holds
+    // ALL occurrences of its k-mers, so the sample is exact for its part of the k-mer space); when every k-mer occurs r >= 2 times
+    // on average (reads with coverage), build a table with r times fewer blocks, each from r neighbouring buckets -- every
+    // table-sized pass of phase 1 then costs what the distinct k-mers cost, not what the occurrences cost.
+    int merge_r = 0;
+    u64 scatter_ovf = 0;
+    if (fresh && !set->rcap && set->nblocks >= 256 && !getenv("KC_NO_RESIZE")) {
+        KC_HIP(ctx, hipMemcpyAsync(&scatter_ovf, set->counters + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // (a bucket that overflowed keeps only part of its keys, and the clean-up sweep below addresses blocks of the scatter
+        // geometry: such inputs keep the table as it is)
+        if (!scatter_ovf) {
+            const int stride = set->nblocks >= 64 * 128 ? 64 : (int)(set->nblocks / 128);
+            const u64 nsample = (set->nblocks + stride - 1) / stride;
+            hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)nsample), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
+                               (const u64 *)bcursor, 1, set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, 0, stride);
+            u64 hs[4] = {0, 0, 0, 0};
+            KC_HIP(ctx, hipMemcpyAsync(hs, set->counters, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
+            const u64 distinct = hs[2], occ = hs[3];
+            int r = 1;
+            while (2 * r <= KC_MAX_SEG && distinct && occ >= (u64)(2 * r) * distinct && set->nblocks % (u64)(2 * r) == 0 && set->nblocks / (u64)(2 * r) >= 64) r *= 2;
+            if (getenv("KC_SET_TRACE"))
+                fprintf(stderr, "[set] sample of %llu buckets: %llu occurrences, %llu distinct -> %d scatter bucket(s) per table block\n", (unsigned long long)nsample,
+                        (unsigned long long)occ, (unsigned long long)distinct, r);
+            if (r > 1) {
+                merge_r = r;
+                kc_release(ctx, set->keys); kc_release(ctx, set->state); kc_release(ctx, set->tags);
+                set->keys = nullptr; set->state = nullptr; set->tags = nullptr;
+                set->nblocks /= (u64)r;
+                set->cap = set->nblocks << set->bshift;
+                KC_TRY(set_alloc_table(set, set->cap, &set->keys, &set->state, &set->tags, false));
+            }
+        }
+    }
     if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
     set->unclean = false;                        // the build kernel writes every slot, state and tag of every block
     hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                       (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0);
+                       (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0);
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    h[3] |= scatter_ovf;
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu\n", W,
                 (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3]);
@@ -803,7 +859,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     set->unclean = false;
     hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
-                       (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G);
+                       (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G, 0, 0);
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
