@@ -35,7 +35,8 @@ CHUNK_RECORDS = 100000  # the record set is generated in chunks of this many rec
 def traffic_from_profile(kernel_substr, records, k):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS workload (separate FETCH_SIZE /
     WRITE_SIZE passes, tools/collect_profile.sh -> tools/summarize_profile.py); None when no profile of it is committed."""
-    name = {(2500000, 31): "r02_final_cfg2_2p5G_traffic.json", (100000, 31): "r02_final_cfg1_traffic.json"}.get((records, k))
+    name = {(2500000, 31): "r03_cfg2_2p5G_traffic.json", (100000, 31): "r03_cfg1_traffic.json", (100000, 63): "r03_k63_traffic.json",
+            (100000, 127): "r03_k127_traffic.json"}.get((records, k))
     path = os.path.join(ROOT, "profiles", name) if name else None
     if not path or not os.path.exists(path):
         return None, None
@@ -345,7 +346,7 @@ def main():
         us_probe = sum(s["us_probe_kernel"] for s in stats) / len(stats)
         us_insert = sum(s["us_insert_kernel"] for s in stats) / len(stats)
         if us_probe >= us_insert:
-            name, us, ksub = "kc_choose_dense_kernel<W,K> (neighbour probe, round 1)", us_probe, "kc_choose_dense_kernel"
+            name, us, ksub = "kc_probe_block_kernel<W,K,SK> (neighbour probe, round 1)", us_probe, "kc_probe_block_kernel"
             alg_bytes = N * (2 * W + 16)          # one successful probe read per side (2W) + the two 8-B port links written
         else:
             name, us, ksub = "k-mer set build (kc_bucket_scatter_kernel + kc_block_build_kernel)", us_insert, "kc_bucket_scatter_kernel"

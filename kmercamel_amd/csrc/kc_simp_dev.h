@@ -713,26 +713,29 @@ __device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 
     return (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD) | splitbit;
 }
 
-#define KC_PROBE_THREADS 512
-#define KC_PROBE_WAVES (KC_PROBE_THREADS / 64)
 #define KC_PROBE_SSTACK 128   /* per wave: occupied slots waiting for a full step (< 64 left over + 64 new) */
-#define KC_PROBE_ESTACK 120   /* per wave: listed ports waiting for a full step (< 64 left over + up to 64 new per port; more go to the spill list) */
-static inline size_t kc_probe_lds_bytes(int bshift, int W, bool stage_keys) {
+// per wave: listed ports waiting for a full step (< 64 left over + the new ones of one port; more go to the spill list).  MM: the
+// minimizer hash of the port's middle is stacked with it (4 more bytes per entry); else the external pass recomputes it.
+#define KC_PROBE_ESTACK(MM) ((MM) ? 120 : 112)
+static inline size_t kc_probe_lds_bytes(int bshift, int W, bool stage_keys, int nt, bool mm) {
     const size_t bs = (size_t)1 << bshift;
-    return bs + (stage_keys ? bs * W * 8 : 0) + (size_t)KC_PROBE_WAVES * (KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK * 6);
+    return bs + (stage_keys ? bs * W * 8 : 0) + (size_t)(nt / 64) * (KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK(mm) * (mm ? 6 : 2));
 }
-template <int W, int KC, bool SK>
-__global__ void __launch_bounds__(KC_PROBE_THREADS) kc_probe_block_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
-                                                                         u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
-                                                                         u64 branch_shard_cap, u64 *branch_cursors, u64 *spill, u64 spill_cap,
-                                                                         u64 *spill_cursor) {
+template <int W, int KC, bool SK, int NT, bool MM>
+__global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
+                                                            u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
+                                                            u64 branch_shard_cap, u64 *branch_cursors, u64 *spill, u64 spill_cap,
+                                                            u64 *spill_cursor) {
+    constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM), WBYTES = KC_PROBE_SSTACK * 2 + ECAP * (MM ? 6 : 2);
     // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
     // [w bs/8, (w+1) bs/8) in rows of 64, pushes the occupied ones on its own stack and takes 64 off it whenever that many wait, so
     // every step runs with all lanes busy and no wave ever waits for another (with block-wide lists and barriers every stretch
     // ended in a nearly empty step that the other seven waves sat out: 4.1 ms against 3.6 ms per 10^8 k-mers).  A port that the
     // one-window search does not settle (home in another block: ~10 %; second match or no empty slot in the window: ~5 %) goes on
     // the wave's second stack with the minimizer hash of its middle, and is looked up in global memory 64 at a time.
-    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][per wave: slot stack u16 x 128, port stack u16 x 120 + u32 x 120]
+    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][per wave: slot stack u16 x 128, port stack u16 x ECAP (+ u32 x ECAP)]
+    // Single-word keys: 1024 threads and port stacks without the hash = 79 KB, two workgroups per CU = 8 waves per SIMD (the kernel
+    // waits on LDS and memory more than it issues: at 4 waves per SIMD its VALU pipes were half idle).
     extern __shared__ ulonglong2 kc_pb[];
     const int k = KC ? KC : k_rt;
     const int m = KC ? KC_MSPEC : set.m;
@@ -743,10 +746,10 @@ __global__ void __launch_bounds__(KC_PROBE_THREADS) kc_probe_block_kernel(SetVie
     u8 *st = reinterpret_cast<u8 *>(kc_pb);
     u64 *sk = reinterpret_cast<u64 *>(st + bs);
     const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    u8 *wbase = st + bs + (SK ? (size_t)bs * W * 8 : 0) + (size_t)wv * (KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK * 6);
+    u8 *wbase = st + bs + (SK ? (size_t)bs * W * 8 : 0) + (size_t)wv * WBYTES;
     unsigned short *sstack = reinterpret_cast<unsigned short *>(wbase);
-    u32 *emmh = reinterpret_cast<u32 *>(wbase + KC_PROBE_SSTACK * 2);
-    unsigned short *epid = reinterpret_cast<unsigned short *>(wbase + KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK * 4);
+    unsigned short *epid = reinterpret_cast<unsigned short *>(wbase + KC_PROBE_SSTACK * 2);
+    u32 *emmh = reinterpret_cast<u32 *>(wbase + KC_PROBE_SSTACK * 2 + ECAP * 2);   // (MM only; 4-byte aligned: ECAP is even)
     {
         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(set.tags + base);
         for (u32 j = threadIdx.x; j < bs / 16; j += KC_PROBE_THREADS) kc_pb[j] = src[j];
@@ -800,7 +803,14 @@ __global__ void __launch_bounds__(KC_PROBE_THREADS) kc_probe_block_kernel(SetVie
                     const u64 slot = base + so;
                     const Key<W> x = load_x(so);
                     const Key<W> xr = key_rc(x, k);
-                    const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, emmh[ecnt + lane]);
+                    u32 mmh;
+                    if (MM) mmh = emmh[ecnt + lane];
+                    else {
+                        const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+                        const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+                        mmh = kc_mid_min<W, KC>(mid, midr, k, m);
+                    }
+                    const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
                     u64 cs[4]; u32 qb;
                     if (!kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb)) to_spill((slot << 1) | (u64)port);
                     else link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors,
@@ -846,8 +856,8 @@ __global__ void __launch_bounds__(KC_PROBE_THREADS) kc_probe_block_kernel(SetVie
                 const unsigned long long dm = __ballot(defer);
                 if (dm) {
                     const u32 nd = (u32)__popcll(dm);
-                    if (ecnt + nd <= KC_PROBE_ESTACK) {
-                        if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); emmh[at] = mmh; }
+                    if (ecnt + nd <= (u32)ECAP) {
+                        if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); if (MM) emmh[at] = mmh; }
                         ecnt += nd;
                     } else if (defer) to_spill((slot << 1) | (u64)port);
                 }

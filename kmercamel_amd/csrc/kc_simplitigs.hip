@@ -826,21 +826,28 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&spill, spill_cap));
         // middle-based homes: one workgroup per block, tags (and single-word keys of blocks up to 8192 slots) staged in LDS
         const bool stage_keys = W == 1 && set->bshift <= 13 && !getenv("KC_NOSTAGE");
-        const size_t lds = kc_probe_lds_bytes(set->bshift, W, stage_keys) + (getenv("KC_PROBE_PAD") ? (size_t)atoi(getenv("KC_PROBE_PAD")) : 0);
+        const int NT1 = getenv("KC_PROBE_NT512") ? 512 : 1024;   // (tuning knob: the 512-thread form of the single-word kernel)
+        const int nt = (stage_keys && NT1 == 1024) ? 1024 : 512;
+        const bool mm = nt == 512;
+        const size_t lds = kc_probe_lds_bytes(set->bshift, W, stage_keys, nt, mm) + (getenv("KC_PROBE_PAD") ? (size_t)atoi(getenv("KC_PROBE_PAD")) : 0);
         const unsigned pgrid = (unsigned)((set->nblocks + 7) / 8 * 8);
         auto launch = [&](auto kern) -> int {
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (getenv("KC_SIMP_TRACE")) {
                 int nb = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), KC_PROBE_THREADS, lds);
-                fprintf(stderr, "[simp] probe kernel: %zu bytes of LDS per workgroup, %d workgroups per CU\n", lds, nb);
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), nt, lds);
+                fprintf(stderr, "[simp] probe kernel: %d threads, %zu bytes of LDS per workgroup, %d workgroups per CU\n", nt, lds, nb);
             }
-            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(KC_PROBE_THREADS), lds, ctx->stream, sv, link, k, compl_, xcd_aware, heads_sh, heads_shard_cap,
+            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware, heads_sh, heads_shard_cap,
                                heads_cursors, branch_sh, branch_shard_cap, branch_cursors, spill, spill_cap, spill_cursor);
             return KC_OK;
         };
-        if (stage_keys) { if constexpr (W == 1) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true>) : launch(kc_probe_block_kernel<W, 0, true>)); }
-        else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false>) : launch(kc_probe_block_kernel<W, 0, false>));
+        if (stage_keys) {
+            if constexpr (W == 1) {
+                if (nt == 1024) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false>));
+                else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 512, true>) : launch(kc_probe_block_kernel<W, 0, true, 512, true>));
+            }
+        } else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true>));
     } else {
         // plain hashing (k < 18): per-key homes, 8 lookups per k-mer
         const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);

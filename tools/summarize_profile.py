@@ -42,7 +42,7 @@ def main(src, tag):
         out["_calibration"] = {"kernel": pk[0], "known_read_bytes": nbytes, "fetch_size_bytes_raw": out[pk[0]]["fetch_size_bytes_raw"],
                                "ratio_known_over_raw": round(nbytes / out[pk[0]]["fetch_size_bytes_raw"], 3) if nbytes else None}
     json.dump(out, open("profiles/%s_traffic.json" % tag, "w"), indent=1, sort_keys=True)
-    dom = [k for k in out if "kc_choose_dense_kernel" in k]
+    dom = [k for k in out if "kc_probe_block_kernel" in k]
     if dom:
         print(dom[0], out[dom[0]])
     print(out.get("_calibration"))
