@@ -340,6 +340,59 @@ __global__ void __launch_bounds__(256) kc_shard_apply_jump_kernel(const u64 *__r
     if (ended) last[e] = a & ~((u64)1 << 63);
 }
 
+// ---- fragment ranking by waves (bidirectional sets, chains of moderate length in fragments: read sets).  Pointer jumping
+// keeps EVERY fragment exchanging 24 bytes for log2(chain length) rounds -- ~160 bytes per fragment, the largest item of the
+// whole exchange.  A wave costs each fragment one 24-byte message: every chain head starts one, a fragment that receives
+// {its entry port, payload, nodes before it} notes both and passes {successor port, payload, nodes + own length} on.  Both
+// directions of every chain run at once, and what a fragment needs of its own direction -- the nodes from here to the chain's
+// end and the chain's final fragment -- is what its TWIN (the same run walked the other way, entered at this one's exit port)
+// learnt from the wave of the opposite direction: the nodes before the twin, and the payload, which the head of that wave set
+// to its own twin = the final fragment of this direction.  Rounds = fragments of the longest chain; inputs with long chains
+// (genomes) stay with pointer jumping.
+__global__ void __launch_bounds__(256) kc_shard_wave_init_kernel(const u64 *__restrict__ link, const u64 *__restrict__ entries, u64 n, const u64 *__restrict__ f_exit,
+                                                                 const u32 *__restrict__ fidx, u64 rlo2, int me, u64 *pay, u64 *poff, u8 *flags) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool head = LK_STATE(link[entries[t]]) == LK_DEAD;
+    pay[t] = head ? KC_GID(me, fidx[f_exit[t] - rlo2]) : KC_NONE64;
+    poff[t] = 0;
+    flags[t] = head ? 1 : 0;
+}
+// senders of a round = the fragments reached in the previous one that have a successor
+__global__ void __launch_bounds__(256) kc_shard_wave_flag_kernel(const u8 *__restrict__ reached_now, const u64 *__restrict__ f_partner, u64 n, u8 *send) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) send[t] = reached_now[t] && f_partner[t] != KC_NONE64;
+}
+__global__ void __launch_bounds__(256) kc_shard_wave_send_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ f_partner, const u64 *__restrict__ f_len,
+                                                                 const u64 *__restrict__ pay, const u64 *__restrict__ poff, u64 rcap2, u64 *msgs, u8 *dest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = act[t], p = f_partner[e];
+    msgs[3 * t] = p; msgs[3 * t + 1] = pay[e]; msgs[3 * t + 2] = poff[e] + f_len[e];
+    dest[t] = (u8)(p / rcap2);
+}
+__global__ void __launch_bounds__(256) kc_shard_wave_recv_kernel(const u64 *__restrict__ m, u64 n, const u32 *__restrict__ fidx, u64 rlo2, u64 *pay, u64 *poff, u8 *reached_next) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u32 e = fidx[m[3 * t] - rlo2];
+    pay[e] = m[3 * t + 1]; poff[e] = m[3 * t + 2];
+    reached_next[e] = 1;
+}
+// what pointer jumping would have left behind: dist = nodes from the fragment's first node to the chain's end, last = the chain's
+// final fragment, nxt = none; fragments no wave reached (cross-rank cycles) keep their successor port in nxt and are flagged
+__global__ void __launch_bounds__(256) kc_shard_wave_finish_kernel(u64 n, const u64 *__restrict__ f_exit, const u32 *__restrict__ fidx, u64 rlo2, const u64 *__restrict__ f_len,
+                                                                   const u64 *__restrict__ f_partner, const u64 *__restrict__ pay, const u64 *__restrict__ poff, u64 *dist,
+                                                                   u64 *last, u64 *nxt, u8 *unreached) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u32 tw = fidx[f_exit[t] - rlo2];
+    const bool ok = pay[t] != KC_NONE64 && pay[tw] != KC_NONE64;
+    dist[t] = ok ? poff[tw] + f_len[t] : f_len[t];
+    last[t] = ok ? pay[tw] : KC_NONE64;
+    nxt[t] = ok ? KC_NONE64 : f_partner[t];
+    unreached[t] = ok ? 0 : 1;
+}
+
 // ---- cycles.  K-mers all of whose ports are matched and that no entry reaches lie on cycles inside this rank: they are
 // listed here and cut by kc_cycles_parallel_kernel / kc_cycles_kernel (kc_simp_dev.h).  Fragments that never reach a chain
 // end lie on cycles that span ranks: each reports its smallest key, the ranks agree on every cycle's minimum (host, the
@@ -866,10 +919,93 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
         }
         KC_HIP(ctx, hipGetLastError());
-        // pointer jumping
+        // ---- ranking by waves (see kc_shard_wave_init_kernel) when the set is bidirectional and the chains are short in fragments
         u64 prev_active = ~(u64)0, n_act = 0;
-        bool stalled = false;
-        for (int round = 0;; ++round) {
+        bool stalled = false, ranked = false;
+        {
+            u64 tot[2] = {n_ent, 0};   // fragments, chain heads (counted below) over all ranks
+            u64 wave_max = 2048;
+            if (const char *e = getenv("KC_WAVE_MAX")) wave_max = (u64)atoll(e);   // 0: always pointer jumping (tests)
+            u64 *pay = nullptr, *poff = nullptr, *msgs = nullptr;
+            u8 *reach_a = nullptr, *reach_b = nullptr, *wdest = nullptr;
+            KC_TRY(scope.alloc(&pay, n_ent + 1)); KC_TRY(scope.alloc(&poff, n_ent + 1)); KC_TRY(scope.alloc(&reach_a, n_ent + 1)); KC_TRY(scope.alloc(&reach_b, n_ent + 1));
+            if (n_ent) hipLaunchKernelGGL(kc_shard_wave_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, (const u64 *)f_exit,
+                                          (const u32 *)fidx, 2 * rlo, me, pay, poff, reach_a);
+            if (n_ent) {
+                KC_TRY(kcu_select_flagged(ctx, iota, reach_a, n_ent, act, cur + 2 * KC_USTRIDE));
+                KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &tot[1], 1));
+            }
+            KC_TRY(kcc_allreduce_sum(c, tot, 2));
+            // a chain has tot[0] / tot[1] fragments on average: waves only when that many rounds are affordable
+            bool wave = complements && wave_max && tot[1] && tot[0] / tot[1] <= wave_max / 8;
+            u64 wrounds = 0;
+            while (wave) {
+                u64 n_send = 0;
+                if (n_ent) {
+                    hipLaunchKernelGGL(kc_shard_wave_flag_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u8 *)reach_a, (const u64 *)f_partner, n_ent, flags8);
+                    KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
+                    KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_send, 1));
+                }
+                u64 tot_send = n_send;
+                KC_TRY(kcc_allreduce_sum(c, &tot_send, 1));
+                if (tot_send == 0) break;
+                if (++wrounds > wave_max) { wave = false; break; }   // a chain much longer than the average: pointer jumping after all
+                KC_TRY(scope.alloc(&msgs, 3 * n_send + 1)); KC_TRY(scope.alloc(&wdest, n_send + 1));
+                if (n_send) hipLaunchKernelGGL(kc_shard_wave_send_kernel, dim3(kc_grid(n_send, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_send, (const u64 *)f_partner,
+                                               (const u64 *)f_len, (const u64 *)pay, (const u64 *)poff, 2 * rcap, msgs, wdest);
+                KcRoute rt;
+                KC_TRY(kcr_build(c, wdest, n_send, &rt));
+                u64 *rq = nullptr;
+                int rc = kcr_forward(c, rt, msgs, 3, 3, &rq);
+                if (rc == KC_OK && n_ent && hipMemsetAsync(reach_b, 0, n_ent, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+                if (rc == KC_OK && rt.n_recv)
+                    hipLaunchKernelGGL(kc_shard_wave_recv_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, pay, poff, reach_b);
+                (void)hipStreamSynchronize(ctx->stream);
+                kcr_free(ctx, &rt);
+                kc_release(ctx, rq);
+                scope.release(msgs); scope.release(wdest);
+                KC_TRY(rc);
+                std::swap(reach_a, reach_b);
+                ++rounds;
+            }
+            if (wave) {
+                // every chain with ends is ranked; fragments no wave reached lie on cycles that span ranks
+                if (n_ent) {
+                    hipLaunchKernelGGL(kc_shard_wave_finish_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, n_ent, (const u64 *)f_exit, (const u32 *)fidx, 2 * rlo,
+                                       (const u64 *)f_len, (const u64 *)f_partner, (const u64 *)pay, (const u64 *)poff, dist, last, nxt, flags8);
+                    KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
+                    KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_act, 1));
+                }
+                u64 tot_un = n_act;
+                KC_TRY(kcc_allreduce_sum(c, &tot_un, 1));
+                ranked = true;
+                if (tot_un) {
+                    // their successor ports -> fragment ids (the one exchange pointer jumping starts with), for the cycle analysis below
+                    stalled = true;
+                    u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
+                    u8 *dest = nullptr;
+                    KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
+                    if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, 1, 2 * rcap, req, dest);
+                    KcRoute rt;
+                    KC_TRY(kcr_build(c, dest, n_act, &rt));
+                    int rc = kcr_forward(c, rt, req, 1, 1, &rq);
+                    if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
+                    if (rc == KC_OK && rt.n_recv) hipLaunchKernelGGL(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
+                    if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, n_act + 1);
+                    if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
+                    if (rc == KC_OK && n_act) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
+                    if (rc == KC_OK && n_ent && hipMemcpyAsync(succ0, nxt, n_ent * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+                    (void)hipStreamSynchronize(ctx->stream);
+                    kcr_free(ctx, &rt);
+                    kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
+                    scope.release(req); scope.release(dest);
+                    KC_TRY(rc);
+                }
+            }
+            scope.release(pay); scope.release(poff); scope.release(reach_a); scope.release(reach_b);
+        }
+        // pointer jumping (unidirectional sets, long chains)
+        for (int round = 0; !ranked; ++round) {
             n_act = 0;
             if (n_ent) {
                 hipLaunchKernelGGL(kc_shard_active_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)nxt, n_ent, flags8);
