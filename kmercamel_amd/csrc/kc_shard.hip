@@ -27,8 +27,6 @@
 #include <unordered_map>
 #include <unordered_set>
 
-#define KC_USH 16       /* cursor shards of the record / query lists */
-#define KC_USTRIDE 16   /* words between two cursors: one 128-byte line each */
 #define KC_GID(rank, idx) (((u64)(rank) << 40) | (u64)(idx))
 #define KC_GID_RANK(g) ((int)((g) >> 40))
 #define KC_GID_IDX(g) ((g) & (((u64)1 << 40) - 1))
@@ -36,131 +34,6 @@
 #define KC_MAX_RANKS_SH 64
 
 namespace {
-
-struct ShLists {
-    u64 *qry;        // queries {key[W], pid, home}: W + 2 words, shard s owns [s * qry_scap, ...)
-    u64 qry_scap;
-    u64 *qry_cur;    // KC_USH cursors
-    u64 *edges;      // branch ports list their edges {x pid, y pid, priority, base, key x, key y}: 4 + 2 W words
-    u64 edge_cap;
-    u64 *edge_cur;
-    u64 *flags;      // [0] a list overflowed
-};
-
-// Settle one port from the slots of its candidates (cs[c], entered on port bit c of qb): the link word.  A branch port (>= 2
-// existing candidates) chooses its best edge here too -- provisionally -- and lists all its edges for the replicated branch
-// matching, which overrides the choice where the sequential rule says so.
-template <int W>
-__device__ __forceinline__ u64 kc_shard_settle_port(int k, int complements, const u64 pid, const Key<W> &x, const Key<W> &xr, const u64 (&cs)[4], const u32 qb,
-                                                    const ShLists &L) {
-    const int port = (int)(pid & 1);
-    u32 nfound = 0, bc = 0;
-#pragma unroll
-    for (u32 c = 0; c < 4; ++c)
-        if (cs[c] != KC_NONE64) { ++nfound; bc = c; }
-    if (nfound == 0) return LK_DEAD;
-    u64 bslot = 0;
-#pragma unroll
-    for (u32 c = 0; c < 4; ++c) bslot = (c == bc) ? cs[c] : bslot;
-    if (nfound == 1) return LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, bslot);
-    const u64 hx = key_hash(x);
-    Key<W> by = x; int bq = 0; u64 bpr = 0; bool have = false;
-    const u64 e0 = atomicAdd((ull *)L.edge_cur, (ull)nfound);
-    if (e0 + nfound > L.edge_cap) L.flags[0] = 1;
-    u32 ne = 0;
-    for (u32 c = 0; c < 4; ++c) {
-        u64 ts = KC_NONE64;
-#pragma unroll
-        for (u32 cc = 0; cc < 4; ++cc) ts = (c == cc) ? cs[cc] : ts;
-        if (ts == KC_NONE64) continue;
-        int q;
-        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
-        const u64 pr = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
-        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bc = c; bslot = ts; have = true; }
-        if (e0 + ne < L.edge_cap) {
-            u64 *e = L.edges + (e0 + ne) * (4 + 2 * W);
-            e[0] = pid; e[1] = (ts << 1) | (u64)q; e[2] = pr; e[3] = port ? c : 3 - c;
-            for (int w = 0; w < W; ++w) { e[4 + w] = x.w[w]; e[4 + W + w] = y.w[w]; }
-        }
-        ++ne;
-    }
-    return LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot);   // provisional; the branch matching overrides it
-}
-
-// ---------------------------------------------------------------------------------------------------- phase 1a
-// Round 1 over this rank's slot range.  Same sweep as the single-GPU round 1 (workgroup = 2048 slots of one block, block tags
-// staged in LDS).  The 4 candidates of a port share their home (kc_set_dev.h), hence their owner: a port is either settled here
-// or, when that home lies in another rank's range, becomes ONE query {x, port} that the owner answers with the finished link
-// word (24 bytes out, 8 back per remote port, where per-candidate queries cost 4 x 16).  List space is reserved once per
-// wavefront and sweep step.
-template <int W, int KC>
-__global__ void __launch_bounds__(256, 4) kc_shard_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
-                                                              ShLists L, int stage_words) {
-    extern __shared__ u64 kc_stage[];
-    __shared__ unsigned short kc_list[KC_CHOOSE_SLOTS];
-    __shared__ u32 kc_nlist;
-    const int k = KC ? KC : k_rt;
-    const u64 base = set.rlo + kc_xcd_block_id(xcd_aware) * (u64)KC_CHOOSE_SLOTS;
-    const u64 end = set.rlo + set.rcap;
-    if (base >= end) return;
-    if (threadIdx.x == 0) kc_nlist = 0;
-    const u64 sblk = base >> set.bshift;
-    {
-        const u64 *src = reinterpret_cast<const u64 *>(set.tags + (sblk << set.bshift));
-        for (int j = threadIdx.x; j < stage_words; j += 256) kc_stage[j] = src[j];
-    }
-    __syncthreads();
-    const u8 *tg = reinterpret_cast<const u8 *>(kc_stage) + (base & (((u64)1 << set.bshift) - 1));
-    for (u32 i = threadIdx.x; i < KC_CHOOSE_SLOTS; i += 256)
-        if (base + i < end && tg[i] != 0) kc_list[atomicAdd(&kc_nlist, 1u)] = (unsigned short)i;
-    __syncthreads();
-    const u32 n = kc_nlist;
-    const u32 shard = ((u32)blockIdx.x * 4u + (threadIdx.x >> 6)) & (KC_USH - 1);
-    const int QW = W + 2;
-#pragma unroll 1
-    for (u32 t0 = 0; t0 < n; t0 += 256) {
-        const u32 t = t0 + threadIdx.x;
-        const bool active = t < n;
-        KcCand2<W> cd;
-        u64 slot = 0;
-        u32 rem = 0;   // bit p = port p is answered by another rank
-        if (active) {
-            slot = base + kc_list[t];
-            kc_cand_lookup_mid<W, KC, true>(set, k_rt, complements, slot, reinterpret_cast<const u8 *>(kc_stage), sblk, cd);
-#pragma unroll
-            for (int port = 0; port < 2; ++port) {
-                const u64 pid = (slot << 1) | (u64)port;
-                if (port == 1 && cd.xpal) { link[pid] = LK_DEAD; continue; }
-                if (cd.cslot[port * 4] == KC_REMOTE) { rem |= 1u << port; continue; }
-                const u64 cs[4] = {cd.cslot[port * 4], cd.cslot[port * 4 + 1], cd.cslot[port * 4 + 2], cd.cslot[port * 4 + 3]};
-                link[pid] = kc_shard_settle_port<W>(k, complements, pid, cd.x, cd.xr, cs, (cd.qbits >> (port * 4)) & 15u, L);
-            }
-        }
-        // query space is reserved once per wavefront and sweep step (every lane runs every step, so all 64 take part): exclusive
-        // prefix sums of the query count (0..2) by ballots over its bit planes, one atomic.
-        const u32 nq = (rem & 1) + (rem >> 1);
-        const unsigned long long lt = ((unsigned long long)1 << (threadIdx.x & 63)) - 1;
-        u32 my_qry = 0, tot_qry = 0;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { const unsigned long long m = __ballot((nq >> j) & 1u); my_qry += (u32)__popcll(m & lt) << j; tot_qry += (u32)__popcll(m) << j; }
-        u64 base_qry = 0;
-        if ((threadIdx.x & 63) == 0 && tot_qry) base_qry = atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)tot_qry);
-        base_qry = __shfl(base_qry, 0, 64);
-        if (nq) {
-            u64 qpos = base_qry + my_qry;
-#pragma unroll
-            for (int port = 0; port < 2; ++port) {
-                if (!((rem >> port) & 1)) continue;
-                if (qpos >= L.qry_scap) { L.flags[0] = 1; break; }
-                u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * QW;
-                for (int w = 0; w < W; ++w) qq[w] = cd.x.w[w];
-                qq[W] = (slot << 1) | (u64)port;
-                qq[W + 1] = cd.phome[port];
-                ++qpos;
-            }
-        }
-    }
-}
 
 // destination rank of every query (owner of the home slot)
 template <int W>
@@ -743,26 +616,43 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     // An overflow doubles the lists and repeats the sweep, collectively.
     const double p_rem = 2.0 / (double)(k - set->mlen) * (double)(G - 1) / (double)G;   // (a middle holds k - m - 1 m-mers: its neighbour's minimizer differs with probability ~2 / (k - m))
     u64 qry_scap = (u64)(1.15 * 2.0 * p_rem * (double)N_local) / KC_USH + 4096;
-    u64 edge_cap = N_local / 64 + ((u64)1 << 16);
-    const int stage_words = (int)(((u64)1 << set->bshift) / 8 + 1);
-    const unsigned cgrid = kc_grid8(rcap, KC_CHOOSE_SLOTS);
+    u64 edge_cap = N_local / 64 + ((u64)1 << 16), spill_cap = N_local / 64 + ((u64)1 << 16);
+    u64 *spill = nullptr;
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
     u64 nq = 0, n_branch_edges = 0;
     for (int attempt = 0;; ++attempt) {
         KC_TRY(scope.alloc(&L.qry, qry_scap * KC_USH * QW));
         KC_TRY(scope.alloc(&L.edges, edge_cap * EW + 1));
+        KC_TRY(scope.alloc(&spill, spill_cap + 1));
         L.qry_scap = qry_scap; L.edge_cap = edge_cap;
         L.qry_cur = cur + KC_USH * KC_USTRIDE; L.flags = cur + 2 * KC_USH * KC_USTRIDE; L.edge_cur = cur + (2 * KC_USH + 1) * KC_USTRIDE;
         KC_HIP(ctx, hipMemsetAsync(cur, 0, (2 * KC_USH + 4) * KC_USTRIDE * 8, ctx->stream));
         KC_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-        if (k == KSPEC && set->mlen == KC_MSPEC && !getenv("KC_NO_KSPEC"))
-            hipLaunchKernelGGL((kc_shard_choose_kernel<W, KSPEC>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
-        else
-            hipLaunchKernelGGL((kc_shard_choose_kernel<W, 0>), dim3(cgrid), dim3(256), (size_t)stage_words * 8, ctx->stream, sv, link, k, complements, 1, L, stage_words);
+        {
+            // the single-GPU round-1 kernel in its SH form: one workgroup per block of this rank (tags, and single-word keys, staged in LDS)
+            const bool kspec = k == KSPEC && set->mlen == KC_MSPEC && !getenv("KC_NO_KSPEC");
+            const bool stage_keys = W == 1 && set->bshift <= 13 && !getenv("KC_NOSTAGE");
+            const int nt = stage_keys ? 1024 : 512;
+            const bool mm = nt == 512;
+            const size_t lds = kc_probe_lds_bytes(set->bshift, W, stage_keys, nt, mm);
+            const u64 bpr = rcap >> set->bshift;
+            const unsigned pgrid = (unsigned)((bpr + 7) / 8 * 8);
+            auto launch = [&](auto kern) -> int {
+                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                u64 *spill_cur = cur + (2 * KC_USH + 2) * KC_USTRIDE;
+                hipLaunchKernelGGL(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, complements, 1, (u64 *)nullptr, (u64)0, (u64 *)nullptr, (u64 *)nullptr, (u64)0,
+                                   (u64 *)nullptr, spill, spill_cap, spill_cur, L);
+                hipLaunchKernelGGL((kc_shard_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, complements, (const u64 *)spill, spill_cap, (const u64 *)spill_cur, L);
+                return KC_OK;
+            };
+            if (stage_keys) {
+                if constexpr (W == 1) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false, true>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false, true>));
+            } else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true, true>));
+        }
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
         if (trace) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[shard %d/%d] probe sweep done (%s), N_local=%llu\n", me, G, hipGetErrorString(e), (unsigned long long)N_local); }
-        auto grow = [&]() { scope.release(L.qry); scope.release(L.edges); qry_scap = qry_scap * 3 + 4096; edge_cap = edge_cap * 4 + n_branch_edges; };
+        auto grow = [&]() { scope.release(L.qry); scope.release(L.edges); scope.release(spill); qry_scap = qry_scap * 3 + 4096; edge_cap = edge_cap * 4 + n_branch_edges; spill_cap *= 4; };
         {   // a list overflowed during the sweep: every rank repeats it with larger lists (nothing has been exchanged yet)
             u64 any = 0;
             KC_TRY(read_words(ctx, L.flags, &any, 1));
@@ -815,6 +705,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         grow();   // (the owners' branch edge lists overflowed while answering: sweep and exchange once more)
     }
     scope.release(L.qry); L.qry = nullptr;
+    scope.release(spill);
     // the branch subgraph: every rank's edges to every rank, settled identically everywhere
     {
         u64 *all = nullptr, n_all = 0;

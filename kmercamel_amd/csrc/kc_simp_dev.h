@@ -713,6 +713,60 @@ __device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 
     return (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD) | splitbit;
 }
 
+// ---- lists of the hash-sharded flow's round 1 (kc_shard.hip): queries for the ports another rank answers, the edges of branch ports
+#define KC_USH 16       /* cursor shards of the query list */
+#define KC_USTRIDE 16   /* words between two cursors: one 128-byte line each */
+struct ShLists {
+    u64 *qry;        // queries {key[W], pid, home}: W + 2 words, shard s owns [s * qry_scap, ...)
+    u64 qry_scap;
+    u64 *qry_cur;    // KC_USH cursors
+    u64 *edges;      // branch ports list their edges {x pid, y pid, priority, base, key x, key y}: 4 + 2 W words
+    u64 edge_cap;
+    u64 *edge_cur;
+    u64 *flags;      // [0] a list overflowed
+};
+
+// Settle one port from the slots of its candidates (cs[c], entered on port bit c of qb): the link word.  A branch port (>= 2
+// existing candidates) chooses its best edge here too -- provisionally -- and lists all its edges for the replicated branch
+// matching, which overrides the choice where the sequential rule says so.
+template <int W>
+__device__ __forceinline__ u64 kc_shard_settle_port(int k, int complements, const u64 pid, const Key<W> &x, const Key<W> &xr, const u64 (&cs)[4], const u32 qb,
+                                                    const ShLists &L) {
+    const int port = (int)(pid & 1);
+    u32 nfound = 0, bc = 0;
+#pragma unroll
+    for (u32 c = 0; c < 4; ++c)
+        if (cs[c] != KC_NONE64) { ++nfound; bc = c; }
+    if (nfound == 0) return LK_DEAD;
+    u64 bslot = 0;
+#pragma unroll
+    for (u32 c = 0; c < 4; ++c) bslot = (c == bc) ? cs[c] : bslot;
+    if (nfound == 1) return LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, bslot);
+    const u64 hx = key_hash(x);
+    Key<W> by = x; int bq = 0; u64 bpr = 0; bool have = false;
+    const u64 e0 = atomicAdd((ull *)L.edge_cur, (ull)nfound);
+    if (e0 + nfound > L.edge_cap) L.flags[0] = 1;
+    u32 ne = 0;
+    for (u32 c = 0; c < 4; ++c) {
+        u64 ts = KC_NONE64;
+#pragma unroll
+        for (u32 cc = 0; cc < 4; ++cc) ts = (c == cc) ? cs[cc] : ts;
+        if (ts == KC_NONE64) continue;
+        int q;
+        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+        const u64 pr = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
+        if (!have || edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bc = c; bslot = ts; have = true; }
+        if (e0 + ne < L.edge_cap) {
+            u64 *e = L.edges + (e0 + ne) * (4 + 2 * W);
+            e[0] = pid; e[1] = (ts << 1) | (u64)q; e[2] = pr; e[3] = port ? c : 3 - c;
+            for (int w = 0; w < W; ++w) { e[4 + w] = x.w[w]; e[4 + W + w] = y.w[w]; }
+        }
+        ++ne;
+    }
+    return LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot);   // provisional; the branch matching overrides it
+}
+
+
 #define KC_PROBE_SSTACK 128   /* per wave: occupied slots waiting for a full step (< 64 left over + 64 new) */
 // per wave: listed ports waiting for a full step (< 64 left over + the new ones of one port; more go to the spill list).  MM: the
 // minimizer hash of the port's middle is stacked with it (4 more bytes per entry); else the external pass recomputes it.
@@ -721,11 +775,14 @@ static inline size_t kc_probe_lds_bytes(int bshift, int W, bool stage_keys, int 
     const size_t bs = (size_t)1 << bshift;
     return bs + (stage_keys ? bs * W * 8 : 0) + (size_t)(nt / 64) * (KC_PROBE_SSTACK * 2 + KC_PROBE_ESTACK(mm) * (mm ? 6 : 2));
 }
-template <int W, int KC, bool SK, int NT, bool MM>
+// SH (hash-sharded flow): the workgroups sweep this rank's blocks; a port whose home lies in another rank's range becomes ONE query
+// {x, port id, home} (the owner answers with the finished link word); ports are settled by kc_shard_settle_port (plain link
+// words, branch ports list their edges in L), nothing is listed for the single-GPU chain discovery.
+template <int W, int KC, bool SK, int NT, bool MM, bool SH = false>
 __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
                                                             u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
                                                             u64 branch_shard_cap, u64 *branch_cursors, u64 *spill, u64 spill_cap,
-                                                            u64 *spill_cursor) {
+                                                            u64 *spill_cursor, ShLists L = ShLists{}) {
     constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM), WBYTES = KC_PROBE_SSTACK * 2 + ECAP * (MM ? 6 : 2);
     // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
     // [w bs/8, (w+1) bs/8) in rows of 64, pushes the occupied ones on its own stack and takes 64 off it whenever that many wait, so
@@ -739,8 +796,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     extern __shared__ ulonglong2 kc_pb[];
     const int k = KC ? KC : k_rt;
     const int m = KC ? KC_MSPEC : set.m;
-    const u64 blk = kc_xcd_block_id(xcd_aware);
-    if (blk >= set.nblocks) return;
+    const u64 lblk = kc_xcd_block_id(xcd_aware);   // (SH: index among this rank's blocks)
+    if (lblk >= (SH ? set.rcap >> set.bshift : set.nblocks)) return;
+    const u64 blk = (SH ? set.rlo >> set.bshift : 0) + lblk;
     const u32 bs = 1u << set.bshift;
     const u64 base = blk << set.bshift;
     u8 *st = reinterpret_cast<u8 *>(kc_pb);
@@ -771,12 +829,70 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     auto to_spill = [&](u64 pid) {
         const u64 at = atomicAdd((ull *)spill_cursor, 1ULL);
         if (at < spill_cap) spill[at] = pid;
+        else if (SH) L.flags[0] = 1;   // (the sharded flow repeats the sweep with larger lists)
     };
     const unsigned long long ltm = ((unsigned long long)1 << lane) - 1;
     auto wave_sync = [&]() {   // LDS traffic between the lanes of this wave: the hardware keeps a wave's LDS instructions in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // a listed port (called by all lanes of the wave that are in the current step; `on` = this lane has one): the window search
+    // in global memory, or -- SH, home on another rank -- a query
+    auto settle_listed = [&](bool on, u32 so, int port, u32 mmh_in) {
+        const u64 slot = base + so;
+        bool remote = false;
+        Key<W> x = key_zero<W>(), xr = x;
+        KcPortDesc d{};
+        if (on) {
+            x = load_x(so);
+            xr = key_rc(x, k);
+            u32 mmh = mmh_in;
+            if (!MM) {
+                const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+                const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+                mmh = kc_mid_min<W, KC>(mid, midr, k, m);
+            }
+            d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
+            remote = SH && d.home - set.rlo >= set.rcap;
+            if (!remote) {
+                u64 cs[4]; u32 qb;
+                const bool ok = kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb);
+                if (!ok) to_spill((slot << 1) | (u64)port);   // (rare: generic lookups in a kernel of their own keep this one lean)
+                else if (SH) {
+                    // at most one candidate: the word; a branch port is settled (and lists its edges) in the spill kernel
+                    u32 nf = 0, bc = 0;
+                    u64 bs1 = 0;
+#pragma unroll
+                    for (u32 c = 0; c < 4; ++c)
+                        if (cs[c] != KC_NONE64) { ++nf; bc = c; bs1 = cs[c]; }
+                    if (nf >= 2) to_spill((slot << 1) | (u64)port);
+                    else link[(slot << 1) | (u64)port] = nf ? LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, bs1) : LK_DEAD;
+                }
+                else link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch,
+                                                                        branch_shard_cap, branch_cursors);
+            }
+        }
+        if (SH) {   // query space: one reservation per wave and call
+            const unsigned long long rm = __ballot(remote);
+            if (rm) {
+                const u32 shard = ((u32)blockIdx.x * (u32)KC_PROBE_WAVES + (u32)wv) & (KC_USH - 1);
+                u64 qbase = 0;
+                const int leader = __builtin_ctzll(rm);
+                if (lane == leader) qbase = atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], (ull)__popcll(rm));
+                qbase = __shfl(qbase, leader, 64);
+                if (remote) {
+                    const u64 qpos = qbase + (u64)__popcll(rm & ltm);
+                    if (qpos >= L.qry_scap) L.flags[0] = 1;
+                    else {
+                        u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * (W + 2);
+                        for (int w = 0; w < W; ++w) qq[w] = x.w[w];
+                        qq[W] = (slot << 1) | (u64)port;
+                        qq[W + 1] = d.home;
+                    }
+                }
+            }
+        }
     };
     u32 scnt = 0, ecnt = 0;   // entries on the two stacks (wave-uniform)
     const u32 per_wave = bs / KC_PROBE_WAVES, rows = (per_wave + 63) / 64;
@@ -797,25 +913,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 // ---- 64 listed ports (fewer when draining): generic window search in global memory
                 const u32 take = ecnt < 64 ? ecnt : 64;
                 ecnt -= take;
-                if ((u32)lane < take) {
-                    const u32 e = epid[ecnt + lane], so = e >> 1;
-                    const int port = (int)(e & 1u);
-                    const u64 slot = base + so;
-                    const Key<W> x = load_x(so);
-                    const Key<W> xr = key_rc(x, k);
-                    u32 mmh;
-                    if (MM) mmh = emmh[ecnt + lane];
-                    else {
-                        const Key<W> lm = key_lowmask<W>(2 * (k - 2));
-                        const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
-                        mmh = kc_mid_min<W, KC>(mid, midr, k, m);
-                    }
-                    const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
-                    u64 cs[4]; u32 qb;
-                    if (!kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb)) to_spill((slot << 1) | (u64)port);
-                    else link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors,
-                                                                           branch, branch_shard_cap, branch_cursors);
-                }
+                const bool on = (u32)lane < take;
+                const u32 e = on ? epid[ecnt + lane] : 0u;
+                settle_listed(on, e >> 1, (int)(e & 1u), (MM && on) ? emmh[ecnt + lane] : 0u);
                 wave_sync();
                 continue;
             }
@@ -828,7 +928,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             const Key<W> x = load_x(so);
             const Key<W> xr = key_rc(x, k);
             const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
-            const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;           // every ~256th k-mer (by slot) is a splitter of the segment-parallel walks
+            const u64 splitbit = (!SH && (slot & 0xffull) == 0) ? LK_SPLIT : 0;    // every ~256th k-mer (by slot) is a splitter of the segment-parallel walks
             u32 minL, minR;
             kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
             u64 wd0 = 0, wd1 = 0;
@@ -842,14 +942,14 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     if (port == 1 && xpal) {   // palindromes link on port L only
                         word = LK_DEAD | splitbit;
                         done = true;
-                        if (complements) kc_push_sharded((slot << 1) | 1, heads, heads_shard_cap, heads_cursors);
+                        if (!SH && complements) kc_push_sharded((slot << 1) | 1, heads, heads_shard_cap, heads_cursors);
                     } else {
                         const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
                         bool found; u32 c, q; u64 sl;
                         if ((d.home >> set.bshift) == blk && kc_port_search_one<W, SK>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl)) {
                             word = (found ? LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) : LK_DEAD) | splitbit;
                             done = true;
-                            if (!found && (complements || port == 0)) kc_push_sharded((slot << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+                            if (!SH && !found && (complements || port == 0)) kc_push_sharded((slot << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
                         } else defer = true;
                     }
                 }
@@ -859,7 +959,8 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     if (ecnt + nd <= (u32)ECAP) {
                         if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); if (MM) emmh[at] = mmh; }
                         ecnt += nd;
-                    } else if (defer) to_spill((slot << 1) | (u64)port);
+                    } else if (SH) settle_listed(defer, so, port, mmh);   // (no room on the stack: settled on the spot)
+                    else if (defer) to_spill((slot << 1) | (u64)port);
                 }
                 if (done) { if (port) wd1 = word; else wd0 = word; have |= 1u << port; }
             }
@@ -889,6 +990,22 @@ __global__ void __launch_bounds__(256) kc_probe_spill_kernel(SetView<W> set, u64
     }
 }
 
+// the same for the hash-sharded flow: the spilled ports are local ones (remote ports became queries)
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_spill_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ spill,
+                                                             u64 spill_cap, const u64 *__restrict__ spill_cursor, ShLists L) {
+    u64 n = *spill_cursor;
+    if (n > spill_cap) n = spill_cap;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
+        const u64 pid = spill[t];
+        const int port = (int)(pid & 1);
+        const Key<W> x = set_key_at(set, pid >> 1);
+        const Key<W> xr = key_rc(x, k);
+        u64 cs[4]; u32 qb;
+        kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+        link[pid] = kc_shard_settle_port<W>(k, complements, pid, x, xr, cs, qb, L);
+    }
+}
 // round 1 by generic lookups over the whole table, one thread per slot: the fallback when the spill list of the block kernel
 // overflows (tables with many overfull blocks)
 template <int W>
