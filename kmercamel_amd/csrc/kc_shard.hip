@@ -107,11 +107,13 @@ struct FragRec {
     u64 pool_cap;
     u64 *pool_cursor;
 };
-// one thread per entry: walk the links while they stay on this rank; record the appended bases
-template <bool MARK>
+// one thread per entry: walk the links while they stay on this rank; record the appended bases.  FRAG: the in-block runs have
+// been contracted (kc_frag_contract_kernel over this rank's blocks): a run is crossed through the shortcut in its end node's
+// inward link word -- one or two scattered lines per ~9 nodes instead of one per node.
+template <bool MARK, bool FRAG>
 __global__ void __launch_bounds__(256) kc_shard_walk_kernel(const u64 *__restrict__ link, u64 rlo, u64 rcap, const u64 *__restrict__ entries, u64 n,
                                                             u64 *f_exit, u64 *f_partner, u64 *f_len, u32 *f_stream, u32 *fidx, FragRec rec, u8 *visited,
-                                                            u64 *flags) {
+                                                            u64 *flags, KcFrag frag, int bshift) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 h = entries[t];
@@ -121,27 +123,78 @@ __global__ void __launch_bounds__(256) kc_shard_walk_kernel(const u64 *__restric
     int nacc = 0, wi = 0;
     u32 chunk = KC_NO_CHUNK, first_chunk = KC_NO_CHUNK;
     bool ok = true;
+    u64 batch_next = 0;
+    int batch_left = 0;
     auto flush_word = [&](u64 word) {
-        if (chunk == KC_NO_CHUNK || wi == KC_FCW) {
-            const u64 nc = atomicAdd((ull *)rec.pool_cursor, 1ULL);
+        if (chunk == KC_NO_CHUNK) {
+            // the first chunk of walk t is chunk t: no reservation.  (Walks that hop over contracted runs reach their flushes in
+            // different loop trips, so a shared cursor here means one same-address atomic per walk, ~10 ns each: measured 79 ms
+            // against 43 ms for the plain walk of 10^9 k-mers before this.)
+            chunk = first_chunk = (u32)t;
+            wi = 0;
+        } else if (wi == KC_FCW) {
+            // later chunks are reserved eight at a time (a walk longer than one chunk is usually much longer: whole reads when one
+            // rank holds everything)
+            if (batch_left == 0) {
+                batch_next = n + atomicAdd((ull *)rec.pool_cursor, 8ULL);
+                batch_left = 8;
+            }
+            const u64 nc = batch_next++;
+            --batch_left;
             if (nc >= rec.pool_cap) { ok = false; return; }
-            if (first_chunk == KC_NO_CHUNK) first_chunk = (u32)nc; else rec.chunk_next[chunk] = (u32)nc;
+            rec.chunk_next[chunk] = (u32)nc;
             chunk = (u32)nc;
             wi = 0;
         }
         rec.pool[(u64)chunk * KC_FCW + (u64)wi++] = word;
     };
+    // append nb (1..32) bases given right-aligned in `bits` (first base in the highest pair) to the recording
+    auto push_group = [&](u64 bits, int nb) {
+        const int room = 32 - nacc;
+        if (nb < room) { acc = (acc << (2 * nb)) | bits; nacc += nb; return; }
+        const int rest = nb - room;
+        const u64 hi = rest ? (bits >> (2 * rest)) : bits;
+        const u64 word = room == 32 ? hi : ((acc << (2 * room)) | hi);
+        if (ok) flush_word(word);
+        acc = rest ? (bits & (((u64)1 << (2 * rest)) - 1)) : 0;
+        nacc = rest;
+    };
     int xp;
     while (true) {
         if (MARK) visited[cur - rlo] = 1;
         xp = co == 0 ? 1 : 0;
-        const u64 w = link[(cur << 1) | (u64)xp];
+        u64 w = link[(cur << 1) | (u64)xp];
+        if (FRAG && KC_SC_IS(w)) {
+            if (w & KC_SC_NEXT) {   // the run and the step out of it (to a slot of this rank) in one word
+                const u64 nb1 = ((w >> 45) & 7) + 1;
+                push_group(((((w >> 48) & 0x3fffull) >> (14 - 2 * (nb1 - 1))) << 2) | ((w >> 43) & 3), (int)nb1);
+                len += nb1;
+                cur = (w >> 6) & (((u64)1 << 36) - 1);
+                co = (int)((w >> 42) & 1);
+                continue;
+            }
+            const u64 blk = cur >> bshift;
+            u64 nb;
+            if (w & KC_SC_EXT) {
+                nb = (w >> 21) & 0x3fff;
+                const u64 *src = frag.pool + ((blk - frag.blk0) & 63) * frag.shard_cap + frag.blk_pool_base[blk - frag.blk0] + (w >> 35);
+                for (u64 i = 0; i < nb; i += 32) {
+                    const int mm = nb - i >= 32 ? 32 : (int)(nb - i);
+                    push_group(src[i >> 5] >> (64 - 2 * mm), mm);
+                }
+            } else {
+                nb = (w >> 21) & 31;
+                if (nb) push_group(w >> (64 - 2 * nb), (int)nb);
+            }
+            len += nb;
+            cur = (blk << bshift) | ((w >> 6) & 0x3fff);
+            co = (int)((w >> 20) & 1);
+            xp = co == 0 ? 1 : 0;
+            w = link[(cur << 1) | (u64)xp];   // the far end's way out of the run: a plain word
+        }
         if (!LK_IS_MATCHED(w)) break;
         if (LK_SLOT(w) - rlo >= rcap) { partner = LK_PID(w); break; }
-        if (!MARK) {
-            acc = (acc << 2) | LK_BASE(w);
-            if (++nacc == 32) { if (ok) flush_word(acc); acc = 0; nacc = 0; }
-        }
+        if (!MARK) push_group(LK_BASE(w), 1);
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
         ++len;
@@ -739,6 +792,18 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     u8 *flags8 = nullptr;
     KC_TRY(scope.alloc(&fidx, 2 * rcap));
     u64 rounds = 0, cycles_cut = 0;
+    // in-block runs contracted before the fragment walks (kc_frag_contract_kernel over this rank's blocks; the replaced link words are
+    // logged): as soon as anything has to walk or cut plain links (cycles) the words are put back and the plain walk takes over
+    bool frag_ok = set->mlen && set->bshift <= 13 && !getenv("KC_NOFRAG"), contracted = false;
+    u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr, *flog = nullptr, *fblog = nullptr;
+    const u64 bpr_blocks = rcap >> set->bshift;
+    auto restore_links = [&]() -> int {
+        if (!contracted) return KC_OK;
+        hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)bpr_blocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog, (const u64 *)fblog, set->bshift, rlo >> set->bshift);
+        KC_HIP(ctx, hipGetLastError());
+        contracted = false; frag_ok = false;
+        return KC_OK;
+    };
     for (int pass = 0;; ++pass) {
         if (pass == 64) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not settle after cutting cycles");
         // entries, fragment walks; cycles inside this rank are cut on the spot (no exchange involved)
@@ -762,13 +827,31 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(scope.alloc(&f_exit, n_ent + 1)); KC_TRY(scope.alloc(&f_partner, n_ent + 1)); KC_TRY(scope.alloc(&f_len, n_ent + 1));
             KC_TRY(scope.alloc(&f_stream, n_ent + 1));
             FragRec frec{};
-            frec.pool_cap = n_ent + 2 * N_local / (32 * KC_FCW) + 1024;
+            frec.pool_cap = n_ent + 2 * N_local / (32 * KC_FCW) + N_local / 8 + 1024;   // (first chunks by walk index, later ones in batches of 8 of which up to 7 stay unused)
             KC_TRY(scope.alloc(&pool, frec.pool_cap * KC_FCW)); KC_TRY(scope.alloc(&chunk_next, frec.pool_cap));
             frec.pool = pool; frec.chunk_next = chunk_next; frec.pool_cursor = cur;
             KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
+            KcFrag fr{nullptr, nullptr, 0, 0};
+            if (frag_ok && !contracted && n_ent && bpr_blocks) {
+                const u64 pool_cap = (N_local / 16 + 65536) / 64 * 64, log_cap = (N_local / 3 + 65536) / 64 * 64;
+                KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, bpr_blocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16));
+                KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, bpr_blocks));
+                KC_HIP(ctx, hipMemsetAsync(fcur, 0, 2 * 64 * 16 * 8, ctx->stream));
+                const size_t flds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
+                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
+                                   log_cap, fcur + 64 * 16, fblog);
+                KC_HIP(ctx, hipGetLastError());
+                contracted = true;
+                fr = KcFrag{fpool, fbase, pool_cap / 64, rlo >> set->bshift};
+            }
             if (n_ent) {
-                hipLaunchKernelGGL((kc_shard_walk_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
-                                   f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE);
+                if (contracted)
+                    hipLaunchKernelGGL((kc_shard_walk_kernel<false, true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                                       f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE, fr, set->bshift);
+                else
+                    hipLaunchKernelGGL((kc_shard_walk_kernel<false, false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                                       f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE, fr, set->bshift);
                 hipLaunchKernelGGL(kc_shard_sum_kernel, dim3(256), dim3(256), 0, ctx->stream, (const u64 *)f_len, n_ent, cur + 2 * KC_USTRIDE);
             }
             KC_HIP(ctx, hipGetLastError());
@@ -777,6 +860,12 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             if (hw[KC_USTRIDE]) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted");
             const u64 walked = hw[2 * KC_USTRIDE] / (complements ? 2 : 1);
             if (walked == N_local) break;
+            if (contracted) {   // cycles: everything below walks and cuts plain links -- put them back and walk again
+                KC_TRY(restore_links());
+                scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
+                --lpass;
+                continue;
+            }
             // some k-mers are reached by no fragment: cycles that stay inside this rank
             if (lpass == 3) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
             u8 *visited = nullptr;
@@ -784,8 +873,8 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(scope.alloc(&visited, rcap));
             KC_HIP(ctx, hipMemsetAsync(visited, 0, rcap, ctx->stream));
             if (n_ent)
-                hipLaunchKernelGGL((kc_shard_walk_kernel<true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
-                                   f_exit, f_partner, f_len, f_stream, fidx, frec, visited, cur + KC_USTRIDE);
+                hipLaunchKernelGGL((kc_shard_walk_kernel<true, false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                                   f_exit, f_partner, f_len, f_stream, fidx, frec, visited, cur + KC_USTRIDE, fr, set->bshift);
             KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
             hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
             KC_TRY(read_words(ctx, cur + 3 * KC_USTRIDE, &nunvis, 1));
@@ -937,6 +1026,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         }
         if (!stalled) break;
         // cycles that span ranks: agree on every cycle's smallest k-mer, cut there, start over
+        KC_TRY(restore_links());   // (the rows below walk plain links, the cut rewrites them)
         {
             const int RW = 3 + W;
             u64 *rows = nullptr, *all = nullptr, n_all = 0;

@@ -1102,3 +1102,189 @@ __global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set,
     heads[pos] = (start << 1) | 0;
     if (two) heads[pos + 1] = partner;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Fragment contraction.  A chain walk costs one scattered 128-byte line per step for 8 useful bytes (measured: the walk
+// kernel moves 16x its algorithmic bytes and sits at the HBM transaction ceiling), but ~90 % of its steps stay inside one
+// table block (consecutive k-mers share their minimizer).  So every block first contracts the chain pieces that lie inside
+// it: one workgroup loads the block's port links (16 B per slot) into LDS, walks every in-block run ("fragment") there from
+// both of its ends, and replaces the INWARD link word of each end node by a shortcut: far end node, the number of nodes, and
+// the appended bases of the run (up to 19 inline, longer runs through a word pool).  The chain walk then hops from fragment
+// to fragment: two scattered lines per fragment instead of one per node.  Every replaced word is logged first (8 B per
+// fragment end): if the hop walk finds a chain beyond the limit or misses k-mers (cycles), kc_frag_restore_kernel puts the
+// words back and the classic flow takes over on the original links; inputs whose chains are long on average skip the
+// contraction in the first place.  An end that finds no room in a list or pool simply keeps its plain link (the walk then
+// steps through that fragment node by node from this side).
+//
+// MEASURED (MI355X, k = 31, 2.5e9 k-mers): contraction 43 ms + hop walk 32 ms against the plain walk's 111 ms.  (The hop walk
+// first ran at 71 ms -- not for its memory accesses: scattered 8-byte reads run at ~49 G/s on this GPU whatever the footprint,
+// tools/rand_probe.hip -- but because every walk reserved its first recording chunk with an atomic on one shared cursor and,
+// once walks hop over runs of different lengths, the lanes of a wave reach that point in different loop trips, so the
+// compiler's wave-level aggregation of the atomic no longer applied: ~5e6 same-address atomics at ~13 ns each.  The first
+// chunk of walk t is now chunk t.)
+//
+// shortcut word: bits 0-1 = 0 (LK_OPEN, not a state of a finished port) and bit 5 (LK_REJ) set; bit 2: the bases are in the
+// pool; bits 6-19 far node (slot offset in the block); bit 20 orientation at the far node; inline: bits 21-25 number of bases,
+// bits 26-63 the bases (first one in the highest pair); pool: bits 21-34 nodes - 1, bits 35-63 first pool word (relative to
+// the block's pool base).
+#define KC_SC_IS(w) ((((w) & 3ull) == 0ull) && ((w) & LK_REJ))
+#define KC_SC_EXT 4ull
+#define KC_SC_NEXT 8ull
+#define KC_SC_INLINE_MAX 19
+#define KC_SC_NEXT_MAX 7
+#define KC_FRAG_LONGS 512       /* runs of more than 20 nodes per block that get pool space (expected ~100) */
+#define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
+template <int W>
+__global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
+                                                                u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log) {
+    // LDS: per port of the block one 32-bit word -- bit 31: matched to a slot of this block; then bits 0-13 that slot's offset,
+    // bit 14 the port entered there, bits 15-16 the appended base -- then the list of long runs and the list of fragment ends.
+    // (76 KB for 8192-slot blocks: two workgroups share a CU.)
+    extern __shared__ u32 kc_fl[];
+    __shared__ u32 n_long, n_words, n_ent;
+    __shared__ u64 pbase, lbase;
+    __shared__ int log_ok;
+    const u32 bs = 1u << set.bshift;
+    const u64 blk = (set.rlo >> set.bshift) + blockIdx.x;   // (hash-sharded tables: the blocks of this rank; pool / log arrays are indexed by the LOCAL block)
+    const u64 base = blk << set.bshift;
+    const u64 lblk = blockIdx.x;
+    u32 *longs = kc_fl + 2 * (size_t)bs;                            // (local port id of the entry, first pool word)
+    const u32 long_cap = KC_FRAG_LONGS, ent_cap = KC_FRAG_ENTRIES;
+    unsigned short *ents = reinterpret_cast<unsigned short *>(longs + 2 * long_cap);   // local port ids of the fragment ends
+    if (threadIdx.x == 0) { n_long = 0; n_words = 0; n_ent = 0; }
+    // one 16-byte load per slot (both port words) and one tag byte; bit 30 of the digest = the slot is occupied
+    for (u32 s = threadIdx.x; s < bs; s += blockDim.x) {
+        const bool occ = set.tags[base + s] != 0;
+        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(link + (base + s) * 2);
+        const u64 w2[2] = {ww.x, ww.y};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const u64 w = w2[p];
+            const bool in = occ && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
+            kc_fl[2 * s + p] = (occ ? 0x40000000u : 0u) |
+                               (in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15)) : 0u);
+        }
+    }
+    __syncthreads();
+    auto walk = [&](u32 s, int o, u32 &far, int &fo, u32 &len, u64 &bases, u64 *ext, bool fill) {
+        // from the oriented node (s, o) along the links that stay in this block; bases = the appended bases, first one highest
+        u32 cur = s;
+        int co = o;
+        len = 1; bases = 0;
+        u64 acc = 0; int nacc = 0; u32 wi = 0;
+        while (len <= bs) {   // (a run has at most bs nodes; the bound only guards against a corrupt table)
+            const u32 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
+            if (!(w >> 31)) break;
+            const u64 b = (w >> 15) & 3;
+            if (len <= KC_SC_INLINE_MAX) bases |= b << (36 - 2 * (len - 1));
+            if (fill) { acc = (acc << 2) | b; if (++nacc == 32) { ext[wi++] = acc; acc = 0; nacc = 0; } }
+            cur = w & 0x3fffu;
+            co = (int)((w >> 14) & 1);
+            ++len;
+        }
+        if (fill && nacc) ext[wi] = acc << (64 - 2 * nacc);
+        far = cur; fo = co;
+    };
+    // The fragment ends first go into a list (one LDS atomic per wavefront and sweep step: ballot + popcount), so that the walks
+    // below run with every lane busy -- walking straight from the slot sweep kept ~3 of 64 lanes active.
+    const int lane = threadIdx.x & 63;
+    for (u32 s0 = 0; s0 < bs; s0 += blockDim.x) {
+        const u32 s = s0 + threadIdx.x;
+        for (int o = 0; o < (complements ? 2 : 1); ++o) {
+            // an end of a run of >= 2 nodes: occupied, not entered from inside the block, left towards a slot of the block
+            const u32 f_in = s < bs ? kc_fl[2 * s + o] : 0u, f_out = s < bs ? kc_fl[2 * s + (o == 0 ? 1 : 0)] : 0u;   // (blocks of < 1024 slots: KC_BSHIFT)
+            const bool is_end = (f_in & 0x40000000u) && !(f_in >> 31) && (f_out >> 31);
+            const unsigned long long m = __ballot(is_end);
+            if (!m) continue;
+            u32 at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&n_ent, (u32)__popcll(m));
+            at0 = __shfl(at0, 0, 64);
+            if (is_end) {
+                const u32 at = at0 + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1));
+                if (at < ent_cap) ents[at] = (unsigned short)(2 * s + (u32)o);   // (an end beyond the list keeps its plain link)
+            }
+        }
+    }
+    __syncthreads();
+    const u32 ne = n_ent < ent_cap ? n_ent : ent_cap;
+    // every word about to be replaced is logged first (kc_frag_restore_kernel puts it back if the hop walk has to be abandoned):
+    // the original word with the local port id in its unused bits 46-59.  No log space: the block keeps its plain links.
+    if (threadIdx.x == 0) {
+        const u64 lshard = log_cap / 64;
+        const u64 b = ne ? atomicAdd((ull *)&log_cursors[(blockIdx.x & 63) * 16], (ull)ne) : 0;
+        log_ok = b + ne <= lshard;
+        lbase = (u64)(blockIdx.x & 63) * lshard + b;
+        blk_log[lblk] = log_ok ? ((lbase << 16) | (u64)ne) : 0;
+    }
+    __syncthreads();
+    if (!log_ok) return;
+    for (u32 e = threadIdx.x; e < ne; e += blockDim.x) {
+        const u32 s = ents[e] >> 1;
+        const int o = (int)(ents[e] & 1);
+        u32 far, len; int fo; u64 bases;
+        walk(s, o, far, fo, len, bases, nullptr, false);
+        const u32 xp = o == 0 ? 1u : 0u;
+        log[lbase + e] = link[(base + s) * 2 + xp] | ((u64)(2 * s + xp) << 46);
+        // runs of up to 8 nodes whose far end is matched onwards also carry that onward link (the walk then skips the far end's
+        // line altogether): bit 3 set, bits 6-41 next slot, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
+        // inside the run, bits 48-61 those bases
+        const u64 wfar = (len - 1 <= KC_SC_NEXT_MAX) ? link[(base + far) * 2 + (fo == 0 ? 1u : 0u)] : 0;
+        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && LK_SLOT(wfar) < ((u64)1 << 36) && LK_SLOT(wfar) - set.rlo < set.rcap) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
+            link[(base + s) * 2 + xp] = LK_REJ | KC_SC_NEXT | (LK_SLOT(wfar) << 6) | (LK_PORT(wfar) << 42) | (LK_BASE(wfar) << 43) | ((u64)(len - 1) << 45) |
+                                        ((bases >> 24) << 48);
+        } else if (len - 1 <= KC_SC_INLINE_MAX) {
+            link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
+        } else {
+            const u32 nw = (len - 1 + 31) / 32;
+            const u32 at = atomicAdd(&n_long, 1u);
+            const u32 rel = atomicAdd(&n_words, nw);
+            // (more long runs than the list holds, or a run of 2^14 nodes: that end keeps its plain link)
+            if (at < long_cap && len - 1 < (1u << 14)) { longs[2 * at] = 2 * s + (u32)o; longs[2 * at + 1] = rel; }
+        }
+    }
+    __syncthreads();
+    if (n_long == 0) return;
+    if (threadIdx.x == 0) {
+        pbase = atomicAdd((ull *)&pool_cursors[(blockIdx.x & 63) * 16], (ull)n_words);
+        blk_pool_base[lblk] = pbase;
+    }
+    __syncthreads();
+    // pool shard s owns the words [s * pool_cap / 64, (s + 1) * pool_cap / 64)
+    const u64 shard_cap = pool_cap / 64, shard_lo = (u64)(blockIdx.x & 63) * shard_cap;
+    if (pbase + n_words > shard_cap) return;   // no pool space: the long runs of this block keep their plain links
+    const u32 nl = n_long < long_cap ? n_long : long_cap;
+    for (u32 i = threadIdx.x; i < nl; i += blockDim.x) {
+        const u32 pid = longs[2 * i], rel = longs[2 * i + 1];
+        const u32 s = pid >> 1; const int o = (int)(pid & 1);
+        u32 far, len; int fo; u64 bases;
+        walk(s, o, far, fo, len, bases, pool + shard_lo + pbase + rel, true);
+        const u32 xp = o == 0 ? 1u : 0u;
+        link[(base + s) * 2 + xp] = LK_REJ | KC_SC_EXT | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | ((u64)rel << 35);
+    }
+}
+
+// puts the logged link words back (the hop walk met a chain beyond the limit, or the input has cycles: the classic flow
+// takes over on the original links)
+static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, const u64 *__restrict__ log, const u64 *__restrict__ blk_log, int bshift, u64 blk0) {
+    const u64 blk = blockIdx.x;
+    const u64 e = blk_log[blk];
+    const u32 n = (u32)(e & 0xffffu);
+    const u64 lb = e >> 16;
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+        const u64 w = log[lb + i];
+        link[(((blk0 + blk) << bshift) << 1) + ((w >> 46) & 0x3fffu)] = w & ~(0x3fffull << 46);
+    }
+}
+
+// measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a
+// chain is emitted (bi: the one starting at the smaller key) and records the winners.
+// MARK: also flag visited nodes (only needed when the node count shows that cycles exist).
+// REC: also record the bases appended along the walk (32 per word, first base in bits 63:62) into 32-word chunks drawn
+// from `pool`, so that the winning direction is later emitted by copying its recording instead of walking the chain a
+// third time (every step of a walk is a scattered 128-byte line fetch; the recording is 2 bits per step).
+struct KcFrag {          // fragment shortcuts in the link words (kc_frag_contract_kernel); pool == nullptr: none
+    const u64 *pool;
+    const u64 *blk_pool_base;
+    u64 shard_cap;
+    u64 blk0;        // first block of the range the contraction ran over (hash-sharded tables: the rank's first block)
+};
