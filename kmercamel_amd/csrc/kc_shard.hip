@@ -808,22 +808,46 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         if (pass == 64) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not settle after cutting cycles");
         // entries, fragment walks; cycles inside this rank are cut on the spot (no exchange involved)
         for (int lpass = 0;; ++lpass) {
-            const u64 ntiles = (rcap + 2047) / 2048;
-            u64 *tcount = nullptr;
-            unsigned short *emasks = nullptr;
-            KC_TRY(scope.alloc(&tcount, ntiles + 2));
-            KC_TRY(scope.alloc(&emasks, ntiles * 256));
-            hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
-                               (const u64 *)nullptr, tcount, emasks);
-            KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
-            KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
+            // entries: listed by the contraction kernel on its way (it has every link word of the block in registers), or by a sweep of
+            // their own (no contraction: cycles, KC_NOFRAG; or more entries than the list was sized for)
+            KcFrag fr{nullptr, nullptr, 0, 0};
+            bool have_entries = false;
+            if (frag_ok && !contracted && bpr_blocks) {
+                const u64 pool_cap = (N_local / 16 + 65536) / 64 * 64, log_cap = (N_local / 3 + 65536) / 64 * 64, ecap = N_local / 2 + 65536;
+                KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, bpr_blocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16 + 16));
+                KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, bpr_blocks));
+                KC_TRY(scope.alloc(&entries, ecap + 1));
+                KC_HIP(ctx, hipMemsetAsync(fcur, 0, (2 * 64 * 16 + 16) * 8, ctx->stream));
+                const size_t flds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
+                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
+                                   log_cap, fcur + 64 * 16, fblog, entries, ecap, fcur + 2 * 64 * 16);
+                KC_HIP(ctx, hipGetLastError());
+                contracted = true;
+                fr = KcFrag{fpool, fbase, pool_cap / 64, rlo >> set->bshift};
+                KC_TRY(read_words(ctx, fcur + 2 * 64 * 16, &n_ent, 1));
+                have_entries = n_ent <= ecap;
+                if (!have_entries) scope.release(entries);
+            } else if (contracted) fr = KcFrag{fpool, fbase, ((N_local / 16 + 65536) / 64 * 64) / 64, rlo >> set->bshift};
+            if (!have_entries) {
+                const u64 ntiles = (rcap + 2047) / 2048;
+                u64 *tcount = nullptr;
+                unsigned short *emasks = nullptr;
+                KC_TRY(scope.alloc(&tcount, ntiles + 2));
+                KC_TRY(scope.alloc(&emasks, ntiles * 256));
+                hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                                   (const u64 *)nullptr, tcount, emasks);
+                KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
+                KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
+                if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
+                KC_TRY(scope.alloc(&entries, n_ent + 1));
+                hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                                   (const u64 *)tcount, entries, emasks);
+                KC_HIP(ctx, hipGetLastError());
+                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                scope.release(tcount); scope.release(emasks);
+            }
             if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
-            KC_TRY(scope.alloc(&entries, n_ent + 1));
-            hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
-                               (const u64 *)tcount, entries, emasks);
-            KC_HIP(ctx, hipGetLastError());
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            scope.release(tcount); scope.release(emasks);
             KC_TRY(scope.alloc(&f_exit, n_ent + 1)); KC_TRY(scope.alloc(&f_partner, n_ent + 1)); KC_TRY(scope.alloc(&f_len, n_ent + 1));
             KC_TRY(scope.alloc(&f_stream, n_ent + 1));
             FragRec frec{};
@@ -831,20 +855,6 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(scope.alloc(&pool, frec.pool_cap * KC_FCW)); KC_TRY(scope.alloc(&chunk_next, frec.pool_cap));
             frec.pool = pool; frec.chunk_next = chunk_next; frec.pool_cursor = cur;
             KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
-            KcFrag fr{nullptr, nullptr, 0, 0};
-            if (frag_ok && !contracted && n_ent && bpr_blocks) {
-                const u64 pool_cap = (N_local / 16 + 65536) / 64 * 64, log_cap = (N_local / 3 + 65536) / 64 * 64;
-                KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, bpr_blocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16));
-                KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, bpr_blocks));
-                KC_HIP(ctx, hipMemsetAsync(fcur, 0, 2 * 64 * 16 * 8, ctx->stream));
-                const size_t flds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
-                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
-                                   log_cap, fcur + 64 * 16, fblog);
-                KC_HIP(ctx, hipGetLastError());
-                contracted = true;
-                fr = KcFrag{fpool, fbase, pool_cap / 64, rlo >> set->bshift};
-            }
             if (n_ent) {
                 if (contracted)
                     hipLaunchKernelGGL((kc_shard_walk_kernel<false, true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,

@@ -1136,7 +1136,11 @@ __global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set,
 #define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
 template <int W>
 __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
-                                                                u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log) {
+                                                                u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log,
+                                                                u64 *ent_out = nullptr, u64 ent_cap = 0, u64 *ent_cursor = nullptr) {
+    // ent_out (hash-sharded flow): the block's ENTRIES are listed on the way -- oriented nodes (slot << 1 | o) whose entry port o is
+    // dead or matched to a slot of another rank, i.e. the starts of this rank's chain fragments (the link words are in registers
+    // here anyway; a sweep of their own over 16 bytes per slot cost 15 ms per 10^9 k-mers).  One reservation per block.
     // LDS: per port of the block one 32-bit word -- bit 31: matched to a slot of this block; then bits 0-13 that slot's offset,
     // bit 14 the port entered there, bits 15-16 the appended base -- then the list of long runs and the list of fragment ends.
     // (76 KB for 8192-slot blocks: two workgroups share a CU.)
@@ -1149,11 +1153,13 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     const u64 base = blk << set.bshift;
     const u64 lblk = blockIdx.x;
     u32 *longs = kc_fl + 2 * (size_t)bs;                            // (local port id of the entry, first pool word)
-    const u32 long_cap = KC_FRAG_LONGS, ent_cap = KC_FRAG_ENTRIES;
+    const u32 long_cap = KC_FRAG_LONGS, fe_cap = KC_FRAG_ENTRIES;
     unsigned short *ents = reinterpret_cast<unsigned short *>(longs + 2 * long_cap);   // local port ids of the fragment ends
     if (threadIdx.x == 0) { n_long = 0; n_words = 0; n_ent = 0; }
     // one 16-byte load per slot (both port words) and one tag byte; bit 30 of the digest = the slot is occupied
-    for (u32 s = threadIdx.x; s < bs; s += blockDim.x) {
+    u32 emask = 0;   // bit 2 i + p: port p of the slot of sweep step i is an entry
+    int step = 0;
+    for (u32 s = threadIdx.x; s < bs; s += blockDim.x, ++step) {
         const bool occ = set.tags[base + s] != 0;
         const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(link + (base + s) * 2);
         const u64 w2[2] = {ww.x, ww.y};
@@ -1163,9 +1169,33 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
             const bool in = occ && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
             kc_fl[2 * s + p] = (occ ? 0x40000000u : 0u) |
                                (in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15)) : 0u);
+            if (ent_out && occ && (p == 0 || complements) && step < 16 &&
+                (LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - set.rlo >= set.rcap)))
+                emask |= 1u << (2 * step + p);
         }
     }
     __syncthreads();
+    if (ent_out) {   // (uniform: every thread of the workgroup takes part)
+        __shared__ u32 e_wsum[16];
+        __shared__ u64 e_base;
+        const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const u32 cnt = (u32)__popc(emask);
+        u32 inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d, 64); if (ln >= d) inc += o; }
+        if (ln == 63) e_wsum[wv] = inc;
+        __syncthreads();
+        u32 before = 0, tot = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { if (i < wv) before += e_wsum[i]; tot += e_wsum[i]; }
+        if (threadIdx.x == 0) e_base = tot ? atomicAdd((ull *)ent_cursor, (ull)tot) : 0;
+        __syncthreads();
+        u64 pos = e_base + before + inc - cnt;
+        for (int j = 0; emask != 0 && j < 32; ++j)
+            if ((emask >> j) & 1u) {
+                if (pos < ent_cap) ent_out[pos] = ((base + (u64)threadIdx.x + (u64)(j >> 1) * blockDim.x) << 1) | (u64)(j & 1);
+                ++pos;
+            }
+    }
     auto walk = [&](u32 s, int o, u32 &far, int &fo, u32 &len, u64 &bases, u64 *ext, bool fill) {
         // from the oriented node (s, o) along the links that stay in this block; bases = the appended bases, first one highest
         u32 cur = s;
@@ -1201,12 +1231,12 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
             at0 = __shfl(at0, 0, 64);
             if (is_end) {
                 const u32 at = at0 + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1));
-                if (at < ent_cap) ents[at] = (unsigned short)(2 * s + (u32)o);   // (an end beyond the list keeps its plain link)
+                if (at < fe_cap) ents[at] = (unsigned short)(2 * s + (u32)o);   // (an end beyond the list keeps its plain link)
             }
         }
     }
     __syncthreads();
-    const u32 ne = n_ent < ent_cap ? n_ent : ent_cap;
+    const u32 ne = n_ent < fe_cap ? n_ent : fe_cap;
     // every word about to be replaced is logged first (kc_frag_restore_kernel puts it back if the hop walk has to be abandoned):
     // the original word with the local port id in its unused bits 46-59.  No log space: the block keeps its plain links.
     if (threadIdx.x == 0) {
