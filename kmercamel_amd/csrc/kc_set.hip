@@ -799,6 +799,16 @@ int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_
 
 // AddKMers over all ranks: count the occurrences per table block, lay the canonical k-mers out block by block (= owner by
 // owner), all-to-all the per-block counts and the keys, build every owned block in LDS from its `world` segments.
+// dense layout of the scatter buckets: bucket b's first cnt[b] keys -> out[off[b] ...] (one workgroup per bucket)
+__global__ void __launch_bounds__(256) kc_bucket_compact_kernel(const u64 *__restrict__ fixed, const u64 *__restrict__ cnt, const u64 *__restrict__ off, int bshift, int W,
+                                                                u64 *out) {
+    const u64 b = blockIdx.x;
+    const u64 n = cnt[b] * (u64)W;
+    const u64 *src = fixed + ((b << bshift) * (u64)W);
+    u64 *dst = out + off[b] * (u64)W;
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved) {
     kc_ctx *ctx = set->ctx;
     KcScope scope(ctx);
@@ -818,7 +828,32 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     if (lds_scatter > 64 * 1024)
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     const bool have = len >= (u64)set->k;
-    if (have)
+    // ONE roll over the input: the k-mers go into fixed-capacity buckets (one of 2^bshift keys per table block, as on one GPU) and a
+    // copy lays them out densely by block = by owner afterwards.  (Counting first and scattering into the exact layout rolled
+    // every k-mer twice: +12 ms per 10^9.)  A bucket that overflows (a block that receives more than 2^bshift occurrences from
+    // this rank alone) sends the rank back to the two-pass form.
+    u64 *fixed = nullptr;
+    bool one_pass = have && !getenv("KC_SHARD_TWO_PASS");
+    if (one_pass) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if ((double)nblocks * (double)bs * 8.0 * W > 0.5 * (double)free_b) one_pass = false;
+    }
+    if (one_pass) {
+        KC_TRY(scope.alloc(&fixed, nblocks * bs * W));
+        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                           set->complements, 0, kc_view_raw<W>(set), fixed, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
+        u64 hovf = 0;
+        KC_HIP(ctx, hipMemcpyAsync(&hovf, set->counters + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hovf) {
+            one_pass = false;
+            scope.release(fixed); fixed = nullptr;
+            KC_HIP(ctx, hipMemsetAsync(bcount, 0, (nblocks + 1) * 8, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
+        }
+    }
+    if (have && !one_pass)
         hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                            set->complements, 0, kc_view_raw<W>(set), (u64 *)nullptr, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 1);
     KC_TRY(kcu_exclusive_scan(ctx, bcount, boff, nblocks));
@@ -827,7 +862,12 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const u64 occ_local = h_off[nblocks];
     KC_TRY(scope.alloc(&bucket, occ_local * W + 1));
-    if (have)
+    if (one_pass) {
+        hipLaunchKernelGGL(kc_bucket_compact_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, (const u64 *)fixed, (const u64 *)bcount, (const u64 *)boff, set->bshift, W, bucket);
+        KC_HIP(ctx, hipGetLastError());
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        scope.release(fixed);
+    } else if (have)
         hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                            set->complements, 0, kc_view_raw<W>(set), bucket, bcur, set->counters, ppt, stage_cap, (const u64 *)boff, 0);
     KC_HIP(ctx, hipGetLastError());
