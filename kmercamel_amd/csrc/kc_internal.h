@@ -179,6 +179,7 @@ int kcu_compact_shards(kc_ctx *ctx, const u64 *src, u64 shard_cap, const u64 *d_
 struct kc_comm;
 struct KcRoute {
     u64 n = 0, n_recv = 0;
+    u64 n_total = 0;                          // items of all ranks together (every rank knows the whole count matrix)
     u64 *perm = nullptr;                      // device: send position -> item
     std::vector<u64> scnt, soff, rcnt, roff;  // items per peer
 };

@@ -936,15 +936,17 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                     KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
                     KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_send, 1));
                 }
-                u64 tot_send = n_send;
-                KC_TRY(kcc_allreduce_sum(c, &tot_send, 1));
-                if (tot_send == 0) break;
-                if (++wrounds > wave_max) { wave = false; break; }   // a chain much longer than the average: pointer jumping after all
                 KC_TRY(scope.alloc(&msgs, 3 * n_send + 1)); KC_TRY(scope.alloc(&wdest, n_send + 1));
                 if (n_send) hipLaunchKernelGGL(kc_shard_wave_send_kernel, dim3(kc_grid(n_send, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_send, (const u64 *)f_partner,
                                                (const u64 *)f_len, (const u64 *)pay, (const u64 *)poff, 2 * rcap, msgs, wdest);
                 KcRoute rt;
-                KC_TRY(kcr_build(c, wdest, n_send, &rt));
+                KC_TRY(kcr_build(c, wdest, n_send, &rt));   // (its count exchange also says whether any rank still sends: no collective of its own for that)
+                if (rt.n_total == 0 || ++wrounds > wave_max) {
+                    if (rt.n_total) wave = false;   // a chain much longer than the average: pointer jumping after all
+                    kcr_free(ctx, &rt);
+                    scope.release(msgs); scope.release(wdest);
+                    break;
+                }
                 u64 *rq = nullptr;
                 int rc = kcr_forward(c, rt, msgs, 3, 3, &rq);
                 if (rc == KC_OK && n_ent && hipMemsetAsync(reach_b, 0, n_ent, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;

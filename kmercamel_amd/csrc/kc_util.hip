@@ -418,6 +418,8 @@ int kcr_build(kc_comm *c, const u8 *dest, u64 n, KcRoute *r) {
     o = 0;
     for (int p = 0; p < G; ++p) { r->rcnt[p] = all[(size_t)p * G + c->rank]; r->roff[p] = o; o += r->rcnt[p]; }
     r->n_recv = o;
+    r->n_total = 0;
+    for (u64 v : all) r->n_total += v;
     if (n) {
         rc = kc_alloc(ctx, &r->perm, n);
         if (rc != KC_OK) { kc_release(ctx, cnt); return rc; }
