@@ -628,10 +628,10 @@ class Comm:
             self.h = None
 
 
-def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length=None):
+def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length=None, want_mask=False):
     """kc_compute_sharded: collective over comm's ranks; `seq` = THIS rank's records joined by '\\n' (may be empty).
-    The ComputeResult holds this rank's slice of the one masked superstring (see .slice(), .array())."""
-    flags = FLAG_COMPLEMENTS if complements else 0
+    The ComputeResult holds this rank's slice of the one masked superstring (see .slice(), .array(), .strings(want_mask))."""
+    flags = (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0)
     h = ctypes.c_void_p()
     if device_ptr is not None:
         flags |= FLAG_INPUT_ON_DEVICE

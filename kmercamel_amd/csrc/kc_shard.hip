@@ -513,6 +513,56 @@ __global__ void __launch_bounds__(256) kc_shard_place_kernel(const u64 *__restri
     if (sh && sh + 2 * cnt > 64) atomicOr((ull *)&words[wi + 1], (ull)(payload << (64 - sh)));
 }
 
+// ---- -M (global.h:185-195) on the sharded path: every lower-case position of this rank's slice asks the OWNER of the k-mer that
+// starts there whether the set holds it (the k-mer may run up to k-1 characters into the following slices: `halo`).
+// pass 1 (FILL = false): mask = out, lower-case k-mer starts are counted per thread tile; pass 2: queries {key} + position.
+template <int W, bool FILL>
+__global__ void __launch_bounds__(256) kc_shard_mask_query_kernel(const char *__restrict__ out, u64 n, const char *__restrict__ halo, u64 goff, u64 L, int k, int complements,
+                                                                  SetView<W> set, u64 bpr_slots, char *mask, u64 *tile_count, const u64 *__restrict__ tile_off, u64 *qkeys,
+                                                                  u64 *qpos, u8 *qdest) {
+    const u64 p = kc_gtid();
+    bool ask = false;
+    Key<W> x = key_zero<W>();
+    if (p < n) {
+        const char c = out[p];
+        if (!FILL) mask[p] = c;
+        if (c > 'Z' && goff + p + (u64)k <= L) {
+            ask = true;
+            if (FILL) {
+                for (int i = 0; i < k; ++i) {
+                    const u64 q = p + (u64)i;
+                    const u32 up = ((u32)(u8)(q < n ? out[q] : halo[q - n])) & 0xDFu;
+                    u32 code = (up >> 1) & 3u;
+                    code ^= code >> 1;
+                    x = key_append(x, (u64)code, k);
+                }
+                if (complements) { const Key<W> r = key_rc(x, k); if (key_lt(r, x)) x = r; }
+            }
+        }
+    }
+    u64 tot;
+    const u64 ex = kc_block_excl_scan(ask ? 1 : 0, &tot);
+    if (!FILL) { if (threadIdx.x == 0) tile_count[(u64)blockIdx.y * gridDim.x + blockIdx.x] = tot; return; }
+    if (ask) {
+        const u64 at = tile_off[(u64)blockIdx.y * gridDim.x + blockIdx.x] + ex;
+        for (int w = 0; w < W; ++w) qkeys[at * W + w] = x.w[w];
+        qpos[at] = p;
+        qdest[at] = (u8)(set_place(set, x).home / bpr_slots);
+    }
+}
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_mask_answer_kernel(SetView<W> set, const u64 *__restrict__ q, u64 n, u64 *ans) {
+    const u64 t = kc_gtid();
+    if (t >= n) return;
+    Key<W> key;
+    for (int w = 0; w < W; ++w) key.w[w] = q[t * W + w];
+    ans[t] = set_find(set, key) != KC_NONE64 ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) kc_shard_mask_apply_kernel(const u64 *__restrict__ qpos, const u64 *__restrict__ ans, u64 n, char *mask) {
+    const u64 t = kc_gtid();
+    if (t < n && ans[t]) mask[qpos[t]] = (char)(mask[qpos[t]] - ('a' - 'A'));
+}
+
 // per-simplitig destination rank: owner of the output offset at which its on-path vertex starts
 __global__ void __launch_bounds__(256) kc_shard_simp_dest_kernel(const u64 *__restrict__ dist, const u64 *__restrict__ endv, u64 start, u64 S, u64 V, u64 Ltot, int G,
                                                                  u8 *simp_dest, u64 *rank_lo, u64 *rank_hi, const u64 *__restrict__ weight) {
@@ -626,7 +676,7 @@ template <int W> void settle_branches(const std::vector<u64> &rows, u64 n, std::
     }
 }
 
-template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, int k, int complements, kc_result **out) {
+template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, int k, int complements, int want_mask, kc_result **out) {
     KcScope scope(ctx);
     const int G = c->world, me = c->rank;
     const bool trace = trace_on();
@@ -1222,6 +1272,65 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     r->ctx = ctx; r->length = Ltot; r->slice_off = lo; r->slice_len = hi - lo;
     int rc = kc_alloc(ctx, &r->d_out, r->slice_len + 8);
     if (rc == KC_OK && r->slice_len) rc = kce_emit_ranked(simp, &rk, lo, G, me, r->d_out);
+    if (rc == KC_OK && want_mask) {
+        // -M: the mask probes go to the owners of the k-mers (collective: every rank takes part, whatever its slice holds)
+        const u64 n = r->slice_len;
+        rc = kc_alloc(ctx, &r->d_mask, n + 8);
+        // the first k-1 characters of every slice, to every rank: a k-mer that starts near the end of a slice runs into the next ones
+        const int HW = 2 + 16;   // {offset, length, up to 127 characters}
+        u64 mine[HW] = {0}, all[64 * HW];
+        mine[0] = lo; mine[1] = n;
+        if (rc == KC_OK && n) {
+            const u64 nh = n < (u64)(k - 1) ? n : (u64)(k - 1);
+            if (hipMemcpyAsync(mine + 2, r->d_out, nh, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+        }
+        if (rc == KC_OK) rc = kcc_allgather_words(c, mine, all, HW);
+        char halo_h[128] = {0};
+        if (rc == KC_OK) {
+            for (int i = 0; i < k - 1; ++i) {
+                const u64 g = hi + (u64)i;   // global position of halo character i
+                for (int p = 0; p < G; ++p) {
+                    const u64 po = all[p * HW], pn = all[p * HW + 1];
+                    if (pn && g >= po && g < po + pn && g - po < (u64)(k - 1)) halo_h[i] = reinterpret_cast<const char *>(all + p * HW + 2)[g - po];
+                }
+            }
+        }
+        char *halo = nullptr;
+        u64 *tcnt = nullptr, *toff = nullptr, *qkeys = nullptr, *qpos = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
+        u8 *qdest = nullptr;
+        if (rc == KC_OK) rc = scope.alloc(&halo, 128);
+        if (rc == KC_OK && hipMemcpyAsync(halo, halo_h, 128, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+        const dim3 gq = kc_grid2(n ? n : 1, 256);
+        const u64 ntile = (u64)gq.x * gq.y;
+        u64 nqm = 0;
+        if (rc == KC_OK) rc = scope.alloc(&tcnt, ntile + 2);
+        if (rc == KC_OK) rc = scope.alloc(&toff, ntile + 2);
+        if (rc == KC_OK) {
+            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, false>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcap,
+                               r->d_mask, tcnt, (const u64 *)nullptr, (u64 *)nullptr, (u64 *)nullptr, (u8 *)nullptr);
+            rc = kcu_exclusive_scan(ctx, tcnt, toff, ntile);
+            if (rc == KC_OK) rc = read_words(ctx, toff + ntile, &nqm, 1);
+        }
+        if (rc == KC_OK) rc = scope.alloc(&qkeys, nqm * W + 1);
+        if (rc == KC_OK) rc = scope.alloc(&qpos, nqm + 1);
+        if (rc == KC_OK) rc = scope.alloc(&qdest, nqm + 1);
+        if (rc == KC_OK)
+            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, true>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcap,
+                               r->d_mask, tcnt, (const u64 *)toff, qkeys, qpos, qdest);
+        KcRoute rt;
+        if (rc == KC_OK) rc = kcr_build(c, qdest, nqm, &rt);
+        if (rc == KC_OK) rc = kcr_forward(c, rt, qkeys, W, W, &rq);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
+        if (rc == KC_OK && rt.n_recv)
+            hipLaunchKernelGGL((kc_shard_mask_answer_kernel<W>), kc_grid2(rt.n_recv, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, ans);
+        if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nqm + 1);
+        if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
+        if (rc == KC_OK && nqm)
+            hipLaunchKernelGGL(kc_shard_mask_apply_kernel, kc_grid2(nqm, 256), dim3(256), 0, ctx->stream, (const u64 *)qpos, (const u64 *)ansb, nqm, r->d_mask);
+        (void)hipStreamSynchronize(ctx->stream);
+        kcr_free(ctx, &rt);
+        kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
+    }
     KC_HIP(ctx, hipEventRecord(eend, ctx->stream));
     KC_HIP(ctx, hipEventSynchronize(eend));
     if (rc != KC_OK) { kc_result_destroy(r); return rc; }
@@ -1245,8 +1354,9 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     *out = nullptr;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
     if (k < 18 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
-    if (flags & (KC_FLAG_SIMPLITIGS_INPUT | KC_FLAG_WANT_MASK) || ((flags >> 8) & 0xff) > 1)
-        return kc_fail(ctx, KC_E_ARG, "-S, -M and -z are not part of the hash-sharded path (use kc_compute)");
+    if ((flags & KC_FLAG_SIMPLITIGS_INPUT) || ((flags >> 8) & 0xff) > 1)
+        return kc_fail(ctx, KC_E_ARG, "-S and -z are not part of the hash-sharded path (use kc_compute)");
+    const int want_mask = (flags & KC_FLAG_WANT_MASK) ? 1 : 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
     const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;
     u8 *d_own = nullptr;
@@ -1258,9 +1368,9 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     }
     int rc;
     switch (kc_words_for_k(k)) {
-        case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, out); break;
-        case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, out); break;
-        default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, out); break;
+        case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, want_mask, out); break;
+        case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, want_mask, out); break;
+        default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, want_mask, out); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d_own);

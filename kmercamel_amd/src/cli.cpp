@@ -126,7 +126,7 @@ static void write_all(int fd, const char *data, size_t n) {
 // beyond the number of devices share them round robin), each with its own context and a communicator of the in-process
 // thread transport; the records are cut into N contiguous parts, kc_compute_sharded builds ONE masked superstring --
 // byte-identical to the single-GPU result -- and every rank copies its slice into place.
-static int run_compute_sharded(const std::string &path, int k, std::ostream *of, bool complements, int gpus) {
+static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus) {
     WriteLog("Started computation of a masked superstring from '" + path + "'.");
     Records recs = load_records(path, false);
     const std::string &j = recs.joined;
@@ -147,7 +147,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
     std::vector<std::string> err(gpus);
     std::vector<int> rcs(gpus, KC_OK);
     std::vector<uint64_t> st(16, 0);
-    std::string out;
+    std::string out, mask;
     std::mutex out_mu;
     std::condition_variable out_cv;
     bool out_ready = false;
@@ -158,14 +158,14 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         if (rc == KC_OK) rc = kc_comm_create_threads(ctx, group, r, &comm);
         if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; _exit(1); }   // (the others would wait for it forever)
         const uint64_t len = cut[r + 1] > cut[r] ? cut[r + 1] - cut[r] - (cut[r + 1] == j.size() ? 0 : 1) : 0;   // (the separator after the part is not part of it)
-        rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, complements ? KC_FLAG_COMPLEMENTS : 0, &res[r]);
+        rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0), &res[r]);
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
         if (rc != KC_OK && rc != KC_E_NO_KMERS) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
         if (rc == KC_OK) {
             if (r == 0) {
                 kc_result_stats(res[0], st.data());
-                { std::lock_guard<std::mutex> lk(out_mu); out.resize(st[2]); out_ready = true; }
+                { std::lock_guard<std::mutex> lk(out_mu); out.resize(st[2]); if (maskf) mask.resize(st[2]); out_ready = true; }
                 out_cv.notify_all();
             } else {
                 std::unique_lock<std::mutex> lk(out_mu);
@@ -173,7 +173,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
             }
             uint64_t off = 0, n = 0;
             kc_result_slice(res[r], &off, &n);
-            if (n && kc_result_copy(res[r], &out[off], nullptr) != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot copy its slice" << std::endl; _exit(1); }
+            if (n && kc_result_copy(res[r], &out[off], maskf ? &mask[off] : nullptr) != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot copy its slice" << std::endl; _exit(1); }
             kc_result_destroy(res[r]);
         }
         kc_comm_destroy(comm);
@@ -190,9 +190,11 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
     }
     WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     WriteName(path, "greedy", k, false, !complements, *of);
+    if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
     WriteLog("Finished 2. part: Hamiltonian path.");
     of->write(out.data(), (std::streamsize)out.size());
+    if (maskf != nullptr) { maskf->write(mask.data(), (std::streamsize)mask.size()); *maskf << std::endl; }   // global.h:206-208
     WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
     *of << std::endl;
     return 0;
@@ -202,8 +204,8 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
                 int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1) {
     if (gpus > 1) {
         // what the hash-sharded path does not cover runs on one GPU, as without the option
-        if (!lower_bound && !assume_simplitigs && maskf == nullptr && min_frequency == 1 && k >= 18) return run_compute_sharded(path, k, of, complements, gpus);
-        std::cerr << "Note: --gpus applies to plain `compute -k K` with K >= 18 (no -S, -M, -z); running on one GPU." << std::endl;
+        if (!lower_bound && !assume_simplitigs && min_frequency == 1 && k >= 18) return run_compute_sharded(path, k, of, maskf, complements, gpus);
+        std::cerr << "Note: --gpus applies to `compute -k K [-M F]` with K >= 18 (no -S, -z); running on one GPU." << std::endl;
     }
     if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
     else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");

@@ -255,8 +255,14 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
     assert run("compute", "-k", "31", "-o", o1, fa).returncode == 0
     p = subprocess.run([BIN, "compute", "-k", "31", "-o", o2, fa], capture_output=True, text=True, env=dict(os.environ, KMERCAMEL_GPUS="2"))
     assert p.returncode == 0 and open(o1).read() == open(o2).read()
-    # -M / -z / -S / small k: one GPU, with a note
-    m = str(tmp_path / "m.fa")
-    p = run("compute", "-k", "31", "-M", m, "--gpus", "2", fa)
-    assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "31", fa).stdout
+    # -M on the sharded path: the mask probes go to the owners of the k-mers
+    for path, k in ((fa, "31"), (br, "23"), (genome, "31")):
+        m1, m2 = str(tmp_path / "m1.fa"), str(tmp_path / "m2.fa")
+        a = run("compute", "-k", k, "-M", m1, path)
+        b = run("compute", "-k", k, "-M", m2, "--gpus", "3", path)
+        assert a.returncode == 0 and b.returncode == 0, b.stderr[-500:]
+        assert a.stdout == b.stdout and open(m1).read() == open(m2).read(), (path, k)
+    # -z / -S / small k: one GPU, with a note
+    p = run("compute", "-k", "23", "-z", "2", "--gpus", "2", br)   # (overlapping reads: k-mers that occur twice exist)
+    assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "23", "-z", "2", br).stdout
     assert run("compute", "-k", "31", "--gpus", "0", fa).returncode == 1
