@@ -63,6 +63,10 @@ SIGNATURES = {
     "kc_comm_create_rccl": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vpp]),
     "kc_comm_destroy": (None, [_vp]),
     "kc_comm_stats": (ctypes.c_int, [_vp, _u64p]),
+    "kc_thread_group_create": (ctypes.c_int, [ctypes.c_int, _vpp]),
+    "kc_thread_group_destroy": (None, [_vp]),
+    "kc_comm_create_threads": (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vpp]),
+    "kc_device_count": (ctypes.c_int, []),
     "kc_shard_geometry": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
     "kc_shard_owner_of": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64, _u8p]),
     "kc_compute_sharded": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),

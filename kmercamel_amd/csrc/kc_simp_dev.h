@@ -4,6 +4,8 @@
 #pragma once
 #include "kc_internal.h"
 #include "kc_scan_dev.h"
+#include <unordered_map>
+#include <vector>
 
 #define KC_MSPEC 16   /* minimizer length the k = 31 / 63 / 127 specialisations are compiled for (= kc_default_mlen) */
 #define LK_OPEN 0ull
@@ -1038,6 +1040,127 @@ struct KcRec {
     u64 *chain_stream;  // per chain: first chunk (KC_NO_CHUNK if it has a single node)
     u64 *chain_tail;    // per chain: oriented last node (slot << 1 | orientation)
 };
+
+// ---- Where a cycle is opened (oracle: simplitigs_canonical_order).  The reference's delete-as-you-go walk never closes a cycle
+// (simplitigs.h:161-183): it would have run on from one of the cycle's k-mers into a neighbouring chain.  So a cycle is cut at
+// the port that has the most preferred candidate edge (priority, then the ordered endpoint tuple) to a port that the matching
+// left DEAD -- phase 2 then joins that chain end and the opened cycle with k-1 characters, as if they had been one simplitig --
+// and only without such an edge at its minimum key on port L.  The k-mers on cycles are few: their rows and the candidate
+// edges come to the host, which walks the cycles and decides; the same code serves the hash-sharded flow.
+// row of a k-mer on a cycle: {slot, link word of port L, link word of port R, key[W]}
+template <int W>
+__global__ void __launch_bounds__(256) kc_cycle_rows_kernel(SetView<W> set, const u64 *__restrict__ link, const u64 *__restrict__ list, u64 n, u64 *rows) {
+    const u64 t = kc_gtid();
+    if (t >= n) return;
+    const u64 slot = list[t];
+    u64 *r = rows + t * (3 + W);
+    r[0] = slot; r[1] = link[slot << 1]; r[2] = link[(slot << 1) | 1];
+    const Key<W> key = set_key_at(set, slot);
+    for (int w = 0; w < W; ++w) r[3 + w] = key.w[w];
+}
+// candidate edges of the ports of the listed k-mers to dead ports of this table: {priority, x pid, y pid, key y[W]}
+template <int W>
+__global__ void __launch_bounds__(256) kc_cycle_cand_kernel(SetView<W> set, const u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ list, u64 n,
+                                                            u64 *cand, u64 cand_cap, u64 *cursor) {
+    const u64 t = kc_gtid();
+    if (t >= 2 * n) return;
+    const u64 slot = list[t >> 1];
+    const int port = (int)(t & 1);
+    const Key<W> x = set_key_at(set, slot);
+    const Key<W> xr = key_rc(x, k);
+    const u64 hx = key_hash(x);
+    for (u32 c = 0; c < 4; ++c) {
+        int q;
+        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+        if (key_eq(y, x)) continue;
+        const u64 ys = set_find(set, y);
+        if (ys == KC_NONE64) continue;
+        if (LK_STATE(link[(ys << 1) | (u64)q]) != LK_DEAD) continue;
+        const u64 at = atomicAdd((ull *)cursor, 1ULL);
+        if (at >= cand_cap) continue;
+        u64 *r = cand + at * (3 + W);
+        r[0] = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
+        r[1] = (slot << 1) | (u64)port; r[2] = (ys << 1) | (u64)q;
+        for (int w = 0; w < W; ++w) r[3 + w] = y.w[w];
+    }
+}
+// open the cycles at the chosen ports; the opened ports join the head list (cursor[0] = number of heads, cursor[4] += cuts)
+static __global__ void __launch_bounds__(256) kc_cycle_apply_kernel(u64 *link, const u64 *__restrict__ cuts, u64 n, int complements, u64 *heads, u64 *cursor) {
+    const u64 t = kc_gtid();
+    if (t >= n) return;
+    const u64 pid = cuts[t];
+    const u64 w = link[pid];
+    const u64 partner = LK_PID(w);
+    link[pid] = LK_DEAD | (w & LK_SPLIT);
+    link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
+    // a dead port is the entry of a directed chain (unidirectional sets: the L ports only, cf. kc_push_head)
+    const bool h1 = complements || !(pid & 1), h2 = (complements || !(partner & 1)) && partner != pid;
+    const u64 pos = atomicAdd((ull *)cursor, (ull)((h1 ? 1 : 0) + (h2 ? 1 : 0)));
+    u64 at = pos;
+    if (h1) heads[at++] = pid;
+    if (h2) heads[at] = partner;
+    atomicAdd((ull *)(cursor + 4), 1ULL);
+}
+// host: walk the cycles of `rows`, choose every cycle's port to cut.  rows: n x (3 + W), cand: m x (3 + W) as above.
+template <int W>
+static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const std::vector<u64> &cand, u64 m, std::vector<u64> &cuts) {
+    const int RW = 3 + W;
+    auto key_lt_h = [](const u64 *a, const u64 *b) { for (int i = W - 1; i >= 0; --i) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; } return false; };
+    auto key_eq_h = [](const u64 *a, const u64 *b) { for (int i = 0; i < W; ++i) if (a[i] != b[i]) return false; return true; };
+    std::unordered_map<u64, u64> at;
+    at.reserve(n * 2);
+    for (u64 i = 0; i < n; ++i) at[rows[i * RW]] = i;
+    std::vector<u64> cyc(n, ~(u64)0), minnode;
+    for (u64 i = 0; i < n; ++i) {
+        if (cyc[i] != ~(u64)0) continue;
+        const u64 id = minnode.size();
+        u64 cur = i, best = i, steps = 0;
+        int co = 0;
+        bool closed = false;
+        while (steps++ <= n) {
+            cyc[cur] = id;
+            if (key_lt_h(&rows[cur * RW + 3], &rows[best * RW + 3])) best = cur;
+            const u64 w = rows[cur * RW + (co == 0 ? 2 : 1)];   // leave through R when entered on L
+            auto it = at.find(LK_SLOT(w));
+            if (!LK_IS_MATCHED(w) || it == at.end()) break;     // (not a closed cycle of listed k-mers: left alone)
+            cur = it->second;
+            co = LK_PORT(w) == 0 ? 0 : 1;
+            if (cur == i) { closed = true; break; }
+        }
+        minnode.push_back(closed ? best : ~(u64)0);
+    }
+    // the most preferred candidate edge per cycle
+    struct Best { bool have = false; u64 pr = 0; const u64 *ka = nullptr, *kb = nullptr; int pa = 0, pb = 0; u64 xpid = 0; };
+    std::vector<Best> bc(minnode.size());
+    for (u64 j = 0; j < m; ++j) {
+        const u64 *c = &cand[j * RW];
+        auto it = at.find(c[1] >> 1);
+        if (it == at.end()) continue;
+        const u64 id = cyc[it->second];
+        if (id == ~(u64)0 || minnode[id] == ~(u64)0) continue;
+        if (at.count(c[2] >> 1)) continue;   // (a dead port is never on a cycle; kept for safety)
+        const u64 *kx = &rows[it->second * RW + 3], *ky = c + 3;
+        const int px = (int)(c[1] & 1), py = (int)(c[2] & 1);
+        const bool x_first = key_lt_h(kx, ky) || (key_eq_h(kx, ky) && px <= py);
+        Best e; e.have = true; e.pr = c[0]; e.xpid = c[1];
+        e.ka = x_first ? kx : ky; e.pa = x_first ? px : py; e.kb = x_first ? ky : kx; e.pb = x_first ? py : px;
+        Best &b = bc[id];
+        bool better = !b.have;
+        if (!better) {
+            if (e.pr != b.pr) better = e.pr > b.pr;
+            else if (!key_eq_h(e.ka, b.ka)) better = key_lt_h(e.ka, b.ka);
+            else if (e.pa != b.pa) better = e.pa < b.pa;
+            else if (!key_eq_h(e.kb, b.kb)) better = key_lt_h(e.kb, b.kb);
+            else better = e.pb < b.pb;
+        }
+        if (better) b = e;
+    }
+    cuts.clear();
+    for (size_t id = 0; id < minnode.size(); ++id) {
+        if (minnode[id] == ~(u64)0) continue;
+        cuts.push_back(bc[id].have ? bc[id].xpid : (rows[minnode[id] * RW] << 1));
+    }
+}
 
 // cycles (rare): one thread, sequential.  Cut each cycle at its minimum key, on that node's port L, and append the cut
 // ends to the head list (cursor[0] = number of heads); the chains are then found by the ordinary discovery pass.

@@ -898,12 +898,34 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
                            cnt + 1);
         KC_HIP(ctx, hipMemcpyAsync(cnt, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
-        if (pass == 0)   // all cycles of up to 4096 k-mers at once; longer ones (if any) by the sequential kernel in the next pass
-            hipLaunchKernelGGL((kc_cycles_parallel_kernel<W>), dim3(kc_grid(nunvis, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)ulist,
-                               nunvis, compl_, heads2, cnt, (u64)4096);
-        else
-            hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited, compl_, heads2,
-                               cnt);
+        {
+            // rows of the k-mers on cycles and the candidate edges of their ports to dead ports -> host, which walks the cycles and
+            // chooses every cycle's port to cut (kc_cycles_decide) -> kc_cycle_apply_kernel
+            const int RW = 3 + W;
+            u64 *rows_d = nullptr, *cand_d = nullptr, *cuts_d = nullptr;
+            const u64 cand_cap = nunvis + 65536;
+            KC_TRY(scope.alloc(&rows_d, nunvis * RW)); KC_TRY(scope.alloc(&cand_d, cand_cap * RW));
+            KC_HIP(ctx, hipMemsetAsync(cnt + 6, 0, 8, ctx->stream));
+            hipLaunchKernelGGL((kc_cycle_rows_kernel<W>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows_d);
+            hipLaunchKernelGGL((kc_cycle_cand_kernel<W>), kc_grid2(2 * nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, compl_, (const u64 *)ulist, nunvis,
+                               cand_d, cand_cap, cnt + 6);
+            KC_HIP(ctx, hipGetLastError());
+            u64 ncand = 0;
+            KC_TRY(read_u64(ctx, cnt + 6, &ncand));
+            if (ncand > cand_cap) return kc_fail(ctx, KC_E_CAPACITY, "too many candidate edges between cycles and chain ends");
+            std::vector<u64> rows(nunvis * RW), cand(ncand * RW), cuts;
+            KC_HIP(ctx, hipMemcpyAsync(rows.data(), rows_d, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            if (ncand) KC_HIP(ctx, hipMemcpyAsync(cand.data(), cand_d, cand.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            kc_cycles_decide<W>(rows, nunvis, cand, ncand, cuts);
+            if (cuts.empty()) return kc_fail(ctx, KC_E_NO_DEVICE, "k-mers outside every chain that lie on no cycle");
+            KC_TRY(scope.alloc(&cuts_d, cuts.size()));
+            KC_HIP(ctx, hipMemcpyAsync(cuts_d, cuts.data(), cuts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(kc_cycle_apply_kernel, kc_grid2(cuts.size(), 256), dim3(256), 0, ctx->stream, link, (const u64 *)cuts_d, (u64)cuts.size(), compl_, heads2, cnt);
+            KC_HIP(ctx, hipGetLastError());
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (cuts is a host vector)
+            scope.release(rows_d); scope.release(cand_d); scope.release(cuts_d);
+        }
         {
             u64 hcyc[5] = {0, 0, 0, 0, 0};
             KC_HIP(ctx, hipMemcpyAsync(hcyc, cnt, 40, hipMemcpyDeviceToHost, ctx->stream));

@@ -21,6 +21,7 @@
 #include <vector>
 #include <algorithm>
 #include <unordered_map>
+#include <unordered_set>
 #include <stdexcept>
 #include <fstream>
 #include <chrono>
@@ -510,7 +511,9 @@ std::vector<Simplitig> simplitigs_canonical_order(std::vector<K> keys, int k, bo
         if (a == b) continue;
         if (link[a] == NONE && link[b] == NONE) { link[a] = b; link[b] = a; }
     }
-    // cycles: cut at the minimum key of the cycle, on its port L.
+    // cycles: cut next to a dead port, else at the minimum key of the cycle on its port L (see below).
+    std::vector<uint8_t> dead_before(2 * n, 0);   // ports dead after the matching (ports opened by a cut do not count: the rule is independent of the order of the cycles)
+    for (size_t pidx = 0; pidx < 2 * n; ++pidx) dead_before[pidx] = link[pidx] == NONE;
     std::vector<uint8_t> seen(n, 0);
     size_t cycles_cut = 0;
     auto step = [&](uint32_t node, int o, uint32_t &nnode, int &no) -> bool {  // o=0: enter L leave R; o=1: enter R leave L
@@ -537,8 +540,28 @@ std::vector<Simplitig> simplitigs_canonical_order(std::vector<K> keys, int k, bo
             cur = nx; co = no;
             if (cur == i) break;
         }
-        uint32_t other = link[2 * best + 0];
-        link[2 * best + 0] = NONE;
+        // Where to cut: the reference's delete-as-you-go walk never closes a cycle (simplitigs.h:161-183) -- it would have run on
+        // from one of these k-mers into a neighbouring chain.  So the cycle is opened at the port that has the most preferred
+        // candidate edge (the order of `edges`) to a DEAD port outside the cycle: the overlap merge of phase 2 then joins that chain
+        // end and the opened cycle with k-1 characters, as if they had been one simplitig.  No such edge: at the minimum key, port L.
+        uint32_t cutport = 2 * best + 0;
+        {
+            std::vector<uint8_t> oncyc_mark;   // (cycles are few and short: a scan of the sorted edge list per cycle)
+            std::unordered_set<uint32_t> oncyc;
+            { uint32_t c2 = i; int o2 = 0; while (true) { oncyc.insert(c2); uint32_t nx = 0; int no = 0; step(c2, o2, nx, no); c2 = nx; o2 = no; if (c2 == i) break; } }
+            bool found = false;
+            for (auto &e : edges) {
+                const uint32_t a = 2 * e.ia + e.pa, b = 2 * e.ib + e.pb;
+                if (a == b) continue;
+                for (int sw = 0; sw < 2 && !found; ++sw) {
+                    const uint32_t x = sw ? b : a, y = sw ? a : b;
+                    if (oncyc.count(x >> 1) && !oncyc.count(y >> 1) && link[y] == NONE && dead_before[y]) { cutport = x; found = true; }
+                }
+                if (found) break;   // edges are sorted by preference: the first hit is the best
+            }
+        }
+        const uint32_t other = link[cutport];
+        link[cutport] = NONE;
         link[other] = NONE;
         ++cycles_cut;
     }

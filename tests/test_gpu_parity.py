@@ -633,17 +633,16 @@ def test_compute_spneumoniae(ctx, oracle, golden_dir, k, complements):
     rc, want_mask = oracle.maskopt(out, k, complements, minimize=False)
     assert rc == 0 and mask == want_mask
     assert hashlib.md5("".join(sorted(got_set)).encode()).hexdigest() == g["set_md5"]
-    # Superstring length vs the reference.  The simplitig sets differ, and there is a structural reason for the
-    # direction of the difference: the canonical rule is a matching of ports, so it can close a cycle, which is then cut at its
-    # smallest k-mer into one more simplitig; the reference's delete-as-you-go walk can never close one.  On all eight runs
-    # the excess of simplitigs is at most the number of cycles cut (measured: +4/4, +6/7, +4/7, +3/7, +2/4, +7/7, +1/2, +2/3),
-    # each extra simplitig costs at most k - 1 characters, and the measured |dL|/L are the ones asserted below.
+    # Superstring length vs the reference.  The simplitig sets differ: the canonical rule is a matching of ports, so it
+    # can close a cycle, which the reference's delete-as-you-go walk never does -- it would have run on into a neighbouring chain.
+    # A cycle is therefore opened at the port with the most preferred edge to a chain end (kc_cycles_decide), where phase 2 joins
+    # the two with k - 1 characters.  With that rule the superstring is never longer than the reference's on these eight runs
+    # (measured dL: -11, -5, -124, -39, -128, -162, -161, -392 characters); the count of simplitigs may exceed the reference's
+    # by at most the number of cycles cut.
     cycles = r.stats["cycles_cut"]
     assert r.stats["n_simplitigs"] - g["S"] <= cycles, (r.stats["n_simplitigs"], g["S"], cycles)
-    assert r.length - g["L"] <= cycles * (k - 1)
-    measured = {(13, True): 0, (13, False): 18, (31, True): 25, (31, False): -35, (63, True): 139, (63, False): 267, (127, True): 97, (127, False): 580}
-    assert r.length - g["L"] == measured[(k, complements)]
-    assert abs(r.length - g["L"]) / g["L"] <= 2.7e-4
+    assert r.length <= g["L"], (r.length, g["L"])
+    assert (g["L"] - r.length) / g["L"] <= 2.7e-4
     # T-C: byte-identical to the oracle's canonical-order mode
     rc, want, wmask, st = oracle.compute_file(path, k, complements, False, mode=1)
     assert rc == 0 and out == want and mask == wmask
