@@ -319,10 +319,10 @@ __global__ void __launch_bounds__(256) kc_shard_wave_finish_kernel(u64 n, const 
     unreached[t] = ok ? 0 : 1;
 }
 
-// ---- cycles.  K-mers all of whose ports are matched and that no entry reaches lie on cycles inside this rank: they are
-// listed here and cut by kc_cycles_parallel_kernel / kc_cycles_kernel (kc_simp_dev.h).  Fragments that never reach a chain
-// end lie on cycles that span ranks: each reports its smallest key, the ranks agree on every cycle's minimum (host, the
-// cycles are few) and the owner cuts it on that k-mer's port L -- the same cut as the single-GPU flow and the oracle.
+// ---- cycles.  K-mers that no fragment reaches lie on cycles inside this rank, fragments that the ranking never connects to a
+// chain end lie on cycles that span ranks.  Both kinds are dealt with together after the ranking: the rows of their k-mers are
+// all-gathered (they are few), every rank looks up the candidate edges of the ports whose home it owns (kc_shard_cycle_cand_kernel),
+// those are all-gathered too, and every rank takes the same decisions as the single-GPU flow and the oracle (kc_cycles_decide).
 __global__ void __launch_bounds__(256) kc_shard_sum_kernel(const u64 *__restrict__ a, u64 n, u64 *out) {
     u64 s = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) s += a[i];
@@ -337,45 +337,63 @@ __global__ void __launch_bounds__(256) kc_shard_unvisited_kernel(const u8 *__res
     const u64 pos = atomicAdd((ull *)cursor, 1ULL);
     if (FILL) list[pos] = rlo + t;
 }
-// rows {fragment id, successor id, slot of the smallest key, that key} of the fragments in `act`
-template <int W>
-__global__ void __launch_bounds__(256) kc_shard_cycle_rows_kernel(SetView<W> set, const u64 *__restrict__ link, u64 rlo, u64 rcap, const u64 *__restrict__ act, u64 n,
-                                                                  const u64 *__restrict__ entries, const u64 *__restrict__ succ0, int me, u64 *rows) {
+// mark the k-mers of the fragments that are on chains with ends (skip[t]: fragment t was never reached by the ranking)
+__global__ void __launch_bounds__(256) kc_shard_mark_kernel(const u64 *__restrict__ link, u64 rlo, u64 rcap, const u64 *__restrict__ entries, u64 n, const u8 *__restrict__ skip, u8 *visited) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const u64 e = act[t], h = entries[e];
-    u64 cur = h >> 1, best = cur;
+    if (t >= n || skip[t]) return;
+    const u64 h = entries[t];
+    u64 cur = h >> 1;
     int co = (int)(h & 1);
-    Key<W> bk = set_key_at(set, cur);
     while (true) {
+        visited[cur - rlo] = 1;
         const u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         if (!LK_IS_MATCHED(w) || LK_SLOT(w) - rlo >= rcap) break;
         cur = LK_SLOT(w);
         co = LK_PORT(w) == 0 ? 0 : 1;
-        const Key<W> ck = set_key_at(set, cur);
-        if (key_lt(ck, bk)) { bk = ck; best = cur; }
     }
-    u64 *r = rows + t * (3 + W);
-    r[0] = KC_GID(me, e); r[1] = succ0[e]; r[2] = best;
-    for (int w = 0; w < W; ++w) r[3 + w] = bk.w[w];
 }
-// cut the listed k-mers (those on this rank) on their port L; partner[i] = the port that faced it (KC_NONE64 for foreign slots)
-__global__ void __launch_bounds__(256) kc_shard_cut_kernel(u64 *link, const u64 *__restrict__ slots, u64 n, u64 rlo, u64 rcap, u64 *partner) {
+// candidate edges of the ports of the gathered cycle k-mers (rows: {slot, link L, link R, key}) whose home this rank owns, to
+// ports that the matching left dead: {priority, x pid, y pid, key y} (cf. kc_cycle_cand_kernel)
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_cycle_cand_kernel(SetView<W> set, const u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ rows, u64 n,
+                                                                  u64 *cand, u64 cand_cap, u64 *cursor) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    partner[t] = KC_NONE64;
-    const u64 slot = slots[t];
-    if (slot - rlo >= rcap) return;
-    const u64 w = link[slot << 1];
-    if (!LK_IS_MATCHED(w)) return;
-    partner[t] = LK_PID(w);
-    link[slot << 1] = LK_DEAD;
+    if (t >= 2 * n) return;
+    const u64 *r = rows + (t >> 1) * (3 + W);
+    const int port = (int)(t & 1);
+    Key<W> x;
+    for (int w = 0; w < W; ++w) x.w[w] = r[3 + w];
+    const Key<W> xr = key_rc(x, k);
+    const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+    const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+    const KcPortDesc d = kc_port_desc<W, 0>(set, x, xr, k, complements, port, kc_mid_min<W, 0>(mid, midr, k, set.m));
+    if (d.home - set.rlo >= set.rcap) return;
+    u64 cs[4]; u32 qb;
+    kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+    const u64 hx = key_hash(x);
+    for (u32 c = 0; c < 4; ++c) {
+        u64 ys = KC_NONE64;
+#pragma unroll
+        for (u32 cc = 0; cc < 4; ++cc) ys = (c == cc) ? cs[cc] : ys;
+        if (ys == KC_NONE64) continue;
+        const u64 yw = link[(ys << 1) | (u64)((qb >> c) & 1u)];
+        if (LK_STATE(yw) != LK_DEAD || (yw & LK_CUT)) continue;
+        int q;
+        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
+        const u64 at = atomicAdd((ull *)cursor, 1ULL);
+        if (at >= cand_cap) continue;
+        u64 *o = cand + at * (3 + W);
+        o[0] = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
+        o[1] = (r[0] << 1) | (u64)port; o[2] = (ys << 1) | (u64)q;
+        for (int w = 0; w < W; ++w) o[3 + w] = y.w[w];
+    }
 }
+// open the cycles: the listed ports (those of this rank) become dead
 __global__ void __launch_bounds__(256) kc_shard_kill_kernel(u64 *link, const u64 *__restrict__ pids, u64 n, u64 rlo2, u64 rcap2) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 pid = pids[t];
-    if (pid != KC_NONE64 && pid - rlo2 < rcap2) link[pid] = LK_DEAD;
+    if (pid != KC_NONE64 && pid - rlo2 < rcap2) link[pid] = LK_DEAD | LK_CUT;
 }
 
 // ---- chain heads: fragments whose entry port is dead.  They ask the owner of the chain's final fragment for the tail
@@ -836,7 +854,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                        (unsigned long long)N, (unsigned long long)nq, (unsigned long long)n_branch_edges);
     // ---------------- phase 1b: fragments (the discovery restarts after a cycle has been cut)
     u64 *entries = nullptr, n_ent = 0;
-    u64 *f_exit = nullptr, *f_partner = nullptr, *f_len = nullptr, *nxt = nullptr, *dist = nullptr, *last = nullptr, *iota = nullptr, *act = nullptr, *succ0 = nullptr;
+    u64 *f_exit = nullptr, *f_partner = nullptr, *f_len = nullptr, *nxt = nullptr, *dist = nullptr, *last = nullptr, *iota = nullptr, *act = nullptr;
     u32 *f_stream = nullptr, *fidx = nullptr, *chunk_next = nullptr;
     u64 *pool = nullptr;
     u8 *flags8 = nullptr;
@@ -856,8 +874,9 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     };
     for (int pass = 0;; ++pass) {
         if (pass == 64) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not settle after cutting cycles");
-        // entries, fragment walks; cycles inside this rank are cut on the spot (no exchange involved)
-        for (int lpass = 0;; ++lpass) {
+        // entries, fragment walks.  K-mers that no fragment reaches lie on cycles inside this rank: counted here, cut after the ranking
+        u64 missing = 0;
+        {
             // entries: listed by the contraction kernel on its way (it has every link word of the block in registers), or by a sweep of
             // their own (no contraction: cycles, KC_NOFRAG; or more entries than the list was sized for)
             KcFrag fr{nullptr, nullptr, 0, 0};
@@ -919,40 +938,10 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(read_words(ctx, cur, hw, 3 * KC_USTRIDE));
             if (hw[KC_USTRIDE]) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted");
             const u64 walked = hw[2 * KC_USTRIDE] / (complements ? 2 : 1);
-            if (walked == N_local) break;
-            if (contracted) {   // cycles: everything below walks and cuts plain links -- put them back and walk again
-                KC_TRY(restore_links());
-                scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
-                --lpass;
-                continue;
-            }
-            // some k-mers are reached by no fragment: cycles that stay inside this rank
-            if (lpass == 3) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
-            u8 *visited = nullptr;
-            u64 *ulist = nullptr, *dummy_heads = nullptr, nunvis = 0;
-            KC_TRY(scope.alloc(&visited, rcap));
-            KC_HIP(ctx, hipMemsetAsync(visited, 0, rcap, ctx->stream));
-            if (n_ent)
-                hipLaunchKernelGGL((kc_shard_walk_kernel<true, false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
-                                   f_exit, f_partner, f_len, f_stream, fidx, frec, visited, cur + KC_USTRIDE, fr, set->bshift);
-            KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
-            hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
-            KC_TRY(read_words(ctx, cur + 3 * KC_USTRIDE, &nunvis, 1));
-            if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree");
-            KC_TRY(scope.alloc(&ulist, nunvis)); KC_TRY(scope.alloc(&dummy_heads, 2 * nunvis + 2));
-            KC_HIP(ctx, hipMemsetAsync(cur + 3 * KC_USTRIDE, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
-            if (lpass == 0)
-                hipLaunchKernelGGL((kc_cycles_parallel_kernel<W>), dim3(kc_grid(nunvis, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, complements, dummy_heads, cur, (u64)4096);
-            else
-                hipLaunchKernelGGL((kc_cycles_kernel<W>), dim3(1), dim3(64), 0, ctx->stream, sv, link, (const u64 *)ulist, nunvis, visited - rlo, complements, dummy_heads, cur);
-            KC_HIP(ctx, hipGetLastError());
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ++cycles_cut;
-            scope.release(visited); scope.release(ulist); scope.release(dummy_heads);
-            scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
+            if (walked > N_local) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree");
+            missing = N_local - walked;
         }
-        KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1)); KC_TRY(scope.alloc(&succ0, n_ent + 1));
+        KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1));
         KC_TRY(scope.alloc(&iota, n_ent + 1)); KC_TRY(scope.alloc(&act, n_ent + 1)); KC_TRY(scope.alloc(&flags8, n_ent + 1));
         if (n_ent) {
             hipLaunchKernelGGL(kc_shard_jump_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)f_partner, (const u64 *)f_len, n_ent, me, nxt, dist, last);
@@ -1021,28 +1010,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 u64 tot_un = n_act;
                 KC_TRY(kcc_allreduce_sum(c, &tot_un, 1));
                 ranked = true;
-                if (tot_un) {
-                    // their successor ports -> fragment ids (the one exchange pointer jumping starts with), for the cycle analysis below
-                    stalled = true;
-                    u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *ansb = nullptr;
-                    u8 *dest = nullptr;
-                    KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
-                    if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, 1, 2 * rcap, req, dest);
-                    KcRoute rt;
-                    KC_TRY(kcr_build(c, dest, n_act, &rt));
-                    int rc = kcr_forward(c, rt, req, 1, 1, &rq);
-                    if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
-                    if (rc == KC_OK && rt.n_recv) hipLaunchKernelGGL(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
-                    if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, n_act + 1);
-                    if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
-                    if (rc == KC_OK && n_act) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
-                    if (rc == KC_OK && n_ent && hipMemcpyAsync(succ0, nxt, n_ent * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
-                    (void)hipStreamSynchronize(ctx->stream);
-                    kcr_free(ctx, &rt);
-                    kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
-                    scope.release(req); scope.release(dest);
-                    KC_TRY(rc);
-                }
+                stalled = tot_un != 0;
             }
             scope.release(pay); scope.release(poff); scope.release(reach_a); scope.release(reach_b);
         }
@@ -1078,7 +1046,6 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 if (round == 0) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
                 else hipLaunchKernelGGL(kc_shard_apply_jump_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt, dist, last);
             }
-            if (rc == KC_OK && round == 0 && n_ent && hipMemcpyAsync(succ0, nxt, n_ent * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
             (void)hipStreamSynchronize(ctx->stream);
             kcr_free(ctx, &rt);
             kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
@@ -1086,57 +1053,67 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(rc);
             ++rounds;
         }
-        if (!stalled) break;
-        // cycles that span ranks: agree on every cycle's smallest k-mer, cut there, start over
-        KC_TRY(restore_links());   // (the rows below walk plain links, the cut rewrites them)
+        {
+            u64 any_missing = missing;
+            KC_TRY(kcc_allreduce_max(c, &any_missing, 1));
+            if (!stalled && !any_missing) break;
+        }
+        // cycles (inside ranks and across them): every rank lists its k-mers that are on no chain with ends, all ranks take the same
+        // decisions (kc_cycles_decide), the owners open the cycles, and the discovery starts over
+        KC_TRY(restore_links());   // (everything below walks plain links, the cut rewrites them)
         {
             const int RW = 3 + W;
-            u64 *rows = nullptr, *all = nullptr, n_all = 0;
-            KC_TRY(scope.alloc(&rows, (n_act + 1) * RW));
-            if (n_act)
-                hipLaunchKernelGGL((kc_shard_cycle_rows_kernel<W>), dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, rlo, rcap, (const u64 *)act, n_act,
-                                   (const u64 *)entries, (const u64 *)succ0, me, rows);
-            KC_TRY(allgather_rows(c, rows, n_act, RW, &all, &n_all, nullptr));
-            scope.release(rows);
-            std::vector<u64> h(n_all * RW), cuts;
-            KC_HIP(ctx, hipMemcpyAsync(h.data(), all, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            kc_release(ctx, all);
-            std::unordered_map<u64, u64> at;
-            at.reserve(n_all * 2);
-            for (u64 i = 0; i < n_all; ++i) at[h[i * RW]] = i;
-            std::vector<u8> seen(n_all, 0);
-            std::unordered_set<u64> cut_set;
-            for (u64 i = 0; i < n_all; ++i) {
-                if (seen[i]) continue;
-                u64 j = i, best = i, steps = 0;
-                bool closed = false;
-                while (!seen[j]) {
-                    seen[j] = 1;
-                    if (hkey_lt<W>(h.data() + j * RW + 3, h.data() + best * RW + 3)) best = j;
-                    auto it = at.find(h[j * RW + 1]);
-                    if (it == at.end()) break;          // leads to a fragment that did terminate: not a cycle after all
-                    j = it->second;
-                    if (j == i) { closed = true; break; }
-                    if (++steps > n_all) break;
-                }
-                if (closed && cut_set.insert(h[best * RW + 2]).second) cuts.push_back(h[best * RW + 2]);
+            u8 *visited = nullptr;
+            u64 *ulist = nullptr, *rows = nullptr, *all = nullptr, *cand = nullptr, *allc = nullptr, n_all = 0, n_allc = 0, nunvis = 0, ncand = 0;
+            KC_TRY(scope.alloc(&visited, rcap + 1));
+            KC_HIP(ctx, hipMemsetAsync(visited, 0, rcap, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
+            if (n_ent) hipLaunchKernelGGL(kc_shard_mark_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent, (const u8 *)flags8, visited);
+            hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
+            KC_HIP(ctx, hipGetLastError());
+            KC_TRY(read_words(ctx, cur + 3 * KC_USTRIDE, &nunvis, 1));
+            KC_TRY(scope.alloc(&ulist, nunvis + 1)); KC_TRY(scope.alloc(&rows, (nunvis + 1) * RW));
+            KC_HIP(ctx, hipMemsetAsync(cur + 3 * KC_USTRIDE, 0, 8, ctx->stream));
+            if (nunvis) {
+                hipLaunchKernelGGL((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
+                hipLaunchKernelGGL((kc_cycle_rows_kernel<W>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows);
             }
+            KC_HIP(ctx, hipGetLastError());
+            KC_TRY(allgather_rows(c, rows, nunvis, RW, &all, &n_all, nullptr));
+            scope.release(visited); scope.release(ulist); scope.release(rows);
+            if (n_all == 0) { kc_release(ctx, all); return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle"); }
+            const u64 cand_cap = n_all + 65536;
+            int rc = kc_alloc(ctx, &cand, cand_cap * RW);
+            if (rc == KC_OK) {
+                hipLaunchKernelGGL((kc_shard_cycle_cand_kernel<W>), kc_grid2(2 * n_all, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)all, n_all,
+                                   cand, cand_cap, cur + 2 * KC_USTRIDE);
+                rc = read_words(ctx, cur + 2 * KC_USTRIDE, &ncand, 1);
+            }
+            u64 over = rc == KC_OK && ncand > cand_cap;
+            if (rc == KC_OK) rc = kcc_allreduce_max(c, &over, 1);
+            if (rc == KC_OK && over) rc = kc_fail(ctx, KC_E_CAPACITY, "too many candidate edges between cycles and chain ends");
+            if (rc == KC_OK) rc = allgather_rows(c, cand, ncand, RW, &allc, &n_allc, nullptr);
+            std::vector<u64> h(n_all * RW), hc(n_allc * RW), cuts, partners;
+            if (rc == KC_OK && hipMemcpyAsync(h.data(), all, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+            if (rc == KC_OK && n_allc && hipMemcpyAsync(hc.data(), allc, hc.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+            (void)hipStreamSynchronize(ctx->stream);
+            kc_release(ctx, all); kc_release(ctx, cand); kc_release(ctx, allc);
+            KC_TRY(rc);
+            kc_cycles_decide<W>(h, n_all, hc, n_allc, cuts, &partners);
             if (cuts.empty()) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle");
-            u64 *dcuts = nullptr, *partner = nullptr, *allp = nullptr, n_allp = 0;
-            KC_TRY(scope.alloc(&dcuts, cuts.size())); KC_TRY(scope.alloc(&partner, cuts.size()));
+            const u64 ncut = cuts.size();
+            cuts.insert(cuts.end(), partners.begin(), partners.end());
+            u64 *dcuts = nullptr;
+            KC_TRY(scope.alloc(&dcuts, cuts.size()));
             KC_HIP(ctx, hipMemcpyAsync(dcuts, cuts.data(), cuts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(kc_shard_cut_kernel, dim3(kc_grid(cuts.size(), 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dcuts, (u64)cuts.size(), rlo, rcap, partner);
+            hipLaunchKernelGGL(kc_shard_kill_kernel, dim3(kc_grid(cuts.size(), 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dcuts, (u64)cuts.size(), 2 * rlo, 2 * rcap);
+            KC_HIP(ctx, hipGetLastError());
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            KC_TRY(allgather_rows(c, partner, cuts.size(), 1, &allp, &n_allp, nullptr));
-            if (n_allp) hipLaunchKernelGGL(kc_shard_kill_kernel, dim3(kc_grid(n_allp, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)allp, n_allp, 2 * rlo, 2 * rcap);
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            kc_release(ctx, allp);
-            scope.release(dcuts); scope.release(partner);
-            cycles_cut += cuts.size();
+            scope.release(dcuts);
+            cycles_cut += ncut;
         }
         scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
-        scope.release(nxt); scope.release(dist); scope.release(last); scope.release(succ0); scope.release(iota); scope.release(act); scope.release(flags8);
+        scope.release(nxt); scope.release(dist); scope.release(last); scope.release(iota); scope.release(act); scope.release(flags8);
     }
     // chain heads gather their tails; winners become chain records
     const int CW = 3 + 3 * W;

@@ -12,6 +12,7 @@
 #define LK_CHOICE 1ull
 #define LK_MATCHED 2ull
 #define LK_DEAD 3ull
+#define LK_CUT 4ull                   /* on a dead port: it was made by opening a cycle (not one of the ports the matching left dead) */
 #define LK_STATE(w) ((w) & 3ull)
 #define LK_PORT(w) (((w) >> 2) & 1ull)
 #define LK_BASE(w) (((w) >> 3) & 3ull)
@@ -1075,7 +1076,8 @@ __global__ void __launch_bounds__(256) kc_cycle_cand_kernel(SetView<W> set, cons
         if (key_eq(y, x)) continue;
         const u64 ys = set_find(set, y);
         if (ys == KC_NONE64) continue;
-        if (LK_STATE(link[(ys << 1) | (u64)q]) != LK_DEAD) continue;
+        const u64 yw = link[(ys << 1) | (u64)q];
+        if (LK_STATE(yw) != LK_DEAD || (yw & LK_CUT)) continue;
         const u64 at = atomicAdd((ull *)cursor, 1ULL);
         if (at >= cand_cap) continue;
         u64 *r = cand + at * (3 + W);
@@ -1091,8 +1093,8 @@ static __global__ void __launch_bounds__(256) kc_cycle_apply_kernel(u64 *link, c
     const u64 pid = cuts[t];
     const u64 w = link[pid];
     const u64 partner = LK_PID(w);
-    link[pid] = LK_DEAD | (w & LK_SPLIT);
-    link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
+    link[pid] = LK_DEAD | LK_CUT | (w & LK_SPLIT);
+    link[partner] = LK_DEAD | LK_CUT | (link[partner] & LK_SPLIT);
     // a dead port is the entry of a directed chain (unidirectional sets: the L ports only, cf. kc_push_head)
     const bool h1 = complements || !(pid & 1), h2 = (complements || !(partner & 1)) && partner != pid;
     const u64 pos = atomicAdd((ull *)cursor, (ull)((h1 ? 1 : 0) + (h2 ? 1 : 0)));
@@ -1103,7 +1105,7 @@ static __global__ void __launch_bounds__(256) kc_cycle_apply_kernel(u64 *link, c
 }
 // host: walk the cycles of `rows`, choose every cycle's port to cut.  rows: n x (3 + W), cand: m x (3 + W) as above.
 template <int W>
-static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const std::vector<u64> &cand, u64 m, std::vector<u64> &cuts) {
+static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const std::vector<u64> &cand, u64 m, std::vector<u64> &cuts, std::vector<u64> *partners = nullptr) {
     const int RW = 3 + W;
     auto key_lt_h = [](const u64 *a, const u64 *b) { for (int i = W - 1; i >= 0; --i) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; } return false; };
     auto key_eq_h = [](const u64 *a, const u64 *b) { for (int i = 0; i < W; ++i) if (a[i] != b[i]) return false; return true; };
@@ -1112,7 +1114,7 @@ static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const s
     for (u64 i = 0; i < n; ++i) at[rows[i * RW]] = i;
     std::vector<u64> cyc(n, ~(u64)0), minnode;
     for (u64 i = 0; i < n; ++i) {
-        if (cyc[i] != ~(u64)0) continue;
+        if (cyc[i] != ~(u64)0 || at[rows[i * RW]] != i) continue;   // (a k-mer listed twice: one row speaks for it)
         const u64 id = minnode.size();
         u64 cur = i, best = i, steps = 0;
         int co = 0;
@@ -1158,73 +1160,12 @@ static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const s
     cuts.clear();
     for (size_t id = 0; id < minnode.size(); ++id) {
         if (minnode[id] == ~(u64)0) continue;
-        cuts.push_back(bc[id].have ? bc[id].xpid : (rows[minnode[id] * RW] << 1));
+        const u64 pid = bc[id].have ? bc[id].xpid : (rows[minnode[id] * RW] << 1);
+        cuts.push_back(pid);
+        if (partners) partners->push_back(LK_PID(rows[at[pid >> 1] * RW + 1 + (pid & 1)]));   // the port that faces it
     }
 }
 
-// cycles (rare): one thread, sequential.  Cut each cycle at its minimum key, on that node's port L, and append the cut
-// ends to the head list (cursor[0] = number of heads); the chains are then found by the ordinary discovery pass.
-template <int W>
-__global__ void kc_cycles_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, u8 *visited, int complements, u64 *heads,
-                                 u64 *cursor) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    u64 nh = cursor[0];
-    for (u64 i = 0; i < nlist; ++i) {
-        u64 start = list[i];
-        if (visited[start]) continue;
-        u64 cur = start, best = start;
-        int co = 0;
-        Key<W> bk = set_key_at(set, start);
-        do {
-            visited[cur] = 1;
-            Key<W> ck = set_key_at(set, cur);
-            if (key_lt(ck, bk)) { bk = ck; best = cur; }
-            u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
-            cur = LK_SLOT(w);
-            co = LK_PORT(w) == 0 ? 0 : 1;
-        } while (cur != start);
-        const u64 wl = link[(best << 1) | 0];
-        const u64 partner = LK_PID(wl);              // the port that faced best's port L
-        link[partner] = LK_DEAD | (link[partner] & LK_SPLIT);
-        link[(best << 1) | 0] = LK_DEAD | (wl & LK_SPLIT);
-        ++cursor[4];                                  // cycles cut
-        heads[nh++] = (best << 1) | 0;                // entry port of orientation o is port o
-        if (complements || !(partner & 1)) { if (partner != ((best << 1) | 0)) heads[nh++] = partner; }
-    }
-    cursor[0] = nh;
-}
-
-// the same cut, in parallel: every k-mer left on a cycle walks its cycle (at most `max_steps` steps) and the one holding the
-// cycle's minimum key cuts it.  A cycle longer than max_steps is left alone (cursor[2] = 1): the caller then runs the
-// sequential kernel above in a further pass.  Walkers may meet a link another thread has just cut: they simply stop.
-template <int W>
-__global__ void __launch_bounds__(256) kc_cycles_parallel_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ list, u64 nlist, int complements,
-                                                                 u64 *heads, u64 *cursor, u64 max_steps) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nlist) return;
-    const u64 start = list[t];
-    u64 cur = start, steps = 0;
-    int co = 0;
-    const Key<W> sk = set_key_at(set, start);
-    do {
-        if (cur != start && key_lt(set_key_at(set, cur), sk)) return;   // not the minimum of its cycle
-        const u64 w = __hip_atomic_load(&link[(cur << 1) | (u64)(co == 0 ? 1 : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!LK_IS_MATCHED(w)) return;                                    // cut under our feet (then start is not the minimum either)
-        cur = LK_SLOT(w);
-        co = LK_PORT(w) == 0 ? 0 : 1;
-        if (++steps > max_steps) { atomicExch((ull *)(cursor + 2), 1ULL); return; }
-    } while (cur != start);
-    // start holds the minimum key of its cycle
-    const u64 wl = link[(start << 1) | 0];
-    const u64 partner = LK_PID(wl);
-    __hip_atomic_store(&link[partner], LK_DEAD | (link[partner] & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&link[(start << 1) | 0], LK_DEAD | (wl & LK_SPLIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool two = (complements || !(partner & 1)) && partner != ((start << 1) | 0);
-    const u64 pos = atomicAdd((ull *)cursor, two ? 2ULL : 1ULL);
-    atomicAdd((ull *)(cursor + 4), 1ULL);             // cycles cut
-    heads[pos] = (start << 1) | 0;
-    if (two) heads[pos + 1] = partner;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Fragment contraction.  A chain walk costs one scattered 128-byte line per step for 8 useful bytes (measured: the walk
