@@ -86,10 +86,36 @@ def test_ranks_wide_keys_and_branching_reads(ctx, tmp_path, k):
 @pytest.mark.parametrize("world,k,mode", [(2, 31, "bi"), (3, 31, "uni"), (4, 23, "bi"), (2, 63, "bi")])
 def test_ranks_real_genome_with_cycles(ctx, golden_dir, tmp_path, world, k, mode):
     """S. pneumoniae (the reference's data/spneumoniae.fa): chains of > 10^5 k-mers, branch ports, and a few cycles -- cut at
-    their smallest k-mer whether they stay on one rank or span several.  One record, so some ranks hold no input at all."""
+    where their best edge to a chain end is, whether they stay on one rank or span several.  One record, so some ranks hold no
+    input at all."""
     fa = os.path.join(golden_dir, "spneumoniae.fa.gz")
     got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), timeout=900)
     assert np.array_equal(got, single(ctx, fa, k, mode == "bi")), (world, k, mode)
+
+
+@pytest.mark.parametrize("k,mode", [(19, "bi"), (31, "bi"), (31, "uni"), (33, "bi")])
+def test_ranks_cycles_next_to_chain_ends(ctx, tmp_path, k, mode):
+    """circular sequences (cycles of k-mers, short ones that stay in a block and long ones that span ranks), each with reads that
+    run into the circle or out of it (edges from cycle ports to dead ports: where the cycle is opened), and isolated circles
+    (opened at their smallest k-mer); pointer jumping and waves"""
+    import random
+    rng = random.Random(k * 7 + len(mode))
+    recs = []
+    for i in range(60):
+        n = rng.choice([k + 1, k + 5, 3 * k, 500, 4000])
+        c = "".join(rng.choice("ACGT") for _ in range(n))
+        recs.append((c + c[: k - 1]).encode())
+        for _ in range(rng.randint(0, 3)):
+            at = rng.randrange(n)
+            rot = (c + c)[at: at + k - 1]
+            tail = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 40)))
+            recs.append((rot + tail).encode() if rng.random() < 0.5 else (tail + rot).encode())
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    want = single(ctx, fa, k, mode == "bi")
+    for world, env in ((2, None), (3, {"KC_WAVE_MAX": "0"}), (4, None)):
+        got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), extra_env=env)
+        assert np.array_equal(got, want), (world, env)
 
 
 def test_ranks_cfg1_full_size(ctx, tmp_path):
