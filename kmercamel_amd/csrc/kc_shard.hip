@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) kc_shard_mark_kernel(const u64 *__restric
     }
 }
 // candidate edges of the ports of the gathered cycle k-mers (rows: {slot, link L, link R, key}) whose home this rank owns, to
-// ports that the matching left dead: {priority, x pid, y pid, key y} (cf. kc_cycle_cand_kernel)
+// ports that the matching left dead (rows as kc_cycle_cand_kernel writes them)
 template <int W>
 __global__ void __launch_bounds__(256) kc_shard_cycle_cand_kernel(SetView<W> set, const u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ rows, u64 n,
                                                                   u64 *cand, u64 cand_cap, u64 *cursor) {
@@ -380,22 +380,9 @@ __global__ void __launch_bounds__(256) kc_shard_cycle_cand_kernel(SetView<W> set
         if (LK_STATE(yw) != LK_DEAD || (yw & LK_CUT)) continue;
         int q;
         const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
-        const u64 at = atomicAdd((ull *)cursor, 1ULL);
-        if (at >= cand_cap) continue;
-        u64 *o = cand + at * (3 + W);
-        o[0] = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
-        o[1] = (r[0] << 1) | (u64)port; o[2] = (ys << 1) | (u64)q;
-        for (int w = 0; w < W; ++w) o[3 + w] = y.w[w];
+        kc_cycle_cand_emit<W>(x, hx, r[0], port, y, ys, q, k, cand, cand_cap, cursor);
     }
 }
-// open the cycles: the listed ports (those of this rank) become dead
-__global__ void __launch_bounds__(256) kc_shard_kill_kernel(u64 *link, const u64 *__restrict__ pids, u64 n, u64 rlo2, u64 rcap2) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const u64 pid = pids[t];
-    if (pid != KC_NONE64 && pid - rlo2 < rcap2) link[pid] = LK_DEAD | LK_CUT;
-}
-
 // ---- chain heads: fragments whose entry port is dead.  They ask the owner of the chain's final fragment for the tail
 // (oriented tail node + its key) and decide whether their direction is the one that is emitted.
 __global__ void __launch_bounds__(256) kc_shard_head_flags_kernel(const u64 *__restrict__ link, const u64 *__restrict__ entries, u64 n, u8 *flags) {
@@ -1082,8 +1069,9 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(allgather_rows(c, rows, nunvis, RW, &all, &n_all, nullptr));
             scope.release(visited); scope.release(ulist); scope.release(rows);
             if (n_all == 0) { kc_release(ctx, all); return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle"); }
+            const int CW = 4 + W;
             const u64 cand_cap = n_all + 65536;
-            int rc = kc_alloc(ctx, &cand, cand_cap * RW);
+            int rc = kc_alloc(ctx, &cand, cand_cap * CW);
             if (rc == KC_OK) {
                 hipLaunchKernelGGL((kc_shard_cycle_cand_kernel<W>), kc_grid2(2 * n_all, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)all, n_all,
                                    cand, cand_cap, cur + 2 * KC_USTRIDE);
@@ -1092,25 +1080,23 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             u64 over = rc == KC_OK && ncand > cand_cap;
             if (rc == KC_OK) rc = kcc_allreduce_max(c, &over, 1);
             if (rc == KC_OK && over) rc = kc_fail(ctx, KC_E_CAPACITY, "too many candidate edges between cycles and chain ends");
-            if (rc == KC_OK) rc = allgather_rows(c, cand, ncand, RW, &allc, &n_allc, nullptr);
-            std::vector<u64> h(n_all * RW), hc(n_allc * RW), cuts, partners;
+            if (rc == KC_OK) rc = allgather_rows(c, cand, ncand, CW, &allc, &n_allc, nullptr);
+            std::vector<u64> h(n_all * RW), hc(n_allc * CW), fix;
             if (rc == KC_OK && hipMemcpyAsync(h.data(), all, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
             if (rc == KC_OK && n_allc && hipMemcpyAsync(hc.data(), allc, hc.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
             (void)hipStreamSynchronize(ctx->stream);
             kc_release(ctx, all); kc_release(ctx, cand); kc_release(ctx, allc);
             KC_TRY(rc);
-            kc_cycles_decide<W>(h, n_all, hc, n_allc, cuts, &partners);
-            if (cuts.empty()) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle");
-            const u64 ncut = cuts.size();
-            cuts.insert(cuts.end(), partners.begin(), partners.end());
-            u64 *dcuts = nullptr;
-            KC_TRY(scope.alloc(&dcuts, cuts.size()));
-            KC_HIP(ctx, hipMemcpyAsync(dcuts, cuts.data(), cuts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(kc_shard_kill_kernel, dim3(kc_grid(cuts.size(), 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dcuts, (u64)cuts.size(), 2 * rlo, 2 * rcap);
+            const u64 ncyc = kc_cycles_decide<W>(h, n_all, hc, n_allc, fix);
+            if (ncyc == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle");
+            u64 *dfix = nullptr;
+            KC_TRY(scope.alloc(&dfix, fix.size()));
+            KC_HIP(ctx, hipMemcpyAsync(dfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(kc_shard_apply_fix_kernel, dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dfix, (u64)(fix.size() / 2), 2 * rlo, 2 * rcap);
             KC_HIP(ctx, hipGetLastError());
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            scope.release(dcuts);
-            cycles_cut += ncut;
+            scope.release(dfix);
+            cycles_cut += ncyc;
         }
         scope.release(entries); scope.release(f_exit); scope.release(f_partner); scope.release(f_len); scope.release(f_stream); scope.release(pool); scope.release(chunk_next);
         scope.release(nxt); scope.release(dist); scope.release(last); scope.release(iota); scope.release(act); scope.release(flags8);

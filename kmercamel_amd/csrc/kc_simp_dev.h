@@ -5,6 +5,8 @@
 #include "kc_internal.h"
 #include "kc_scan_dev.h"
 #include <unordered_map>
+#include <unordered_set>
+#include <algorithm>
 #include <vector>
 
 #define KC_MSPEC 16   /* minimizer length the k = 31 / 63 / 127 specialisations are compiled for (= kc_default_mlen) */
@@ -1043,11 +1045,13 @@ struct KcRec {
 };
 
 // ---- Where a cycle is opened (oracle: simplitigs_canonical_order).  The reference's delete-as-you-go walk never closes a cycle
-// (simplitigs.h:161-183): it would have run on from one of the cycle's k-mers into a neighbouring chain.  So a cycle is cut at
-// the port that has the most preferred candidate edge (priority, then the ordered endpoint tuple) to a port that the matching
-// left DEAD -- phase 2 then joins that chain end and the opened cycle with k-1 characters, as if they had been one simplitig --
-// and only without such an edge at its minimum key on port L.  The k-mers on cycles are few: their rows and the candidate
-// edges come to the host, which walks the cycles and decides; the same code serves the hash-sharded flow.
+// (simplitigs.h:161-183): it would have run on from one of the cycle's k-mers into a neighbouring chain.  So the candidate edges
+// from a port x.p on a cycle to a port y.q that the matching left DEAD are taken in the matching's own order (priority, then the
+// ordered endpoint tuple): if x's cycle is still closed and y.q still free, the cycle is opened at x.p and x.p is matched with
+// y.q -- the cycle becomes the continuation of that chain, as in the reference's walk; the port that faced x.p dies.  A cycle
+// that no such edge opens is cut at its minimum key on port L.  Ports that die here do not count as DEAD for this rule (LK_CUT):
+// it depends on the matching only.  The k-mers on cycles are few: their rows and candidate edges come to the host, which walks
+// the cycles and decides; the same code serves the hash-sharded flow.
 // row of a k-mer on a cycle: {slot, link word of port L, link word of port R, key[W]}
 template <int W>
 __global__ void __launch_bounds__(256) kc_cycle_rows_kernel(SetView<W> set, const u64 *__restrict__ link, const u64 *__restrict__ list, u64 n, u64 *rows) {
@@ -1059,7 +1063,19 @@ __global__ void __launch_bounds__(256) kc_cycle_rows_kernel(SetView<W> set, cons
     const Key<W> key = set_key_at(set, slot);
     for (int w = 0; w < W; ++w) r[3 + w] = key.w[w];
 }
-// candidate edges of the ports of the listed k-mers to dead ports of this table: {priority, x pid, y pid, key y[W]}
+// the base a walk appends when it steps into node y through port q (the LK_BASE of the port word that points there)
+template <int W> __device__ __forceinline__ u64 kc_step_base(const Key<W> &y, int q, int k) { return q == 0 ? (y.w[0] & 3) : 3 - (u64)key_at(y, k, 0); }
+// one candidate edge x.p -> y.q (y.q dead): {priority, x pid, y pid, base into y | base into x << 2, key y[W]}
+template <int W>
+__device__ __forceinline__ void kc_cycle_cand_emit(const Key<W> &x, u64 hx, u64 xslot, int port, const Key<W> &y, u64 yslot, int q, int k, u64 *cand, u64 cand_cap, u64 *cursor) {
+    const u64 at = atomicAdd((ull *)cursor, 1ULL);
+    if (at >= cand_cap) return;
+    u64 *r = cand + at * (4 + W);
+    r[0] = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
+    r[1] = (xslot << 1) | (u64)port; r[2] = (yslot << 1) | (u64)q;
+    r[3] = kc_step_base(y, q, k) | (kc_step_base(x, port, k) << 2);
+    for (int w = 0; w < W; ++w) r[4 + w] = y.w[w];
+}
 template <int W>
 __global__ void __launch_bounds__(256) kc_cycle_cand_kernel(SetView<W> set, const u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ list, u64 n,
                                                             u64 *cand, u64 cand_cap, u64 *cursor) {
@@ -1078,35 +1094,32 @@ __global__ void __launch_bounds__(256) kc_cycle_cand_kernel(SetView<W> set, cons
         if (ys == KC_NONE64) continue;
         const u64 yw = link[(ys << 1) | (u64)q];
         if (LK_STATE(yw) != LK_DEAD || (yw & LK_CUT)) continue;
-        const u64 at = atomicAdd((ull *)cursor, 1ULL);
-        if (at >= cand_cap) continue;
-        u64 *r = cand + at * (3 + W);
-        r[0] = kc_mix64(kc_port_term(hx, port) + kc_port_term(key_hash(y), q));
-        r[1] = (slot << 1) | (u64)port; r[2] = (ys << 1) | (u64)q;
-        for (int w = 0; w < W; ++w) r[3 + w] = y.w[w];
+        kc_cycle_cand_emit<W>(x, hx, slot, port, y, ys, q, k, cand, cand_cap, cursor);
     }
 }
-// open the cycles at the chosen ports; the opened ports join the head list (cursor[0] = number of heads, cursor[4] += cuts)
-static __global__ void __launch_bounds__(256) kc_cycle_apply_kernel(u64 *link, const u64 *__restrict__ cuts, u64 n, int complements, u64 *heads, u64 *cursor) {
+// write the decided link words {pid, word} (single-GPU flow: the splitter flag of the port stays)
+static __global__ void __launch_bounds__(256) kc_cycle_fix_kernel(u64 *link, const u64 *__restrict__ fix, u64 n) {
     const u64 t = kc_gtid();
     if (t >= n) return;
-    const u64 pid = cuts[t];
-    const u64 w = link[pid];
-    const u64 partner = LK_PID(w);
-    link[pid] = LK_DEAD | LK_CUT | (w & LK_SPLIT);
-    link[partner] = LK_DEAD | LK_CUT | (link[partner] & LK_SPLIT);
-    // a dead port is the entry of a directed chain (unidirectional sets: the L ports only, cf. kc_push_head)
-    const bool h1 = complements || !(pid & 1), h2 = (complements || !(partner & 1)) && partner != pid;
-    const u64 pos = atomicAdd((ull *)cursor, (ull)((h1 ? 1 : 0) + (h2 ? 1 : 0)));
-    u64 at = pos;
-    if (h1) heads[at++] = pid;
-    if (h2) heads[at] = partner;
-    atomicAdd((ull *)(cursor + 4), 1ULL);
+    const u64 pid = fix[2 * t];
+    link[pid] = fix[2 * t + 1] | (link[pid] & LK_SPLIT);
 }
-// host: walk the cycles of `rows`, choose every cycle's port to cut.  rows: n x (3 + W), cand: m x (3 + W) as above.
+// the head list after the cycles were opened: the old heads that are still dead (one that a cycle was attached to is not) and the
+// ports that died.  A dead port is the entry of a directed chain (unidirectional sets: the L ports only, cf. kc_push_head).
+static __global__ void __launch_bounds__(256) kc_heads_refresh_kernel(const u64 *__restrict__ link, const u64 *__restrict__ heads, u64 nheads, const u64 *__restrict__ fix, u64 nfix,
+                                                                      int complements, u64 *out, u64 *cursor) {
+    const u64 t = kc_gtid();
+    if (t >= nheads + nfix) return;
+    u64 pid;
+    if (t < nheads) { pid = heads[t]; if (LK_STATE(link[pid]) != LK_DEAD) return; }
+    else { pid = fix[2 * (t - nheads)]; if (LK_STATE(fix[2 * (t - nheads) + 1]) != LK_DEAD || !(complements || !(pid & 1))) return; }
+    out[atomicAdd((ull *)cursor, 1ULL)] = pid;
+}
+// host: walk the cycles of `rows` (n x (3 + W)), take the candidate edges `cand` (m x (4 + W)) in order of preference; fix = {pid, link
+// word} of every port that changes; returns the number of cycles opened
 template <int W>
-static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const std::vector<u64> &cand, u64 m, std::vector<u64> &cuts, std::vector<u64> *partners = nullptr) {
-    const int RW = 3 + W;
+static inline u64 kc_cycles_decide(const std::vector<u64> &rows, u64 n, const std::vector<u64> &cand, u64 m, std::vector<u64> &fix) {
+    const int RW = 3 + W, CW = 4 + W;
     auto key_lt_h = [](const u64 *a, const u64 *b) { for (int i = W - 1; i >= 0; --i) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; } return false; };
     auto key_eq_h = [](const u64 *a, const u64 *b) { for (int i = 0; i < W; ++i) if (a[i] != b[i]) return false; return true; };
     std::unordered_map<u64, u64> at;
@@ -1131,41 +1144,54 @@ static inline void kc_cycles_decide(const std::vector<u64> &rows, u64 n, const s
         }
         minnode.push_back(closed ? best : ~(u64)0);
     }
-    // the most preferred candidate edge per cycle
-    struct Best { bool have = false; u64 pr = 0; const u64 *ka = nullptr, *kb = nullptr; int pa = 0, pb = 0; u64 xpid = 0; };
-    std::vector<Best> bc(minnode.size());
+    // the candidate edges in the matching's order of preference
+    struct Edge { u64 pr; const u64 *ka, *kb; int pa, pb; const u64 *c; u64 id; };
+    std::vector<Edge> edges;
+    edges.reserve(m);
     for (u64 j = 0; j < m; ++j) {
-        const u64 *c = &cand[j * RW];
+        const u64 *c = &cand[j * CW];
         auto it = at.find(c[1] >> 1);
         if (it == at.end()) continue;
         const u64 id = cyc[it->second];
         if (id == ~(u64)0 || minnode[id] == ~(u64)0) continue;
         if (at.count(c[2] >> 1)) continue;   // (a dead port is never on a cycle; kept for safety)
-        const u64 *kx = &rows[it->second * RW + 3], *ky = c + 3;
+        const u64 *kx = &rows[it->second * RW + 3], *ky = c + 4;
         const int px = (int)(c[1] & 1), py = (int)(c[2] & 1);
         const bool x_first = key_lt_h(kx, ky) || (key_eq_h(kx, ky) && px <= py);
-        Best e; e.have = true; e.pr = c[0]; e.xpid = c[1];
-        e.ka = x_first ? kx : ky; e.pa = x_first ? px : py; e.kb = x_first ? ky : kx; e.pb = x_first ? py : px;
-        Best &b = bc[id];
-        bool better = !b.have;
-        if (!better) {
-            if (e.pr != b.pr) better = e.pr > b.pr;
-            else if (!key_eq_h(e.ka, b.ka)) better = key_lt_h(e.ka, b.ka);
-            else if (e.pa != b.pa) better = e.pa < b.pa;
-            else if (!key_eq_h(e.kb, b.kb)) better = key_lt_h(e.kb, b.kb);
-            else better = e.pb < b.pb;
-        }
-        if (better) b = e;
+        edges.push_back(Edge{c[0], x_first ? kx : ky, x_first ? ky : kx, x_first ? px : py, x_first ? py : px, c, id});
     }
-    cuts.clear();
+    std::sort(edges.begin(), edges.end(), [&](const Edge &a, const Edge &b) {
+        if (a.pr != b.pr) return a.pr > b.pr;
+        if (!key_eq_h(a.ka, b.ka)) return key_lt_h(a.ka, b.ka);
+        if (a.pa != b.pa) return a.pa < b.pa;
+        if (!key_eq_h(a.kb, b.kb)) return key_lt_h(a.kb, b.kb);
+        return a.pb < b.pb;
+    });
+    std::vector<u8> opened(minnode.size(), 0);
+    std::unordered_set<u64> taken;
+    fix.clear();
+    u64 ncyc = 0;
+    auto kill_partner = [&](u64 pid) {
+        const u64 partner = LK_PID(rows[at[pid >> 1] * RW + 1 + (pid & 1)]);   // the port that faces it
+        fix.push_back(partner); fix.push_back(LK_DEAD | LK_CUT);
+    };
+    for (const Edge &e : edges) {
+        const u64 xpid = e.c[1], ypid = e.c[2];
+        if (opened[e.id] || taken.count(ypid)) continue;
+        opened[e.id] = 1; taken.insert(ypid); ++ncyc;
+        kill_partner(xpid);
+        fix.push_back(xpid); fix.push_back(LK_MAKE(LK_MATCHED, ypid & 1, e.c[3] & 3, ypid >> 1));
+        fix.push_back(ypid); fix.push_back(LK_MAKE(LK_MATCHED, xpid & 1, (e.c[3] >> 2) & 3, xpid >> 1));
+    }
     for (size_t id = 0; id < minnode.size(); ++id) {
-        if (minnode[id] == ~(u64)0) continue;
-        const u64 pid = bc[id].have ? bc[id].xpid : (rows[minnode[id] * RW] << 1);
-        cuts.push_back(pid);
-        if (partners) partners->push_back(LK_PID(rows[at[pid >> 1] * RW + 1 + (pid & 1)]));   // the port that faces it
+        if (minnode[id] == ~(u64)0 || opened[id]) continue;
+        const u64 pid = rows[minnode[id] * RW] << 1;
+        kill_partner(pid);
+        if (LK_PID(rows[minnode[id] * RW + 1]) != pid) { fix.push_back(pid); fix.push_back(LK_DEAD | LK_CUT); }   // (a port matched with itself: one word)
+        ++ncyc;
     }
+    return ncyc;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Fragment contraction.  A chain walk costs one scattered 128-byte line per step for 8 useful bytes (measured: the walk

@@ -892,19 +892,16 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
         u64 *ulist = nullptr, *heads2 = nullptr;
         KC_TRY(scope.alloc(&ulist, nunvis));
-        KC_TRY(scope.alloc(&heads2, nheads + 2 * nunvis + 1));   // every cycle adds at most two heads
-        KC_HIP(ctx, hipMemcpyAsync(heads2, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
         hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
                            cnt + 1);
-        KC_HIP(ctx, hipMemcpyAsync(cnt, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
         {
             // rows of the k-mers on cycles and the candidate edges of their ports to dead ports -> host, which walks the cycles and
-            // chooses every cycle's port to cut (kc_cycles_decide) -> kc_cycle_apply_kernel
-            const int RW = 3 + W;
-            u64 *rows_d = nullptr, *cand_d = nullptr, *cuts_d = nullptr;
+            // decides where each is opened (kc_cycles_decide) -> kc_cycle_fix_kernel, new head list
+            const int RW = 3 + W, CW = 4 + W;
+            u64 *rows_d = nullptr, *cand_d = nullptr, *fix_d = nullptr;
             const u64 cand_cap = nunvis + 65536;
-            KC_TRY(scope.alloc(&rows_d, nunvis * RW)); KC_TRY(scope.alloc(&cand_d, cand_cap * RW));
+            KC_TRY(scope.alloc(&rows_d, nunvis * RW)); KC_TRY(scope.alloc(&cand_d, cand_cap * CW));
             KC_HIP(ctx, hipMemsetAsync(cnt + 6, 0, 8, ctx->stream));
             hipLaunchKernelGGL((kc_cycle_rows_kernel<W>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows_d);
             hipLaunchKernelGGL((kc_cycle_cand_kernel<W>), kc_grid2(2 * nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, compl_, (const u64 *)ulist, nunvis,
@@ -913,24 +910,24 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             u64 ncand = 0;
             KC_TRY(read_u64(ctx, cnt + 6, &ncand));
             if (ncand > cand_cap) return kc_fail(ctx, KC_E_CAPACITY, "too many candidate edges between cycles and chain ends");
-            std::vector<u64> rows(nunvis * RW), cand(ncand * RW), cuts;
+            std::vector<u64> rows(nunvis * RW), cand(ncand * CW), fix;
             KC_HIP(ctx, hipMemcpyAsync(rows.data(), rows_d, rows.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             if (ncand) KC_HIP(ctx, hipMemcpyAsync(cand.data(), cand_d, cand.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            kc_cycles_decide<W>(rows, nunvis, cand, ncand, cuts);
-            if (cuts.empty()) return kc_fail(ctx, KC_E_NO_DEVICE, "k-mers outside every chain that lie on no cycle");
-            KC_TRY(scope.alloc(&cuts_d, cuts.size()));
-            KC_HIP(ctx, hipMemcpyAsync(cuts_d, cuts.data(), cuts.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(kc_cycle_apply_kernel, kc_grid2(cuts.size(), 256), dim3(256), 0, ctx->stream, link, (const u64 *)cuts_d, (u64)cuts.size(), compl_, heads2, cnt);
+            const u64 ncyc = kc_cycles_decide<W>(rows, nunvis, cand, ncand, fix);
+            if (ncyc == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "k-mers outside every chain that lie on no cycle");
+            const u64 nfix = fix.size() / 2;
+            KC_TRY(scope.alloc(&fix_d, fix.size()));
+            KC_TRY(scope.alloc(&heads2, nheads + nfix + 1));
+            KC_HIP(ctx, hipMemcpyAsync(fix_d, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(kc_cycle_fix_kernel, kc_grid2(nfix, 256), dim3(256), 0, ctx->stream, link, (const u64 *)fix_d, nfix);
+            hipLaunchKernelGGL(kc_heads_refresh_kernel, kc_grid2(nheads + nfix, 256), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)heads, nheads, (const u64 *)fix_d, nfix,
+                               compl_, heads2, cnt);
             KC_HIP(ctx, hipGetLastError());
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (cuts is a host vector)
-            scope.release(rows_d); scope.release(cand_d); scope.release(cuts_d);
-        }
-        {
-            u64 hcyc[5] = {0, 0, 0, 0, 0};
-            KC_HIP(ctx, hipMemcpyAsync(hcyc, cnt, 40, hipMemcpyDeviceToHost, ctx->stream));
-            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            nheads = hcyc[0]; cycles_cut += hcyc[4];
+            KC_TRY(read_u64(ctx, cnt, &nheads));   // (synchronises: fix is a host vector)
+            cycles_cut += ncyc;
+            scope.release(rows_d); scope.release(cand_d); scope.release(fix_d);
         }
         scope.release(heads); heads = heads2;
         scope.release(ulist); scope.release(visited);

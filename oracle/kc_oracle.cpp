@@ -511,7 +511,7 @@ std::vector<Simplitig> simplitigs_canonical_order(std::vector<K> keys, int k, bo
         if (a == b) continue;
         if (link[a] == NONE && link[b] == NONE) { link[a] = b; link[b] = a; }
     }
-    // cycles: cut next to a dead port, else at the minimum key of the cycle on its port L (see below).
+    // cycles (see below)
     std::vector<uint8_t> dead_before(2 * n, 0);   // ports dead after the matching (ports opened by a cut do not count: the rule is independent of the order of the cycles)
     for (size_t pidx = 0; pidx < 2 * n; ++pidx) dead_before[pidx] = link[pidx] == NONE;
     std::vector<uint8_t> seen(n, 0);
@@ -530,37 +530,47 @@ std::vector<Simplitig> simplitigs_canonical_order(std::vector<K> keys, int k, bo
             while (true) { seen[cur] = 1; uint32_t nx; int no; if (!step(cur, co, nx, no)) break; cur = nx; co = no; }
         }
     }
+    // Where a cycle is opened: the reference's delete-as-you-go walk never closes a cycle (simplitigs.h:161-183) -- it would have
+    // run on from one of these k-mers into a neighbouring chain.  So the candidate edges from a port x.p on a cycle to a port y.q
+    // that the matching left DEAD are taken in the matching's own order of preference (the order of `edges`): if x's cycle is
+    // still closed and y.q still free, the cycle is opened at x.p and x.p is matched with y.q -- the cycle becomes the
+    // continuation of that chain, as in the reference's walk.  (Ports that die by opening a cycle do not count: the rule depends
+    // on the matching only, not on an order of the cycles.)  A cycle no such edge opens is cut at its minimum key on port L.
+    std::vector<uint32_t> cyc_of(n, NONE), cyc_min;
     for (uint32_t i = 0; i < n; ++i) {
         if (seen[i]) continue;
+        const uint32_t id = (uint32_t)cyc_min.size();
         uint32_t cur = i, best = i; int co = 0;
         while (true) {
-            seen[cur] = 1;
+            seen[cur] = 1; cyc_of[cur] = id;
             if (keys[cur] < keys[best]) best = cur;
             uint32_t nx; int no; step(cur, co, nx, no);
             cur = nx; co = no;
             if (cur == i) break;
         }
-        // Where to cut: the reference's delete-as-you-go walk never closes a cycle (simplitigs.h:161-183) -- it would have run on
-        // from one of these k-mers into a neighbouring chain.  So the cycle is opened at the port that has the most preferred
-        // candidate edge (the order of `edges`) to a DEAD port outside the cycle: the overlap merge of phase 2 then joins that chain
-        // end and the opened cycle with k-1 characters, as if they had been one simplitig.  No such edge: at the minimum key, port L.
-        uint32_t cutport = 2 * best + 0;
-        {
-            std::vector<uint8_t> oncyc_mark;   // (cycles are few and short: a scan of the sorted edge list per cycle)
-            std::unordered_set<uint32_t> oncyc;
-            { uint32_t c2 = i; int o2 = 0; while (true) { oncyc.insert(c2); uint32_t nx = 0; int no = 0; step(c2, o2, nx, no); c2 = nx; o2 = no; if (c2 == i) break; } }
-            bool found = false;
-            for (auto &e : edges) {
-                const uint32_t a = 2 * e.ia + e.pa, b = 2 * e.ib + e.pb;
-                if (a == b) continue;
-                for (int sw = 0; sw < 2 && !found; ++sw) {
-                    const uint32_t x = sw ? b : a, y = sw ? a : b;
-                    if (oncyc.count(x >> 1) && !oncyc.count(y >> 1) && link[y] == NONE && dead_before[y]) { cutport = x; found = true; }
-                }
-                if (found) break;   // edges are sorted by preference: the first hit is the best
+        cyc_min.push_back(best);
+    }
+    std::vector<uint8_t> opened(cyc_min.size(), 0);
+    if (!cyc_min.empty()) {
+        for (auto &e : edges) {
+            const uint32_t a = 2 * e.ia + e.pa, b = 2 * e.ib + e.pb;
+            if (a == b) continue;
+            for (int sw = 0; sw < 2; ++sw) {
+                const uint32_t x = sw ? b : a, y = sw ? a : b;
+                const uint32_t id = cyc_of[x >> 1];
+                if (id == NONE || opened[id] || !dead_before[y] || link[y] != NONE) continue;
+                const uint32_t other = link[x];
+                link[other] = NONE;
+                link[x] = y; link[y] = x;
+                opened[id] = 1;
+                ++cycles_cut;
+                break;
             }
         }
-        const uint32_t other = link[cutport];
+    }
+    for (size_t id = 0; id < cyc_min.size(); ++id) {
+        if (opened[id]) continue;
+        const uint32_t cutport = 2 * cyc_min[id] + 0, other = link[cutport];
         link[cutport] = NONE;
         link[other] = NONE;
         ++cycles_cut;
