@@ -964,8 +964,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     if (ecnt + nd <= (u32)ECAP) {
                         if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); if (MM) emmh[at] = mmh; }
                         ecnt += nd;
-                    } else if (SH) settle_listed(defer, so, port, mmh);   // (no room on the stack: settled on the spot)
-                    else if (defer) to_spill((slot << 1) | (u64)port);
+                    } else if (defer) to_spill((slot << 1) | (u64)port);   // (no room on the stack; SH: the spill kernel turns remote ones into queries)
                 }
                 if (done) { if (port) wd1 = word; else wd0 = word; have |= 1u << port; }
             }
@@ -995,7 +994,7 @@ __global__ void __launch_bounds__(256) kc_probe_spill_kernel(SetView<W> set, u64
     }
 }
 
-// the same for the hash-sharded flow: the spilled ports are local ones (remote ports became queries)
+// the same for the hash-sharded flow (a spilled port whose home lies on another rank becomes a query here)
 template <int W>
 __global__ void __launch_bounds__(256) kc_shard_spill_kernel(SetView<W> set, u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ spill,
                                                              u64 spill_cap, const u64 *__restrict__ spill_cursor, ShLists L) {
@@ -1006,6 +1005,23 @@ __global__ void __launch_bounds__(256) kc_shard_spill_kernel(SetView<W> set, u64
         const int port = (int)(pid & 1);
         const Key<W> x = set_key_at(set, pid >> 1);
         const Key<W> xr = key_rc(x, k);
+        if (set.m) {
+            const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+            const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+            const KcPortDesc d = kc_port_desc<W, 0>(set, x, xr, k, complements, port, kc_mid_min<W, 0>(mid, midr, k, set.m));
+            if (d.home - set.rlo >= set.rcap) {
+                const u32 shard = (u32)t & (KC_USH - 1);
+                const u64 qpos = atomicAdd((ull *)&L.qry_cur[shard * KC_USTRIDE], 1ULL);
+                if (qpos >= L.qry_scap) L.flags[0] = 1;
+                else {
+                    u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * (W + 2);
+                    for (int w = 0; w < W; ++w) qq[w] = x.w[w];
+                    qq[W] = pid;
+                    qq[W + 1] = d.home;
+                }
+                continue;
+            }
+        }
         u64 cs[4]; u32 qb;
         kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
         link[pid] = kc_shard_settle_port<W>(k, complements, pid, x, xr, cs, qb, L);
