@@ -399,9 +399,10 @@ __device__ __forceinline__ void kc_port_search_generic(const SetView<W> &set, in
 // KC_NONE64; bit c of qb = the port that candidate is entered on.  Returns false when the window search cannot settle the port
 // (palindromic middle, local probe run exhausted): the caller then uses kc_port_search_generic, or hands the port on.
 //   LT: the home lies in block `sblk` whose tags are staged in LDS (stage_tags); SK: that block's keys are staged too.
-template <int W, bool LT, bool SK>
+//   LT == 2: decided per port -- a home in block `sblk` is read from the staged copies (through flat pointers), any other from the table
+template <int W, int LT, bool SK>
 __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, const u64 slot, int port,
-                                               const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, u64 (&cs)[4], u32 &qb) {
+                                               const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, u64 (&cs)[4], u32 &qb, const u64 sblk = ~(u64)0) {
     const u32 bmask = (1u << set.bshift) - 1u;
 #pragma unroll
     for (int c = 0; c < 4; ++c) cs[c] = KC_NONE64;
@@ -410,7 +411,9 @@ __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int
     if (!slow) {
         const u32 lo7 = 0x7f7f7f7fu, hi7 = 0x80808080u, gather = 0x204081u;
         const u32 pat4 = d.pat * 0x01010101u, msk4 = d.msk * 0x01010101u;
-        const u8 *tg = LT ? stage_tags + ((u32)d.home & bmask) : set.tags + d.home;
+        const bool staged = LT == 1 || (LT == 2 && (d.home >> set.bshift) == sblk);
+        const u8 *tg = staged ? stage_tags + ((u32)d.home & bmask) : set.tags + d.home;
+        const u64 *kb = (SK && staged) ? stage_keys : set.keys;
         u32 off = 0;
         while (true) {
             u64 wd;
@@ -433,9 +436,13 @@ __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int
                 const u64 sl = d.home + (u64)(off + j);
                 if (sl == slot) continue;                             // x itself (no self edges)
                 Key<W> kk;
-                if (LT && SK) {
+                if (LT == 1 && SK) {
 #pragma unroll
                     for (int w = 0; w < W; ++w) kk.w[w] = stage_keys[(size_t)((u32)sl & bmask) * W + w];
+                } else if (LT == 2 && SK) {
+                    const size_t ki = (size_t)(staged ? (u64)((u32)sl & bmask) : sl) * W;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) kk.w[w] = kb[ki + w];
                 } else kk = set_key_at(set, sl);
                 u32 c, q;
                 if (kc_neighbour_match(kk, x, xr, port, k, complements, c, q)) {
@@ -801,7 +808,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     extern __shared__ ulonglong2 kc_pb[];
     const int k = KC ? KC : k_rt;
     const int m = KC ? KC_MSPEC : set.m;
-    const u64 lblk = kc_xcd_block_id(xcd_aware);   // (SH: index among this rank's blocks)
+    const u64 lblk = kc_xcd_block_id(xcd_aware & 1);   // (SH: index among this rank's blocks)
     if (lblk >= (SH ? set.rcap >> set.bshift : set.nblocks)) return;
     const u64 blk = (SH ? set.rlo >> set.bshift : 0) + lblk;
     const u32 bs = 1u << set.bshift;
@@ -862,7 +869,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             remote = SH && d.home - set.rlo >= set.rcap;
             if (!remote) {
                 u64 cs[4]; u32 qb;
-                const bool ok = kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb);
+                const bool ok = kc_port_search<W, 2, SK>(set, k, complements, x, xr, slot, port, d, st, sk, cs, qb, (xcd_aware & 2) ? ~(u64)0 : blk);   // (bit 1: test knob, table reads only)
                 if (!ok) to_spill((slot << 1) | (u64)port);   // (rare: generic lookups in a kernel of their own keep this one lean)
                 else if (SH) {
                     // at most one candidate: the word; a branch port is settled (and lists its edges) in the spill kernel

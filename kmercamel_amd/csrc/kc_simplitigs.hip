@@ -655,7 +655,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), nt, lds);
                 fprintf(stderr, "[simp] probe kernel: %d threads, %zu bytes of LDS per workgroup, %d workgroups per CU\n", nt, lds, nb);
             }
-            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware, heads_sh, heads_shard_cap,
+            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware | (getenv("KC_PROBE_LISTED_GLOBAL") ? 2 : 0), heads_sh, heads_shard_cap,
                                heads_cursors, branch_sh, branch_shard_cap, branch_cursors, spill, spill_cap, spill_cursor, ShLists{});
             return KC_OK;
         };
