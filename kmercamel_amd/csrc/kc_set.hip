@@ -348,6 +348,20 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         }
         seg_pre[nseg] = a;
     }
+    // single-word keys of a plain bucket: the first four keys of every thread are on their way while the LDS table is set up
+    // (the block is otherwise one global latency after the other: counts, keys, then the stores)
+    const bool pf = W == 1 && nseg == 0 && !(fresh & 2);   // (bit 1 of `fresh`: test knob, no prefetch)
+    fresh &= 1;
+    u64 pre0 = 0, pre1 = 0, pre2 = 0, pre3 = 0;
+    if (pf) {
+        u64 n0 = bcursor[src_blk];
+        if (n0 > bs) n0 = bs;
+        const u64 *bk = bucket + base;
+        if (threadIdx.x < n0) pre0 = bk[threadIdx.x];
+        if (threadIdx.x + 1024u < n0) pre1 = bk[threadIdx.x + 1024u];
+        if (threadIdx.x + 2048u < n0) pre2 = bk[threadIdx.x + 2048u];
+        if (threadIdx.x + 3072u < n0) pre3 = bk[threadIdx.x + 3072u];
+    }
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
         reinterpret_cast<u64 *>(const_cast<u8 *>(lt))[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
     __syncthreads();
@@ -361,7 +375,8 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     if (nseg) n = seg_pre[nseg];
     else { n = bcursor[src_blk]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
     u32 added = 0;
-    for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
+    int it = 0;
+    for (u64 j = threadIdx.x; j < n; j += blockDim.x, ++it) {
         Key<W> key;
         u64 src = base + j;
         if (nseg) {
@@ -369,7 +384,9 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
             while (q + 1 < nseg && j >= seg_pre[q + 1]) ++q;
             src = seg_lo[q] + (j - seg_pre[q]);
         }
-        for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
+        if (pf && it < 4) key.w[0] = it == 0 ? pre0 : (it == 1 ? pre1 : (it == 2 ? pre2 : pre3));
+        else
+            for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
         const u64 top = key.w[W - 1];
         u32 off; u8 tag;
         set_place_local(set, key, &off, &tag);
@@ -688,7 +705,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
     set->unclean = false;                        // the build kernel writes every slot, state and tag of every block
     hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                       (const u64 *)bcursor, fresh, set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0);
+                       (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0);
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
