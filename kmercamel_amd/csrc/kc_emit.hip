@@ -111,25 +111,41 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
     bool rc = v >= S;
     u64 L = lens[sidx], wb = woff[sidx], n = weight[v];
     u64 upper_end = L - (u64)k;   // indices <= upper_end are k-mer starts of the simplitig
-    // every lane spells 8 consecutive characters per step (one 8-byte store); blockIdx.y splits long vertices (assembled
-    // genomes give simplitigs of Mbp) into interleaved 512-character slices
-    for (u64 t0 = ((u64)blockIdx.y * 64 + lane) * 8; t0 < n; t0 += (u64)gridDim.y * 512) {
-        u64 packed = 0;
-        const int cnt = (n - t0 >= 8) ? 8 : (int)(n - t0);
+    // every lane spells 32 consecutive characters per step -- one packed word forwards; backwards the 32 bases that end at L-1-t0,
+    // complemented and reversed as a word -- in four 8-byte stores; blockIdx.y splits long vertices (assembled genomes give
+    // simplitigs of Mbp) into interleaved 2048-character slices
+    for (u64 t0 = ((u64)blockIdx.y * 64 + lane) * 32; t0 < n; t0 += (u64)gridDim.y * 2048) {
+        const int cnt = (n - t0 >= 32) ? 32 : (int)(n - t0);
+        u64 w;   // the 32 bases in the order they are written, first one in the highest pair
+        if (!rc) w = words[wb + (t0 >> 5)];
+        else {
+            const u64 jh = L - 1 - t0;   // base of the first character; the window is [jh - 31, jh]
+            u64 X;
+            if (jh < 31) X = words[wb] >> (2 * (31 - jh));
+            else {
+                const u64 ws = jh - 31;
+                const int sh = (int)(ws & 31) * 2;
+                const u64 wa = words[wb + (ws >> 5)];
+                X = sh ? ((wa << sh) | (words[wb + (ws >> 5) + 1] >> (64 - sh))) : wa;
+            }
+            const u64 r = __brevll(~X);   // pairs reversed, but the two bits of each pair swapped: swap them back
+            w = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const u64 t = t0 + (u64)i;
-            if (i < cnt) {
-                u64 j = rc ? (L - 1 - t) : t;
-                u64 b = (words[wb + (j >> 5)] >> (62 - 2 * (j & 31))) & 3;
-                if (rc) b = 3 - b;
-                u64 c = (u64)(unsigned char)"ACGT"[b];
-                if (t > upper_end) c += (u64)('a' - 'A');
+        for (int g = 0; g < 4; ++g) {
+            if (8 * g >= cnt) break;
+            u64 packed = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u64 bse = (w >> (62 - 2 * (8 * g + i))) & 3;
+                u64 c = (0x54474341ull >> (8 * bse)) & 0xffull;   // "ACGT"
+                if (t0 + (u64)(8 * g + i) > upper_end) c += (u64)('a' - 'A');
                 packed |= c << (8 * i);
             }
+            const int m = cnt - 8 * g;
+            if (m >= 8) __builtin_memcpy(out + off + t0 + 8 * g, &packed, 8);
+            else for (int i = 0; i < m; ++i) out[off + t0 + (u64)(8 * g + i)] = (char)(packed >> (8 * i));
         }
-        if (cnt == 8) __builtin_memcpy(out + off + t0, &packed, 8);
-        else for (int i = 0; i < cnt; ++i) out[off + t0 + (u64)i] = (char)(packed >> (8 * i));
     }
 }
 
