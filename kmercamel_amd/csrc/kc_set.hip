@@ -306,6 +306,119 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
     if (overflow) atomicExch((ull *)&counters[3], 1ULL);
 }
 
+// ---- the same scatter, wave-cooperative (single-word keys, minimizer tables).  The rolling form above keeps two rings of
+// win = k - m - 1 hashes and the keys of the open run in LDS for every thread (176 B per thread: 3 waves per SIMD), rolls k - 1
+// warm-up bases per thread and waits for every reservation where it is issued.  Here a LANE IS A POSITION: lane i of a wave takes
+// the k-mer that ends at position p0 + i straight out of the packed sequence (two words and a funnel shift -- no rolling, no
+// warm-up), hashes the m-mer that ends there, and the minimizer of the k-mer's middle is a sliding minimum over the win lanes
+// before it: doubling steps with shuffles, the lanes below 0 come from the previous chunk's registers (a wave walks `chunks`
+// consecutive 64-position chunks, one extra in front for those).  Runs of equal blocks are found with a ballot; the first lane
+// of a run reserves for all of it, the others get the base by shuffle and store their own key.  No LDS at all.
+__device__ __forceinline__ u64 kc_extract_bases(const u64 *__restrict__ codes, u64 s, int nb) {   // the nb <= 32 bases from position s on, right-aligned
+    const u64 wi = s >> 5;
+    const int o = (int)(s & 31);
+    u64 v = codes[wi] << (2 * o);
+    if (o && 32 - o < nb) v |= codes[wi + 1] >> (64 - 2 * o);
+    return v >> (64 - 2 * nb);
+}
+__device__ __forceinline__ bool kc_any_break(const u64 *__restrict__ brk, u64 s, int nb) {         // a break bit among the nb <= 32 positions from s on
+    const u64 wi = s >> 6;
+    const int o = (int)(s & 63);
+    u64 b = brk[wi] >> o;
+    if (o + nb > 64) b |= brk[wi + 1] << (64 - o);
+    return (b & (((u64)1 << nb) - 1)) != 0;
+}
+__device__ __forceinline__ u32 kc_halo_get(u32 prev, u32 cur, int idx) {   // value of lane idx of this chunk, or of lane 64 + idx of the previous one
+    const u32 a = __shfl(cur, idx & 63, 64), b = __shfl(prev, idx & 63, 64);
+    return idx >= 0 ? a : b;
+}
+__global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
+                                                                     int complements, int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters,
+                                                                     int chunks) {
+    const int lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 P0 = wave * (u64)chunks * 64;
+    if (P0 >= len) return;
+    const int m = set.m, win = k - m - 1;
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const u64 bs = (u64)1 << set.bshift;
+    u32 a1p = ~0u, a2p = ~0u, a4p = ~0u, a8p = ~0u;
+    bool overflow = false;
+    struct Chunk { bool valid, starts; u64 key, blk; unsigned long long vm, sm; };
+    // one chunk: this lane's k-mer and block, the wave's run structure (c = -1: only the hashes, for the halo of chunk 0)
+    auto compute = [&](int c) -> Chunk {
+        Chunk R{false, false, 0, ~(u64)0, 0, 0};
+        const long long pp = (long long)P0 + 64LL * c + lane;
+        const bool inr = pp >= 0 && (u64)pp < len;
+        const u64 p = inr ? (u64)pp : 0;
+        // canonical hash of the m-mer that ends here (all ones: none)
+        u32 h = ~0u;
+        if (inr && p + 1 >= (u64)m && !kc_any_break(brk, p + 1 - (u64)m, m)) {
+            const u32 mm = (u32)kc_extract_bases(codes, p + 1 - (u64)m, m);
+            u32 r = __brev(~mm);
+            r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+            r >>= 32 - 2 * m;
+            h = kc_mmer_hash(mm & maskm, r);
+        }
+        // the k-mer that ends here
+        if (c >= 0 && inr && p + 1 >= (u64)k && !kc_any_break(brk, p + 1 - (u64)k, k)) {
+            const u64 fp = p + 1 - (u64)k;
+            R.valid = !case_sensitive || !((low[fp >> 6] >> (fp & 63)) & 1);
+            if (R.valid) {
+                Key<1> f; f.w[0] = kc_extract_bases(codes, fp, k);
+                R.key = f.w[0];
+                if (complements) { const Key<1> r = key_rc(f, k); if (r.w[0] < R.key) R.key = r.w[0]; }
+            }
+        }
+        // sliding minimum over the win lanes before this one
+        const u32 a1 = h;
+        u32 t = kc_halo_get(a1p, a1, lane - 1); const u32 a2 = a1 < t ? a1 : t;
+        t = kc_halo_get(a2p, a2, lane - 2); const u32 a4 = a2 < t ? a2 : t;
+        t = kc_halo_get(a4p, a4, lane - 4); const u32 a8 = a4 < t ? a4 : t;
+        u32 pm = ~0u;
+        int at = lane - 1;
+        if (win & 8) { t = kc_halo_get(a8p, a8, at); pm = t < pm ? t : pm; at -= 8; }
+        if (win & 4) { t = kc_halo_get(a4p, a4, at); pm = t < pm ? t : pm; at -= 4; }
+        if (win & 2) { t = kc_halo_get(a2p, a2, at); pm = t < pm ? t : pm; at -= 2; }
+        if (win & 1) { t = kc_halo_get(a1p, a1, at); pm = t < pm ? t : pm; }
+        a1p = a1; a2p = a2; a4p = a4; a8p = a8;
+        // runs of equal blocks among the valid lanes
+        R.blk = R.valid ? set_block_home(set, pm, 0) >> set.bshift : ~(u64)0;
+        const u64 blk_before = __shfl_up(R.blk, 1, 64);
+        R.starts = R.valid && (lane == 0 || blk_before != R.blk);
+        R.vm = __ballot(R.valid); R.sm = __ballot(R.starts);
+        return R;
+    };
+    // the first lane of a run reserves for all of it ...
+    auto reserve = [&](const Chunk &R) -> u64 {
+        if (!R.starts) return 0;
+        const unsigned long long stop = (R.sm | ~R.vm) >> lane >> 1;   // the run ends before the next start or invalid lane (two shifts: lane 63 shifts by 64 in all)
+        const int rl = stop ? __builtin_ctzll(stop) + 1 : 64 - lane;
+        return atomicAdd((ull *)&bcursor[R.blk], (ull)rl);
+    };
+    // ... the others get the base by shuffle and store their own key
+    auto commit = [&](const Chunk &R, u64 base) {
+        const unsigned long long below = R.sm & (((unsigned long long)2 << lane) - 1);   // the starts at or below this lane
+        const int leader = below ? 63 - __builtin_clzll(below) : 0;
+        base = __shfl(base, leader, 64);
+        if (R.valid) {
+            const u64 at2 = base + (u64)(lane - leader);
+            if (at2 < bs) bucket[(R.blk << set.bshift) + at2] = R.key;
+            else overflow = true;   // (the bucket keeps the keys that still fit; the caller re-inserts through the global path)
+        }
+    };
+    (void)compute(-1);
+    // two chunks per trip: both reservations are in flight before either is waited for
+    for (int c = 0; c < chunks; c += 2) {
+        if (P0 + 64ULL * (u64)c >= len) break;   // (wave-uniform)
+        const Chunk A = compute(c), B = compute(c + 1);
+        const u64 ba = reserve(A), bb = reserve(B);
+        commit(A, ba);
+        commit(B, bb);
+    }
+    if (overflow) atomicExch((ull *)&counters[3], 1ULL);
+}
+
 // one workgroup per table block; dynamic LDS: (1 << bshift) keys of W words + (1 << bshift) tag bytes.  A slot is claimed
 // by an LDS compare-and-swap on its MOST significant key word (never all ones: 2k < 64 W), then the other words and
 // finally the tag byte are written; a lane that finds "its" top word in an unpublished slot looks again in its next loop
@@ -660,8 +773,21 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     // (set on every call: the attribute belongs to the current device's copy of the kernel, and the call is cheap)
     if (lds_scatter > 64 * 1024)
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bucket_scatter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
-    hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
-                       set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
+    bool wave_form = false;
+    if constexpr (W == 1) {
+        // the wave-cooperative form (kc_bucket_scatter_wave_kernel): single-word keys on a minimizer table; KC_SCATTER_ROLL=1 keeps the rolling form
+        wave_form = set->mlen && set->mlen <= 16 && set->k - set->mlen - 1 >= 1 && set->k - set->mlen - 1 <= 15 && !getenv("KC_SCATTER_ROLL");
+        if (wave_form) {
+            int chunks = 16;   // (even)
+            if (const char *e = getenv("KC_SCATTER_CHUNKS")) { const int v = atoi(e); if (v >= 2 && v <= 4096) chunks = v & ~1; }   // tuning knob
+            const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+            hipLaunchKernelGGL(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks);
+        }
+    }
+    if (!wave_form)
+        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
+                           set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
     const size_t lds_build = (size_t)bs * (8 * W + 1);
     KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
     const int fresh = set->size_host == 0 ? 1 : 0;
@@ -858,8 +984,19 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     }
     if (one_pass) {
         KC_TRY(scope.alloc(&fixed, nblocks * bs * W));
-        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
-                           set->complements, 0, kc_view_raw<W>(set), fixed, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
+        bool wave_form = false;
+        if constexpr (W == 1) {   // (as in insert_bucketed_w)
+            wave_form = set->mlen && set->mlen <= 16 && set->k - set->mlen - 1 >= 1 && set->k - set->mlen - 1 <= 15 && !getenv("KC_SCATTER_ROLL");
+            if (wave_form) {
+                const int chunks = 16;
+                const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+                hipLaunchKernelGGL(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+                                   0, kc_view_raw<1>(set), fixed, bcount, set->counters, chunks);
+            }
+        }
+        if (!wave_form)
+            hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                               set->complements, 0, kc_view_raw<W>(set), fixed, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
         u64 hovf = 0;
         KC_HIP(ctx, hipMemcpyAsync(&hovf, set->counters + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
