@@ -139,13 +139,16 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [{"KC_BUCKET_MIN": "0"}, {"KC_BUCKET_MIN": "1000000000"}, {"KC_NOREC": "1"}, {"KC_NOSTAGE": "1"},
-                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_NOFRAG": "1"}, {"KC_CHAIN_LIMIT": "600"}],
+                                   {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_NOFRAG": "1"}, {"KC_CHAIN_LIMIT": "600"},
+                                   {"KC_BUCKET_MIN": "0", "KC_SCATTER_ROLL": "1"}, {"KC_BUCKET_MIN": "0", "KC_PROBE_LISTED_GLOBAL": "1"},
+                                   {"KC_BUCKET_MIN": "0", "KC_BUILD_NOPREFETCH": "1", "KC_SCATTER_CHUNKS": "2"}],
                          ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "plain-walk",
-                              "fragment-contraction-then-restore"])
+                              "fragment-contraction-then-restore", "rolling-scatter", "listed-ports-from-the-table", "no-build-prefetch"])
 def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
     """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
-    walk, LDS tag staging) must give the same set and the same simplitigs; KC_LOCAL_PROBES=2 makes block-local probe runs
-    overflow, so the spill list + global second home of the bucketed build are exercised too."""
+    walk, LDS tag staging; the wave-cooperative bucket scatter -- default with KC_BUCKET_MIN=0 for single-word keys on minimizer
+    tables -- against the rolling one) must give the same set and the same simplitigs; KC_LOCAL_PROBES=2 makes block-local probe
+    runs overflow, so the spill list + global second home of the bucketed build are exercised too."""
     for name, value in knobs.items():
         monkeypatch.setenv(name, value)
     rng = random.Random(4242)
@@ -172,6 +175,35 @@ def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, mon
                 assert sim.strings() == want
                 sim.close()
             s1.close(); s2.close()
+
+
+@pytest.mark.parametrize("roll", [False, True], ids=["wave-scatter", "rolling-scatter"])
+def test_bucket_scatter_edge_cases(ctx, oracle, roll, monkeypatch):
+    """The two bucket scatter kernels (kc_bucket_scatter_wave_kernel: a lane is a position; kc_bucket_scatter_kernel: a thread rolls
+    a stretch) on what their position arithmetic has to get right: records shorter than k and of exactly k, N and lower case
+    anywhere (case-sensitive inserts: the first base decides, parser.h:41-42), lengths around the 64-position chunks and the 16-chunk
+    stretches of a wave, every single-word k with a minimizer table."""
+    monkeypatch.setenv("KC_BUCKET_MIN", "0")
+    if roll:
+        monkeypatch.setenv("KC_SCATTER_ROLL", "1")
+    rng = random.Random(99)
+    for k in (18, 19, 24, 31, 32):
+        for total in (k, 63, 64, 65, 1023, 1024, 1025, 1024 + k, 5000, 70000):
+            recs, n = [], 0
+            while n < total:
+                ln = rng.choice([1, k - 1, k, k + 1, 2 * k, 100, 333]) if rng.random() < 0.7 else rng.randint(1, 2000)
+                ln = min(ln, total - n)
+                alphabet = rng.choice(["ACGT", "ACGTN", "ACGTacgt", "ACGTacgtN"])
+                recs.append("".join(rng.choice(alphabet) for _ in range(ln)))
+                n += ln + 1
+            seq = "\n".join(recs)
+            for complements in (True, False):
+                for cs in (False, True):
+                    want = sorted(oracle.kmer_set(seq.replace("\n", "N"), k, complements, case_sensitive=cs))
+                    s1 = kc.KmerSet(ctx, k, complements, capacity_hint=len(seq))
+                    s1.AddKMers(seq, case_sensitive=cs)
+                    assert sorted(s1.keys()) == want, (k, total, complements, cs)
+                    s1.close()
 
 
 @pytest.mark.parametrize("k", [21, 31, 63, 127])
