@@ -419,6 +419,102 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
     if (overflow) atomicExch((ull *)&counters[3], 1ULL);
 }
 
+// The same for wide keys (k up to 127: the window of the sliding minimum has up to k - 17 = 110 positions, i.e. it reaches two
+// chunks back; the rolling form keeps 2 * 110 hashes per thread in LDS there and runs 64 threads per workgroup).
+__device__ __forceinline__ bool kc_any_break_long(const u64 *__restrict__ brk, u64 s, int n) {
+    bool any = false;
+    for (int o = 0; o < n; o += 32) any = any || kc_any_break(brk, s + (u64)o, n - o < 32 ? n - o : 32);
+    return any;
+}
+__device__ __forceinline__ u32 kc_halo_get3(u32 p2, u32 p1, u32 cur, int idx) {   // lane idx of this chunk (idx >= 0), of the previous one (>= -64), of the one before
+    const u32 a = __shfl(cur, idx & 63, 64), b = __shfl(p1, idx & 63, 64), c = __shfl(p2, idx & 63, 64);
+    return idx >= 0 ? a : (idx >= -64 ? b : c);
+}
+template <int W>
+__global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
+                                                                          int complements, int case_sensitive, SetView<W> set, u64 *bucket, u64 *bcursor, u64 *counters,
+                                                                          int chunks) {
+    const int lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u64 P0 = wave * (u64)chunks * 64;
+    if (P0 >= len) return;
+    const int m = set.m, win = k - m - 1;
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const u64 bs = (u64)1 << set.bshift;
+    // A[j]: minimum over the 2^j hashes that end at this lane; p1 / p2: the same one / two chunks back
+    u32 A[7], p1[7], p2[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { p1[j] = ~0u; p2[j] = ~0u; }
+    bool overflow = false;
+    for (int c = -2; c < chunks; ++c) {
+        const long long pp = (long long)P0 + 64LL * c + lane;
+        const bool inr = pp >= 0 && (u64)pp < len;
+        const u64 p = inr ? (u64)pp : 0;
+        if (c >= 0 && P0 + 64ULL * (u64)c >= len) break;   // (wave-uniform)
+        u32 h = ~0u;
+        if (inr && p + 1 >= (u64)m && !kc_any_break(brk, p + 1 - (u64)m, m)) {
+            const u32 mm = (u32)kc_extract_bases(codes, p + 1 - (u64)m, m);
+            u32 r = __brev(~mm);
+            r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+            r >>= 32 - 2 * m;
+            h = kc_mmer_hash(mm & maskm, r);
+        }
+        bool valid = false;
+        Key<W> key = key_zero<W>();
+        if (c >= 0 && inr && p + 1 >= (u64)k && !kc_any_break_long(brk, p + 1 - (u64)k, k)) {
+            const u64 fp = p + 1 - (u64)k;
+            valid = !case_sensitive || !((low[fp >> 6] >> (fp & 63)) & 1);
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) {   // word j: the bases 32 j ... 32 j + 31 counted from the END of the k-mer
+                    const int nb = k - 32 * j >= 32 ? 32 : k - 32 * j;
+                    key.w[j] = nb > 0 ? kc_extract_bases(codes, p + 1 - (u64)(32 * j) - (u64)nb, nb) : 0;
+                }
+                if (complements) { const Key<W> r = key_rc(key, k); if (key_lt(r, key)) key = r; }
+            }
+        }
+        A[0] = h;
+#pragma unroll
+        for (int j = 1; j < 7; ++j) {
+            const int d = 1 << (j - 1);
+            const u32 a = __shfl(A[j - 1], (lane - d) & 63, 64), b = __shfl(p1[j - 1], (lane - d) & 63, 64);
+            const u32 t = lane - d >= 0 ? a : b;
+            A[j] = A[j - 1] < t ? A[j - 1] : t;
+        }
+        u32 pm = ~0u;
+        int at = lane - 1;
+#pragma unroll
+        for (int j = 6; j >= 0; --j)
+            if (win & (1 << j)) { const u32 t = kc_halo_get3(p2[j], p1[j], A[j], at); pm = t < pm ? t : pm; at -= 1 << j; }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) { p2[j] = p1[j]; p1[j] = A[j]; }
+        if (c < 0) continue;
+        const u64 blk = valid ? set_block_home(set, pm, 0) >> set.bshift : ~(u64)0;
+        const u64 blk_before = __shfl_up(blk, 1, 64);
+        const bool starts = valid && (lane == 0 || blk_before != blk);
+        const unsigned long long vm = __ballot(valid), sm = __ballot(starts);
+        if (!vm) continue;
+        u64 base = 0;
+        if (starts) {
+            const unsigned long long stop = (sm | ~vm) >> lane >> 1;
+            const int rl = stop ? __builtin_ctzll(stop) + 1 : 64 - lane;
+            base = atomicAdd((ull *)&bcursor[blk], (ull)rl);
+        }
+        const unsigned long long below = sm & (((unsigned long long)2 << lane) - 1);
+        const int leader = below ? 63 - __builtin_clzll(below) : 0;
+        base = __shfl(base, leader, 64);
+        if (valid) {
+            const u64 at2 = base + (u64)(lane - leader);
+            if (at2 < bs) {
+                u64 *dst = bucket + ((blk << set.bshift) + at2) * W;
+#pragma unroll
+                for (int w = 0; w < W; ++w) dst[w] = key.w[w];
+            } else overflow = true;
+        }
+    }
+    if (overflow) atomicExch((ull *)&counters[3], 1ULL);
+}
+
 // one workgroup per table block; dynamic LDS: (1 << bshift) keys of W words + (1 << bshift) tag bytes.  A slot is claimed
 // by an LDS compare-and-swap on its MOST significant key word (never all ones: 2k < 64 W), then the other words and
 // finally the tag byte are written; a lane that finds "its" top word in an unpublished slot looks again in its next loop
@@ -785,6 +881,15 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
                                case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks);
         }
     }
+    if constexpr (W > 1) {
+        wave_form = set->mlen && set->mlen <= 16 && set->k - set->mlen - 1 >= 1 && set->k - set->mlen - 1 <= 127 && !getenv("KC_SCATTER_ROLL");
+        if (wave_form) {
+            const int chunks = 16;
+            const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+            hipLaunchKernelGGL(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                               set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, chunks);
+        }
+    }
     if (!wave_form)
         hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
                            set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
@@ -992,6 +1097,15 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
                 const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
                 hipLaunchKernelGGL(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
                                    0, kc_view_raw<1>(set), fixed, bcount, set->counters, chunks);
+            }
+        }
+        if constexpr (W > 1) {
+            wave_form = set->mlen && set->mlen <= 16 && set->k - set->mlen - 1 >= 1 && set->k - set->mlen - 1 <= 127 && !getenv("KC_SCATTER_ROLL");
+            if (wave_form) {
+                const int chunks = 16;
+                const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+                hipLaunchKernelGGL(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                                   set->complements, 0, kc_view_raw<W>(set), fixed, bcount, set->counters, chunks);
             }
         }
         if (!wave_form)

@@ -182,12 +182,12 @@ def test_bucket_scatter_edge_cases(ctx, oracle, roll, monkeypatch):
     """The two bucket scatter kernels (kc_bucket_scatter_wave_kernel: a lane is a position; kc_bucket_scatter_kernel: a thread rolls
     a stretch) on what their position arithmetic has to get right: records shorter than k and of exactly k, N and lower case
     anywhere (case-sensitive inserts: the first base decides, parser.h:41-42), lengths around the 64-position chunks and the 16-chunk
-    stretches of a wave, every single-word k with a minimizer table."""
+    stretches of a wave, single-word and wide keys with a minimizer table."""
     monkeypatch.setenv("KC_BUCKET_MIN", "0")
     if roll:
         monkeypatch.setenv("KC_SCATTER_ROLL", "1")
     rng = random.Random(99)
-    for k in (18, 19, 24, 31, 32):
+    for k in (18, 19, 24, 31, 32, 33, 47, 63, 64, 65, 100, 127):   # (wide keys: kc_bucket_scatter_wave_wide_kernel, windows of up to 110 positions)
         for total in (k, 63, 64, 65, 1023, 1024, 1025, 1024 + k, 5000, 70000):
             recs, n = [], 0
             while n < total:
