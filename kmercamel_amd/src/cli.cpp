@@ -126,6 +126,7 @@ static void write_all(int fd, const char *data, size_t n) {
 // beyond the number of devices share them round robin), each with its own context and a communicator of the in-process
 // thread transport; the records are cut into N contiguous parts, kc_compute_sharded builds ONE masked superstring --
 // byte-identical to the single-GPU result -- and every rank copies its slice into place.
+static const int KC_CLI_SHARDED_FALLBACK = -1000;
 static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus) {
     WriteLog("Started computation of a masked superstring from '" + path + "'.");
     Records recs = load_records(path, false);
@@ -161,7 +162,9 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0), &res[r]);
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
-        if (rc != KC_OK && rc != KC_E_NO_KMERS) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
+        // S >= N / 5 (main.cpp:175, the sparse branch): every rank learns it from the same replicated simplitig list and returns together
+        const bool sparse_case = rc == KC_E_ARG && err[r].find("sparse branch") != std::string::npos;
+        if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
         if (rc == KC_OK) {
             if (r == 0) {
                 kc_result_stats(res[0], st.data());
@@ -188,6 +191,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
         return usage_subcommand("compute");
     }
+    if (rcs[0] == KC_E_ARG) return KC_CLI_SHARDED_FALLBACK;   // (the sparse branch: the caller runs the input on one GPU)
     WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
@@ -202,12 +206,18 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
 
 int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
                 int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1) {
+    bool started_logged = false;
     if (gpus > 1) {
         // what the hash-sharded path does not cover runs on one GPU, as without the option
-        if (!lower_bound && !assume_simplitigs && min_frequency == 1 && k >= 18) return run_compute_sharded(path, k, of, maskf, complements, gpus);
-        std::cerr << "Note: --gpus applies to `compute -k K [-M F]` with K >= 18 (no -S, -z); running on one GPU." << std::endl;
+        if (!lower_bound && !assume_simplitigs && min_frequency == 1 && k >= 18) {
+            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus);
+            if (rc != KC_CLI_SHARDED_FALLBACK) return rc;
+            std::cerr << "Note: too many simplitigs for the dense overlap graph (main.cpp:175); the sparse branch runs on one GPU." << std::endl;
+            started_logged = true;
+        } else std::cerr << "Note: --gpus applies to `compute -k K [-M F]` with K >= 18 (no -S, -z); running on one GPU." << std::endl;
     }
-    if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
+    if (started_logged) { /* run_compute_sharded has logged the start */ }
+    else if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
     else WriteLog("Started computation of a masked superstring length lower bound from '" + path + "'.");
     const bool trace = std::getenv("KC_CLI_TRACE") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();

@@ -265,4 +265,13 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
     # -z / -S / small k: one GPU, with a note
     p = run("compute", "-k", "23", "-z", "2", "--gpus", "2", br)   # (overlapping reads: k-mers that occur twice exist)
     assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "23", "-z", "2", br).stdout
+    # an input whose simplitigs are too many for the dense overlap graph (S >= N / 5, main.cpp:175): the ranks find out together
+    # after phase 1 and the CLI runs the sparse branch on one GPU
+    sp = str(tmp_path / "sparse.fa")
+    with open(sp, "wb") as f:
+        for i, r in enumerate(gen.random_records(4000, 33, seed=5)):   # 3 k-mers per record at k = 31
+            f.write(b">s%d\n%s\n" % (i, r))
+    p = run("compute", "-k", "31", "--gpus", "2", sp)
+    assert p.returncode == 0 and "sparse branch runs on one GPU" in p.stderr, p.stderr[-500:]
+    assert p.stdout == run("compute", "-k", "31", sp).stdout
     assert run("compute", "-k", "31", "--gpus", "0", fa).returncode == 1
