@@ -869,7 +869,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KcFrag fr{nullptr, nullptr, 0, 0};
             bool have_entries = false;
             if (frag_ok && !contracted && bpr_blocks) {
-                const u64 pool_cap = (N_local / 16 + 65536) / 64 * 64, log_cap = (N_local / 3 + 65536) / 64 * 64, ecap = N_local / 2 + 65536;
+                const u64 pool_cap = (rcap / 16 + 65536) / 64 * 64, log_cap = (rcap / 6 + 65536) / 64 * 64, ecap = N_local / 2 + 65536;   // (per-block shares, as on one GPU)
                 KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, bpr_blocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16 + 16));
                 KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, bpr_blocks));
                 KC_TRY(scope.alloc(&entries, ecap + 1));
@@ -880,11 +880,11 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                                    log_cap, fcur + 64 * 16, fblog, entries, ecap, fcur + 2 * 64 * 16);
                 KC_HIP(ctx, hipGetLastError());
                 contracted = true;
-                fr = KcFrag{fpool, fbase, pool_cap / 64, rlo >> set->bshift};
+                fr = KcFrag{fpool, fbase, 0, rlo >> set->bshift};
                 KC_TRY(read_words(ctx, fcur + 2 * 64 * 16, &n_ent, 1));
                 have_entries = n_ent <= ecap;
                 if (!have_entries) scope.release(entries);
-            } else if (contracted) fr = KcFrag{fpool, fbase, ((N_local / 16 + 65536) / 64 * 64) / 64, rlo >> set->bshift};
+            } else if (contracted) fr = KcFrag{fpool, fbase, 0, rlo >> set->bshift};
             if (!have_entries) {
                 const u64 ntiles = (rcap + 2047) / 2048;
                 u64 *tcount = nullptr;

@@ -1259,8 +1259,6 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     // (76 KB for 8192-slot blocks: two workgroups share a CU.)
     extern __shared__ u32 kc_fl[];
     __shared__ u32 n_long, n_words, n_ent;
-    __shared__ u64 pbase, lbase;
-    __shared__ int log_ok;
     const u32 bs = 1u << set.bshift;
     const u64 blk = (set.rlo >> set.bshift) + blockIdx.x;   // (hash-sharded tables: the blocks of this rank; pool / log arrays are indexed by the LOCAL block)
     const u64 base = blk << set.bshift;
@@ -1280,8 +1278,11 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         for (int p = 0; p < 2; ++p) {
             const u64 w = w2[p];
             const bool in = occ && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
+            // (bits 17-18: state MATCHED rather than CHOICE, splitter flag -- with them the word of an in-block link can be rebuilt
+            // exactly from the digest, so the log below needs no second, scattered read of the link array)
             kc_fl[2 * s + p] = (occ ? 0x40000000u : 0u) |
-                               (in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15)) : 0u);
+                               (in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15) |
+                                      (LK_STATE(w) == LK_MATCHED ? 1u << 17 : 0u) | ((w & LK_SPLIT) ? 1u << 18 : 0u)) : 0u);
             if (ent_out && occ && (p == 0 || complements) && step < 16 &&
                 (LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - set.rlo >= set.rcap)))
                 emask |= 1u << (2 * step + p);
@@ -1352,14 +1353,12 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     const u32 ne = n_ent < fe_cap ? n_ent : fe_cap;
     // every word about to be replaced is logged first (kc_frag_restore_kernel puts it back if the hop walk has to be abandoned):
     // the original word with the local port id in its unused bits 46-59.  No log space: the block keeps its plain links.
-    if (threadIdx.x == 0) {
-        const u64 lshard = log_cap / 64;
-        const u64 b = ne ? atomicAdd((ull *)&log_cursors[(blockIdx.x & 63) * 16], (ull)ne) : 0;
-        log_ok = b + ne <= lshard;
-        lbase = (u64)(blockIdx.x & 63) * lshard + b;
-        blk_log[lblk] = log_ok ? ((lbase << 16) | (u64)ne) : 0;
-    }
-    __syncthreads();
+    // (every block owns log_cap / gridDim.x log entries and pool_cap / gridDim.x pool words: a reservation from shared cursors
+    // was a global atomic round trip that the whole workgroup waited for, twice per block)
+    const u64 lcap_blk = log_cap / gridDim.x;
+    const bool log_ok = ne <= lcap_blk;
+    const u64 lbase = lblk * lcap_blk;
+    if (threadIdx.x == 0) blk_log[lblk] = log_ok ? ((lbase << 16) | (u64)ne) : 0;
     if (!log_ok) return;
     for (u32 e = threadIdx.x; e < ne; e += blockDim.x) {
         const u32 s = ents[e] >> 1;
@@ -1367,7 +1366,11 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         u32 far, len; int fo; u64 bases;
         walk(s, o, far, fo, len, bases, nullptr, false);
         const u32 xp = o == 0 ? 1u : 0u;
-        log[lbase + e] = link[(base + s) * 2 + xp] | ((u64)(2 * s + xp) << 46);
+        {
+            const u32 dg = kc_fl[2 * s + xp];   // (in-block by construction: the run continues through this port)
+            const u64 orig = LK_MAKE((dg >> 17) & 1u ? LK_MATCHED : LK_CHOICE, (dg >> 14) & 1u, (dg >> 15) & 3u, base + (u64)(dg & 0x3fffu)) | ((dg >> 18) & 1u ? LK_SPLIT : 0ull);
+            log[lbase + e] = orig | ((u64)(2 * s + xp) << 46);
+        }
         // runs of up to 8 nodes whose far end is matched onwards also carry that onward link (the walk then skips the far end's
         // line altogether): bit 3 set, bits 6-41 next slot, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
         // inside the run, bits 48-61 those bases
@@ -1387,20 +1390,15 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     }
     __syncthreads();
     if (n_long == 0) return;
-    if (threadIdx.x == 0) {
-        pbase = atomicAdd((ull *)&pool_cursors[(blockIdx.x & 63) * 16], (ull)n_words);
-        blk_pool_base[lblk] = pbase;
-    }
-    __syncthreads();
-    // pool shard s owns the words [s * pool_cap / 64, (s + 1) * pool_cap / 64)
-    const u64 shard_cap = pool_cap / 64, shard_lo = (u64)(blockIdx.x & 63) * shard_cap;
-    if (pbase + n_words > shard_cap) return;   // no pool space: the long runs of this block keep their plain links
+    const u64 pcap_blk = pool_cap / gridDim.x, pbase = lblk * pcap_blk;   // (absolute: KcFrag::shard_cap is 0)
+    if (threadIdx.x == 0) blk_pool_base[lblk] = pbase;
+    if (n_words > pcap_blk) return;   // no pool space: the long runs of this block keep their plain links
     const u32 nl = n_long < long_cap ? n_long : long_cap;
     for (u32 i = threadIdx.x; i < nl; i += blockDim.x) {
         const u32 pid = longs[2 * i], rel = longs[2 * i + 1];
         const u32 s = pid >> 1; const int o = (int)(pid & 1);
         u32 far, len; int fo; u64 bases;
-        walk(s, o, far, fo, len, bases, pool + shard_lo + pbase + rel, true);
+        walk(s, o, far, fo, len, bases, pool + pbase + rel, true);
         const u32 xp = o == 0 ? 1u : 0u;
         link[(base + s) * 2 + xp] = LK_REJ | KC_SC_EXT | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | ((u64)rel << 35);
     }

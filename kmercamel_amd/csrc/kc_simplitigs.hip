@@ -783,8 +783,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                         2 * N / nheads <= KC_CHAIN_LIMIT / 2;
         if (use_frag) {
             u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr, *flog = nullptr, *fblog = nullptr;
-            const u64 pool_cap = (N / 16 + 65536) / 64 * 64;
-            const u64 log_cap = (N / 3 + 65536) / 64 * 64;     // two ends per in-block run, ~N/10 runs
+            // per block (the kernel divides both evenly): 1/6 slot of log entries -- two ends per in-block run, ~1 run per 9 k-mers -- and
+            // 1/16 slot of pool words (runs beyond 19 nodes: ~100 per block of 8192 slots, one or two words each)
+            const u64 pool_cap = (cap / 16 + 65536) / 64 * 64;
+            const u64 log_cap = (cap / 6 + 65536) / 64 * 64;
             KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, set->nblocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16));
             KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, set->nblocks));
             KC_HIP(ctx, hipMemsetAsync(fcur, 0, 2 * 64 * 16 * 8, ctx->stream));
@@ -792,7 +794,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
                                flog, log_cap, fcur + 64 * 16, fblog);
-            const KcFrag fr{fpool, fbase, pool_cap / 64, 0};
+            const KcFrag fr{fpool, fbase, 0, 0};
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                KC_CHAIN_LIMIT, rec, fr);
