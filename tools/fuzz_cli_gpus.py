@@ -10,8 +10,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fuzz_parity
 BIN = os.path.join(ROOT, "kmercamel_amd", "bin", "kmercamel")
 
-def run(args, timeout=120):
-    p = subprocess.run([BIN] + args, capture_output=True, timeout=timeout)
+def run(args, timeout=120, env=None):
+    p = subprocess.run([BIN] + args, capture_output=True, timeout=timeout, env=env)
     return p.returncode, p.stdout, p.stderr
 
 def main():
@@ -40,20 +40,28 @@ def main():
             gpus = rng.choice([2, 2, 3, 4])
             base = ["compute", "-k", str(k)] + (["-u"] if uni else [])
             outs = []
+            # the alternative paths of the sharded flow, now and then: pointer jumping instead of waves (or waves cut short), plain
+            # walks, the two-pass bucket layout, replicated phase 2, the rolling scatter
+            knobs = {}
+            if rng.random() < 0.3: knobs["KC_WAVE_MAX"] = rng.choice(["0", "4", "64"])
+            if rng.random() < 0.15: knobs["KC_NOFRAG"] = "1"
+            if rng.random() < 0.15: knobs["KC_SHARD_TWO_PASS"] = "1"
+            if rng.random() < 0.15: knobs["KC_SHARD_REPLICATE_PHASE2"] = "1"
+            if rng.random() < 0.15: knobs["KC_SCATTER_ROLL"] = "1"
             for extra in ([], ["--gpus", str(gpus)]):
                 o = os.path.join(d, "o%d" % len(outs)); m = os.path.join(d, "m%d" % len(outs))
                 for f in (o, m):
                     if os.path.exists(f): os.remove(f)
-                rc, so, se = run(base + extra + ["-o", o] + (["-M", m] if mask else []) + [fa])
+                rc, so, se = run(base + extra + ["-o", o] + (["-M", m] if mask else []) + [fa], env=dict(os.environ, **knobs) if extra else None)
                 if rc != 0 and b"contains no k-mers" not in se:
-                    print("FAILED rc", rc, base + extra, se[-2000:].decode(errors="replace")); print("seed", seed, "case", n, shape, k); sys.exit(1)
+                    print("FAILED rc", rc, base + extra, knobs, se[-2000:].decode(errors="replace")); print("seed", seed, "case", n, shape, k); sys.exit(1)
                 # (an input without k-mers ends both runs with the usage text and the same exit code)
                 outs.append((rc, open(o, "rb").read() if rc == 0 else b"", open(m, "rb").read() if mask and rc == 0 else b""))
             if outs[0] != outs[1]:
                 keep = os.path.join(ROOT, "gpurun_out", "fuzz_cli_fail.fa")
                 os.makedirs(os.path.dirname(keep), exist_ok=True)
                 open(keep, "w").write(open(fa).read())
-                print("MISMATCH seed", seed, "case", n, shape, "k", k, "gpus", gpus, "uni", uni, "mask", mask, "input kept in", keep); sys.exit(1)
+                print("MISMATCH seed", seed, "case", n, shape, "k", k, "gpus", gpus, "uni", uni, "mask", mask, "knobs", knobs, "input kept in", keep); sys.exit(1)
             n += 1; shapes[shape] = shapes.get(shape, 0) + 1
     print("cli --gpus fuzz ok: %d cases in %.0f s, seed %d, shapes %s" % (n, time.time() - t0, seed, shapes))
 
