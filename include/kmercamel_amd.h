@@ -164,8 +164,11 @@ int kc_comm_stats(kc_comm *comm, uint64_t *stats);
 int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, uint64_t *out6);
 int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner);
 /* The greedy branch of kmercamel<>() over all ranks' records: `seq`/`len` are THIS rank's records (joined by '\n', may be
- * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE, KC_FLAG_WANT_MASK (k >= 18; -S and
- * -z go through the single-GPU kc_compute).  The result holds this rank's slice; stats as kc_result_stats with global counts. */
+ * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE, KC_FLAG_WANT_MASK, KC_FLAG_MIN_FREQUENCY
+ * (k >= 18; -S goes through the single-GPU kc_compute).  KC_E_ARG with a message ending in "not part of the hash-sharded path" is
+ * returned by ALL ranks together for inputs the path does not cover (the sparse branch, main.cpp:175; -z with overflowing table
+ * blocks): the caller then runs kc_compute on one GPU.  The result holds this rank's slice; stats as kc_result_stats with global
+ * counts. */
 int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out);
 /* position and size of this rank's slice inside the superstring (offset 0 / whole length for kc_compute results);
  * kc_result_device_ptrs / kc_result_copy address the slice */

@@ -632,10 +632,10 @@ class Comm:
             self.h = None
 
 
-def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length=None, want_mask=False):
+def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length=None, want_mask=False, min_frequency=1):
     """kc_compute_sharded: collective over comm's ranks; `seq` = THIS rank's records joined by '\\n' (may be empty).
     The ComputeResult holds this rank's slice of the one masked superstring (see .slice(), .array(), .strings(want_mask))."""
-    flags = (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0)
+    flags = (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0) | ((min_frequency & 0xff) << 8 if min_frequency > 1 else 0)
     h = ctypes.c_void_p()
     if device_ptr is not None:
         flags |= FLAG_INPUT_ON_DEVICE

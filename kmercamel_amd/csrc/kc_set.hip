@@ -640,6 +640,112 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
 }
 
+// hash-sharded -z (ReadKMersFiltered / AddKMersWithFrequencies, parser.h:51-85,122-141): as kc_block_build_kernel for a block whose keys
+// arrived in nseg segments, but only the keys that occur at least min_count times among them stay.  Pass 1 inserts every key and
+// counts its occurrences (a 16-bit counter per slot behind the tags, two to a word; counting stops at 256: min_count <= 255) and
+// notes for every received key the slot it ended up in (`where`, 2 B per key); the table is cleared; pass 2 inserts the keys whose
+// slot counted min_count or more.  A key that finds no room in its block's probe run raises counters[3]: the spill list has no
+// counters, the caller leaves the sharded path.
+template <int W>
+__global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> set, const u64 *__restrict__ bucket, u64 *counters, const u64 *__restrict__ seg_scan,
+                                                                     int nseg, u32 min_count, unsigned short *where) {
+    extern __shared__ u64 kc_blk[];
+    __shared__ u64 seg_lo[KC_MAX_SEG], seg_pre[KC_MAX_SEG + 1];
+    __shared__ u32 added_s;
+    const u32 bs = 1u << set.bshift;
+    u64 *lk = kc_blk;
+    volatile u8 *lt = reinterpret_cast<volatile u8 *>(kc_blk + (size_t)bs * W);
+    u32 *cnt = reinterpret_cast<u32 *>(const_cast<u8 *>(lt) + bs);   // bs / 2 words
+    const u64 base = set.rlo + ((u64)blockIdx.x << set.bshift);
+    if (threadIdx.x == 0) {
+        added_s = 0;
+        u64 a = 0;
+        for (int q = 0; q < nseg; ++q) {
+            const u64 lo = seg_scan[(u64)q * gridDim.x + blockIdx.x], hi = seg_scan[(u64)q * gridDim.x + blockIdx.x + 1];
+            seg_lo[q] = lo; seg_pre[q] = a; a += hi - lo;
+        }
+        seg_pre[nseg] = a;
+    }
+    auto clear = [&]() {
+        for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x) reinterpret_cast<u64 *>(const_cast<u8 *>(lt))[i] = 0;
+        for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) lk[i] = ~(u64)0;
+    };
+    clear();
+    for (u32 i = threadIdx.x; i < bs / 2; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const u64 n = seg_pre[nseg];
+    auto src_of = [&](u64 j) -> u64 {
+        int q = 0;
+        while (q + 1 < nseg && j >= seg_pre[q + 1]) ++q;
+        return seg_lo[q] + (j - seg_pre[q]);
+    };
+    // insert `key` (or find it): the slot, or 0xffff when the block-local probe run is exhausted; *claimed = this call put it there
+    auto insert = [&](const Key<W> &key, bool *claimed) -> u32 {
+        const u64 top = key.w[W - 1];
+        u32 off; u8 tag;
+        set_place_local(set, key, &off, &tag);
+        *claimed = false;
+        u32 p = 0;
+        while (p < set.local_probes) {
+            const u32 s = off + p;
+            u64 cur = lk[(size_t)s * W + W - 1];
+            if (cur == ~(u64)0) cur = atomicCAS((ull *)&lk[(size_t)s * W + W - 1], ~0ULL, (ull)top);
+            if (cur == ~(u64)0) {   // claimed: publish
+                for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lt[s] = tag;
+                *claimed = true;
+                return s;
+            } else if (cur == top) {
+                if (W > 1 && lt[s] == 0) continue;   // being published by another lane: look again (p unchanged)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                bool eq = true;
+                for (int w = 0; w < W - 1; ++w) eq = eq && (lk[(size_t)s * W + w] == key.w[w]);
+                if (eq) return s;
+                ++p;
+            } else ++p;
+        }
+        return 0xffffu;
+    };
+    bool lost = false;
+    for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
+        const u64 src = src_of(j);
+        Key<W> key;
+        for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
+        bool claimed;
+        const u32 s = insert(key, &claimed);
+        where[src] = (unsigned short)s;
+        if (s == 0xffffu) { lost = true; continue; }
+        u32 *c = &cnt[s >> 1];
+        const u32 sh = 16u * (s & 1u);
+        if (((*reinterpret_cast<volatile u32 *>(c) >> sh) & 0xffffu) < 256u) atomicAdd(c, 1u << sh);
+    }
+    if (lost) atomicExch((ull *)&counters[3], 1ULL);
+    __syncthreads();
+    clear();
+    __syncthreads();
+    u32 added = 0;
+    for (u64 j = threadIdx.x; j < n; j += blockDim.x) {
+        const u64 src = src_of(j);
+        const u32 s0 = where[src];
+        if (s0 == 0xffffu || ((cnt[s0 >> 1] >> (16u * (s0 & 1u))) & 0xffffu) < min_count) continue;
+        Key<W> key;
+        for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
+        bool claimed;
+        (void)insert(key, &claimed);   // (fits: the survivors are a subset of what fitted in pass 1)
+        if (claimed) ++added;
+    }
+    if (added) atomicAdd(&added_s, added);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
+    for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
+        reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
+    if (W > 1)
+        for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
+    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at the end of the range
+    if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
+}
+
 template <int W>
 __global__ void __launch_bounds__(256) kc_insert_list_kernel(SetView<W> set, const u64 *__restrict__ list, u64 n, u64 *counters) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1057,7 +1163,7 @@ __global__ void __launch_bounds__(256) kc_bucket_compact_kernel(const u64 *__res
     for (u64 i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
-template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved) {
+template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved, int min_count) {
     kc_ctx *ctx = set->ctx;
     KcScope scope(ctx);
     const int G = c->world;
@@ -1163,15 +1269,30 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     // build the owned blocks
     const u64 ovf_cap = (u64)1 << 20;
     KC_TRY(scope.alloc(&ovf, ovf_cap * W));
-    const size_t lds_build = (size_t)bs * (8 * W + 1);
-    KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
+    const size_t lds_build = (size_t)bs * (8 * W + 1) + (min_count > 1 ? 2 * (size_t)bs : 0);
     set->unclean = false;
-    hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
-                       (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G, 0, 0);
+    if (min_count > 1) {
+        // -z: count the occurrences of every key where they all meet, keep those seen min_count times or more
+        unsigned short *where = nullptr;
+        KC_TRY(scope.alloc(&where, nrecv + 4));
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_filter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
+        KC_HIP(ctx, hipMemsetAsync(set->counters + 3, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(kc_block_build_filter_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys, set->counters,
+                           (const u64 *)seg_scan, G, (u32)min_count, where);
+    } else {
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
+        hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
+                           (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G, 0, 0);
+    }
     KC_HIP(ctx, hipGetLastError());
     u64 h[4] = {0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (min_count > 1) {   // (collective: a rank whose blocks overflowed takes everybody out of the sharded path)
+        u64 lost = h[3];
+        KC_TRY(kcc_allreduce_max(c, &lost, 1));
+        if (lost) return kc_fail(ctx, KC_E_ARG, "-z with table blocks that overflow is not part of the hash-sharded path");
+    }
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] rank %d/%d sharded build W=%d: %llu of %llu blocks (2^%d slots), %llu occurrences in, %llu received, size %llu, spills %llu\n", c->rank, G, W,
                 (unsigned long long)bpr, (unsigned long long)nblocks, set->bshift, (unsigned long long)occ_local, (unsigned long long)nrecv, (unsigned long long)h[0],
@@ -1183,11 +1304,13 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     }
     return kcs_refresh_size(set);
 }
-int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved) {
+int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved, int min_count) {
+    if (min_count > 1 && (((size_t)1 << set->bshift) * (8 * (size_t)set->W + 3) > KC_MAX_DYN_LDS || set->bshift > 15))
+        return kc_fail(set->ctx, KC_E_ARG, "-z with this table geometry is not part of the hash-sharded path");
     switch (set->W) {
-        case 1: return build_sharded_w<1>(set, c, d_codes, d_brk, d_low, len, moved);
-        case 2: return build_sharded_w<2>(set, c, d_codes, d_brk, d_low, len, moved);
-        default: return build_sharded_w<4>(set, c, d_codes, d_brk, d_low, len, moved);
+        case 1: return build_sharded_w<1>(set, c, d_codes, d_brk, d_low, len, moved, min_count);
+        case 2: return build_sharded_w<2>(set, c, d_codes, d_brk, d_low, len, moved, min_count);
+        default: return build_sharded_w<4>(set, c, d_codes, d_brk, d_low, len, moved, min_count);
     }
 }
 

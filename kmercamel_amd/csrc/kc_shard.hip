@@ -681,7 +681,7 @@ template <int W> void settle_branches(const std::vector<u64> &rows, u64 n, std::
     }
 }
 
-template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, int k, int complements, int want_mask, kc_result **out) {
+template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, int k, int complements, int want_mask, int min_frequency, kc_result **out) {
     KcScope scope(ctx);
     const int G = c->world, me = c->rank;
     const bool trace = trace_on();
@@ -699,7 +699,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
         int rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
         u64 moved = 0;
-        if (rc == KC_OK) rc = kcs_build_sharded(set, c, codes, brk, low, len, &moved);
+        if (rc == KC_OK) rc = kcs_build_sharded(set, c, codes, brk, low, len, &moved, min_frequency);
         (void)hipStreamSynchronize(ctx->stream);
         kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low);
         KC_TRY(rc);
@@ -1317,8 +1317,8 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     *out = nullptr;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
     if (k < 18 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
-    if ((flags & KC_FLAG_SIMPLITIGS_INPUT) || ((flags >> 8) & 0xff) > 1)
-        return kc_fail(ctx, KC_E_ARG, "-S and -z are not part of the hash-sharded path (use kc_compute)");
+    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail(ctx, KC_E_ARG, "-S is not part of the hash-sharded path (use kc_compute)");
+    const int min_frequency = ((flags >> 8) & 0xff) ? (int)((flags >> 8) & 0xff) : 1;   // -z (parser.h:122-141): counted where all occurrences of a k-mer meet, at its owner
     const int want_mask = (flags & KC_FLAG_WANT_MASK) ? 1 : 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
     const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;
@@ -1331,9 +1331,9 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     }
     int rc;
     switch (kc_words_for_k(k)) {
-        case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, want_mask, out); break;
-        case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, want_mask, out); break;
-        default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, want_mask, out); break;
+        case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
+        case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
+        default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d_own);

@@ -127,7 +127,7 @@ static void write_all(int fd, const char *data, size_t n) {
 // thread transport; the records are cut into N contiguous parts, kc_compute_sharded builds ONE masked superstring --
 // byte-identical to the single-GPU result -- and every rank copies its slice into place.
 static const int KC_CLI_SHARDED_FALLBACK = -1000;
-static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus) {
+static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus, int min_frequency, std::string *why) {
     WriteLog("Started computation of a masked superstring from '" + path + "'.");
     Records recs = load_records(path, false);
     const std::string &j = recs.joined;
@@ -159,11 +159,11 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         if (rc == KC_OK) rc = kc_comm_create_threads(ctx, group, r, &comm);
         if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; _exit(1); }   // (the others would wait for it forever)
         const uint64_t len = cut[r + 1] > cut[r] ? cut[r + 1] - cut[r] - (cut[r + 1] == j.size() ? 0 : 1) : 0;   // (the separator after the part is not part of it)
-        rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0), &res[r]);
+        rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0) | (min_frequency > 1 ? KC_FLAG_MIN_FREQUENCY(min_frequency) : 0), &res[r]);
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
         // S >= N / 5 (main.cpp:175, the sparse branch): every rank learns it from the same replicated simplitig list and returns together
-        const bool sparse_case = rc == KC_E_ARG && err[r].find("sparse branch") != std::string::npos;
+        const bool sparse_case = rc == KC_E_ARG && err[r].find("not part of the hash-sharded path") != std::string::npos;
         if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
         if (rc == KC_OK) {
             if (r == 0) {
@@ -191,7 +191,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
         return usage_subcommand("compute");
     }
-    if (rcs[0] == KC_E_ARG) return KC_CLI_SHARDED_FALLBACK;   // (the sparse branch: the caller runs the input on one GPU)
+    if (rcs[0] == KC_E_ARG) { *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }   // (what the ranks found out together, e.g. the sparse branch: the caller runs the input on one GPU)
     WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
@@ -209,12 +209,13 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     bool started_logged = false;
     if (gpus > 1) {
         // what the hash-sharded path does not cover runs on one GPU, as without the option
-        if (!lower_bound && !assume_simplitigs && min_frequency == 1 && k >= 18) {
-            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus);
+        if (!lower_bound && !assume_simplitigs && k >= 18) {
+            std::string why;
+            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, &why);
             if (rc != KC_CLI_SHARDED_FALLBACK) return rc;
-            std::cerr << "Note: too many simplitigs for the dense overlap graph (main.cpp:175); the sparse branch runs on one GPU." << std::endl;
+            std::cerr << "Note: " << why << "; running on one GPU." << std::endl;
             started_logged = true;
-        } else std::cerr << "Note: --gpus applies to `compute -k K [-M F]` with K >= 18 (no -S, -z); running on one GPU." << std::endl;
+        } else std::cerr << "Note: --gpus applies to `compute -k K [-M F] [-z N]` with K >= 18 (no -S); running on one GPU." << std::endl;
     }
     if (started_logged) { /* run_compute_sharded has logged the start */ }
     else if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");

@@ -38,7 +38,9 @@ def main():
     comm = kc.Comm.rccl(ctx, dist) if backend == "nccl" else kc.Comm.torch_host(ctx, dist)
     recs = [r[2] for r in kc.read_records(path)]
     mine = b"\n".join(split_records(recs, rank, world))
-    r = kc.compute_sharded(ctx, comm, mine, k, mode == "bi")
+    # mode: "bi" / "uni", optionally with "-zN" (minimum frequency N)
+    strand, _, z = mode.partition("-z")
+    r = kc.compute_sharded(ctx, comm, mine, k, strand == "bi", min_frequency=int(z) if z else 1)
     off, n = r.slice()
     piece = r.array().copy()
     stats = dict(r.stats)

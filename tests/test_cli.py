@@ -227,7 +227,7 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
     """`compute --gpus N` (new long option / KMERCAMEL_GPUS): N rank threads in one process, the k-mer set
     hash-sharded over them, exchanges through the in-process thread transport (ranks beyond the device count share the GPU).
     Same bytes as without the option: random reads, branching reads, a genome with cycles (one record: some ranks get no
-    input); option combinations the sharded path does not cover run on one GPU and say so."""
+    input); `-M` and `-z` on the sharded path; what it does not cover runs on one GPU and says so."""
     import gzip
     recs = gen.random_records(3000, 400, seed=21)
     fa = str(tmp_path / "reads.fa")
@@ -262,9 +262,17 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
         b = run("compute", "-k", k, "-M", m2, "--gpus", "3", path)
         assert a.returncode == 0 and b.returncode == 0, b.stderr[-500:]
         assert a.stdout == b.stdout and open(m1).read() == open(m2).read(), (path, k)
-    # -z / -S / small k: one GPU, with a note
-    p = run("compute", "-k", "23", "-z", "2", "--gpus", "2", br)   # (overlapping reads: k-mers that occur twice exist)
-    assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "23", "-z", "2", br).stdout
+    # -z on the sharded path: the occurrences of a k-mer are counted where they all meet, at its owner (overlapping reads: k-mers
+    # that occur twice or three times exist)
+    for z in ("2", "3"):
+        for extra in ((), ("-u",)):
+            want = run("compute", "-k", "23", "-z", z, *extra, br)
+            got = run("compute", "-k", "23", "-z", z, *extra, "--gpus", "3", br)
+            assert want.returncode == 0 and got.returncode == 0, got.stderr[-500:]
+            assert "running on one GPU" not in got.stderr and got.stdout == want.stdout, (z, extra)
+    # small k: one GPU, with a note
+    p = run("compute", "-k", "15", "--gpus", "2", br)
+    assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "15", br).stdout
     # an input whose simplitigs are too many for the dense overlap graph (S >= N / 5, main.cpp:175): the ranks find out together
     # after phase 1 and the CLI runs the sparse branch on one GPU
     sp = str(tmp_path / "sparse.fa")
@@ -272,6 +280,6 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
         for i, r in enumerate(gen.random_records(4000, 33, seed=5)):   # 3 k-mers per record at k = 31
             f.write(b">s%d\n%s\n" % (i, r))
     p = run("compute", "-k", "31", "--gpus", "2", sp)
-    assert p.returncode == 0 and "sparse branch runs on one GPU" in p.stderr, p.stderr[-500:]
+    assert p.returncode == 0 and "sparse branch" in p.stderr and "running on one GPU" in p.stderr, p.stderr[-500:]
     assert p.stdout == run("compute", "-k", "31", sp).stdout
     assert run("compute", "-k", "31", "--gpus", "0", fa).returncode == 1

@@ -93,6 +93,24 @@ def test_ranks_real_genome_with_cycles(ctx, golden_dir, tmp_path, world, k, mode
     assert np.array_equal(got, single(ctx, fa, k, mode == "bi")), (world, k, mode)
 
 
+@pytest.mark.parametrize("k", [23, 63])
+def test_ranks_min_frequency_filter(ctx, tmp_path, k):
+    """-z on the sharded path (ReadKMersFiltered, parser.h:122-141): every occurrence of a k-mer, whichever rank read it, is counted
+    at the k-mer's owner; the k-mers seen fewer than z times leave the table before phase 1.  Overlapping reads from both strands
+    with errors: occurrence counts of 1 ... ~10."""
+    recs = [r for r in gen.stress_reads(genome_len=20000, n_reads=900, read_len=max(150, 2 * k), seed=5 + k, n_frac=0.002, lower_frac=0.05) if len(r) >= k]
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    for z in (2, 3):
+        for mode in ("bi", "uni"):
+            r = kc.compute_file(ctx, fa, k, mode == "bi", min_frequency=z)
+            want = r.array().copy()
+            r.close()
+            for world in (2, 3):
+                got = run_ranks(world, fa, k, "%s-z%d" % (mode, z), str(tmp_path / "out.npy"))
+                assert np.array_equal(got, want), (z, mode, world)
+
+
 @pytest.mark.parametrize("k,mode", [(19, "bi"), (31, "bi"), (31, "uni"), (33, "bi")])
 def test_ranks_cycles_next_to_chain_ends(ctx, tmp_path, k, mode):
     """circular sequences (cycles of k-mers, short ones that stay in a block and long ones that span ranks), each with reads that

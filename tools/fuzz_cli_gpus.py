@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check of the hash-sharded path through the CLI on the GPU box: `python tools/fuzz_cli_gpus.py [seconds] [seed]`.
 Random inputs (the shapes of tools/fuzz_parity.py: reads with errors / N / lower case, low-complexity strings, repeats, circular
-sequences with tails, copies), k in 18..127, 2-4 rank threads sharing the GPU, both strand modes, -M now and then; every case
+sequences with tails, copies), k in 18..127, 2-4 rank threads sharing the GPU, both strand modes, -M and -z now and then; every case
 compares the bytes of `kmercamel compute --gpus N` with those of the plain `kmercamel compute` (which the other fuzz run holds
 against the oracle)."""
 import os, random, subprocess, sys, tempfile, time
@@ -38,7 +38,7 @@ def main():
             uni = rng.random() < 0.3
             mask = rng.random() < 0.3
             gpus = rng.choice([2, 2, 3, 4])
-            base = ["compute", "-k", str(k)] + (["-u"] if uni else [])
+            base = ["compute", "-k", str(k)] + (["-u"] if uni else []) + (["-z", str(rng.choice([2, 3]))] if rng.random() < 0.25 else [])
             outs = []
             # the alternative paths of the sharded flow, now and then: pointer jumping instead of waves (or waves cut short), plain
             # walks, the two-pass bucket layout, replicated phase 2, the rolling scatter
