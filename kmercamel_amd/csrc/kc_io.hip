@@ -177,6 +177,11 @@ __global__ void __launch_bounds__(256) tok_write_kernel(const u8 *__restrict__ r
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---- reader: plain files by read(), gzip (and anything zlib passes through) by gzread, "-" = stdin
+// copy threads per pinned chunk (reads from the page cache into it, copies out of it): KC_IO_THREADS, default 4
+static int kc_io_threads() {
+    static const int t = [] { const char *e = getenv("KC_IO_THREADS"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
+    return t;
+}
 struct Reader {
     int fd = -1;
     gzFile gz = nullptr;
@@ -197,7 +202,7 @@ struct Reader {
         if (size >= 0 && !getenv("KC_IO_SERIAL")) {
             // page-cache / tmpfs reads are memory copies in the kernel: one thread moves ~5 GB/s, four move the chunk in a quarter of the time
             const size_t want = (size_t)std::min<off_t>((off_t)cap, size > pos ? size - pos : 0);
-            const int T = want >= ((size_t)8 << 20) ? 4 : 1;
+            const int T = want >= ((size_t)8 << 20) ? kc_io_threads() : 1;
             std::atomic<bool> bad{false};
             auto part = [&](int t) {
                 size_t lo = want * (size_t)t / (size_t)T, hi = want * (size_t)(t + 1) / (size_t)T;
@@ -507,7 +512,7 @@ extern "C" int kc_result_write_mem(kc_result *r, void *dst_v, int which) {
         }
         if (hipEventSynchronize(ev[slot]) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
         const u64 n = len_in[slot];
-        const int T = (n >= ((u64)8 << 20) && !getenv("KC_IO_SERIAL")) ? 4 : 1;
+        const int T = (n >= ((u64)8 << 20) && !getenv("KC_IO_SERIAL")) ? kc_io_threads() : 1;
         const char *buf = hb[slot];
         char *at = dst + done;
         auto part = [&](int t) { const u64 lo = n * (u64)t / (u64)T, hi = n * (u64)(t + 1) / (u64)T; memcpy(at + lo, buf + lo, hi - lo); };
