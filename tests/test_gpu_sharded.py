@@ -164,6 +164,31 @@ def test_rccl_transport_single_rank(ctx, tmp_path):
     assert np.array_equal(np.load(str(tmp_path / "out.npy")), single(ctx, fa, 31, True))
 
 
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(_visible_gpus() < 2 or not os.environ.get("KC_TEST_MULTI_GPU"),
+                    reason="opt-in (KC_TEST_MULTI_GPU=1) and needs two GPUs: the grouped ncclSend/ncclRecv path between ranks has never run on this pool's 1-GPU boxes")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_transport_between_gpus(ctx, golden_dir, tmp_path, world):
+    """RCCL over xGMI with one rank per GPU (runs only where the box has the GPUs): random reads, both strand modes, and the genome
+    with cycles -- byte-identical to one GPU"""
+    if _visible_gpus() < world:
+        pytest.skip("needs %d GPUs" % world)
+    recs = gen.random_records(4000, 600, seed=13)
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    for path, k, mode in ((fa, 31, "bi"), (fa, 31, "uni"), (fa, 63, "bi"), (os.path.join(golden_dir, "spneumoniae.fa.gz"), 31, "bi")):
+        port = 29950 + (os.getpid() + world) % 40
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(ROOT, "tests", "shard_worker.py"), path, str(k), mode, str(tmp_path / "out.npy"), "--backend", "nccl"]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+        assert np.array_equal(np.load(str(tmp_path / "out.npy")), single(ctx, path, k, mode == "bi")), (path, k, mode)
+
+
 def test_bench_gpus2_line(tmp_path):
     """bench.py --gpus 2 (its own launcher, host-staged transport because the box has one GPU): a strong-scaling line on one record set"""
     import json
