@@ -170,6 +170,11 @@ int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64
  * blocks): the caller then runs kc_compute on one GPU.  The result holds this rank's slice; stats as kc_result_stats with global
  * counts. */
 int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out);
+/* -S over all ranks (simplitigs_from_fasta, simplitigs.h:89-103; main.cpp:150-160): THIS rank's simplitig records one after the other
+ * (no separators) with their offsets[0..n_records], as kc_compute takes them; the ranks' records in rank order are the simplitig
+ * list.  Flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE (-M with -S goes through the single-GPU kc_compute).  Collective. */
+int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, const uint64_t *offsets, uint64_t n_records, int k,
+                                  uint32_t flags, kc_result **out);
 /* position and size of this rank's slice inside the superstring (offset 0 / whole length for kc_compute results);
  * kc_result_device_ptrs / kc_result_copy address the slice */
 int kc_result_slice(kc_result *r, uint64_t *offset, uint64_t *slice_len);

@@ -6,6 +6,6 @@ api.py (ctypes mirror of the reference's operator interface, used by tests and b
 from . import api  # noqa: F401
 from .api import (Context, KmerSet, Simplitigs, KcError, ReadKMers, ReadKMersFiltered, get_simplitigs, simplitigs_from_strings,  # noqa: F401
                   simplitigs_from_fasta, OverlapHamiltonianPath, SuperstringFromPath, Global, LowerBoundLength, Optimize,
-                  compute, compute_file, read_records, Comm, compute_sharded)
+                  compute, compute_file, read_records, Comm, compute_sharded, compute_sharded_simplitigs)
 
 __version__ = "0.1.0"

@@ -70,6 +70,7 @@ SIGNATURES = {
     "kc_shard_geometry": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _u64p]),
     "kc_shard_owner_of": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, _u64p, ctypes.c_uint64, _u8p]),
     "kc_compute_sharded": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
+    "kc_compute_sharded_simplitigs": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
     "kc_result_slice": (ctypes.c_int, [_vp, _u64p, _u64p]),
     "kc_read_fasta_device": (ctypes.c_int, [_vp, ctypes.c_char_p, _vpp, _u64p, ctypes.POINTER(ctypes.c_int)]),
     "kc_device_free": (None, [_vp, _vp]),
@@ -643,6 +644,20 @@ def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length
     else:
         ptr, n, _keep = _host_bytes(seq)
         ctx.check(ctx.lib.kc_compute_sharded(ctx.h, comm.h, ptr, n, k, flags, ctypes.byref(h)))
+    return ComputeResult(ctx, h)
+
+
+def compute_sharded_simplitigs(ctx, comm, records, k, complements=True):
+    """kc_compute_sharded_simplitigs (-S): `records` = THIS rank's simplitigs (list of bytes); collective over comm's ranks."""
+    offs, o = [], 0
+    for r in records:
+        offs.append(o)
+        o += len(r)
+    offs.append(o)
+    arr = (ctypes.c_uint64 * len(offs))(*offs)
+    ptr, n, _keep = _host_bytes(b"".join(records))
+    h = ctypes.c_void_p()
+    ctx.check(ctx.lib.kc_compute_sharded_simplitigs(ctx.h, comm.h, ptr, n, arr, len(records), k, FLAG_COMPLEMENTS if complements else 0, ctypes.byref(h)))
     return ComputeResult(ctx, h)
 
 

@@ -589,6 +589,39 @@ __global__ void __launch_bounds__(256) kc_shard_simp_dest_kernel(const u64 *__re
         if (hi_s[i]) { atomicMin((ull *)&rank_lo[i], (ull)lo_s[i]); atomicMax((ull *)&rank_hi[i], (ull)hi_s[i]); }
 }
 
+
+// ---- -S (simplitigs_from_fasta, simplitigs.h:89-103) on the sharded path: the records ARE the simplitigs.  Every rank packs its own,
+// the ranks all-gather {length, first k-mer, last k-mer} per simplitig in record order (= the reference's order), phases 2-3 run as
+// for computed simplitigs, and the packed words of a simplitig travel to the rank that emits it.
+// rows {length, first k-mer[W], last k-mer[W]} of this rank's simplitigs
+__global__ void __launch_bounds__(256) kc_shard_srows_kernel(const u64 *__restrict__ lens, const u64 *__restrict__ firstK, const u64 *__restrict__ lastK, u64 n, int W, u64 *rows) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u64 *r = rows + t * (u64)(1 + 2 * W);
+    r[0] = lens[t];
+    for (int w = 0; w < W; ++w) { r[1 + w] = firstK[t * W + w]; r[1 + W + w] = lastK[t * W + w]; }
+}
+// the replicated list from the gathered rows; nw[i] = words of simplitig i
+__global__ void __launch_bounds__(256) kc_shard_sfill_kernel(const u64 *__restrict__ rows, u64 S, int W, u64 *lens, u64 *nw, u64 *firstK, u64 *lastK) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S) return;
+    const u64 *r = rows + t * (u64)(1 + 2 * W);
+    lens[t] = r[0]; nw[t] = r[0] / 32 + 1;
+    for (int w = 0; w < W; ++w) { firstK[t * W + w] = r[1 + w]; lastK[t * W + w] = r[1 + W + w]; }
+}
+// one message per packed word of this rank's simplitigs: {position in bases | 31 << 58, the word} to the rank that emits the simplitig
+__global__ void __launch_bounds__(256) kc_shard_smsg_kernel(const u64 *__restrict__ lwords, const u64 *__restrict__ lwoff, u64 n_local, u64 nwords_local, u64 g0,
+                                                            const u64 *__restrict__ gwoff, const u8 *__restrict__ simp_dest, u64 *msgs, u8 *mdest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nwords_local) return;
+    u64 lo = 0, hi = n_local + 1;   // upper bound of t in lwoff[0 .. n_local]
+    while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (lwoff[mid] <= t) lo = mid + 1; else hi = mid; }
+    const u64 i = lo - 1, j = t - lwoff[i], g = g0 + i;
+    msgs[2 * t] = ((gwoff[g] + j) * 32) | ((u64)31 << 58);
+    msgs[2 * t + 1] = lwords[t];
+    mdest[t] = simp_dest[g];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------- host flow
@@ -1310,6 +1343,112 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     return KC_OK;
 }
 
+
+template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, const u64 *offsets, u64 n_rec, int k, int complements, kc_result **out) {
+    KcScope scope(ctx);
+    const int G = c->world, me = c->rank;
+    hipEvent_t e0 = ctx->ev[0], e3 = ctx->ev[3], eend;
+    KC_HIP(ctx, hipEventCreate(&eend));
+    struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } evg{eend};
+    KC_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    // this rank's simplitigs, packed (a record shorter than k or with another letter than ACGT is an error here as on one GPU; the
+    // ranks agree on it before anybody enters an exchange)
+    kc_simplitigs *mine = nullptr;
+    int lrc = KC_OK;
+    if (n_rec) lrc = kcp_simplitigs_from_device_ascii(ctx, k, d_seq, len, offsets, n_rec, 1, &mine);
+    struct SimpGuard { kc_simplitigs *s; ~SimpGuard() { if (s) kc_simplitigs_destroy(s); } } mineg{mine};
+    {
+        u64 bad = lrc != KC_OK ? (u64)(-lrc) : 0;
+        KC_TRY(kcc_allreduce_max(c, &bad, 1));
+        if (bad) return lrc != KC_OK ? lrc : kc_fail(ctx, -(int)bad, "another rank's simplitig records are not valid");
+    }
+    const int RW = 1 + 2 * W;
+    u64 *rows = nullptr, *all = nullptr, S = 0;
+    std::vector<u64> counts;
+    KC_TRY(scope.alloc(&rows, (n_rec + 1) * RW));
+    if (n_rec) hipLaunchKernelGGL(kc_shard_srows_kernel, dim3(kc_grid(n_rec, 256)), dim3(256), 0, ctx->stream, (const u64 *)mine->lens, (const u64 *)mine->firstK, (const u64 *)mine->lastK, n_rec, W, rows);
+    KC_HIP(ctx, hipGetLastError());
+    KC_TRY(allgather_rows(c, rows, n_rec, RW, &all, &S, &counts));
+    scope.release(rows);
+    if (S == 0) { kc_release(ctx, all); return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty"); }
+    u64 g0 = 0;
+    for (int p = 0; p < me; ++p) g0 += counts[p];
+    // the replicated simplitig list (record order: rank by rank)
+    kc_simplitigs *simp = new kc_simplitigs();
+    simp->ctx = ctx; simp->k = k; simp->W = W; simp->n = S;
+    struct SimpGuard2 { kc_simplitigs *s; ~SimpGuard2() { if (s) kc_simplitigs_destroy(s); } } simpg{simp};
+    u64 *nw = nullptr;
+    KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
+    KC_TRY(kc_alloc(ctx, &simp->firstK, S * W + 1)); KC_TRY(kc_alloc(ctx, &simp->lastK, S * W + 1));
+    KC_TRY(scope.alloc(&nw, S + 1));
+    hipLaunchKernelGGL(kc_shard_sfill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all, S, W, simp->lens, nw, simp->firstK, simp->lastK);
+    KC_HIP(ctx, hipGetLastError());
+    KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S, false));
+    u64 wsum = 0, bases_local = n_rec ? mine->total_bases : 0, bases = 0;
+    KC_TRY(read_words(ctx, simp->woff + S, &wsum, 1));
+    bases = bases_local;
+    KC_TRY(kcc_allreduce_sum(c, &bases, 1));
+    simp->nwords = wsum; simp->total_bases = bases;
+    KC_TRY(kc_alloc(ctx, &simp->words, wsum + 2));
+    KC_HIP(ctx, hipMemsetAsync(simp->words, 0, (wsum + 2) * 8, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    kc_release(ctx, all);
+    scope.release(nw);
+    const u64 N = bases - S * (u64)(k - 1);
+    // phase 2 (the keys of a level divided among the ranks) and the path ranking
+    KcPathDev path;
+    KC_TRY(kco_overlap_path_device(simp, complements, 0, &path, c));
+    struct PathGuard { kc_ctx *c; KcPathDev *p; ~PathGuard() { kco_path_release(c, p); } } pathg{ctx, &path};
+    KC_HIP(ctx, hipEventRecord(e3, ctx->stream));
+    KcRank rk;
+    KC_TRY(kce_rank_path(simp, &path, &rk));
+    struct RankGuard { kc_ctx *c; KcRank *r; ~RankGuard() { kce_rank_release(c, r); } } rankg{ctx, &rk};
+    const u64 V = path.V, Ltot = rk.L;
+    // phase 3: the packed words to the emitting ranks, emit
+    u8 *simp_dest = nullptr;
+    u64 *rank_rng = nullptr;
+    KC_TRY(scope.alloc(&simp_dest, S + 1)); KC_TRY(scope.alloc(&rank_rng, 2 * KC_MAX_RANKS_SH));
+    KC_HIP(ctx, hipMemsetAsync(rank_rng, 0xff, KC_MAX_RANKS_SH * 8, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(rank_rng + KC_MAX_RANKS_SH, 0, KC_MAX_RANKS_SH * 8, ctx->stream));
+    hipLaunchKernelGGL(kc_shard_simp_dest_kernel, dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)rk.dist, (const u64 *)rk.endv, rk.start, S, V, Ltot, G, simp_dest,
+                       rank_rng, rank_rng + KC_MAX_RANKS_SH, (const u64 *)rk.weight);
+    {
+        const u64 n_msg = n_rec ? mine->nwords : 0;
+        u64 *msgs = nullptr, *rmsgs = nullptr;
+        u8 *mdest = nullptr;
+        KC_TRY(scope.alloc(&msgs, 2 * n_msg + 2)); KC_TRY(scope.alloc(&mdest, n_msg + 1));
+        if (n_msg)
+            hipLaunchKernelGGL(kc_shard_smsg_kernel, dim3(kc_grid(n_msg, 256)), dim3(256), 0, ctx->stream, (const u64 *)mine->words, (const u64 *)mine->woff, n_rec, n_msg, g0,
+                               (const u64 *)simp->woff, (const u8 *)simp_dest, msgs, mdest);
+        KC_HIP(ctx, hipGetLastError());
+        KcRoute rt;
+        KC_TRY(kcr_build(c, mdest, n_msg, &rt));
+        int rc = kcr_forward(c, rt, msgs, 2, 2, &rmsgs);
+        if (rc == KC_OK && rt.n_recv)
+            hipLaunchKernelGGL(kc_shard_place_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rmsgs, rt.n_recv, simp->words);
+        (void)hipStreamSynchronize(ctx->stream);
+        kcr_free(ctx, &rt);
+        kc_release(ctx, rmsgs);
+        KC_TRY(rc);
+    }
+    u64 h_rng[2 * KC_MAX_RANKS_SH];
+    KC_TRY(read_words(ctx, rank_rng, h_rng, 2 * KC_MAX_RANKS_SH));
+    u64 lo = h_rng[me], hi = h_rng[KC_MAX_RANKS_SH + me];
+    if (lo == ~(u64)0) { lo = 0; hi = 0; }   // no block starts in this rank's share
+    kc_result *r = new kc_result();
+    r->ctx = ctx; r->length = Ltot; r->slice_off = lo; r->slice_len = hi - lo;
+    int rc = kc_alloc(ctx, &r->d_out, r->slice_len + 8);
+    if (rc == KC_OK && r->slice_len) rc = kce_emit_ranked(simp, &rk, lo, G, me, r->d_out);
+    KC_HIP(ctx, hipEventRecord(eend, ctx->stream));
+    KC_HIP(ctx, hipEventSynchronize(eend));
+    if (rc != KC_OK) { kc_result_destroy(r); return rc; }
+    r->stats[0] = N; r->stats[1] = S; r->stats[2] = Ltot; r->stats[4] = V;
+    r->stats[8] = (u64)(1000.0 * ev_ms(e0, e3)); r->stats[9] = (u64)(1000.0 * ev_ms(e3, eend));
+    r->stats[13] = path.repairs; r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
+    *out = r;
+    return KC_OK;
+}
+
 }  // namespace
 
 extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out) {
@@ -1334,6 +1473,36 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
         case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
         case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
         default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    kc_release(ctx, d_own);
+    return rc;
+}
+
+// -S on the sharded path: `seq` = this rank's simplitig records one after the other (no separators), offsets[0..n_records] their
+// starts and the end, as kc_compute takes them (simplitigs_from_fasta, simplitigs.h:89-103).  Collective.
+extern "C" int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, const uint64_t *offsets, uint64_t n_records, int k, uint32_t flags,
+                                             kc_result **out) {
+    if (!ctx || !comm || !out || (!seq && len) || (!offsets && n_records)) return KC_E_ARG;
+    *out = nullptr;
+    if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
+    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
+    if (flags & KC_FLAG_WANT_MASK) return kc_fail(ctx, KC_E_ARG, "-S with -M is not part of the hash-sharded path");
+    if (((flags >> 8) & 0xff) > 1) return kc_fail(ctx, KC_E_ARG, "Inputting simplitigs is not compatible with frequency filterring.");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;
+    u8 *d_own = nullptr;
+    const u8 *d_seq = (const u8 *)seq;
+    if (!(flags & KC_FLAG_INPUT_ON_DEVICE)) {
+        KC_TRY(kc_alloc(ctx, &d_own, len + 64));
+        if (len) KC_HIP(ctx, hipMemcpyAsync(d_own, seq, len, hipMemcpyHostToDevice, ctx->stream));
+        d_seq = d_own;
+    }
+    int rc;
+    switch (kc_words_for_k(k)) {
+        case 1: rc = compute_sharded_simplitigs_w<1>(ctx, comm, d_seq, len, offsets, n_records, k, complements, out); break;
+        case 2: rc = compute_sharded_simplitigs_w<2>(ctx, comm, d_seq, len, offsets, n_records, k, complements, out); break;
+        default: rc = compute_sharded_simplitigs_w<4>(ctx, comm, d_seq, len, offsets, n_records, k, complements, out); break;
     }
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d_own);

@@ -127,13 +127,22 @@ static void write_all(int fd, const char *data, size_t n) {
 // thread transport; the records are cut into N contiguous parts, kc_compute_sharded builds ONE masked superstring --
 // byte-identical to the single-GPU result -- and every rank copies its slice into place.
 static const int KC_CLI_SHARDED_FALLBACK = -1000;
-static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus, int min_frequency, std::string *why) {
+static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus, int min_frequency, bool assume_simplitigs,
+                               std::string *why) {
     WriteLog("Started computation of a masked superstring from '" + path + "'.");
-    Records recs = load_records(path, false);
+    Records recs = load_records(path, assume_simplitigs);
     const std::string &j = recs.joined;
-    // part r = the records from the first line start at or after byte len * r / N
+    // part r = the records from the first line start at or after byte len * r / N (-S: records rec_cut[r] .. rec_cut[r + 1], with their
+    // offsets counted from the part's first byte)
     std::vector<size_t> cut(gpus + 1, j.size());
-    cut[0] = 0;
+    std::vector<uint64_t> rec_cut(gpus + 1, recs.n);
+    std::vector<std::vector<uint64_t>> part_offsets(gpus);
+    cut[0] = 0; rec_cut[0] = 0;
+    if (assume_simplitigs) {
+        for (int r = 1; r < gpus; ++r) { rec_cut[r] = recs.n * (uint64_t)r / (uint64_t)gpus; cut[r] = recs.offsets[rec_cut[r]]; }
+        for (int r = 0; r < gpus; ++r)
+            for (uint64_t i = rec_cut[r]; i <= rec_cut[r + 1]; ++i) part_offsets[r].push_back(recs.offsets[i] - recs.offsets[rec_cut[r]]);
+    } else
     for (int r = 1; r < gpus; ++r) {
         size_t p = j.size() / gpus * r;
         if (p < cut[r - 1]) p = cut[r - 1];
@@ -158,8 +167,13 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         int rc = kc_ctx_create(r % ndev, &ctx);
         if (rc == KC_OK) rc = kc_comm_create_threads(ctx, group, r, &comm);
         if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; _exit(1); }   // (the others would wait for it forever)
-        const uint64_t len = cut[r + 1] > cut[r] ? cut[r + 1] - cut[r] - (cut[r + 1] == j.size() ? 0 : 1) : 0;   // (the separator after the part is not part of it)
-        rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0) | (min_frequency > 1 ? KC_FLAG_MIN_FREQUENCY(min_frequency) : 0), &res[r]);
+        if (assume_simplitigs)
+            rc = kc_compute_sharded_simplitigs(ctx, comm, j.data() + cut[r], cut[r + 1] - cut[r], part_offsets[r].data(), rec_cut[r + 1] - rec_cut[r], k,
+                                               complements ? KC_FLAG_COMPLEMENTS : 0, &res[r]);
+        else {
+            const uint64_t len = cut[r + 1] > cut[r] ? cut[r + 1] - cut[r] - (cut[r + 1] == j.size() ? 0 : 1) : 0;   // (the separator after the part is not part of it)
+            rc = kc_compute_sharded(ctx, comm, j.data() + cut[r], len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0) | (min_frequency > 1 ? KC_FLAG_MIN_FREQUENCY(min_frequency) : 0), &res[r]);
+        }
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
         // S >= N / 5 (main.cpp:175, the sparse branch): every rank learns it from the same replicated simplitig list and returns together
@@ -192,7 +206,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         return usage_subcommand("compute");
     }
     if (rcs[0] == KC_E_ARG) { *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }   // (what the ranks found out together, e.g. the sparse branch: the caller runs the input on one GPU)
-    WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
+    if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
@@ -209,13 +223,13 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     bool started_logged = false;
     if (gpus > 1) {
         // what the hash-sharded path does not cover runs on one GPU, as without the option
-        if (!lower_bound && !assume_simplitigs && k >= 18) {
+        if (!lower_bound && (assume_simplitigs ? maskf == nullptr : k >= 18)) {
             std::string why;
-            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, &why);
+            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, assume_simplitigs, &why);
             if (rc != KC_CLI_SHARDED_FALLBACK) return rc;
             std::cerr << "Note: " << why << "; running on one GPU." << std::endl;
             started_logged = true;
-        } else std::cerr << "Note: --gpus applies to `compute -k K [-M F] [-z N]` with K >= 18 (no -S); running on one GPU." << std::endl;
+        } else std::cerr << "Note: --gpus applies to `compute -k K [-M F] [-z N]` with K >= 18 and to `compute -S` without -M; running on one GPU." << std::endl;
     }
     if (started_logged) { /* run_compute_sharded has logged the start */ }
     else if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");

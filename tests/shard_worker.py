@@ -38,9 +38,12 @@ def main():
     comm = kc.Comm.rccl(ctx, dist) if backend == "nccl" else kc.Comm.torch_host(ctx, dist)
     recs = [r[2] for r in kc.read_records(path)]
     mine = b"\n".join(split_records(recs, rank, world))
-    # mode: "bi" / "uni", optionally with "-zN" (minimum frequency N)
-    strand, _, z = mode.partition("-z")
-    r = kc.compute_sharded(ctx, comm, mine, k, strand == "bi", min_frequency=int(z) if z else 1)
+    # mode: "bi" / "uni", optionally with "-zN" (minimum frequency N) or "-S" (the records are simplitigs)
+    if mode.endswith("-S"):
+        r = kc.compute_sharded_simplitigs(ctx, comm, split_records(recs, rank, world), k, mode.startswith("bi"))
+    else:
+        strand, _, z = mode.partition("-z")
+        r = kc.compute_sharded(ctx, comm, mine, k, strand == "bi", min_frequency=int(z) if z else 1)
     off, n = r.slice()
     piece = r.array().copy()
     stats = dict(r.stats)

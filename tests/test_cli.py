@@ -270,6 +270,17 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
             got = run("compute", "-k", "23", "-z", z, *extra, "--gpus", "3", br)
             assert want.returncode == 0 and got.returncode == 0, got.stderr[-500:]
             assert "running on one GPU" not in got.stderr and got.stdout == want.stdout, (z, extra)
+    # -S on the sharded path: the records are the simplitigs (record order), no k-mer table involved (any k)
+    sf = str(tmp_path / "simplitigs.fa")
+    with open(sf, "wb") as f:
+        for i, r in enumerate(gen.random_records(900, 77, seed=9) + gen.random_records(50, 31, seed=10)):
+            f.write(b">s%d\n%s\n" % (i, r))
+    for k in ("31", "15"):
+        for extra in ((), ("-u",)):
+            want = run("compute", "-k", k, "-S", *extra, sf)
+            got = run("compute", "-k", k, "-S", *extra, "--gpus", "3", sf)
+            assert want.returncode == 0 and got.returncode == 0, got.stderr[-500:]
+            assert "running on one GPU" not in got.stderr and got.stdout == want.stdout, (k, extra)
     # small k: one GPU, with a note
     p = run("compute", "-k", "15", "--gpus", "2", br)
     assert p.returncode == 0 and "running on one GPU" in p.stderr and p.stdout == run("compute", "-k", "15", br).stdout

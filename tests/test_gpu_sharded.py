@@ -93,6 +93,36 @@ def test_ranks_real_genome_with_cycles(ctx, golden_dir, tmp_path, world, k, mode
     assert np.array_equal(got, single(ctx, fa, k, mode == "bi")), (world, k, mode)
 
 
+@pytest.mark.parametrize("k", [13, 31, 63, 127])
+def test_ranks_simplitigs_input(ctx, tmp_path, k):
+    """-S on the sharded path (simplitigs_from_fasta, simplitigs.h:89-103): the records are the simplitigs, in record order; every rank
+    packs its own, phase 2 runs on the all-gathered end k-mers, the packed words travel to the rank that emits them.  Records of k
+    ... 3k+50 characters with overlaps between their ends, both strand modes, 2-4 ranks (some with no record at all)."""
+    import random
+    rng = random.Random(31 * k)
+    recs = []
+    for i in range(700):
+        n = rng.choice([k, k + 1, 2 * k, 3 * k + 50])
+        head = recs[rng.randrange(len(recs))][-(k - 1):] if recs and rng.random() < 0.5 else b""   # an overlap with an earlier record's end
+        body = bytes(rng.choice(b"ACGT") for _ in range(max(0, n - len(head))))
+        recs.append((head + body)[:max(n, k)] if len(head + body) >= k else head + body + b"A" * k)
+    fa = str(tmp_path / "simp.fa")
+    write_fasta(fa, recs)
+    for mode in ("bi", "uni"):
+        r = kc.compute_file(ctx, fa, k, mode == "bi", assume_simplitigs=True)
+        want = r.array().copy()
+        r.close()
+        for world in (2, 3, 4):
+            got = run_ranks(world, fa, k, mode + "-S", str(tmp_path / "out.npy"))
+            assert np.array_equal(got, want), (mode, world)
+    few = str(tmp_path / "few.fa")
+    write_fasta(few, recs[:2])
+    r = kc.compute_file(ctx, few, k, True, assume_simplitigs=True)
+    want = r.array().copy()
+    r.close()
+    assert np.array_equal(run_ranks(4, few, k, "bi-S", str(tmp_path / "out.npy")), want)
+
+
 @pytest.mark.parametrize("k", [23, 63])
 def test_ranks_min_frequency_filter(ctx, tmp_path, k):
     """-z on the sharded path (ReadKMersFiltered, parser.h:122-141): every occurrence of a k-mer, whichever rank read it, is counted

@@ -32,13 +32,16 @@ def main():
                     at = rng.randrange(max(1, len(c) - k))
                     tail = fuzz_parity.rand_seq(rng, rng.randint(1, 60))
                     recs.append(c[at:at + k - 1] + tail if rng.random() < 0.5 else tail + c[at:at + k - 1])
+            simp = rng.random() < 0.15   # -S: the records are simplitigs (only records that can be: k or more letters of ACGT)
+            if simp:
+                recs = [r.upper() for r in recs if len(r) >= k and set(r.upper()) <= set("ACGT")][:20000] or [fuzz_parity.rand_seq(rng, k + 7)]
             with open(fa, "w") as f:
                 for i, r in enumerate(recs):
                     f.write(">r%d\n%s\n" % (i, r))
             uni = rng.random() < 0.3
-            mask = rng.random() < 0.3
+            mask = rng.random() < 0.3 and not simp
             gpus = rng.choice([2, 2, 3, 4])
-            base = ["compute", "-k", str(k)] + (["-u"] if uni else []) + (["-z", str(rng.choice([2, 3]))] if rng.random() < 0.25 else [])
+            base = ["compute", "-k", str(k)] + (["-u"] if uni else []) + (["-S"] if simp else (["-z", str(rng.choice([2, 3]))] if rng.random() < 0.25 else []))
             outs = []
             # the alternative paths of the sharded flow, now and then: pointer jumping instead of waves (or waves cut short), plain
             # walks, the two-pass bucket layout, replicated phase 2, the rolling scatter
