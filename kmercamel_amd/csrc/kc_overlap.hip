@@ -138,40 +138,85 @@ __device__ __forceinline__ void ov_list_hit(u8 hit, u64 v, u64 *hit_count, u64 *
     }
 }
 
+// The same for a thread that handled OV_ITEMS vertices (bit j of `hits`: vertex v[j] is a hit): one reservation per workgroup of
+// 256 x OV_ITEMS vertices.  (On reads with coverage nearly every workgroup has a hit at every level: with one vertex per thread the
+// ~20 000 same-address atomics of a 5e6-vertex sweep were 0.25 ms of each of the two sweeps of a level.)
+#define OV_ITEMS 8
+__device__ __forceinline__ void ov_list_hits(u32 hits, const u64 (&v)[OV_ITEMS], u64 *hit_count, u64 *hit_list, u64 hit_cap) {
+    __shared__ u32 wcount[4];
+    __shared__ u64 wbase;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 c = (u32)__popc(hits);
+    u32 inc = c;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(inc, dd, 64); if (lane >= dd) inc += o; }
+    if (lane == 63) wcount[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        wbase = tot ? atomicAdd((ull *)hit_count, (ull)tot) : 0;
+    }
+    __syncthreads();
+    if (c) {
+        u64 pos = wbase + (u64)(inc - c);
+        for (int j = 0; j < wv; ++j) pos += wcount[j];
+#pragma unroll
+        for (int j = 0; j < OV_ITEMS; ++j)
+            if ((hits >> j) & 1u) { if (pos < hit_cap) hit_list[pos] = v[j]; ++pos; }
+    }
+}
+
+// (a workgroup takes 256 x OV_ITEMS consecutive positions of the active list, thread t the positions base + j * 256 + t)
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, const u64 *__restrict__ actS, u64 nS,
                                                               const u64 *__restrict__ suf, const u64 *__restrict__ pre, int k, int d,
                                                               int complements, u8 *hitS, u64 *hit_count, u64 *hit_list, u64 hit_cap, u32 G, u32 me) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u8 hit = 0;
-    u64 v = 0;
-    if (i < nS) {
-        v = actS[i];
-        Key<W> key = key_suffix(load_key<W>(suf, v), d);
-        u64 s = ov_key_is_ours(key, G, me) ? level_find(t, key, pre, k, d) : KC_NONE64;
-        if (s != KC_NONE64) {
-            atomicAnd(&t.flags[s], ~2u);
-            if (is_representative(key, d, complements)) hit = 1;
+    const u64 base = (u64)blockIdx.x * (256 * OV_ITEMS) + threadIdx.x;
+    u32 hits = 0;
+    u64 v[OV_ITEMS];
+#pragma unroll
+    for (int j = 0; j < OV_ITEMS; ++j) {
+        const u64 i = base + (u64)j * 256;
+        v[j] = 0;
+        if (i < nS) {
+            v[j] = actS[i];
+            Key<W> key = key_suffix(load_key<W>(suf, v[j]), d);
+            u64 s = ov_key_is_ours(key, G, me) ? level_find(t, key, pre, k, d) : KC_NONE64;
+            u8 hit = 0;
+            if (s != KC_NONE64) {
+                atomicAnd(&t.flags[s], ~2u);
+                if (is_representative(key, d, complements)) hit = 1;
+            }
+            hitS[i] = hit;
+            hits |= (u32)hit << j;
         }
-        hitS[i] = hit;
     }
-    ov_list_hit(hit, v, hit_count, hit_list, hit_cap);
+    ov_list_hits(hits, v, hit_count, hit_list, hit_cap);
 }
 
 template <int W>
 __global__ void __launch_bounds__(256) ov_flag_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
                                                              const u64 *__restrict__ pre, const u64 *__restrict__ pslot, int k, int d,
                                                              int complements, u8 *hitP, u64 *hit_count, u64 *hit_list, u64 hit_cap) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u8 hit = 0;
-    if (i < nP) {
-        if (pslot[i] != KC_NONE64 && !(t.flags[pslot[i]] & 2u)) {   // (KC_NONE64: the key belongs to another rank)
-            Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
-            if (is_representative(key, d, complements)) hit = 1;
+    const u64 base = (u64)blockIdx.x * (256 * OV_ITEMS) + threadIdx.x;
+    u32 hits = 0;
+    u64 v[OV_ITEMS];
+#pragma unroll
+    for (int j = 0; j < OV_ITEMS; ++j) {
+        const u64 i = base + (u64)j * 256;
+        v[j] = 0;
+        if (i < nP) {
+            u8 hit = 0;
+            if (pslot[i] != KC_NONE64 && !(t.flags[pslot[i]] & 2u)) {   // (KC_NONE64: the key belongs to another rank)
+                Key<W> key = key_prefix(load_key<W>(pre, actP[i]), k, d);
+                if (is_representative(key, d, complements)) hit = 1;
+            }
+            hitP[i] = hit;
+            if (hit) v[j] = actP[i];
+            hits |= (u32)hit << j;
         }
-        hitP[i] = hit;
     }
-    ov_list_hit(hit, hit ? actP[i] : 0, hit_count, hit_list, hit_cap);
+    ov_list_hits(hits, v, hit_count, hit_list, hit_cap);
 }
 
 // ---- levels d >= 16 through ONE table (large inputs).  A hit at level d >= 16 needs the first 16 bases of the prefix to
@@ -718,9 +763,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             cnt = fresh_cnt();
             hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                                (const u64 *)pre, k, d, pslot, PG, pme);
-            hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
+            hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid((nS + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
                                (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
-            hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
+            hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid((nP + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
                                (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
             KC_TRY(read_back(ctx, hp, cnt, 4));
             return KC_OK;
