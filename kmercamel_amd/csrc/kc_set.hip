@@ -5,6 +5,7 @@
 // 8-byte (W*8-byte) slot access of the insert.
 #include "kc_internal.h"
 #include "kc_comm.h"
+#include "kc_scan_dev.h"
 #include <chrono>
 
 // ------------------------------------------------------------------------------------------------- pool / ctx
@@ -866,7 +867,55 @@ extern "C" void kc_set_destroy(kc_set *set) {
     kc_release(ctx, set->tags);
     kc_release(ctx, set->counts);
     kc_release(ctx, set->counters);
+    kc_release(ctx, set->nbase);
     delete set;
+}
+
+// ---- dense node ids (phase 1 numbers the k-mers in slot order; kc_set_dev.h, kc_simp_dev.h).  One workgroup per block: counts[b] =
+// occupied slots of block b, and key word 0 of every empty slot = the number of occupied slots before it in the block (single-word
+// keys: under KC_ANN_MARK).  The block-build kernel of the bucketed path leaves the same words behind on its way (dense_ok stays
+// set); this sweep serves tables that saw a direct insert since.
+static void kcs_void_dense(kc_set *set) {
+    set->dense_ok = false;
+    if (set->nbase) { (void)hipStreamSynchronize(set->ctx->stream); kc_release(set->ctx, set->nbase); set->nbase = nullptr; }
+}
+template <int W>
+__global__ void __launch_bounds__(256) kc_annotate_kernel(SetView<W> set, u64 *counts) {
+    const u32 bs = 1u << set.bshift, per = bs >> 8;   // (blocks have >= 512 slots)
+    const u64 base = set.rlo + ((u64)blockIdx.x << set.bshift);
+    const u8 *tg = set.tags + base + (u64)threadIdx.x * per;
+    u32 c = 0;
+    for (u32 i = 0; i < per; ++i) c += tg[i] != 0 ? 1u : 0u;
+    u64 tot;
+    u64 at = kc_block_excl_scan((u64)c, &tot);
+    for (u32 i = 0; i < per; ++i) {
+        if (tg[i] != 0) { ++at; continue; }
+        set.keys[(base + (u64)threadIdx.x * per + i) * W] = W == 1 ? (KC_ANN_MARK | at) : at;
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+int kcs_prepare_dense(kc_set *set, u64 *n_local) {
+    kc_ctx *ctx = set->ctx;
+    const u64 nblk = (set->rcap ? set->rcap : set->cap) >> set->bshift;
+    if (!set->dense_ok || !set->nbase) {
+        if (set->bshift < 9) return kc_fail(ctx, KC_E_ARG, "blocks of fewer than 512 slots");
+        if (set->nbase) { kc_release(ctx, set->nbase); set->nbase = nullptr; }
+        KC_TRY(kc_alloc(ctx, &set->nbase, nblk + 2));
+        switch (set->W) {
+            case 1: hipLaunchKernelGGL(kc_annotate_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<1>(set), set->nbase); break;
+            case 2: hipLaunchKernelGGL(kc_annotate_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<2>(set), set->nbase); break;
+            default: hipLaunchKernelGGL(kc_annotate_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<4>(set), set->nbase); break;
+        }
+        KC_HIP(ctx, hipGetLastError());
+        KC_TRY(kcu_exclusive_scan(ctx, set->nbase, set->nbase, nblk));   // nbase[nblk] = k-mers of this table
+        set->dense_ok = true;
+        set->nid_lo = 0;
+    }
+    if (n_local) {
+        KC_HIP(ctx, hipMemcpyAsync(n_local, set->nbase + nblk, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return KC_OK;
 }
 
 int kcs_refresh_size(kc_set *set) {
@@ -884,6 +933,7 @@ template <int W> static SetView<W> view_of(const kc_set *s) { return kc_view<W>(
 // Move every k-mer (min_count == 0) or every k-mer counted >= min_count times into the freshly allocated table.
 static int kcs_rebuild(kc_set *set, u64 ncap, u64 nnblocks, u64 *nkeys, u32 *nstate, u8 *ntags, u32 min_count) {
     kc_ctx *ctx = set->ctx;
+    kcs_void_dense(set);
     kc_set to = *set;
     to.keys = nkeys; to.state = nstate; to.tags = ntags; to.cap = ncap; to.nblocks = nnblocks;
     u32 *ncounts = nullptr;
@@ -1305,6 +1355,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     return kcs_refresh_size(set);
 }
 int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved, int min_count) {
+    kcs_void_dense(set);
     if (min_count > 1 && (((size_t)1 << set->bshift) * (8 * (size_t)set->W + 3) > KC_MAX_DYN_LDS || set->bshift > 15))
         return kc_fail(set->ctx, KC_E_ARG, "-z with this table geometry is not part of the hash-sharded path");
     switch (set->W) {
@@ -1317,6 +1368,7 @@ int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
     kc_ctx *ctx = set->ctx;
     if (len == 0) return KC_OK;
+    kcs_void_dense(set);
     (void)hipEventRecord(ctx->ev[6], ctx->stream);
     int rc = bucketed_applies(set, len) ? insert_bucketed(set, d_codes, d_brk, d_low, len, case_sensitive)
                                         : insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);

@@ -40,7 +40,17 @@ template <int W> struct SetView {
     // above are biased by -rlo so that they are indexed with GLOBAL slot numbers.  One GPU: rlo = 0, rcap = cap.
     u64 rlo, rcap;
     int complements;   // strand mode of the set (the canonical orientation of a middle is the smaller of it and its reverse complement)
+    // dense node ids (phase 1, kc_simp_dev.h): the k-mers are numbered in slot order; nbase[b] = id of the first k-mer of block b
+    // (nblocks + 1 entries, valid after kcs_prepare_dense; biased like the table pointers on hash-sharded sets)
+    const u64 *nbase;
 };
+// Dense ids without a rank directory: once a table is finished (kcs_prepare_dense), the key word 0 of every EMPTY slot holds the
+// number of occupied slots before it in its block (single-word keys: under the mark below -- the top pair of a k-mer word is
+// never 11).  The id of the k-mer in slot s is then nbase[block] + ann(e) - (e - s) for the first empty slot e after s: one more
+// 8-byte load from the line (or the LDS copy) the lookup of s has just touched, instead of a second scattered line per lookup.
+#define KC_ANN_MARK ((u64)3 << 62)
+#define KC_ANN_COUNT(w) ((u64)(w) & 0xffffffffull)
+KC_HD bool kc_word_is_empty(u64 w) { return (w >> 62) == 3; }   // single-word keys: ~0 (never annotated) or mark | count
 
 // plain hashing (m == 0): `ph` = key_place_hash(key); its low 7 bits give the tag
 KC_HD u8 kc_tag_of(u64 ph) { return (u8)(0x80u | ((u32)ph & 0x7fu)); }
@@ -178,9 +188,9 @@ template <int W> __device__ __forceinline__ int set_insert_at(const SetView<W> &
             u64 slot = set_probe_slot(s, home, ghome, probes);
             unsigned long long cur = keys[slot];
             if (cur == kv) { *slot_out = slot; return 0; }
-            if (cur == ~0ULL) {
-                unsigned long long prev = atomicCAS(&keys[slot], ~0ULL, kv);
-                if (prev == ~0ULL) { set_write_tag(s, slot, pl.tag); *slot_out = slot; return 1; }
+            if (kc_word_is_empty(cur)) {   // (~0, or the count a finished table left there: kcs_prepare_dense)
+                unsigned long long prev = atomicCAS(&keys[slot], cur, kv);
+                if (prev == cur) { set_write_tag(s, slot, pl.tag); *slot_out = slot; return 1; }
                 if (prev == kv) { *slot_out = slot; return 0; }
             }
         }
@@ -271,13 +281,47 @@ template <int W> __device__ __forceinline__ u64 set_find_at(const SetView<W> &s,
 template <int W> __device__ __forceinline__ u64 set_find(const SetView<W> &s, const Key<W> &key) { return set_find_at(s, key, set_place(s, key)); }
 
 template <int W> __device__ __forceinline__ bool set_slot_full(const SetView<W> &s, u64 slot) {
-    if constexpr (W == 1) return s.keys[slot] != ~(u64)0;
+    if constexpr (W == 1) return !kc_word_is_empty(s.keys[slot]);
     else return s.state[slot] == KC_ST_FULL;
 }
 template <int W> __device__ __forceinline__ Key<W> set_key_at(const SetView<W> &s, u64 slot) {
     Key<W> r;
     for (int i = 0; i < W; ++i) r.w[i] = s.keys[slot * W + i];
     return r;
+}
+
+// ---- dense node ids <-> slots on a table prepared by kcs_prepare_dense (generic forms: a few dependent loads each; the round-1
+// kernels of phase 1 get the same numbers out of the tag windows they have in their hands, kc_simp_dev.h)
+// number of occupied slots of block `blk` before its slot offset i (0 <= i <= block size)
+template <int W> __device__ __forceinline__ u64 set_count_before(const SetView<W> &s, u64 blk, u32 i) {
+    const u32 bs = 1u << s.bshift;
+    const u64 base = blk << s.bshift;
+    const u64 hi7 = 0x8080808080808080ULL;
+    u32 e = i;
+    while (e < bs) {   // first empty slot at or after i (8 tags per unaligned load; the 8 bytes behind the table mirror its start)
+        u64 wd;
+        __builtin_memcpy(&wd, s.tags + base + e, 8);
+        u64 emp = ~wd & hi7;
+        if (bs - e < 8) emp &= ((u64)1 << (8 * (bs - e))) - 1;
+        if (emp) { e += (u32)__builtin_ctzll(emp) >> 3; break; }
+        e += 8;
+    }
+    if (e >= bs) return (s.nbase[blk + 1] - s.nbase[blk]) - (u64)(bs - i);   // occupied up to the end of the block
+    return KC_ANN_COUNT(s.keys[(base + e) * W]) - (u64)(e - i);
+}
+// id of the k-mer in the (occupied) slot
+template <int W> __device__ __forceinline__ u64 set_nid_of_slot(const SetView<W> &s, u64 slot) {
+    const u64 blk = slot >> s.bshift;
+    return s.nbase[blk] + set_count_before(s, blk, (u32)(slot - (blk << s.bshift)));
+}
+// slot of the k-mer with this id (binary searches over the block bases and inside the block: the rare paths only)
+template <int W> __device__ __forceinline__ u64 set_slot_of_nid(const SetView<W> &s, u64 nid) {
+    u64 lo = s.rlo >> s.bshift, hi = (s.rlo + s.rcap) >> s.bshift;   // largest block with nbase[blk] <= nid
+    while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (s.nbase[mid] <= nid) lo = mid; else hi = mid; }
+    const u64 blk = lo, r = nid - s.nbase[blk];
+    u32 a = 0, b = (1u << s.bshift) - 1;   // smallest offset i with count_before(i + 1) > r
+    while (a < b) { const u32 mid = (a + b) >> 1; if (set_count_before(s, blk, mid + 1) > r) b = mid; else a = mid + 1; }
+    return (blk << s.bshift) + a;
 }
 
 #endif  // __HIPCC__

@@ -400,9 +400,13 @@ __device__ __forceinline__ void kc_port_search_generic(const SetView<W> &set, in
 // (palindromic middle, local probe run exhausted): the caller then uses kc_port_search_generic, or hands the port on.
 //   LT: the home lies in block `sblk` whose tags are staged in LDS (stage_tags); SK: that block's keys are staged too.
 //   LT == 2: decided per port -- a home in block `sblk` is read from the staged copies (through flat pointers), any other from the table
-template <int W, int LT, bool SK>
+//   DN: *eoff = offset from the home of the empty slot E that ended the run.  The k-mers between a match and E are all present, so
+//   a candidate's dense node id is nbase[block] + count(E) - (E - slot); count(E) sits in the key word of E, next to the keys the
+//   search has just read (kc_port_delta)
+template <int W, int LT, bool SK, bool DN = false>
 __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, const u64 slot, int port,
-                                               const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, u64 (&cs)[4], u32 &qb, const u64 sblk = ~(u64)0) {
+                                               const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, u64 (&cs)[4], u32 &qb, const u64 sblk = ~(u64)0,
+                                               u32 *eoff = nullptr) {
     const u32 bmask = (1u << set.bshift) - 1u;
 #pragma unroll
     for (int c = 0; c < 4; ++c) cs[c] = KC_NONE64;
@@ -452,7 +456,10 @@ __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int
                     qb |= q << c;
                 }
             }
-            if (fe < 8 && !(left < 8 && fe == left)) break;          // a real empty slot: every candidate of this home has been seen
+            if (fe < 8 && !(left < 8 && fe == left)) {               // a real empty slot: every candidate of this home has been seen
+                if (DN) *eoff = off + fe;   // (the caller turns it into the id - slot difference: kc_port_delta)
+                break;
+            }
             if (left <= 8) { slow = true; break; }                    // local run exhausted: the rest may sit at the second home
             off += 8;
         }
@@ -460,6 +467,14 @@ __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int
     return !slow;
 }
 
+// (dense node id - slot) of the k-mers that sit between the home of a port and the empty slot at home + eoff that ended its run
+template <int W, bool SK>
+__device__ __forceinline__ u64 kc_port_delta(const SetView<W> &set, const u64 home, const u32 eoff, const bool staged, const u64 *stage_keys) {
+    const u32 bmask = (1u << set.bshift) - 1u;
+    const u64 eabs = home + (u64)eoff;
+    const u64 ann = (SK && staged) ? stage_keys[(size_t)((u32)eabs & bmask) * W] : set.keys[eabs * W];
+    return set.nbase[home >> set.bshift] + KC_ANN_COUNT(ann) - eabs;
+}
 // Is the stored key kk a neighbour of x on `port`?  A neighbour is x shifted by one character with the extension c at the free
 // end, or the reverse complement of that: kk XOR (the shifted x, or the shifted RC(x)) is then zero outside the extension
 // position.  (Stored keys are canonical, so a match with either strand is the canonical candidate; no candidate key is built.)
@@ -498,9 +513,11 @@ __device__ __forceinline__ bool kc_neighbour_match(const Key<W> &kk, const Key<W
 // with at most one tag match before it (then that key decides).  Anything else -- no empty slot among the 8, a second match (a tag
 // false positive or a branch), a palindromic middle -- returns false and the port is looked up by the loop version later, pooled
 // with the ports of other k-mers: inside the sweep a second loop trip for 2 of 64 lanes costs the whole wave a trip.
-template <int W, bool SK>
+// DN: sl comes back as the dense node id of the match (the home lies in the staged block, whose first id is nb0): the slots from
+// the match to the window's first empty slot are all occupied, and that empty slot's key word holds the count before it.
+template <int W, bool SK, bool DN = false>
 __device__ __forceinline__ bool kc_port_search_one(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, const u64 slot, int port,
-                                                   const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, bool &found, u32 &c, u32 &q, u64 &sl) {
+                                                   const KcPortDesc &d, const u8 *stage_tags, const u64 *stage_keys, bool &found, u32 &c, u32 &q, u64 &sl, const u64 nb0 = 0) {
     const u32 bmask = (1u << set.bshift) - 1u;
     const u32 lo7 = 0x7f7f7f7fu, hi7 = 0x80808080u, gather = 0x204081u;
     const u32 pat4 = d.pat * 0x01010101u, msk4 = d.msk * 0x01010101u;
@@ -525,6 +542,11 @@ __device__ __forceinline__ bool kc_port_search_one(const SetView<W> &set, int k,
         for (int w = 0; w < W; ++w) kk.w[w] = stage_keys[(size_t)((u32)sl & bmask) * W + w];
     } else kk = set_key_at(set, sl);
     found = kc_neighbour_match(kk, x, xr, port, k, complements, c, q) && H != 0 && sl != slot;   // (sl == slot: x itself, no self edges)
+    if (DN) {
+        const u64 es = d.home + (u64)fe;
+        const u64 ann = SK ? stage_keys[(size_t)((u32)es & bmask) * W] : set.keys[es * W];
+        sl = nb0 + KC_ANN_COUNT(ann) - (u64)(fe - j);   // (no match: j = 8 > fe, the value is not used)
+    }
     return true;
 }
 
@@ -616,13 +638,14 @@ __device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *
     const u64 (&cslot)[8] = cd.cslot;
     const u32 qbits = cd.qbits;
     const bool xpal = cd.xpal;
-    // every ~256th k-mer (by slot) is a splitter: chains are walked segment-wise between splitters
-    const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;
+    // every 256th k-mer (by dense id) is a splitter: chains are walked segment-wise between splitters
+    const u64 nid = set_nid_of_slot(set, slot);
+    const u64 splitbit = ((nid & 0xffull) == 0) ? LK_SPLIT : 0;
 #pragma unroll
     for (int port = 0; port < 2; ++port) {
-        const u64 pid = (slot << 1) | (u64)port;
+        const u64 pid = (nid << 1) | (u64)port;
         if (port == 1 && xpal) {
-            link[pid] = LK_DEAD | splitbit;
+            link[pid] = LK_MAKE(LK_DEAD, 0, 0, slot) | splitbit;
             if (complements) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);
             continue;
         }
@@ -641,7 +664,7 @@ __device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *
             u64 pr = kc_mix64(kc_port_term(hxk, port) + kc_port_term(key_hash(y), q));
             if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bbase = port ? c : 3 - c; }
         }
-        link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, bbase, bslot) : LK_DEAD) | splitbit;
+        link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, bbase, set_nid_of_slot(set, bslot)) : LK_MAKE(LK_DEAD, 0, 0, slot)) | splitbit;
         if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
         if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);   // branch port: it has to reject the others
     }
@@ -691,13 +714,16 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
 // ("external") ports are then looked up in global memory with every lane busy -- handled inline they made each sweep step of
 // every wave wait for two dependent global round trips on behalf of a few lanes (measured: waves waited 70 % of their cycles).
 // LDS: tags + keys + the two lists = 76 KB for 8192-slot blocks of 64-bit keys, two workgroups per CU (80 KB each did not fit twice).
+// `nid` = dense id of the k-mer in `slot`; cs[] (+ delta) = dense ids of the candidates.  A DEAD word carries the SLOT of its own k-mer:
+// chain ends are where a key is needed (orientation, order, first k-mer), and the walks have that word in their hands there.
 template <int W>
-__device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 slot, const int port, const Key<W> &x,
+__device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 nid, const u64 slot, const int port, const Key<W> &x,
                                                const Key<W> &xr, const u64 (&cs)[4], const u32 qb, u64 *heads, u64 heads_shard_cap, u64 *heads_cursors,
-                                               u64 *branch, u64 branch_shard_cap, u64 *branch_cursors) {
-    // every ~256th k-mer (by slot) is a splitter: chains are walked segment-wise between splitters
-    const u64 splitbit = ((slot & 0xffull) == 0) ? LK_SPLIT : 0;
-    const u64 pid = (slot << 1) | (u64)port;
+                                               u64 *branch, u64 branch_shard_cap, u64 *branch_cursors, const u64 delta = 0) {
+    // (cs[] + delta = the candidates' dense ids: the block kernel passes slots and the one difference its window search found)
+    // every 256th k-mer (by id) is a splitter: chains are walked segment-wise between splitters
+    const u64 splitbit = ((nid & 0xffull) == 0) ? LK_SPLIT : 0;
+    const u64 pid = (nid << 1) | (u64)port;
     int nfound = 0;
     u32 bc = 0, bq = 0;
     u64 bslot = 0;
@@ -722,7 +748,7 @@ __device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 
     }
     if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
     if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);
-    return (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot) : LK_DEAD) | splitbit;
+    return (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot + delta) : LK_MAKE(LK_DEAD, 0, 0, slot)) | splitbit;
 }
 
 // ---- lists of the hash-sharded flow's round 1 (kc_shard.hip): queries for the ports another rank answers, the edges of branch ports
@@ -796,16 +822,23 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                                                             u64 branch_shard_cap, u64 *branch_cursors, u64 *spill, u64 spill_cap,
                                                             u64 *spill_cursor, ShLists L = ShLists{}) {
     constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM), WBYTES = KC_PROBE_SSTACK * 2 + ECAP * (MM ? 6 : 2);
+    // DN (single-GPU flow): link words are addressed by DENSE node ids and carry dense ids -- 16 bytes per K-MER, written
+    // contiguously (the k-mers of a block are numbered in slot order from set.nbase[block] on), not 16 bytes per slot of a table at
+    // load 0.5 written in 64-byte pieces.  The hash-sharded flow (SH) still numbers its ports by slot.
+    constexpr bool DN = !SH;
     // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
-    // [w bs/8, (w+1) bs/8) in rows of 64, pushes the occupied ones on its own stack and takes 64 off it whenever that many wait, so
+    // [w bs/8, (w+1) bs/8) in rows of 64, queues the occupied ones and takes 64 off the queue whenever that many wait, so
     // every step runs with all lanes busy and no wave ever waits for another (with block-wide lists and barriers every stretch
     // ended in a nearly empty step that the other seven waves sat out: 4.1 ms against 3.6 ms per 10^8 k-mers).  A port that the
     // one-window search does not settle (home in another block: ~10 %; second match or no empty slot in the window: ~5 %) goes on
-    // the wave's second stack with the minimizer hash of its middle, and is looked up in global memory 64 at a time.
-    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][per wave: slot stack u16 x 128, port stack u16 x ECAP (+ u32 x ECAP)]
+    // the wave's port stack with the minimizer hash of its middle, and is looked up in global memory 64 at a time.
+    // The slot queue is first-in first-out (a ring of 128): the j-th k-mer a wave takes is the j-th occupied slot of its share, so a
+    // lane knows its dense id without looking anything up, and the 64 lanes of a step write 1 KB of consecutive link words.
+    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][per wave: slot ring u16 x 128, port stack u16 x ECAP (+ u32 x ECAP)]
     // Single-word keys: 1024 threads and port stacks without the hash = 79 KB, two workgroups per CU = 8 waves per SIMD (the kernel
     // waits on LDS and memory more than it issues: at 4 waves per SIMD its VALU pipes were half idle).
     extern __shared__ ulonglong2 kc_pb[];
+    __shared__ u32 kc_wcnt[NT / 64];
     const int k = KC ? KC : k_rt;
     const int m = KC ? KC_MSPEC : set.m;
     const u64 lblk = kc_xcd_block_id(xcd_aware & 1);   // (SH: index among this rank's blocks)
@@ -830,6 +863,21 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         }
     }
     __syncthreads();
+    const u32 per_wave = bs / KC_PROBE_WAVES, rows = (per_wave + 63) / 64;
+    // DN: the number of k-mers in the shares of the waves before this one (the dense id of this wave's first k-mer)
+    u64 nb0 = 0;
+    u32 wfirst = 0;
+    if (DN) {
+        u32 mine = 0;
+        for (u32 row = 0; row < rows; ++row) {
+            const u32 off = row * 64 + (u32)lane, so = (u32)wv * per_wave + off;
+            mine += (u32)__popcll(__ballot(off < per_wave && st[so] != 0));
+        }
+        if (lane == 0) kc_wcnt[wv] = mine;
+        __syncthreads();
+        for (int i = 0; i < wv; ++i) wfirst += kc_wcnt[i];
+        nb0 = set.nbase[blk];
+    }
     auto load_x = [&](u32 so) {
         Key<W> r;
         if (SK) {
@@ -838,7 +886,23 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         } else r = set_key_at(set, base + so);
         return r;
     };
-    auto to_spill = [&](u64 pid) {
+    // DN: k-mers of this block before slot offset `so` (occupied), from the staged tags and the count in the next empty slot
+    auto local_rank = [&](u32 so) -> u64 {
+        const u64 hi7 = 0x8080808080808080ULL;
+        u32 e = so + 1;
+        while (e < bs) {
+            u64 wd;
+            __builtin_memcpy(&wd, st + e, 8);   // (the bytes behind the tags are LDS of this workgroup: masked below)
+            u64 emp = ~wd & hi7;
+            if (bs - e < 8) emp &= ((u64)1 << (8 * (bs - e))) - 1;
+            if (emp) { e += (u32)__builtin_ctzll(emp) >> 3; break; }
+            e += 8;
+        }
+        if (e >= bs) return (set.nbase[blk + 1] - nb0) - (u64)(bs - so);
+        const u64 ann = SK ? sk[(size_t)e * W] : set.keys[(base + e) * W];
+        return KC_ANN_COUNT(ann) - (u64)(e - so);
+    };
+    auto to_spill = [&](u64 pid) {   // (by SLOT: the spill kernels find the dense id themselves)
         const u64 at = atomicAdd((ull *)spill_cursor, 1ULL);
         if (at < spill_cap) spill[at] = pid;
         else if (SH) L.flags[0] = 1;   // (the sharded flow repeats the sweep with larger lists)
@@ -869,7 +933,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             remote = SH && d.home - set.rlo >= set.rcap;
             if (!remote) {
                 u64 cs[4]; u32 qb;
-                const bool ok = kc_port_search<W, 2, SK>(set, k, complements, x, xr, slot, port, d, st, sk, cs, qb, (xcd_aware & 2) ? ~(u64)0 : blk);   // (bit 1: test knob, table reads only)
+                u32 eoff = 0;
+                const u64 sblk = (xcd_aware & 2) ? ~(u64)0 : blk;   // (bit 1: test knob, table reads only)
+                const bool ok = kc_port_search<W, 2, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, cs, qb, sblk, &eoff);
                 if (!ok) to_spill((slot << 1) | (u64)port);   // (rare: generic lookups in a kernel of their own keep this one lean)
                 else if (SH) {
                     // at most one candidate: the word; a branch port is settled (and lists its edges) in the spill kernel
@@ -881,8 +947,12 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     if (nf >= 2) to_spill((slot << 1) | (u64)port);
                     else link[(slot << 1) | (u64)port] = nf ? LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, bs1) : LK_DEAD;
                 }
-                else link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch,
-                                                                        branch_shard_cap, branch_cursors);
+                else {
+                    const u64 delta = kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk);
+                    const u64 nid = nb0 + local_rank(so);
+                    link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch,
+                                                                     branch_shard_cap, branch_cursors, delta);
+                }
             }
         }
         if (SH) {   // query space: one reservation per wave and call
@@ -906,8 +976,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             }
         }
     };
-    u32 scnt = 0, ecnt = 0;   // entries on the two stacks (wave-uniform)
-    const u32 per_wave = bs / KC_PROBE_WAVES, rows = (per_wave + 63) / 64;
+    u32 shead = 0, stail = 0, ecnt = 0;   // slot ring: taken / queued so far; entries on the port stack (all wave-uniform)
 #pragma unroll 1
     for (u32 row = 0; row <= rows; ++row) {
         const bool drain = row == rows;
@@ -915,13 +984,13 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             const u32 off = row * 64 + (u32)lane, so = (u32)wv * per_wave + off;
             const bool occ = off < per_wave && st[so] != 0;
             const unsigned long long mk = __ballot(occ);
-            if (occ) sstack[scnt + (u32)__popcll(mk & ltm)] = (unsigned short)so;
-            scnt += (u32)__popcll(mk);
+            if (occ) sstack[(stail + (u32)__popcll(mk & ltm)) & (KC_PROBE_SSTACK - 1)] = (unsigned short)so;
+            stail += (u32)__popcll(mk);
             wave_sync();
         }
 #pragma unroll 1
-        while (scnt >= 64 || ecnt >= 64 || (drain && (scnt | ecnt))) {
-            if (ecnt >= 64 || (drain && scnt == 0)) {
+        while (stail - shead >= 64 || ecnt >= 64 || (drain && ((stail - shead) | ecnt))) {
+            if (ecnt >= 64 || (drain && stail == shead)) {
                 // ---- 64 listed ports (fewer when draining): generic window search in global memory
                 const u32 take = ecnt < 64 ? ecnt : 64;
                 ecnt -= take;
@@ -931,16 +1000,20 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 wave_sync();
                 continue;
             }
-            // ---- 64 k-mers (fewer when draining)
+            // ---- 64 k-mers (fewer when draining), oldest first
+            const u32 scnt = stail - shead;
             const u32 take = scnt < 64 ? scnt : 64;
-            scnt -= take;
             const bool active = (u32)lane < take;
-            const u32 so = active ? sstack[scnt + lane] : 0u;
+            const u32 so = active ? sstack[(shead + (u32)lane) & (KC_PROBE_SSTACK - 1)] : 0u;
             const u64 slot = base + so;
+            const u32 rank = wfirst + shead + (u32)lane;                           // (DN) this k-mer's number within the block
+            shead += take;
+            auto own = [&]() -> u64 { return DN ? nb0 + (u64)rank : slot; };        // what a port of this k-mer is numbered by
             const Key<W> x = load_x(so);
             const Key<W> xr = key_rc(x, k);
             const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
-            const u64 splitbit = (!SH && (slot & 0xffull) == 0) ? LK_SPLIT : 0;    // every ~256th k-mer (by slot) is a splitter of the segment-parallel walks
+            const bool split = !SH && (((u32)nb0 + rank) & 0xffu) == 0;            // every 256th k-mer is a splitter of the segment-parallel walks
+            auto deadw = [&]() -> u64 { return DN ? LK_MAKE(LK_DEAD, 0, 0, slot) : LK_DEAD; };   // (a dead port's word carries the slot of its k-mer)
             u32 minL, minR;
             kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
             u64 wd0 = 0, wd1 = 0;
@@ -952,16 +1025,16 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 const u32 mmh = port ? minR : minL;
                 if (active) {
                     if (port == 1 && xpal) {   // palindromes link on port L only
-                        word = LK_DEAD | splitbit;
+                        word = deadw();
                         done = true;
-                        if (!SH && complements) kc_push_sharded((slot << 1) | 1, heads, heads_shard_cap, heads_cursors);
+                        if (!SH && complements) kc_push_sharded((own() << 1) | 1, heads, heads_shard_cap, heads_cursors);
                     } else {
                         const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
                         bool found; u32 c, q; u64 sl;
-                        if ((d.home >> set.bshift) == blk && kc_port_search_one<W, SK>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl)) {
-                            word = (found ? LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) : LK_DEAD) | splitbit;
+                        if ((d.home >> set.bshift) == blk && kc_port_search_one<W, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl, nb0)) {
+                            word = found ? LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) : deadw();
                             done = true;
-                            if (!SH && !found && (complements || port == 0)) kc_push_sharded((slot << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+                            if (!SH && !found && (complements || port == 0)) kc_push_sharded((own() << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
                         } else defer = true;
                     }
                 }
@@ -975,10 +1048,12 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 }
                 if (done) { if (port) wd1 = word; else wd0 = word; have |= 1u << port; }
             }
-            // both words of a slot in one 16-byte store whenever both ports were settled here
-            if (have == 3u) *reinterpret_cast<ulonglong2 *>(link + (slot << 1)) = make_ulonglong2(wd0, wd1);
-            else if (have == 1u) link[slot << 1] = wd0;
-            else if (have == 2u) link[(slot << 1) | 1] = wd1;
+            // both words of a k-mer in one 16-byte store whenever both ports were settled here
+            if (split) { wd0 |= LK_SPLIT; wd1 |= LK_SPLIT; }
+            u64 *lw = link + (own() << 1);
+            if (have == 3u) *reinterpret_cast<ulonglong2 *>(lw) = make_ulonglong2(wd0, wd1);
+            else if (have == 1u) lw[0] = wd0;
+            else if (have == 2u) lw[1] = wd1;
             wave_sync();
         }
     }
@@ -991,13 +1066,17 @@ __global__ void __launch_bounds__(256) kc_probe_spill_kernel(SetView<W> set, u64
     u64 n = *spill_cursor;
     if (n > spill_cap) n = spill_cap;   // (overflow: the caller redoes round 1 with the generic kernel)
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
-        const u64 pid = spill[t], slot = pid >> 1;
+        const u64 pid = spill[t], slot = pid >> 1;   // (listed by slot)
         const int port = (int)(pid & 1);
         const Key<W> x = set_key_at(set, slot);
         const Key<W> xr = key_rc(x, k);
         u64 cs[4]; u32 qb;
         kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
-        link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cs[c] != KC_NONE64) cs[c] = set_nid_of_slot(set, cs[c]);
+        const u64 nid = set_nid_of_slot(set, slot);
+        link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
     }
 }
 
@@ -1044,15 +1123,19 @@ __global__ void __launch_bounds__(256) kc_probe_generic_kernel(SetView<W> set, u
     const Key<W> x = set_key_at(set, slot);
     const Key<W> xr = key_rc(x, k);
     const bool xpal = complements && key_eq(x, xr);
+    const u64 nid = set_nid_of_slot(set, slot);
     for (int port = 0; port < 2; ++port) {
         if (port == 1 && xpal) {
-            link[(slot << 1) | 1] = LK_DEAD | (((slot & 0xffull) == 0) ? LK_SPLIT : 0);
-            if (complements) kc_push_sharded((slot << 1) | 1, heads, heads_shard_cap, heads_cursors);
+            link[(nid << 1) | 1] = LK_MAKE(LK_DEAD, 0, 0, slot) | (((nid & 0xffull) == 0) ? LK_SPLIT : 0);
+            if (complements) kc_push_sharded((nid << 1) | 1, heads, heads_shard_cap, heads_cursors);
             continue;
         }
         u64 cs[4]; u32 qb;
         kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
-        link[(slot << 1) | (u64)port] = kc_choose_port<W>(k, complements, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cs[c] != KC_NONE64) cs[c] = set_nid_of_slot(set, cs[c]);
+        link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
     }
 }
 
@@ -1076,13 +1159,15 @@ struct KcRec {
 // it depends on the matching only.  The k-mers on cycles are few: their rows and candidate edges come to the host, which walks
 // the cycles and decides; the same code serves the hash-sharded flow.
 // row of a k-mer on a cycle: {slot, link word of port L, link word of port R, key[W]}
-template <int W>
+// (DN: the k-mers are listed, and the ports numbered, by dense node id -- the single-GPU flow; else by slot)
+template <int W, bool DN = false>
 __global__ void __launch_bounds__(256) kc_cycle_rows_kernel(SetView<W> set, const u64 *__restrict__ link, const u64 *__restrict__ list, u64 n, u64 *rows) {
     const u64 t = kc_gtid();
     if (t >= n) return;
-    const u64 slot = list[t];
+    const u64 id = list[t];
+    const u64 slot = DN ? set_slot_of_nid(set, id) : id;
     u64 *r = rows + t * (3 + W);
-    r[0] = slot; r[1] = link[slot << 1]; r[2] = link[(slot << 1) | 1];
+    r[0] = id; r[1] = link[id << 1]; r[2] = link[(id << 1) | 1];
     const Key<W> key = set_key_at(set, slot);
     for (int w = 0; w < W; ++w) r[3 + w] = key.w[w];
 }
@@ -1104,9 +1189,9 @@ __global__ void __launch_bounds__(256) kc_cycle_cand_kernel(SetView<W> set, cons
                                                             u64 *cand, u64 cand_cap, u64 *cursor) {
     const u64 t = kc_gtid();
     if (t >= 2 * n) return;
-    const u64 slot = list[t >> 1];
+    const u64 nid = list[t >> 1];   // (single-GPU flow: dense node ids)
     const int port = (int)(t & 1);
-    const Key<W> x = set_key_at(set, slot);
+    const Key<W> x = set_key_at(set, set_slot_of_nid(set, nid));
     const Key<W> xr = key_rc(x, k);
     const u64 hx = key_hash(x);
     for (u32 c = 0; c < 4; ++c) {
@@ -1115,17 +1200,22 @@ __global__ void __launch_bounds__(256) kc_cycle_cand_kernel(SetView<W> set, cons
         if (key_eq(y, x)) continue;
         const u64 ys = set_find(set, y);
         if (ys == KC_NONE64) continue;
-        const u64 yw = link[(ys << 1) | (u64)q];
+        const u64 yn = set_nid_of_slot(set, ys);
+        const u64 yw = link[(yn << 1) | (u64)q];
         if (LK_STATE(yw) != LK_DEAD || (yw & LK_CUT)) continue;
-        kc_cycle_cand_emit<W>(x, hx, slot, port, y, ys, q, k, cand, cand_cap, cursor);
+        kc_cycle_cand_emit<W>(x, hx, nid, port, y, yn, q, k, cand, cand_cap, cursor);
     }
 }
-// write the decided link words {pid, word} (single-GPU flow: the splitter flag of the port stays)
-static __global__ void __launch_bounds__(256) kc_cycle_fix_kernel(u64 *link, const u64 *__restrict__ fix, u64 n) {
+// write the decided link words {pid, word} (single-GPU flow: the splitter flag of the port stays; a port that dies gets the slot of
+// its k-mer into its word, like every dead port)
+template <int W>
+__global__ void __launch_bounds__(256) kc_cycle_fix_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ fix, u64 n) {
     const u64 t = kc_gtid();
     if (t >= n) return;
     const u64 pid = fix[2 * t];
-    link[pid] = fix[2 * t + 1] | (link[pid] & LK_SPLIT);
+    u64 w = fix[2 * t + 1];
+    if (LK_STATE(w) == LK_DEAD) w |= set_slot_of_nid(set, pid >> 1) << 6;
+    link[pid] = w | (link[pid] & LK_SPLIT);
 }
 // the head list after the cycles were opened: the old heads that are still dead (one that a cycle was attached to is not) and the
 // ports that died.  A dead port is the entry of a directed chain (unidirectional sets: the L ports only, cf. kc_push_head).
@@ -1247,49 +1337,54 @@ static inline u64 kc_cycles_decide(const std::vector<u64> &rows, u64 n, const st
 #define KC_SC_NEXT_MAX 7
 #define KC_FRAG_LONGS 512       /* runs of more than 20 nodes per block that get pool space (expected ~100) */
 #define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
-template <int W>
+// DN (single-GPU flow): the links are addressed by dense node ids, so the block's link words are the contiguous range
+// [nbase[blk], nbase[blk + 1]) x 16 bytes -- no tag bytes are read and no empty slot's words are streamed.  A shortcut then names
+// its far node by the signed distance in ids (bits 6-19, two's complement) and a pool run by its absolute first word (bits 35-63),
+// so the hop walk needs no block arithmetic.
+template <int W, bool DN = false>
 __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
                                                                 u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log,
                                                                 u64 *ent_out = nullptr, u64 ent_cap = 0, u64 *ent_cursor = nullptr) {
     // ent_out (hash-sharded flow): the block's ENTRIES are listed on the way -- oriented nodes (slot << 1 | o) whose entry port o is
     // dead or matched to a slot of another rank, i.e. the starts of this rank's chain fragments (the link words are in registers
     // here anyway; a sweep of their own over 16 bytes per slot cost 15 ms per 10^9 k-mers).  One reservation per block.
-    // LDS: per port of the block one 32-bit word -- bit 31: matched to a slot of this block; then bits 0-13 that slot's offset,
+    // LDS: per port of the block one 32-bit word -- bit 31: matched to a node of this block; then bits 0-13 that node's offset,
     // bit 14 the port entered there, bits 15-16 the appended base -- then the list of long runs and the list of fragment ends.
     // (76 KB for 8192-slot blocks: two workgroups share a CU.)
     extern __shared__ u32 kc_fl[];
     __shared__ u32 n_long, n_words, n_ent;
     const u32 bs = 1u << set.bshift;
     const u64 blk = (set.rlo >> set.bshift) + blockIdx.x;   // (hash-sharded tables: the blocks of this rank; pool / log arrays are indexed by the LOCAL block)
-    const u64 base = blk << set.bshift;
+    const u64 base = DN ? set.nbase[blk] : blk << set.bshift;                       // first node of the block (DN: dense id, else slot)
+    const u32 nn = DN ? (u32)(set.nbase[blk + 1] - set.nbase[blk]) : bs;            // nodes (DN) / slots of the block
     const u64 lblk = blockIdx.x;
     u32 *longs = kc_fl + 2 * (size_t)bs;                            // (local port id of the entry, first pool word)
     const u32 long_cap = KC_FRAG_LONGS, fe_cap = KC_FRAG_ENTRIES;
     unsigned short *ents = reinterpret_cast<unsigned short *>(longs + 2 * long_cap);   // local port ids of the fragment ends
     if (threadIdx.x == 0) { n_long = 0; n_words = 0; n_ent = 0; }
-    // one 16-byte load per slot (both port words) and one tag byte; bit 30 of the digest = the slot is occupied
+    // one 16-byte load per node (both port words) and (slot-addressed links) one tag byte; bit 30 of the digest = occupied
     u32 emask = 0;   // bit 2 i + p: port p of the slot of sweep step i is an entry
     int step = 0;
-    for (u32 s = threadIdx.x; s < bs; s += blockDim.x, ++step) {
-        const bool occ = set.tags[base + s] != 0;
+    for (u32 s = threadIdx.x; s < nn; s += blockDim.x, ++step) {
+        const bool occ = DN ? true : set.tags[base + s] != 0;
         const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(link + (base + s) * 2);
         const u64 w2[2] = {ww.x, ww.y};
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const u64 w = w2[p];
-            const bool in = occ && LK_IS_MATCHED(w) && (LK_SLOT(w) >> set.bshift) == blk;
+            const bool in = occ && LK_IS_MATCHED(w) && (DN ? LK_SLOT(w) - base < (u64)nn : (LK_SLOT(w) >> set.bshift) == blk);
             // (bits 17-18: state MATCHED rather than CHOICE, splitter flag -- with them the word of an in-block link can be rebuilt
             // exactly from the digest, so the log below needs no second, scattered read of the link array)
             kc_fl[2 * s + p] = (occ ? 0x40000000u : 0u) |
-                               (in ? (0x80000000u | ((u32)LK_SLOT(w) & (bs - 1)) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15) |
+                               (in ? (0x80000000u | (u32)(LK_SLOT(w) - base) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15) |
                                       (LK_STATE(w) == LK_MATCHED ? 1u << 17 : 0u) | ((w & LK_SPLIT) ? 1u << 18 : 0u)) : 0u);
-            if (ent_out && occ && (p == 0 || complements) && step < 16 &&
+            if (!DN && ent_out && occ && (p == 0 || complements) && step < 16 &&
                 (LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - set.rlo >= set.rcap)))
                 emask |= 1u << (2 * step + p);
         }
     }
     __syncthreads();
-    if (ent_out) {   // (uniform: every thread of the workgroup takes part)
+    if (!DN && ent_out) {   // (uniform: every thread of the workgroup takes part)
         __shared__ u32 e_wsum[16];
         __shared__ u64 e_base;
         const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1329,14 +1424,16 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         if (fill && nacc) ext[wi] = acc << (64 - 2 * nacc);
         far = cur; fo = co;
     };
+    // the far node as a shortcut names it: its offset in the block, or (DN) its signed distance from the end node s
+    auto far_field = [&](u32 far, u32 s) -> u64 { return DN ? (u64)((far - s) & 0x3fffu) : (u64)far; };
     // The fragment ends first go into a list (one LDS atomic per wavefront and sweep step: ballot + popcount), so that the walks
     // below run with every lane busy -- walking straight from the slot sweep kept ~3 of 64 lanes active.
     const int lane = threadIdx.x & 63;
-    for (u32 s0 = 0; s0 < bs; s0 += blockDim.x) {
+    for (u32 s0 = 0; s0 < nn; s0 += blockDim.x) {
         const u32 s = s0 + threadIdx.x;
         for (int o = 0; o < (complements ? 2 : 1); ++o) {
             // an end of a run of >= 2 nodes: occupied, not entered from inside the block, left towards a slot of the block
-            const u32 f_in = s < bs ? kc_fl[2 * s + o] : 0u, f_out = s < bs ? kc_fl[2 * s + (o == 0 ? 1 : 0)] : 0u;   // (blocks of < 1024 slots: KC_BSHIFT)
+            const u32 f_in = s < nn ? kc_fl[2 * s + o] : 0u, f_out = s < nn ? kc_fl[2 * s + (o == 0 ? 1 : 0)] : 0u;   // (blocks of < 1024 slots: KC_BSHIFT)
             const bool is_end = (f_in & 0x40000000u) && !(f_in >> 31) && (f_out >> 31);
             const unsigned long long m = __ballot(is_end);
             if (!m) continue;
@@ -1372,14 +1469,14 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
             log[lbase + e] = orig | ((u64)(2 * s + xp) << 46);
         }
         // runs of up to 8 nodes whose far end is matched onwards also carry that onward link (the walk then skips the far end's
-        // line altogether): bit 3 set, bits 6-41 next slot, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
+        // line altogether): bit 3 set, bits 6-41 next node, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
         // inside the run, bits 48-61 those bases
         const u64 wfar = (len - 1 <= KC_SC_NEXT_MAX) ? link[(base + far) * 2 + (fo == 0 ? 1u : 0u)] : 0;
-        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && LK_SLOT(wfar) < ((u64)1 << 36) && LK_SLOT(wfar) - set.rlo < set.rcap) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
+        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && LK_SLOT(wfar) < ((u64)1 << 36) && (DN || LK_SLOT(wfar) - set.rlo < set.rcap)) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
             link[(base + s) * 2 + xp] = LK_REJ | KC_SC_NEXT | (LK_SLOT(wfar) << 6) | (LK_PORT(wfar) << 42) | (LK_BASE(wfar) << 43) | ((u64)(len - 1) << 45) |
                                         ((bases >> 24) << 48);
         } else if (len - 1 <= KC_SC_INLINE_MAX) {
-            link[(base + s) * 2 + xp] = LK_REJ | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
+            link[(base + s) * 2 + xp] = LK_REJ | (far_field(far, s) << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | (bases << 26);
         } else {
             const u32 nw = (len - 1 + 31) / 32;
             const u32 at = atomicAdd(&n_long, 1u);
@@ -1400,20 +1497,22 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         u32 far, len; int fo; u64 bases;
         walk(s, o, far, fo, len, bases, pool + pbase + rel, true);
         const u32 xp = o == 0 ? 1u : 0u;
-        link[(base + s) * 2 + xp] = LK_REJ | KC_SC_EXT | ((u64)far << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | ((u64)rel << 35);
+        link[(base + s) * 2 + xp] = LK_REJ | KC_SC_EXT | (far_field(far, s) << 6) | ((u64)fo << 20) | ((u64)(len - 1) << 21) | ((DN ? pbase + (u64)rel : (u64)rel) << 35);
     }
 }
 
 // puts the logged link words back (the hop walk met a chain beyond the limit, or the input has cycles: the classic flow
-// takes over on the original links)
-static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, const u64 *__restrict__ log, const u64 *__restrict__ blk_log, int bshift, u64 blk0) {
+// takes over on the original links).  nbase != nullptr: links addressed by dense node ids (first id of every block).
+static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, const u64 *__restrict__ log, const u64 *__restrict__ blk_log, int bshift, u64 blk0,
+                                                                     const u64 *__restrict__ nbase = nullptr) {
     const u64 blk = blockIdx.x;
     const u64 e = blk_log[blk];
     const u32 n = (u32)(e & 0xffffu);
     const u64 lb = e >> 16;
+    const u64 first = nbase ? nbase[blk0 + blk] : (blk0 + blk) << bshift;
     for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
         const u64 w = log[lb + i];
-        link[(((blk0 + blk) << bshift) << 1) + ((w >> 46) & 0x3fffu)] = w & ~(0x3fffull << 46);
+        link[(first << 1) + ((w >> 46) & 0x3fffu)] = w & ~(0x3fffull << 46);
     }
 }
 

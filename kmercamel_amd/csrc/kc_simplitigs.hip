@@ -24,8 +24,8 @@ __global__ void __launch_bounds__(256) kc_reject_kernel(SetView<W> set, u64 *lin
                                                         u64 nbranch, u64 *work_out, u64 work_cap, u64 *cursor) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbranch) return;
-    const u64 pid = branch[t];
-    const u64 slot = pid >> 1;
+    const u64 pid = branch[t];   // (ports are numbered by dense node id: kc_set_dev.h)
+    const u64 slot = set_slot_of_nid(set, pid >> 1);
     const int port = (int)(pid & 1);
     const Key<W> x = set_key_at(set, slot);
     const u64 chosen = LK_PID(link[pid]);
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) kc_reject_kernel(SetView<W> set, u64 *lin
         if (key_eq(y, x)) continue;
         u64 tslot = set_find(set, y);
         if (tslot == KC_NONE64) continue;
-        u64 cpid = (tslot << 1) | (u64)q;
+        u64 cpid = (set_nid_of_slot(set, tslot) << 1) | (u64)q;
         if (cpid == chosen) continue;
         u64 wc = link[cpid];   // round-1 words are stable here apart from their LK_REJ bit
         if (LK_STATE(wc) == LK_CHOICE && LK_PID(wc) == pid) {   // it chose this port, this port chose another: void, round 2
@@ -62,16 +62,17 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
                                                         const u64 *__restrict__ work, u64 nwork, int xcd_aware, u64 *heads,
                                                         u64 heads_cap, u64 *heads_cursor) {
     const int k = KC ? KC : k_rt;
-    u64 t = (FIRST ? kc_xcd_block_id(xcd_aware) : (u64)blockIdx.x) * blockDim.x + threadIdx.x;
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    (void)xcd_aware;
     if (t >= nwork) return;
-    u64 pid = FIRST ? t : work[t];
-    u64 slot = pid >> 1;
+    static_assert(!FIRST, "round 1 is kc_probe_block_kernel / kc_choose_dense_kernel");
+    u64 pid = work[t];   // (dense node id << 1 | port)
+    u64 slot = set_slot_of_nid(set, pid >> 1);
     int port = (int)(pid & 1);
-    if (FIRST) { if (!set_slot_full(set, slot)) return; }
     Key<W> x = set_key_at(set, slot);
     Key<W> xr = key_rc(x, k);
     if (complements && port == 1 && key_eq(x, xr)) {   // palindromes link on port L only
-        link[pid] = LK_DEAD | (link[pid] & LK_SPLIT);
+        link[pid] = LK_MAKE(LK_DEAD, 0, 0, slot) | (link[pid] & LK_SPLIT);
         kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
         return;
     }
@@ -96,7 +97,8 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         if (key_eq(y, x)) continue;
         u64 tslot = set_find(set, y);
         if (tslot == KC_NONE64) continue;
-        if (!FIRST) {
+        tslot = set_nid_of_slot(set, tslot);   // from here on: the candidate's dense id
+        {
             u64 wt = link[(tslot << 1) | (u64)q];
             if (LK_IS_MATCHED(wt)) continue;
         }
@@ -107,40 +109,30 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
         if (edge_preferred(x, port, y, q, pr, by, bq, bpr)) { by = y; bq = q; bpr = pr; bslot = tslot; bbase = port ? c : 3 - c; }
     }
     // FIRST is no longer launched (round 1 = kc_choose_dense_kernel); later rounds mark their choice as tentative
-    link[pid] = (nfound ? (LK_MAKE(LK_CHOICE, bq, bbase, bslot) | (FIRST ? 0 : LK_REJ)) : LK_DEAD) | (link[pid] & LK_SPLIT);
+    link[pid] = (nfound ? (LK_MAKE(LK_CHOICE, bq, bbase, bslot) | LK_REJ) : LK_MAKE(LK_DEAD, 0, 0, slot)) | (link[pid] & LK_SPLIT);
     if (!nfound) kc_push_head(pid, complements, heads, heads_cap, heads_cursor);
 }
 
 // Fallback for heavily branching graphs (the branch list overflowed): check every round-1 choice against its target
 // directly. FILL = false counts the unreciprocated ports, FILL = true marks them LK_REJ and lists them.
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, const u8 *__restrict__ tags, u64 cap, u64 *work_out, u64 *cursor) {
-    // a thread takes 32 slots (8-byte loads of their tag bytes): the table is sized by k-mer OCCURRENCES, so inputs with
-    // coverage leave most slots empty and the sweep, not the work, was the cost (36 ms per 10^9 slots with one thread per slot)
-    const u64 slot0 = kc_gtid() * 32;   // 32 slots per thread: four 8-byte loads of tag bytes
-    u64 m = 0;   // bit 2i+p: port p of slot0+i is an unreciprocated choice
-    for (int g8 = 0; g8 < 4; ++g8) {
-        const u64 s8 = slot0 + 8 * (u64)g8;
-        if (s8 >= cap) break;
-        u64 tg = 0;
-        if (s8 + 8 <= cap) tg = *reinterpret_cast<const u64 *>(tags + s8);
-        else for (u64 i = 0; s8 + i < cap; ++i) tg |= (u64)tags[s8 + i] << (8 * i);
-        for (int i = 0; tg != 0 && i < 8; ++i) {
-            if (!((tg >> (8 * i)) & 0xff)) continue;
-            for (int port = 0; port < 2; ++port) {
-                const u64 pid = ((s8 + (u64)i) << 1) | (u64)port;
-                u64 w = link[pid];
-                if (LK_STATE(w) != LK_CHOICE) continue;
-                u64 wt = link[LK_PID(w)];   // only LK_REJ bits change concurrently
-                if (LK_STATE(wt) == LK_CHOICE && LK_PID(wt) == pid) continue;
-                m |= (u64)1 << (16 * g8 + 2 * i + port);
-            }
+__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, u64 n_nodes, u64 *work_out, u64 *cursor) {
+    // a thread takes 32 nodes (dense ids: every one is a k-mer)
+    const u64 n0 = kc_gtid() * 32;
+    u64 m = 0;   // bit 2i+p: port p of node n0+i is an unreciprocated choice
+    for (int i = 0; i < 32 && n0 + (u64)i < n_nodes; ++i)
+        for (int port = 0; port < 2; ++port) {
+            const u64 pid = ((n0 + (u64)i) << 1) | (u64)port;
+            u64 w = link[pid];
+            if (LK_STATE(w) != LK_CHOICE) continue;
+            u64 wt = link[LK_PID(w)];   // only LK_REJ bits change concurrently
+            if (LK_STATE(wt) == LK_CHOICE && LK_PID(wt) == pid) continue;
+            m |= (u64)1 << (2 * i + port);
         }
-    }
     u64 pos = kc_block_reserve((u32)__popcll(m), cursor);   // (branching inputs list 10^7 ports here: one add per workgroup, not per port)
     if (FILL)
         for (int j = 0; m != 0 && j < 64; ++j)
-            if ((m >> j) & 1) { const u64 pid = (slot0 << 1) + (u64)j; atomicOr((ull *)&link[pid], (ull)LK_REJ); work_out[pos++] = pid; }
+            if ((m >> j) & 1) { const u64 pid = (n0 << 1) + (u64)j; atomicOr((ull *)&link[pid], (ull)LK_REJ); work_out[pos++] = pid; }
 }
 
 // Later rounds: a tentative choice (CHOICE|REJ) is confirmed when its target's tentative choice points back.
@@ -163,31 +155,21 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
     if (again && pos < work_cap) work_out[pos] = pid;
 }
 
-// heads of directed chains: oriented node (slot, o) whose entry port (L for o=0, R for o=1) is not matched.
-template <int W, bool FILL>
-__global__ void __launch_bounds__(256) kc_heads_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, u64 *heads,
-                                                       u64 *cursor) {
-    const u64 slot0 = kc_gtid() * 32;   // 32 slots per thread, found through four loads of their tag bytes (see kc_mutual_scan_kernel)
-    u64 m = 0;   // bit 2i+o: (slot0+i, o) is a head
+// heads of directed chains: oriented node (id, o) whose entry port (L for o=0, R for o=1) is not matched.
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_heads_kernel(const u64 *__restrict__ link, u64 n_nodes, int complements, u64 *heads, u64 *cursor) {
+    const u64 n0 = kc_gtid() * 32;   // 32 nodes per thread
+    u64 m = 0;   // bit 2i+o: (n0+i, o) is a head
     const int no = complements ? 2 : 1;
-    for (int g8 = 0; g8 < 4; ++g8) {
-        const u64 s8 = slot0 + 8 * (u64)g8;
-        if (s8 >= set.cap) break;
-        u64 tg = 0;
-        if (s8 + 8 <= set.cap) tg = *reinterpret_cast<const u64 *>(set.tags + s8);
-        else for (u64 i = 0; s8 + i < set.cap; ++i) tg |= (u64)set.tags[s8 + i] << (8 * i);
-        for (int i = 0; tg != 0 && i < 8; ++i) {
-            if (!((tg >> (8 * i)) & 0xff)) continue;
-            for (int o = 0; o < no; ++o) {
-                u64 w = link[((s8 + (u64)i) << 1) | (u64)(o == 0 ? 0 : 1)];
-                if (!LK_IS_MATCHED(w)) m |= (u64)1 << (16 * g8 + 2 * i + o);
-            }
+    for (int i = 0; i < 32 && n0 + (u64)i < n_nodes; ++i)
+        for (int o = 0; o < no; ++o) {
+            u64 w = link[((n0 + (u64)i) << 1) | (u64)o];
+            if (!LK_IS_MATCHED(w)) m |= (u64)1 << (2 * i + o);
         }
-    }
     u64 pos = kc_block_reserve((u32)__popcll(m), cursor);
     if (FILL)
         for (int j = 0; m != 0 && j < 64; ++j)
-            if ((m >> j) & 1) heads[pos++] = (slot0 << 1) + (u64)j;
+            if ((m >> j) & 1) heads[pos++] = (n0 << 1) + (u64)j;
 }
 
 template <int W, bool MARK, bool REC, bool FRAG = false>
@@ -196,10 +178,12 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
                                                               u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit, KcRec rec,
                                                               KcFrag frag = KcFrag{nullptr, nullptr, 0, 0}) {
     // limit: give up (cursor[7] = 1) on a chain longer than this; the caller then switches to the segment-parallel path
+    // Nodes are dense ids.  The two places that need a KEY -- the chain's two end k-mers -- find its slot in the word of the dead
+    // port there: the head's entry port, and the exit port the walk ends on.
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nheads) return;
     u64 h = heads[t];
-    u64 slot = h >> 1, cur = slot;
+    u64 cur = h >> 1;
     int o = (int)(h & 1), co = o;
     u64 len = 1;
     u64 acc = 0;
@@ -232,9 +216,10 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         acc = rest ? (bits & (((u64)1 << (2 * rest)) - 1)) : 0;
         nacc = rest;
     };
+    u64 w = 0;
     while (true) {
         if (MARK) visited[cur] = 1;
-        u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+        w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
         if (FRAG && KC_SC_IS(w)) {
             // a contracted run: take its bases, continue at its far end
             if (w & KC_SC_NEXT) {
@@ -250,11 +235,10 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
                 }
                 continue;
             }
-            const u64 blk = cur >> set.bshift;
             u64 nb;
             if (w & KC_SC_EXT) {
                 nb = (w >> 21) & 0x3fff;
-                const u64 *src = frag.pool + ((blk - frag.blk0) & 63) * frag.shard_cap + frag.blk_pool_base[blk - frag.blk0] + (w >> 35);
+                const u64 *src = frag.pool + (w >> 35);
                 if (REC)
                     for (u64 i = 0; i < nb; i += 32) {
                         const int m = nb - i >= 32 ? 32 : (int)(nb - i);
@@ -265,7 +249,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
                 if (REC && nb) push_group(w >> (64 - 2 * nb), (int)nb);
             }
             len += nb;
-            cur = (blk << set.bshift) | ((w >> 6) & 0x3fff);
+            cur += (u64)(long long)((int)(((u32)(w >> 6) & 0x3fffu) ^ 0x2000u) - 0x2000);   // the far node: a signed 14-bit distance in ids
             co = (int)((w >> 20) & 1);
             if (len > limit) {
                 if (__hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicExch((ull *)(cursor + 7), 1ULL);
@@ -284,9 +268,11 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
         // once any walk has hit the limit the whole pass is void: stop wasting steps (checked every 256 steps)
         if (limit != ~(u64)0 && (len & 255) == 0 && __hip_atomic_load(cursor + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     }
-    Key<W> hk = set_key_at(set, slot);
+    // here w is the word of the port the walk ends on: dead, carrying the slot of the tail k-mer (as the head's entry port does)
+    const u64 hslot = LK_SLOT(link[h]), tslot = LK_SLOT(w);
+    Key<W> hk = set_key_at(set, hslot);
     bool winner = true;
-    if (complements) winner = (len == 1) ? (o == 0) : key_lt(hk, set_key_at(set, cur));
+    if (complements) winner = (len == 1) ? (o == 0) : key_lt(hk, set_key_at(set, tslot));
     if (!winner) return;
     if (REC) {
         if (nacc && rec_ok) flush_word(acc << (64 - 2 * nacc));
@@ -297,16 +283,15 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     chain_head[pos] = h;
     chain_len[pos] = len;
     for (int i = 0; i < W; ++i) chain_key[pos * W + i] = hk.w[i];
-    if (REC) { rec.chain_stream[pos] = first_chunk; rec.chain_tail[pos] = (cur << 1) | (u64)co; }
+    if (REC) { rec.chain_stream[pos] = first_chunk; rec.chain_tail[pos] = (tslot << 1) | (u64)co; }   // (the tail by SLOT: the stream emit only needs its key)
 }
 
-template <int W, bool FILL>
-__global__ void __launch_bounds__(256) kc_unvisited_kernel(SetView<W> set, const u8 *__restrict__ visited, u64 *list, u64 *cursor) {
-    u64 slot = kc_gtid();
-    if (slot >= set.cap) return;
-    if (!set_slot_full(set, slot) || visited[slot]) return;
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_unvisited_kernel(u64 n_nodes, const u8 *__restrict__ visited, u64 *list, u64 *cursor) {
+    u64 nid = kc_gtid();
+    if (nid >= n_nodes || visited[nid]) return;
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
-    if (FILL) list[pos] = slot;
+    if (FILL) list[pos] = nid;
 }
 
 __global__ void __launch_bounds__(256) kc_iota_kernel(u64 *a, u64 n) {
@@ -343,7 +328,7 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
     u64 h = chain_head[perm[t]];
     u64 cur = h >> 1;
     int co = (int)(h & 1);
-    Key<W> kx = set_key_at(set, cur);
+    Key<W> kx = set_key_at(set, LK_SLOT(link[h]));   // (the head's entry port is dead: its word carries the slot)
     if (co) kx = key_rc(kx, k);
     for (int i = 0; i < W; ++i) firstK[t * W + i] = kx.w[i];
     u64 wp = woff[t], acc = 0;
@@ -368,7 +353,7 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
 
 // emit from the recordings of the measure pass: first k bases from the head key, then the recorded appended bases
 template <int W>
-__global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, int k, const u64 *__restrict__ chain_head,
+__global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, const u64 *__restrict__ link, int k, const u64 *__restrict__ chain_head,
                                                              const u64 *__restrict__ chain_len, const u64 *__restrict__ chain_stream,
                                                              const u64 *__restrict__ chain_tail, const u64 *__restrict__ perm, u64 n,
                                                              const u64 *__restrict__ pool, const u32 *__restrict__ chunk_next,
@@ -377,7 +362,7 @@ __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, int
     if (t >= n) return;
     const u64 p = perm[t];
     const u64 h = chain_head[p], len = chain_len[p], tail = chain_tail[p];
-    Key<W> kx = set_key_at(set, h >> 1);
+    Key<W> kx = set_key_at(set, LK_SLOT(link[h]));   // (the head's entry port is dead: its word carries the slot; the tail is listed by slot)
     if (h & 1) kx = key_rc(kx, k);
     for (int i = 0; i < W; ++i) firstK[t * W + i] = kx.w[i];
     Key<W> kl = set_key_at(set, tail >> 1);
@@ -423,11 +408,11 @@ __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, int
 // of its segments (length/256 steps) to get the chain's length, tail and segment offsets; segments finally emit their
 // bases in parallel.  A multi-Mbp chain therefore costs ~256 sequential steps instead of millions.
 #define KC_SEG_NONE (~(u64)0)
-__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, const u8 *__restrict__ tags, u64 cap,
+__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, u64 n_nodes,
                                                               int complements, u64 *starts, u64 *cursor) {
-    // splitters are the occupied slots whose index is a multiple of 256 (the choose kernel flags exactly those LK_SPLIT)
+    // splitters are the nodes whose dense id is a multiple of 256 (round 1 flags exactly those LK_SPLIT)
     const u64 slot = ((u64)blockIdx.x * blockDim.x + threadIdx.x) << 8;
-    if (slot >= cap || tags[slot] == 0) return;
+    if (slot >= n_nodes) return;
     const int no = complements ? 2 : 1;
     for (int o = 0; o < no; ++o) {
         u64 w = link[(slot << 1) | (u64)o];          // entry port of orientation o is port o
@@ -456,7 +441,7 @@ __global__ void __launch_bounds__(256) kc_segment_walk_kernel(const u64 *__restr
     u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
     while (true) {
         if (visited) visited[cur] = 1;
-        if (!LK_IS_MATCHED(w)) { if (!visited) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (cur << 1) | (u64)co; } break; }
+        if (!LK_IS_MATCHED(w)) { if (!visited) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (LK_SLOT(w) << 1) | (u64)co; } break; }   // (the tail by SLOT, from its dead port's word)
         u64 nxt = LK_SLOT(w);
         int no = LK_PORT(w) == 0 ? 0 : 1;
         u64 wn = link[(nxt << 1) | (u64)(no == 0 ? 1 : 0)];
@@ -482,7 +467,7 @@ __global__ void __launch_bounds__(256) kc_chain_reduce_kernel(SetView<W> set, co
         if (seg_next[j] == KC_SEG_NONE) { tail = seg_tail[j]; break; }
         j = seg_next[j];
     }
-    Key<W> hk = set_key_at(set, id >> 1);
+    Key<W> hk = set_key_at(set, LK_SLOT(link[id]));   // (a head's entry port is dead: its word carries the slot)
     bool winner = true;
     if (complements) winner = (total == 1) ? ((id & 1) == 0) : key_lt(hk, set_key_at(set, tail >> 1));
     if (!winner) return;
@@ -518,7 +503,9 @@ __global__ void __launch_bounds__(256) kc_segment_emit_kernel(SetView<W> set, co
     const u64 r = rank[ch], wb = woff[r], off = seg_off[j];
     u64 cur = starts[j] >> 1;
     int co = (int)(starts[j] & 1);
-    Key<W> kx = set_key_at(set, cur);
+    // the start's k-mer: a head's slot is in the word of its (dead) entry port, a splitter's is searched for (one per 256 k-mers)
+    const u64 w_in = link[starts[j]];
+    Key<W> kx = set_key_at(set, LK_IS_MATCHED(w_in) ? set_slot_of_nid(set, cur) : LK_SLOT(w_in));
     if (co) kx = key_rc(kx, k);
     u64 pos, acc = 0, wi;   // pos = next base position in the chain's string; acc = bits gathered for word wi
     auto put = [&](u64 b) {
@@ -603,15 +590,22 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     KcScope scope(ctx);
     const int k = set->k, compl_ = set->complements;
     SetView<W> sv = kc_view<W>(set);
-    const u64 cap = set->cap, nports = cap * 2;
+    const u64 cap = set->cap;
     const int xcd_aware = getenv("KC_NOXCD") ? 0 : 1;
     KC_TRY(kcs_refresh_size(set));
     const u64 N = set->size_host;
     if (N == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    // Nodes are DENSE ids: the k-mers numbered in slot order (kc_set_dev.h).  The port links are 16 bytes per k-mer, written
+    // contiguously by round 1, not 16 bytes per slot of a table at load 0.5.
+    u64 n_dense = 0;
+    KC_TRY(kcs_prepare_dense(set, &n_dense));
+    if (n_dense != N) return kc_fail(ctx, KC_E_NO_DEVICE, "k-mer count and occupied slots disagree");
+    sv = kc_view<W>(set);
+    const u64 nports = N * 2;
     u64 *link = nullptr, *cnt = nullptr;
-    KC_TRY(scope.alloc(&link, nports));
+    KC_TRY(scope.alloc(&link, nports + 2));
     KC_TRY(scope.alloc(&cnt, 8));
-    // (no clearing of `link`: round 1 writes both words of every occupied slot, and nothing ever reads an empty slot's)
+    // (no clearing of `link`: round 1 writes both words of every k-mer)
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
     // heads (ports that die) and the work list of unresolved ports are collected on the fly into bounded buffers; an
     // overflow (never seen on read-like inputs) falls back to exact counting passes.
@@ -703,7 +697,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
         // kc_reject_kernel run may already have set are simply found again
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, link, N,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
         scope.release(work_a); scope.release(work_b);
@@ -711,7 +705,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&work_a, work_cap));
         KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, link, (const u8 *)set->tags, cap, work_a,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, link, N, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
@@ -732,17 +726,17 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
 
     // chain heads
     u64 nheads = 0;
-    const u64 nsplit_max = (cap + 255) >> 8;   // splitters: occupied slots with index % 256 == 0
+    const u64 nsplit_max = (N + 255) >> 8;   // splitters: nodes with id % 256 == 0
     KC_TRY(read_u64(ctx, heads_cursor, &nheads));
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<W, false>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+        hipLaunchKernelGGL((kc_heads_kernel<false>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, N, compl_,
                            (u64 *)nullptr, cnt);
         KC_TRY(read_u64(ctx, cnt, &nheads));
         KC_TRY(scope.alloc(&heads, nheads + 1));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<W, true>), kc_grid2((cap + 31) / 32, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_, heads,
+        hipLaunchKernelGGL((kc_heads_kernel<true>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, N, compl_, heads,
                            cnt);
     }
     // ---- chain discovery.  Pass 0 works on the heads round 1..n produced.  K-mers on cycles (every port matched) are
@@ -785,14 +779,15 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr, *flog = nullptr, *fblog = nullptr;
             // per block (the kernel divides both evenly): 1/6 slot of log entries -- two ends per in-block run, ~1 run per 9 k-mers -- and
             // 1/16 slot of pool words (runs beyond 19 nodes: ~100 per block of 8192 slots, one or two words each)
-            const u64 pool_cap = (cap / 16 + 65536) / 64 * 64;
+            u64 pool_cap = (cap / 16 + 65536) / 64 * 64;
+            if (pool_cap > ((u64)1 << 29)) pool_cap = (u64)1 << 29;   // (a shortcut names a pool run by its absolute first word in 29 bits; blocks without room keep plain links)
             const u64 log_cap = (cap / 6 + 65536) / 64 * 64;
             KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, set->nblocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16));
             KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, set->nblocks));
             KC_HIP(ctx, hipMemsetAsync(fcur, 0, 2 * 64 * 16 * 8, ctx->stream));
             const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
-            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
+            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
                                flog, log_cap, fcur + 64 * 16, fblog);
             const KcFrag fr{fpool, fbase, 0, 0};
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
@@ -811,7 +806,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 // a chain beyond the limit, or k-mers on cycles (reached from no head): put the replaced link words back and
                 // let the classic flow below run on the original links
                 hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog,
-                                   (const u64 *)fblog, set->bshift, (u64)0);
+                                   (const u64 *)fblog, set->bshift, (u64)0, (const u64 *)set->nbase);
                 KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
                 if (hf[7]) known_long = true;
                 use_frag = false;
@@ -850,7 +845,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
             KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                               (const u8 *)set->tags, cap, compl_, starts_raw, cnt + 6);
+                               N, compl_, starts_raw, cnt + 6);
             KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
             KC_TRY(kcu_sort_pairs(ctx, starts_raw, starts, nullptr, nullptr, nstarts, 0, 64));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -875,8 +870,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // ---- not every k-mer is on a chain with ends: cycles.  Mark what the heads reach, cut the rest, go again.
         if (pass == 2) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not cover the set after cutting the cycles");
         u8 *visited = nullptr;
-        KC_TRY(scope.alloc(&visited, cap));
-        KC_HIP(ctx, hipMemsetAsync(visited, 0, cap, ctx->stream));
+        KC_TRY(scope.alloc(&visited, N));
+        KC_HIP(ctx, hipMemsetAsync(visited, 0, N, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         if (too_long) {
             if (nstarts)
@@ -887,7 +882,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<W, false>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u8 *)visited,
+        hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(N, 256), dim3(256), 0, ctx->stream, N, (const u8 *)visited,
                            (u64 *)nullptr, cnt + 1);
         u64 nunvis = 0;
         KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
@@ -895,7 +890,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         u64 *ulist = nullptr, *heads2 = nullptr;
         KC_TRY(scope.alloc(&ulist, nunvis));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<W, true>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, (const u8 *)visited, ulist,
+        hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(N, 256), dim3(256), 0, ctx->stream, N, (const u8 *)visited, ulist,
                            cnt + 1);
         {
             // rows of the k-mers on cycles and the candidate edges of their ports to dead ports -> host, which walks the cycles and
@@ -905,7 +900,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             const u64 cand_cap = nunvis + 65536;
             KC_TRY(scope.alloc(&rows_d, nunvis * RW)); KC_TRY(scope.alloc(&cand_d, cand_cap * CW));
             KC_HIP(ctx, hipMemsetAsync(cnt + 6, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_cycle_rows_kernel<W>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows_d);
+            hipLaunchKernelGGL((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows_d);
             hipLaunchKernelGGL((kc_cycle_cand_kernel<W>), kc_grid2(2 * nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, compl_, (const u64 *)ulist, nunvis,
                                cand_d, cand_cap, cnt + 6);
             KC_HIP(ctx, hipGetLastError());
@@ -923,7 +918,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_TRY(scope.alloc(&heads2, nheads + nfix + 1));
             KC_HIP(ctx, hipMemcpyAsync(fix_d, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(kc_cycle_fix_kernel, kc_grid2(nfix, 256), dim3(256), 0, ctx->stream, link, (const u64 *)fix_d, nfix);
+            hipLaunchKernelGGL((kc_cycle_fix_kernel<W>), kc_grid2(nfix, 256), dim3(256), 0, ctx->stream, sv, link, (const u64 *)fix_d, nfix);
             hipLaunchKernelGGL(kc_heads_refresh_kernel, kc_grid2(nheads + nfix, 256), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)heads, nheads, (const u64 *)fix_d, nfix,
                                compl_, heads2, cnt);
             KC_HIP(ctx, hipGetLastError());
@@ -973,7 +968,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(rank);
     } else if (use_stream) {
-        hipLaunchKernelGGL((kc_stream_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, k, (const u64 *)chain_head,
+        hipLaunchKernelGGL((kc_stream_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
                            (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
                            (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
     } else {
