@@ -51,9 +51,9 @@ struct kc_set {
     u64 size_host = 0;
     u64 rlo = 0, rcap = 0;   // hash-sharded sets: the global slots [rlo, rlo + rcap) live here (rcap == 0: all of them); keys / state / tags / counts
                              // are then LOCAL arrays of rcap entries
-    u64 *nbase = nullptr;    // dense node ids: first id of every block (blocks of this rank + 1 entries), see kcs_prepare_dense
-    bool dense_ok = false;   // nbase and the counts in the empty slots describe the table as it is (any insertion voids them)
-    u64 nid_lo = 0;          // hash-sharded sets: id of this rank's first k-mer
+    u32 *ncount = nullptr;   // dense node ids: k-mers per block (blocks of this rank), see kcs_prepare_dense and SetView
+    u32 nstride = 0;         // ids per block = the largest ncount, rounded up to a multiple of 8
+    bool dense_ok = false;   // ncount / nstride and the counts in the empty slots describe the table as it is (any insertion voids them)
     mutable bool unclean = false;   // table allocated but not filled with EMPTY yet (a bucketed build of a fresh set overwrites every
                                     // slot, so the 9 B/slot fill is deferred until something else needs the table)
 };
@@ -62,7 +62,7 @@ int kcs_clean_table(const kc_set *s);   // kc_set.hip
 template <int W> static inline SetView<W> kc_view_raw(const kc_set *s) {
     const u64 rcap = s->rcap ? s->rcap : s->cap;
     return SetView<W>{s->keys - s->rlo * W, s->state ? s->state - s->rlo : nullptr, s->tags - s->rlo, s->cap, s->nblocks, s->bshift, s->mlen, s->k,
-                      s->local_probes, s->rlo, rcap, s->complements, s->nbase ? s->nbase - (s->rlo >> s->bshift) : nullptr};
+                      s->local_probes, s->rlo, rcap, s->complements, s->ncount ? s->ncount - (s->rlo >> s->bshift) : nullptr, s->nstride};
 }
 // every kernel reaches the table through a view: this is where a deferred fill happens
 template <int W> static inline SetView<W> kc_view(const kc_set *s) {
@@ -197,7 +197,7 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
 int kcs_reserve(kc_set *set, u64 additional);
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive);
 int kcs_refresh_size(kc_set *set);
-int kcs_prepare_dense(kc_set *set, u64 *n_local = nullptr);   // dense node ids for phase 1: counts in the empty slots + set->nbase (no-op when still valid)
+int kcs_prepare_dense(kc_set *set);   // dense node ids for phase 1: counts in the empty slots, set->ncount / nstride (no-op when still valid)
 int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out);   // collective
 int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved_bytes, int min_count = 1);   // collective; min_count > 1: -z
 // kc_simplitigs.hip

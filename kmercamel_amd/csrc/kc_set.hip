@@ -522,10 +522,13 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const 
 // iteration (nobody waits inside an iteration, so lanes of one wave cannot block each other).
 #define KC_MAX_SEG 64
 #define KC_MAX_DYN_LDS (160 * 1024 - 4096)   /* dynamic LDS limit requested for the build kernels (their static LDS is ~1 KB) */
-template <int W>
+template <int W, bool IDS = false>
 __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
                                                               int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap,
-                                                              const u64 *__restrict__ seg_scan, int nseg, int merge_r, int sample_stride) {
+                                                              const u64 *__restrict__ seg_scan, int nseg, int merge_r, int sample_stride,
+                                                              u32 *ncount_out = nullptr) {
+    // IDS: the block leaves with its dense node ids prepared (kc_set_dev.h): key word 0 of every empty slot = the
+    // number of occupied slots before it, ncount_out[block] = its k-mers, counters[4] = the largest block.
     // nseg == 0: the block's keys are bucket[block * 2^bshift ...], bcursor[block] of them (single GPU).  nseg > 0 (hash-sharded
     // build): the block is LOCAL block blockIdx.x of this rank's range and its keys arrived in nseg segments, one per source
     // rank: segment q = bucket[seg_scan[q * gridDim.x + block] .. seg_scan[q * gridDim.x + block + 1]).
@@ -632,11 +635,49 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         if (threadIdx.x == 0) { atomicAdd((ull *)&counters[2], (ull)added_s); atomicAdd((ull *)&counters[3], (ull)n); }
         return;
     }
-    for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
-    for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
-        reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
-    if (W > 1)
-        for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
+    if (IDS) {
+        // Write-out with the dense node ids prepared on the way: wave w owns the slots [w bs/16, (w+1) bs/16) and writes them in
+        // rows of 64 (512 contiguous bytes per row of single-word keys); an empty slot leaves with the number of occupied slots
+        // before it (ballot + popcount on top of the count of the waves before) instead of the empty marker.
+        const u32 nwv = blockDim.x >> 6, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const u32 per_wave = bs / nwv, rows = (per_wave + 63) / 64;   // (per_wave is a multiple of 8: blocks have >= 512 slots)
+        const unsigned long long ltm = ((unsigned long long)1 << lane) - 1;
+        // occupied slots in the shares of the waves before this one: every wave counts them for itself, 8 tags per LDS load (no
+        // barrier, no waiting for one another -- the block's other workgroup on the CU is in its insert phase meanwhile)
+        u32 at = 0;
+        {
+            const u64 *lt64 = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt));
+            const u32 words_before = wv * per_wave / 8;
+            for (u32 i = lane; i < words_before; i += 64) at += (u32)__popcll(lt64[i] & 0x8080808080808080ULL);   // (tag bytes of occupied slots have bit 7 set)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) at += __shfl_xor(at, d, 64);
+        }
+        for (u32 r = 0; r < rows; ++r) {
+            const u32 off = r * 64 + lane, sl = wv * per_wave + off;
+            const bool in = off < per_wave, occ = in && lt[sl] != 0;
+            const unsigned long long mk = __ballot(occ);
+            if (in) {
+                const u64 cnt = (u64)(at + (u32)__popcll(mk & ltm));
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    u64 v = lk[(size_t)sl * W + w];
+                    if (!occ && w == 0) v = W == 1 ? (KC_ANN_MARK | cnt) : cnt;
+                    set.keys[(base + sl) * W + w] = v;
+                }
+                if (W > 1) set.state[base + sl] = occ ? KC_ST_FULL : KC_ST_EMPTY;
+            }
+            at += (u32)__popcll(mk);
+        }
+        for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
+            reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
+        if (threadIdx.x == blockDim.x - 64) ncount_out[blockIdx.x] = at;   // (the last wave ends on the block's total; the largest block: kc_max_u32_kernel)
+    } else {
+        for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
+        for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
+            reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
+        if (W > 1)
+            for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
+    }
     if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at the end of the range
     if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
 }
@@ -852,8 +893,8 @@ extern "C" int kc_set_create(kc_ctx *ctx, int k, int complements, uint64_t capac
     s->cap = cap;
     int rc = set_alloc_table(s, cap, &s->keys, &s->state, &s->tags, false);   // filled on first use (kc_view), or never (bucketed build)
     s->unclean = true;
-    if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 4);
-    if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 8);   // [0] size, [1] capacity flag, [2] [3] scratch of the builds, [4] largest block (dense ids)
+    if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 8 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     if (rc != KC_OK) { kc_set_destroy(s); return rc; }
     *out = s;
     return KC_OK;
@@ -867,20 +908,20 @@ extern "C" void kc_set_destroy(kc_set *set) {
     kc_release(ctx, set->tags);
     kc_release(ctx, set->counts);
     kc_release(ctx, set->counters);
-    kc_release(ctx, set->nbase);
+    kc_release(ctx, set->ncount);
     delete set;
 }
 
-// ---- dense node ids (phase 1 numbers the k-mers in slot order; kc_set_dev.h, kc_simp_dev.h).  One workgroup per block: counts[b] =
-// occupied slots of block b, and key word 0 of every empty slot = the number of occupied slots before it in the block (single-word
-// keys: under KC_ANN_MARK).  The block-build kernel of the bucketed path leaves the same words behind on its way (dense_ok stays
-// set); this sweep serves tables that saw a direct insert since.
+// ---- dense node ids (phase 1 numbers the k-mers of a block in slot order; kc_set_dev.h, kc_simp_dev.h).  One workgroup per block:
+// ncount[b] = occupied slots of block b (its maximum into counters[4]), and key word 0 of every empty slot = the number of occupied
+// slots before it in the block (single-word keys: under KC_ANN_MARK).  The block-build kernel of the bucketed path leaves the same
+// words behind on its way (dense_ok stays set); this sweep serves tables that saw a direct insert since.
 static void kcs_void_dense(kc_set *set) {
     set->dense_ok = false;
-    if (set->nbase) { (void)hipStreamSynchronize(set->ctx->stream); kc_release(set->ctx, set->nbase); set->nbase = nullptr; }
+    if (set->ncount) { (void)hipStreamSynchronize(set->ctx->stream); kc_release(set->ctx, set->ncount); set->ncount = nullptr; }
 }
 template <int W>
-__global__ void __launch_bounds__(256) kc_annotate_kernel(SetView<W> set, u64 *counts) {
+__global__ void __launch_bounds__(256) kc_annotate_kernel(SetView<W> set, u32 *ncount, u64 *max_out) {
     const u32 bs = 1u << set.bshift, per = bs >> 8;   // (blocks have >= 512 slots)
     const u64 base = set.rlo + ((u64)blockIdx.x << set.bshift);
     const u8 *tg = set.tags + base + (u64)threadIdx.x * per;
@@ -892,29 +933,35 @@ __global__ void __launch_bounds__(256) kc_annotate_kernel(SetView<W> set, u64 *c
         if (tg[i] != 0) { ++at; continue; }
         set.keys[(base + (u64)threadIdx.x * per + i) * W] = W == 1 ? (KC_ANN_MARK | at) : at;
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+    if (threadIdx.x == 0) { ncount[blockIdx.x] = (u32)tot; if (tot > *(volatile u64 *)max_out) atomicMax((ull *)max_out, (ull)tot); }
 }
-int kcs_prepare_dense(kc_set *set, u64 *n_local) {
+__global__ void __launch_bounds__(256) kc_max_u32_kernel(const u32 *__restrict__ a, u64 n, u64 *out) {
+    u32 m = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) m = a[i] > m ? a[i] : m;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax((ull *)out, (ull)m);
+}
+static u32 kcs_stride_for(u64 max_count) { return (u32)((max_count + 7) / 8 * 8 + (max_count == 0 ? 8 : 0)); }   // (a multiple of 8: every block's link words start on a 128-byte line)
+int kcs_prepare_dense(kc_set *set) {
     kc_ctx *ctx = set->ctx;
     const u64 nblk = (set->rcap ? set->rcap : set->cap) >> set->bshift;
-    if (!set->dense_ok || !set->nbase) {
-        if (set->bshift < 9) return kc_fail(ctx, KC_E_ARG, "blocks of fewer than 512 slots");
-        if (set->nbase) { kc_release(ctx, set->nbase); set->nbase = nullptr; }
-        KC_TRY(kc_alloc(ctx, &set->nbase, nblk + 2));
-        switch (set->W) {
-            case 1: hipLaunchKernelGGL(kc_annotate_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<1>(set), set->nbase); break;
-            case 2: hipLaunchKernelGGL(kc_annotate_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<2>(set), set->nbase); break;
-            default: hipLaunchKernelGGL(kc_annotate_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<4>(set), set->nbase); break;
-        }
-        KC_HIP(ctx, hipGetLastError());
-        KC_TRY(kcu_exclusive_scan(ctx, set->nbase, set->nbase, nblk));   // nbase[nblk] = k-mers of this table
-        set->dense_ok = true;
-        set->nid_lo = 0;
+    if (set->dense_ok && set->ncount) return KC_OK;
+    if (set->bshift < 9) return kc_fail(ctx, KC_E_ARG, "blocks of fewer than 512 slots");
+    if (set->ncount) { kc_release(ctx, set->ncount); set->ncount = nullptr; }
+    KC_TRY(kc_alloc(ctx, &set->ncount, nblk + 2));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
+    switch (set->W) {
+        case 1: hipLaunchKernelGGL(kc_annotate_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<1>(set), set->ncount, set->counters + 4); break;
+        case 2: hipLaunchKernelGGL(kc_annotate_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<2>(set), set->ncount, set->counters + 4); break;
+        default: hipLaunchKernelGGL(kc_annotate_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<4>(set), set->ncount, set->counters + 4); break;
     }
-    if (n_local) {
-        KC_HIP(ctx, hipMemcpyAsync(n_local, set->nbase + nblk, 8, hipMemcpyDeviceToHost, ctx->stream));
-        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    KC_HIP(ctx, hipGetLastError());
+    u64 mx = 0;
+    KC_HIP(ctx, hipMemcpyAsync(&mx, set->counters + 4, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    set->nstride = kcs_stride_for(mx);
+    set->dense_ok = true;
     return KC_OK;
 }
 
@@ -1091,13 +1138,25 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     }
     if (!fresh) KC_TRY(kcs_clean_table(set));   // (cannot be pending on a non-empty set; kept for clarity)
     set->unclean = false;                        // the build kernel writes every slot, state and tag of every block
-    hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                       (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0);
+    // the blocks leave the build with their dense node ids prepared (void again if anything is inserted behind the kernel's back)
+    kcs_void_dense(set);
+    KC_TRY(kc_alloc(ctx, &set->ncount, set->nblocks + 2));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
+    if (getenv("KC_NO_BUILD_IDS"))   // (test knob: the sweep of kcs_prepare_dense instead)
+        hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
+    else {
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
+        hipLaunchKernelGGL((kc_block_build_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
+        hipLaunchKernelGGL(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
+    }
     KC_HIP(ctx, hipGetLastError());
-    u64 h[4] = {0, 0, 0, 0};
+    u64 h[5] = {0, 0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h[3] |= scatter_ovf;
+    if (!h[2] && !h[3] && !getenv("KC_NO_BUILD_IDS")) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (KC_NO_BUILD_IDS: test knob, the sweep of kcs_prepare_dense instead)
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu\n", W,
                 (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3]);
@@ -1194,8 +1253,8 @@ int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->tags, s->rcap + 8);
     if (rc == KC_OK && s->W != 1) rc = kc_alloc(ctx, &s->state, s->rcap);
     s->unclean = true;
-    if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 4);
-    if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 4 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    if (rc == KC_OK) rc = kc_alloc(ctx, &s->counters, 8);   // [0] size, [1] capacity flag, [2] [3] scratch of the builds, [4] largest block (dense ids)
+    if (rc == KC_OK && hipMemsetAsync(s->counters, 0, 8 * sizeof(u64), ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     if (rc != KC_OK) { kc_set_destroy(s); return rc; }
     *out = s;
     return KC_OK;

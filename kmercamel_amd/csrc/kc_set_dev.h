@@ -40,14 +40,18 @@ template <int W> struct SetView {
     // above are biased by -rlo so that they are indexed with GLOBAL slot numbers.  One GPU: rlo = 0, rcap = cap.
     u64 rlo, rcap;
     int complements;   // strand mode of the set (the canonical orientation of a middle is the smaller of it and its reverse complement)
-    // dense node ids (phase 1, kc_simp_dev.h): the k-mers are numbered in slot order; nbase[b] = id of the first k-mer of block b
-    // (nblocks + 1 entries, valid after kcs_prepare_dense; biased like the table pointers on hash-sharded sets)
-    const u64 *nbase;
+    // dense node ids (phase 1, kc_simp_dev.h): the k-mers of block b are numbered b * nstride + (rank among the block's occupied
+    // slots); nstride = the largest number of k-mers in any block (rounded up to a multiple of 8), ncount[b] = k-mers of block b
+    // (valid after kcs_prepare_dense; biased like the table pointers on hash-sharded sets).  Ids are dense inside a block and leave
+    // nstride - ncount[b] unused ids behind it: what a port is numbered by never needs a directory lookup.
+    const u32 *ncount;
+    u32 nstride;
 };
-// Dense ids without a rank directory: once a table is finished (kcs_prepare_dense), the key word 0 of every EMPTY slot holds the
-// number of occupied slots before it in its block (single-word keys: under the mark below -- the top pair of a k-mer word is
-// never 11).  The id of the k-mer in slot s is then nbase[block] + ann(e) - (e - s) for the first empty slot e after s: one more
-// 8-byte load from the line (or the LDS copy) the lookup of s has just touched, instead of a second scattered line per lookup.
+// Dense ids without a rank directory: once a table is finished (the bucketed build does it on its way, else kcs_prepare_dense), the
+// key word 0 of every EMPTY slot holds the number of occupied slots before it in its block (single-word keys: under the mark
+// below -- the top pair of a k-mer word is never 11).  The id of the k-mer in slot s is then block * nstride + ann(e) - (e - s) for
+// the first empty slot e after s: one more 8-byte load from the line (or the LDS copy) the lookup of s has just touched, instead of
+// a second scattered line per lookup.
 #define KC_ANN_MARK ((u64)3 << 62)
 #define KC_ANN_COUNT(w) ((u64)(w) & 0xffffffffull)
 KC_HD bool kc_word_is_empty(u64 w) { return (w >> 62) == 3; }   // single-word keys: ~0 (never annotated) or mark | count
@@ -306,19 +310,22 @@ template <int W> __device__ __forceinline__ u64 set_count_before(const SetView<W
         if (emp) { e += (u32)__builtin_ctzll(emp) >> 3; break; }
         e += 8;
     }
-    if (e >= bs) return (s.nbase[blk + 1] - s.nbase[blk]) - (u64)(bs - i);   // occupied up to the end of the block
+    if (e >= bs) return (u64)s.ncount[blk] - (u64)(bs - i);   // occupied up to the end of the block
     return KC_ANN_COUNT(s.keys[(base + e) * W]) - (u64)(e - i);
 }
 // id of the k-mer in the (occupied) slot
 template <int W> __device__ __forceinline__ u64 set_nid_of_slot(const SetView<W> &s, u64 slot) {
     const u64 blk = slot >> s.bshift;
-    return s.nbase[blk] + set_count_before(s, blk, (u32)(slot - (blk << s.bshift)));
+    return blk * (u64)s.nstride + set_count_before(s, blk, (u32)(slot - (blk << s.bshift)));
 }
-// slot of the k-mer with this id (binary searches over the block bases and inside the block: the rare paths only)
+// is this id in use (ids leave gaps behind every block)?
+template <int W> __device__ __forceinline__ bool set_nid_valid(const SetView<W> &s, u64 nid) {
+    const u64 blk = nid / s.nstride;
+    return (u32)(nid - blk * s.nstride) < s.ncount[blk];
+}
+// slot of the k-mer with this id (a binary search inside the block: the rare paths only)
 template <int W> __device__ __forceinline__ u64 set_slot_of_nid(const SetView<W> &s, u64 nid) {
-    u64 lo = s.rlo >> s.bshift, hi = (s.rlo + s.rcap) >> s.bshift;   // largest block with nbase[blk] <= nid
-    while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (s.nbase[mid] <= nid) lo = mid; else hi = mid; }
-    const u64 blk = lo, r = nid - s.nbase[blk];
+    const u64 blk = nid / s.nstride, r = nid - blk * s.nstride;
     u32 a = 0, b = (1u << s.bshift) - 1;   // smallest offset i with count_before(i + 1) > r
     while (a < b) { const u32 mid = (a + b) >> 1; if (set_count_before(s, blk, mid + 1) > r) b = mid; else a = mid + 1; }
     return (blk << s.bshift) + a;

@@ -401,7 +401,7 @@ __device__ __forceinline__ void kc_port_search_generic(const SetView<W> &set, in
 //   LT: the home lies in block `sblk` whose tags are staged in LDS (stage_tags); SK: that block's keys are staged too.
 //   LT == 2: decided per port -- a home in block `sblk` is read from the staged copies (through flat pointers), any other from the table
 //   DN: *eoff = offset from the home of the empty slot E that ended the run.  The k-mers between a match and E are all present, so
-//   a candidate's dense node id is nbase[block] + count(E) - (E - slot); count(E) sits in the key word of E, next to the keys the
+//   a candidate's dense node id is block * nstride + count(E) - (E - slot); count(E) sits in the key word of E, next to the keys the
 //   search has just read (kc_port_delta)
 template <int W, int LT, bool SK, bool DN = false>
 __device__ __forceinline__ bool kc_port_search(const SetView<W> &set, int k, int complements, const Key<W> &x, const Key<W> &xr, const u64 slot, int port,
@@ -473,7 +473,7 @@ __device__ __forceinline__ u64 kc_port_delta(const SetView<W> &set, const u64 ho
     const u32 bmask = (1u << set.bshift) - 1u;
     const u64 eabs = home + (u64)eoff;
     const u64 ann = (SK && staged) ? stage_keys[(size_t)((u32)eabs & bmask) * W] : set.keys[eabs * W];
-    return set.nbase[home >> set.bshift] + KC_ANN_COUNT(ann) - eabs;
+    return (home >> set.bshift) * (u64)set.nstride + KC_ANN_COUNT(ann) - eabs;
 }
 // Is the stored key kk a neighbour of x on `port`?  A neighbour is x shifted by one character with the extension c at the free
 // end, or the reverse complement of that: kk XOR (the shifted x, or the shifted RC(x)) is then zero outside the extension
@@ -823,7 +823,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                                                             u64 *spill_cursor, ShLists L = ShLists{}) {
     constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM), WBYTES = KC_PROBE_SSTACK * 2 + ECAP * (MM ? 6 : 2);
     // DN (single-GPU flow): link words are addressed by DENSE node ids and carry dense ids -- 16 bytes per K-MER, written
-    // contiguously (the k-mers of a block are numbered in slot order from set.nbase[block] on), not 16 bytes per slot of a table at
+    // contiguously (the k-mers of a block are numbered in slot order from block * set.nstride on), not 16 bytes per slot of a table at
     // load 0.5 written in 64-byte pieces.  The hash-sharded flow (SH) still numbers its ports by slot.
     constexpr bool DN = !SH;
     // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         if (lane == 0) kc_wcnt[wv] = mine;
         __syncthreads();
         for (int i = 0; i < wv; ++i) wfirst += kc_wcnt[i];
-        nb0 = set.nbase[blk];
+        nb0 = blk * (u64)set.nstride;
     }
     auto load_x = [&](u32 so) {
         Key<W> r;
@@ -898,7 +898,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             if (emp) { e += (u32)__builtin_ctzll(emp) >> 3; break; }
             e += 8;
         }
-        if (e >= bs) return (set.nbase[blk + 1] - nb0) - (u64)(bs - so);
+        if (e >= bs) return (u64)set.ncount[blk] - (u64)(bs - so);
         const u64 ann = SK ? sk[(size_t)e * W] : set.keys[(base + e) * W];
         return KC_ANN_COUNT(ann) - (u64)(e - so);
     };
@@ -1338,7 +1338,7 @@ static inline u64 kc_cycles_decide(const std::vector<u64> &rows, u64 n, const st
 #define KC_FRAG_LONGS 512       /* runs of more than 20 nodes per block that get pool space (expected ~100) */
 #define KC_FRAG_ENTRIES 4096    /* fragment ends per block (expected ~900 of 16384 ports) */
 // DN (single-GPU flow): the links are addressed by dense node ids, so the block's link words are the contiguous range
-// [nbase[blk], nbase[blk + 1]) x 16 bytes -- no tag bytes are read and no empty slot's words are streamed.  A shortcut then names
+// [blk * nstride, blk * nstride + ncount[blk]) x 16 bytes -- no tag bytes are read and no empty slot's words are streamed.  A shortcut then names
 // its far node by the signed distance in ids (bits 6-19, two's complement) and a pool run by its absolute first word (bits 35-63),
 // so the hop walk needs no block arithmetic.
 template <int W, bool DN = false>
@@ -1355,8 +1355,8 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
     __shared__ u32 n_long, n_words, n_ent;
     const u32 bs = 1u << set.bshift;
     const u64 blk = (set.rlo >> set.bshift) + blockIdx.x;   // (hash-sharded tables: the blocks of this rank; pool / log arrays are indexed by the LOCAL block)
-    const u64 base = DN ? set.nbase[blk] : blk << set.bshift;                       // first node of the block (DN: dense id, else slot)
-    const u32 nn = DN ? (u32)(set.nbase[blk + 1] - set.nbase[blk]) : bs;            // nodes (DN) / slots of the block
+    const u64 base = DN ? blk * (u64)set.nstride : blk << set.bshift;               // first node of the block (DN: dense id, else slot)
+    const u32 nn = DN ? set.ncount[blk] : bs;                                       // nodes (DN) / slots of the block
     const u64 lblk = blockIdx.x;
     u32 *longs = kc_fl + 2 * (size_t)bs;                            // (local port id of the entry, first pool word)
     const u32 long_cap = KC_FRAG_LONGS, fe_cap = KC_FRAG_ENTRIES;
@@ -1502,14 +1502,14 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
 }
 
 // puts the logged link words back (the hop walk met a chain beyond the limit, or the input has cycles: the classic flow
-// takes over on the original links).  nbase != nullptr: links addressed by dense node ids (first id of every block).
+// takes over on the original links).  nstride != 0: links addressed by dense node ids (ids per block).
 static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, const u64 *__restrict__ log, const u64 *__restrict__ blk_log, int bshift, u64 blk0,
-                                                                     const u64 *__restrict__ nbase = nullptr) {
+                                                                     u32 nstride = 0) {
     const u64 blk = blockIdx.x;
     const u64 e = blk_log[blk];
     const u32 n = (u32)(e & 0xffffu);
     const u64 lb = e >> 16;
-    const u64 first = nbase ? nbase[blk0 + blk] : (blk0 + blk) << bshift;
+    const u64 first = nstride ? (blk0 + blk) * (u64)nstride : (blk0 + blk) << bshift;
     for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
         const u64 w = log[lb + i];
         link[(first << 1) + ((w >> 46) & 0x3fffu)] = w & ~(0x3fffull << 46);

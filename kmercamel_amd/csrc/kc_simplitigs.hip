@@ -17,6 +17,11 @@
 
 #include "kc_simp_dev.h"
 
+// node ids leave gaps behind every block (kc_set_dev.h): the first ncount[b] of block b's nstride ids are in use
+__device__ __forceinline__ bool kc_nid_in_use(u64 nid, const u32 *__restrict__ ncount, u32 nstride) {
+    const u64 blk = nid / nstride;
+    return (u32)(nid - blk * nstride) < ncount[blk];
+}
 // Branch ports re-enumerate their candidates and reject every existing one they did not choose: the rejected port's
 // round-1 choice (which can only have been this port) is not reciprocated, so it joins the work list of round 2.
 template <int W>
@@ -116,12 +121,13 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
 // Fallback for heavily branching graphs (the branch list overflowed): check every round-1 choice against its target
 // directly. FILL = false counts the unreciprocated ports, FILL = true marks them LK_REJ and lists them.
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, u64 n_nodes, u64 *work_out, u64 *cursor) {
-    // a thread takes 32 nodes (dense ids: every one is a k-mer)
+__global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride, u64 *work_out, u64 *cursor) {
+    // a thread takes 32 node ids (the ids in use: the first ncount[b] of every block's nstride)
     const u64 n0 = kc_gtid() * 32;
     u64 m = 0;   // bit 2i+p: port p of node n0+i is an unreciprocated choice
     for (int i = 0; i < 32 && n0 + (u64)i < n_nodes; ++i)
         for (int port = 0; port < 2; ++port) {
+            if (!kc_nid_in_use(n0 + (u64)i, ncount, nstride)) continue;
             const u64 pid = ((n0 + (u64)i) << 1) | (u64)port;
             u64 w = link[pid];
             if (LK_STATE(w) != LK_CHOICE) continue;
@@ -157,12 +163,13 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
 
 // heads of directed chains: oriented node (id, o) whose entry port (L for o=0, R for o=1) is not matched.
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_heads_kernel(const u64 *__restrict__ link, u64 n_nodes, int complements, u64 *heads, u64 *cursor) {
-    const u64 n0 = kc_gtid() * 32;   // 32 nodes per thread
+__global__ void __launch_bounds__(256) kc_heads_kernel(const u64 *__restrict__ link, u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride, int complements, u64 *heads, u64 *cursor) {
+    const u64 n0 = kc_gtid() * 32;   // 32 node ids per thread
     u64 m = 0;   // bit 2i+o: (n0+i, o) is a head
     const int no = complements ? 2 : 1;
     for (int i = 0; i < 32 && n0 + (u64)i < n_nodes; ++i)
         for (int o = 0; o < no; ++o) {
+            if (!kc_nid_in_use(n0 + (u64)i, ncount, nstride)) continue;
             u64 w = link[((n0 + (u64)i) << 1) | (u64)o];
             if (!LK_IS_MATCHED(w)) m |= (u64)1 << (2 * i + o);
         }
@@ -287,9 +294,9 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
 }
 
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_unvisited_kernel(u64 n_nodes, const u8 *__restrict__ visited, u64 *list, u64 *cursor) {
+__global__ void __launch_bounds__(256) kc_unvisited_kernel(u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride, const u8 *__restrict__ visited, u64 *list, u64 *cursor) {
     u64 nid = kc_gtid();
-    if (nid >= n_nodes || visited[nid]) return;
+    if (nid >= n_nodes || visited[nid] || !kc_nid_in_use(nid, ncount, nstride)) return;
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
     if (FILL) list[pos] = nid;
 }
@@ -408,11 +415,11 @@ __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, con
 // of its segments (length/256 steps) to get the chain's length, tail and segment offsets; segments finally emit their
 // bases in parallel.  A multi-Mbp chain therefore costs ~256 sequential steps instead of millions.
 #define KC_SEG_NONE (~(u64)0)
-__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, u64 n_nodes,
+__global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride,
                                                               int complements, u64 *starts, u64 *cursor) {
     // splitters are the nodes whose dense id is a multiple of 256 (round 1 flags exactly those LK_SPLIT)
     const u64 slot = ((u64)blockIdx.x * blockDim.x + threadIdx.x) << 8;
-    if (slot >= n_nodes) return;
+    if (slot >= n_nodes || !kc_nid_in_use(slot, ncount, nstride)) return;
     const int no = complements ? 2 : 1;
     for (int o = 0; o < no; ++o) {
         u64 w = link[(slot << 1) | (u64)o];          // entry port of orientation o is port o
@@ -597,11 +604,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (N == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
     // Nodes are DENSE ids: the k-mers numbered in slot order (kc_set_dev.h).  The port links are 16 bytes per k-mer, written
     // contiguously by round 1, not 16 bytes per slot of a table at load 0.5.
-    u64 n_dense = 0;
-    KC_TRY(kcs_prepare_dense(set, &n_dense));
-    if (n_dense != N) return kc_fail(ctx, KC_E_NO_DEVICE, "k-mer count and occupied slots disagree");
+    KC_TRY(kcs_prepare_dense(set));
     sv = kc_view<W>(set);
-    const u64 nports = N * 2;
+    const u64 NID = set->nblocks * (u64)set->nstride;   // node ids (block b owns [b * nstride, b * nstride + its k-mers))
+    const u32 *ncount = set->ncount;
+    const u32 nstride = set->nstride;
+    const u64 nports = NID * 2;
     u64 *link = nullptr, *cnt = nullptr;
     KC_TRY(scope.alloc(&link, nports + 2));
     KC_TRY(scope.alloc(&cnt, 8));
@@ -697,7 +705,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
         // kc_reject_kernel run may already have set are simply found again
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, link, N,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, link, NID, ncount, nstride,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
         scope.release(work_a); scope.release(work_b);
@@ -705,7 +713,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&work_a, work_cap));
         KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, link, N, work_a,
+        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, link, NID, ncount, nstride, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
@@ -726,17 +734,17 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
 
     // chain heads
     u64 nheads = 0;
-    const u64 nsplit_max = (N + 255) >> 8;   // splitters: nodes with id % 256 == 0
+    const u64 nsplit_max = (NID + 255) >> 8;   // splitters: nodes with id % 256 == 0
     KC_TRY(read_u64(ctx, heads_cursor, &nheads));
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<false>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, N, compl_,
+        hipLaunchKernelGGL((kc_heads_kernel<false>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, NID, ncount, nstride, compl_,
                            (u64 *)nullptr, cnt);
         KC_TRY(read_u64(ctx, cnt, &nheads));
         KC_TRY(scope.alloc(&heads, nheads + 1));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<true>), kc_grid2((N + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, N, compl_, heads,
+        hipLaunchKernelGGL((kc_heads_kernel<true>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, NID, ncount, nstride, compl_, heads,
                            cnt);
     }
     // ---- chain discovery.  Pass 0 works on the heads round 1..n produced.  K-mers on cycles (every port matched) are
@@ -806,7 +814,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 // a chain beyond the limit, or k-mers on cycles (reached from no head): put the replaced link words back and
                 // let the classic flow below run on the original links
                 hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog,
-                                   (const u64 *)fblog, set->bshift, (u64)0, (const u64 *)set->nbase);
+                                   (const u64 *)fblog, set->bshift, (u64)0, nstride);
                 KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
                 if (hf[7]) known_long = true;
                 use_frag = false;
@@ -845,7 +853,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
             KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                               N, compl_, starts_raw, cnt + 6);
+                               NID, ncount, nstride, compl_, starts_raw, cnt + 6);
             KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
             KC_TRY(kcu_sort_pairs(ctx, starts_raw, starts, nullptr, nullptr, nstarts, 0, 64));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -870,8 +878,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // ---- not every k-mer is on a chain with ends: cycles.  Mark what the heads reach, cut the rest, go again.
         if (pass == 2) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not cover the set after cutting the cycles");
         u8 *visited = nullptr;
-        KC_TRY(scope.alloc(&visited, N));
-        KC_HIP(ctx, hipMemsetAsync(visited, 0, N, ctx->stream));
+        KC_TRY(scope.alloc(&visited, NID));
+        KC_HIP(ctx, hipMemsetAsync(visited, 0, NID, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         if (too_long) {
             if (nstarts)
@@ -882,7 +890,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(N, 256), dim3(256), 0, ctx->stream, N, (const u8 *)visited,
+        hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited,
                            (u64 *)nullptr, cnt + 1);
         u64 nunvis = 0;
         KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
@@ -890,7 +898,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         u64 *ulist = nullptr, *heads2 = nullptr;
         KC_TRY(scope.alloc(&ulist, nunvis));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(N, 256), dim3(256), 0, ctx->stream, N, (const u8 *)visited, ulist,
+        hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited, ulist,
                            cnt + 1);
         {
             // rows of the k-mers on cycles and the candidate edges of their ports to dead ports -> host, which walks the cycles and

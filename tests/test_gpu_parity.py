@@ -141,9 +141,11 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
 @pytest.mark.parametrize("knobs", [{"KC_BUCKET_MIN": "0"}, {"KC_BUCKET_MIN": "1000000000"}, {"KC_NOREC": "1"}, {"KC_NOSTAGE": "1"},
                                    {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_NOFRAG": "1"}, {"KC_CHAIN_LIMIT": "600"},
                                    {"KC_BUCKET_MIN": "0", "KC_SCATTER_ROLL": "1"}, {"KC_BUCKET_MIN": "0", "KC_PROBE_LISTED_GLOBAL": "1"},
-                                   {"KC_BUCKET_MIN": "0", "KC_BUILD_NOPREFETCH": "1", "KC_SCATTER_CHUNKS": "2"}],
+                                   {"KC_BUCKET_MIN": "0", "KC_BUILD_NOPREFETCH": "1", "KC_SCATTER_CHUNKS": "2"},
+                                   {"KC_BUCKET_MIN": "0", "KC_NO_BUILD_IDS": "1"}],
                          ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "plain-walk",
-                              "fragment-contraction-then-restore", "rolling-scatter", "listed-ports-from-the-table", "no-build-prefetch"])
+                              "fragment-contraction-then-restore", "rolling-scatter", "listed-ports-from-the-table", "no-build-prefetch",
+                              "node-ids-by-a-sweep-of-their-own"])
 def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
     """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
     walk, LDS tag staging; the wave-cooperative bucket scatter -- default with KC_BUCKET_MIN=0 for single-word keys on minimizer

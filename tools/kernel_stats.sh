@@ -8,6 +8,6 @@ rm -f $OUT/*/*_kernel_trace.csv
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")[0]
-for r in list(csv.DictReader(open(f)))[:8]:
+for r in list(csv.DictReader(open(f)))[:16]:
     print(r["Name"][:60].ljust(60), r["Calls"].rjust(5), "%10.1f us avg" % (float(r["AverageNs"]) / 1e3), r["Percentage"])
 PY
