@@ -115,8 +115,8 @@ int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offse
                kc_result **out);
 /* stats[16]: 0 n_kmers, 1 n_simplitigs, 2 length, 3 sparse_branch, 4 n_vertices, 5 matching_rounds,
  *            6.. device time per phase in microseconds: 6 pack+insert, 7 simplitigs, 8 overlap path, 9 emit(+mask),
- *            10 neighbour-probe kernel time (us, HIP events around the launch of kc_choose_dense_kernel -- the dominant
- *            kernel), 11 k-mer insert kernel time (us, summed over its launches), 12 table capacity,
+ *            10 neighbour-probe kernel time (us, HIP events around the launch of kc_probe_block_kernel -- the dominant
+ *            kernel; kc_choose_dense_kernel for k < 18), 11 k-mer insert kernel time (us, summed over its launches), 12 table capacity,
  *            13 overlap repair rounds, 14 total device us, 15 reserved */
 int kc_result_stats(kc_result *r, uint64_t *stats);
 /* the same followed by more: stats[16] cycles the simplitig rule had to cut (every k-mer of such a cycle has both ports
@@ -165,7 +165,7 @@ int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, ui
 int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner);
 /* The greedy branch of kmercamel<>() over all ranks' records: `seq`/`len` are THIS rank's records (joined by '\n', may be
  * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE, KC_FLAG_WANT_MASK, KC_FLAG_MIN_FREQUENCY
- * (k >= 18; -S goes through the single-GPU kc_compute).  KC_E_ARG with a message ending in "not part of the hash-sharded path" is
+ * (k >= 18; -S input: kc_compute_sharded_simplitigs).  KC_E_ARG with a message ending in "not part of the hash-sharded path" is
  * returned by ALL ranks together for inputs the path does not cover (the sparse branch, main.cpp:175; -z with overflowing table
  * blocks): the caller then runs kc_compute on one GPU.  The result holds this rank's slice; stats as kc_result_stats with global
  * counts. */

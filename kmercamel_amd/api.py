@@ -625,7 +625,7 @@ class Comm:
     def stats(self):
         st = (ctypes.c_uint64 * 8)()
         self.ctx.check(self.ctx.lib.kc_comm_stats(self.h, st))
-        return {"bytes_sent": st[0], "bytes_received": st[1], "calls": st[2], "us_in_collectives": st[3]}
+        return {"bytes_sent": st[0], "bytes_received": st[1], "calls": st[2], "us_in_collectives": st[3], "self_sendrecv_calls": st[4]}
 
     def close(self):
         if self.h:

@@ -46,7 +46,7 @@ struct kc_comm {
     void *nccl_comm = nullptr;
     u64 *d_small = nullptr;   // device scratch for the host-word all-gather
     // statistics
-    u64 bytes_sent = 0, bytes_received = 0, calls = 0;
+    u64 bytes_sent = 0, bytes_received = 0, calls = 0, self_sendrecv_calls = 0;
     double seconds = 0;
 };
 

@@ -3,24 +3,27 @@
 #include "kc_comm.h"
 #include <chrono>
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// ---- RCCL entry points (rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclSend/ncclRecv, ncclGroupStart/End, ncclAllGather)
-struct NcclId { char internal[128]; };
-typedef int (*fn_get_id)(NcclId *);
-typedef int (*fn_init_rank)(void **, int, NcclId, int);
-typedef int (*fn_destroy)(void *);
-typedef int (*fn_sendrecv)(void *, size_t, int, int, void *, hipStream_t);
-typedef int (*fn_group)();
-typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
-typedef const char *(*fn_errstr)(int);
+// ---- RCCL entry points: the prototypes and types come from <rccl/rccl.h> (the library itself is dlopen'ed, not linked)
+typedef ncclUniqueId NcclId;
+static_assert(sizeof(NcclId) == 128, "kc_rccl_unique_id hands out 128 bytes");
+typedef decltype(&ncclGetUniqueId) fn_get_id;
+typedef decltype(&ncclCommInitRank) fn_init_rank;
+typedef decltype(&ncclCommDestroy) fn_destroy;
+typedef decltype(&ncclSend) fn_send;
+typedef decltype(&ncclRecv) fn_recv;
+typedef decltype(&ncclGroupStart) fn_group;
+typedef decltype(&ncclAllGather) fn_allgather;
+typedef decltype(&ncclGetErrorString) fn_errstr;
 struct Rccl {
     void *lib = nullptr;
     fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_destroy destroy = nullptr;
-    fn_sendrecv send = nullptr, recv = nullptr; fn_group group_start = nullptr, group_end = nullptr;
+    fn_send send = nullptr; fn_recv recv = nullptr; fn_group group_start = nullptr, group_end = nullptr;
     fn_allgather allgather = nullptr; fn_errstr errstr = nullptr;
     bool load(std::string &err) {
         if (lib) return true;
@@ -28,7 +31,7 @@ struct Rccl {
         for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
         if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
         get_id = (fn_get_id)dlsym(lib, "ncclGetUniqueId"); init_rank = (fn_init_rank)dlsym(lib, "ncclCommInitRank");
-        destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy"); send = (fn_sendrecv)dlsym(lib, "ncclSend"); recv = (fn_sendrecv)dlsym(lib, "ncclRecv");
+        destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy"); send = (fn_send)dlsym(lib, "ncclSend"); recv = (fn_recv)dlsym(lib, "ncclRecv");
         group_start = (fn_group)dlsym(lib, "ncclGroupStart"); group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
         allgather = (fn_allgather)dlsym(lib, "ncclAllGather"); errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
         if (!get_id || !init_rank || !destroy || !send || !recv || !group_start || !group_end || !allgather) { err = "librccl.so lacks an expected symbol"; return false; }
@@ -36,10 +39,10 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
-const int kNcclUint8 = 1;   // ncclUint8 (rccl.h ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1)
+const ncclDataType_t kNcclUint8 = ncclUint8;
 
 int nccl_fail(kc_ctx *ctx, const char *what, int rc) {
-    return kc_fail(ctx, KC_E_TRANSPORT, std::string(what) + ": RCCL error " + std::to_string(rc) + (g_rccl.errstr ? std::string(" (") + g_rccl.errstr(rc) + ")" : ""));
+    return kc_fail(ctx, KC_E_TRANSPORT, std::string(what) + ": RCCL error " + std::to_string(rc) + (g_rccl.errstr ? std::string(" (") + g_rccl.errstr((ncclResult_t)rc) + ")" : ""));
 }
 
 int ensure_stage(kc_comm *c, size_t send_bytes, size_t recv_bytes) {
@@ -108,18 +111,22 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
         if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == KC_OK) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: copy failed");
         g->barrier();   // the senders may reuse their buffers
     } else {
-        // the part a rank keeps for itself is a device-to-device copy; the rest goes out as one group of sends and receives
+        // the part a rank keeps for itself is a device-to-device copy; the rest goes out as one group of sends and receives.
+        // KC_RCCL_SELF_SENDRECV=1 (tests): the rank's own part goes through ncclSend / ncclRecv to itself as well, so that the
+        // grouped send / receive code -- prototypes, datatype, zero counts, stream order -- runs on a box with a single GPU.
+        static const bool self_sr = getenv("KC_RCCL_SELF_SENDRECV") != nullptr;
         if (send_cnt[c->rank] != recv_cnt[c->rank]) return kc_fail(ctx, KC_E_ARG, "all-to-all: a rank's send and receive counts for itself differ");
-        if (send_cnt[c->rank])
+        if (send_cnt[c->rank] && !self_sr)
             KC_HIP(ctx, hipMemcpyAsync((u8 *)d_recv + recv_off[c->rank], (const u8 *)d_send + send_off[c->rank], send_cnt[c->rank], hipMemcpyDeviceToDevice, ctx->stream));
         int e = g_rccl.group_start();
         if (e) return nccl_fail(ctx, "ncclGroupStart", e);
         for (int p = 0; p < G && !e; ++p) {
-            if (p == c->rank) continue;
-            if (send_cnt[p]) e = g_rccl.send(const_cast<u8 *>((const u8 *)d_send + send_off[p]), send_cnt[p], kNcclUint8, p, c->nccl_comm, ctx->stream);
-            if (!e && recv_cnt[p]) e = g_rccl.recv((u8 *)d_recv + recv_off[p], recv_cnt[p], kNcclUint8, p, c->nccl_comm, ctx->stream);
+            if (p == c->rank && !self_sr) continue;
+            if (send_cnt[p]) e = g_rccl.send((const u8 *)d_send + send_off[p], send_cnt[p], kNcclUint8, p, (ncclComm_t)c->nccl_comm, ctx->stream);
+            if (!e && recv_cnt[p]) e = g_rccl.recv((u8 *)d_recv + recv_off[p], recv_cnt[p], kNcclUint8, p, (ncclComm_t)c->nccl_comm, ctx->stream);
         }
         int e2 = g_rccl.group_end();
+        if (self_sr) ++c->self_sendrecv_calls;
         if (e || e2) rc = nccl_fail(ctx, "grouped ncclSend/ncclRecv", e ? e : e2);
     }
     c->seconds += now_s() - t0;
@@ -147,7 +154,7 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
             const int nw = words - w0 < 64 ? words - w0 : 64;
             u64 *d_in = c->d_small, *d_out = c->d_small + 64;
             KC_HIP(ctx, hipMemcpyAsync(d_in, in + w0, (size_t)nw * 8, hipMemcpyHostToDevice, ctx->stream));
-            int e = g_rccl.allgather(d_in, d_out, (size_t)nw * 8, kNcclUint8, c->nccl_comm, ctx->stream);
+            int e = g_rccl.allgather(d_in, d_out, (size_t)nw * 8, kNcclUint8, (ncclComm_t)c->nccl_comm, ctx->stream);
             if (e) return nccl_fail(ctx, "ncclAllGather", e);
             KC_HIP(ctx, hipMemcpyAsync(piece.data(), d_out, (size_t)nw * 8 * c->world, hipMemcpyDeviceToHost, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -230,7 +237,7 @@ extern "C" int kc_comm_create_rccl(kc_ctx *ctx, int rank, int world, const void 
     KC_HIP(ctx, hipSetDevice(ctx->device));
     NcclId id;
     memcpy(id.internal, id128, 128);
-    void *comm = nullptr;
+    ncclComm_t comm = nullptr;
     int e = g_rccl.init_rank(&comm, world, id, rank);
     if (e) return nccl_fail(ctx, "ncclCommInitRank", e);
     kc_comm *c = new kc_comm();
@@ -246,7 +253,7 @@ extern "C" void kc_comm_destroy(kc_comm *c) {
     if (c->stage_send) (void)hipHostFree(c->stage_send);
     if (c->stage_recv) (void)hipHostFree(c->stage_recv);
     if (c->d_small) kc_release(c->ctx, c->d_small);
-    if (c->nccl_comm) (void)g_rccl.destroy(c->nccl_comm);
+    if (c->nccl_comm) (void)g_rccl.destroy((ncclComm_t)c->nccl_comm);
     delete c;
 }
 
@@ -254,5 +261,6 @@ extern "C" int kc_comm_stats(kc_comm *c, uint64_t *stats) {
     if (!c || !stats) return KC_E_ARG;
     for (int i = 0; i < 8; ++i) stats[i] = 0;
     stats[0] = c->bytes_sent; stats[1] = c->bytes_received; stats[2] = c->calls; stats[3] = (u64)(c->seconds * 1e6);
+    stats[4] = c->self_sendrecv_calls;   // exchanges whose own part went through ncclSend / ncclRecv (KC_RCCL_SELF_SENDRECV, tests)
     return KC_OK;
 }

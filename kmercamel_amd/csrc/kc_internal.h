@@ -91,12 +91,17 @@ struct kc_result {
     u64 stats_ext[16] = {0};   // [0] cycles cut by the simplitig rule, [1] k-mers on this rank, [2] neighbour queries sent (sharded runs)
 };
 
+// (set by kc_grid when a launch would need 2^32 or more threads in one dimension: the launch then fails -- a grid of 0 workgroups is
+// an invalid configuration -- and the next KC_HIP reports KC_E_ARG with that reason instead of a bare HIP error)
+inline thread_local bool kc_grid_overflowed = false;
 #define KC_HIP(ctx, call)                                                                                  \
     do {                                                                                                   \
         hipError_t e__ = (call);                                                                           \
         if (e__ != hipSuccess) {                                                                           \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
-            return KC_E_NO_DEVICE;                                                                         \
+            const bool big__ = kc_grid_overflowed;                                                         \
+            kc_grid_overflowed = false;                                                                    \
+            (ctx)->err = std::string(big__ ? "the input needs a 1-D launch of 2^32 or more threads (not supported): " : "") + #call + ": " + hipGetErrorString(e__) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
+            return big__ ? KC_E_ARG : KC_E_NO_DEVICE;                                                      \
         }                                                                                                  \
     } while (0)
 
@@ -151,11 +156,11 @@ struct KcScope {
 };
 
 // A dispatch carries its size in work-items as 32 bits per dimension: a 1-D launch of 2^32 or more threads is silently
-// truncated.  kc_grid refuses such a launch loudly; kernels that sweep table-sized ranges (> 2^32 slots at 2.5 G k-mers)
+// truncated.  kc_grid refuses such a launch (the call fails with KC_E_ARG); kernels that sweep table-sized ranges (> 2^32 slots at 2.5 G k-mers)
 // are launched on kc_grid2's 2-D grid and number their threads with kc_gtid().
 static inline unsigned kc_grid(u64 n, unsigned block) {
     u64 g = (n + block - 1) / block;
-    if (g * block >= ((u64)1 << 32)) { fprintf(stderr, "kmercamel_amd: internal error: 1-D launch of %llu threads\n", (unsigned long long)(g * block)); abort(); }
+    if (g * block >= ((u64)1 << 32)) { kc_grid_overflowed = true; return 0u; }   // (the launch fails, KC_HIP turns that into KC_E_ARG)
     return (unsigned)(g ? g : 1);
 }
 static inline dim3 kc_grid2(u64 n, unsigned block) {

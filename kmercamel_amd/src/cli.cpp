@@ -128,9 +128,12 @@ static void write_all(int fd, const char *data, size_t n) {
 // byte-identical to the single-GPU result -- and every rank copies its slice into place.
 static const int KC_CLI_SHARDED_FALLBACK = -1000;
 static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus, int min_frequency, bool assume_simplitigs,
-                               std::string *why) {
+                               std::string *why, Records *loaded) {
     WriteLog("Started computation of a masked superstring from '" + path + "'.");
-    Records recs = load_records(path, assume_simplitigs);
+    // (the records stay with the caller: if the ranks hand the input back -- sparse branch, -z overflow -- the single-GPU run must not
+    // read the input a second time; stdin, FIFOs and process substitutions can be read only once)
+    *loaded = load_records(path, assume_simplitigs);
+    Records &recs = *loaded;
     const std::string &j = recs.joined;
     // part r = the records from the first line start at or after byte len * r / N (-S: records rec_cut[r] .. rec_cut[r + 1], with their
     // offsets counted from the part's first byte)
@@ -219,17 +222,20 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
 }
 
 int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
-                int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1) {
+                int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1, bool gpus_explicit = true) {
     bool started_logged = false;
+    Records recs;             // the input, once it has been read on the host
+    bool have_recs = false;
     if (gpus > 1) {
         // what the hash-sharded path does not cover runs on one GPU, as without the option
         if (!lower_bound && (assume_simplitigs ? maskf == nullptr : k >= 18)) {
             std::string why;
-            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, assume_simplitigs, &why);
+            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, assume_simplitigs, &why, &recs);
             if (rc != KC_CLI_SHARDED_FALLBACK) return rc;
             std::cerr << "Note: " << why << "; running on one GPU." << std::endl;
             started_logged = true;
-        } else std::cerr << "Note: --gpus applies to `compute -k K [-M F] [-z N]` with K >= 18 and to `compute -S` without -M; running on one GPU." << std::endl;
+            have_recs = true;
+        } else if (gpus_explicit) std::cerr << "Note: --gpus applies to `compute -k K [-M F] [-z N]` with K >= 18 and to `compute -S` without -M; running on one GPU." << std::endl;
     }
     if (started_logged) { /* run_compute_sharded has logged the start */ }
     else if (!lower_bound) WriteLog("Started computation of a masked superstring from '" + path + "'.");
@@ -296,7 +302,6 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
             } else if (fd >= 0) ::close(fd);
         }
     }
-    Records recs;
     kc_ctx *ctx = nullptr;
     void *d_seq = nullptr;
     uint64_t d_len = 0;
@@ -308,7 +313,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         struct stat sti;
         reopenable = path != "-" && ::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode);
     }
-    if (!assume_simplitigs && !lower_bound && reopenable && !std::getenv("KC_CLI_NOSTREAM")) {
+    if (!assume_simplitigs && !lower_bound && reopenable && !have_recs && !std::getenv("KC_CLI_NOSTREAM")) {
         // FASTA goes to the device in pinned chunks and is tokenised there while the next chunk is read (no joined host copy)
         ctx = kcamd::context();
         mark("device context ready");
@@ -324,7 +329,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (streamed) mark("input on the device");
     }
     if (!streamed) {
-        recs = load_records(path, assume_simplitigs);
+        if (!have_recs) recs = load_records(path, assume_simplitigs);
         mark("records loaded");
         ctx = kcamd::context();
         mark("device context ready");
@@ -439,13 +444,19 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     bool complements = true, d_set = false, assume_simplitigs = false;
     int min_frequency = 1;
     int gpus = 1;
-    if (const char *e = std::getenv("KMERCAMEL_GPUS")) gpus = std::atoi(e);
+    bool gpus_explicit = false;   // --gpus on the command line (the environment variable applies silently where the sharded path does)
+    if (const char *e = std::getenv("KMERCAMEL_GPUS")) {
+        char *end = nullptr;
+        const long v = std::strtol(e, &end, 10);
+        if (*e && end && !*end && v >= 1 && v <= 64) gpus = (int)v;
+        else std::cerr << "Warning: KMERCAMEL_GPUS='" << e << "' is not an integer between 1 and 64; ignored." << std::endl;
+    }
     // the reference's options are short ones (main.cpp:234); the multi-GPU opt-in is a NEW long option, existing command lines are unchanged
     static const struct option long_opts[] = {{"gpus", required_argument, nullptr, 1000}, {nullptr, 0, nullptr, 0}};
     try {
         while ((opt = getopt_long(argc, argv, lowerbound ? "k:huxSz:" : "k:d:a:o:huxM:Sz:", long_opts, nullptr)) != -1) {
             switch (opt) {
-                case 1000: gpus = std::stoi(optarg); break;
+                case 1000: gpus = std::stoi(optarg); gpus_explicit = true; break;
                 case 'o': output.open(optarg); of = &output; out_path = optarg; break;
                 case 'k': k = std::stoi(optarg); break;
                 case 'd': d_set = true; d_max = std::stoi(optarg); break;
@@ -478,7 +489,7 @@ int camel_compute(int argc, char **argv, bool lowerbound) {
     if (min_frequency != 1 && assume_simplitigs) return fail("Inputting simplitigs is not compatible with frequency filterring.");
     if (algorithm != "greedy") return fail("Algorithm '" + algorithm + "' not supported by the MI355X build (greedy only).");
     if (gpus < 1 || gpus > 64) return fail("--gpus must be between 1 and 64.");
-    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency, out_path, mask_path, gpus);
+    return run_compute(path, k, of, maskf, complements, assume_simplitigs, lowerbound, min_frequency, out_path, mask_path, gpus, gpus_explicit);
 }
 
 // Optimize (masks.h:239-261) for max-one / min-one

@@ -67,7 +67,8 @@ def main():
             gathered[0][4]["calls"]), flush=True)
         import json
         with open(out_path + ".stats.json", "w") as f:
-            json.dump({"world": world, "n_kmers": stats["n_kmers"], "bytes_sent_per_owned_kmer": per_rank, "collectives": gathered[0][4]["calls"]}, f)
+            json.dump({"world": world, "n_kmers": stats["n_kmers"], "bytes_sent_per_owned_kmer": per_rank, "collectives": gathered[0][4]["calls"],
+                       "self_sendrecv_calls": gathered[0][4].get("self_sendrecv_calls", 0)}, f)
     comm.close()
     ctx.close()
     dist.destroy_process_group()

@@ -293,4 +293,17 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
     p = run("compute", "-k", "31", "--gpus", "2", sp)
     assert p.returncode == 0 and "sparse branch" in p.stderr and "running on one GPU" in p.stderr, p.stderr[-500:]
     assert p.stdout == run("compute", "-k", "31", sp).stdout
+    # the same through stdin: the ranks have consumed the stream, the one-GPU run must work from what they read (a second read of `-`,
+    # a FIFO or a process substitution finds nothing)
+    with open(sp, "rb") as f:
+        q = subprocess.run([BIN, "compute", "-k", "31", "--gpus", "2", "-"], stdin=f, capture_output=True)
+    assert q.returncode == 0 and b"running on one GPU" in q.stderr, q.stderr[-500:]
+    assert q.stdout.split(b"\n", 1)[1] == p.stdout.encode().split(b"\n", 1)[1]   # (the header names the path)
     assert run("compute", "-k", "31", "--gpus", "0", fa).returncode == 1
+    # KMERCAMEL_GPUS: a value that is no number between 1 and 64 is ignored with a warning (not "--gpus must be ..."), and the
+    # variable never prints the one-GPU note for commands the sharded path does not cover
+    for bad in ("", "two", "0", "999"):
+        e = subprocess.run([BIN, "compute", "-k", "31", fa], capture_output=True, text=True, env=dict(os.environ, KMERCAMEL_GPUS=bad))
+        assert e.returncode == 0 and "KMERCAMEL_GPUS" in e.stderr and e.stdout == run("compute", "-k", "31", fa).stdout, e.stderr[-300:]
+    e = subprocess.run([BIN, "compute", "-k", "15", br], capture_output=True, text=True, env=dict(os.environ, KMERCAMEL_GPUS="2"))
+    assert e.returncode == 0 and "running on one GPU" not in e.stderr
