@@ -97,10 +97,13 @@ template <int W> __device__ __forceinline__ bool ov_key_is_ours(const Key<W> &ke
 }
 template <int W>
 __global__ void __launch_bounds__(256) ov_insert_prefix_kernel(LevelTable<W> t, const u64 *__restrict__ actP, u64 nP,
-                                                               const u64 *__restrict__ pre, int k, int d, u64 *pslot, u32 G, u32 me) {
+                                                               const u64 *__restrict__ pre, const u64 *__restrict__ pred, int k, int d, u64 *pslot, u32 G, u32 me) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nP) return;
     u64 j = actP[i];
+    // (the active lists are compacted lazily -- only when a quarter of their entries have died -- so every sweep checks for itself
+    // whether a listed vertex still is an active prefix / suffix vertex)
+    if (pred[j] != KC_NONE64) { pslot[i] = KC_NONE64; return; }
     Key<W> key = key_prefix(load_key<W>(pre, j), k, d);
     if (!ov_key_is_ours(key, G, me)) { pslot[i] = KC_NONE64; return; }
     u64 s = level_insert(t, key, j, pre, k, d);
@@ -169,7 +172,7 @@ __device__ __forceinline__ void ov_list_hits(u32 hits, const u64 (&v)[OV_ITEMS],
 // (a workgroup takes 256 x OV_ITEMS consecutive positions of the active list, thread t the positions base + j * 256 + t)
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, const u64 *__restrict__ actS, u64 nS,
-                                                              const u64 *__restrict__ suf, const u64 *__restrict__ pre, int k, int d,
+                                                              const u64 *__restrict__ suf, const u64 *__restrict__ pre, const u64 *__restrict__ edge_from, int k, int d,
                                                               int complements, u8 *hitS, u64 *hit_count, u64 *hit_list, u64 hit_cap, u32 G, u32 me) {
     const u64 base = (u64)blockIdx.x * (256 * OV_ITEMS) + threadIdx.x;
     u32 hits = 0;
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(256) ov_probe_suffix_kernel(LevelTable<W> t, c
         if (i < nS) {
             v[j] = actS[i];
             Key<W> key = key_suffix(load_key<W>(suf, v[j]), d);
-            u64 s = ov_key_is_ours(key, G, me) ? level_find(t, key, pre, k, d) : KC_NONE64;
+            u64 s = (edge_from[v[j]] == KC_NONE64 && ov_key_is_ours(key, G, me)) ? level_find(t, key, pre, k, d) : KC_NONE64;   // (a listed vertex may have died: lazy compaction)
             u8 hit = 0;
             if (s != KC_NONE64) {
                 atomicAnd(&t.flags[s], ~2u);
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(256) ov_t16_build_kernel(T16 t, const u64 *__r
 }
 template <int W>
 __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__restrict__ actS, u64 nS, const u64 *__restrict__ suf, const u64 *__restrict__ pre,
-                                                         const u64 *__restrict__ pred, int k, int d, int complements, u8 *hitS, u32 *markP, u64 *cnt, u64 *hs_list,
+                                                         const u64 *__restrict__ pred, const u64 *__restrict__ edge_from, int k, int d, int complements, u8 *hitS, u32 *markP, u64 *cnt, u64 *hs_list,
                                                          u64 *hp_list, u64 hit_cap, u32 G, u32 me) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u8 hit = 0;
@@ -253,7 +256,7 @@ __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__res
     if (i < nS) {
         u = actS[i];
         const Key<W> key = key_suffix(load_key<W>(suf, u), d);
-        if (ov_key_is_ours(key, G, me)) {
+        if (edge_from[u] == KC_NONE64 && ov_key_is_ours(key, G, me)) {   // (a listed vertex may have died: lazy compaction)
             const u64 k16 = key_prefix(key, d, 16).w[0] & 0xffffffffull;
             u64 s = kc_mix64(k16) & t.mask;
             u64 cur;
@@ -283,6 +286,46 @@ __global__ void __launch_bounds__(256) ov_probe16_kernel(T16 t, const u64 *__res
         hitS[i] = hit;
     }
     ov_list_hit(hit, u, cnt + 1, hs_list, hit_cap);
+}
+
+// Counts, for the levels d0, d0 - 1, ... d0 - nlev + 1 (all >= 16) at once, the active suffix vertices that would hit at that level
+// if nothing changed in between: hist[j] for level d0 - j.  Edges only ever REMOVE vertices from the active sets, so a level that
+// counts zero here has no hit when its turn comes, whatever the levels before it did: the level loop skips it without a launch or
+// a read-back (k = 127 on 10^5 reads: 110 such levels in a row).  Levels that count something are probed as usual.
+template <int W>
+__global__ void __launch_bounds__(256) ov_count16_kernel(T16 t, const u64 *__restrict__ actS, u64 nS, const u64 *__restrict__ suf, const u64 *__restrict__ pre,
+                                                         const u64 *__restrict__ pred, const u64 *__restrict__ edge_from, int k, int d0, int nlev, u64 *hist,
+                                                         u32 G, u32 me) {
+    __shared__ u32 lh[128];
+    if (threadIdx.x < 128) lh[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nS) {
+        const u64 u = actS[i];
+        if (edge_from[u] == KC_NONE64) {
+            const Key<W> sfx = load_key<W>(suf, u);
+            for (int j = 0; j < nlev; ++j) {
+                const int d = d0 - j;
+                const Key<W> key = key_suffix(sfx, d);
+                if (!ov_key_is_ours(key, G, me)) continue;
+                const u64 k16 = key_prefix(key, d, 16).w[0] & 0xffffffffull;
+                u64 s = kc_mix64(k16) & t.mask;
+                u64 cur;
+                while ((cur = t.key[s]) != ~(u64)0 && cur != k16) s = (s + 1) & t.mask;
+                if (cur != k16) continue;
+                bool found = false;
+                int steps = 0;
+                for (u32 v = t.head[s]; v != 0xffffffffu && !found; v = t.next[v]) {
+                    if (++steps > KC_T16_CHAIN_MAX) { found = true; break; }   // (a long chain: let the level's own probe decide)
+                    if (pred[v] != KC_NONE64) continue;
+                    found = key_eq(key_prefix(load_key<W>(pre, v), k, d), key);
+                }
+                if (found) atomicAdd(&lh[j], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)nlev && lh[threadIdx.x]) atomicAdd((ull *)&hist[threadIdx.x], (ull)lh[threadIdx.x]);
 }
 
 // hitP (by position in actP) and the exact number of prefix hits from the per-vertex marks of ov_probe16_kernel: only needed
@@ -410,6 +453,26 @@ __global__ void __launch_bounds__(256) ov_fix_kernel(const u64 *__restrict__ ne,
     }
     if (WRITE) { first_snap[l0] = f; last_snap[f] = l0; }
     else atomicAdd((ull *)covered, (ull)steps);
+}
+// the level is acyclic: write the new path ends and clear the coverage marks in one launch (one thread per logged edge; the two
+// jobs touch different arrays)
+__global__ void __launch_bounds__(256) ov_fix_write_clear_kernel(const u64 *__restrict__ ne, const u64 *__restrict__ n_ptr, const u64 *__restrict__ edge_from,
+                                                                 const u64 *__restrict__ pred, u64 *first_snap, u64 *last_snap, u8 *cov) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n = *n_ptr;
+    if (t >= n) return;
+    const u64 y = ne[t * 5 + 1];
+    cov[y] = 0;
+    const u64 l0 = last_snap[y];
+    if (edge_from[l0] != KC_NONE64) return;   // not the tail of its merged path
+    u64 f = y, steps = 0;
+    while (steps <= n) {
+        const u64 xp = pred[f];
+        if (xp == KC_NONE64) break;
+        ++steps;
+        f = first_snap[xp];
+    }
+    first_snap[l0] = f; last_snap[f] = l0;
 }
 
 // cycle repair (rare, one thread): among the cycles left uncovered, find the one whose latest event is earliest, and
@@ -736,13 +799,20 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     if (log_sharded) { KC_TRY(scope.alloc(&ne_sh, 64 * ne_shcap * 5)); KC_TRY(scope.alloc(&ne_shcur, 65 * 16)); }
     g.ne_sh = nullptr; g.ne_shcur = ne_shcur; g.ne_shcap = ne_shcap;
     u64 nS = V, nP = V, repairs = 0, tag_base = 0;
+    u64 lenS = V, lenP = V;   // entries of the active lists (>= the live vertices nS / nP: the lists are compacted lazily, see the end of the loop)
+    // windowed hit counts through the 16-mer table (ov_count16_kernel): levels [win_lo, win_hi] have been counted
+    u64 *whist = nullptr;
+    KC_TRY(scope.alloc(&whist, 64));
+    int win_hi = -1, win_lo = 0;
+    u64 wcount[32] = {0};
+    bool win_on = t16_on && !split && !getenv("KC_OV_NO_WINDOW");
     std::vector<u64> h_bl;
     if (!lower_bound) {   // tag 0xffffffff = written by nobody
         KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
     }
 
-    KC_HIP(ctx, hipHostMalloc((void **)&hp, 512, hipHostMallocDefault));
+    KC_HIP(ctx, hipHostMalloc((void **)&hp, 1024, hipHostMallocDefault));   // (hp[64..96): the window counts)
     w.h_flag = hp + 15;   // (the level loop reads back at most 9 words; hp[32..] are staging words of the sharded flow)
     u64 *ne_all = nullptr;
     if (split) KC_TRY(scope.alloc(&ne_all, V * 10 + 10));
@@ -761,20 +831,39 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
             KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
             cnt = fresh_cnt();
-            hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
-                               (const u64 *)pre, k, d, pslot, PG, pme);
-            hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid((nS + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, nS,
-                               (const u64 *)suf, (const u64 *)pre, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
-            hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid((nP + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, nP,
+            hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, lenP,
+                               (const u64 *)pre, (const u64 *)pred, k, d, pslot, PG, pme);
+            hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid((lenS + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, lenS,
+                               (const u64 *)suf, (const u64 *)pre, (const u64 *)edge_from, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
+            hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid((lenP + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, lenP,
                                (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
             KC_TRY(read_back(ctx, hp, cnt, 4));
             return KC_OK;
         };
         if (t16_on && !t16_dead && d >= 16) {
+            // Small active sets: count the hits of a window of levels in one sweep first (ov_count16_kernel); a level that counts
+            // zero is skipped without a launch or a read-back.  The window shrinks to nothing once most levels have hits.
+            if (win_on && (d > win_hi || d < win_lo)) {
+                int B = (int)(((u64)1 << 22) / (lenS ? lenS : 1));
+                if (B > 32) B = 32;
+                if (B > d - 15) B = d - 15;
+                if (B >= 2) {
+                    KC_HIP(ctx, hipMemsetAsync(whist, 0, 32 * 8, ctx->stream));
+                    hipLaunchKernelGGL((ov_count16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
+                                       (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, B, whist, PG, pme);
+                    KC_TRY(read_back(ctx, hp + 64, whist, B));
+                    int with_hits = 0;
+                    for (int j = 0; j < B; ++j) { wcount[j] = hp[64 + j]; with_hits += wcount[j] != 0; }
+                    win_hi = d; win_lo = d - B + 1;
+                    if (2 * with_hits > B) win_on = false;   // (hits at most levels: the count costs as much as the levels themselves)
+                    if (trace) fprintf(stderr, "[ov] window d=%d..%d: %d level(s) with hits\n", win_hi, win_lo, with_hits);
+                } else win_on = false;
+            }
+            if (d <= win_hi && d >= win_lo && wcount[win_hi - d] == 0) continue;   // counted: no suffix vertex can hit at this level
             // one sweep over the active suffixes through the 16-mer table of the prefix ends (see ov_probe16_kernel)
             cnt = fresh_cnt();
-            hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, nS, (const u64 *)suf,
-                               (const u64 *)pre, (const u64 *)pred, k, d, complements, hitS, markP, cnt, hs_ids, hp_ids, (u64)KC_SMALL_ROWS, PG, pme);
+            hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
+                               (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, complements, hitS, markP, cnt, hs_ids, hp_ids, (u64)KC_SMALL_ROWS, PG, pme);
             KC_TRY(read_back(ctx, hp, cnt, 6));
             if (hp[4]) {   // a chain beyond the limit (repetitive ends; chains never shrink): this level and the later ones take tables of their own
                 t16_dead = true;
@@ -784,7 +873,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 if (hp[5] || hp[3] >= KC_SMALL_ROWS || getenv("KC_NO_SMALL_SORT")) {
                     // many prefix hits: their exact number and hitP (read by the ordered compaction) come from a sweep over the marks
                     u64 *c2 = fresh_cnt();
-                    hipLaunchKernelGGL(ov_marks_to_hits_kernel, dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP, (const u32 *)markP, hitP,
+                    hipLaunchKernelGGL(ov_marks_to_hits_kernel, dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP, (const u32 *)markP, hitP,
                                        c2, hp_ids, (u64)KC_SMALL_ROWS);
                     KC_TRY(read_back(ctx, hp + 48, c2, 1));
                     hp[3] = hp[48];
@@ -824,7 +913,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         if (!local_any) { /* nothing of ours at this level: only the exchange below */ }
         else if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
         else {
-            KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, nS));
+            KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, lenS));
             hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
                                (const u64 *)suf, k, d, hs_keys);
             KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3, 0, true, &bkS));
@@ -832,7 +921,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         if (!local_any) { }
         else if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
         else {
-            KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, nP));
+            KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, lenP));
             hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
                                (const u64 *)pre, k, d, hp_keys);
             KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3, 1, true, &bkP));
@@ -941,9 +1030,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             }
             if (nNew == 0 || lower_bound) break;
             if (covered == nNew) {
-                hipLaunchKernelGGL((ov_fix_kernel<true>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
-                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, CNT + 2);
-                hipLaunchKernelGGL(ov_clear_cov_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, cov);
+                hipLaunchKernelGGL(ov_fix_write_clear_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
+                                   (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov);
                 break;
             }
             // a cycle slipped through a stale path-end test: blacklist its earliest closing event, undo, replay
@@ -971,21 +1059,24 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         }
         h_bl.clear(); g.nbl = 0;   // the blacklist is per level
         if (nNew == 0) continue;
-        // 6. shrink the active lists
-        hipLaunchKernelGGL((ov_still_active_kernel<true>), dim3(kc_grid(nS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, nS,
+        // 6. shrink the active lists -- lazily: every sweep checks for itself whether a listed vertex is still active, so the lists
+        // are only compacted (two flag sweeps + two ordered compactions: 8 launches) once a quarter of their entries have died
+        if (!lower_bound) { nS -= nNew; nP -= nNew; }   // every new edge removes exactly one suffix vertex and one prefix vertex
+        if (!lower_bound && !getenv("KC_OV_EAGER_SHRINK") && (lenS - nS) * 4 <= lenS && (lenP - nP) * 4 <= lenP) continue;
+        hipLaunchKernelGGL((ov_still_active_kernel<true>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, lenS,
                            (const u64 *)edge_from, (const u64 *)pred, hitS);
-        hipLaunchKernelGGL((ov_still_active_kernel<false>), dim3(kc_grid(nP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, nP,
+        hipLaunchKernelGGL((ov_still_active_kernel<false>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP,
                            (const u64 *)edge_from, (const u64 *)pred, hitP);
         if (lower_bound) {   // an edge may have been logged twice: take the exact counts
             u64 nS2 = 0, nP2 = 0;
-            KC_TRY(select_flagged(w, actS, hitS, actS2, nS, &nS2));
-            KC_TRY(select_flagged(w, actP, hitP, actP2, nP, &nP2));
+            KC_TRY(select_flagged(w, actS, hitS, actS2, lenS, &nS2));
+            KC_TRY(select_flagged(w, actP, hitP, actP2, lenP, &nP2));
             nS = nS2; nP = nP2;
-        } else {             // every new edge removes exactly one suffix vertex and one prefix vertex
-            KC_TRY(select_flagged_nosync(w, actS, hitS, actS2, nS));
-            KC_TRY(select_flagged_nosync(w, actP, hitP, actP2, nP));
-            nS -= nNew; nP -= nNew;
+        } else {
+            KC_TRY(select_flagged_nosync(w, actS, hitS, actS2, lenS));
+            KC_TRY(select_flagged_nosync(w, actP, hitP, actP2, lenP));
         }
+        lenS = nS; lenP = nP;
         std::swap(actS, actS2); std::swap(actP, actP2);
     }
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
