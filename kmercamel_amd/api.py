@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkmercamel_amd.so")
 
 KC_OK = 0
-KC_E_NO_DEVICE, KC_E_EMPTY, KC_E_INVALID_CHAR, KC_E_ARG, KC_E_CAPACITY, KC_E_IO, KC_E_NO_KMERS = -1, -2, -3, -4, -5, -6, -7
+KC_E_NO_DEVICE, KC_E_EMPTY, KC_E_INVALID_CHAR, KC_E_ARG, KC_E_CAPACITY, KC_E_IO, KC_E_NO_KMERS, KC_E_TRANSPORT = -1, -2, -3, -4, -5, -6, -7, -8
 FLAG_COMPLEMENTS, FLAG_SIMPLITIGS_INPUT, FLAG_WANT_MASK, FLAG_INPUT_ON_DEVICE = 1, 2, 4, 8
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -621,6 +621,13 @@ class Comm:
         ctx.check(ctx.lib.kc_comm_create_callbacks(ctx.h, rank, world, ctypes.cast(fa, ctypes.c_void_p), ctypes.cast(fg, ctypes.c_void_p), None,
                                                    ctypes.byref(h)))
         return cls(ctx, h, rank, world, keep=(fa, fg))
+
+    @classmethod
+    def threads(cls, ctx, group, rank, world):
+        """rank `rank` of an in-process thread group (kc_thread_group_create(world)): the transport of `kmercamel compute --gpus N`"""
+        h = ctypes.c_void_p()
+        ctx.check(ctx.lib.kc_comm_create_threads(ctx.h, group, rank, ctypes.byref(h)))
+        return cls(ctx, h, rank, world)
 
     def stats(self):
         st = (ctypes.c_uint64 * 8)()

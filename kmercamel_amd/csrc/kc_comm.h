@@ -23,11 +23,19 @@ struct kc_thread_group {
     u64 generation = 0;
     bool failed = false;
     struct Post { const void *d_send; const u64 *send_off, *send_cnt; int device; const u64 *words; } post[64];
-    void barrier() {
+    // false: a rank has failed on its own and left (abort()): nobody waits for it, every later exchange fails with KC_E_TRANSPORT
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
         const u64 gen = generation;
         if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        else cv.wait(lk, [&] { return generation != gen || failed; });
+        return !failed;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
     }
 };
 
@@ -59,3 +67,10 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words);
 // convenience: element-wise sum / max over ranks of a few host words
 int kcc_allreduce_sum(kc_comm *c, u64 *vals, int words);
 int kcc_allreduce_max(kc_comm *c, u64 *vals, int words);
+// After a collective entry point (kc_compute_sharded*) returned `rc` on this rank.  An error that the ranks did NOT take together
+// (the agreed ones end in "not part of the hash-sharded path" / "no k-mers" / "cannot be empty" / "(on some rank)") means the peers
+// are still inside the flow and will wait for this rank in their next exchange: the thread transport wakes them with
+// KC_E_TRANSPORT (kc_thread_group::abort).  RCCL and caller-supplied transports have no such channel -- as with any NCCL program
+// the job is lost then and the launcher's watchdog has to end it; the failure points that can be CHECKED (capacity of the spill
+// lists and recording pools) are therefore agreed among the ranks before anybody returns.
+void kcc_after_collective_call(kc_comm *c, int rc);

@@ -97,7 +97,7 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
         kc_thread_group *g = c->group;
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // what this rank sends is complete before anybody reads it
         g->post[c->rank] = kc_thread_group::Post{d_send, send_off, send_cnt, ctx->device, nullptr};
-        g->barrier();
+        if (!g->barrier()) return kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
         for (int p = 0; p < G && rc == KC_OK; ++p) {
             const kc_thread_group::Post &q = g->post[p];
             const u64 n = q.send_cnt[c->rank];
@@ -109,7 +109,7 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
             if (e != hipSuccess) rc = kc_fail(ctx, KC_E_TRANSPORT, std::string("thread transport copy: ") + hipGetErrorString(e));
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == KC_OK) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: copy failed");
-        g->barrier();   // the senders may reuse their buffers
+        if (!g->barrier() && rc == KC_OK) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");   // (else: the senders may reuse their buffers)
     } else {
         // the part a rank keeps for itself is a device-to-device copy; the rest goes out as one group of sends and receives.
         // KC_RCCL_SELF_SENDRECV=1 (tests): the rank's own part goes through ncclSend / ncclRecv to itself as well, so that the
@@ -144,9 +144,9 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
     } else if (c->kind == 3) {
         kc_thread_group *g = c->group;
         g->post[c->rank].words = in;
-        g->barrier();
+        if (!g->barrier()) return kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
         for (int p = 0; p < c->world; ++p) memcpy(out + (size_t)p * words, g->post[p].words, (size_t)words * 8);
-        g->barrier();
+        if (!g->barrier()) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
     } else {
         // through a 64-word device window per rank; longer vectors go in pieces
         std::vector<u64> piece((size_t)64 * c->world);
@@ -163,6 +163,14 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
     }
     c->seconds += now_s() - t0;
     return rc;
+}
+
+void kcc_after_collective_call(kc_comm *c, int rc) {
+    if (rc == KC_OK || !c || c->kind != 3 || !c->group) return;
+    const std::string &e = c->ctx->err;
+    for (const char *agreed : {"not part of the hash-sharded path", "no k-mers", "cannot be empty", "(on some rank)", "another rank has failed"})
+        if (e.find(agreed) != std::string::npos) return;
+    c->group->abort();
 }
 
 int kcc_allreduce_sum(kc_comm *c, u64 *vals, int words) {

@@ -774,10 +774,13 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
         Key<W> key;
         for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
         bool claimed;
-        (void)insert(key, &claimed);   // (fits: the survivors are a subset of what fitted in pass 1)
+        // (the survivors are a subset of what fitted in pass 1, but bounded probe runs depend on the insertion order: a survivor that
+        // finds no room now is reported like one in pass 1 -- the ranks then leave the sharded path together)
+        if (insert(key, &claimed) == 0xffffu) lost = true;
         if (claimed) ++added;
     }
     if (added) atomicAdd(&added_s, added);
+    if (lost) atomicExch((ull *)&counters[3], 1ULL);
     __syncthreads();
     for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
@@ -1406,7 +1409,11 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         fprintf(stderr, "[set] rank %d/%d sharded build W=%d: %llu of %llu blocks (2^%d slots), %llu occurrences in, %llu received, size %llu, spills %llu\n", c->rank, G, W,
                 (unsigned long long)bpr, (unsigned long long)nblocks, set->bshift, (unsigned long long)occ_local, (unsigned long long)nrecv, (unsigned long long)h[0],
                 (unsigned long long)h[2]);
-    if (h[2] > ovf_cap) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded build: too many k-mers spilled out of their blocks");
+    {   // (agreed among the ranks: one that returned alone here would leave its peers waiting in the next exchange)
+        u64 over = h[2] > ovf_cap ? 1 : 0;
+        KC_TRY(kcc_allreduce_max(c, &over, 1));
+        if (over) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded build: too many k-mers spilled out of their blocks (on some rank)");
+    }
     if (h[2]) {
         hipLaunchKernelGGL(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), (const u64 *)ovf, h[2], set->counters);
         KC_HIP(ctx, hipGetLastError());

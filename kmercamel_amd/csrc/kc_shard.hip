@@ -741,6 +741,8 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     u64 N = N_local;
     KC_TRY(kcc_allreduce_sum(c, &N, 1));
     if (N == 0) return kc_fail(ctx, KC_E_NO_KMERS, "input contains no k-mers");
+    if (const char *e = getenv("KC_TEST_FAIL_RANK"))   // (tests: this rank fails on its own, between two exchanges)
+        if (atoi(e) == me) return kc_fail(ctx, KC_E_NO_DEVICE, "test: this rank fails on its own");
     KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
     SetView<W> sv = kc_view<W>(set);
     const u64 rlo = set->rlo, rcap = set->rcap;
@@ -895,7 +897,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     for (int pass = 0;; ++pass) {
         if (pass == 64) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not settle after cutting cycles");
         // entries, fragment walks.  K-mers that no fragment reaches lie on cycles inside this rank: counted here, cut after the ranking
-        u64 missing = 0;
+        u64 missing = 0, walk_err = 0;
         {
             // entries: listed by the contraction kernel on its way (it has every link word of the block in registers), or by a sweep of
             // their own (no contraction: cycles, KC_NOFRAG; or more entries than the list was sized for)
@@ -956,10 +958,16 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_HIP(ctx, hipGetLastError());
             u64 hw[3 * KC_USTRIDE];
             KC_TRY(read_words(ctx, cur, hw, 3 * KC_USTRIDE));
-            if (hw[KC_USTRIDE]) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted");
+            if (hw[KC_USTRIDE]) walk_err = 1;
             const u64 walked = hw[2 * KC_USTRIDE] / (complements ? 2 : 1);
-            if (walked > N_local) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree");
-            missing = N_local - walked;
+            if (walked > N_local) walk_err = 2;
+            missing = walk_err ? 0 : N_local - walked;
+        }
+        {   // (a rank that returned alone here would leave its peers waiting in the ranking's exchanges: the ranks agree first)
+            u64 e = walk_err;
+            KC_TRY(kcc_allreduce_max(c, &e, 1));
+            if (e == 1) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted (on some rank)");
+            if (e) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree (on some rank)");
         }
         KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1));
         KC_TRY(scope.alloc(&iota, n_ent + 1)); KC_TRY(scope.alloc(&act, n_ent + 1)); KC_TRY(scope.alloc(&flags8, n_ent + 1));
@@ -1476,6 +1484,7 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     }
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d_own);
+    kcc_after_collective_call(comm, rc);
     return rc;
 }
 
@@ -1506,5 +1515,6 @@ extern "C" int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const v
     }
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d_own);
+    kcc_after_collective_call(comm, rc);
     return rc;
 }

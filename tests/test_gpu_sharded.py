@@ -219,6 +219,44 @@ def test_rccl_send_recv_code_runs_on_one_gpu(ctx, tmp_path, k, mode):
     assert np.array_equal(np.load(str(tmp_path / "out.npy")), w)
 
 
+def test_a_rank_that_fails_alone_releases_its_peers(tmp_path, monkeypatch):
+    """In-process thread transport (kc_thread_group, what `compute --gpus N` uses): a rank that fails on its own between two exchanges
+    (forced with KC_TEST_FAIL_RANK) must not leave the others waiting for it: they come back with KC_E_TRANSPORT."""
+    import ctypes
+    import threading
+    from kmercamel_amd import api
+    lib = api.load()
+    world = 3
+    g = ctypes.c_void_p()
+    assert lib.kc_thread_group_create(world, ctypes.byref(g)) == 0
+    recs = gen.random_records(600, 300, seed=4)
+    monkeypatch.setenv("KC_TEST_FAIL_RANK", "1")
+    codes, errs = [None] * world, [None] * world
+
+    def rank_main(r):
+        c = kc.Context(0)
+        comm = kc.Comm.threads(c, g, r, world)
+        mine = b"\n".join(recs[len(recs) * r // world: len(recs) * (r + 1) // world])
+        try:
+            res = kc.compute_sharded(c, comm, mine, 31, True)
+            res.close()
+            codes[r] = 0
+        except kc.KcError as e:
+            codes[r], errs[r] = e.code, str(e)
+        comm.close()
+        c.close()
+
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for the one that failed"
+    assert codes[1] == api.KC_E_NO_DEVICE and "fails on its own" in errs[1], (codes, errs)
+    assert codes[0] == api.KC_E_TRANSPORT and codes[2] == api.KC_E_TRANSPORT, (codes, errs)
+    lib.kc_thread_group_destroy(g)
+
+
 def _visible_gpus():
     try:
         import torch
