@@ -202,6 +202,8 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
 int kcs_reserve(kc_set *set, u64 additional);
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive);
 int kcs_refresh_size(kc_set *set);
+struct kc_comm;
+int kcs_prepare_dense_sharded(kc_set *set, kc_comm *c);   // the same on a hash-sharded set + one nstride for all ranks (collective)
 int kcs_prepare_dense(kc_set *set);   // dense node ids for phase 1: counts in the empty slots, set->ncount / nstride (no-op when still valid)
 int kcs_create_sharded(kc_ctx *ctx, kc_comm *c, int k, int complements, u64 occ_local, kc_set **out);   // collective
 int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved_bytes, int min_count = 1);   // collective; min_count > 1: -z

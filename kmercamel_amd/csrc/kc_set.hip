@@ -968,6 +968,16 @@ int kcs_prepare_dense(kc_set *set) {
     return KC_OK;
 }
 
+// hash-sharded sets: every rank prepares its own blocks, then the ranks agree on the ids per block (the largest block anywhere), so
+// that node id / nstride is the GLOBAL block and says which rank holds the node.  Collective.
+int kcs_prepare_dense_sharded(kc_set *set, kc_comm *c) {
+    KC_TRY(kcs_prepare_dense(set));
+    u64 mx = set->nstride;
+    KC_TRY(kcc_allreduce_max(c, &mx, 1));
+    set->nstride = (u32)mx;
+    return KC_OK;
+}
+
 int kcs_refresh_size(kc_set *set) {
     kc_ctx *ctx = set->ctx;
     u64 h[2] = {0, 0};
@@ -1383,6 +1393,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     KC_TRY(scope.alloc(&ovf, ovf_cap * W));
     const size_t lds_build = (size_t)bs * (8 * W + 1) + (min_count > 1 ? 2 * (size_t)bs : 0);
     set->unclean = false;
+    bool ids_built = false;
     if (min_count > 1) {
         // -z: count the occurrences of every key where they all meet, keep those seen min_count times or more
         unsigned short *where = nullptr;
@@ -1392,14 +1403,21 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         hipLaunchKernelGGL(kc_block_build_filter_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys, set->counters,
                            (const u64 *)seg_scan, G, (u32)min_count, where);
     } else {
-        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
-        hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
-                           (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G, 0, 0);
+        // (the blocks leave the build with their dense node ids prepared, as on one GPU: kcs_prepare_dense_sharded then only has to
+        // agree on the largest block among the ranks)
+        KC_TRY(kc_alloc(ctx, &set->ncount, bpr + 2));
+        KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
+        hipLaunchKernelGGL((kc_block_build_kernel<W, true>), dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
+                           (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G, 0, 0, set->ncount);
+        hipLaunchKernelGGL(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, bpr, set->counters + 4);
+        ids_built = true;
     }
     KC_HIP(ctx, hipGetLastError());
-    u64 h[4] = {0, 0, 0, 0};
+    u64 h[5] = {0, 0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ids_built && !h[2]) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (spills are inserted behind the kernel's back: the sweep of kcs_prepare_dense then)
     if (min_count > 1) {   // (collective: a rank whose blocks overflowed takes everybody out of the sharded path)
         u64 lost = h[3];
         KC_TRY(kcc_allreduce_max(c, &lost, 1));

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) kc_shard_answer_kernel(SetView<W> set, in
     if (t >= n) return;
     Key<W> x;
     for (int w = 0; w < W; ++w) x.w[w] = q[t * (W + 1) + w];
-    const u64 pid = q[t * (W + 1) + W];
+    const u64 pid = q[t * (W + 1) + W] & (((u64)1 << 48) - 1);   // the asking port by dense node id (the bits above: the slot offset of its k-mer, for the asker's fill kernel)
     const int port = (int)(pid & 1);
     const Key<W> xr = key_rc(x, k);
     const Key<W> lm = key_lowmask<W>(2 * (k - 2));
@@ -57,25 +57,43 @@ __global__ void __launch_bounds__(256) kc_shard_answer_kernel(SetView<W> set, in
     u64 cs[4]; u32 qb;
     if (!kc_port_search<W, false, false>(set, k, complements, x, xr, KC_NONE64, port, d, nullptr, nullptr, cs, qb))
         kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (cs[c] != KC_NONE64) cs[c] = set_nid_of_slot(set, cs[c]);   // (the link words carry dense node ids)
     ans[t] = kc_shard_settle_port<W>(k, complements, pid, x, xr, cs, qb, L);
 }
-__global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restrict__ qry, const u64 *__restrict__ ans, u64 n, int QW, u64 *link) {
+// the asker's side: the answered word goes into its port; a dead port gets the slot of its k-mer, every word the slot offset (LK_OWN)
+__global__ void __launch_bounds__(256) kc_shard_fill_kernel(const u64 *__restrict__ qry, const u64 *__restrict__ ans, u64 n, int QW, u64 *link, u32 nstride, int bshift) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) link[qry[t * (u64)QW + QW - 2]] = ans[t];
+    if (t >= n) return;
+    const u64 pw = qry[t * (u64)QW + QW - 2], pid = pw & (((u64)1 << 48) - 1), so = pw >> 48;
+    u64 w = ans[t];
+    if (LK_STATE(w) == LK_DEAD) w = LK_MAKE(LK_DEAD, 0, 0, (((pid >> 1) / nstride) << bshift) | so);
+    link[pid] = w | LK_OWN_BITS(so);
 }
-__global__ void __launch_bounds__(256) kc_shard_apply_fix_kernel(u64 *link, const u64 *__restrict__ fix, u64 n, u64 rlo2, u64 rcap2) {
+// decided link words {pid, word} (branch subgraph, cycles): the ports this rank holds; the slot offset of the port's k-mer stays, a
+// port that dies gets its slot
+template <int W>
+__global__ void __launch_bounds__(256) kc_shard_apply_fix_kernel(SetView<W> set, u64 *link, const u64 *__restrict__ fix, u64 n, u64 rlo2, u64 rcap2) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 pid = fix[2 * t];
-    if (pid - rlo2 < rcap2) link[pid] = fix[2 * t + 1];
+    if (pid - rlo2 >= rcap2) return;
+    const u64 old = link[pid];
+    // (a word that the contraction replaced and kc_frag_restore_kernel put back has lost the offset: look the slot up)
+    const u64 off = (old & LK_OWN_VALID) ? LK_OWN(old) : (set_slot_of_nid(set, pid >> 1) & (((u64)1 << set.bshift) - 1));
+    u64 w = fix[2 * t + 1] & ~LK_OWN_MASK;
+    if (LK_STATE(w) == LK_DEAD) w |= ((((pid >> 1) / set.nstride) << set.bshift) | off) << 6;
+    link[pid] = w | LK_OWN_BITS(off);
 }
 
 // ---------------------------------------------------------------------------------------------------- phase 1b: fragments
 // entry = oriented node (slot, o) whose entry port o is dead (a chain head) or matched to a slot of another rank
 // (two passes: count, then fill at the scanned offsets.  The count pass keeps every thread's 16-bit entry mask, so the fill pass
 // does not sweep the 16 bytes per slot of link words a second time.)
+// (rlo, rcap: the NODE IDS of this rank -- block * nstride + rank in the block; the first ncount[block] ids of a block are in use)
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_shard_entries_kernel(const u64 *__restrict__ link, const u8 *__restrict__ tags, u64 rlo, u64 rcap, int complements,
+__global__ void __launch_bounds__(256) kc_shard_entries_kernel(const u64 *__restrict__ link, const u32 *__restrict__ ncount, u32 nstride, u64 rlo, u64 rcap, int complements,
                                                                const u64 *__restrict__ tile_off, u64 *out, unsigned short *masks) {
     const u64 base = rlo + (u64)blockIdx.x * 2048 + (u64)threadIdx.x * 8;
     u64 c = 0;
@@ -84,7 +102,7 @@ __global__ void __launch_bounds__(256) kc_shard_entries_kernel(const u64 *__rest
     else {
         for (int i = 0; i < 8; ++i) {
             const u64 slot = base + i;
-            if (slot >= rlo + rcap || tags[slot] == 0) continue;
+            if (slot >= rlo + rcap || (u32)(slot % nstride) >= ncount[slot / nstride]) continue;
             for (int o = 0; o < (complements ? 2 : 1); ++o) {
                 const u64 w = link[(slot << 1) | (u64)o];
                 const bool entry = LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - rlo >= rcap);
@@ -173,11 +191,10 @@ __global__ void __launch_bounds__(256) kc_shard_walk_kernel(const u64 *__restric
                 co = (int)((w >> 42) & 1);
                 continue;
             }
-            const u64 blk = cur >> bshift;
             u64 nb;
             if (w & KC_SC_EXT) {
                 nb = (w >> 21) & 0x3fff;
-                const u64 *src = frag.pool + ((blk - frag.blk0) & 63) * frag.shard_cap + frag.blk_pool_base[blk - frag.blk0] + (w >> 35);
+                const u64 *src = frag.pool + (w >> 35);   // (dense node ids: the pool run by its absolute first word)
                 for (u64 i = 0; i < nb; i += 32) {
                     const int mm = nb - i >= 32 ? 32 : (int)(nb - i);
                     push_group(src[i >> 5] >> (64 - 2 * mm), mm);
@@ -187,7 +204,7 @@ __global__ void __launch_bounds__(256) kc_shard_walk_kernel(const u64 *__restric
                 if (nb) push_group(w >> (64 - 2 * nb), (int)nb);
             }
             len += nb;
-            cur = (blk << bshift) | ((w >> 6) & 0x3fff);
+            cur += (u64)(long long)((int)(((u32)(w >> 6) & 0x3fffu) ^ 0x2000u) - 0x2000);   // the far node: a signed 14-bit distance in ids
             co = (int)((w >> 20) & 1);
             xp = co == 0 ? 1 : 0;
             w = link[(cur << 1) | (u64)xp];   // the far end's way out of the run: a plain word
@@ -331,9 +348,9 @@ __global__ void __launch_bounds__(256) kc_shard_sum_kernel(const u64 *__restrict
     if (threadIdx.x == 0 && tot) atomicAdd((ull *)out, (ull)tot);
 }
 template <bool FILL>
-__global__ void __launch_bounds__(256) kc_shard_unvisited_kernel(const u8 *__restrict__ tags, const u8 *__restrict__ visited, u64 rlo, u64 rcap, u64 *list, u64 *cursor) {
+__global__ void __launch_bounds__(256) kc_shard_unvisited_kernel(const u32 *__restrict__ ncount, u32 nstride, const u8 *__restrict__ visited, u64 rlo, u64 rcap, u64 *list, u64 *cursor) {
     const u64 t = kc_gtid();
-    if (t >= rcap || tags[rlo + t] == 0 || visited[t]) return;
+    if (t >= rcap || (u32)((rlo + t) % nstride) >= ncount[(rlo + t) / nstride] || visited[t]) return;
     const u64 pos = atomicAdd((ull *)cursor, 1ULL);
     if (FILL) list[pos] = rlo + t;
 }
@@ -376,6 +393,7 @@ __global__ void __launch_bounds__(256) kc_shard_cycle_cand_kernel(SetView<W> set
 #pragma unroll
         for (u32 cc = 0; cc < 4; ++cc) ys = (c == cc) ? cs[cc] : ys;
         if (ys == KC_NONE64) continue;
+        ys = set_nid_of_slot(set, ys);   // (ports are numbered by dense node id)
         const u64 yw = link[(ys << 1) | (u64)((qb >> c) & 1u)];
         if (LK_STATE(yw) != LK_DEAD || (yw & LK_CUT)) continue;
         int q;
@@ -396,23 +414,23 @@ __global__ void __launch_bounds__(256) kc_shard_tailreq_kernel(const u64 *__rest
     req[t] = g; dest[t] = (u8)KC_GID_RANK(g);
 }
 template <int W>
-__global__ void __launch_bounds__(256) kc_shard_tailans_kernel(SetView<W> set, const u64 *__restrict__ req, u64 n, const u64 *__restrict__ f_exit, u64 *ans) {
+__global__ void __launch_bounds__(256) kc_shard_tailans_kernel(SetView<W> set, const u64 *__restrict__ link, const u64 *__restrict__ req, u64 n, const u64 *__restrict__ f_exit, u64 *ans) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 x = f_exit[KC_GID_IDX(req[t])];
     ans[t * (W + 1)] = x;
-    const Key<W> key = set_key_at(set, x >> 1);
+    const Key<W> key = set_key_at(set, LK_SLOT(link[x]));   // (the chain ends on a dead port: its word carries the slot of the k-mer)
     for (int w = 0; w < W; ++w) ans[t * (W + 1) + 1 + w] = key.w[w];
 }
 // chain record (3 + 3W words): {final fragment id, nodes, head key (canonical), first k-mer (oriented), last k-mer (oriented)}
 template <int W>
-__global__ void __launch_bounds__(256) kc_shard_chain_kernel(SetView<W> set, int k, int complements, const u64 *__restrict__ heads, u64 n,
+__global__ void __launch_bounds__(256) kc_shard_chain_kernel(SetView<W> set, const u64 *__restrict__ link, int k, int complements, const u64 *__restrict__ heads, u64 n,
                                                              const u64 *__restrict__ entries, const u64 *__restrict__ dist, const u64 *__restrict__ last,
                                                              const u64 *__restrict__ tail, u64 *chains, u64 *cursor) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 e = heads[t], h = entries[e], len = dist[e];
-    const Key<W> hk = set_key_at(set, h >> 1);
+    const Key<W> hk = set_key_at(set, LK_SLOT(link[h]));   // (a head's entry port is dead: its word carries the slot)
     Key<W> tk;
     for (int w = 0; w < W; ++w) tk.w[w] = tail[t * (W + 1) + 1 + w];
     const u64 tx = tail[t * (W + 1)];   // tail node << 1 | exit port
@@ -457,7 +475,8 @@ __device__ __forceinline__ u64 kc_lower_bound64(const u64 *a, u64 n, u64 v) {
 template <bool FILL>
 __global__ void __launch_bounds__(256) kc_shard_msg_kernel(int k, const u64 *__restrict__ entries, u64 n, const u64 *__restrict__ f_len, const u64 *__restrict__ dist,
                                                            const u64 *__restrict__ last, const u32 *__restrict__ f_stream, const u64 *__restrict__ pool,
-                                                           const u32 *__restrict__ chunk_next, const u64 *__restrict__ keys_biased, int W, const u64 *__restrict__ fin_sorted,
+                                                           const u32 *__restrict__ chunk_next, const u64 *__restrict__ keys_biased, const u64 *__restrict__ link, u32 nstride, int bshift, int W,
+                                                           const u64 *__restrict__ fin_sorted,
                                                            const u64 *__restrict__ fin_simp, u64 S, const u64 *__restrict__ lens, const u64 *__restrict__ woff,
                                                            const u8 *__restrict__ simp_dest, u64 *mcount, const u64 *__restrict__ moff, u64 *msgs, u8 *mdest) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -476,7 +495,9 @@ __global__ void __launch_bounds__(256) kc_shard_msg_kernel(int k, const u64 *__r
     // oriented first k-mer of the fragment
     const u64 h = entries[t];
     u64 kw[4] = {0, 0, 0, 0};
-    for (int w = 0; w < W; ++w) kw[w] = keys_biased[(h >> 1) * (u64)W + w];
+    // the fragment's first k-mer: the word of its entry port (dead, or matched to a node of another rank) carries the slot offset
+    const u64 hslot = (((h >> 1) / nstride) << bshift) | LK_OWN(link[h]);
+    for (int w = 0; w < W; ++w) kw[w] = keys_biased[hslot * (u64)W + w];
     auto base_at = [&](int idx) -> u64 {   // idx-th base of the oriented k-mer
         if (h & 1) {   // reverse complement: base idx = complement of forward base k - 1 - idx
             const int s = 2 * idx;
@@ -744,8 +765,16 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     if (const char *e = getenv("KC_TEST_FAIL_RANK"))   // (tests: this rank fails on its own, between two exchanges)
         if (atoi(e) == me) return kc_fail(ctx, KC_E_NO_DEVICE, "test: this rank fails on its own");
     KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    // Ports are numbered by DENSE node id (kc_set_dev.h): block * nstride + the k-mer's rank among the block's occupied slots, with
+    // the same nstride on every rank -- so rank r holds the ids [r * rcap, (r + 1) * rcap) with rcap = blocks per rank * nstride, and
+    // everything below addresses links, fragments and visit marks in that id space exactly as it used to in the slot space (at
+    // half the bytes: 16 per k-mer instead of 16 per slot of a table at load 0.5).  rloS / rcapS are the table slots of this rank.
+    KC_TRY(kcs_prepare_dense_sharded(set, c));
     SetView<W> sv = kc_view<W>(set);
-    const u64 rlo = set->rlo, rcap = set->rcap;
+    const u64 rloS = set->rlo, rcapS = set->rcap;
+    const u32 nstride = set->nstride;
+    const u64 rlo = (rloS >> set->bshift) * (u64)nstride, rcap = (rcapS >> set->bshift) * (u64)nstride;
+    const u32 *ncount = sv.ncount;   // (biased: indexed by global block)
     // ---------------- phase 1a: links
     u64 *link_alloc = nullptr;
     KC_TRY(scope.alloc(&link_alloc, 2 * rcap));
@@ -778,7 +807,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             const int nt = stage_keys ? 1024 : 512;
             const bool mm = nt == 512;
             const size_t lds = kc_probe_lds_bytes(set->bshift, W, stage_keys, nt, mm);
-            const u64 bpr = rcap >> set->bshift;
+            const u64 bpr = rcapS >> set->bshift;
             const unsigned pgrid = (unsigned)((bpr + 7) / 8 * 8);
             auto launch = [&](auto kern) -> int {
                 KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -819,7 +848,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(kcu_compact_shards(ctx, L.qry, qry_scap, L.qry_cur, KC_USH, KC_USTRIDE, QW, qc, &nq, &ovf));
             u8 *dest = nullptr;
             KC_TRY(scope.alloc(&dest, nq + 1));
-            if (nq) hipLaunchKernelGGL((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcap, dest);
+            if (nq) hipLaunchKernelGGL((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcapS, dest);
             KcRoute rt;
             KC_TRY(kcr_build(c, dest, nq, &rt));
             u64 *rq = nullptr, *ans = nullptr, *ansb = nullptr;
@@ -831,7 +860,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nq + 1);
             if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
             if (rc == KC_OK && nq)
-                hipLaunchKernelGGL(kc_shard_fill_kernel, dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, QW, link);
+                hipLaunchKernelGGL(kc_shard_fill_kernel, dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, QW, link, nstride, set->bshift);
             (void)hipStreamSynchronize(ctx->stream);
             kcr_free(ctx, &rt);
             kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
@@ -863,7 +892,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 u64 *dfix = nullptr;
                 KC_TRY(scope.alloc(&dfix, fix.size()));
                 KC_HIP(ctx, hipMemcpyAsync(dfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL(kc_shard_apply_fix_kernel, dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dfix, (u64)(fix.size() / 2),
+                hipLaunchKernelGGL((kc_shard_apply_fix_kernel<W>), dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)dfix, (u64)(fix.size() / 2),
                                    2 * rlo, 2 * rcap);
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 scope.release(dfix);
@@ -886,10 +915,10 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     // logged): as soon as anything has to walk or cut plain links (cycles) the words are put back and the plain walk takes over
     bool frag_ok = set->mlen && set->bshift <= 13 && !getenv("KC_NOFRAG"), contracted = false;
     u64 *fpool = nullptr, *fbase = nullptr, *fcur = nullptr, *flog = nullptr, *fblog = nullptr;
-    const u64 bpr_blocks = rcap >> set->bshift;
+    const u64 bpr_blocks = rcapS >> set->bshift;
     auto restore_links = [&]() -> int {
         if (!contracted) return KC_OK;
-        hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)bpr_blocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog, (const u64 *)fblog, set->bshift, rlo >> set->bshift);
+        hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)bpr_blocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog, (const u64 *)fblog, set->bshift, rloS >> set->bshift, nstride);
         KC_HIP(ctx, hipGetLastError());
         contracted = false; frag_ok = false;
         return KC_OK;
@@ -904,35 +933,37 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KcFrag fr{nullptr, nullptr, 0, 0};
             bool have_entries = false;
             if (frag_ok && !contracted && bpr_blocks) {
-                const u64 pool_cap = (rcap / 16 + 65536) / 64 * 64, log_cap = (rcap / 6 + 65536) / 64 * 64, ecap = N_local / 2 + 65536;   // (per-block shares, as on one GPU)
+                u64 pool_cap = (rcapS / 16 + 65536) / 64 * 64;
+                if (pool_cap > ((u64)1 << 29)) pool_cap = (u64)1 << 29;   // (a shortcut names a pool run by its absolute first word in 29 bits)
+                const u64 log_cap = (rcapS / 6 + 65536) / 64 * 64, ecap = N_local / 2 + 65536;   // (per-block shares, as on one GPU)
                 KC_TRY(scope.alloc(&fpool, pool_cap)); KC_TRY(scope.alloc(&fbase, bpr_blocks)); KC_TRY(scope.alloc(&fcur, 2 * 64 * 16 + 16));
                 KC_TRY(scope.alloc(&flog, log_cap)); KC_TRY(scope.alloc(&fblog, bpr_blocks));
                 KC_TRY(scope.alloc(&entries, ecap + 1));
                 KC_HIP(ctx, hipMemsetAsync(fcur, 0, (2 * 64 * 16 + 16) * 8, ctx->stream));
                 const size_t flds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
-                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((kc_frag_contract_kernel<W>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
+                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
                                    log_cap, fcur + 64 * 16, fblog, entries, ecap, fcur + 2 * 64 * 16);
                 KC_HIP(ctx, hipGetLastError());
                 contracted = true;
-                fr = KcFrag{fpool, fbase, 0, rlo >> set->bshift};
+                fr = KcFrag{fpool, fbase, 0, rloS >> set->bshift};
                 KC_TRY(read_words(ctx, fcur + 2 * 64 * 16, &n_ent, 1));
                 have_entries = n_ent <= ecap;
                 if (!have_entries) scope.release(entries);
-            } else if (contracted) fr = KcFrag{fpool, fbase, 0, rlo >> set->bshift};
+            } else if (contracted) fr = KcFrag{fpool, fbase, 0, rloS >> set->bshift};
             if (!have_entries) {
                 const u64 ntiles = (rcap + 2047) / 2048;
                 u64 *tcount = nullptr;
                 unsigned short *emasks = nullptr;
                 KC_TRY(scope.alloc(&tcount, ntiles + 2));
                 KC_TRY(scope.alloc(&emasks, ntiles * 256));
-                hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, ncount, nstride, rlo, rcap, complements,
                                    (const u64 *)nullptr, tcount, emasks);
                 KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
                 KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
                 if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
                 KC_TRY(scope.alloc(&entries, n_ent + 1));
-                hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, (const u8 *)sv.tags, rlo, rcap, complements,
+                hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, ncount, nstride, rlo, rcap, complements,
                                    (const u64 *)tcount, entries, emasks);
                 KC_HIP(ctx, hipGetLastError());
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1097,14 +1128,14 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_HIP(ctx, hipMemsetAsync(visited, 0, rcap, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
             if (n_ent) hipLaunchKernelGGL(kc_shard_mark_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent, (const u8 *)flags8, visited);
-            hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
+            hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, ncount, nstride, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
             KC_HIP(ctx, hipGetLastError());
             KC_TRY(read_words(ctx, cur + 3 * KC_USTRIDE, &nunvis, 1));
             KC_TRY(scope.alloc(&ulist, nunvis + 1)); KC_TRY(scope.alloc(&rows, (nunvis + 1) * RW));
             KC_HIP(ctx, hipMemsetAsync(cur + 3 * KC_USTRIDE, 0, 8, ctx->stream));
             if (nunvis) {
-                hipLaunchKernelGGL((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, (const u8 *)sv.tags, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
-                hipLaunchKernelGGL((kc_cycle_rows_kernel<W>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows);
+                hipLaunchKernelGGL((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, ncount, nstride, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
+                hipLaunchKernelGGL((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows);
             }
             KC_HIP(ctx, hipGetLastError());
             KC_TRY(allgather_rows(c, rows, nunvis, RW, &all, &n_all, nullptr));
@@ -1133,7 +1164,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             u64 *dfix = nullptr;
             KC_TRY(scope.alloc(&dfix, fix.size()));
             KC_HIP(ctx, hipMemcpyAsync(dfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(kc_shard_apply_fix_kernel, dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)dfix, (u64)(fix.size() / 2), 2 * rlo, 2 * rcap);
+            hipLaunchKernelGGL((kc_shard_apply_fix_kernel<W>), dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)dfix, (u64)(fix.size() / 2), 2 * rlo, 2 * rcap);
             KC_HIP(ctx, hipGetLastError());
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             scope.release(dfix);
@@ -1162,13 +1193,13 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         int rc = kcr_forward(c, rt, req, 1, 1, &rq);
         if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * (W + 1) + 1);
         if (rc == KC_OK && rt.n_recv)
-            hipLaunchKernelGGL((kc_shard_tailans_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, (const u64 *)f_exit, ans);
+            hipLaunchKernelGGL((kc_shard_tailans_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)rq, rt.n_recv, (const u64 *)f_exit, ans);
         if (rc == KC_OK) rc = kc_alloc(ctx, &tail, n_heads * (W + 1) + 1);
         if (rc == KC_OK) rc = kcr_backward(c, rt, ans, W + 1, tail);
         if (rc == KC_OK) rc = scope.alloc(&chains, (n_heads + 1) * CW);
         KC_HIP(ctx, hipMemsetAsync(cur, 0, 2 * 8, ctx->stream));
         if (rc == KC_OK && n_heads)
-            hipLaunchKernelGGL((kc_shard_chain_kernel<W>), dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, sv, k, complements, (const u64 *)heads, n_heads,
+            hipLaunchKernelGGL((kc_shard_chain_kernel<W>), dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)heads, n_heads,
                                (const u64 *)entries, (const u64 *)dist, (const u64 *)last, (const u64 *)tail, chains, cur);
         u64 hc[2] = {0, 0};
         if (rc == KC_OK) rc = read_words(ctx, cur, hc, 2);
@@ -1248,14 +1279,14 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         KC_TRY(scope.alloc(&mcount, n_ent + 2)); KC_TRY(scope.alloc(&moff, n_ent + 2));
         if (n_ent)
             hipLaunchKernelGGL((kc_shard_msg_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
-                               (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, W, (const u64 *)fin_sorted,
+                               (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, (const u64 *)link, nstride, set->bshift, W, (const u64 *)fin_sorted,
                                (const u64 *)fin_simp, S, (const u64 *)simp->lens, (const u64 *)simp->woff, (const u8 *)simp_dest, mcount, (const u64 *)nullptr, (u64 *)nullptr, (u8 *)nullptr);
         KC_TRY(kcu_exclusive_scan(ctx, mcount, moff, n_ent));
         KC_TRY(read_words(ctx, moff + n_ent, &n_msg, 1));
         KC_TRY(scope.alloc(&msgs, 2 * n_msg + 2)); KC_TRY(scope.alloc(&mdest, n_msg + 1));
         if (n_ent)
             hipLaunchKernelGGL((kc_shard_msg_kernel<true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
-                               (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, W, (const u64 *)fin_sorted,
+                               (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, (const u64 *)link, nstride, set->bshift, W, (const u64 *)fin_sorted,
                                (const u64 *)fin_simp, S, (const u64 *)simp->lens, (const u64 *)simp->woff, (const u8 *)simp_dest, mcount, (const u64 *)moff, msgs, mdest);
         KC_HIP(ctx, hipGetLastError());
         KcRoute rt;
@@ -1310,7 +1341,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         if (rc == KC_OK) rc = scope.alloc(&tcnt, ntile + 2);
         if (rc == KC_OK) rc = scope.alloc(&toff, ntile + 2);
         if (rc == KC_OK) {
-            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, false>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcap,
+            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, false>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcapS,
                                r->d_mask, tcnt, (const u64 *)nullptr, (u64 *)nullptr, (u64 *)nullptr, (u8 *)nullptr);
             rc = kcu_exclusive_scan(ctx, tcnt, toff, ntile);
             if (rc == KC_OK) rc = read_words(ctx, toff + ntile, &nqm, 1);
@@ -1319,7 +1350,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         if (rc == KC_OK) rc = scope.alloc(&qpos, nqm + 1);
         if (rc == KC_OK) rc = scope.alloc(&qdest, nqm + 1);
         if (rc == KC_OK)
-            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, true>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcap,
+            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, true>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcapS,
                                r->d_mask, tcnt, (const u64 *)toff, qkeys, qpos, qdest);
         KcRoute rt;
         if (rc == KC_OK) rc = kcr_build(c, qdest, nqm, &rt);

@@ -20,7 +20,15 @@
 #define LK_BASE(w) (((w) >> 3) & 3ull)
 #define LK_REJ 32ull                  /* bit 5: the choice is not (yet) known to be reciprocated */
 #define LK_SPLIT (1ull << 63)          /* the node of this port is a splitter: a segment start for the parallel chain walks */
-#define LK_SLOT(w) (((w) & ~LK_SPLIT) >> 6)
+#define LK_SLOT(w) ((((w) & ~LK_SPLIT) >> 6) & (((u64)1 << 36) - 1))   /* the target node (a dead port: the slot of its own k-mer); 36 bits */
+/* bits 42-56 (hash-sharded flow): the offset of the word's OWN k-mer inside its table block -- with the block (node id / nstride) that
+   is its slot, so whoever holds a port word can read the k-mer's key (the first k-mer of a chain fragment, whose entry port is
+   dead or matched to a node of another rank) */
+#define LK_OWN_SHIFT 42
+#define LK_OWN(w) (((w) >> LK_OWN_SHIFT) & 0x7fffull)
+#define LK_OWN_VALID (1ull << 57)      /* the word carries the offset (a word put back from the contraction log does not) */
+#define LK_OWN_MASK ((0x7fffull << LK_OWN_SHIFT) | LK_OWN_VALID)
+#define LK_OWN_BITS(off) (((u64)(off) << LK_OWN_SHIFT) | LK_OWN_VALID)
 #define LK_PID(w) ((LK_SLOT(w) << 1) | LK_PORT(w))
 #define LK_MAKE(state, port, base, slot) ((u64)(state) | ((u64)(port) << 2) | ((u64)(base) << 3) | ((u64)(slot) << 6))
 // Round 1 needs no accept pass: the edge relation is symmetric, so a port's choice can only be unreciprocated if its
@@ -767,6 +775,8 @@ struct ShLists {
 // Settle one port from the slots of its candidates (cs[c], entered on port bit c of qb): the link word.  A branch port (>= 2
 // existing candidates) chooses its best edge here too -- provisionally -- and lists all its edges for the replicated branch
 // matching, which overrides the choice where the sequential rule says so.
+// (pid: the port by dense node id; cs[]: the candidates' dense node ids; a dead port's word is LK_DEAD here -- whoever writes it into the
+// link array puts the slot of the port's k-mer in, which only the port's own rank knows)
 template <int W>
 __device__ __forceinline__ u64 kc_shard_settle_port(int k, int complements, const u64 pid, const Key<W> &x, const Key<W> &xr, const u64 (&cs)[4], const u32 qb,
                                                     const ShLists &L) {
@@ -824,8 +834,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM), WBYTES = KC_PROBE_SSTACK * 2 + ECAP * (MM ? 6 : 2);
     // DN (single-GPU flow): link words are addressed by DENSE node ids and carry dense ids -- 16 bytes per K-MER, written
     // contiguously (the k-mers of a block are numbered in slot order from block * set.nstride on), not 16 bytes per slot of a table at
-    // load 0.5 written in 64-byte pieces.  The hash-sharded flow (SH) still numbers its ports by slot.
-    constexpr bool DN = !SH;
+    // load 0.5 written in 64-byte pieces.  The hash-sharded flow (SH) numbers its ports the same way (nstride is the same on every
+    // rank, so a node id says which rank holds it); its words also carry the slot offset of their own k-mer (LK_OWN).
+    constexpr bool DN = true;
     // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
     // [w bs/8, (w+1) bs/8) in rows of 64, queues the occupied ones and takes 64 off the queue whenever that many wait, so
     // every step runs with all lanes busy and no wave ever waits for another (with block-wide lists and barriers every stretch
@@ -945,7 +956,11 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     for (u32 c = 0; c < 4; ++c)
                         if (cs[c] != KC_NONE64) { ++nf; bc = c; bs1 = cs[c]; }
                     if (nf >= 2) to_spill((slot << 1) | (u64)port);
-                    else link[(slot << 1) | (u64)port] = nf ? LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, bs1) : LK_DEAD;
+                    else {
+                        const u64 nid = nb0 + local_rank(so);
+                        const u64 tgt = nf ? bs1 + kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk) : slot;
+                        link[(nid << 1) | (u64)port] = (nf ? LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, tgt) : LK_MAKE(LK_DEAD, 0, 0, tgt)) | LK_OWN_BITS(so);
+                    }
                 }
                 else {
                     const u64 delta = kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk);
@@ -969,7 +984,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     else {
                         u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * (W + 2);
                         for (int w = 0; w < W; ++w) qq[w] = x.w[w];
-                        qq[W] = (slot << 1) | (u64)port;
+                        qq[W] = ((nb0 + local_rank(so)) << 1) | (u64)port | ((u64)so << 48);   // the asking port by node id; bits 48-62: the slot offset of its k-mer (kc_shard_fill_kernel)
                         qq[W + 1] = d.home;
                     }
                 }
@@ -1013,7 +1028,8 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             const Key<W> xr = key_rc(x, k);
             const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
             const bool split = !SH && (((u32)nb0 + rank) & 0xffu) == 0;            // every 256th k-mer is a splitter of the segment-parallel walks
-            auto deadw = [&]() -> u64 { return DN ? LK_MAKE(LK_DEAD, 0, 0, slot) : LK_DEAD; };   // (a dead port's word carries the slot of its k-mer)
+            const u64 ownbits = SH ? LK_OWN_BITS(so) : 0;                           // (hash-sharded flow: the words carry the slot offset of their k-mer)
+            auto deadw = [&]() -> u64 { return LK_MAKE(LK_DEAD, 0, 0, slot) | ownbits; };   // (a dead port's word carries the slot of its k-mer)
             u32 minL, minR;
             kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
             u64 wd0 = 0, wd1 = 0;
@@ -1032,7 +1048,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                         const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
                         bool found; u32 c, q; u64 sl;
                         if ((d.home >> set.bshift) == blk && kc_port_search_one<W, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl, nb0)) {
-                            word = found ? LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) : deadw();
+                            word = found ? (LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) | ownbits) : deadw();
                             done = true;
                             if (!SH && !found && (complements || port == 0)) kc_push_sharded((own() << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
                         } else defer = true;
@@ -1087,10 +1103,12 @@ __global__ void __launch_bounds__(256) kc_shard_spill_kernel(SetView<W> set, u64
     u64 n = *spill_cursor;
     if (n > spill_cap) n = spill_cap;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
-        const u64 pid = spill[t];
-        const int port = (int)(pid & 1);
-        const Key<W> x = set_key_at(set, pid >> 1);
+        const u64 spid = spill[t], slot = spid >> 1;   // (listed by slot)
+        const int port = (int)(spid & 1);
+        const Key<W> x = set_key_at(set, slot);
         const Key<W> xr = key_rc(x, k);
+        const u64 pid = (set_nid_of_slot(set, slot) << 1) | (u64)port;
+        const u64 so = slot & (((u64)1 << set.bshift) - 1);
         if (set.m) {
             const Key<W> lm = key_lowmask<W>(2 * (k - 2));
             const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
@@ -1102,7 +1120,7 @@ __global__ void __launch_bounds__(256) kc_shard_spill_kernel(SetView<W> set, u64
                 else {
                     u64 *qq = L.qry + ((u64)shard * L.qry_scap + qpos) * (W + 2);
                     for (int w = 0; w < W; ++w) qq[w] = x.w[w];
-                    qq[W] = pid;
+                    qq[W] = pid | (so << 48);
                     qq[W + 1] = d.home;
                 }
                 continue;
@@ -1110,7 +1128,12 @@ __global__ void __launch_bounds__(256) kc_shard_spill_kernel(SetView<W> set, u64
         }
         u64 cs[4]; u32 qb;
         kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
-        link[pid] = kc_shard_settle_port<W>(k, complements, pid, x, xr, cs, qb, L);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (cs[c] != KC_NONE64) cs[c] = set_nid_of_slot(set, cs[c]);
+        u64 w = kc_shard_settle_port<W>(k, complements, pid, x, xr, cs, qb, L);
+        if (LK_STATE(w) == LK_DEAD) w = LK_MAKE(LK_DEAD, 0, 0, slot);
+        link[pid] = w | LK_OWN_BITS(so);
     }
 }
 // round 1 by generic lookups over the whole table, one thread per slot: the fallback when the spill list of the block kernel
@@ -1378,13 +1401,15 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
             kc_fl[2 * s + p] = (occ ? 0x40000000u : 0u) |
                                (in ? (0x80000000u | (u32)(LK_SLOT(w) - base) | ((u32)LK_PORT(w) << 14) | ((u32)LK_BASE(w) << 15) |
                                       (LK_STATE(w) == LK_MATCHED ? 1u << 17 : 0u) | ((w & LK_SPLIT) ? 1u << 18 : 0u)) : 0u);
-            if (!DN && ent_out && occ && (p == 0 || complements) && step < 16 &&
-                (LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && LK_SLOT(w) - set.rlo >= set.rcap)))
+            // (DN: node ids of this rank = [blocks before it * nstride, + its blocks * nstride))
+            if (ent_out && occ && (p == 0 || complements) && step < 16 &&
+                (LK_STATE(w) == LK_DEAD || (LK_IS_MATCHED(w) && (DN ? LK_SLOT(w) - (set.rlo >> set.bshift) * (u64)set.nstride >= (set.rcap >> set.bshift) * (u64)set.nstride
+                                                                     : LK_SLOT(w) - set.rlo >= set.rcap))))
                 emask |= 1u << (2 * step + p);
         }
     }
     __syncthreads();
-    if (!DN && ent_out) {   // (uniform: every thread of the workgroup takes part)
+    if (ent_out) {   // (uniform: every thread of the workgroup takes part)
         __shared__ u32 e_wsum[16];
         __shared__ u64 e_base;
         const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1472,7 +1497,8 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         // line altogether): bit 3 set, bits 6-41 next node, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
         // inside the run, bits 48-61 those bases
         const u64 wfar = (len - 1 <= KC_SC_NEXT_MAX) ? link[(base + far) * 2 + (fo == 0 ? 1u : 0u)] : 0;
-        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && LK_SLOT(wfar) < ((u64)1 << 36) && (DN || LK_SLOT(wfar) - set.rlo < set.rcap)) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
+        const bool far_here = DN ? LK_SLOT(wfar) - (set.rlo >> set.bshift) * (u64)set.nstride < (set.rcap >> set.bshift) * (u64)set.nstride : LK_SLOT(wfar) - set.rlo < set.rcap;
+        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && far_here) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
             link[(base + s) * 2 + xp] = LK_REJ | KC_SC_NEXT | (LK_SLOT(wfar) << 6) | (LK_PORT(wfar) << 42) | (LK_BASE(wfar) << 43) | ((u64)(len - 1) << 45) |
                                         ((bases >> 24) << 48);
         } else if (len - 1 <= KC_SC_INLINE_MAX) {
