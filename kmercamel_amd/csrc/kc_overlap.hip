@@ -847,7 +847,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 int B = (int)(((u64)1 << 22) / (lenS ? lenS : 1));
                 if (B > 32) B = 32;
                 if (B > d - 15) B = d - 15;
-                if (B >= 2) {
+                if (B >= 4) {   // (a window of two or three levels costs what the levels cost)
                     KC_HIP(ctx, hipMemsetAsync(whist, 0, 32 * 8, ctx->stream));
                     hipLaunchKernelGGL((ov_count16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
                                        (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, B, whist, PG, pme);
