@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, con
 // of its segments (length/256 steps) to get the chain's length, tail and segment offsets; segments finally emit their
 // bases in parallel.  A multi-Mbp chain therefore costs ~256 sequential steps instead of millions.
 #define KC_SEG_NONE (~(u64)0)
+#define KC_SEG_LOSER (~(u64)1)   /* seg_chain: the segment belongs to the direction of a chain that is not emitted (reached from a head all the same) */
 __global__ void __launch_bounds__(256) kc_split_starts_kernel(const u64 *__restrict__ link, u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride,
                                                               int complements, u64 *starts, u64 *cursor) {
     // splitters are the nodes whose dense id is a multiple of 256 (round 1 flags exactly those LK_SPLIT)
@@ -434,28 +435,33 @@ __device__ __forceinline__ u64 kc_find_start(const u64 *starts, u64 n, u64 id) {
     return lo;   // callers only look up ids that are present
 }
 // one thread per start (sorted ascending): nodes until the next splitter (exclusive) or the tail (inclusive)
+// MODE 0: measure (seg_len / seg_next / seg_tail).  MODE 1: measure and mark every node walked in `visited` -- the k-mers on cycles
+// WITHOUT a splitter are then exactly the unmarked ones, no marking walk of its own (as long as this one: a scattered line per
+// node) is needed.  MODE 2: the segments that kc_chain_reduce_kernel assigned to NO chain (seg_chain: their splitters
+// lie on cycles, no head reaches them) take their marks back; nothing else is written.
+template <int MODE>
 __global__ void __launch_bounds__(256) kc_segment_walk_kernel(const u64 *__restrict__ link, const u64 *__restrict__ starts, u64 nstarts,
                                                               u64 *seg_len, u64 *seg_next, u64 *seg_tail, u8 *visited,
-                                                              const u64 *__restrict__ seg_chain) {
-    // visited != nullptr: marking pass -- only the segments that chain_reduce assigned to a chain with ends (seg_chain) mark
-    // their nodes (splitters on cycles start segments too, but no head reaches them), nothing else is written
+                                                              const u64 *__restrict__ seg_chain, u64 max_len) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nstarts) return;
-    if (visited && seg_chain[j] == KC_SEG_NONE) return;
+    if (MODE == 2 && seg_chain[j] != KC_SEG_NONE) return;
     u64 cur = starts[j] >> 1;
     int co = (int)(starts[j] & 1);
     u64 len = 1;
     u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
     while (true) {
-        if (visited) visited[cur] = 1;
-        if (!LK_IS_MATCHED(w)) { if (!visited) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (LK_SLOT(w) << 1) | (u64)co; } break; }   // (the tail by SLOT, from its dead port's word)
+        if (MODE == 1) visited[cur] = 1;
+        if (MODE == 2) visited[cur] = 0;
+        if (!LK_IS_MATCHED(w)) { if (MODE != 2) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (LK_SLOT(w) << 1) | (u64)co; } break; }   // (the tail by SLOT, from its dead port's word)
         u64 nxt = LK_SLOT(w);
         int no = LK_PORT(w) == 0 ? 0 : 1;
         u64 wn = link[(nxt << 1) | (u64)(no == 0 ? 1 : 0)];
-        if (wn & LK_SPLIT) { if (!visited) { seg_next[j] = kc_find_start(starts, nstarts, (nxt << 1) | (u64)no); seg_tail[j] = KC_SEG_NONE; } break; }
-        cur = nxt; co = no; w = wn; ++len;
+        if (wn & LK_SPLIT) { if (MODE != 2) { seg_next[j] = kc_find_start(starts, nstarts, (nxt << 1) | (u64)no); seg_tail[j] = KC_SEG_NONE; } break; }
+        cur = nxt; co = no; w = wn;
+        if (++len > max_len) { if (MODE != 2) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = 0; } break; }   // (cannot happen on consistent links: a segment ends at a splitter or a chain end; never spin)
     }
-    if (!visited) seg_len[j] = len;
+    if (MODE != 2) seg_len[j] = len;
 }
 // one thread per start that is a chain head: walk the list of segments
 template <int W>
@@ -477,7 +483,15 @@ __global__ void __launch_bounds__(256) kc_chain_reduce_kernel(SetView<W> set, co
     Key<W> hk = set_key_at(set, LK_SLOT(link[id]));   // (a head's entry port is dead: its word carries the slot)
     bool winner = true;
     if (complements) winner = (total == 1) ? ((id & 1) == 0) : key_lt(hk, set_key_at(set, tail >> 1));
-    if (!winner) return;
+    if (!winner) {   // (its segments are told apart from those that no head reaches: the splitters on cycles)
+        j = j0;
+        while (true) {
+            seg_chain[j] = KC_SEG_LOSER;
+            if (seg_next[j] == KC_SEG_NONE) break;
+            j = seg_next[j];
+        }
+        return;
+    }
     atomicAdd((ull *)(cursor + 3), (ull)total);
     u64 pos = atomicAdd((ull *)cursor, 1ULL);
     chain_head[pos] = id;
@@ -506,7 +520,7 @@ __global__ void __launch_bounds__(256) kc_segment_emit_kernel(SetView<W> set, co
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nstarts) return;
     const u64 ch = seg_chain[j];
-    if (ch == KC_SEG_NONE) return;
+    if (ch >= KC_SEG_LOSER) return;   // (KC_SEG_NONE / KC_SEG_LOSER: not a segment of an emitted direction)
     const u64 r = rank[ch], wb = woff[r], off = seg_off[j];
     u64 cur = starts[j] >> 1;
     int co = (int)(starts[j] & 1);
@@ -760,6 +774,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u32 *chunk_next = nullptr;
     u64 *pool = nullptr, *chain_stream = nullptr, *chain_tail = nullptr;
     bool seg_ok = false, use_stream = false, known_long = false;
+    u8 *seg_marks = nullptr;   // nodes walked by the first long-chain pass (kc_segment_walk_kernel<1>)
     u64 nstarts = 0, nchains = 0;
     for (int pass = 0;; ++pass) {
         const u64 max_chains = nheads + 1;
@@ -862,9 +877,20 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_TRY(scope.alloc(&seg_chain, nstarts + 1)); KC_TRY(scope.alloc(&seg_off, nstarts + 1));
             KC_HIP(ctx, hipMemsetAsync(seg_chain, 0xff, (nstarts + 1) * 8, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
+            // the first long-chain pass marks what it walks: should the chains not cover the set (cycles), the unmarked k-mers are at
+            // hand without a second walk over everything (pass 1 and later know that the cycles are cut: no marks)
+            seg_marks = nullptr;
+            if (pass == 0 && !getenv("KC_SEG_NOMARK")) {
+                KC_TRY(scope.alloc(&seg_marks, NID));
+                KC_HIP(ctx, hipMemsetAsync(seg_marks, 0, NID, ctx->stream));
+            }
             if (nstarts) {
-                hipLaunchKernelGGL(kc_segment_walk_kernel, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, (u8 *)nullptr, (const u64 *)nullptr);
+                if (seg_marks)
+                    hipLaunchKernelGGL(kc_segment_walk_kernel<1>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, seg_marks, (const u64 *)nullptr, NID);
+                else
+                    hipLaunchKernelGGL(kc_segment_walk_kernel<0>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, (u8 *)nullptr, (const u64 *)nullptr, NID);
                 hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                                    (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
                                    seg_off, chain_head, chain_len, chain_key, cnt);
@@ -878,13 +904,28 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // ---- not every k-mer is on a chain with ends: cycles.  Mark what the heads reach, cut the rest, go again.
         if (pass == 2) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery does not cover the set after cutting the cycles");
         u8 *visited = nullptr;
-        KC_TRY(scope.alloc(&visited, NID));
-        KC_HIP(ctx, hipMemsetAsync(visited, 0, NID, ctx->stream));
-        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        if (too_long) {
+        bool marked = false;
+        if (too_long && seg_marks) {
+            // marked by the measuring walk already; the segments no chain took (their splitters lie on cycles) take their marks back
+            visited = seg_marks;
+            seg_marks = nullptr;
+            marked = true;
             if (nstarts)
-                hipLaunchKernelGGL(kc_segment_walk_kernel, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain);
+                hipLaunchKernelGGL(kc_segment_walk_kernel<2>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID);
+        } else {
+            KC_TRY(scope.alloc(&visited, NID));
+            KC_HIP(ctx, hipMemsetAsync(visited, 0, NID, ctx->stream));
+        }
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
+        if (too_long && marked) {
+        } else if (too_long) {
+            if (nstarts) {   // (a marking walk of its own, then the segments of no chain take their marks back)
+                hipLaunchKernelGGL(kc_segment_walk_kernel<1>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)nullptr, NID);
+                hipLaunchKernelGGL(kc_segment_walk_kernel<2>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID);
+            }
         } else if (nheads) {
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
@@ -943,6 +984,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     }
     KC_HIP(ctx, hipGetLastError());
     scope.release(heads);
+    scope.release(seg_marks);
 
     // order chains by head key, size them, emit
     const u64 S = nchains;

@@ -50,9 +50,9 @@ def test_shape_properties_and_alternative_paths(ctx, shape, scale, monkeypatch):
     a2, _ = _compute(ctx, seq)
     assert np.array_equal(a, a2)                          # deterministic
     # the same bytes whichever device path produces them: plain chain walks, forced segment walks, direct inserts, the node-id
-    # sweep instead of the build kernel's, eager compaction and no level windows in phase 2
+    # sweep instead of the build kernel's, eager compaction and no level windows in phase 2, a marking walk of its own for the cycles
     for env in ({"KC_NOFRAG": "1"}, {"KC_CHAIN_LIMIT": "64"}, {"KC_BUCKET_MIN": "100000000000"}, {"KC_NO_BUILD_IDS": "1"},
-                {"KC_OV_EAGER_SHRINK": "1", "KC_OV_NO_WINDOW": "1"}):
+                {"KC_OV_EAGER_SHRINK": "1", "KC_OV_NO_WINDOW": "1"}, {"KC_SEG_NOMARK": "1"}):
         for kk, v in env.items():
             monkeypatch.setenv(kk, v)
         a3, st3 = _compute(ctx, seq)
