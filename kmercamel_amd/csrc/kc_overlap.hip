@@ -21,6 +21,7 @@
 #include "kc_comm.h"
 #include "kc_overlap_logic.h"
 #include "kc_overlap_lds.h"
+#include "kc_scan_dev.h"
 
 #define LV_EMPTY (~(u64)0)
 #define KC_CNT_BLOCKS 256
@@ -557,6 +558,316 @@ __global__ void __launch_bounds__(256) ov_still_active_kernel(const u64 *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GROUPED LEVELS: the level loop without the host in it.  A level of the host-driven loop needs the hit
+// counts on the host twice (to size its compactions, sorts and match launches) and ~27 launches; here the members of a key
+// bucket are brought together by the level table itself -- every slot counts its prefix and suffix vertices, the slot's
+// creator reserves the bucket's stretch of the member arrays, the vertices scatter themselves into it through the slot's
+// cursors, and the thread (or wavefront) that replays the bucket puts its few members in order first -- so no compaction, no
+// key extraction and no sort is launched, every kernel takes its sizes from a block of device words (OVG_*), and the host
+// enqueues ALL remaining levels back to back and looks at the outcome once.  A level that needs what this path does not do --
+// a repair (a cycle slipped through), a bucket beyond a wavefront's LDS, a count beyond 16 bits -- raises OVG_STATUS: every
+// later kernel returns at once, and the host runs that level through the host-driven loop and resumes here.
+// The replay is the same code (kc_match_bucket / kc_match_bucket_lds) on the same ascending member lists: identical results.
+enum { OVG_LENS = 0, OVG_LENP, OVG_LIVES, OVG_LIVEP, OVG_NB, OVG_TOTS, OVG_TOTP, OVG_STATUS, OVG_MASK, OVG_COVERED, OVG_NE, OVG_BIG, OVG_HUGE, OVG_CUR, OVG_COMPACT,
+       OVG_UNSORTED, OVG_NEWS, OVG_NEWP, OVG_LEVELS_DONE, OVG_EDGES, OVG_WORDS = 32 };
+#define OVG_GRID 1024
+#define OVG_NONE32 0xffffffffu
+#define OVG_REASON_REPAIR 1
+#define OVG_REASON_BIG 2      /* a bucket with more members than a wavefront replays out of LDS, or a slot count beyond 16 bits */
+#define OVG_REASON_LOG 3
+struct OvgBuf {
+    u64 *act[4];       // active suffix lists (0, 1) and prefix lists (2, 3): st[OVG_CUR] says which of each pair is current
+    u64 *pslot;        // per prefix list position: level-table slot | creator << 63, or ~0
+    u32 *sslot;        // per suffix list position: slot or OVG_NONE32
+    u32 *cnt2;         // per slot: suffix count << 16 | prefix count; after the buckets are laid out: the fill cursors
+    u32 *boS, *boP;    // per slot: first member of its bucket in memS / memP, or OVG_NONE32
+    u64 *memS, *memP, *scrS, *scrP;   // members / replay scratch
+    u64 *descA, *descB;               // per bucket: offS | cS << 32, offP | cP << 32
+    u64 *big, *huge;   // descriptors of the buckets replayed by a wavefront
+    u64 big_cap, huge_cap, tcap;
+};
+__device__ __forceinline__ void ovg_poison(u64 *st, int d, int reason) {
+    atomicCAS((ull *)&st[OVG_STATUS], 0ULL, (ull)((u64)(d + 1) | ((u64)reason << 8)));
+}
+// one thread: sizes of the level
+template <int W> __global__ void ovg_begin_kernel(u64 *st, u64 *shcur, u64 tcap) {
+    if (st[OVG_STATUS]) return;
+    if (threadIdx.x == 0) {
+        st[OVG_NB] = 0; st[OVG_TOTS] = 0; st[OVG_TOTP] = 0; st[OVG_COVERED] = 0; st[OVG_NE] = 0; st[OVG_BIG] = 0; st[OVG_HUGE] = 0; st[OVG_COMPACT] = 0;
+        u64 lcap = 64;
+        while (lcap < 2 * st[OVG_LIVEP] + 16 && lcap < tcap) lcap <<= 1;
+        st[OVG_MASK] = lcap - 1;
+    }
+    for (int i = threadIdx.x; i < 65 * 16; i += blockDim.x) shcur[i] = 0;
+}
+template <int W> __global__ void __launch_bounds__(256) ovg_clear_kernel(const u64 *__restrict__ st, LevelTable<W> t, u32 *cnt2) {
+    if (st[OVG_STATUS]) return;
+    const u64 n = st[OVG_MASK] + 1;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) { t.slot[i] = LV_EMPTY; cnt2[i] = 0; }
+}
+// insert-or-find that also says whether this call created the slot
+template <int W>
+__device__ __forceinline__ u64 level_insert_c(const LevelTable<W> &t, const Key<W> &key, u64 j, const u64 *pre, int k, int d, bool *created) {
+    u64 s = key_hash(key) & t.mask;
+    *created = false;
+    while (true) {
+        u64 cur = __hip_atomic_load(&t.slot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == LV_EMPTY) {
+            u64 want = (W == 1) ? key.w[0] : j;
+            u64 prev = atomicCAS((ull *)&t.slot[s], (ull)LV_EMPTY, (ull)want);
+            if (prev == LV_EMPTY) { *created = true; return s; }
+            cur = prev;
+        }
+        bool same;
+        if constexpr (W == 1) same = (cur == key.w[0]);
+        else same = key_eq(key_prefix(load_key<W>(pre, cur), k, d), key);
+        if (same) return s;
+        s = (s + 1) & t.mask;
+    }
+}
+template <int W>
+__global__ void __launch_bounds__(256) ovg_insert_kernel(u64 *st, LevelTable<W> t, OvgBuf b, const u64 *__restrict__ pre, const u64 *__restrict__ pred, int k, int d) {
+    if (st[OVG_STATUS]) return;
+    t.mask = st[OVG_MASK];
+    const u64 n = st[OVG_LENP];
+    const u64 *actP = b.act[2 + (st[OVG_CUR] & 1)];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 j = actP[i];
+        if (pred[j] != KC_NONE64) { b.pslot[i] = KC_NONE64; continue; }   // (no longer an active prefix vertex: the lists are compacted lazily)
+        const Key<W> key = key_prefix(load_key<W>(pre, j), k, d);
+        bool created;
+        const u64 s = level_insert_c(t, key, j, pre, k, d, &created);
+        const u32 old = atomicAdd(&b.cnt2[s], 1u);
+        if ((old & 0xffffu) >= 0xfff0u) ovg_poison(st, d, OVG_REASON_BIG);
+        b.pslot[i] = s | ((u64)created << 63);
+    }
+}
+template <int W>
+__global__ void __launch_bounds__(256) ovg_probe_kernel(u64 *st, LevelTable<W> t, OvgBuf b, const u64 *__restrict__ suf, const u64 *__restrict__ pre,
+                                                        const u64 *__restrict__ edge_from, int k, int d) {
+    if (st[OVG_STATUS]) return;
+    t.mask = st[OVG_MASK];
+    const u64 n = st[OVG_LENS];
+    const u64 *actS = b.act[st[OVG_CUR] & 1];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 v = actS[i];
+        u32 sl = OVG_NONE32;
+        if (edge_from[v] == KC_NONE64) {
+            const Key<W> key = key_suffix(load_key<W>(suf, v), d);
+            const u64 s = level_find(t, key, pre, k, d);
+            if (s != KC_NONE64) {
+                const u32 old = atomicAdd(&b.cnt2[s], 1u << 16);
+                if ((old >> 16) >= 0xfff0u) ovg_poison(st, d, OVG_REASON_BIG);
+                sl = (u32)s;
+            }
+        }
+        b.sslot[i] = sl;
+    }
+}
+// the creator of a slot lays out its bucket: the key's representative (of {key, RC(key)}) with members on both sides
+template <int W>
+__global__ void __launch_bounds__(256) ovg_buckets_kernel(u64 *st, LevelTable<W> t, OvgBuf b, const u64 *__restrict__ pre, int k, int d, int complements) {
+    if (st[OVG_STATUS]) return;
+    __shared__ u64 base3[3];
+    const u64 n = st[OVG_LENP];
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x; i0 < n; i0 += (u64)gridDim.x * blockDim.x) {   // (block-uniform trip count: barriers inside)
+        const u64 i = i0 + threadIdx.x;
+        u32 cS = 0, cP = 0;
+        u64 s = 0;
+        bool mine = false, bucket = false;
+        if (i < n) {
+            const u64 ps = b.pslot[i];
+            if (ps != KC_NONE64 && (ps >> 63)) {
+                mine = true;
+                s = ps & ~((u64)1 << 63);
+                const u32 c = b.cnt2[s];
+                cS = c >> 16; cP = c & 0xffffu;
+                if (cS && cP) {
+                    Key<W> key;
+                    if constexpr (W == 1) key.w[0] = t.slot[s];
+                    else key = key_prefix(load_key<W>(pre, t.slot[s]), k, d);
+                    bucket = is_representative(key, d, complements);
+                    if (bucket && (u64)cS + cP > KC_LDS_HUGE) ovg_poison(st, d, OVG_REASON_BIG);
+                }
+            }
+        }
+        u64 t0, t1, t2;
+        const u64 e0 = kc_block_excl_scan(bucket ? 1 : 0, &t0);
+        const u64 e1 = kc_block_excl_scan(bucket ? cS : 0, &t1);
+        const u64 e2 = kc_block_excl_scan(bucket ? cP : 0, &t2);
+        if (threadIdx.x == 0) {
+            base3[0] = t0 ? atomicAdd((ull *)&st[OVG_NB], (ull)t0) : 0;
+            base3[1] = t1 ? atomicAdd((ull *)&st[OVG_TOTS], (ull)t1) : 0;
+            base3[2] = t2 ? atomicAdd((ull *)&st[OVG_TOTP], (ull)t2) : 0;
+        }
+        __syncthreads();
+        if (mine) {
+            if (bucket) {
+                const u64 bi = base3[0] + e0, oS = base3[1] + e1, oP = base3[2] + e2;
+                b.boS[s] = (u32)oS; b.boP[s] = (u32)oP;
+                b.descA[bi] = oS | ((u64)cS << 32); b.descB[bi] = oP | ((u64)cP << 32);
+            } else b.boS[s] = OVG_NONE32;
+            b.cnt2[s] = 0;   // from here on: the fill cursors of the bucket
+        }
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) ovg_scatter_kernel(const u64 *__restrict__ st, OvgBuf b) {
+    if (st[OVG_STATUS]) return;
+    const u64 nS = st[OVG_LENS], nP = st[OVG_LENP];
+    const u64 *actS = b.act[st[OVG_CUR] & 1], *actP = b.act[2 + (st[OVG_CUR] & 1)];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nS + nP; i += (u64)gridDim.x * blockDim.x) {
+        if (i < nS) {
+            const u32 s = b.sslot[i];
+            if (s == OVG_NONE32) continue;
+            const u32 o = b.boS[s];
+            if (o == OVG_NONE32) continue;
+            b.memS[(u64)o + (atomicAdd(&b.cnt2[s], 1u << 16) >> 16)] = actS[i];
+        } else {
+            const u64 ps = b.pslot[i - nS];
+            if (ps == KC_NONE64) continue;
+            const u64 s = ps & ~((u64)1 << 63);
+            if (b.boS[s] == OVG_NONE32) continue;
+            b.memP[(u64)b.boP[s] + (atomicAdd(&b.cnt2[s], 1u) & 0xffffu)] = actP[i - nS];
+        }
+    }
+}
+__device__ __forceinline__ void ovg_insertion_sort(u64 *a, u32 n) {
+    for (u32 i = 1; i < n; ++i) {
+        const u64 v = a[i];
+        u32 j = i;
+        while (j > 0 && a[j - 1] > v) { a[j] = a[j - 1]; --j; }
+        a[j] = v;
+    }
+}
+// one thread per bucket: small ones are put in order and replayed here, the others are handed to a wavefront each
+template <int W>
+__global__ void __launch_bounds__(64) ovg_match_kernel(OvArgs g, u64 *st, OvgBuf b, const u64 *__restrict__ suf) {
+    if (st[OVG_STATUS]) return;
+    const u64 nb = st[OVG_NB];
+    const u32 lds_min = (st[OVG_TOTS] + st[OVG_TOTP] <= 32768) ? 4u : g.lds_min;   // (few hits: even small buckets get a wavefront and LDS)
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < nb; t += (u64)gridDim.x * blockDim.x) {
+        const u64 dA = b.descA[t], dB = b.descB[t];
+        const u64 oS = dA & 0xffffffffull, oP = dB & 0xffffffffull;
+        const u32 cS = (u32)(dA >> 32), cP = (u32)(dB >> 32);
+        const Key<W> key = key_suffix(load_key<W>(suf, b.memS[oS]), g.d);
+        int mode = KC_MODE_UNI;
+        if (g.complements) mode = (g.d == 0 || key_eq(key_rc(key, g.d), key)) ? KC_MODE_PAL : KC_MODE_PAIR;
+        const u32 members = cS + cP;
+        if (members >= lds_min) {
+            const bool hg = members > KC_LDS_MAX;
+            const u64 pos = atomicAdd((ull *)&st[hg ? OVG_HUGE : OVG_BIG], 1ULL);
+            if (pos < (hg ? b.huge_cap : b.big_cap)) {
+                u64 *dsc = (hg ? b.huge : b.big) + pos * 5;
+                dsc[0] = oS; dsc[1] = oS + cS; dsc[2] = oP; dsc[3] = oP + cP; dsc[4] = (u64)mode;
+                continue;
+            }
+            ovg_poison(st, g.d, OVG_REASON_BIG);   // (cannot happen with the caller's sizing)
+            continue;
+        }
+        ovg_insertion_sort(b.memS + oS, cS);
+        ovg_insertion_sort(b.memP + oP, cP);
+        kc_match_bucket(g, b.memS + oS, cS, b.memP + oP, cP, mode, g.tag_base + (u32)t, b.scrS + oS, b.scrP + oP);
+    }
+}
+// one wavefront per listed bucket (workgroups of 64 take the descriptors in turn)
+__global__ void __launch_bounds__(64) ovg_match_lds_kernel(OvArgs g, const u64 *__restrict__ st, OvgBuf b, int huge) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char kc_lds[];
+    if (st[OVG_STATUS]) return;
+    u64 nb = st[huge ? OVG_HUGE : OVG_BIG];
+    const u64 cap = huge ? b.huge_cap : b.big_cap;
+    if (nb > cap) nb = cap;
+    const u64 *list = huge ? b.huge : b.big;
+    for (u64 i = blockIdx.x; i < nb; i += gridDim.x) {
+        const u64 *dsc = list + i * 5;
+        kc_match_bucket_lds(g, b.memS + dsc[0], (u32)(dsc[1] - dsc[0]), b.memP + dsc[2], (u32)(dsc[3] - dsc[2]), (int)dsc[4], kc_lds, true);
+        __syncthreads();
+    }
+}
+// verification: as ov_fix_kernel<false>, over the gathered log, any grid
+__global__ void __launch_bounds__(256) ovg_cover_kernel(u64 *st, const u64 *__restrict__ ne, const u64 *__restrict__ n_ptr, const u64 *__restrict__ edge_from,
+                                                        const u64 *__restrict__ pred, const u64 *__restrict__ first_snap, const u64 *__restrict__ last_snap, u8 *cov) {
+    if (st[OVG_STATUS]) return;
+    const u64 n = *n_ptr;
+    u64 mine = 0;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
+        const u64 y = ne[t * 5 + 1];
+        const u64 l0 = last_snap[y];
+        if (edge_from[l0] != KC_NONE64) continue;   // not the tail of its merged path
+        u64 f = y, steps = 0;
+        while (steps <= n) {
+            const u64 xp = pred[f];
+            if (xp == KC_NONE64) break;
+            cov[f] = 1;
+            ++steps;
+            f = first_snap[xp];
+        }
+        mine += steps;
+    }
+    if (mine) atomicAdd((ull *)&st[OVG_COVERED], (ull)mine);
+}
+// one thread: the level is acyclic iff every new edge was covered by a walk from a path's tail; else the host repairs it
+__global__ void ovg_decide_kernel(u64 *st, const u64 *__restrict__ n_ptr, const u64 *__restrict__ shflag, int d) {
+    if (st[OVG_STATUS]) return;
+    const u64 n = *n_ptr;
+    st[OVG_NE] = n;
+    if (*shflag) { ovg_poison(st, d, OVG_REASON_LOG); return; }
+    if (st[OVG_COVERED] != n) { ovg_poison(st, d, OVG_REASON_REPAIR); return; }
+}
+// new path ends + coverage marks cleared (ov_fix_write_clear_kernel, any grid); then the level's book-keeping
+__global__ void __launch_bounds__(256) ovg_write_kernel(const u64 *__restrict__ st, const u64 *__restrict__ ne, const u64 *__restrict__ edge_from, const u64 *__restrict__ pred,
+                                                        u64 *first_snap, u64 *last_snap, u8 *cov) {
+    if (st[OVG_STATUS]) return;
+    const u64 n = st[OVG_NE];
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
+        const u64 y = ne[t * 5 + 1];
+        cov[y] = 0;
+        const u64 l0 = last_snap[y];
+        if (edge_from[l0] != KC_NONE64) continue;
+        u64 f = y, steps = 0;
+        while (steps <= n) {
+            const u64 xp = pred[f];
+            if (xp == KC_NONE64) break;
+            ++steps;
+            f = first_snap[xp];
+        }
+        first_snap[l0] = f; last_snap[f] = l0;
+    }
+}
+__global__ void ovg_end_kernel(u64 *st, int d) {
+    if (st[OVG_STATUS]) return;
+    const u64 n = st[OVG_NE];   // every new edge removes exactly one suffix vertex and one prefix vertex
+    st[OVG_LIVES] -= n; st[OVG_LIVEP] -= n; st[OVG_EDGES] += n;
+    st[OVG_LEVELS_DONE] = (u64)d;
+    st[OVG_NEWS] = 0; st[OVG_NEWP] = 0;
+    st[OVG_COMPACT] = ((st[OVG_LENS] - st[OVG_LIVES]) * 4 > st[OVG_LENS] || (st[OVG_LENP] - st[OVG_LIVEP]) * 4 > st[OVG_LENP]) ? 1 : 0;
+}
+// lazy compaction of the active lists (the order inside them does not matter to the grouped levels)
+__global__ void __launch_bounds__(256) ovg_compact_kernel(u64 *st, OvgBuf b, const u64 *__restrict__ edge_from, const u64 *__restrict__ pred) {
+    if (st[OVG_STATUS] || !st[OVG_COMPACT]) return;
+    const u64 nS = st[OVG_LENS], nP = st[OVG_LENP];
+    const int cur = (int)(st[OVG_CUR] & 1);
+    const u64 *srcS = b.act[cur], *srcP = b.act[2 + cur];
+    u64 *dstS = b.act[cur ^ 1], *dstP = b.act[2 + (cur ^ 1)];
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x; i0 < nS + nP; i0 += (u64)gridDim.x * blockDim.x) {
+        const u64 i = i0 + threadIdx.x;
+        u64 v = 0;
+        bool keepS = false, keepP = false;
+        if (i < nS) { v = srcS[i]; keepS = edge_from[v] == KC_NONE64; }
+        else if (i < nS + nP) { v = srcP[i - nS]; keepP = pred[v] == KC_NONE64; }
+        const u64 pS = kc_block_reserve(keepS ? 1u : 0u, &st[OVG_NEWS]);
+        const u64 pP = kc_block_reserve(keepP ? 1u : 0u, &st[OVG_NEWP]);
+        if (keepS) dstS[pS] = v;
+        if (keepP) dstP[pP] = v;
+    }
+}
+__global__ void ovg_swap_kernel(u64 *st) {
+    if (st[OVG_STATUS] || !st[OVG_COMPACT]) return;
+    st[OVG_LENS] = st[OVG_NEWS]; st[OVG_LENP] = st[OVG_NEWP];
+    st[OVG_CUR] ^= 1; st[OVG_UNSORTED] = 1; st[OVG_COMPACT] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 struct OvWork;
 static int read_back(kc_ctx *ctx, u64 *h_pinned, const u64 *d, int n) {
     KC_HIP(ctx, hipMemcpyAsync(h_pinned, d, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -795,7 +1106,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     // sharded new-edge log (see ov_add_event): every shard could hold a whole level's edges of an evenly spread load four times over
     u64 *ne_sh = nullptr, *ne_shcur = nullptr;
     const u64 ne_shcap = (2 * V) / 16 + 1024;
-    const bool log_sharded = V >= ((u64)1 << 16) && !getenv("KC_NO_SHARDED_LOG");
+    const bool log_sharded = (V >= ((u64)1 << 16) && !getenv("KC_NO_SHARDED_LOG")) || (!lower_bound && !split && !getenv("KC_OV_HOST_LOOP"));   // (the grouped levels always log through the shards)
     if (log_sharded) { KC_TRY(scope.alloc(&ne_sh, 64 * ne_shcap * 5)); KC_TRY(scope.alloc(&ne_shcur, 65 * 16)); }
     g.ne_sh = nullptr; g.ne_shcur = ne_shcur; g.ne_shcap = ne_shcap;
     u64 nS = V, nP = V, repairs = 0, tag_base = 0;
@@ -816,7 +1127,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     w.h_flag = hp + 15;   // (the level loop reads back at most 9 words; hp[32..] are staging words of the sharded flow)
     u64 *ne_all = nullptr;
     if (split) KC_TRY(scope.alloc(&ne_all, V * 10 + 10));
-    for (int d = k - 1; d >= 0 && nS > 0 && nP > 0; --d) {
+    auto run_level_host = [&](const int d) -> int {   // one level of the host-driven loop
         g.d = d;
         const bool trace = getenv("KC_OV_TRACE") != nullptr;
         auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -859,7 +1170,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                     if (trace) fprintf(stderr, "[ov] window d=%d..%d: %d level(s) with hits\n", win_hi, win_lo, with_hits);
                 } else win_on = false;
             }
-            if (d <= win_hi && d >= win_lo && wcount[win_hi - d] == 0) continue;   // counted: no suffix vertex can hit at this level
+            if (d <= win_hi && d >= win_lo && wcount[win_hi - d] == 0) return KC_OK;   // counted: no suffix vertex can hit at this level
             // one sweep over the active suffixes through the 16-mer table of the prefix ends (see ov_probe16_kernel)
             cnt = fresh_cnt();
             hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
@@ -890,7 +1201,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         const bool any = local_any || split;
         if (trace) t_hits = now_us();
         if (!any && trace) fprintf(stderr, "[ov] d=%d nS=%llu no hits: %.0f us\n", d, (unsigned long long)nS, t_hits - t_level);
-        if (!any) continue;   // no key seen from both sides at this overlap length
+        if (!any) return KC_OK;   // no key seen from both sides at this overlap length
         // 2. compact the hits (ordered; the counts are already known) ...
         // 3. ... and sort them by key (stable: ids ascending inside a key).  Few hits: the probe kernels have listed them
         // already (unordered); one workgroup derives the keys and sorts the rows by (key, id) in LDS.
@@ -950,7 +1261,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             g.lds_min = (u32)((nHS + nHP <= 32768 && !getenv("KC_LDS_MIN")) ? 4 : lds_min);
             g.abort2 = (bkS || bkP) ? w.d_flag : nullptr;
             // many events (the mid levels of a read set): the log goes through 64 cursors and is gathered afterwards
-            const bool shlog = log_sharded && local_any && nHS >= 4096;
+            const bool shlog = log_sharded && V >= ((u64)1 << 16) && !getenv("KC_NO_SHARDED_LOG") && local_any && nHS >= 4096;   // (small inputs: one bucket can outgrow a shard)
             g.ne_sh = shlog ? ne_sh : nullptr;
             if (shlog) KC_HIP(ctx, hipMemsetAsync(ne_shcur, 0, 65 * 16 * 8, ctx->stream));
             // after a read-back that carried the overflow words (hp[16], hp[17]): sort the overflowed side(s) again, LSD this time
@@ -1058,11 +1369,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                     (unsigned long long)nHS, (unsigned long long)nNew, (unsigned long long)hp[8], t_hits - t_level, t_sorted - t_hits, t_matched - t_sorted);
         }
         h_bl.clear(); g.nbl = 0;   // the blacklist is per level
-        if (nNew == 0) continue;
+        if (nNew == 0) return KC_OK;
         // 6. shrink the active lists -- lazily: every sweep checks for itself whether a listed vertex is still active, so the lists
         // are only compacted (two flag sweeps + two ordered compactions: 8 launches) once a quarter of their entries have died
         if (!lower_bound) { nS -= nNew; nP -= nNew; }   // every new edge removes exactly one suffix vertex and one prefix vertex
-        if (!lower_bound && !getenv("KC_OV_EAGER_SHRINK") && (lenS - nS) * 4 <= lenS && (lenP - nP) * 4 <= lenP) continue;
+        if (!lower_bound && !getenv("KC_OV_EAGER_SHRINK") && (lenS - nS) * 4 <= lenS && (lenP - nP) * 4 <= lenP) return KC_OK;
         hipLaunchKernelGGL((ov_still_active_kernel<true>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, lenS,
                            (const u64 *)edge_from, (const u64 *)pred, hitS);
         hipLaunchKernelGGL((ov_still_active_kernel<false>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP,
@@ -1078,6 +1389,120 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         }
         lenS = nS; lenP = nP;
         std::swap(actS, actS2); std::swap(actP, actP2);
+        return KC_OK;
+    };
+    // ---- the grouped levels (no host in the loop; see OVG_* above): every level that builds a table of its own, i.e. all but the
+    // levels d >= 16 that go through the 16-mer table.  KC_OV_HOST_LOOP=1: the host-driven loop for everything.
+    const bool grouped_ok = !lower_bound && !split && !getenv("KC_OV_HOST_LOOP");
+    u64 *ovg_st = nullptr, *ovg_lcnt = nullptr;
+    OvgBuf ob{};
+    bool lists_unsorted = false;
+    if (grouped_ok) {
+        KC_TRY(scope.alloc(&ovg_st, OVG_WORDS));
+        KC_TRY(scope.alloc(&ovg_lcnt, 128 * 16));
+        KC_TRY(scope.alloc(&ob.sslot, V + 1));
+        KC_TRY(scope.alloc(&ob.boS, tcap + 1)); KC_TRY(scope.alloc(&ob.boP, tcap + 1));
+        ob.cnt2 = reinterpret_cast<u32 *>(tab.slot + tcap);   // (the flag words of the host-driven levels)
+        ob.pslot = pslot;
+        ob.memS = hs_ids2; ob.memP = hp_ids2; ob.scrS = hs_ids; ob.scrP = hp_ids; ob.descA = hs_keys; ob.descB = hp_keys;
+        ob.big = big; ob.huge = huge; ob.big_cap = big_cap; ob.huge_cap = huge_cap; ob.tcap = tcap;
+        if (getenv("KC_OVG_NO_LDS")) { ob.big_cap = 0; ob.huge_cap = 0; }   // (test knob: every bucket a wavefront would replay sends its level to the host-driven loop)
+        KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(ovg_match_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kc_lds_bytes_bound(KC_LDS_HUGE)));
+    }
+    // levels d_hi .. 0 enqueued back to back, one look at the outcome; *next = the level the host-driven loop has to run (-1: none)
+    auto run_grouped = [&](const int d_hi, int *next) -> int {
+        *next = -1;
+        u64 h_st[OVG_WORDS] = {0};
+        h_st[OVG_LENS] = lenS; h_st[OVG_LENP] = lenP; h_st[OVG_LIVES] = nS; h_st[OVG_LIVEP] = nP;
+        KC_HIP(ctx, hipMemcpyAsync(ovg_st, h_st, sizeof h_st, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (h_st is on the stack)
+        ob.act[0] = actS; ob.act[1] = actS2; ob.act[2] = actP; ob.act[3] = actP2;
+        // the new-edge log: through the 64 shards (gathered per level) on large inputs; straight into the dense log on small ones, where
+        // one bucket can hold more events than a shard and an add per event on one word does not matter
+        const bool shl = V >= ((u64)1 << 16) && ne_sh != nullptr;
+        g.abort2 = nullptr; g.nbl = 0; g.lds_min = (u32)lds_min; g.ne_sh = shl ? ne_sh : nullptr;
+        u64 *gcnt = nullptr;
+        std::vector<u64 *> level_cnt((size_t)d_hi + 1, nullptr);
+        KC_HIP(ctx, hipMemsetAsync(ovg_lcnt, 0, 128 * 16 * 8, ctx->stream));   // one counter block per level of this run (level d: block d)
+        for (int d = d_hi; d >= 0; --d) {
+            g.d = d;
+            if (tag_base + nP + 2 >= 0xfffffff0ull) {   // (writer tags: a fresh range per level, never reused without clearing)
+                KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
+                KC_HIP(ctx, hipMemsetAsync(last, 0xff, V * 8, ctx->stream));
+                tag_base = 0;
+            }
+            g.tag_base = (u32)tag_base;
+            tag_base += nP + 1;   // (a level has at most as many buckets as live prefix vertices at the start of this run)
+            gcnt = ovg_lcnt + 16 * (size_t)d;
+            level_cnt[(size_t)d] = gcnt;
+            g.ne_count = gcnt;
+            hipLaunchKernelGGL((ovg_begin_kernel<W>), dim3(1), dim3(256), 0, ctx->stream, ovg_st, ne_shcur, tcap);
+            hipLaunchKernelGGL((ovg_clear_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, tab, ob.cnt2);
+            hipLaunchKernelGGL((ovg_insert_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, (const u64 *)pred, k, d);
+            hipLaunchKernelGGL((ovg_probe_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)suf, (const u64 *)pre, (const u64 *)edge_from, k, d);
+            hipLaunchKernelGGL((ovg_buckets_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, k, d, complements);
+            hipLaunchKernelGGL(ovg_scatter_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, ob);
+            hipLaunchKernelGGL((ovg_match_kernel<W>), dim3(4 * OVG_GRID), dim3(64), 0, ctx->stream, g, ovg_st, ob, (const u64 *)suf);
+            hipLaunchKernelGGL(ovg_match_lds_kernel, dim3(2 * OVG_GRID), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g, (const u64 *)ovg_st, ob, 0);
+            hipLaunchKernelGGL(ovg_match_lds_kernel, dim3(64), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g, (const u64 *)ovg_st, ob, 1);
+            if (shl) hipLaunchKernelGGL(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, gcnt);
+            hipLaunchKernelGGL(ovg_cover_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, (const u64 *)ne, (const u64 *)gcnt, (const u64 *)edge_from, (const u64 *)pred,
+                               (const u64 *)first_snap, (const u64 *)last_snap, cov);
+            hipLaunchKernelGGL(ovg_decide_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, (const u64 *)gcnt, (const u64 *)(ne_shcur + 64 * 16), d);
+            hipLaunchKernelGGL(ovg_write_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, (const u64 *)ne, (const u64 *)edge_from, (const u64 *)pred, first_snap,
+                               last_snap, cov);
+            hipLaunchKernelGGL(ovg_end_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, d);
+            hipLaunchKernelGGL(ovg_compact_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, ob, (const u64 *)edge_from, (const u64 *)pred);
+            hipLaunchKernelGGL(ovg_swap_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st);
+        }
+        KC_HIP(ctx, hipGetLastError());
+        KC_HIP(ctx, hipMemcpyAsync(h_st, ovg_st, sizeof h_st, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_st[OVG_CUR] & 1) { std::swap(actS, actS2); std::swap(actP, actP2); }
+        lenS = h_st[OVG_LENS]; lenP = h_st[OVG_LENP]; nS = h_st[OVG_LIVES]; nP = h_st[OVG_LIVEP];
+        if (h_st[OVG_UNSORTED]) lists_unsorted = true;
+        if (getenv("KC_OV_TRACE"))
+            fprintf(stderr, "[ov] grouped levels %d..: status %llx, %llu edges, %llu / %llu live suffix / prefix vertices left\n", d_hi, (unsigned long long)h_st[OVG_STATUS],
+                    (unsigned long long)h_st[OVG_EDGES], (unsigned long long)nS, (unsigned long long)nP);
+        if (!h_st[OVG_STATUS]) return KC_OK;
+        const int dp = (int)(h_st[OVG_STATUS] & 0xff) - 1, reason = (int)(h_st[OVG_STATUS] >> 8);
+        if (reason == OVG_REASON_LOG) return kc_fail(ctx, KC_E_NO_DEVICE, "a shard of the new-edge log overflowed");
+        // whatever level dp logged is taken back (a repair: everything; a bucket this path does not take: what the others matched)
+        u64 *c2 = level_cnt[(size_t)dp];   // (the dense log's length, when the level logged straight into it)
+        if (shl) {
+            c2 = fresh_cnt();
+            hipLaunchKernelGGL(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, c2);
+        }
+        u64 nlog = 0;
+        KC_HIP(ctx, hipMemcpyAsync(&nlog, c2, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (nlog) hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nlog, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nlog, edge_from, overlaps, pred, eidx, cov);
+        KC_HIP(ctx, hipGetLastError());
+        *next = dp;
+        return KC_OK;
+    };
+    // the host-driven levels want their lists ascending (the grouped ones compact them in any order)
+    auto sort_lists = [&]() -> int {
+        if (!lists_unsorted) return KC_OK;
+        KC_TRY(kcu_sort_pairs(ctx, actS, actS2, nullptr, nullptr, lenS, 0, 40, false));
+        KC_TRY(kcu_sort_pairs(ctx, actP, actP2, nullptr, nullptr, lenP, 0, 40, false));
+        std::swap(actS, actS2); std::swap(actP, actP2);
+        lists_unsorted = false;
+        return KC_OK;
+    };
+    for (int d = k - 1; d >= 0 && nS > 0 && nP > 0;) {
+        const bool t16_level = t16_on && !t16_dead && d >= 16;
+        if (grouped_ok && !t16_level) {
+            int next = -1;
+            KC_TRY(run_grouped(d, &next));
+            if (next < 0) break;
+            KC_TRY(sort_lists());
+            KC_TRY(run_level_host(next));
+            d = next - 1;
+            continue;
+        }
+        KC_TRY(run_level_host(d));
+        --d;
     }
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ok = true;

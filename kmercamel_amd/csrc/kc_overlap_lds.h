@@ -43,8 +43,24 @@ __device__ __forceinline__ u32 lds_find(const u64 *a, u32 n, u64 v) {   // index
     return (lo < n && a[lo] == v) ? lo : KC_LDS_NONE;
 }
 
-// one wavefront (blockDim = 64); smem = dynamic LDS of at least kc_lds_bytes(nA, nB)
-__device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, const u64 *gB, u32 nB, int mode, unsigned char *smem) {
+// ascending order of the n vertex ids in a[] (LDS), by their rank among themselves (ids are distinct): every lane places its
+// elements; tmp[] = n words of LDS.  n^2 / 64 compares per lane -- for the member lists of the grouped levels, which arrive unordered.
+__device__ __forceinline__ void kc_lds_rank_sort(u64 *a, u32 n, u32 *tmp) {
+    const int lane = threadIdx.x & 63;
+    for (u32 i = lane; i < n; i += 64) tmp[i] = (u32)a[i];
+    __syncthreads();
+    for (u32 i = lane; i < n; i += 64) {
+        const u32 v = tmp[i];
+        u32 r = 0;
+        for (u32 j = 0; j < n; ++j) r += tmp[j] < v ? 1u : 0u;
+        a[r] = (u64)v;
+    }
+    __syncthreads();
+}
+
+// one wavefront (blockDim = 64); smem = dynamic LDS of at least kc_lds_bytes(nA, nB).  unsorted: gA / gB come in any order (the
+// grouped levels scatter the members of a bucket through atomic cursors) and are put in ascending order here.
+__device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, const u64 *gB, u32 nB, int mode, unsigned char *smem, bool unsorted = false) {
     const int lane = threadIdx.x & 63;
     const u64 S = g.S;
     const bool bi = g.complements != 0;
@@ -68,6 +84,7 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
     for (u32 i = lane; i < nA; i += 64) { b.A[i] = gA[i]; b.usedA[i] = 0; }
     for (u32 j = lane; j < nB; j += 64) { b.B[j] = gB[j]; b.usedB[j] = 0; }
     __syncthreads();
+    if (unsorted) { kc_lds_rank_sort(b.A, nA, b.evU); kc_lds_rank_sort(b.B, nB, b.evU); }   // (evU: n words, free until the replay)
     for (u32 i = lane; i < nA; i += 64) {
         u64 F = g.lower_bound ? 0 : g.first_snap[b.A[i]];
         LdsEnd e;
