@@ -1490,9 +1490,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         lists_unsorted = false;
         return KC_OK;
     };
+    // Which loop a level takes: the grouped levels win where a level is bound by launches and read-backs (few live vertices: 10^5
+    // reads, the late levels of any input); with millions of live vertices a level is bound by its sweeps, and the host-driven one
+    // makes fewer of them (measured at 5 10^6 vertices: 26.2 ms for the whole phase, 32.4 ms with every table level grouped, and
+    // 26.8 - 27.4 ms with only the late levels grouped: tools/r4_ovgmax.sh).  KC_OVG_MAX = live vertices (suffix + prefix) up to
+    // which the grouped levels are used.
+    u64 ovg_max = (u64)1 << 20;
+    if (const char *e = getenv("KC_OVG_MAX")) ovg_max = (u64)atoll(e);
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0;) {
         const bool t16_level = t16_on && !t16_dead && d >= 16;
-        if (grouped_ok && !t16_level) {
+        if (grouped_ok && !t16_level && nS + nP <= ovg_max) {
             int next = -1;
             KC_TRY(run_grouped(d, &next));
             if (next < 0) break;

@@ -449,7 +449,11 @@ def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
         assert int(np.bitwise_xor.reduce(ka * mix)) == int(np.bitwise_xor.reduce(kb * mix))
     sa.close(); sb.close()
     for env in ({"KC_NOFRAG": "1"}, {"KC_T16_MIN": "1000000000000"}, {"KC_T16_FORCE": "1"}, {"KC_NO_BUCKET_SORT": "1"}, {"KC_NO_SHARDED_LOG": "1"},
-                {"KC_SAMPLED_RANK_MIN": "1000000000000"}, {"KC_SAMPLED_RANK_MIN": "0"}):
+                {"KC_SAMPLED_RANK_MIN": "1000000000000"}, {"KC_SAMPLED_RANK_MIN": "0"},
+                # phase 2: the host-driven loop for every level / the grouped levels for every table level / no wavefront replays in
+                # them (every larger bucket sends its level back to the host-driven loop) / eager compaction, no level windows
+                {"KC_OV_HOST_LOOP": "1"}, {"KC_OVG_MAX": "1000000000000"}, {"KC_OVG_MAX": "1000000000000", "KC_OVG_NO_LDS": "1"},
+                {"KC_OV_EAGER_SHRINK": "1", "KC_OV_NO_WINDOW": "1"}):
         for name, value in env.items():
             monkeypatch.setenv(name, value)
         r2 = kc.compute(ctx, seq, k, True)
