@@ -128,10 +128,13 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         if (rc == KC_OK && min_frequency > 1) rc = kc_set_enable_counting(set);
         u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
         if (rc == KC_OK && len >= (u64)k) {
-            // the port links of phase 1 (16 B per slot) are the largest block of the run and the build buckets of phase 0 (8 W B
-            // per slot) are gone by then: obtain the larger of the two now, so that both phases use the same memory
+            // the port links of phase 1 are the largest block of the run and the build buckets of phase 0 (8 W B per slot) are gone
+            // by then: obtain the larger of the two now, so that both phases use the same memory.  The links are 16 B per node id,
+            // nstride ids per block (the largest block: ~0.64 of a block's slots on uniform data at load 0.5): 0.7 x 16 B per slot is
+            // reserved; a table with a fuller block simply obtains a larger block of its own when phase 1 starts.
             void *arena = nullptr;
-            if (ctx->pool.alloc(&arena, set->cap * 16) == hipSuccess) ctx->pool.release(arena); else (void)hipGetLastError();
+            const size_t arena_bytes = set->W == 1 ? (size_t)(set->cap / 4 * 45) : (size_t)set->cap * 16;
+            if (ctx->pool.alloc(&arena, arena_bytes) == hipSuccess) ctx->pool.release(arena); else (void)hipGetLastError();
             rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
             if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, 0);
         }

@@ -22,6 +22,7 @@ hipError_t KcPool::alloc(void **out, size_t bytes) {
         *out = free_list[best].p;
         live[*out] = free_list[best].size;
         live_bytes += free_list[best].size;
+        if (getenv("KC_POOL_TRACE") && need >= ((size_t)1 << 30)) fprintf(stderr, "[pool] reuse %.2f GB for %.2f GB -> live %.2f GB\n", free_list[best].size / 1e9, need / 1e9, live_bytes / 1e9);
         free_list.erase(free_list.begin() + best);
         if (live_bytes > peak_bytes) peak_bytes = live_bytes;
         return hipSuccess;
@@ -39,6 +40,8 @@ hipError_t KcPool::alloc(void **out, size_t bytes) {
     live[*out] = need;
     live_bytes += need;
     if (live_bytes > peak_bytes) peak_bytes = live_bytes;
+    static const bool trace = getenv("KC_POOL_TRACE") != nullptr;
+    if (trace && need >= ((size_t)1 << 30)) fprintf(stderr, "[pool] hipMalloc %.2f GB -> live %.2f GB (cached %zu blocks)\n", need / 1e9, live_bytes / 1e9, free_list.size());
     return hipSuccess;
 }
 void KcPool::release(void *p) {
@@ -1171,8 +1174,8 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     h[3] |= scatter_ovf;
     if (!h[2] && !h[3] && !getenv("KC_NO_BUILD_IDS")) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (KC_NO_BUILD_IDS: test knob, the sweep of kcs_prepare_dense instead)
     if (getenv("KC_SET_TRACE"))
-        fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu\n", W,
-                (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3]);
+        fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu, largest block %llu k-mers\n", W,
+                (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[4]);
     if (h[2] > ovf_cap)   // the spill list overflowed: the global path inserts whatever is still missing
         return insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);
     if (h[3]) {           // some buckets overflowed (blocks hit by high-multiplicity repeats): a second sweep inserts only those blocks' k-mers
