@@ -53,6 +53,7 @@ struct kc_set {
                              // are then LOCAL arrays of rcap entries
     u32 *ncount = nullptr;   // dense node ids: k-mers per block (blocks of this rank), see kcs_prepare_dense and SetView
     u32 nstride = 0;         // ids per block = the largest ncount, rounded up to a multiple of 8
+    float occ_ratio = 0;     // occurrences per distinct k-mer in the sample the bucketed build took of a fresh set (0: not sampled)
     bool dense_ok = false;   // ncount / nstride and the counts in the empty slots describe the table as it is (any insertion voids them)
     mutable bool unclean = false;   // table allocated but not filled with EMPTY yet (a bucketed build of a fresh set overwrites every
                                     // slot, so the 9 B/slot fill is deferred until something else needs the table)

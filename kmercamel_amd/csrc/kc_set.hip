@@ -1137,6 +1137,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
             const u64 distinct = hs[2], occ = hs[3];
+            set->occ_ratio = distinct ? (float)((double)occ / (double)distinct) : 0.f;
             int r = 1;
             while (2 * r <= KC_MAX_SEG && distinct && occ >= (u64)(2 * r) * distinct && set->nblocks % (u64)(2 * r) == 0 && set->nblocks / (u64)(2 * r) >= 64) r *= 2;
             if (getenv("KC_SET_TRACE"))

@@ -1542,6 +1542,99 @@ static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, 
     }
 }
 
+// The k-mers NO walk reached, from SPARSE marks (long-chain inputs; dense node ids).  A segment walk that marked every node it
+// passes wrote one scattered byte per node and direction -- three times the cost of the walk itself (measured on 2.4e9 genome
+// k-mers: 335 ms against 116 ms).  The walks therefore mark only where a chain ENTERS a block (the node reached by a link from
+// another block, a chain's head, its tail): one mark per in-block run and direction.  This kernel turns those marks back into the
+// list of unvisited k-mers: one workgroup per block rebuilds the block's runs in LDS exactly as kc_frag_contract_kernel does (same
+// digest, same ends), and a run whose entry end carries no mark -- no walk came in there -- is on a cycle, all of it; so are the
+// nodes of cycles that never leave the block (they have no end at all).  FILL = false counts, FILL = true lists (node ids).
+template <int W, bool FILL>
+__global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, const u8 *__restrict__ visited,
+                                                                 u64 *out, u64 *cursor) {
+    // LDS: the digest (one 32-bit word per port, see kc_frag_contract_kernel; bit 29 of a node's port-0 word: on a run that was
+    // walked here, bit 28: marked), the ends (2 * bs u16), the unvisited nodes of the block (bs u16)
+    extern __shared__ u32 kc_fl[];
+    __shared__ u32 n_ent, n_out;
+    __shared__ u64 g_base;
+    const u32 bs = 1u << set.bshift;
+    const u64 blk = (set.rlo >> set.bshift) + blockIdx.x;
+    const u64 base = blk * (u64)set.nstride;
+    const u32 nn = set.ncount[blk];
+    unsigned short *ents = reinterpret_cast<unsigned short *>(kc_fl + 2 * (size_t)bs);
+    unsigned short *lst = ents + 2 * (size_t)bs;
+    if (threadIdx.x == 0) { n_ent = 0; n_out = 0; }
+    for (u32 s = threadIdx.x; s < nn; s += blockDim.x) {
+        const ulonglong2 ww = *reinterpret_cast<const ulonglong2 *>(link + (base + s) * 2);
+        const u64 w2[2] = {ww.x, ww.y};
+        const u32 vis = visited[base + s] ? 1u << 28 : 0u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const u64 w = w2[p];
+            const bool in = LK_IS_MATCHED(w) && LK_SLOT(w) - base < (u64)nn;
+            kc_fl[2 * s + p] = 0x40000000u | (p == 0 ? vis : 0u) | (in ? (0x80000000u | (u32)(LK_SLOT(w) - base) | ((u32)LK_PORT(w) << 14)) : 0u);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (u32 s0 = 0; s0 < nn; s0 += blockDim.x) {
+        const u32 s = s0 + threadIdx.x;
+        for (int o = 0; o < (complements ? 2 : 1); ++o) {
+            const u32 f_in = s < nn ? kc_fl[2 * s + o] : 0u, f_out = s < nn ? kc_fl[2 * s + (o == 0 ? 1 : 0)] : 0u;
+            const bool is_end = (f_in & 0x40000000u) && !(f_in >> 31) && (f_out >> 31);
+            const unsigned long long m = __ballot(is_end);
+            if (!m) continue;
+            u32 at0 = 0;
+            if (lane == 0) at0 = atomicAdd(&n_ent, (u32)__popcll(m));
+            at0 = __shfl(at0, 0, 64);
+            if (is_end) ents[at0 + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1))] = (unsigned short)(2 * s + (u32)o);   // (at most 2 nn ends)
+        }
+    }
+    __syncthreads();
+    const u32 ne = n_ent;
+    for (u32 e = threadIdx.x; e < ne; e += blockDim.x) {
+        const u32 s = ents[e] >> 1;
+        const int o = (int)(ents[e] & 1);
+        // walk the run, flag its nodes; an unmarked run is listed by the walk from its smaller end (unidirectional: its only end)
+        u32 cur = s, len = 1; int co = o;
+        atomicOr(&kc_fl[2 * cur], 1u << 29);
+        while (len <= bs) {
+            const u32 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
+            if (!(w >> 31)) break;
+            cur = w & 0x3fffu; co = (int)((w >> 14) & 1); ++len;
+            atomicOr(&kc_fl[2 * cur], 1u << 29);
+        }
+        const bool marked = (kc_fl[2 * s] >> 28) & 1u;
+        if (marked || (complements && cur < s)) continue;
+        u32 at = atomicAdd(&n_out, len);
+        cur = s; co = o;
+        for (u32 i = 0; i < len; ++i) {
+            if (at + i < bs) lst[at + i] = (unsigned short)cur;
+            const u32 w = kc_fl[2 * cur + (co == 0 ? 1 : 0)];
+            cur = w & 0x3fffu; co = (int)((w >> 14) & 1);
+        }
+    }
+    __syncthreads();
+    // nodes on no run: alone in the block (unvisited iff unmarked), or on a cycle inside the block
+    for (u32 s = threadIdx.x; s < nn; s += blockDim.x) {
+        const u32 f0 = kc_fl[2 * s], f1 = kc_fl[2 * s + 1];
+        if ((f0 >> 29) & 1u) continue;
+        const bool in0 = f0 >> 31, in1 = f1 >> 31;
+        // (a node with exactly one link inside the block is the end of a run and carries the flag)
+        const bool unv = (!in0 && !in1) ? !((f0 >> 28) & 1u) : (in0 && in1);
+        if (!unv) continue;
+        const u32 at = atomicAdd(&n_out, 1u);
+        if (at < bs) lst[at] = (unsigned short)s;
+    }
+    __syncthreads();
+    const u32 no = n_out < bs ? n_out : bs;
+    if (no == 0) return;
+    if (threadIdx.x == 0) g_base = atomicAdd((ull *)cursor, (ull)no);
+    __syncthreads();
+    if (FILL)
+        for (u32 i = threadIdx.x; i < no; i += blockDim.x) out[g_base + i] = base + (u64)lst[i];
+}
+
 // measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a
 // chain is emitted (bi: the one starting at the smaller key) and records the winners.
 // MARK: also flag visited nodes (only needed when the node count shows that cycles exist).

@@ -435,14 +435,17 @@ __device__ __forceinline__ u64 kc_find_start(const u64 *starts, u64 n, u64 id) {
     return lo;   // callers only look up ids that are present
 }
 // one thread per start (sorted ascending): nodes until the next splitter (exclusive) or the tail (inclusive)
-// MODE 0: measure (seg_len / seg_next / seg_tail).  MODE 1: measure and mark every node walked in `visited` -- the k-mers on cycles
-// WITHOUT a splitter are then exactly the unmarked ones, no marking walk of its own (as long as this one: a scattered line per
-// node) is needed.  MODE 2: the segments that kc_chain_reduce_kernel assigned to NO chain (seg_chain: their splitters
-// lie on cycles, no head reaches them) take their marks back; nothing else is written.
+// MODE 0: measure (seg_len / seg_next / seg_tail).  MODE 1: measure and mark in `visited` -- the k-mers on cycles WITHOUT a
+// splitter are then the ones no mark accounts for, and no marking walk of its own (as long as this one: a scattered line per node)
+// is needed.  MODE 2: the segments that kc_chain_reduce_kernel assigned to NO chain (seg_chain: their splitters lie on cycles, no
+// head reaches them) take their marks back; nothing else is written.
+// nstride != 0: SPARSE marks -- only the nodes where the walk enters a block (reached by a link from another block; the start node
+// when it is a head or entered from another block; the tail): one scattered byte per in-block run instead of one per node
+// (marking every node made this walk three times as slow); kc_frag_unvisited_kernel reads them.
 template <int MODE>
 __global__ void __launch_bounds__(256) kc_segment_walk_kernel(const u64 *__restrict__ link, const u64 *__restrict__ starts, u64 nstarts,
                                                               u64 *seg_len, u64 *seg_next, u64 *seg_tail, u8 *visited,
-                                                              const u64 *__restrict__ seg_chain, u64 max_len) {
+                                                              const u64 *__restrict__ seg_chain, u64 max_len, u32 nstride) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nstarts) return;
     if (MODE == 2 && seg_chain[j] != KC_SEG_NONE) return;
@@ -450,14 +453,25 @@ __global__ void __launch_bounds__(256) kc_segment_walk_kernel(const u64 *__restr
     int co = (int)(starts[j] & 1);
     u64 len = 1;
     u64 w = link[(cur << 1) | (u64)(co == 0 ? 1 : 0)];
+    u64 lo = 0;          // sparse marks: first id of the block the walk is in
+    bool entered = true; // ... and whether `cur` was entered from outside it
+    if (MODE != 0 && nstride) {
+        lo = cur / nstride * nstride;
+        const u64 win = link[(cur << 1) | (u64)co];   // (the entry port's word: same 16 bytes)
+        entered = !LK_IS_MATCHED(win) || LK_SLOT(win) - lo >= (u64)nstride;
+    }
     while (true) {
-        if (MODE == 1) visited[cur] = 1;
-        if (MODE == 2) visited[cur] = 0;
-        if (!LK_IS_MATCHED(w)) { if (MODE != 2) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (LK_SLOT(w) << 1) | (u64)co; } break; }   // (the tail by SLOT, from its dead port's word)
+        const bool tail = !LK_IS_MATCHED(w);
+        if (MODE != 0 && (entered || tail)) visited[cur] = MODE == 1 ? 1 : 0;
+        if (tail) { if (MODE != 2) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = (LK_SLOT(w) << 1) | (u64)co; } break; }   // (the tail by SLOT, from its dead port's word)
         u64 nxt = LK_SLOT(w);
         int no = LK_PORT(w) == 0 ? 0 : 1;
         u64 wn = link[(nxt << 1) | (u64)(no == 0 ? 1 : 0)];
         if (wn & LK_SPLIT) { if (MODE != 2) { seg_next[j] = kc_find_start(starts, nstarts, (nxt << 1) | (u64)no); seg_tail[j] = KC_SEG_NONE; } break; }
+        if (MODE != 0 && nstride) {
+            entered = nxt - lo >= (u64)nstride;
+            if (entered) lo = nxt / nstride * nstride;
+        }
         cur = nxt; co = no; w = wn;
         if (++len > max_len) { if (MODE != 2) { seg_next[j] = KC_SEG_NONE; seg_tail[j] = 0; } break; }   // (cannot happen on consistent links: a segment ends at a splitter or a chain end; never spin)
     }
@@ -634,6 +648,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // (sized for read-like inputs -- 2 heads per simplitig, hardly any branch port; a cold process pays ~26 ms per GB it obtains
     // from hipMalloc, so generous bounds are not free.  Overflows take the exact paths below.)
     u64 heads_cap = N / 32 + 65536, work_cap = N / 64 + 65536;
+    // (reads with coverage -- the build's sample saw every k-mer several times -- have an error-made tip or bubble every few dozen
+    // k-mers: 19.7 10^6 simplitigs and as many branch ports per 7.3 10^8 k-mers at 30x with 1 % errors; the exact paths cost 80 ms there)
+    if (set->occ_ratio >= 1.5f) { heads_cap = N / 6 + 65536; work_cap = N / 6 + 65536; }
     u64 *heads = nullptr, *work_a = nullptr, *work_b = nullptr;
     KC_TRY(scope.alloc(&heads, heads_cap));
     KC_TRY(scope.alloc(&work_a, work_cap));
@@ -709,6 +726,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                        (const u64 *)branch_cursors, branch, work_cap, branch_cursor);
     u64 nbranch = 0, nwork = 0, rounds = 1;
     KC_TRY(read_u64(ctx, branch_cursor, &nbranch));
+    if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] round 1: %llu branch ports (list of %llu)\n", (unsigned long long)nbranch, (unsigned long long)work_cap);
     scope.release(heads_sh); scope.release(branch_sh); scope.release(shard_cur);
     if (nbranch && nbranch <= work_cap) {
         hipLaunchKernelGGL((kc_reject_kernel<W>), dim3(kc_grid(nbranch, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)branch,
@@ -750,6 +768,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 nheads = 0;
     const u64 nsplit_max = (NID + 255) >> 8;   // splitters: nodes with id % 256 == 0
     KC_TRY(read_u64(ctx, heads_cursor, &nheads));
+    if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] %llu chain heads (list of %llu), %llu matching round(s)\n", (unsigned long long)nheads, (unsigned long long)heads_cap, (unsigned long long)rounds);
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
@@ -775,6 +794,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 *pool = nullptr, *chain_stream = nullptr, *chain_tail = nullptr;
     bool seg_ok = false, use_stream = false, known_long = false;
     u8 *seg_marks = nullptr;   // nodes walked by the first long-chain pass (kc_segment_walk_kernel<1>)
+    // (marks of the segment walks: where a walk enters a block only -- kc_frag_unvisited_kernel turns them into the unvisited k-mers;
+    // blocks beyond what that kernel keeps in LDS, or KC_SEG_DENSE_MARKS: every node is marked)
+    const u32 sparse_stride = (set->bshift <= 13 && !getenv("KC_SEG_DENSE_MARKS")) ? nstride : 0u;
     u64 nstarts = 0, nchains = 0;
     for (int pass = 0;; ++pass) {
         const u64 max_chains = nheads + 1;
@@ -887,10 +909,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             if (nstarts) {
                 if (seg_marks)
                     hipLaunchKernelGGL(kc_segment_walk_kernel<1>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, seg_marks, (const u64 *)nullptr, NID);
+                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, seg_marks, (const u64 *)nullptr, NID, sparse_stride);
                 else
                     hipLaunchKernelGGL(kc_segment_walk_kernel<0>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, (u8 *)nullptr, (const u64 *)nullptr, NID);
+                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, (u8 *)nullptr, (const u64 *)nullptr, NID, 0u);
                 hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                                    (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
                                    seg_off, chain_head, chain_len, chain_key, cnt);
@@ -912,7 +934,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             marked = true;
             if (nstarts)
                 hipLaunchKernelGGL(kc_segment_walk_kernel<2>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID);
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID, sparse_stride);
         } else {
             KC_TRY(scope.alloc(&visited, NID));
             KC_HIP(ctx, hipMemsetAsync(visited, 0, NID, ctx->stream));
@@ -922,25 +944,38 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         } else if (too_long) {
             if (nstarts) {   // (a marking walk of its own, then the segments of no chain take their marks back)
                 hipLaunchKernelGGL(kc_segment_walk_kernel<1>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)nullptr, NID);
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)nullptr, NID, sparse_stride);
                 hipLaunchKernelGGL(kc_segment_walk_kernel<2>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID);
+                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID, sparse_stride);
             }
         } else if (nheads) {
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited,
-                           (u64 *)nullptr, cnt + 1);
+        const bool sparse_marks = too_long && sparse_stride;
+        const size_t lds_unv = (size_t)14 << set->bshift;
+        if (sparse_marks) {
+            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_unvisited_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_unv));
+            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_unvisited_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_unv));
+            hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, false>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, (const u64 *)link, compl_,
+                               (const u8 *)visited, (u64 *)nullptr, cnt + 1);
+        } else
+            hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited,
+                               (u64 *)nullptr, cnt + 1);
         u64 nunvis = 0;
         KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
+        if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] pass %d: %llu k-mers on cycles (%s marks)\n", pass, (unsigned long long)nunvis, sparse_marks ? "sparse" : "dense");
         if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
         u64 *ulist = nullptr, *heads2 = nullptr;
         KC_TRY(scope.alloc(&ulist, nunvis));
         KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited, ulist,
-                           cnt + 1);
+        if (sparse_marks)
+            hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, (const u64 *)link, compl_,
+                               (const u8 *)visited, ulist, cnt + 1);
+        else
+            hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited, ulist,
+                               cnt + 1);
         {
             // rows of the k-mers on cycles and the candidate edges of their ports to dead ports -> host, which walks the cycles and
             // decides where each is opened (kc_cycles_decide) -> kc_cycle_fix_kernel, new head list
