@@ -1138,6 +1138,13 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 hipLaunchKernelGGL((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows);
             }
             KC_HIP(ctx, hipGetLastError());
+            {
+                // every rank holds ALL rows (and walks them on the host): bounded, and the ranks find out together.  (2^27 k-mers on
+                // cycles are ~5 GB of rows per rank; an input like that is not what the cycle rule was made for.)
+                u64 tot = nunvis;
+                KC_TRY(kcc_allreduce_sum(c, &tot, 1));
+                if (tot > ((u64)1 << 27)) return kc_fail(ctx, KC_E_CAPACITY, "too many k-mers on cycles for the replicated cycle rule (on some rank)");
+            }
             KC_TRY(allgather_rows(c, rows, nunvis, RW, &all, &n_all, nullptr));
             scope.release(visited); scope.release(ulist); scope.release(rows);
             if (n_all == 0) { kc_release(ctx, all); return kc_fail(ctx, KC_E_NO_DEVICE, "fragment ranking stalled without a cycle"); }

@@ -1367,7 +1367,9 @@ static inline u64 kc_cycles_decide(const std::vector<u64> &rows, u64 n, const st
 template <int W, bool DN = false>
 __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
                                                                 u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log,
-                                                                u64 *ent_out = nullptr, u64 ent_cap = 0, u64 *ent_cursor = nullptr) {
+                                                                u64 *ent_out = nullptr, u64 ent_cap = 0, u64 *ent_cursor = nullptr, int no_next = 0) {
+    // no_next: no shortcut skips the far end of its run (the segment-parallel hop walks stop AT certain run ends, so every end must
+    // be landed on).
     // ent_out (hash-sharded flow): the block's ENTRIES are listed on the way -- oriented nodes (slot << 1 | o) whose entry port o is
     // dead or matched to a slot of another rank, i.e. the starts of this rank's chain fragments (the link words are in registers
     // here anyway; a sweep of their own over 16 bytes per slot cost 15 ms per 10^9 k-mers).  One reservation per block.
@@ -1496,9 +1498,9 @@ __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, 
         // runs of up to 8 nodes whose far end is matched onwards also carry that onward link (the walk then skips the far end's
         // line altogether): bit 3 set, bits 6-41 next node, bit 42 its port, bits 43-44 the base of that step, bits 45-47 bases
         // inside the run, bits 48-61 those bases
-        const u64 wfar = (len - 1 <= KC_SC_NEXT_MAX) ? link[(base + far) * 2 + (fo == 0 ? 1u : 0u)] : 0;
+        const u64 wfar = (!no_next && len - 1 <= KC_SC_NEXT_MAX) ? link[(base + far) * 2 + (fo == 0 ? 1u : 0u)] : 0;
         const bool far_here = DN ? LK_SLOT(wfar) - (set.rlo >> set.bshift) * (u64)set.nstride < (set.rcap >> set.bshift) * (u64)set.nstride : LK_SLOT(wfar) - set.rlo < set.rcap;
-        if (len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && far_here) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
+        if (!no_next && len - 1 <= KC_SC_NEXT_MAX && LK_IS_MATCHED(wfar) && far_here) {   // (a link that leaves the rank ends a fragment there: its far node must stay visible)
             link[(base + s) * 2 + xp] = LK_REJ | KC_SC_NEXT | (LK_SLOT(wfar) << 6) | (LK_PORT(wfar) << 42) | (LK_BASE(wfar) << 43) | ((u64)(len - 1) << 45) |
                                         ((bases >> 24) << 48);
         } else if (len - 1 <= KC_SC_INLINE_MAX) {

@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(256) kc_chain_reduce_kernel(SetView<W> set, co
     u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j0 >= nstarts) return;
     const u64 id = starts[j0];
-    if (LK_IS_MATCHED(link[id])) return;             // entry port matched: a splitter start, not a head
+    if (LK_IS_MATCHED(link[id]) || KC_SC_IS(link[id])) return;   // entry port matched (or the inward port of a contracted run): a splitter start, not a head
     u64 total = 0, j = j0, tail = 0;
     while (true) {
         total += seg_len[j];
@@ -570,6 +570,156 @@ __global__ void __launch_bounds__(256) kc_segment_emit_kernel(SetView<W> set, co
         kx = key_append(kx, b, k);
         put(b);
         cur = nxt; co = no; w = wn;
+    }
+    if (acc) atomicOr((ull *)&words[wi], (ull)acc);
+}
+
+// ---- the segment-parallel path over CONTRACTED links (kc_frag_contract_kernel with no_next): the walks hop from run to run, two
+// scattered lines per in-block run (~9 k-mers) instead of one per k-mer.  A hop walk only ever lands on the ends of contracted runs
+// and on the nodes of uncontracted stretches, so the splitters are chosen among the former: a node whose id is a multiple of 64
+// and one of whose words is a shortcut (~1 in 290 k-mers).  Both the lister and a walk that lands on a node see that in the node's
+// two words.  Marks (MODE 1 / 2) are the sparse ones of kc_segment_walk_kernel: they are read after the links have been restored.
+#define KC_FSPLIT_MASK 63ull
+__device__ __forceinline__ bool kc_hop_splitter(u64 nid, const ulonglong2 &ww) { return (nid & KC_FSPLIT_MASK) == 0 && (KC_SC_IS(ww.x) || KC_SC_IS(ww.y)); }
+__device__ __forceinline__ ulonglong2 kc_link_pair(const u64 *__restrict__ link, u64 nid) { return *reinterpret_cast<const ulonglong2 *>(link + (nid << 1)); }
+// the far end of the run a shortcut word stands for: node, orientation there, bases (= nodes - 1)
+__device__ __forceinline__ void kc_hop_decode(u64 w, u64 cur, u64 &far, int &fo, u64 &nb) {
+    nb = (w & KC_SC_EXT) ? ((w >> 21) & 0x3fffull) : ((w >> 21) & 31ull);
+    far = cur + (u64)(long long)((int)(((u32)(w >> 6) & 0x3fffu) ^ 0x2000u) - 0x2000);
+    fo = (int)((w >> 20) & 1);
+}
+__global__ void __launch_bounds__(256) kc_split_starts_hop_kernel(const u64 *__restrict__ link, u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride,
+                                                                  int complements, u64 *starts, u64 *cursor) {
+    const u64 nid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) << 6;
+    if (nid >= n_nodes || !kc_nid_in_use(nid, ncount, nstride)) return;
+    const ulonglong2 ww = kc_link_pair(link, nid);
+    if (!kc_hop_splitter(nid, ww)) return;
+    const int no = complements ? 2 : 1;
+    for (int o = 0; o < no; ++o) {
+        const u64 e = o ? ww.y : ww.x;                        // entry port of orientation o is port o
+        if (!KC_SC_IS(e) && !LK_IS_MATCHED(e)) continue;       // dead entry port: a head (already listed)
+        const u64 pos = atomicAdd((ull *)cursor, 1ULL);
+        starts[pos] = (nid << 1) | (u64)o;
+    }
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) kc_segment_hop_kernel(const u64 *__restrict__ link, const u64 *__restrict__ starts, u64 nstarts,
+                                                             u64 *seg_len, u64 *seg_next, u64 *seg_tail, u8 *visited,
+                                                             const u64 *__restrict__ seg_chain, u64 max_len, u32 nstride) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nstarts) return;
+    if (MODE == 2 && seg_chain[j] != KC_SEG_NONE) return;
+    u64 cur = starts[j] >> 1;
+    int co = (int)(starts[j] & 1);
+    ulonglong2 ww = kc_link_pair(link, cur);
+    u64 len = 1, lo = 0;
+    bool entered = false;   // `cur` was reached by a link from another block (or is a chain's head)
+    if (MODE != 0) {
+        lo = cur / nstride * nstride;
+        const u64 win = co == 0 ? ww.x : ww.y;
+        entered = !KC_SC_IS(win) && (!LK_IS_MATCHED(win) || LK_SLOT(win) - lo >= (u64)nstride);
+    }
+    u64 next = KC_SEG_NONE, tailv = KC_SEG_NONE;
+    while (true) {
+        const u64 wl = co == 0 ? ww.y : ww.x;   // the word of the port the walk leaves through
+        if (KC_SC_IS(wl)) {
+            if (MODE != 0 && entered) visited[cur] = MODE == 1 ? 1 : 0;
+            u64 far, nb; int fo;
+            kc_hop_decode(wl, cur, far, fo, nb);
+            const ulonglong2 wf = kc_link_pair(link, far);
+            if (kc_hop_splitter(far, wf)) { len += nb - 1; next = (far << 1) | (u64)fo; break; }
+            len += nb; cur = far; co = fo; ww = wf; entered = false;
+            if (len > max_len) { tailv = 0; break; }   // (cannot happen on consistent links; never spin)
+            continue;
+        }
+        const bool tail = !LK_IS_MATCHED(wl);
+        if (MODE != 0 && (entered || tail)) visited[cur] = MODE == 1 ? 1 : 0;
+        if (tail) { tailv = (LK_SLOT(wl) << 1) | (u64)co; break; }   // (the tail by SLOT, from its dead port's word)
+        const u64 nxt = LK_SLOT(wl);
+        const int no = LK_PORT(wl) == 0 ? 0 : 1;
+        const ulonglong2 wn = kc_link_pair(link, nxt);
+        if (kc_hop_splitter(nxt, wn)) { next = (nxt << 1) | (u64)no; break; }
+        if (MODE != 0) { entered = nxt - lo >= (u64)nstride; if (entered) lo = nxt / nstride * nstride; }
+        cur = nxt; co = no; ww = wn;
+        if (++len > max_len) { tailv = 0; break; }
+    }
+    if (MODE != 2) {
+        seg_len[j] = len;
+        seg_next[j] = next == KC_SEG_NONE ? KC_SEG_NONE : kc_find_start(starts, nstarts, next);
+        seg_tail[j] = tailv;
+    }
+}
+// one thread per segment of an emitted chain, over contracted links: the bases of a run leave as groups
+template <int W>
+__global__ void __launch_bounds__(256) kc_segment_hop_emit_kernel(SetView<W> set, const u64 *__restrict__ link, int k, const u64 *__restrict__ fpool,
+                                                                  const u64 *__restrict__ starts, u64 nstarts, const u64 *__restrict__ seg_chain,
+                                                                  const u64 *__restrict__ seg_off, const u64 *__restrict__ rank,
+                                                                  const u64 *__restrict__ woff, u64 *words, u64 *firstK, u64 *lastK) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nstarts) return;
+    const u64 ch = seg_chain[j];
+    if (ch >= KC_SEG_LOSER) return;
+    const u64 r = rank[ch], wb = woff[r], off = seg_off[j];
+    u64 cur = starts[j] >> 1;
+    int co = (int)(starts[j] & 1);
+    ulonglong2 ww = kc_link_pair(link, cur);
+    u64 pos, acc = 0, wi;   // pos = next base position in the chain's string; acc = bits gathered for word wi
+    // n (1..32) bases, right-aligned in `bits`, first base in the highest pair
+    auto put_group = [&](u64 bits, int n) {
+        const int room = 32 - (int)(pos & 31);
+        pos += (u64)n;
+        if (n < room) { acc |= bits << (2 * (room - n)); return; }
+        const int rest = n - room;
+        acc |= rest ? (bits >> (2 * rest)) : bits;
+        atomicOr((ull *)&words[wi], (ull)acc);
+        ++wi;
+        acc = rest ? bits << (64 - 2 * rest) : 0;
+    };
+    {
+        // the start's k-mer: a head's slot is in the word of its (dead) entry port, a splitter's is searched for
+        const u64 w_in = co == 0 ? ww.x : ww.y;
+        Key<W> kx = set_key_at(set, LK_STATE(w_in) == LK_DEAD ? LK_SLOT(w_in) : set_slot_of_nid(set, cur));
+        if (co) kx = key_rc(kx, k);
+        if (off == 0) {               // chain head: the whole first k-mer
+            for (int i = 0; i < W; ++i) firstK[r * W + i] = kx.w[i];
+            pos = 0; wi = wb;
+            for (int i = 0; i < k; ++i) put_group((u64)key_at(kx, k, i), 1);
+        } else {                      // later segment: its first node contributes the last base of its oriented k-mer
+            pos = (u64)(k - 1) + off; wi = wb + (pos >> 5);
+            put_group(kx.w[0] & 3, 1);
+        }
+    }
+    while (true) {
+        const u64 wl = co == 0 ? ww.y : ww.x;
+        if (KC_SC_IS(wl)) {
+            u64 far, nb; int fo;
+            kc_hop_decode(wl, cur, far, fo, nb);
+            const ulonglong2 wf = kc_link_pair(link, far);
+            const bool stop = kc_hop_splitter(far, wf);   // (the step onto a splitter belongs to the splitter's segment)
+            const u64 total = nb - (stop ? 1 : 0);
+            if (wl & KC_SC_EXT) {
+                const u64 *src = fpool + (wl >> 35);
+                for (u64 i = 0; i < total; i += 32) {
+                    const int m = total - i >= 32 ? 32 : (int)(total - i);
+                    put_group(src[i >> 5] >> (64 - 2 * m), m);
+                }
+            } else if (total) put_group((wl >> (64 - 2 * nb)) >> (2 * (nb - total)), (int)total);
+            if (stop) break;
+            cur = far; co = fo; ww = wf;
+            continue;
+        }
+        if (!LK_IS_MATCHED(wl)) {     // tail of the chain: its k-mer by the slot in the dead word
+            Key<W> kt = set_key_at(set, LK_SLOT(wl));
+            if (co) kt = key_rc(kt, k);
+            for (int i = 0; i < W; ++i) lastK[r * W + i] = kt.w[i];
+            break;
+        }
+        const u64 nxt = LK_SLOT(wl);
+        const int no = LK_PORT(wl) == 0 ? 0 : 1;
+        const ulonglong2 wn = kc_link_pair(link, nxt);
+        if (kc_hop_splitter(nxt, wn)) break;
+        put_group(LK_BASE(wl), 1);
+        cur = nxt; co = no; ww = wn;
     }
     if (acc) atomicOr((ull *)&words[wi], (ull)acc);
 }
@@ -794,10 +944,37 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     u64 *pool = nullptr, *chain_stream = nullptr, *chain_tail = nullptr;
     bool seg_ok = false, use_stream = false, known_long = false;
     u8 *seg_marks = nullptr;   // nodes walked by the first long-chain pass (kc_segment_walk_kernel<1>)
+    u64 nstarts = 0, nchains = 0;
     // (marks of the segment walks: where a walk enters a block only -- kc_frag_unvisited_kernel turns them into the unvisited k-mers;
     // blocks beyond what that kernel keeps in LDS, or KC_SEG_DENSE_MARKS: every node is marked)
     const u32 sparse_stride = (set->bshift <= 13 && !getenv("KC_SEG_DENSE_MARKS")) ? nstride : 0u;
-    u64 nstarts = 0, nchains = 0;
+    // Long chains over CONTRACTED links (kc_segment_hop_kernel): the in-block runs are contracted first, the segment walks and the emit
+    // hop from run to run.  KC_SEG_PLAIN=1: the plain segment walks (one scattered line per k-mer).
+    const bool hop_ok = set->mlen && sparse_stride && !getenv("KC_NOFRAG") && !getenv("KC_SEG_PLAIN");
+    bool hop = false;   // the links are contracted right now
+    u64 *hpool = nullptr, *hbase = nullptr, *hcur = nullptr, *hlog = nullptr, *hblog = nullptr;
+    auto hop_restore = [&]() {   // the logged words go back (before anything reads or changes plain links: the unvisited list, the cycle rule)
+        if (!hop) return;
+        hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)hlog, (const u64 *)hblog, set->bshift, (u64)0, nstride);
+        scope.release(hpool); scope.release(hbase); scope.release(hcur); scope.release(hlog); scope.release(hblog);
+        hpool = hbase = hcur = hlog = hblog = nullptr;
+        hop = false;
+    };
+    // one thread per segment start: mode 0 measure, 1 measure + mark, 2 the segments of no chain take their marks back
+    auto seg_walk = [&](int mode, u8 *marks) {
+        const dim3 g(kc_grid(nstarts, 256)), b(256);
+        const u64 *sc = mode == 2 ? (const u64 *)seg_chain : (const u64 *)nullptr;
+        const u32 st = mode == 0 ? 0u : sparse_stride;
+        if (hop) {
+            if (mode == 0) hipLaunchKernelGGL(kc_segment_hop_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride);
+            else if (mode == 1) hipLaunchKernelGGL(kc_segment_hop_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride);
+            else hipLaunchKernelGGL(kc_segment_hop_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride);
+        } else {
+            if (mode == 0) hipLaunchKernelGGL(kc_segment_walk_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
+            else if (mode == 1) hipLaunchKernelGGL(kc_segment_walk_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
+            else hipLaunchKernelGGL(kc_segment_walk_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
+        }
+    };
     for (int pass = 0;; ++pass) {
         const u64 max_chains = nheads + 1;
         KC_TRY(scope.alloc(&chain_head, max_chains));
@@ -883,18 +1060,38 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // ---- some chain is long: segment-parallel path
         seg_ok = false;
         if (too_long) {
-            const u64 max_starts = nheads + 2 * nsplit_max + 1;
+            if (hop_ok) {
+                // contract the in-block runs (every run end stays a landing place: no_next), as kc_frag_contract_kernel is used for reads
+                u64 pool_cap = (cap / 16 + 65536) / 64 * 64;
+                if (pool_cap > ((u64)1 << 29)) pool_cap = (u64)1 << 29;
+                const u64 log_cap = (cap / 6 + 65536) / 64 * 64;
+                KC_TRY(scope.alloc(&hpool, pool_cap)); KC_TRY(scope.alloc(&hbase, set->nblocks)); KC_TRY(scope.alloc(&hcur, 2 * 64 * 16));
+                KC_TRY(scope.alloc(&hlog, log_cap)); KC_TRY(scope.alloc(&hblog, set->nblocks));
+                KC_HIP(ctx, hipMemsetAsync(hcur, 0, 2 * 64 * 16 * 8, ctx->stream));
+                const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
+                KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, hpool, pool_cap, hcur, hbase,
+                                   hlog, log_cap, hcur + 64 * 16, hblog, (u64 *)nullptr, (u64)0, (u64 *)nullptr, 1);
+                hop = true;
+            }
+            const u64 nsplit_hop = (NID + 63) >> 6;
+            const u64 max_starts = nheads + 2 * (hop ? nsplit_hop : nsplit_max) + 1;
             u64 *starts_raw = nullptr;
             KC_TRY(scope.alloc(&starts_raw, max_starts));
             KC_TRY(scope.alloc(&starts, max_starts));
             KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
             KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                               NID, ncount, nstride, compl_, starts_raw, cnt + 6);
+            if (hop)
+                hipLaunchKernelGGL(kc_split_starts_hop_kernel, kc_grid2(nsplit_hop, 256), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   NID, ncount, nstride, compl_, starts_raw, cnt + 6);
+            else
+                hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                                   NID, ncount, nstride, compl_, starts_raw, cnt + 6);
             KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
             KC_TRY(kcu_sort_pairs(ctx, starts_raw, starts, nullptr, nullptr, nstarts, 0, 64));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             scope.release(starts_raw);
+            if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] pass %d: long chains, %llu segment starts (%s links)\n", pass, (unsigned long long)nstarts, hop ? "contracted" : "plain");
             KC_TRY(scope.alloc(&seg_len, nstarts + 1)); KC_TRY(scope.alloc(&seg_next, nstarts + 1)); KC_TRY(scope.alloc(&seg_tail, nstarts + 1));
             KC_TRY(scope.alloc(&seg_chain, nstarts + 1)); KC_TRY(scope.alloc(&seg_off, nstarts + 1));
             KC_HIP(ctx, hipMemsetAsync(seg_chain, 0xff, (nstarts + 1) * 8, ctx->stream));
@@ -907,12 +1104,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 KC_HIP(ctx, hipMemsetAsync(seg_marks, 0, NID, ctx->stream));
             }
             if (nstarts) {
-                if (seg_marks)
-                    hipLaunchKernelGGL(kc_segment_walk_kernel<1>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, seg_marks, (const u64 *)nullptr, NID, sparse_stride);
-                else
-                    hipLaunchKernelGGL(kc_segment_walk_kernel<0>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                       (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, (u8 *)nullptr, (const u64 *)nullptr, NID, 0u);
+                seg_walk(seg_marks ? 1 : 0, seg_marks);
                 hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                                    (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
                                    seg_off, chain_head, chain_len, chain_key, cnt);
@@ -932,9 +1124,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             visited = seg_marks;
             seg_marks = nullptr;
             marked = true;
-            if (nstarts)
-                hipLaunchKernelGGL(kc_segment_walk_kernel<2>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID, sparse_stride);
+            if (nstarts) seg_walk(2, visited);
         } else {
             KC_TRY(scope.alloc(&visited, NID));
             KC_HIP(ctx, hipMemsetAsync(visited, 0, NID, ctx->stream));
@@ -943,15 +1133,14 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         if (too_long && marked) {
         } else if (too_long) {
             if (nstarts) {   // (a marking walk of its own, then the segments of no chain take their marks back)
-                hipLaunchKernelGGL(kc_segment_walk_kernel<1>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)nullptr, NID, sparse_stride);
-                hipLaunchKernelGGL(kc_segment_walk_kernel<2>, dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
-                                   (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, visited, (const u64 *)seg_chain, NID, sparse_stride);
+                seg_walk(1, visited);
+                seg_walk(2, visited);
             }
         } else if (nheads) {
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
+        hop_restore();   // (the marks are by node: what follows reads and changes plain links)
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         const bool sparse_marks = too_long && sparse_stride;
         const size_t lds_unv = (size_t)14 << set->bshift;
@@ -1047,9 +1236,14 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&rank, S + 1));
         KC_HIP(ctx, hipMemsetAsync(s->words, 0, (s->nwords + 1) * 8, ctx->stream));
         hipLaunchKernelGGL(kc_inverse_perm_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)perm, S, rank);
-        hipLaunchKernelGGL((kc_segment_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
-                           (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
-                           s->words, s->firstK, s->lastK);
+        if (hop)
+            hipLaunchKernelGGL((kc_segment_hop_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)hpool,
+                               (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
+                               s->words, s->firstK, s->lastK);
+        else
+            hipLaunchKernelGGL((kc_segment_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
+                               (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
+                               s->words, s->firstK, s->lastK);
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(rank);
     } else if (use_stream) {

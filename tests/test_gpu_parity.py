@@ -117,10 +117,17 @@ def test_simplitigs_match_canonical_oracle(ctx, oracle, k, complements):
         sim.close(); s.close()
 
 
-@pytest.mark.parametrize("k", [4, 13, 31, 40, 127])
-def test_segment_parallel_walks_forced(ctx, oracle, k, monkeypatch):
-    # KC_CHAIN_LIMIT=2 makes every chain of more than 2 k-mers "long": the splitter/segment path handles all of them
+@pytest.mark.parametrize("k,links", [(4, "default"), (13, "default"), (31, "default"), (40, "default"), (127, "default"),
+                                     (31, "plain"), (127, "plain"), (31, "plain-dense-marks"), (63, "default")])
+def test_segment_parallel_walks_forced(ctx, oracle, k, links, monkeypatch):
+    # KC_CHAIN_LIMIT=2 makes every chain of more than 2 k-mers "long": the splitter/segment path handles all of them.  On minimizer
+    # tables (k >= 18) the segments hop over contracted runs by default; KC_SEG_PLAIN keeps the plain links (one step per k-mer),
+    # KC_SEG_DENSE_MARKS the per-node marks of the plain walks.
     monkeypatch.setenv("KC_CHAIN_LIMIT", "2")
+    if links != "default":
+        monkeypatch.setenv("KC_SEG_PLAIN", "1")
+    if links == "plain-dense-marks":
+        monkeypatch.setenv("KC_SEG_DENSE_MARKS", "1")
     rng = random.Random(31 + k)
     cases = ["\n".join(r.decode() for r in gen.stress_reads(6000, 150, 200 if k < 100 else 400, seed=100 + k)),
              _rand_seq(rng, 30000), _rand_seq(rng, 3000, "AC"), _rand_seq(rng, 1500) * 3]
@@ -231,7 +238,7 @@ def test_fragment_contraction_path(ctx, k, monkeypatch):
             want.close()
             monkeypatch.delenv("KC_NOFRAG")
             assert (cycles > 0) == (name == "reads+cycles")
-            for env in ({}, {"KC_CHAIN_LIMIT": "1200"}, {"KC_BSHIFT": "10"}):
+            for env in ({}, {"KC_CHAIN_LIMIT": "1200"}, {"KC_CHAIN_LIMIT": "1200", "KC_SEG_PLAIN": "1"}, {"KC_CHAIN_LIMIT": "40", "KC_BSHIFT": "10"}, {"KC_BSHIFT": "10"}):
                 for var, value in env.items():
                     monkeypatch.setenv(var, value)
                 got = kc.compute(ctx, seq, k, complements)

@@ -46,8 +46,10 @@ def main():
             k = rng.choice([2, 3, 5, 8, 11, 13, 15, 16, 17, 23, 31, 32, 33, 47, 63, 64, 65, 100, 127, rng.randint(2, 127)])
             compl = rng.random() < 0.7
             os.environ["KC_BUCKET_MIN"] = rng.choice(["0", "0", "1048576"])
-            if rng.random() < 0.15: os.environ["KC_CHAIN_LIMIT"] = str(rng.choice([2, 64, 700]))
+            if rng.random() < 0.25: os.environ["KC_CHAIN_LIMIT"] = str(rng.choice([2, 64, 700]))
             else: os.environ.pop("KC_CHAIN_LIMIT", None)
+            if rng.random() < 0.3: os.environ["KC_SEG_PLAIN"] = "1"      # long chains: plain segment walks instead of hops over contracted runs
+            else: os.environ.pop("KC_SEG_PLAIN", None)
             # small blocks / short local probe runs: block-local spills, second homes, bucket overflows
             if rng.random() < 0.2: os.environ["KC_BSHIFT"] = str(rng.choice([9, 10, 11]))
             else: os.environ.pop("KC_BSHIFT", None)
@@ -74,7 +76,7 @@ def main():
                 import shutil
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 shutil.copy(fa, os.path.join(ROOT, "gpurun_out", "fuzz_last.fa"))
-                print("case %d: %s k=%d compl=%s shape=%s env=%s" % (n, entry, k, compl, shape, {v: os.environ.get(v) for v in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_BSHIFT", "KC_LOCAL_PROBES")}), flush=True)
+                print("case %d: %s k=%d compl=%s shape=%s env=%s" % (n, entry, k, compl, shape, {v: os.environ.get(v) for v in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_SEG_PLAIN", "KC_BSHIFT", "KC_LOCAL_PROBES")}), flush=True)
             try:
                 if entry == "S": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, assume_simplitigs=True)
                 elif entry == "z": r = kc.compute_file(ctx, fa, k, compl, want_mask=True, min_frequency=zf)
@@ -85,7 +87,7 @@ def main():
                     os.makedirs(os.path.dirname(keep), exist_ok=True)
                     os.replace(fa, keep)
                     print("GPU failed (%s) where the oracle succeeded: %s k=%d compl=%s shape=%s seed=%d case=%d env=%s -> %s" % (
-                        e, entry, k, compl, shape, seed, n, {v: os.environ.get(v) for v in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_BSHIFT", "KC_LOCAL_PROBES")}, keep))
+                        e, entry, k, compl, shape, seed, n, {v: os.environ.get(v) for v in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_SEG_PLAIN", "KC_BSHIFT", "KC_LOCAL_PROBES")}, keep))
                     sys.exit(1)
                 n += 1
                 continue
@@ -100,7 +102,7 @@ def main():
                 keep = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d.fa" % (seed, n))
                 os.makedirs(os.path.dirname(keep), exist_ok=True)
                 os.replace(fa, keep)
-                print("MISMATCH case %d (%s): k=%d compl=%s shape=%s env=%s -> %s" % (n, entry, k, compl, shape, {e: os.environ.get(e) for e in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_BSHIFT", "KC_LOCAL_PROBES")}, keep))
+                print("MISMATCH case %d (%s): k=%d compl=%s shape=%s env=%s -> %s" % (n, entry, k, compl, shape, {e: os.environ.get(e) for e in ("KC_BUCKET_MIN", "KC_CHAIN_LIMIT", "KC_SEG_PLAIN", "KC_BSHIFT", "KC_LOCAL_PROBES")}, keep))
                 sys.exit(1)
             shapes[shape] = shapes.get(shape, 0) + 1
             n += 1
