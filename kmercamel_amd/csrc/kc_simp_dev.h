@@ -1553,7 +1553,7 @@ static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, 
 // nodes of cycles that never leave the block (they have no end at all).  FILL = false counts, FILL = true lists (node ids).
 template <int W, bool FILL>
 __global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, const u8 *__restrict__ visited,
-                                                                 u64 *out, u64 *cursor) {
+                                                                 u64 *out, u64 out_cap, u64 *cursor) {
     // LDS: the digest (one 32-bit word per port, see kc_frag_contract_kernel; bit 29 of a node's port-0 word: on a run that was
     // walked here, bit 28: marked), the ends (2 * bs u16), the unvisited nodes of the block (bs u16)
     extern __shared__ u32 kc_fl[];
@@ -1634,7 +1634,8 @@ __global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set,
     if (threadIdx.x == 0) g_base = atomicAdd((ull *)cursor, (ull)no);
     __syncthreads();
     if (FILL)
-        for (u32 i = threadIdx.x; i < no; i += blockDim.x) out[g_base + i] = base + (u64)lst[i];
+        for (u32 i = threadIdx.x; i < no; i += blockDim.x)
+            if (g_base + i < out_cap) out[g_base + i] = base + (u64)lst[i];   // (the cursor counts on: the caller sees an overflow)
 }
 
 // measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a

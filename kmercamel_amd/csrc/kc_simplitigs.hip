@@ -590,22 +590,27 @@ __device__ __forceinline__ void kc_hop_decode(u64 w, u64 cur, u64 &far, int &fo,
 }
 __global__ void __launch_bounds__(256) kc_split_starts_hop_kernel(const u64 *__restrict__ link, u64 n_nodes, const u32 *__restrict__ ncount, u32 nstride,
                                                                   int complements, u64 *starts, u64 *cursor) {
-    const u64 nid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) << 6;
-    if (nid >= n_nodes || !kc_nid_in_use(nid, ncount, nstride)) return;
-    const ulonglong2 ww = kc_link_pair(link, nid);
-    if (!kc_hop_splitter(nid, ww)) return;
-    const int no = complements ? 2 : 1;
-    for (int o = 0; o < no; ++o) {
-        const u64 e = o ? ww.y : ww.x;                        // entry port of orientation o is port o
-        if (!KC_SC_IS(e) && !LK_IS_MATCHED(e)) continue;       // dead entry port: a head (already listed)
-        const u64 pos = atomicAdd((ull *)cursor, 1ULL);
-        starts[pos] = (nid << 1) | (u64)o;
+    // (one reservation per workgroup: 1.8 10^7 adds on one word took 19 ms)
+    const u64 nid = kc_gtid() << 6;
+    u32 m = 0;   // bit o: the oriented node (nid, o) is a start
+    if (nid < n_nodes && kc_nid_in_use(nid, ncount, nstride)) {
+        const ulonglong2 ww = kc_link_pair(link, nid);
+        if (kc_hop_splitter(nid, ww)) {
+            const int no = complements ? 2 : 1;
+            for (int o = 0; o < no; ++o) {
+                const u64 e = o ? ww.y : ww.x;                           // entry port of orientation o is port o
+                if (KC_SC_IS(e) || LK_IS_MATCHED(e)) m |= 1u << o;      // (a dead entry port: a head, already listed)
+            }
+        }
     }
+    u64 pos = kc_block_reserve((u32)__popc(m), cursor);
+    if (m & 1u) starts[pos++] = nid << 1;
+    if (m & 2u) starts[pos] = (nid << 1) | 1ull;
 }
 template <int MODE>
 __global__ void __launch_bounds__(256) kc_segment_hop_kernel(const u64 *__restrict__ link, const u64 *__restrict__ starts, u64 nstarts,
                                                              u64 *seg_len, u64 *seg_next, u64 *seg_tail, u8 *visited,
-                                                             const u64 *__restrict__ seg_chain, u64 max_len, u32 nstride) {
+                                                             const u64 *__restrict__ seg_chain, u64 max_len, u32 nstride, int both_ends) {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nstarts) return;
     if (MODE == 2 && seg_chain[j] != KC_SEG_NONE) return;
@@ -623,9 +628,11 @@ __global__ void __launch_bounds__(256) kc_segment_hop_kernel(const u64 *__restri
     while (true) {
         const u64 wl = co == 0 ? ww.y : ww.x;   // the word of the port the walk leaves through
         if (KC_SC_IS(wl)) {
-            if (MODE != 0 && entered) visited[cur] = MODE == 1 ? 1 : 0;
             u64 far, nb; int fo;
             kc_hop_decode(wl, cur, far, fo, nb);
+            // (bidirectional sets: a run is entered at both ends, by the walks of the two directions; kc_frag_unvisited_kernel looks at
+            // the mark of its SMALLER end only -- half the scattered stores)
+            if (MODE != 0 && entered && (!both_ends || far > cur)) visited[cur] = MODE == 1 ? 1 : 0;
             const ulonglong2 wf = kc_link_pair(link, far);
             if (kc_hop_splitter(far, wf)) { len += nb - 1; next = (far << 1) | (u64)fo; break; }
             len += nb; cur = far; co = fo; ww = wf; entered = false;
@@ -966,9 +973,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         const u64 *sc = mode == 2 ? (const u64 *)seg_chain : (const u64 *)nullptr;
         const u32 st = mode == 0 ? 0u : sparse_stride;
         if (hop) {
-            if (mode == 0) hipLaunchKernelGGL(kc_segment_hop_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride);
-            else if (mode == 1) hipLaunchKernelGGL(kc_segment_hop_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride);
-            else hipLaunchKernelGGL(kc_segment_hop_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride);
+            if (mode == 0) hipLaunchKernelGGL(kc_segment_hop_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
+            else if (mode == 1) hipLaunchKernelGGL(kc_segment_hop_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
+            else hipLaunchKernelGGL(kc_segment_hop_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
         } else {
             if (mode == 0) hipLaunchKernelGGL(kc_segment_walk_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
             else if (mode == 1) hipLaunchKernelGGL(kc_segment_walk_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
@@ -1144,27 +1151,33 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         const bool sparse_marks = too_long && sparse_stride;
         const size_t lds_unv = (size_t)14 << set->bshift;
+        u64 nunvis = 0;
+        u64 *ulist = nullptr, *heads2 = nullptr;
         if (sparse_marks) {
-            KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_unvisited_kernel<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_unv));
+            // one pass into a list sized for the usual case (k-mers on cycles are few); the cursor counts on past its end
+            u64 ucap = N / 64 + ((u64)1 << 20);
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_unvisited_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_unv));
-            hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, false>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, (const u64 *)link, compl_,
-                               (const u8 *)visited, (u64 *)nullptr, cnt + 1);
-        } else
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                KC_TRY(scope.alloc(&ulist, ucap));
+                KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
+                hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, (const u64 *)link, compl_,
+                                   (const u8 *)visited, ulist, ucap, cnt + 1);
+                KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
+                if (nunvis <= ucap) break;
+                scope.release(ulist); ulist = nullptr;
+                ucap = nunvis;
+            }
+        } else {
             hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited,
                                (u64 *)nullptr, cnt + 1);
-        u64 nunvis = 0;
-        KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
-        if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] pass %d: %llu k-mers on cycles (%s marks)\n", pass, (unsigned long long)nunvis, sparse_marks ? "sparse" : "dense");
-        if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
-        u64 *ulist = nullptr, *heads2 = nullptr;
-        KC_TRY(scope.alloc(&ulist, nunvis));
-        KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-        if (sparse_marks)
-            hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, (const u64 *)link, compl_,
-                               (const u8 *)visited, ulist, cnt + 1);
-        else
+            KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
+            KC_TRY(scope.alloc(&ulist, nunvis + 1));
+            KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
             hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited, ulist,
                                cnt + 1);
+        }
+        if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] pass %d: %llu k-mers on cycles (%s marks)\n", pass, (unsigned long long)nunvis, sparse_marks ? "sparse" : "dense");
+        if (nunvis == 0) return kc_fail(ctx, KC_E_NO_DEVICE, "chain discovery misses k-mers that are not on cycles");
         {
             // rows of the k-mers on cycles and the candidate edges of their ports to dead ports -> host, which walks the cycles and
             // decides where each is opened (kc_cycles_decide) -> kc_cycle_fix_kernel, new head list
