@@ -1117,6 +1117,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     int win_hi = -1, win_lo = 0;
     u64 wcount[32] = {0};
     bool win_on = t16_on && !split && !getenv("KC_OV_NO_WINDOW");
+    bool t16_sampled = false;
     std::vector<u64> h_bl;
     if (!lower_bound) {   // tag 0xffffffff = written by nobody
         KC_HIP(ctx, hipMemsetAsync(first, 0xff, V * 8, ctx->stream));
@@ -1151,6 +1152,22 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             KC_TRY(read_back(ctx, hp, cnt, 4));
             return KC_OK;
         };
+        if (t16_on && !t16_dead && d >= 16 && !t16_sampled && !split && lenS >= ((u64)1 << 20) && !getenv("KC_T16_FORCE")) {
+            // Many vertices: are these overlapping reads?  The hits of a sample of the suffix ends at this level and the next ones
+            // tell -- with a hit for every 64th vertex the per-level tables are the faster path (below), and finding that out by
+            // running the first level through the 16-mer table cost 14 ms on 3.9 10^7 vertices.
+            t16_sampled = true;
+            const u64 ns = (u64)1 << 18;
+            const int B = d - 15 < 4 ? d - 15 : 4;
+            KC_HIP(ctx, hipMemsetAsync(whist, 0, 32 * 8, ctx->stream));
+            hipLaunchKernelGGL((ov_count16_kernel<W>), dim3(kc_grid(ns, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, ns, (const u64 *)suf,
+                               (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, B, whist, PG, pme);
+            KC_TRY(read_back(ctx, hp + 64, whist, B));
+            u64 sh = 0;
+            for (int j = 0; j < B; ++j) sh += hp[64 + j];
+            if (sh * 64 > ns * (u64)B) t16_dead = true;
+            if (trace) fprintf(stderr, "[ov] sample of %llu suffix ends, levels %d..%d: %llu hits -> 16-mer table %s\n", (unsigned long long)ns, d, d - B + 1, (unsigned long long)sh, t16_dead ? "not used" : "used");
+        }
         if (t16_on && !t16_dead && d >= 16) {
             // Small active sets: count the hits of a window of levels in one sweep first (ov_count16_kernel); a level that counts
             // zero is skipped without a launch or a read-back.  The window shrinks to nothing once most levels have hits.

@@ -1367,7 +1367,10 @@ static inline u64 kc_cycles_decide(const std::vector<u64> &rows, u64 n, const st
 template <int W, bool DN = false>
 __global__ void __launch_bounds__(1024) kc_frag_contract_kernel(SetView<W> set, u64 *link, int complements, u64 *pool, u64 pool_cap, u64 *pool_cursors,
                                                                 u64 *blk_pool_base, u64 *log, u64 log_cap, u64 *log_cursors, u64 *blk_log,
-                                                                u64 *ent_out = nullptr, u64 ent_cap = 0, u64 *ent_cursor = nullptr, int no_next = 0) {
+                                                                u64 *ent_out = nullptr, u64 ent_cap = 0, u64 *ent_cursor = nullptr, int no_next = 0, int only_unlogged = 0) {
+    // only_unlogged: a second round over the blocks whose log is empty -- the ones kc_frag_unvisited_kernel put back to plain links for the
+    // cycle rule (and those that never had anything to contract); the others keep their shortcuts.
+    if (only_unlogged && blk_log[blockIdx.x] != 0) return;
     // no_next: no shortcut skips the far end of its run (the segment-parallel hop walks stop AT certain run ends, so every end must
     // be landed on).
     // ent_out (hash-sharded flow): the block's ENTRIES are listed on the way -- oriented nodes (slot << 1 | o) whose entry port o is
@@ -1551,9 +1554,12 @@ static __global__ void __launch_bounds__(256) kc_frag_restore_kernel(u64 *link, 
 // list of unvisited k-mers: one workgroup per block rebuilds the block's runs in LDS exactly as kc_frag_contract_kernel does (same
 // digest, same ends), and a run whose entry end carries no mark -- no walk came in there -- is on a cycle, all of it; so are the
 // nodes of cycles that never leave the block (they have no end at all).  FILL = false counts, FILL = true lists (node ids).
+// log != nullptr: the links are CONTRACTED (kc_frag_contract_kernel); the block's logged words go back into the digest first, and a
+// block that lists anything puts them back into the link array as well (FILL) and gives up its log -- the cycle rule reads and
+// rewrites plain words there, the other blocks keep their shortcuts for the next pass.
 template <int W, bool FILL>
-__global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set, const u64 *__restrict__ link, int complements, const u8 *__restrict__ visited,
-                                                                 u64 *out, u64 out_cap, u64 *cursor) {
+__global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set, u64 *link, int complements, const u8 *__restrict__ visited,
+                                                                 u64 *out, u64 out_cap, u64 *cursor, const u64 *__restrict__ log = nullptr, u64 *blk_log = nullptr) {
     // LDS: the digest (one 32-bit word per port, see kc_frag_contract_kernel; bit 29 of a node's port-0 word: on a run that was
     // walked here, bit 28: marked), the ends (2 * bs u16), the unvisited nodes of the block (bs u16)
     extern __shared__ u32 kc_fl[];
@@ -1575,6 +1581,17 @@ __global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set,
             const u64 w = w2[p];
             const bool in = LK_IS_MATCHED(w) && LK_SLOT(w) - base < (u64)nn;
             kc_fl[2 * s + p] = 0x40000000u | (p == 0 ? vis : 0u) | (in ? (0x80000000u | (u32)(LK_SLOT(w) - base) | ((u32)LK_PORT(w) << 14)) : 0u);
+        }
+    }
+    u32 nlog = 0; u64 lb = 0;
+    if (log) {
+        const u64 e = blk_log[blockIdx.x];
+        nlog = (u32)(e & 0xffffu); lb = e >> 16;
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nlog; i += blockDim.x) {   // (a logged word is an in-block link by construction)
+            const u64 w = log[lb + i];
+            const u32 lp = (u32)((w >> 46) & 0x3fffu);
+            kc_fl[lp] = (kc_fl[lp] & (0x40000000u | (1u << 28))) | 0x80000000u | (u32)(LK_SLOT(w) - base) | ((u32)LK_PORT(w) << 14);
         }
     }
     __syncthreads();
@@ -1633,9 +1650,17 @@ __global__ void __launch_bounds__(1024) kc_frag_unvisited_kernel(SetView<W> set,
     if (no == 0) return;
     if (threadIdx.x == 0) g_base = atomicAdd((ull *)cursor, (ull)no);
     __syncthreads();
-    if (FILL)
+    if (FILL) {
         for (u32 i = threadIdx.x; i < no; i += blockDim.x)
             if (g_base + i < out_cap) out[g_base + i] = base + (u64)lst[i];   // (the cursor counts on: the caller sees an overflow)
+        if (log && nlog) {
+            for (u32 i = threadIdx.x; i < nlog; i += blockDim.x) {
+                const u64 w = log[lb + i];
+                link[(base << 1) + ((w >> 46) & 0x3fffu)] = w & ~(0x3fffull << 46);
+            }
+            if (threadIdx.x == 0) blk_log[blockIdx.x] = 0;
+        }
+    }
 }
 
 // measure pass: one thread per directed chain head. Marks visited nodes, decides which of the two directions of a

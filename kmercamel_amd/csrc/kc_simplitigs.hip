@@ -960,13 +960,6 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     const bool hop_ok = set->mlen && sparse_stride && !getenv("KC_NOFRAG") && !getenv("KC_SEG_PLAIN");
     bool hop = false;   // the links are contracted right now
     u64 *hpool = nullptr, *hbase = nullptr, *hcur = nullptr, *hlog = nullptr, *hblog = nullptr;
-    auto hop_restore = [&]() {   // the logged words go back (before anything reads or changes plain links: the unvisited list, the cycle rule)
-        if (!hop) return;
-        hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)hlog, (const u64 *)hblog, set->bshift, (u64)0, nstride);
-        scope.release(hpool); scope.release(hbase); scope.release(hcur); scope.release(hlog); scope.release(hblog);
-        hpool = hbase = hcur = hlog = hblog = nullptr;
-        hop = false;
-    };
     // one thread per segment start: mode 0 measure, 1 measure + mark, 2 the segments of no chain take their marks back
     auto seg_walk = [&](int mode, u8 *marks) {
         const dim3 g(kc_grid(nstarts, 256)), b(256);
@@ -1068,17 +1061,21 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         seg_ok = false;
         if (too_long) {
             if (hop_ok) {
-                // contract the in-block runs (every run end stays a landing place: no_next), as kc_frag_contract_kernel is used for reads
-                u64 pool_cap = (cap / 16 + 65536) / 64 * 64;
-                if (pool_cap > ((u64)1 << 29)) pool_cap = (u64)1 << 29;
+                // contract the in-block runs (every run end stays a landing place: no_next), as kc_frag_contract_kernel is used for reads.
+                // A second pass finds the contraction of the first: kc_frag_unvisited_kernel put only the blocks with cycles back to
+                // plain links, and only those are contracted again (a cycle that the rule opened is a long stretch of some chain now:
+                // left plain, without splitters, one thread would walk all of it).
+                const u64 pool_cap = std::min<u64>((cap / 16 + 65536) / 64 * 64, (u64)1 << 29);
                 const u64 log_cap = (cap / 6 + 65536) / 64 * 64;
-                KC_TRY(scope.alloc(&hpool, pool_cap)); KC_TRY(scope.alloc(&hbase, set->nblocks)); KC_TRY(scope.alloc(&hcur, 2 * 64 * 16));
-                KC_TRY(scope.alloc(&hlog, log_cap)); KC_TRY(scope.alloc(&hblog, set->nblocks));
-                KC_HIP(ctx, hipMemsetAsync(hcur, 0, 2 * 64 * 16 * 8, ctx->stream));
+                if (!hop) {
+                    KC_TRY(scope.alloc(&hpool, pool_cap)); KC_TRY(scope.alloc(&hbase, set->nblocks)); KC_TRY(scope.alloc(&hcur, 2 * 64 * 16));
+                    KC_TRY(scope.alloc(&hlog, log_cap)); KC_TRY(scope.alloc(&hblog, set->nblocks));
+                    KC_HIP(ctx, hipMemsetAsync(hcur, 0, 2 * 64 * 16 * 8, ctx->stream));
+                }
                 const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
                 KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, hpool, pool_cap, hcur, hbase,
-                                   hlog, log_cap, hcur + 64 * 16, hblog, (u64 *)nullptr, (u64)0, (u64 *)nullptr, 1);
+                                   hlog, log_cap, hcur + 64 * 16, hblog, (u64 *)nullptr, (u64)0, (u64 *)nullptr, 1, hop ? 1 : 0);
                 hop = true;
             }
             const u64 nsplit_hop = (NID + 63) >> 6;
@@ -1095,7 +1092,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
                                    NID, ncount, nstride, compl_, starts_raw, cnt + 6);
             KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
-            KC_TRY(kcu_sort_pairs(ctx, starts_raw, starts, nullptr, nullptr, nstarts, 0, 64));
+            int start_bits = 2;   // (a start is node id << 1 | orientation)
+            while (start_bits < 64 && (NID >> (start_bits - 1)) != 0) ++start_bits;
+            KC_TRY(kcu_sort_pairs(ctx, starts_raw, starts, nullptr, nullptr, nstarts, 0, start_bits));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             scope.release(starts_raw);
             if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] pass %d: long chains, %llu segment starts (%s links)\n", pass, (unsigned long long)nstarts, hop ? "contracted" : "plain");
@@ -1147,7 +1146,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
-        hop_restore();   // (the marks are by node: what follows reads and changes plain links)
+        // (hop: the links stay contracted; kc_frag_unvisited_kernel works from the log and restores the blocks that hold cycles)
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
         const bool sparse_marks = too_long && sparse_stride;
         const size_t lds_unv = (size_t)14 << set->bshift;
@@ -1160,8 +1159,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             for (int attempt = 0; attempt < 2; ++attempt) {
                 KC_TRY(scope.alloc(&ulist, ucap));
                 KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-                hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, (const u64 *)link, compl_,
-                                   (const u8 *)visited, ulist, ucap, cnt + 1);
+                hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, link, compl_,
+                                   (const u8 *)visited, ulist, ucap, cnt + 1, hop ? (const u64 *)hlog : (const u64 *)nullptr, hop ? hblog : (u64 *)nullptr);
                 KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
                 if (nunvis <= ucap) break;
                 scope.release(ulist); ulist = nullptr;

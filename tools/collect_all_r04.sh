@@ -22,5 +22,11 @@ cp gpurun_out/shard_one/*/*_kernel_stats.csv gpurun_out/profiles_r04/r04_shard_o
 cd $R
 timeout 600 python3 tools/shapes.py genome --check --passes 2 > gpurun_out/profiles_r04/r04_shape_genome_2p5G.json 2> gpurun_out/profiles_r04/r04_shape_genome.err
 timeout 600 python3 tools/shapes.py coverage --check --passes 2 > gpurun_out/profiles_r04/r04_shape_coverage_1G.json 2> gpurun_out/profiles_r04/r04_shape_coverage.err
+timeout 600 bash tools/shape_stats.sh genome 1.0 > gpurun_out/profiles_r04/r04_shape_genome_kernel_stats.txt 2>&1
+timeout 600 bash tools/shape_stats.sh coverage 1.0 > gpurun_out/profiles_r04/r04_shape_coverage_kernel_stats.txt 2>&1
+rm -rf gpurun_out/shape_stats
+cd $R
+timeout 300 python3 tools/time_coverage_reads.py > gpurun_out/profiles_r04/r04_coverage_10x.log 2>&1
+KC_OV_TRACE=1 timeout 300 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-cli 2>&1 | grep "^\[ov\]" | tail -40 > gpurun_out/profiles_r04/r04_cfg2_overlap_levels.txt
 timeout 900 python3 bench.py > gpurun_out/profiles_r04/r04_default_bench.log 2>&1
 tail -1 gpurun_out/profiles_r04/r04_default_bench.log | cut -c1-600
