@@ -93,15 +93,19 @@ __global__ void __launch_bounds__(256) em_rank_finish_kernel(const EmRank *__res
     endv[v] = r.endv;
 }
 
-// one wavefront per vertex on the start path
+// G lanes per vertex on the start path: a wavefront (64) for simplitigs of hundreds of characters and more, 8 lanes for short ones
+// (reads with errors: 2 10^7 simplitigs of ~48 characters -- a wavefront each left 62 lanes idle behind six dependent loads)
+template <int G>
 __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ words, const u64 *__restrict__ woff,
                                                       const u64 *__restrict__ lens, u64 S, u64 V, int k, const u64 *__restrict__ dist,
                                                       const u64 *__restrict__ endv, const u64 *__restrict__ weight, u64 start, char *out,
                                                       u64 out_lo, int nranks, int me) {
     // nranks > 1 (hash-sharded flow): this rank emits the vertices whose block starts in its share of the output, into a
     // buffer that begins at output offset out_lo
-    u64 v = (((u64)blockIdx.z * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) >> 6;   // (x, z): vertices; y: slices of long vertices
-    int lane = threadIdx.x & 63;
+    constexpr int LG = G == 64 ? 6 : 3;
+    static_assert(G == 64 || G == 8, "lanes per vertex");
+    u64 v = (((u64)blockIdx.z * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) >> LG;   // (x, z): vertices; y: slices of long vertices
+    int lane = threadIdx.x & (G - 1);
     if (v >= V) return;
     if (endv[v] != endv[start]) return;
     u64 off = dist[start] - dist[v];
@@ -114,7 +118,7 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
     // every lane spells 32 consecutive characters per step -- one packed word forwards; backwards the 32 bases that end at L-1-t0,
     // complemented and reversed as a word -- in four 8-byte stores; blockIdx.y splits long vertices (assembled genomes give
     // simplitigs of Mbp) into interleaved 2048-character slices
-    for (u64 t0 = ((u64)blockIdx.y * 64 + lane) * 32; t0 < n; t0 += (u64)gridDim.y * 2048) {
+    for (u64 t0 = ((u64)blockIdx.y * G + lane) * 32; t0 < n; t0 += (u64)gridDim.y * (G * 32)) {
         const int cnt = (n - t0 >= 32) ? 32 : (int)(n - t0);
         u64 w;   // the 32 bases in the order they are written, first one in the highest pair
         if (!rc) w = words[wb + (t0 >> 5)];
@@ -241,10 +245,17 @@ int kce_emit_ranked(kc_simplitigs *s, const KcRank *r, u64 out_lo, int nranks, i
     unsigned slices = 1;   // waves per vertex: ~8192 characters each on average, at most 256
     if (V && L / V > 16384) { u64 y = L / V / 8192; slices = (unsigned)(y > 256 ? 256 : y); }
     // one wavefront per vertex: from 2^26 vertices on the block count no longer fits one grid dimension's 2^32 work-items
-    const u64 gv = (V * 64 + 255) / 256 ? (V * 64 + 255) / 256 : 1;
+    bool short_ones = V && L / V < 256;   // (L / V: half the mean block, the mirror vertices are not on the path)
+    if (const char *e = getenv("KC_EMIT_LANES")) short_ones = atoi(e) == 8;   // (test knob: 8 or 64)
+    const u64 lanes = short_ones ? 8 : 64;
+    const u64 gv = (V * lanes + 255) / 256 ? (V * lanes + 255) / 256 : 1;
     const unsigned gx = gv > ((u64)1 << 22) ? (1u << 22) : (unsigned)gv, gz = (unsigned)((gv + gx - 1) / gx);
-    hipLaunchKernelGGL(em_emit_kernel, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
-                       (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
+    if (short_ones)
+        hipLaunchKernelGGL(em_emit_kernel<8>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+                           (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
+    else
+        hipLaunchKernelGGL(em_emit_kernel<64>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+                           (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
 }

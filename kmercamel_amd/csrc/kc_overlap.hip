@@ -31,7 +31,7 @@
 
 template <int W> struct LevelTable {
     u64 *slot;     // W==1: the d-mer key; W>1: a representative prefix vertex (its key is re-derived from pre[])
-    u32 *flags;    // INVERTED (so that one 0xff fill clears slots and flags): bit0 clear = has an active prefix, bit1 clear = suffix
+    u32 *flags;    // INVERTED (so that one 0xff fill clears slots and flags): bit1 clear = an active suffix vertex has this key
     u64 mask;      // capacity - 1 (power of two)
 };
 
@@ -107,9 +107,7 @@ __global__ void __launch_bounds__(256) ov_insert_prefix_kernel(LevelTable<W> t, 
     if (pred[j] != KC_NONE64) { pslot[i] = KC_NONE64; return; }
     Key<W> key = key_prefix(load_key<W>(pre, j), k, d);
     if (!ov_key_is_ours(key, G, me)) { pslot[i] = KC_NONE64; return; }
-    u64 s = level_insert(t, key, j, pre, k, d);
-    atomicAnd(&t.flags[s], ~1u);
-    pslot[i] = s;
+    pslot[i] = level_insert(t, key, j, pre, k, d);   // (an occupied slot HAS an active prefix: only the suffix side needs a flag)
 }
 
 // representative rule: a {key, RC(key)} pair is handled by the smaller of the two keys

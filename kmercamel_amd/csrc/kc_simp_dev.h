@@ -35,6 +35,12 @@
 // target had at least two candidates; such "branch" ports (rare) are listed by the choose kernel and send explicit
 // rejections (LK_REJ) to the candidates they did not choose.  A round-1 choice without LK_REJ is therefore mutual.
 // Later rounds write their tentative choices WITH LK_REJ and confirm them to LK_MATCHED in kc_accept_kernel.
+// Entries of the branch list and of the later rounds' work lists: the port id (dense node id << 1 | port) and, when the lister had it
+// in hand, the slot offset of the port's k-mer inside its block -- the kernels that need the KEY of a listed port then skip the
+// search for its slot (set_slot_of_nid: a dozen dependent reads).
+#define KC_WK_HAS_OFF (1ull << 63)
+#define KC_WK_PID(e) ((e) & (((u64)1 << 40) - 1))
+#define KC_WK_TAG(off) ((((u64)(off)) << 40) | KC_WK_HAS_OFF)
 #define LK_IS_MATCHED(w) (LK_STATE(w) == LK_MATCHED || (LK_STATE(w) == LK_CHOICE && !((w) & LK_REJ)))
 
 // "edge (x,px)-(y1,q1) is preferred over edge (x,px)-(y2,q2)": higher priority first, ties by the ordered endpoint tuple.
@@ -674,7 +680,7 @@ __device__ __forceinline__ void kc_choose_dense_one(const SetView<W> &set, u64 *
         }
         link[pid] = (nfound ? LK_MAKE(LK_CHOICE, bq, bbase, set_nid_of_slot(set, bslot)) : LK_MAKE(LK_DEAD, 0, 0, slot)) | splitbit;
         if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
-        if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);   // branch port: it has to reject the others
+        if (nfound >= 2) kc_push_sharded(pid | KC_WK_TAG(slot & (((u64)1 << set.bshift) - 1)), branch, branch_shard_cap, branch_cursors);   // branch port: it has to reject the others
     }
 }
 
@@ -727,7 +733,7 @@ __global__ void __launch_bounds__(256) kc_choose_dense_kernel(SetView<W> set, u6
 template <int W>
 __device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 nid, const u64 slot, const int port, const Key<W> &x,
                                                const Key<W> &xr, const u64 (&cs)[4], const u32 qb, u64 *heads, u64 heads_shard_cap, u64 *heads_cursors,
-                                               u64 *branch, u64 branch_shard_cap, u64 *branch_cursors, const u64 delta = 0) {
+                                               u64 *branch, u64 branch_shard_cap, u64 *branch_cursors, const u64 delta = 0, const u64 wk_tag = 0) {
     // (cs[] + delta = the candidates' dense ids: the block kernel passes slots and the one difference its window search found)
     // every 256th k-mer (by id) is a splitter: chains are walked segment-wise between splitters
     const u64 splitbit = ((nid & 0xffull) == 0) ? LK_SPLIT : 0;
@@ -755,7 +761,7 @@ __device__ __forceinline__ u64 kc_choose_port(int k, int complements, const u64 
         }
     }
     if (!nfound && (complements || port == 0)) kc_push_sharded(pid, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
-    if (nfound >= 2) kc_push_sharded(pid, branch, branch_shard_cap, branch_cursors);
+    if (nfound >= 2) kc_push_sharded(pid | wk_tag, branch, branch_shard_cap, branch_cursors);
     return (nfound ? LK_MAKE(LK_CHOICE, bq, port ? bc : 3 - bc, bslot + delta) : LK_MAKE(LK_DEAD, 0, 0, slot)) | splitbit;
 }
 
@@ -966,7 +972,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     const u64 delta = kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk);
                     const u64 nid = nb0 + local_rank(so);
                     link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch,
-                                                                     branch_shard_cap, branch_cursors, delta);
+                                                                     branch_shard_cap, branch_cursors, delta, KC_WK_TAG(so));
                 }
             }
         }
@@ -1092,7 +1098,8 @@ __global__ void __launch_bounds__(256) kc_probe_spill_kernel(SetView<W> set, u64
         for (int c = 0; c < 4; ++c)
             if (cs[c] != KC_NONE64) cs[c] = set_nid_of_slot(set, cs[c]);
         const u64 nid = set_nid_of_slot(set, slot);
-        link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+        link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors, 0,
+                                                         KC_WK_TAG(slot & (((u64)1 << set.bshift) - 1)));
     }
 }
 
@@ -1158,7 +1165,8 @@ __global__ void __launch_bounds__(256) kc_probe_generic_kernel(SetView<W> set, u
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (cs[c] != KC_NONE64) cs[c] = set_nid_of_slot(set, cs[c]);
-        link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors);
+        link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch, branch_shard_cap, branch_cursors, 0,
+                                                         KC_WK_TAG(slot & (((u64)1 << set.bshift) - 1)));
     }
 }
 

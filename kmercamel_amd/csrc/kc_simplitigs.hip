@@ -18,6 +18,12 @@
 #include "kc_simp_dev.h"
 
 // node ids leave gaps behind every block (kc_set_dev.h): the first ncount[b] of block b's nstride ids are in use
+// the slot of a listed port's k-mer (see KC_WK_TAG)
+template <int W> __device__ __forceinline__ u64 kc_wk_slot(const SetView<W> &set, u64 e) {
+    const u64 nid = KC_WK_PID(e) >> 1;
+    if (!(e & KC_WK_HAS_OFF)) return set_slot_of_nid(set, nid);
+    return ((nid / set.nstride) << set.bshift) | ((e >> 40) & (((u64)1 << set.bshift) - 1));
+}
 __device__ __forceinline__ bool kc_nid_in_use(u64 nid, const u32 *__restrict__ ncount, u32 nstride) {
     const u64 blk = nid / nstride;
     return (u32)(nid - blk * nstride) < ncount[blk];
@@ -27,36 +33,48 @@ __device__ __forceinline__ bool kc_nid_in_use(u64 nid, const u32 *__restrict__ n
 template <int W>
 __global__ void __launch_bounds__(256) kc_reject_kernel(SetView<W> set, u64 *link, int k, int complements, const u64 *__restrict__ branch,
                                                         u64 nbranch, u64 *work_out, u64 work_cap, u64 *cursor) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nbranch) return;
-    const u64 pid = branch[t];   // (ports are numbered by dense node id: kc_set_dev.h)
-    const u64 slot = set_slot_of_nid(set, pid >> 1);
-    const int port = (int)(pid & 1);
-    const Key<W> x = set_key_at(set, slot);
-    const u64 chosen = LK_PID(link[pid]);
-    for (u32 c = 0; c < 4; ++c) {
-        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
-        Key<W> y = nf;
-        int q;
-        if (complements) {
-            Key<W> r = key_rc(nf, k);
-            bool pal = key_eq(nf, r);
-            bool fwd = !key_lt(r, nf);
-            if (!fwd) y = r;
-            q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
-        } else q = port ? 0 : 1;
-        if (key_eq(y, x)) continue;
-        u64 tslot = set_find(set, y);
-        if (tslot == KC_NONE64) continue;
-        u64 cpid = (set_nid_of_slot(set, tslot) << 1) | (u64)q;
-        if (cpid == chosen) continue;
-        u64 wc = link[cpid];   // round-1 words are stable here apart from their LK_REJ bit
-        if (LK_STATE(wc) == LK_CHOICE && LK_PID(wc) == pid) {   // it chose this port, this port chose another: void, round 2
-            atomicOr((ull *)&link[cpid], (ull)LK_REJ);           // (only its target can reject a port, so this happens once)
-            u64 pos = atomicAdd((ull *)cursor, 1ULL);
-            if (pos < work_cap) work_out[pos] = cpid;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 rej[4];   // the ports this one rejects (entries for the work list of round 2)
+    u32 nrej = 0;
+    if (t < nbranch) {
+        const u64 pid = KC_WK_PID(branch[t]);   // (ports are numbered by dense node id: kc_set_dev.h)
+        const u64 slot = kc_wk_slot<W>(set, branch[t]);
+        const int port = (int)(pid & 1);
+        const Key<W> x = set_key_at(set, slot);
+        const Key<W> xr = key_rc(x, k);
+        const u64 chosen = LK_PID(link[pid]);
+        // the candidates of a port share their home (the middle): ONE window search finds all of them, as in round 1
+        u64 cs[4]; u32 qb;
+        bool ok = false;
+        if (set.m) {
+            const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+            const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+            const KcPortDesc d = kc_port_desc<W, 0>(set, x, xr, k, complements, port, kc_mid_min<W, 0>(mid, midr, k, set.m));
+            ok = kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb);
+        }
+        if (!ok) kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
+#pragma unroll
+        for (u32 c = 0; c < 4; ++c) {
+            const u64 tslot = cs[c];
+            if (tslot == KC_NONE64) continue;
+            const u64 cpid = (set_nid_of_slot(set, tslot) << 1) | (u64)((qb >> c) & 1u);
+            if (cpid == chosen) continue;
+            const u64 wc = link[cpid];   // round-1 words are stable here apart from their LK_REJ bit
+            if (LK_STATE(wc) == LK_CHOICE && LK_PID(wc) == pid) {   // it chose this port, this port chose another: void, round 2
+                atomicOr((ull *)&link[cpid], (ull)LK_REJ);           // (only its target can reject a port, so this happens once)
+                const u64 e = cpid | KC_WK_TAG(tslot & (((u64)1 << set.bshift) - 1));
+                if (nrej == 0) rej[0] = e; else if (nrej == 1) rej[1] = e; else if (nrej == 2) rej[2] = e; else rej[3] = e;
+                ++nrej;
+            }
         }
     }
+    // one reservation per workgroup (reads with errors list 2 10^7 ports here: one add per port -- per wave and loop trip after the
+    // compiler's aggregation -- on one word took most of this kernel's 30 ms)
+    u64 pos = kc_block_reserve(nrej, cursor);
+    if (nrej > 0) { if (pos < work_cap) work_out[pos] = rej[0]; ++pos; }
+    if (nrej > 1) { if (pos < work_cap) work_out[pos] = rej[1]; ++pos; }
+    if (nrej > 2) { if (pos < work_cap) work_out[pos] = rej[2]; ++pos; }
+    if (nrej > 3) { if (pos < work_cap) work_out[pos] = rej[3]; }
 }
 
 // One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
@@ -71,8 +89,8 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
     (void)xcd_aware;
     if (t >= nwork) return;
     static_assert(!FIRST, "round 1 is kc_probe_block_kernel / kc_choose_dense_kernel");
-    u64 pid = work[t];   // (dense node id << 1 | port)
-    u64 slot = set_slot_of_nid(set, pid >> 1);
+    u64 pid = KC_WK_PID(work[t]);   // (dense node id << 1 | port)
+    u64 slot = kc_wk_slot<W>(set, work[t]);
     int port = (int)(pid & 1);
     Key<W> x = set_key_at(set, slot);
     Key<W> xr = key_rc(x, k);
@@ -84,24 +102,23 @@ __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__r
     const u64 hxk = key_hash(x);
     int nfound = 0;
     Key<W> by = x; int bq = 0; u64 bpr = 0, bslot = 0; u32 bbase = 0;
-#pragma unroll
+    // (one window search for the four candidates of the port: they share their home)
+    u64 cs[4]; u32 qb;
+    bool ok = false;
+    if (set.m) {
+        const Key<W> lm = key_lowmask<W>(2 * (k - 2));
+        const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
+        const KcPortDesc d = kc_port_desc<W, 0>(set, x, xr, k, complements, port, kc_mid_min<W, 0>(mid, midr, k, set.m));
+        ok = kc_port_search<W, false, false>(set, k, complements, x, xr, slot, port, d, nullptr, nullptr, cs, qb);
+    }
+    if (!ok) kc_port_search_generic<W>(set, k, complements, x, xr, port, cs, qb);
     for (u32 c = 0; c < 4; ++c) {
-        Key<W> nf = port ? key_append(x, (u64)c, k) : key_prepend(x, (u64)c, k);
-        Key<W> y = nf;
-        int q;
-        if (complements) {
-            Key<W> r = port ? key_prepend(xr, (u64)(3 - c), k) : key_append(xr, (u64)(3 - c), k);   // RC(nf)
-            bool pal = key_eq(nf, r);
-            bool fwd = !key_lt(r, nf);  // canonical is nf itself
-            if (!fwd) y = r;
-            // append: entering y on L if y==nf else R; prepend: entering y on R if y==nf else L; palindromes: L
-            q = pal ? 0 : (port ? (fwd ? 0 : 1) : (fwd ? 1 : 0));
-        } else {
-            q = port ? 0 : 1;
-        }
-        if (key_eq(y, x)) continue;
-        u64 tslot = set_find(set, y);
+        u64 tslot = KC_NONE64;
+#pragma unroll
+        for (u32 cc = 0; cc < 4; ++cc) tslot = (c == cc) ? cs[cc] : tslot;
         if (tslot == KC_NONE64) continue;
+        int q;
+        const Key<W> y = kc_neighbour_key_q(x, xr, port, c, k, complements, q);
         tslot = set_nid_of_slot(set, tslot);   // from here on: the candidate's dense id
         {
             u64 wt = link[(tslot << 1) | (u64)q];
@@ -145,10 +162,11 @@ __global__ void __launch_bounds__(256) kc_mutual_scan_kernel(u64 *link, u64 n_no
 __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__restrict__ work, u64 nwork, u64 *work_out,
                                                         u64 work_cap, u64 *cursor) {
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 pid = 0;
+    u64 pid = 0, e = 0;
     bool again = false;   // still unresolved: goes on the next round's list
     if (t < nwork) {
-        pid = work[t];
+        e = work[t];
+        pid = KC_WK_PID(e);
         u64 w = link[pid];
         if (LK_STATE(w) == LK_CHOICE && (w & LK_REJ)) {
             u64 wt = __hip_atomic_load(&link[LK_PID(w)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -158,7 +176,7 @@ __global__ void __launch_bounds__(256) kc_accept_kernel(u64 *link, const u64 *__
         }
     }
     const u64 pos = kc_block_reserve(again ? 1u : 0u, cursor);
-    if (again && pos < work_cap) work_out[pos] = pid;
+    if (again && pos < work_cap) work_out[pos] = e;   // (with its slot offset, if it came with one)
 }
 
 // heads of directed chains: oriented node (id, o) whose entry port (L for o=0, R for o=1) is not matched.

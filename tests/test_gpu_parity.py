@@ -238,7 +238,8 @@ def test_fragment_contraction_path(ctx, k, monkeypatch):
             want.close()
             monkeypatch.delenv("KC_NOFRAG")
             assert (cycles > 0) == (name == "reads+cycles")
-            for env in ({}, {"KC_CHAIN_LIMIT": "1200"}, {"KC_CHAIN_LIMIT": "1200", "KC_SEG_PLAIN": "1"}, {"KC_CHAIN_LIMIT": "40", "KC_BSHIFT": "10"}, {"KC_BSHIFT": "10"}):
+            for env in ({}, {"KC_CHAIN_LIMIT": "1200"}, {"KC_CHAIN_LIMIT": "1200", "KC_SEG_PLAIN": "1"}, {"KC_CHAIN_LIMIT": "40", "KC_BSHIFT": "10"}, {"KC_BSHIFT": "10"},
+                        {"KC_EMIT_LANES": "64"}, {"KC_EMIT_LANES": "8"}):   # (phase 3: a wavefront / 8 lanes per vertex)
                 for var, value in env.items():
                     monkeypatch.setenv(var, value)
                 got = kc.compute(ctx, seq, k, complements)
@@ -460,7 +461,9 @@ def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
                 # phase 2: the host-driven loop for every level / the grouped levels for every table level / no wavefront replays in
                 # them (every larger bucket sends its level back to the host-driven loop) / eager compaction, no level windows
                 {"KC_OV_HOST_LOOP": "1"}, {"KC_OVG_MAX": "1000000000000"}, {"KC_OVG_MAX": "1000000000000", "KC_OVG_NO_LDS": "1"},
-                {"KC_OV_EAGER_SHRINK": "1", "KC_OV_NO_WINDOW": "1"}):
+                {"KC_OV_EAGER_SHRINK": "1", "KC_OV_NO_WINDOW": "1"},
+                # phase 3: 8 lanes per vertex (the form for short simplitigs) on these 1 030-character ones
+                {"KC_EMIT_LANES": "8"}):
         for name, value in env.items():
             monkeypatch.setenv(name, value)
         r2 = kc.compute(ctx, seq, k, True)
