@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out/step
+timeout 2400 python3 -m pytest tests -m gpu -x -q > gpurun_out/step/full.log 2>&1
+echo "full rc=$?" >> gpurun_out/step/full.log; tail -6 gpurun_out/step/full.log
