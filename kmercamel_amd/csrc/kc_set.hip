@@ -567,6 +567,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     // single-word keys of a plain bucket: the first four keys of every thread are on their way while the LDS table is set up
     // (the block is otherwise one global latency after the other: counts, keys, then the stores)
     const bool pf = W == 1 && nseg == 0 && !(fresh & 2);   // (bit 1 of `fresh`: test knob, no prefetch)
+    const bool st16 = !(fresh & 4);                          // (bit 2: test knob, 8-byte stores in the write-out)
     fresh &= 1;
     u64 pre0 = 0, pre1 = 0, pre2 = 0, pre3 = 0;
     if (pf) {
@@ -655,6 +656,22 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) at += __shfl_xor(at, d, 64);
         }
+        if (W == 1 && st16 && per_wave % 128 == 0) {
+            // two neighbouring slots per lane: 16-byte LDS loads and 16-byte stores (1 KB per wave instruction)
+            for (u32 r = 0; r < per_wave / 128; ++r) {
+                const u32 sl = wv * per_wave + r * 128 + 2 * lane;
+                const u32 tg = *reinterpret_cast<const volatile unsigned short *>(lt + sl);
+                const bool occ0 = (tg & 0xffu) != 0, occ1 = (tg >> 8) != 0;
+                const unsigned long long mk0 = __ballot(occ0), mk1 = __ballot(occ1);
+                const u64 cnt0 = (u64)(at + (u32)__popcll(mk0 & ltm) + (u32)__popcll(mk1 & ltm)), cnt1 = cnt0 + (occ0 ? 1 : 0);
+                ulonglong2 v;
+                v.x = lk[sl]; v.y = lk[sl + 1];
+                if (!occ0) v.x = KC_ANN_MARK | cnt0;
+                if (!occ1) v.y = KC_ANN_MARK | cnt1;
+                *reinterpret_cast<ulonglong2 *>(set.keys + base + sl) = v;
+                at += (u32)__popcll(mk0) + (u32)__popcll(mk1);
+            }
+        } else
         for (u32 r = 0; r < rows; ++r) {
             const u32 off = r * 64 + lane, sl = wv * per_wave + off;
             const bool in = off < per_wave, occ = in && lt[sl] != 0;
@@ -1161,11 +1178,11 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
     if (getenv("KC_NO_BUILD_IDS"))   // (test knob: the sweep of kcs_prepare_dense instead)
         hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
     else {
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
         hipLaunchKernelGGL((kc_block_build_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
         hipLaunchKernelGGL(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
     }
     KC_HIP(ctx, hipGetLastError());
