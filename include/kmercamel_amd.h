@@ -156,7 +156,8 @@ int kc_thread_group_create(int world, kc_thread_group **out);
 void kc_thread_group_destroy(kc_thread_group *group);
 int kc_comm_create_threads(kc_ctx *ctx, kc_thread_group *group, int rank, kc_comm **out);
 void kc_comm_destroy(kc_comm *comm);
-/* stats[8]: 0 bytes sent, 1 bytes received, 2 collective calls, 3 microseconds spent inside them (host clock) */
+/* stats[8]: 0 bytes sent, 1 bytes received, 2 collective calls, 3 microseconds spent inside them (host clock), 4 exchanges in which this
+ * rank's own share went through ncclSend / ncclRecv (KC_RCCL_SELF_SENDRECV=1: the RCCL code path with one rank) */
 int kc_comm_stats(kc_comm *comm, uint64_t *stats);
 /* The partition itself, host side only (no GPU needed; the multi-rank CPU tests exercise it): geometry of the table for
  * `total_occurrences` k-mer occurrences over `world` ranks -- out6 = {table blocks, log2 slots per block, blocks per rank,
