@@ -81,6 +81,7 @@ struct kc_simplitigs {
     u64 *words = nullptr;  // nwords
     u64 *firstK = nullptr; // n*W: first k-mer
     u64 *lastK = nullptr;  // n*W: last k-mer
+    float occ_ratio = 0;   // occurrences per distinct k-mer of the set they were built from (kc_set::occ_ratio; 0: unknown) -- a hint for phase 2
 };
 
 struct kc_result {

@@ -1075,7 +1075,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     u32 *markP = nullptr;
     u64 t16_min = (u64)1 << 16;
     if (const char *e = getenv("KC_T16_MIN")) { const long long v = atoll(e); if (v >= 0) t16_min = (u64)v; }
-    const bool t16_on = k - 1 >= 16 && V >= t16_min && V < ((u64)1 << 32) - 1;
+    // (simplitigs of reads with coverage -- the set build saw every k-mer three times or more -- overlap at every level: the per-level
+    // tables are the faster path there, see the sampled check below; the table is not even built)
+    const bool reads_with_coverage = s->occ_ratio >= 3.0f && !getenv("KC_T16_FORCE");
+    const bool t16_on = k - 1 >= 16 && V >= t16_min && V < ((u64)1 << 32) - 1 && !reads_with_coverage;
     bool t16_dead = false;   // the table is not (or no longer) worth using
     if (t16_on) {
         u64 c16 = 64;

@@ -993,6 +993,9 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             else hipLaunchKernelGGL(kc_segment_walk_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
         }
     };
+    // (more k-mers per chain head than the limit: some chain is longer than it, whatever the per-chain pass would find -- the 4 ms it
+    // takes to give up on a genome are saved; k-mers on cycles only make this a cautious guess: the segment path serves short chains too)
+    if (nheads && N / nheads > KC_CHAIN_LIMIT) known_long = true;
     for (int pass = 0;; ++pass) {
         const u64 max_chains = nheads + 1;
         KC_TRY(scope.alloc(&chain_head, max_chains));
@@ -1243,7 +1246,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     // order chains by head key, size them, emit
     const u64 S = nchains;
     kc_simplitigs *s = new kc_simplitigs();
-    s->ctx = ctx; s->k = k; s->W = W; s->n = S;
+    s->ctx = ctx; s->k = k; s->W = W; s->n = S; s->occ_ratio = set->occ_ratio;
     bool built = false;
     auto cleanup = kc_defer([&] { if (!built) kc_simplitigs_destroy(s); });
     u64 *perm = nullptr, *nwords = nullptr;
