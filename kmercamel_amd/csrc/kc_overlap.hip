@@ -1080,6 +1080,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     const bool reads_with_coverage = s->occ_ratio >= 3.0f && !getenv("KC_T16_FORCE");
     const bool t16_on = k - 1 >= 16 && V >= t16_min && V < ((u64)1 << 32) - 1 && !reads_with_coverage;
     bool t16_dead = false;   // the table is not (or no longer) worth using
+    if (getenv("KC_OV_TRACE")) fprintf(stderr, "[ov] V=%llu, occurrences per distinct k-mer of the set %.3f -> 16-mer table %s\n", (unsigned long long)V, (double)s->occ_ratio, t16_on ? "on" : "off");
     if (t16_on) {
         u64 c16 = 64;
         while (c16 < 2 * V + 16) c16 <<= 1;
