@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) kc_reject_kernel(SetView<W> set, u64 *lin
 
 // One thread per port.  FIRST: port id = thread id over all 2*cap ports in XCD-aware order (round 1, nothing is matched
 // yet, so the neighbours' link words are not read); otherwise the port ids come from the work list of unresolved ports
-// (later rounds: few ports, generic lookups).
+// (later rounds: few ports, one window search each -- the four candidates of a port share their home).
 template <int W, bool FIRST, int KC>
 __global__ void __launch_bounds__(256) kc_choose_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements,
                                                         const u64 *__restrict__ work, u64 nwork, int xcd_aware, u64 *heads,
