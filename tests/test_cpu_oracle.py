@@ -272,3 +272,26 @@ def test_bucket_logic_simulation_matches_oracle(oracle):
                 assert rc == 0 and (ef, ov) == want, (k, n, c, lb)
                 repairs += rep
     assert repairs > 0   # the verify/repair loop was exercised
+
+
+def test_real_data_shape_generators_are_deterministic_and_shaped():
+    """tools/shapes.py feeds the full-scale runs and the GPU tests: same seed, same bytes; records of the stated length over ACGT;
+    the coverage reads carry both strands and substitution errors (the reads' k-mers are a superset of most of the genome's)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import numpy as np
+    import shapes
+    g1, cfg = shapes.make_input("genome", 0.0004)
+    g2, _ = shapes.make_input("genome", 0.0004)
+    assert np.array_equal(g1, g2) and cfg["records"] == 25 and cfg["record_bp"] == 40000
+    recs = bytes(g1).split(b"\n")
+    assert len(recs) == 25 and all(len(r) == 40000 and set(r) <= set(b"ACGT") for r in recs)
+    c1, ccfg = shapes.make_input("coverage", 0.001)
+    c2, _ = shapes.make_input("coverage", 0.001)
+    assert np.array_equal(c1, c2)
+    reads = bytes(c1).split(b"\n")
+    assert len(reads) == int(ccfg["genome_bp"] * ccfg["coverage"] / ccfg["read_bp"]) and all(len(r) == 150 for r in reads)
+    # tandem repeats are really there: some record holds a unit repeated back to back
+    recs2 = shapes.genome_records(2, 40000, 5, repeats_per_mbp=0.0, tandems_per_mbp=200.0)
+    s = bytes(shapes.ACGT[recs2[0]])
+    assert any(s[i:i + 60] == s[i + u:i + u + 60] for u in range(40, 400) for i in range(0, len(s) - 500, 997))
