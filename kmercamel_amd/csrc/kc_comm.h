@@ -53,6 +53,11 @@ struct kc_comm {
     // RCCL
     void *nccl_comm = nullptr;
     u64 *d_small = nullptr;   // device scratch for the host-word all-gather
+    // test knobs, read from the environment ONCE when the communicator is created (kcc_read_test_knobs), never on the data path:
+    // KC_RCCL_SELF_SENDRECV=1: with RCCL, a rank's own share goes through grouped ncclSend / ncclRecv to itself too (exercises that
+    // code on a box with one GPU); KC_TEST_FAIL_RANK=r: rank r fails on its own after the build (tests the release of its peers)
+    bool test_self_sendrecv = false;
+    int test_fail_rank = -1;
     // statistics
     u64 bytes_sent = 0, bytes_received = 0, calls = 0, self_sendrecv_calls = 0;
     double seconds = 0;

@@ -64,6 +64,11 @@ int ensure_stage(kc_comm *c, size_t send_bytes, size_t recv_bytes) {
     return KC_OK;
 }
 
+void read_test_knobs(kc_comm *c) {
+    c->test_self_sendrecv = getenv("KC_RCCL_SELF_SENDRECV") != nullptr;
+    if (const char *e = getenv("KC_TEST_FAIL_RANK")) c->test_fail_rank = atoi(e);
+}
+
 }  // namespace
 
 int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64 *send_cnt, void *d_recv, const u64 *recv_off, const u64 *recv_cnt) {
@@ -97,7 +102,7 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
         kc_thread_group *g = c->group;
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // what this rank sends is complete before anybody reads it
         g->post[c->rank] = kc_thread_group::Post{d_send, send_off, send_cnt, ctx->device, nullptr};
-        if (!g->barrier()) return kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
+        if (!g->barrier()) return kc_fail_agreed(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
         for (int p = 0; p < G && rc == KC_OK; ++p) {
             const kc_thread_group::Post &q = g->post[p];
             const u64 n = q.send_cnt[c->rank];
@@ -109,12 +114,12 @@ int kcc_alltoallv(kc_comm *c, const void *d_send, const u64 *send_off, const u64
             if (e != hipSuccess) rc = kc_fail(ctx, KC_E_TRANSPORT, std::string("thread transport copy: ") + hipGetErrorString(e));
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == KC_OK) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: copy failed");
-        if (!g->barrier() && rc == KC_OK) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");   // (else: the senders may reuse their buffers)
+        if (!g->barrier() && rc == KC_OK) rc = kc_fail_agreed(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");   // (else: the senders may reuse their buffers)
     } else {
         // the part a rank keeps for itself is a device-to-device copy; the rest goes out as one group of sends and receives.
-        // KC_RCCL_SELF_SENDRECV=1 (tests): the rank's own part goes through ncclSend / ncclRecv to itself as well, so that the
+        // kc_comm::test_self_sendrecv (KC_RCCL_SELF_SENDRECV=1 when the communicator was created; tests): the rank's own part goes through ncclSend / ncclRecv to itself as well, so that the
         // grouped send / receive code -- prototypes, datatype, zero counts, stream order -- runs on a box with a single GPU.
-        static const bool self_sr = getenv("KC_RCCL_SELF_SENDRECV") != nullptr;
+        const bool self_sr = c->test_self_sendrecv;
         if (send_cnt[c->rank] != recv_cnt[c->rank]) return kc_fail(ctx, KC_E_ARG, "all-to-all: a rank's send and receive counts for itself differ");
         if (send_cnt[c->rank] && !self_sr)
             KC_HIP(ctx, hipMemcpyAsync((u8 *)d_recv + recv_off[c->rank], (const u8 *)d_send + send_off[c->rank], send_cnt[c->rank], hipMemcpyDeviceToDevice, ctx->stream));
@@ -144,9 +149,9 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
     } else if (c->kind == 3) {
         kc_thread_group *g = c->group;
         g->post[c->rank].words = in;
-        if (!g->barrier()) return kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
+        if (!g->barrier()) return kc_fail_agreed(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
         for (int p = 0; p < c->world; ++p) memcpy(out + (size_t)p * words, g->post[p].words, (size_t)words * 8);
-        if (!g->barrier()) rc = kc_fail(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
+        if (!g->barrier()) rc = kc_fail_agreed(ctx, KC_E_TRANSPORT, "thread transport: another rank has failed and left the exchange");
     } else {
         // through a 64-word device window per rank; longer vectors go in pieces
         std::vector<u64> piece((size_t)64 * c->world);
@@ -167,9 +172,7 @@ int kcc_allgather_words(kc_comm *c, const u64 *in, u64 *out, int words) {
 
 void kcc_after_collective_call(kc_comm *c, int rc) {
     if (rc == KC_OK || !c || c->kind != 3 || !c->group) return;
-    const std::string &e = c->ctx->err;
-    for (const char *agreed : {"not part of the hash-sharded path", "no k-mers", "cannot be empty", "(on some rank)", "another rank has failed"})
-        if (e.find(agreed) != std::string::npos) return;
+    if (c->ctx->err_agreed) return;   // every rank is returning this error at this point (kc_fail_agreed): nobody is left waiting
     c->group->abort();
 }
 
@@ -190,6 +193,7 @@ extern "C" int kc_comm_create_self(kc_ctx *ctx, kc_comm **out) {
     if (!ctx || !out) return KC_E_ARG;
     kc_comm *c = new kc_comm();
     c->ctx = ctx; c->rank = 0; c->world = 1; c->kind = 0;
+    read_test_knobs(c);
     *out = c;
     return KC_OK;
 }
@@ -200,6 +204,7 @@ extern "C" int kc_comm_create_callbacks(kc_ctx *ctx, int rank, int world, kc_all
     if (world > 64) return kc_fail(ctx, KC_E_ARG, "at most 64 ranks");
     kc_comm *c = new kc_comm();
     c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 1;
+    read_test_knobs(c);
     c->a2a_host = alltoallv; c->ag_host = allgather; c->user = user;
     *out = c;
     return KC_OK;
@@ -217,6 +222,7 @@ extern "C" int kc_comm_create_threads(kc_ctx *ctx, kc_thread_group *group, int r
     if (!ctx || !group || !out || rank < 0 || rank >= group->world) return KC_E_ARG;
     kc_comm *c = new kc_comm();
     c->ctx = ctx; c->rank = rank; c->world = group->world; c->kind = 3; c->group = group;
+    read_test_knobs(c);
     // ranks on different GPUs read each other's buffers: peer access both ways (already enabled is fine)
     KC_HIP(ctx, hipSetDevice(ctx->device));
     int ndev = 0;
@@ -250,6 +256,7 @@ extern "C" int kc_comm_create_rccl(kc_ctx *ctx, int rank, int world, const void 
     if (e) return nccl_fail(ctx, "ncclCommInitRank", e);
     kc_comm *c = new kc_comm();
     c->ctx = ctx; c->rank = rank; c->world = world; c->kind = 2; c->nccl_comm = comm;
+    read_test_knobs(c);
     if (kc_alloc(ctx, &c->d_small, 64 + 64 * 64) != KC_OK) { (void)g_rccl.destroy(comm); delete c; return KC_E_NO_DEVICE; }
     *out = c;
     return KC_OK;

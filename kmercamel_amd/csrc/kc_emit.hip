@@ -186,18 +186,18 @@ int kce_rank_path(kc_simplitigs *s, const KcPathDev *path, KcRank *r) {
     KC_HIP(ctx, hipMemsetAsync(pred, 0xff, V * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(start, 0xff, 16, ctx->stream));
     unsigned g = kc_grid(V, 256);
-    hipLaunchKernelGGL(em_pred_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, V, pred);
-    hipLaunchKernelGGL(em_start_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)pred, V, start);
-    hipLaunchKernelGGL(em_rank_init_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, (const u8 *)path->overlaps,
+    KC_LAUNCH(em_pred_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, V, pred);
+    KC_LAUNCH(em_start_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)pred, V, start);
+    KC_LAUNCH(em_rank_init_kernel, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)path->edge_from, (const u8 *)path->overlaps,
                        (const u64 *)s->lens, S, V, ra, weight);
     u64 sample_min = KC_RANK_SAMPLE_MIN;
     if (const char *e = getenv("KC_SAMPLED_RANK_MIN")) { const long long v = atoll(e); if (v >= 0) sample_min = (u64)v; }   // (tests force the sampled route with 0)
     if (V < sample_min || V < 2 || V >= ((u64)1 << 32)) {
         for (u64 span = 1; span < V; span <<= 1) {
-            hipLaunchKernelGGL(em_rank_step_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)ra, V, rb);
+            KC_LAUNCH(em_rank_step_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)ra, V, rb);
             std::swap(ra, rb);
         }
-        hipLaunchKernelGGL(em_rank_split_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)ra, V, dist, endv);
+        KC_LAUNCH(em_rank_split_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)ra, V, dist, endv);
     } else {
         u8 *flag = nullptr;
         u64 *iota = nullptr, *spl = nullptr, *before = nullptr, *d_ns = nullptr, ns = 0;
@@ -205,21 +205,21 @@ int kce_rank_path(kc_simplitigs *s, const KcPathDev *path, KcRank *r) {
         KC_TRY(scope.alloc(&flag, V)); KC_TRY(scope.alloc(&spl, V)); KC_TRY(scope.alloc(&before, V)); KC_TRY(scope.alloc(&own, V)); KC_TRY(scope.alloc(&d_ns, 2));
         KC_HIP(ctx, hipMemsetAsync(own, 0, V * 4, ctx->stream));   // (a vertex no walk reaches -- there is none on a path cover -- then points at record 0)
         iota = endv;   // (endv is written last: until then it holds 0..V-1 for the compaction)
-        hipLaunchKernelGGL(em_iota_kernel, dim3(g), dim3(256), 0, ctx->stream, iota, V);
-        hipLaunchKernelGGL(em_mark_splitters_kernel, dim3(g), dim3(256), 0, ctx->stream, ra, (const u64 *)pred, V, flag);
+        KC_LAUNCH(em_iota_kernel, dim3(g), dim3(256), 0, ctx->stream, iota, V);
+        KC_LAUNCH(em_mark_splitters_kernel, dim3(g), dim3(256), 0, ctx->stream, ra, (const u64 *)pred, V, flag);
         KC_TRY(kcu_select_flagged(ctx, iota, flag, V, spl, d_ns, false));
         KC_HIP(ctx, hipMemcpyAsync(&ns, d_ns, 8, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ns) {
             const unsigned gs = kc_grid(ns, 256);
             // segment records live at the splitters' own indices of rb / ra (the jumping rounds ping-pong between the two)
-            hipLaunchKernelGGL(em_segment_walk_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const EmRank *)ra, (const u64 *)spl, ns, rb, own, before);
+            KC_LAUNCH(em_segment_walk_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const EmRank *)ra, (const u64 *)spl, ns, rb, own, before);
             EmRank *sa = rb, *sb = ra;   // (ra's vertex records are no longer needed once the walks are through)
             for (u64 span = 1; span < ns; span <<= 1) {
-                hipLaunchKernelGGL(em_splitter_step_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const EmRank *)sa, (const u64 *)spl, ns, sb);
+                KC_LAUNCH(em_splitter_step_kernel, dim3(gs), dim3(256), 0, ctx->stream, (const EmRank *)sa, (const u64 *)spl, ns, sb);
                 std::swap(sa, sb);
             }
-            hipLaunchKernelGGL(em_rank_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)sa, (const u32 *)own, (const u64 *)before, V, dist, endv);
+            KC_LAUNCH(em_rank_finish_kernel, dim3(g), dim3(256), 0, ctx->stream, (const EmRank *)sa, (const u32 *)own, (const u64 *)before, V, dist, endv);
         }
     }
     KC_HIP(ctx, hipGetLastError());
@@ -251,10 +251,10 @@ int kce_emit_ranked(kc_simplitigs *s, const KcRank *r, u64 out_lo, int nranks, i
     const u64 gv = (V * lanes + 255) / 256 ? (V * lanes + 255) / 256 : 1;
     const unsigned gx = gv > ((u64)1 << 22) ? (1u << 22) : (unsigned)gv, gz = (unsigned)((gv + gx - 1) / gx);
     if (short_ones)
-        hipLaunchKernelGGL(em_emit_kernel<8>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+        KC_LAUNCH(em_emit_kernel<8>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
                            (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
     else
-        hipLaunchKernelGGL(em_emit_kernel<64>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+        KC_LAUNCH(em_emit_kernel<64>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
                            (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
@@ -274,9 +274,9 @@ int kce_superstring(kc_simplitigs *s, const KcPathDev *path, int complements, kc
         if (rc == KC_OK) {
             const dim3 gm = kc_grid2(L, 256);
             switch (set_for_mask->W) {
-                case 1: hipLaunchKernelGGL((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<1>(set_for_mask), mask); break;
-                case 2: hipLaunchKernelGGL((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<2>(set_for_mask), mask); break;
-                default: hipLaunchKernelGGL((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<4>(set_for_mask), mask); break;
+                case 1: KC_LAUNCH((em_mask_kernel<1>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<1>(set_for_mask), mask); break;
+                case 2: KC_LAUNCH((em_mask_kernel<2>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<2>(set_for_mask), mask); break;
+                default: KC_LAUNCH((em_mask_kernel<4>), dim3(gm), dim3(256), 0, ctx->stream, (const char *)out, L, k, complements, kc_view<4>(set_for_mask), mask); break;
             }
             if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "mask kernel launch failed");
         }
@@ -342,8 +342,8 @@ template <int W> static int maskopt_w(kc_ctx *ctx, const char *ms, u64 len, int 
     KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
     SetView<W> sv = kc_view<W>(set);
     const dim3 g = kc_grid2(len, 256);
-    hipLaunchKernelGGL((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
-    hipLaunchKernelGGL((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
+    KC_LAUNCH((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
+    KC_LAUNCH((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
     KC_HIP(ctx, hipGetLastError());
     u64 hbad = 0;
     KC_HIP(ctx, hipMemcpyAsync(out, d_out, len, hipMemcpyDeviceToHost, ctx->stream));

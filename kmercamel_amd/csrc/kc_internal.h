@@ -29,6 +29,7 @@ struct kc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
+    bool err_agreed = false;   // the last error of a collective call was one that every rank takes at the same point (kc_fail_agreed; cleared on entry)
     KcPool pool;
     hipEvent_t ev[8] = {nullptr};
     // dominant-kernel timing (filled by the pipeline)
@@ -93,18 +94,31 @@ struct kc_result {
     u64 stats_ext[16] = {0};   // [0] cycles cut by the simplitig rule, [1] k-mers on this rank, [2] neighbour queries sent (sharded runs)
 };
 
-// (set by kc_grid when a launch would need 2^32 or more threads in one dimension: the launch then fails -- a grid of 0 workgroups is
-// an invalid configuration -- and the next KC_HIP reports KC_E_ARG with that reason instead of a bare HIP error)
+// Set by kc_grid when a launch would need 2^32 or more threads in one dimension (a dispatch carries its size as 32 bits per
+// dimension).  KC_LAUNCH -- the only way this library launches a kernel -- tests it right after the grid expression has been
+// evaluated and returns KC_E_ARG from the calling function BEFORE anything is launched, so no later kernel ever sees the output a
+// skipped launch would have left undefined.  Both KC_LAUNCH and KC_HIP consume the flag on every use, so it cannot go stale.
 inline thread_local bool kc_grid_overflowed = false;
+static inline bool kc_take_grid_overflow() { const bool b = kc_grid_overflowed; kc_grid_overflowed = false; return b; }
+#define KC_GRID_MSG "the input needs a 1-D launch of 2^32 or more threads (not supported)"
 #define KC_HIP(ctx, call)                                                                                  \
     do {                                                                                                   \
         hipError_t e__ = (call);                                                                           \
-        if (e__ != hipSuccess) {                                                                           \
-            const bool big__ = kc_grid_overflowed;                                                         \
-            kc_grid_overflowed = false;                                                                    \
-            (ctx)->err = std::string(big__ ? "the input needs a 1-D launch of 2^32 or more threads (not supported): " : "") + #call + ": " + hipGetErrorString(e__) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
+        const bool big__ = kc_take_grid_overflow();                                                        \
+        if (e__ != hipSuccess || big__) {                                                                  \
+            (ctx)->err = std::string(big__ ? KC_GRID_MSG ": " : "") + #call + ": " + hipGetErrorString(e__) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
             return big__ ? KC_E_ARG : KC_E_NO_DEVICE;                                                      \
         }                                                                                                  \
+    } while (0)
+// (needs `kc_ctx *ctx` in scope and a calling function that returns a KC_* status)
+#define KC_LAUNCH(kern, grid, block, shm, strm, ...)                                                        \
+    do {                                                                                                   \
+        const dim3 grid__ = (grid);                                                                        \
+        if (kc_take_grid_overflow()) {                                                                     \
+            ctx->err = std::string(KC_GRID_MSG) + " @" + __FILE__ + ":" + std::to_string(__LINE__);         \
+            return KC_E_ARG;                                                                               \
+        }                                                                                                  \
+        hipLaunchKernelGGL(kern, grid__, block, shm, strm, __VA_ARGS__);                                    \
     } while (0)
 
 #define KC_TRY(expr)                 \
@@ -115,6 +129,13 @@ inline thread_local bool kc_grid_overflowed = false;
 
 static inline int kc_fail(kc_ctx *ctx, int code, const std::string &msg) {
     if (ctx) ctx->err = msg;
+    return code;
+}
+
+// An error of the hash-sharded flow that all ranks return together (same test on replicated or all-reduced data): the peers are not
+// left waiting in an exchange, so kcc_after_collective_call must not tear the transport down.
+static inline int kc_fail_agreed(kc_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) { ctx->err = msg; ctx->err_agreed = true; }
     return code;
 }
 
@@ -160,9 +181,15 @@ struct KcScope {
 // A dispatch carries its size in work-items as 32 bits per dimension: a 1-D launch of 2^32 or more threads is silently
 // truncated.  kc_grid refuses such a launch (the call fails with KC_E_ARG); kernels that sweep table-sized ranges (> 2^32 slots at 2.5 G k-mers)
 // are launched on kc_grid2's 2-D grid and number their threads with kc_gtid().
+// (test knob, read once: KC_TEST_GRID_LIMIT=n makes launches of n or more threads count as overflowing, so that the refusal can be
+// driven through a real call without 2^32 work items)
+static inline bool kc_grid_test_limit_hit(u64 threads) {
+    static const u64 lim = [] { const char *e = getenv("KC_TEST_GRID_LIMIT"); return e ? strtoull(e, nullptr, 10) : 0ull; }();
+    return lim && threads >= lim;
+}
 static inline unsigned kc_grid(u64 n, unsigned block) {
     u64 g = (n + block - 1) / block;
-    if (g * block >= ((u64)1 << 32)) { kc_grid_overflowed = true; return 0u; }   // (the launch fails, KC_HIP turns that into KC_E_ARG)
+    if (g * block >= ((u64)1 << 32) || kc_grid_test_limit_hit(g * block)) { kc_grid_overflowed = true; return 1u; }   // (KC_LAUNCH refuses the launch)
     return (unsigned)(g ? g : 1);
 }
 static inline dim3 kc_grid2(u64 n, unsigned block) {

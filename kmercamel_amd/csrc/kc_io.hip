@@ -362,9 +362,9 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
         }
         last_byte = src[n - 1];
         const u64 nb = (n + 16383) / 16384;
-        hipLaunchKernelGGL(tok_summary_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const u8 *)dr, n, blocks, aux + 2);
-        hipLaunchKernelGGL(tok_chain_kernel, dim3(1), dim3(256), 0, ctx->stream, (const TokFn *)blocks, nb, aux, aux + 4, aux + 4 + nbmax);
-        hipLaunchKernelGGL(tok_write_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const u8 *)dr, n, (const u64 *)(aux + 4), (const u64 *)(aux + 4 + nbmax), out, out_cap,
+        KC_LAUNCH(tok_summary_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const u8 *)dr, n, blocks, aux + 2);
+        KC_LAUNCH(tok_chain_kernel, dim3(1), dim3(256), 0, ctx->stream, (const TokFn *)blocks, nb, aux, aux + 4, aux + 4 + nbmax);
+        KC_LAUNCH(tok_write_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const u8 *)dr, n, (const u64 *)(aux + 4), (const u64 *)(aux + 4 + nbmax), out, out_cap,
                            aux + 2);
         if (hipGetLastError() != hipSuccess || hipEventRecord(done[b], ctx->stream) != hipSuccess) { rc = kc_fail(ctx, KC_E_NO_DEVICE, "tokeniser launch failed"); break; }
         total_in += n;

@@ -970,9 +970,9 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
         while (P < n) P <<= 1;
         const size_t lds = (size_t)P * (W + 1) * 8;
         switch (W) {
-            case 1: hipLaunchKernelGGL((ov_small_sort_kernel<1, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
-            case 2: hipLaunchKernelGGL((ov_small_sort_kernel<2, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
-            default: hipLaunchKernelGGL((ov_small_sort_kernel<4, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
+            case 1: KC_LAUNCH((ov_small_sort_kernel<1, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
+            case 2: KC_LAUNCH((ov_small_sort_kernel<2, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
+            default: KC_LAUNCH((ov_small_sort_kernel<4, 0>), dim3(1), dim3(1024), lds, ctx->stream, keys, ids, (u32)n, P, (const u64 *)nullptr, 0, d, keys_out, ids_out); break;
         }
         KC_HIP(ctx, hipGetLastError());
         return KC_OK;
@@ -986,16 +986,16 @@ static int sort_rows(OvWork &w, const u64 *keys, const u64 *ids, u64 n, int W, i
     }
     if (W == 1) return kcu_sort_pairs(ctx, keys, keys_out, ids, ids_out, n, 0, total_bits, false);
     u64 *perm = s0, *perm2 = s1, *kw = s2, *kw2 = s3;
-    hipLaunchKernelGGL(ov_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
+    KC_LAUNCH(ov_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
     for (int word = 0; word < W; ++word) {
         int bits = total_bits - 64 * word;
         if (bits <= 0) break;
         if (bits > 64) bits = 64;
-        hipLaunchKernelGGL(ov_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, (const u64 *)perm, n, W, word, kw);
+        KC_LAUNCH(ov_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, (const u64 *)perm, n, W, word, kw);
         KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, n, 0, bits, false));
         std::swap(perm, perm2);
     }
-    hipLaunchKernelGGL(ov_gather_rows_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, (const u64 *)perm, n, W, keys_out,
+    KC_LAUNCH(ov_gather_rows_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, (const u64 *)perm, n, W, keys_out,
                        ids_out);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
@@ -1013,7 +1013,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     const u32 PG = split ? (u32)comm->world : 1u, pme = split ? (u32)comm->rank : 0u;
     const int k = s->k;
     const u64 S = s->n, V = S * (complements ? 2 : 1);
-    if (S == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+    if (S == 0) return kc_fail_agreed(ctx, KC_E_EMPTY, "input cannot be empty");
     if (V >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_ARG, "more than 2^32 overlap-graph vertices are not supported (32-bit writer tags of the path-end entries)");
     OvWork w; w.ctx = ctx;
     u64 *pre, *suf, *edge_from, *pred, *first, *last, *first_snap, *last_snap, *actS, *actP, *actS2, *actP2, *eidx;
@@ -1066,7 +1066,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     if (W > 1) { KC_TRY(scope.alloc(&sc0, V)); KC_TRY(scope.alloc(&sc1, V)); KC_TRY(scope.alloc(&sc2, V)); KC_TRY(scope.alloc(&sc3, V)); }
 
     KC_HIP(ctx, hipMemsetAsync(cov, 0, V, ctx->stream));
-    hipLaunchKernelGGL((ov_init_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->firstK, (const u64 *)s->lastK, S, V, k,
+    KC_LAUNCH((ov_init_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->firstK, (const u64 *)s->lastK, S, V, k,
                        pre, suf, edge_from, overlaps, pred, first, last, first_snap, last_snap, actS, actP, eidx);
     KC_HIP(ctx, hipGetLastError());
 
@@ -1090,7 +1090,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         KC_HIP(ctx, hipMemsetAsync(t16.head, 0xff, c16 * 4, ctx->stream));
         KC_HIP(ctx, hipMemsetAsync(markP, 0, V * 4, ctx->stream));
         u64 *dcnt = fresh_cnt();
-        hipLaunchKernelGGL((ov_t16_build_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)pre, V, k, dcnt);
+        KC_LAUNCH((ov_t16_build_kernel<W>), dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)pre, V, k, dcnt);
         KC_HIP(ctx, hipGetLastError());
         // ends that share their first 16 bases (coverage: many simplitigs begin inside the same stretch of genome) make every
         // lookup compare several candidates exactly; measured, the per-level tables win from ~1.3 vertices per 16-mer on
@@ -1145,11 +1145,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             tab.flags = reinterpret_cast<u32 *>(tab.slot + lcap);
             KC_HIP(ctx, hipMemsetAsync(tab.slot, 0xff, lcap * 12, ctx->stream));
             cnt = fresh_cnt();
-            hipLaunchKernelGGL((ov_insert_prefix_kernel<W>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, lenP,
+            KC_LAUNCH((ov_insert_prefix_kernel<W>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, lenP,
                                (const u64 *)pre, (const u64 *)pred, k, d, pslot, PG, pme);
-            hipLaunchKernelGGL((ov_probe_suffix_kernel<W>), dim3(kc_grid((lenS + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, lenS,
+            KC_LAUNCH((ov_probe_suffix_kernel<W>), dim3(kc_grid((lenS + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actS, lenS,
                                (const u64 *)suf, (const u64 *)pre, (const u64 *)edge_from, k, d, complements, hitS, cnt + 1, hs_ids, KC_SMALL_ROWS, PG, pme);
-            hipLaunchKernelGGL((ov_flag_prefix_kernel<W>), dim3(kc_grid((lenP + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, lenP,
+            KC_LAUNCH((ov_flag_prefix_kernel<W>), dim3(kc_grid((lenP + OV_ITEMS - 1) / OV_ITEMS, 256)), dim3(256), 0, ctx->stream, tab, (const u64 *)actP, lenP,
                                (const u64 *)pre, (const u64 *)pslot, k, d, complements, hitP, cnt + 3, hp_ids, KC_SMALL_ROWS);
             KC_TRY(read_back(ctx, hp, cnt, 4));
             return KC_OK;
@@ -1162,7 +1162,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             const u64 ns = (u64)1 << 18;
             const int B = d - 15 < 4 ? d - 15 : 4;
             KC_HIP(ctx, hipMemsetAsync(whist, 0, 32 * 8, ctx->stream));
-            hipLaunchKernelGGL((ov_count16_kernel<W>), dim3(kc_grid(ns, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, ns, (const u64 *)suf,
+            KC_LAUNCH((ov_count16_kernel<W>), dim3(kc_grid(ns, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, ns, (const u64 *)suf,
                                (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, B, whist, PG, pme);
             KC_TRY(read_back(ctx, hp + 64, whist, B));
             u64 sh = 0;
@@ -1179,7 +1179,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 if (B > d - 15) B = d - 15;
                 if (B >= 4) {   // (a window of two or three levels costs what the levels cost)
                     KC_HIP(ctx, hipMemsetAsync(whist, 0, 32 * 8, ctx->stream));
-                    hipLaunchKernelGGL((ov_count16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
+                    KC_LAUNCH((ov_count16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
                                        (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, B, whist, PG, pme);
                     KC_TRY(read_back(ctx, hp + 64, whist, B));
                     int with_hits = 0;
@@ -1192,7 +1192,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             if (d <= win_hi && d >= win_lo && wcount[win_hi - d] == 0) return KC_OK;   // counted: no suffix vertex can hit at this level
             // one sweep over the active suffixes through the 16-mer table of the prefix ends (see ov_probe16_kernel)
             cnt = fresh_cnt();
-            hipLaunchKernelGGL((ov_probe16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
+            KC_LAUNCH((ov_probe16_kernel<W>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, t16, (const u64 *)actS, lenS, (const u64 *)suf,
                                (const u64 *)pre, (const u64 *)pred, (const u64 *)edge_from, k, d, complements, hitS, markP, cnt, hs_ids, hp_ids, (u64)KC_SMALL_ROWS, PG, pme);
             KC_TRY(read_back(ctx, hp, cnt, 6));
             if (hp[4]) {   // a chain beyond the limit (repetitive ends; chains never shrink): this level and the later ones take tables of their own
@@ -1203,7 +1203,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 if (hp[5] || hp[3] >= KC_SMALL_ROWS || getenv("KC_NO_SMALL_SORT")) {
                     // many prefix hits: their exact number and hitP (read by the ordered compaction) come from a sweep over the marks
                     u64 *c2 = fresh_cnt();
-                    hipLaunchKernelGGL(ov_marks_to_hits_kernel, dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP, (const u32 *)markP, hitP,
+                    KC_LAUNCH(ov_marks_to_hits_kernel, dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP, (const u32 *)markP, hitP,
                                        c2, hp_ids, (u64)KC_SMALL_ROWS);
                     KC_TRY(read_back(ctx, hp + 48, c2, 1));
                     hp[3] = hp[48];
@@ -1230,10 +1230,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             while (P < n) P <<= 1;
             const size_t lds = (size_t)P * (W + 1) * 8;
             if (suffix_side)
-                hipLaunchKernelGGL((ov_small_sort_kernel<W, 1>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
+                KC_LAUNCH((ov_small_sort_kernel<W, 1>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
                                    (const u64 *)suf, k, d, keys_o, ids_o);
             else
-                hipLaunchKernelGGL((ov_small_sort_kernel<W, 2>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
+                KC_LAUNCH((ov_small_sort_kernel<W, 2>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
                                    (const u64 *)pre, k, d, keys_o, ids_o);
         };
         // a bucketed sort that overflows (skewed keys) leaves its flag word set and its output void; the match kernels then
@@ -1244,7 +1244,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         else if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
         else {
             KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, lenS));
-            hipLaunchKernelGGL((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
+            KC_LAUNCH((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
                                (const u64 *)suf, k, d, hs_keys);
             KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3, 0, true, &bkS));
         }
@@ -1252,7 +1252,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         else if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
         else {
             KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, lenP));
-            hipLaunchKernelGGL((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
+            KC_LAUNCH((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
                                (const u64 *)pre, k, d, hp_keys);
             KC_TRY(sort_rows(w, hp_keys, hp_ids, nHP, W, d, hp_keys2, hp_ids2, sc0, sc1, sc2, sc3, 1, true, &bkP));
         }
@@ -1293,22 +1293,22 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                 return KC_OK;
             };
             if (local_any) {
-                hipLaunchKernelGGL((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
+                KC_LAUNCH((ov_match_kernel<W>), dim3(kc_grid(nHS, 64)), dim3(64), 0, ctx->stream, g, (const u64 *)hs_keys2,
                                    (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8, huge, huge_cap, cnt + 9);
                 u64 nblk = (nHS + nHP) / (u64)g.lds_min + 1;
                 if (nblk > big_cap) nblk = big_cap;
-                hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
+                KC_LAUNCH(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
                                    (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8));
                 if (nHS + nHP > KC_LDS_MAX) {   // only then can a bucket be that large
                     u64 nh = (nHS + nHP) / KC_LDS_MAX + 1;
                     if (nh > huge_cap) nh = huge_cap;
-                    hipLaunchKernelGGL(ov_match_lds_kernel, dim3((unsigned)nh), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g,
+                    KC_LAUNCH(ov_match_lds_kernel, dim3((unsigned)nh), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g,
                                        (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)huge, huge_cap, (const u64 *)(cnt + 9));
                 }
             }
             if (shlog) {
                 const u64 per_shard_blocks = (2 * nHS / 64 * 5) / (256 * 8) + 1;
-                hipLaunchKernelGGL(ov_gather_log_kernel, dim3((unsigned)(per_shard_blocks > 1024 ? 1024 : per_shard_blocks), 64), dim3(256), 0, ctx->stream,
+                KC_LAUNCH(ov_gather_log_kernel, dim3((unsigned)(per_shard_blocks > 1024 ? 1024 : per_shard_blocks), 64), dim3(256), 0, ctx->stream,
                                    (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, cnt);
             }
             const u64 *LOG = ne;   // the log the verification works on, and the counter block whose word 0 holds its length
@@ -1316,7 +1316,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             u64 covered = 0;
             if (!split) {
                 if (!lower_bound)
-                    hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
+                    KC_LAUNCH((ov_fix_kernel<false>), dim3(kc_grid(max_new, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, (const u64 *)cnt,
                                        (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, cnt + 2);
                 KC_HIP(ctx, hipGetLastError());
                 if (bkS || bkP) KC_HIP(ctx, hipMemcpyAsync(hp + 16, w.d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1345,13 +1345,13 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                     u64 so[64], sc[64], ro[64], rcv[64], a = 0;
                     for (u32 r = 0; r < PG; ++r) { so[r] = 0; sc[r] = nloc * 40; ro[r] = a * 40; rcv[r] = counts[r] * 40; a += counts[r]; }
                     KC_TRY(kcc_alltoallv(comm, ne, so, sc, ne_all, ro, rcv));
-                    hipLaunchKernelGGL(ov_apply_remote_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne_all, nNew, off_mine,
+                    KC_LAUNCH(ov_apply_remote_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne_all, nNew, off_mine,
                                        off_mine + nloc, d, edge_from, overlaps, pred);
                     CNT = fresh_cnt();
                     hp[32] = nNew;
                     KC_HIP(ctx, hipMemcpyAsync(CNT, hp + 32, 8, hipMemcpyHostToDevice, ctx->stream));
                     LOG = ne_all;
-                    hipLaunchKernelGGL((ov_fix_kernel<false>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
+                    KC_LAUNCH((ov_fix_kernel<false>), dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
                                        (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, CNT + 2);
                     KC_HIP(ctx, hipGetLastError());
                     KC_TRY(read_back(ctx, hp + 40, CNT, 3));
@@ -1360,26 +1360,26 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             }
             if (nNew == 0 || lower_bound) break;
             if (covered == nNew) {
-                hipLaunchKernelGGL(ov_fix_write_clear_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
+                KC_LAUNCH(ov_fix_write_clear_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, (const u64 *)CNT,
                                    (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov);
                 break;
             }
             // a cycle slipped through a stale path-end test: blacklist its earliest closing event, undo, replay
             ++repairs;
             if (h_bl.size() / 2 >= BL_MAX) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap repair list exhausted");
-            hipLaunchKernelGGL(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, eidx);
+            KC_LAUNCH(ov_index_edges_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, eidx);
             KC_HIP(ctx, hipMemsetAsync(CNT + 4, 0, 32, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(CNT + 5, 0xff, 8, ctx->stream));
-            hipLaunchKernelGGL(ov_find_cycle_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew,
+            KC_LAUNCH(ov_find_cycle_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew,
                                (const u64 *)first_snap, (const u64 *)eidx, (const u8 *)cov, CNT + 4);
-            hipLaunchKernelGGL(ov_pick_event_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, CNT + 4);
+            KC_LAUNCH(ov_pick_event_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, CNT + 4);
             KC_TRY(read_back(ctx, hp, CNT + 4, 4));
             if (!hp[0]) return kc_fail(ctx, KC_E_NO_DEVICE, "overlap verification failed without a cycle");
             h_bl.push_back(hp[2]); h_bl.push_back(hp[3]);
             KC_HIP(ctx, hipMemcpyAsync(bl, h_bl.data(), h_bl.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             g.nbl = h_bl.size() / 2;
-            hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, edge_from, overlaps, pred,
+            KC_LAUNCH(ov_undo_kernel, dim3(kc_grid(nNew, 256)), dim3(256), 0, ctx->stream, LOG, nNew, edge_from, overlaps, pred,
                                eidx, cov);
         }
         if (trace) {
@@ -1393,9 +1393,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         // are only compacted (two flag sweeps + two ordered compactions: 8 launches) once a quarter of their entries have died
         if (!lower_bound) { nS -= nNew; nP -= nNew; }   // every new edge removes exactly one suffix vertex and one prefix vertex
         if (!lower_bound && !getenv("KC_OV_EAGER_SHRINK") && (lenS - nS) * 4 <= lenS && (lenP - nP) * 4 <= lenP) return KC_OK;
-        hipLaunchKernelGGL((ov_still_active_kernel<true>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, lenS,
+        KC_LAUNCH((ov_still_active_kernel<true>), dim3(kc_grid(lenS, 256)), dim3(256), 0, ctx->stream, (const u64 *)actS, lenS,
                            (const u64 *)edge_from, (const u64 *)pred, hitS);
-        hipLaunchKernelGGL((ov_still_active_kernel<false>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP,
+        KC_LAUNCH((ov_still_active_kernel<false>), dim3(kc_grid(lenP, 256)), dim3(256), 0, ctx->stream, (const u64 *)actP, lenP,
                            (const u64 *)edge_from, (const u64 *)pred, hitP);
         if (lower_bound) {   // an edge may have been logged twice: take the exact counts
             u64 nS2 = 0, nP2 = 0;
@@ -1455,24 +1455,24 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             gcnt = ovg_lcnt + 16 * (size_t)d;
             level_cnt[(size_t)d] = gcnt;
             g.ne_count = gcnt;
-            hipLaunchKernelGGL((ovg_begin_kernel<W>), dim3(1), dim3(256), 0, ctx->stream, ovg_st, ne_shcur, tcap);
-            hipLaunchKernelGGL((ovg_clear_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, tab, ob.cnt2);
-            hipLaunchKernelGGL((ovg_insert_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, (const u64 *)pred, k, d);
-            hipLaunchKernelGGL((ovg_probe_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)suf, (const u64 *)pre, (const u64 *)edge_from, k, d);
-            hipLaunchKernelGGL((ovg_buckets_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, k, d, complements);
-            hipLaunchKernelGGL(ovg_scatter_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, ob);
-            hipLaunchKernelGGL((ovg_match_kernel<W>), dim3(4 * OVG_GRID), dim3(64), 0, ctx->stream, g, ovg_st, ob, (const u64 *)suf);
-            hipLaunchKernelGGL(ovg_match_lds_kernel, dim3(2 * OVG_GRID), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g, (const u64 *)ovg_st, ob, 0);
-            hipLaunchKernelGGL(ovg_match_lds_kernel, dim3(64), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g, (const u64 *)ovg_st, ob, 1);
-            if (shl) hipLaunchKernelGGL(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, gcnt);
-            hipLaunchKernelGGL(ovg_cover_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, (const u64 *)ne, (const u64 *)gcnt, (const u64 *)edge_from, (const u64 *)pred,
+            KC_LAUNCH((ovg_begin_kernel<W>), dim3(1), dim3(256), 0, ctx->stream, ovg_st, ne_shcur, tcap);
+            KC_LAUNCH((ovg_clear_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, tab, ob.cnt2);
+            KC_LAUNCH((ovg_insert_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, (const u64 *)pred, k, d);
+            KC_LAUNCH((ovg_probe_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)suf, (const u64 *)pre, (const u64 *)edge_from, k, d);
+            KC_LAUNCH((ovg_buckets_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, k, d, complements);
+            KC_LAUNCH(ovg_scatter_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, ob);
+            KC_LAUNCH((ovg_match_kernel<W>), dim3(4 * OVG_GRID), dim3(64), 0, ctx->stream, g, ovg_st, ob, (const u64 *)suf);
+            KC_LAUNCH(ovg_match_lds_kernel, dim3(2 * OVG_GRID), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g, (const u64 *)ovg_st, ob, 0);
+            KC_LAUNCH(ovg_match_lds_kernel, dim3(64), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g, (const u64 *)ovg_st, ob, 1);
+            if (shl) KC_LAUNCH(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, gcnt);
+            KC_LAUNCH(ovg_cover_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, (const u64 *)ne, (const u64 *)gcnt, (const u64 *)edge_from, (const u64 *)pred,
                                (const u64 *)first_snap, (const u64 *)last_snap, cov);
-            hipLaunchKernelGGL(ovg_decide_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, (const u64 *)gcnt, (const u64 *)(ne_shcur + 64 * 16), d);
-            hipLaunchKernelGGL(ovg_write_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, (const u64 *)ne, (const u64 *)edge_from, (const u64 *)pred, first_snap,
+            KC_LAUNCH(ovg_decide_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, (const u64 *)gcnt, (const u64 *)(ne_shcur + 64 * 16), d);
+            KC_LAUNCH(ovg_write_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, (const u64 *)ne, (const u64 *)edge_from, (const u64 *)pred, first_snap,
                                last_snap, cov);
-            hipLaunchKernelGGL(ovg_end_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, d);
-            hipLaunchKernelGGL(ovg_compact_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, ob, (const u64 *)edge_from, (const u64 *)pred);
-            hipLaunchKernelGGL(ovg_swap_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st);
+            KC_LAUNCH(ovg_end_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, d);
+            KC_LAUNCH(ovg_compact_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, ob, (const u64 *)edge_from, (const u64 *)pred);
+            KC_LAUNCH(ovg_swap_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st);
         }
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipMemcpyAsync(h_st, ovg_st, sizeof h_st, hipMemcpyDeviceToHost, ctx->stream));
@@ -1490,12 +1490,12 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         u64 *c2 = level_cnt[(size_t)dp];   // (the dense log's length, when the level logged straight into it)
         if (shl) {
             c2 = fresh_cnt();
-            hipLaunchKernelGGL(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, c2);
+            KC_LAUNCH(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, c2);
         }
         u64 nlog = 0;
         KC_HIP(ctx, hipMemcpyAsync(&nlog, c2, 8, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (nlog) hipLaunchKernelGGL(ov_undo_kernel, dim3(kc_grid(nlog, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nlog, edge_from, overlaps, pred, eidx, cov);
+        if (nlog) KC_LAUNCH(ov_undo_kernel, dim3(kc_grid(nlog, 256)), dim3(256), 0, ctx->stream, (const u64 *)ne, nlog, edge_from, overlaps, pred, eidx, cov);
         KC_HIP(ctx, hipGetLastError());
         *next = dp;
         return KC_OK;

@@ -155,7 +155,7 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
     KC_TRY(kc_alloc(ctx, d_codes, nblk * 2 + 2));
     KC_TRY(kc_alloc(ctx, d_brk, nblk + 1));
     KC_TRY(kc_alloc(ctx, d_low, nblk + 1));
-    hipLaunchKernelGGL(kc_pack2bit_kernel, dim3(kc_grid(nblk, 256)), dim3(256), 0, ctx->stream, (const u8 *)d_seq, len, *d_codes,
+    KC_LAUNCH(kc_pack2bit_kernel, dim3(kc_grid(nblk, 256)), dim3(256), 0, ctx->stream, (const u8 *)d_seq, len, *d_codes,
                        *d_brk, *d_low, nblk);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
@@ -945,11 +945,17 @@ static void kcs_void_dense(kc_set *set) {
     if (set->ncount) { (void)hipStreamSynchronize(set->ctx->stream); kc_release(set->ctx, set->ncount); set->ncount = nullptr; }
 }
 template <int W>
-__global__ void __launch_bounds__(256) kc_annotate_kernel(SetView<W> set, u32 *ncount, u64 *max_out, const u64 *__restrict__ only = nullptr) {
-    // only != nullptr: the listed blocks (the ones that took spilled keys after the build kernel had numbered them; a block listed twice
-    // is numbered twice, with the same result)
+__global__ void __launch_bounds__(256) kc_annotate_kernel(SetView<W> set, u32 *ncount, u64 *max_out, const u64 *__restrict__ only = nullptr, u32 *claim = nullptr) {
+    // only != nullptr: the listed blocks (the ones that took spilled keys after the build kernel had numbered them); a block listed
+    // several times is numbered by the first workgroup that claims it (claim[]: one zero-initialised word per block)
     const u32 bs = 1u << set.bshift, per = bs >> 8;   // (blocks have >= 512 slots)
     const u64 blk = only ? only[blockIdx.x] : (u64)blockIdx.x;
+    if (claim) {
+        __shared__ u32 taken;
+        if (threadIdx.x == 0) taken = atomicExch(&claim[blk], 1u);
+        __syncthreads();
+        if (taken) return;
+    }
     const u64 base = set.rlo + (blk << set.bshift);
     const u8 *tg = set.tags + base + (u64)threadIdx.x * per;
     u32 c = 0;
@@ -979,9 +985,9 @@ int kcs_prepare_dense(kc_set *set) {
     KC_TRY(kc_alloc(ctx, &set->ncount, nblk + 2));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_annotate_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<1>(set), set->ncount, set->counters + 4); break;
-        case 2: hipLaunchKernelGGL(kc_annotate_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<2>(set), set->ncount, set->counters + 4); break;
-        default: hipLaunchKernelGGL(kc_annotate_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<4>(set), set->ncount, set->counters + 4); break;
+        case 1: KC_LAUNCH(kc_annotate_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<1>(set), set->ncount, set->counters + 4); break;
+        case 2: KC_LAUNCH(kc_annotate_kernel<2>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<2>(set), set->ncount, set->counters + 4); break;
+        default: KC_LAUNCH(kc_annotate_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, kc_view<4>(set), set->ncount, set->counters + 4); break;
     }
     KC_HIP(ctx, hipGetLastError());
     u64 mx = 0;
@@ -1028,9 +1034,9 @@ static int kcs_rebuild(kc_set *set, u64 ncap, u64 nnblocks, u64 *nkeys, u32 *nst
     if (set->size_host) {
         const dim3 g = kc_grid2(set->cap, 256);
         switch (set->W) {
-            case 1: hipLaunchKernelGGL(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), view_of<1>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
-            case 2: hipLaunchKernelGGL(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), view_of<2>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
-            default: hipLaunchKernelGGL(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), view_of<4>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
+            case 1: KC_LAUNCH(kc_rehash_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), view_of<1>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
+            case 2: KC_LAUNCH(kc_rehash_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), view_of<2>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
+            default: KC_LAUNCH(kc_rehash_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), view_of<4>(&to), set->counters, (const u32 *)set->counts, ncounts, min_count); break;
         }
         KC_HIP(ctx, hipGetLastError());
     }
@@ -1068,9 +1074,9 @@ static int insert_direct(kc_set *set, const u64 *d_codes, const u64 *d_brk, cons
     const size_t lds = (size_t)win * bs * 4 * 2;   // raw + suffix-minimum arrays of kc_roll_kmers
     unsigned g = kc_grid(nthreads, bs);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
-        case 2: hipLaunchKernelGGL(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
-        default: hipLaunchKernelGGL(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
+        case 1: KC_LAUNCH(kc_insert_kernel<1>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<1>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
+        case 2: KC_LAUNCH(kc_insert_kernel<2>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<2>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
+        default: KC_LAUNCH(kc_insert_kernel<4>, dim3(g), dim3(bs), lds, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements, case_sensitive, view_of<4>(set), set->counters, ppt, set->counts, only_over, over_limit); break;
     }
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
@@ -1117,7 +1123,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             int chunks = 16;   // (even)
             if (const char *e = getenv("KC_SCATTER_CHUNKS")) { const int v = atoi(e); if (v >= 2 && v <= 4096) chunks = v & ~1; }   // tuning knob
             const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
-            hipLaunchKernelGGL(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+            KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
                                case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks);
         }
     }
@@ -1126,12 +1132,12 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
         if (wave_form) {
             const int chunks = 16;
             const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
-            hipLaunchKernelGGL(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+            KC_LAUNCH(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                                set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, chunks);
         }
     }
     if (!wave_form)
-        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
+        KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len,
                            set->k, set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
     const size_t lds_build = (size_t)bs * (8 * W + 1);
     KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
@@ -1151,7 +1157,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
         if (!scatter_ovf) {
             const int stride = set->nblocks >= 64 * 128 ? 64 : (int)(set->nblocks / 128);
             const u64 nsample = (set->nblocks + stride - 1) / stride;
-            hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)nsample), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
+            KC_LAUNCH(kc_block_build_kernel<W>, dim3((unsigned)nsample), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
                                (const u64 *)bcursor, 1, set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, 0, stride);
             u64 hs[4] = {0, 0, 0, 0};
             KC_HIP(ctx, hipMemcpyAsync(hs, set->counters, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
@@ -1181,13 +1187,13 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_TRY(kc_alloc(ctx, &set->ncount, set->nblocks + 2));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
     if (getenv("KC_NO_BUILD_IDS"))   // (test knob: the sweep of kcs_prepare_dense instead)
-        hipLaunchKernelGGL(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
+        KC_LAUNCH(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
                            (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
     else {
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
-        hipLaunchKernelGGL((kc_block_build_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
+        KC_LAUNCH((kc_block_build_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
                            (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
-        hipLaunchKernelGGL(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
+        KC_LAUNCH(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
     }
     KC_HIP(ctx, hipGetLastError());
     u64 h[5] = {0, 0, 0, 0, 0};
@@ -1208,15 +1214,23 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
         // the spilled keys go to their second homes by the global insert; the build kernel has numbered the blocks' nodes already, so the
         // few blocks that take a key now are numbered again (k = 127 on 10^8 reads: 254 spills -- the sweep over the whole table that a
         // voided numbering costs was 3.6 ms of a 27 ms pass)
-        const bool renumber = !h[3] && !getenv("KC_NO_BUILD_IDS") && set->ncount && fresh;
+        // (a renumbering workgroup rewrites a whole block: with spills in more than 1/16 of the blocks the one sweep of kcs_prepare_dense,
+        // which phase 1 runs when dense_ok is unset, is cheaper than block-by-block repairs)
+        const u64 nblk_here = (set->rcap ? set->rcap : set->cap) >> set->bshift;
+        const bool renumber = !h[3] && !getenv("KC_NO_BUILD_IDS") && set->ncount && fresh && h[2] * 16 <= nblk_here;
         u64 *touched = nullptr;
-        if (renumber) KC_TRY(kc_alloc(ctx, &touched, h[2]));
-        auto rel = kc_defer([&] { if (touched) { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, touched); } });
-        hipLaunchKernelGGL(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)ovf, h[2],
+        u32 *claim = nullptr;
+        auto rel = kc_defer([&] { if (touched || claim) { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, touched); kc_release(ctx, claim); } });
+        if (renumber) {
+            KC_TRY(kc_alloc(ctx, &touched, h[2]));
+            KC_TRY(kc_alloc(ctx, &claim, nblk_here));
+            KC_HIP(ctx, hipMemsetAsync(claim, 0, nblk_here * sizeof(u32), ctx->stream));
+        }
+        KC_LAUNCH(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)ovf, h[2],
                            set->counters, touched);
         KC_HIP(ctx, hipGetLastError());
         if (renumber) {
-            hipLaunchKernelGGL(kc_annotate_kernel<W>, dim3((unsigned)h[2]), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), set->ncount, set->counters + 4, (const u64 *)touched);
+            KC_LAUNCH(kc_annotate_kernel<W>, dim3((unsigned)h[2]), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), set->ncount, set->counters + 4, (const u64 *)touched, claim);
             KC_HIP(ctx, hipGetLastError());
             u64 h2[5] = {0, 0, 0, 0, 0};
             KC_HIP(ctx, hipMemcpyAsync(h2, set->counters, sizeof h2, hipMemcpyDeviceToHost, ctx->stream));
@@ -1363,7 +1377,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
             if (wave_form) {
                 const int chunks = 16;
                 const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
-                hipLaunchKernelGGL(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+                KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
                                    0, kc_view_raw<1>(set), fixed, bcount, set->counters, chunks);
             }
         }
@@ -1372,12 +1386,12 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
             if (wave_form) {
                 const int chunks = 16;
                 const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
-                hipLaunchKernelGGL(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                KC_LAUNCH(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                                    set->complements, 0, kc_view_raw<W>(set), fixed, bcount, set->counters, chunks);
             }
         }
         if (!wave_form)
-            hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+            KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                                set->complements, 0, kc_view_raw<W>(set), fixed, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 0);
         u64 hovf = 0;
         KC_HIP(ctx, hipMemcpyAsync(&hovf, set->counters + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1390,7 +1404,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         }
     }
     if (have && !one_pass)
-        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+        KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                            set->complements, 0, kc_view_raw<W>(set), (u64 *)nullptr, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 1);
     KC_TRY(kcu_exclusive_scan(ctx, bcount, boff, nblocks));
     std::vector<u64> h_off(nblocks + 1);
@@ -1399,12 +1413,12 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     const u64 occ_local = h_off[nblocks];
     KC_TRY(scope.alloc(&bucket, occ_local * W + 1));
     if (one_pass) {
-        hipLaunchKernelGGL(kc_bucket_compact_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, (const u64 *)fixed, (const u64 *)bcount, (const u64 *)boff, set->bshift, W, bucket);
+        KC_LAUNCH(kc_bucket_compact_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, (const u64 *)fixed, (const u64 *)bcount, (const u64 *)boff, set->bshift, W, bucket);
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(fixed);
     } else if (have)
-        hipLaunchKernelGGL(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+        KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                            set->complements, 0, kc_view_raw<W>(set), bucket, bcur, set->counters, ppt, stage_cap, (const u64 *)boff, 0);
     KC_HIP(ctx, hipGetLastError());
     // exchange 1: the per-block counts of every owner's blocks
@@ -1440,7 +1454,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         KC_TRY(scope.alloc(&where, nrecv + 4));
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_filter_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
         KC_HIP(ctx, hipMemsetAsync(set->counters + 3, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(kc_block_build_filter_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys, set->counters,
+        KC_LAUNCH(kc_block_build_filter_kernel<W>, dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys, set->counters,
                            (const u64 *)seg_scan, G, (u32)min_count, where);
     } else {
         // (the blocks leave the build with their dense node ids prepared, as on one GPU: kcs_prepare_dense_sharded then only has to
@@ -1448,9 +1462,9 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         KC_TRY(kc_alloc(ctx, &set->ncount, bpr + 2));
         KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
-        hipLaunchKernelGGL((kc_block_build_kernel<W, true>), dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
+        KC_LAUNCH((kc_block_build_kernel<W, true>), dim3((unsigned)bpr), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)rkeys,
                            (const u64 *)nullptr, 1, set->counters, ovf, ovf_cap, (const u64 *)seg_scan, G, 0, 0, set->ncount);
-        hipLaunchKernelGGL(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, bpr, set->counters + 4);
+        KC_LAUNCH(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, bpr, set->counters + 4);
         ids_built = true;
     }
     KC_HIP(ctx, hipGetLastError());
@@ -1461,7 +1475,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     if (min_count > 1) {   // (collective: a rank whose blocks overflowed takes everybody out of the sharded path)
         u64 lost = h[3];
         KC_TRY(kcc_allreduce_max(c, &lost, 1));
-        if (lost) return kc_fail(ctx, KC_E_ARG, "-z with table blocks that overflow is not part of the hash-sharded path");
+        if (lost) return kc_fail_agreed(ctx, KC_E_ARG, "-z with table blocks that overflow is not part of the hash-sharded path");
     }
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] rank %d/%d sharded build W=%d: %llu of %llu blocks (2^%d slots), %llu occurrences in, %llu received, size %llu, spills %llu\n", c->rank, G, W,
@@ -1470,10 +1484,10 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     {   // (agreed among the ranks: one that returned alone here would leave its peers waiting in the next exchange)
         u64 over = h[2] > ovf_cap ? 1 : 0;
         KC_TRY(kcc_allreduce_max(c, &over, 1));
-        if (over) return kc_fail(ctx, KC_E_CAPACITY, "hash-sharded build: too many k-mers spilled out of their blocks (on some rank)");
+        if (over) return kc_fail_agreed(ctx, KC_E_CAPACITY, "hash-sharded build: too many k-mers spilled out of their blocks (on some rank)");
     }
     if (h[2]) {
-        hipLaunchKernelGGL(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), (const u64 *)ovf, h[2], set->counters);
+        KC_LAUNCH(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), (const u64 *)ovf, h[2], set->counters);
         KC_HIP(ctx, hipGetLastError());
     }
     return kcs_refresh_size(set);
@@ -1481,7 +1495,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
 int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved, int min_count) {
     kcs_void_dense(set);
     if (min_count > 1 && (((size_t)1 << set->bshift) * (8 * (size_t)set->W + 3) > KC_MAX_DYN_LDS || set->bshift > 15))
-        return kc_fail(set->ctx, KC_E_ARG, "-z with this table geometry is not part of the hash-sharded path");
+        return kc_fail_agreed(set->ctx, KC_E_ARG, "-z with this table geometry is not part of the hash-sharded path");
     switch (set->W) {
         case 1: return build_sharded_w<1>(set, c, d_codes, d_brk, d_low, len, moved, min_count);
         case 2: return build_sharded_w<2>(set, c, d_codes, d_brk, d_low, len, moved, min_count);
@@ -1598,12 +1612,12 @@ extern "C" int kc_set_erase(kc_set *set, const uint64_t *key_words, uint64_t n, 
     if (rc != KC_OK) { kc_release(ctx, d_keys); return rc; }
     KC_HIP(ctx, hipMemcpyAsync(d_keys, key_words, n * set->W * 8, hipMemcpyHostToDevice, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(kc_fill_u32_kernel, kc_grid2(set->cap, 256), dim3(256), 0, ctx->stream, keep, set->cap, 1u);
+    KC_LAUNCH(kc_fill_u32_kernel, kc_grid2(set->cap, 256), dim3(256), 0, ctx->stream, keep, set->cap, 1u);
     const dim3 g = kc_grid2(n, 256);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_flag_erase_kernel<1>, g, dim3(256), 0, ctx->stream, view_of<1>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
-        case 2: hipLaunchKernelGGL(kc_flag_erase_kernel<2>, g, dim3(256), 0, ctx->stream, view_of<2>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
-        default: hipLaunchKernelGGL(kc_flag_erase_kernel<4>, g, dim3(256), 0, ctx->stream, view_of<4>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
+        case 1: KC_LAUNCH(kc_flag_erase_kernel<1>, g, dim3(256), 0, ctx->stream, view_of<1>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
+        case 2: KC_LAUNCH(kc_flag_erase_kernel<2>, g, dim3(256), 0, ctx->stream, view_of<2>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
+        default: KC_LAUNCH(kc_flag_erase_kernel<4>, g, dim3(256), 0, ctx->stream, view_of<4>(set), (const u64 *)d_keys, n, keep, set->counters + 3); break;
     }
     KC_HIP(ctx, hipGetLastError());
     u64 h[4];
@@ -1645,9 +1659,9 @@ extern "C" int kc_set_export(kc_set *set, uint64_t *out_words) {
     KC_HIP(ctx, hipMemsetAsync(cursor, 0, 8, ctx->stream));
     const dim3 g = kc_grid2(set->cap, 256);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_export_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_out, cursor); break;
-        case 2: hipLaunchKernelGGL(kc_export_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_out, cursor); break;
-        default: hipLaunchKernelGGL(kc_export_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), d_out, cursor); break;
+        case 1: KC_LAUNCH(kc_export_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_out, cursor); break;
+        case 2: KC_LAUNCH(kc_export_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_out, cursor); break;
+        default: KC_LAUNCH(kc_export_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), d_out, cursor); break;
     }
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipMemcpyAsync(out_words, d_out, n * set->W * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1667,9 +1681,9 @@ extern "C" int kc_set_contains(kc_set *set, const uint64_t *key_words, uint64_t 
     KC_HIP(ctx, hipMemcpyAsync(d_keys, key_words, n * set->W * 8, hipMemcpyHostToDevice, ctx->stream));
     const dim3 g = kc_grid2(n, 256);
     switch (set->W) {
-        case 1: hipLaunchKernelGGL(kc_contains_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_keys, n, d_out); break;
-        case 2: hipLaunchKernelGGL(kc_contains_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_keys, n, d_out); break;
-        default: hipLaunchKernelGGL(kc_contains_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), d_keys, n, d_out); break;
+        case 1: KC_LAUNCH(kc_contains_kernel<1>, dim3(g), dim3(256), 0, ctx->stream, view_of<1>(set), d_keys, n, d_out); break;
+        case 2: KC_LAUNCH(kc_contains_kernel<2>, dim3(g), dim3(256), 0, ctx->stream, view_of<2>(set), d_keys, n, d_out); break;
+        default: KC_LAUNCH(kc_contains_kernel<4>, dim3(g), dim3(256), 0, ctx->stream, view_of<4>(set), d_keys, n, d_out); break;
     }
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, ctx->stream));

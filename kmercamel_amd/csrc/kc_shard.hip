@@ -761,9 +761,8 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     const u64 N_local = set->size_host;
     u64 N = N_local;
     KC_TRY(kcc_allreduce_sum(c, &N, 1));
-    if (N == 0) return kc_fail(ctx, KC_E_NO_KMERS, "input contains no k-mers");
-    if (const char *e = getenv("KC_TEST_FAIL_RANK"))   // (tests: this rank fails on its own, between two exchanges)
-        if (atoi(e) == me) return kc_fail(ctx, KC_E_NO_DEVICE, "test: this rank fails on its own");
+    if (N == 0) return kc_fail_agreed(ctx, KC_E_NO_KMERS, "input contains no k-mers");
+    if (c->test_fail_rank == me) return kc_fail(ctx, KC_E_NO_DEVICE, "test: this rank fails on its own");   // (kc_comm::test_fail_rank, a test knob: between two exchanges)
     KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
     // Ports are numbered by DENSE node id (kc_set_dev.h): block * nstride + the k-mer's rank among the block's occupied slots, with
     // the same nstride on every rank -- so rank r holds the ids [r * rcap, (r + 1) * rcap) with rcap = blocks per rank * nstride, and
@@ -812,9 +811,9 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             auto launch = [&](auto kern) -> int {
                 KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 u64 *spill_cur = cur + (2 * KC_USH + 2) * KC_USTRIDE;
-                hipLaunchKernelGGL(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, complements, 1, (u64 *)nullptr, (u64)0, (u64 *)nullptr, (u64 *)nullptr, (u64)0,
+                KC_LAUNCH(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, complements, 1, (u64 *)nullptr, (u64)0, (u64 *)nullptr, (u64 *)nullptr, (u64)0,
                                    (u64 *)nullptr, spill, spill_cap, spill_cur, L);
-                hipLaunchKernelGGL((kc_shard_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, complements, (const u64 *)spill, spill_cap, (const u64 *)spill_cur, L);
+                KC_LAUNCH((kc_shard_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, complements, (const u64 *)spill, spill_cap, (const u64 *)spill_cur, L);
                 return KC_OK;
             };
             if (stage_keys) {
@@ -848,19 +847,19 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(kcu_compact_shards(ctx, L.qry, qry_scap, L.qry_cur, KC_USH, KC_USTRIDE, QW, qc, &nq, &ovf));
             u8 *dest = nullptr;
             KC_TRY(scope.alloc(&dest, nq + 1));
-            if (nq) hipLaunchKernelGGL((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcapS, dest);
+            if (nq) KC_LAUNCH((kc_shard_qdest_kernel<W>), dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, nq, rcapS, dest);
             KcRoute rt;
             KC_TRY(kcr_build(c, dest, nq, &rt));
             u64 *rq = nullptr, *ans = nullptr, *ansb = nullptr;
             int rc = kcr_forward(c, rt, qc, W + 1, QW, &rq);   // the k-mer and the asking port travel; the owner derives the home (one minimizer pass)
             if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
             if (rc == KC_OK && rt.n_recv)
-                hipLaunchKernelGGL((kc_shard_answer_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, k, complements, (const u64 *)rq, rt.n_recv, ans, L);
+                KC_LAUNCH((kc_shard_answer_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, k, complements, (const u64 *)rq, rt.n_recv, ans, L);
             if (trace) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[shard %d/%d] %llu queries out, %llu answered here (%s)\n", me, G, (unsigned long long)nq, (unsigned long long)rt.n_recv, hipGetErrorString(e)); }
             if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nq + 1);
             if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
             if (rc == KC_OK && nq)
-                hipLaunchKernelGGL(kc_shard_fill_kernel, dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, QW, link, nstride, set->bshift);
+                KC_LAUNCH(kc_shard_fill_kernel, dim3(kc_grid(nq, 256)), dim3(256), 0, ctx->stream, (const u64 *)qc, (const u64 *)ansb, nq, QW, link, nstride, set->bshift);
             (void)hipStreamSynchronize(ctx->stream);
             kcr_free(ctx, &rt);
             kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
@@ -892,7 +891,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 u64 *dfix = nullptr;
                 KC_TRY(scope.alloc(&dfix, fix.size()));
                 KC_HIP(ctx, hipMemcpyAsync(dfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL((kc_shard_apply_fix_kernel<W>), dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)dfix, (u64)(fix.size() / 2),
+                KC_LAUNCH((kc_shard_apply_fix_kernel<W>), dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)dfix, (u64)(fix.size() / 2),
                                    2 * rlo, 2 * rcap);
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 scope.release(dfix);
@@ -918,7 +917,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     const u64 bpr_blocks = rcapS >> set->bshift;
     auto restore_links = [&]() -> int {
         if (!contracted) return KC_OK;
-        hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)bpr_blocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog, (const u64 *)fblog, set->bshift, rloS >> set->bshift, nstride);
+        KC_LAUNCH(kc_frag_restore_kernel, dim3((unsigned)bpr_blocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog, (const u64 *)fblog, set->bshift, rloS >> set->bshift, nstride);
         KC_HIP(ctx, hipGetLastError());
         contracted = false; frag_ok = false;
         return KC_OK;
@@ -942,7 +941,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 KC_HIP(ctx, hipMemsetAsync(fcur, 0, (2 * 64 * 16 + 16) * 8, ctx->stream));
                 const size_t flds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
                 KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
+                KC_LAUNCH((kc_frag_contract_kernel<W, true>), dim3((unsigned)bpr_blocks), dim3(1024), flds, ctx->stream, sv, link, complements, fpool, pool_cap, fcur, fbase, flog,
                                    log_cap, fcur + 64 * 16, fblog, entries, ecap, fcur + 2 * 64 * 16);
                 KC_HIP(ctx, hipGetLastError());
                 contracted = true;
@@ -957,13 +956,13 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 unsigned short *emasks = nullptr;
                 KC_TRY(scope.alloc(&tcount, ntiles + 2));
                 KC_TRY(scope.alloc(&emasks, ntiles * 256));
-                hipLaunchKernelGGL((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, ncount, nstride, rlo, rcap, complements,
+                KC_LAUNCH((kc_shard_entries_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, ncount, nstride, rlo, rcap, complements,
                                    (const u64 *)nullptr, tcount, emasks);
                 KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
                 KC_TRY(read_words(ctx, tcount + ntiles, &n_ent, 1));
                 if (n_ent >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_CAPACITY, "more than 2^32 chain fragments on one rank");
                 KC_TRY(scope.alloc(&entries, n_ent + 1));
-                hipLaunchKernelGGL((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, ncount, nstride, rlo, rcap, complements,
+                KC_LAUNCH((kc_shard_entries_kernel<true>), dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, (const u64 *)link, ncount, nstride, rlo, rcap, complements,
                                    (const u64 *)tcount, entries, emasks);
                 KC_HIP(ctx, hipGetLastError());
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -979,12 +978,12 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
             if (n_ent) {
                 if (contracted)
-                    hipLaunchKernelGGL((kc_shard_walk_kernel<false, true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                    KC_LAUNCH((kc_shard_walk_kernel<false, true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
                                        f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE, fr, set->bshift);
                 else
-                    hipLaunchKernelGGL((kc_shard_walk_kernel<false, false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
+                    KC_LAUNCH((kc_shard_walk_kernel<false, false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent,
                                        f_exit, f_partner, f_len, f_stream, fidx, frec, (u8 *)nullptr, cur + KC_USTRIDE, fr, set->bshift);
-                hipLaunchKernelGGL(kc_shard_sum_kernel, dim3(256), dim3(256), 0, ctx->stream, (const u64 *)f_len, n_ent, cur + 2 * KC_USTRIDE);
+                KC_LAUNCH(kc_shard_sum_kernel, dim3(256), dim3(256), 0, ctx->stream, (const u64 *)f_len, n_ent, cur + 2 * KC_USTRIDE);
             }
             KC_HIP(ctx, hipGetLastError());
             u64 hw[3 * KC_USTRIDE];
@@ -997,14 +996,14 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         {   // (a rank that returned alone here would leave its peers waiting in the ranking's exchanges: the ranks agree first)
             u64 e = walk_err;
             KC_TRY(kcc_allreduce_max(c, &e, 1));
-            if (e == 1) return kc_fail(ctx, KC_E_CAPACITY, "fragment recording pool exhausted (on some rank)");
-            if (e) return kc_fail(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree (on some rank)");
+            if (e == 1) return kc_fail_agreed(ctx, KC_E_CAPACITY, "fragment recording pool exhausted (on some rank)");
+            if (e) return kc_fail_agreed(ctx, KC_E_NO_DEVICE, "fragment walks and k-mer count disagree (on some rank)");
         }
         KC_TRY(scope.alloc(&nxt, n_ent + 1)); KC_TRY(scope.alloc(&dist, n_ent + 1)); KC_TRY(scope.alloc(&last, n_ent + 1));
         KC_TRY(scope.alloc(&iota, n_ent + 1)); KC_TRY(scope.alloc(&act, n_ent + 1)); KC_TRY(scope.alloc(&flags8, n_ent + 1));
         if (n_ent) {
-            hipLaunchKernelGGL(kc_shard_jump_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)f_partner, (const u64 *)f_len, n_ent, me, nxt, dist, last);
-            hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
+            KC_LAUNCH(kc_shard_jump_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)f_partner, (const u64 *)f_len, n_ent, me, nxt, dist, last);
+            KC_LAUNCH(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
         }
         KC_HIP(ctx, hipGetLastError());
         // ---- ranking by waves (see kc_shard_wave_init_kernel) when the set is bidirectional and the chains are short in fragments
@@ -1017,7 +1016,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             u64 *pay = nullptr, *poff = nullptr, *msgs = nullptr;
             u8 *reach_a = nullptr, *reach_b = nullptr, *wdest = nullptr;
             KC_TRY(scope.alloc(&pay, n_ent + 1)); KC_TRY(scope.alloc(&poff, n_ent + 1)); KC_TRY(scope.alloc(&reach_a, n_ent + 1)); KC_TRY(scope.alloc(&reach_b, n_ent + 1));
-            if (n_ent) hipLaunchKernelGGL(kc_shard_wave_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, (const u64 *)f_exit,
+            if (n_ent) KC_LAUNCH(kc_shard_wave_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, (const u64 *)f_exit,
                                           (const u32 *)fidx, 2 * rlo, me, pay, poff, reach_a);
             if (n_ent) {
                 KC_TRY(kcu_select_flagged(ctx, iota, reach_a, n_ent, act, cur + 2 * KC_USTRIDE));
@@ -1030,12 +1029,12 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             while (wave) {
                 u64 n_send = 0;
                 if (n_ent) {
-                    hipLaunchKernelGGL(kc_shard_wave_flag_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u8 *)reach_a, (const u64 *)f_partner, n_ent, flags8);
+                    KC_LAUNCH(kc_shard_wave_flag_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u8 *)reach_a, (const u64 *)f_partner, n_ent, flags8);
                     KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
                     KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_send, 1));
                 }
                 KC_TRY(scope.alloc(&msgs, 3 * n_send + 1)); KC_TRY(scope.alloc(&wdest, n_send + 1));
-                if (n_send) hipLaunchKernelGGL(kc_shard_wave_send_kernel, dim3(kc_grid(n_send, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_send, (const u64 *)f_partner,
+                if (n_send) KC_LAUNCH(kc_shard_wave_send_kernel, dim3(kc_grid(n_send, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_send, (const u64 *)f_partner,
                                                (const u64 *)f_len, (const u64 *)pay, (const u64 *)poff, 2 * rcap, msgs, wdest);
                 KcRoute rt;
                 KC_TRY(kcr_build(c, wdest, n_send, &rt));   // (its count exchange also says whether any rank still sends: no collective of its own for that)
@@ -1049,7 +1048,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 int rc = kcr_forward(c, rt, msgs, 3, 3, &rq);
                 if (rc == KC_OK && n_ent && hipMemsetAsync(reach_b, 0, n_ent, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
                 if (rc == KC_OK && rt.n_recv)
-                    hipLaunchKernelGGL(kc_shard_wave_recv_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, pay, poff, reach_b);
+                    KC_LAUNCH(kc_shard_wave_recv_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, pay, poff, reach_b);
                 (void)hipStreamSynchronize(ctx->stream);
                 kcr_free(ctx, &rt);
                 kc_release(ctx, rq);
@@ -1061,7 +1060,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             if (wave) {
                 // every chain with ends is ranked; fragments no wave reached lie on cycles that span ranks
                 if (n_ent) {
-                    hipLaunchKernelGGL(kc_shard_wave_finish_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, n_ent, (const u64 *)f_exit, (const u32 *)fidx, 2 * rlo,
+                    KC_LAUNCH(kc_shard_wave_finish_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, n_ent, (const u64 *)f_exit, (const u32 *)fidx, 2 * rlo,
                                        (const u64 *)f_len, (const u64 *)f_partner, (const u64 *)pay, (const u64 *)poff, dist, last, nxt, flags8);
                     KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
                     KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_act, 1));
@@ -1077,7 +1076,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         for (int round = 0; !ranked; ++round) {
             n_act = 0;
             if (n_ent) {
-                hipLaunchKernelGGL(kc_shard_active_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)nxt, n_ent, flags8);
+                KC_LAUNCH(kc_shard_active_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)nxt, n_ent, flags8);
                 KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, act, cur + 2 * KC_USTRIDE));
                 KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_act, 1));
             }
@@ -1090,20 +1089,20 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             u8 *dest = nullptr;
             const int A = round == 0 ? 1 : 2;
             KC_TRY(scope.alloc(&req, n_act + 1)); KC_TRY(scope.alloc(&dest, n_act + 1));
-            if (n_act) hipLaunchKernelGGL(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, round == 0 ? 1 : 0, 2 * rcap, req, dest);
+            if (n_act) KC_LAUNCH(kc_shard_req_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)nxt, round == 0 ? 1 : 0, 2 * rcap, req, dest);
             KcRoute rt;
             KC_TRY(kcr_build(c, dest, n_act, &rt));
             int rc = kcr_forward(c, rt, req, 1, 1, &rq);
             if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * A + 1);
             if (rc == KC_OK && rt.n_recv) {
-                if (round == 0) hipLaunchKernelGGL(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
-                else hipLaunchKernelGGL(kc_shard_ans_jump_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u64 *)nxt, (const u64 *)dist, (const u64 *)last, ans);
+                if (round == 0) KC_LAUNCH(kc_shard_ans_port_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u32 *)fidx, 2 * rlo, me, ans);
+                else KC_LAUNCH(kc_shard_ans_jump_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rq, rt.n_recv, (const u64 *)nxt, (const u64 *)dist, (const u64 *)last, ans);
             }
             if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, n_act * A + 1);
             if (rc == KC_OK) rc = kcr_backward(c, rt, ans, A, ansb);
             if (rc == KC_OK && n_act) {
-                if (round == 0) hipLaunchKernelGGL(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
-                else hipLaunchKernelGGL(kc_shard_apply_jump_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt, dist, last);
+                if (round == 0) KC_LAUNCH(kc_shard_apply_port_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt);
+                else KC_LAUNCH(kc_shard_apply_jump_kernel, dim3(kc_grid(n_act, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_act, (const u64 *)ansb, nxt, dist, last);
             }
             (void)hipStreamSynchronize(ctx->stream);
             kcr_free(ctx, &rt);
@@ -1127,15 +1126,15 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(scope.alloc(&visited, rcap + 1));
             KC_HIP(ctx, hipMemsetAsync(visited, 0, rcap, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(cur, 0, 4 * KC_USTRIDE * 8, ctx->stream));
-            if (n_ent) hipLaunchKernelGGL(kc_shard_mark_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent, (const u8 *)flags8, visited);
-            hipLaunchKernelGGL((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, ncount, nstride, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
+            if (n_ent) KC_LAUNCH(kc_shard_mark_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, rlo, rcap, (const u64 *)entries, n_ent, (const u8 *)flags8, visited);
+            KC_LAUNCH((kc_shard_unvisited_kernel<false>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, ncount, nstride, (const u8 *)visited, rlo, rcap, (u64 *)nullptr, cur + 3 * KC_USTRIDE);
             KC_HIP(ctx, hipGetLastError());
             KC_TRY(read_words(ctx, cur + 3 * KC_USTRIDE, &nunvis, 1));
             KC_TRY(scope.alloc(&ulist, nunvis + 1)); KC_TRY(scope.alloc(&rows, (nunvis + 1) * RW));
             KC_HIP(ctx, hipMemsetAsync(cur + 3 * KC_USTRIDE, 0, 8, ctx->stream));
             if (nunvis) {
-                hipLaunchKernelGGL((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, ncount, nstride, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
-                hipLaunchKernelGGL((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows);
+                KC_LAUNCH((kc_shard_unvisited_kernel<true>), kc_grid2(rcap, 256), dim3(256), 0, ctx->stream, ncount, nstride, (const u8 *)visited, rlo, rcap, ulist, cur + 3 * KC_USTRIDE);
+                KC_LAUNCH((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows);
             }
             KC_HIP(ctx, hipGetLastError());
             {
@@ -1143,7 +1142,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 // cycles are ~5 GB of rows per rank; an input like that is not what the cycle rule was made for.)
                 u64 tot = nunvis;
                 KC_TRY(kcc_allreduce_sum(c, &tot, 1));
-                if (tot > ((u64)1 << 27)) return kc_fail(ctx, KC_E_CAPACITY, "too many k-mers on cycles for the replicated cycle rule (on some rank)");
+                if (tot > ((u64)1 << 27)) return kc_fail_agreed(ctx, KC_E_CAPACITY, "too many k-mers on cycles for the replicated cycle rule (on some rank)");
             }
             KC_TRY(allgather_rows(c, rows, nunvis, RW, &all, &n_all, nullptr));
             scope.release(visited); scope.release(ulist); scope.release(rows);
@@ -1152,7 +1151,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             const u64 cand_cap = n_all + 65536;
             int rc = kc_alloc(ctx, &cand, cand_cap * CW);
             if (rc == KC_OK) {
-                hipLaunchKernelGGL((kc_shard_cycle_cand_kernel<W>), kc_grid2(2 * n_all, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)all, n_all,
+                KC_LAUNCH((kc_shard_cycle_cand_kernel<W>), kc_grid2(2 * n_all, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)all, n_all,
                                    cand, cand_cap, cur + 2 * KC_USTRIDE);
                 rc = read_words(ctx, cur + 2 * KC_USTRIDE, &ncand, 1);
             }
@@ -1171,7 +1170,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             u64 *dfix = nullptr;
             KC_TRY(scope.alloc(&dfix, fix.size()));
             KC_HIP(ctx, hipMemcpyAsync(dfix, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL((kc_shard_apply_fix_kernel<W>), dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)dfix, (u64)(fix.size() / 2), 2 * rlo, 2 * rcap);
+            KC_LAUNCH((kc_shard_apply_fix_kernel<W>), dim3(kc_grid(fix.size() / 2, 256)), dim3(256), 0, ctx->stream, sv, link, (const u64 *)dfix, (u64)(fix.size() / 2), 2 * rlo, 2 * rcap);
             KC_HIP(ctx, hipGetLastError());
             KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
             scope.release(dfix);
@@ -1187,26 +1186,26 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         u64 *heads = nullptr, n_heads = 0;
         KC_TRY(scope.alloc(&heads, n_ent + 1));
         if (n_ent) {
-            hipLaunchKernelGGL(kc_shard_head_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, flags8);
+            KC_LAUNCH(kc_shard_head_flags_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, flags8);
             KC_TRY(kcu_select_flagged(ctx, iota, flags8, n_ent, heads, cur + 2 * KC_USTRIDE));
             KC_TRY(read_words(ctx, cur + 2 * KC_USTRIDE, &n_heads, 1));
         }
         u64 *req = nullptr, *rq = nullptr, *ans = nullptr, *tail = nullptr;
         u8 *dest = nullptr;
         KC_TRY(scope.alloc(&req, n_heads + 1)); KC_TRY(scope.alloc(&dest, n_heads + 1));
-        if (n_heads) hipLaunchKernelGGL(kc_shard_tailreq_kernel, dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, (const u64 *)heads, n_heads, (const u64 *)last, req, dest);
+        if (n_heads) KC_LAUNCH(kc_shard_tailreq_kernel, dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, (const u64 *)heads, n_heads, (const u64 *)last, req, dest);
         KcRoute rt;
         KC_TRY(kcr_build(c, dest, n_heads, &rt));
         int rc = kcr_forward(c, rt, req, 1, 1, &rq);
         if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv * (W + 1) + 1);
         if (rc == KC_OK && rt.n_recv)
-            hipLaunchKernelGGL((kc_shard_tailans_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)rq, rt.n_recv, (const u64 *)f_exit, ans);
+            KC_LAUNCH((kc_shard_tailans_kernel<W>), dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)rq, rt.n_recv, (const u64 *)f_exit, ans);
         if (rc == KC_OK) rc = kc_alloc(ctx, &tail, n_heads * (W + 1) + 1);
         if (rc == KC_OK) rc = kcr_backward(c, rt, ans, W + 1, tail);
         if (rc == KC_OK) rc = scope.alloc(&chains, (n_heads + 1) * CW);
         KC_HIP(ctx, hipMemsetAsync(cur, 0, 2 * 8, ctx->stream));
         if (rc == KC_OK && n_heads)
-            hipLaunchKernelGGL((kc_shard_chain_kernel<W>), dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)heads, n_heads,
+            KC_LAUNCH((kc_shard_chain_kernel<W>), dim3(kc_grid(n_heads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, complements, (const u64 *)heads, n_heads,
                                (const u64 *)entries, (const u64 *)dist, (const u64 *)last, (const u64 *)tail, chains, cur);
         u64 hc[2] = {0, 0};
         if (rc == KC_OK) rc = read_words(ctx, cur, hc, 2);
@@ -1225,7 +1224,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     u64 *all_chains = nullptr, S = 0;
     KC_TRY(allgather_rows(c, chains, n_chains, CW, &all_chains, &S, nullptr));
     scope.release(chains);
-    if (S * 5 >= N) { kc_release(ctx, all_chains); return kc_fail(ctx, KC_E_ARG, "too many simplitigs for the dense overlap graph (main.cpp:175): the sparse branch is not part of the hash-sharded path"); }
+    if (S * 5 >= N) { kc_release(ctx, all_chains); return kc_fail_agreed(ctx, KC_E_ARG, "too many simplitigs for the dense overlap graph (main.cpp:175): the sparse branch is not part of the hash-sharded path"); }
     kc_simplitigs *simp = new kc_simplitigs();
     simp->ctx = ctx; simp->k = k; simp->W = W; simp->n = S;
     struct SimpGuard { kc_simplitigs *s; ~SimpGuard() { if (s) kc_simplitigs_destroy(s); } } simpg{simp};
@@ -1235,19 +1234,19 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr, *nw = nullptr, *fin = nullptr, *idx = nullptr;
         KC_TRY(scope.alloc(&perm, S + 1)); KC_TRY(scope.alloc(&perm2, S + 1)); KC_TRY(scope.alloc(&kw, S + 1)); KC_TRY(scope.alloc(&kw2, S + 1));
         KC_TRY(scope.alloc(&nw, S + 1)); KC_TRY(scope.alloc(&fin, S + 1)); KC_TRY(scope.alloc(&idx, S + 1));
-        hipLaunchKernelGGL(kc_shard_iota_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, perm, S);
+        KC_LAUNCH(kc_shard_iota_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, perm, S);
         for (int word = 0; word < W; ++word) {
             int bits = 2 * k - 64 * word;
             if (bits <= 0) break;
             if (bits > 64) bits = 64;
-            hipLaunchKernelGGL(kc_shard_row_word_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, 3 + word, kw);
+            KC_LAUNCH(kc_shard_row_word_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, 3 + word, kw);
             KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, S, 0, bits, false));   // (no sync of its own: everything below queues behind it)
             std::swap(perm, perm2);
         }
         KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
         KC_TRY(kc_alloc(ctx, &simp->firstK, S * W + 1)); KC_TRY(kc_alloc(ctx, &simp->lastK, S * W + 1));
         KC_TRY(scope.alloc(&fin_sorted, S + 1)); KC_TRY(scope.alloc(&fin_simp, S + 1));
-        hipLaunchKernelGGL(kc_shard_simp_fill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, W, k, simp->lens, nw,
+        KC_LAUNCH(kc_shard_simp_fill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, W, k, simp->lens, nw,
                            simp->firstK, simp->lastK, fin, idx);
         KC_HIP(ctx, hipGetLastError());
         KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S, false));                       // woff[S] = words in total
@@ -1277,7 +1276,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     KC_TRY(scope.alloc(&simp_dest, S + 1)); KC_TRY(scope.alloc(&rank_rng, 2 * KC_MAX_RANKS_SH));
     KC_HIP(ctx, hipMemsetAsync(rank_rng, 0xff, KC_MAX_RANKS_SH * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(rank_rng + KC_MAX_RANKS_SH, 0, KC_MAX_RANKS_SH * 8, ctx->stream));
-    hipLaunchKernelGGL(kc_shard_simp_dest_kernel, dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)rk.dist, (const u64 *)rk.endv, rk.start, S, V, Ltot, G, simp_dest,
+    KC_LAUNCH(kc_shard_simp_dest_kernel, dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)rk.dist, (const u64 *)rk.endv, rk.start, S, V, Ltot, G, simp_dest,
                        rank_rng, rank_rng + KC_MAX_RANKS_SH, (const u64 *)rk.weight);
     u64 n_msg = 0;
     {
@@ -1285,14 +1284,14 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         u8 *mdest = nullptr;
         KC_TRY(scope.alloc(&mcount, n_ent + 2)); KC_TRY(scope.alloc(&moff, n_ent + 2));
         if (n_ent)
-            hipLaunchKernelGGL((kc_shard_msg_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
+            KC_LAUNCH((kc_shard_msg_kernel<false>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
                                (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, (const u64 *)link, nstride, set->bshift, W, (const u64 *)fin_sorted,
                                (const u64 *)fin_simp, S, (const u64 *)simp->lens, (const u64 *)simp->woff, (const u8 *)simp_dest, mcount, (const u64 *)nullptr, (u64 *)nullptr, (u8 *)nullptr);
         KC_TRY(kcu_exclusive_scan(ctx, mcount, moff, n_ent));
         KC_TRY(read_words(ctx, moff + n_ent, &n_msg, 1));
         KC_TRY(scope.alloc(&msgs, 2 * n_msg + 2)); KC_TRY(scope.alloc(&mdest, n_msg + 1));
         if (n_ent)
-            hipLaunchKernelGGL((kc_shard_msg_kernel<true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
+            KC_LAUNCH((kc_shard_msg_kernel<true>), dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, k, (const u64 *)entries, n_ent, (const u64 *)f_len, (const u64 *)dist,
                                (const u64 *)last, (const u32 *)f_stream, (const u64 *)pool, (const u32 *)chunk_next, (const u64 *)sv.keys, (const u64 *)link, nstride, set->bshift, W, (const u64 *)fin_sorted,
                                (const u64 *)fin_simp, S, (const u64 *)simp->lens, (const u64 *)simp->woff, (const u8 *)simp_dest, mcount, (const u64 *)moff, msgs, mdest);
         KC_HIP(ctx, hipGetLastError());
@@ -1300,7 +1299,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         KC_TRY(kcr_build(c, mdest, n_msg, &rt));
         int rc = kcr_forward(c, rt, msgs, 2, 2, &rmsgs);
         if (rc == KC_OK && rt.n_recv)
-            hipLaunchKernelGGL(kc_shard_place_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rmsgs, rt.n_recv, simp->words);
+            KC_LAUNCH(kc_shard_place_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rmsgs, rt.n_recv, simp->words);
         (void)hipStreamSynchronize(ctx->stream);
         kcr_free(ctx, &rt);
         kc_release(ctx, rmsgs);
@@ -1348,7 +1347,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         if (rc == KC_OK) rc = scope.alloc(&tcnt, ntile + 2);
         if (rc == KC_OK) rc = scope.alloc(&toff, ntile + 2);
         if (rc == KC_OK) {
-            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, false>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcapS,
+            KC_LAUNCH((kc_shard_mask_query_kernel<W, false>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcapS,
                                r->d_mask, tcnt, (const u64 *)nullptr, (u64 *)nullptr, (u64 *)nullptr, (u8 *)nullptr);
             rc = kcu_exclusive_scan(ctx, tcnt, toff, ntile);
             if (rc == KC_OK) rc = read_words(ctx, toff + ntile, &nqm, 1);
@@ -1357,18 +1356,18 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         if (rc == KC_OK) rc = scope.alloc(&qpos, nqm + 1);
         if (rc == KC_OK) rc = scope.alloc(&qdest, nqm + 1);
         if (rc == KC_OK)
-            hipLaunchKernelGGL((kc_shard_mask_query_kernel<W, true>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcapS,
+            KC_LAUNCH((kc_shard_mask_query_kernel<W, true>), gq, dim3(256), 0, ctx->stream, (const char *)r->d_out, n, (const char *)halo, lo, Ltot, k, complements, sv, rcapS,
                                r->d_mask, tcnt, (const u64 *)toff, qkeys, qpos, qdest);
         KcRoute rt;
         if (rc == KC_OK) rc = kcr_build(c, qdest, nqm, &rt);
         if (rc == KC_OK) rc = kcr_forward(c, rt, qkeys, W, W, &rq);
         if (rc == KC_OK) rc = kc_alloc(ctx, &ans, rt.n_recv + 1);
         if (rc == KC_OK && rt.n_recv)
-            hipLaunchKernelGGL((kc_shard_mask_answer_kernel<W>), kc_grid2(rt.n_recv, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, ans);
+            KC_LAUNCH((kc_shard_mask_answer_kernel<W>), kc_grid2(rt.n_recv, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)rq, rt.n_recv, ans);
         if (rc == KC_OK) rc = kc_alloc(ctx, &ansb, nqm + 1);
         if (rc == KC_OK) rc = kcr_backward(c, rt, ans, 1, ansb);
         if (rc == KC_OK && nqm)
-            hipLaunchKernelGGL(kc_shard_mask_apply_kernel, kc_grid2(nqm, 256), dim3(256), 0, ctx->stream, (const u64 *)qpos, (const u64 *)ansb, nqm, r->d_mask);
+            KC_LAUNCH(kc_shard_mask_apply_kernel, kc_grid2(nqm, 256), dim3(256), 0, ctx->stream, (const u64 *)qpos, (const u64 *)ansb, nqm, r->d_mask);
         (void)hipStreamSynchronize(ctx->stream);
         kcr_free(ctx, &rt);
         kc_release(ctx, rq); kc_release(ctx, ans); kc_release(ctx, ansb);
@@ -1412,11 +1411,11 @@ template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const
     u64 *rows = nullptr, *all = nullptr, S = 0;
     std::vector<u64> counts;
     KC_TRY(scope.alloc(&rows, (n_rec + 1) * RW));
-    if (n_rec) hipLaunchKernelGGL(kc_shard_srows_kernel, dim3(kc_grid(n_rec, 256)), dim3(256), 0, ctx->stream, (const u64 *)mine->lens, (const u64 *)mine->firstK, (const u64 *)mine->lastK, n_rec, W, rows);
+    if (n_rec) KC_LAUNCH(kc_shard_srows_kernel, dim3(kc_grid(n_rec, 256)), dim3(256), 0, ctx->stream, (const u64 *)mine->lens, (const u64 *)mine->firstK, (const u64 *)mine->lastK, n_rec, W, rows);
     KC_HIP(ctx, hipGetLastError());
     KC_TRY(allgather_rows(c, rows, n_rec, RW, &all, &S, &counts));
     scope.release(rows);
-    if (S == 0) { kc_release(ctx, all); return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty"); }
+    if (S == 0) { kc_release(ctx, all); return kc_fail_agreed(ctx, KC_E_EMPTY, "input cannot be empty"); }
     u64 g0 = 0;
     for (int p = 0; p < me; ++p) g0 += counts[p];
     // the replicated simplitig list (record order: rank by rank)
@@ -1427,7 +1426,7 @@ template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const
     KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
     KC_TRY(kc_alloc(ctx, &simp->firstK, S * W + 1)); KC_TRY(kc_alloc(ctx, &simp->lastK, S * W + 1));
     KC_TRY(scope.alloc(&nw, S + 1));
-    hipLaunchKernelGGL(kc_shard_sfill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all, S, W, simp->lens, nw, simp->firstK, simp->lastK);
+    KC_LAUNCH(kc_shard_sfill_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all, S, W, simp->lens, nw, simp->firstK, simp->lastK);
     KC_HIP(ctx, hipGetLastError());
     KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S, false));
     u64 wsum = 0, bases_local = n_rec ? mine->total_bases : 0, bases = 0;
@@ -1456,7 +1455,7 @@ template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const
     KC_TRY(scope.alloc(&simp_dest, S + 1)); KC_TRY(scope.alloc(&rank_rng, 2 * KC_MAX_RANKS_SH));
     KC_HIP(ctx, hipMemsetAsync(rank_rng, 0xff, KC_MAX_RANKS_SH * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(rank_rng + KC_MAX_RANKS_SH, 0, KC_MAX_RANKS_SH * 8, ctx->stream));
-    hipLaunchKernelGGL(kc_shard_simp_dest_kernel, dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)rk.dist, (const u64 *)rk.endv, rk.start, S, V, Ltot, G, simp_dest,
+    KC_LAUNCH(kc_shard_simp_dest_kernel, dim3(kc_grid(V, 256)), dim3(256), 0, ctx->stream, (const u64 *)rk.dist, (const u64 *)rk.endv, rk.start, S, V, Ltot, G, simp_dest,
                        rank_rng, rank_rng + KC_MAX_RANKS_SH, (const u64 *)rk.weight);
     {
         const u64 n_msg = n_rec ? mine->nwords : 0;
@@ -1464,14 +1463,14 @@ template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const
         u8 *mdest = nullptr;
         KC_TRY(scope.alloc(&msgs, 2 * n_msg + 2)); KC_TRY(scope.alloc(&mdest, n_msg + 1));
         if (n_msg)
-            hipLaunchKernelGGL(kc_shard_smsg_kernel, dim3(kc_grid(n_msg, 256)), dim3(256), 0, ctx->stream, (const u64 *)mine->words, (const u64 *)mine->woff, n_rec, n_msg, g0,
+            KC_LAUNCH(kc_shard_smsg_kernel, dim3(kc_grid(n_msg, 256)), dim3(256), 0, ctx->stream, (const u64 *)mine->words, (const u64 *)mine->woff, n_rec, n_msg, g0,
                                (const u64 *)simp->woff, (const u8 *)simp_dest, msgs, mdest);
         KC_HIP(ctx, hipGetLastError());
         KcRoute rt;
         KC_TRY(kcr_build(c, mdest, n_msg, &rt));
         int rc = kcr_forward(c, rt, msgs, 2, 2, &rmsgs);
         if (rc == KC_OK && rt.n_recv)
-            hipLaunchKernelGGL(kc_shard_place_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rmsgs, rt.n_recv, simp->words);
+            KC_LAUNCH(kc_shard_place_kernel, dim3(kc_grid(rt.n_recv, 256)), dim3(256), 0, ctx->stream, (const u64 *)rmsgs, rt.n_recv, simp->words);
         (void)hipStreamSynchronize(ctx->stream);
         kcr_free(ctx, &rt);
         kc_release(ctx, rmsgs);
@@ -1500,9 +1499,10 @@ template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const
 extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out) {
     if (!ctx || !comm || !out || (!seq && len)) return KC_E_ARG;
     *out = nullptr;
+    ctx->err_agreed = false;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
-    if (k < 18 || k > 127) return kc_fail(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
-    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail(ctx, KC_E_ARG, "-S is not part of the hash-sharded path (use kc_compute)");
+    if (k < 18 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
+    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail_agreed(ctx, KC_E_ARG, "-S is not part of the hash-sharded path (use kc_compute)");
     const int min_frequency = ((flags >> 8) & 0xff) ? (int)((flags >> 8) & 0xff) : 1;   // -z (parser.h:122-141): counted where all occurrences of a k-mer meet, at its owner
     const int want_mask = (flags & KC_FLAG_WANT_MASK) ? 1 : 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
@@ -1532,9 +1532,10 @@ extern "C" int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const v
                                              kc_result **out) {
     if (!ctx || !comm || !out || (!seq && len) || (!offsets && n_records)) return KC_E_ARG;
     *out = nullptr;
+    ctx->err_agreed = false;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
-    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
-    if (flags & KC_FLAG_WANT_MASK) return kc_fail(ctx, KC_E_ARG, "-S with -M is not part of the hash-sharded path");
+    if (k < 1 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "k must be in 1..127");
+    if (flags & KC_FLAG_WANT_MASK) return kc_fail_agreed(ctx, KC_E_ARG, "-S with -M is not part of the hash-sharded path");
     if (((flags >> 8) & 0xff) > 1) return kc_fail(ctx, KC_E_ARG, "Inputting simplitigs is not compatible with frequency filterring.");
     KC_HIP(ctx, hipSetDevice(ctx->device));
     const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;

@@ -759,7 +759,7 @@ static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k
     KC_TRY(scope.alloc(&perm2, n));
     KC_TRY(scope.alloc(&kw, n));
     KC_TRY(scope.alloc(&kw2, n));
-    hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
+    KC_LAUNCH(kc_iota_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, perm, n);
     // many keys (read sets: one chain per read): one MSD bucket pass + LDS sorts (kcu_sort_rows_bucketed); the LSD passes
     // below remain for small inputs and for key sets so skewed that a bucket overflows
     if (n >= 1024 && !getenv("KC_NO_BUCKET_SORT")) {
@@ -778,7 +778,7 @@ static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k
         int bits = 2 * k - 64 * word;
         if (bits <= 0) break;
         if (bits > 64) bits = 64;
-        hipLaunchKernelGGL(kc_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, d_keys, perm, n, W, word, kw);
+        KC_LAUNCH(kc_gather_word_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, d_keys, perm, n, W, word, kw);
         KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, n, 0, bits));
         std::swap(perm, perm2);
     }
@@ -863,7 +863,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), nt, lds);
                 fprintf(stderr, "[simp] probe kernel: %d threads, %zu bytes of LDS per workgroup, %d workgroups per CU\n", nt, lds, nb);
             }
-            hipLaunchKernelGGL(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware | (getenv("KC_PROBE_LISTED_GLOBAL") ? 2 : 0), heads_sh, heads_shard_cap,
+            KC_LAUNCH(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware | (getenv("KC_PROBE_LISTED_GLOBAL") ? 2 : 0), heads_sh, heads_shard_cap,
                                heads_cursors, branch_sh, branch_shard_cap, branch_cursors, spill, spill_cap, spill_cursor, ShLists{});
             return KC_OK;
         };
@@ -876,35 +876,35 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     } else {
         // plain hashing (k < 18): per-key homes, 8 lookups per k-mer
         const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);
-        hipLaunchKernelGGL((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), 0, ctx->stream, sv, link, k, compl_, xcd_aware,
+        KC_LAUNCH((kc_choose_dense_kernel<W, 0>), dim3(cgrid), dim3(256), 0, ctx->stream, sv, link, k, compl_, xcd_aware,
                            heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors, 0);
     }
     KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     if (set->mlen) {
         // the ports the block kernel handed on (window search not applicable, external list full); if even their list overflowed,
         // round 1 is redone by generic lookups
-        hipLaunchKernelGGL((kc_probe_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)spill, spill_cap,
+        KC_LAUNCH((kc_probe_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)spill, spill_cap,
                            (const u64 *)spill_cursor, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
         u64 nspill = 0;
         KC_TRY(read_u64(ctx, spill_cursor, &nspill));
         if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] round 1: %llu ports handed to the generic lookups\n", (unsigned long long)nspill);
         if (nspill > spill_cap) {
             KC_HIP(ctx, hipMemsetAsync(shard_cur, 0, 2 * KC_NSHARD * KC_SHARD_STRIDE * 8, ctx->stream));
-            hipLaunchKernelGGL((kc_probe_generic_kernel<W>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, link, k, compl_, heads_sh, heads_shard_cap,
+            KC_LAUNCH((kc_probe_generic_kernel<W>), kc_grid2(cap, 256), dim3(256), 0, ctx->stream, sv, link, k, compl_, heads_sh, heads_shard_cap,
                                heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
         }
         scope.release(spill);
     }
-    hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
+    KC_LAUNCH(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)heads_sh, heads_shard_cap,
                        (const u64 *)heads_cursors, heads, heads_cap, heads_cursor);
-    hipLaunchKernelGGL(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)branch_sh, branch_shard_cap,
+    KC_LAUNCH(kc_gather_shards_kernel, dim3(8, KC_NSHARD), dim3(256), 0, ctx->stream, (const u64 *)branch_sh, branch_shard_cap,
                        (const u64 *)branch_cursors, branch, work_cap, branch_cursor);
     u64 nbranch = 0, nwork = 0, rounds = 1;
     KC_TRY(read_u64(ctx, branch_cursor, &nbranch));
     if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] round 1: %llu branch ports (list of %llu)\n", (unsigned long long)nbranch, (unsigned long long)work_cap);
     scope.release(heads_sh); scope.release(branch_sh); scope.release(shard_cur);
     if (nbranch && nbranch <= work_cap) {
-        hipLaunchKernelGGL((kc_reject_kernel<W>), dim3(kc_grid(nbranch, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)branch,
+        KC_LAUNCH((kc_reject_kernel<W>), dim3(kc_grid(nbranch, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)branch,
                            nbranch, work_a, work_cap, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
@@ -912,7 +912,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         // heavily branching graph: exact scan of all round-1 choices (count, then mark + list); rejections a partial
         // kc_reject_kernel run may already have set are simply found again
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<false>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, link, NID, ncount, nstride,
+        KC_LAUNCH((kc_mutual_scan_kernel<false>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, link, NID, ncount, nstride,
                            (u64 *)nullptr, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
         scope.release(work_a); scope.release(work_b);
@@ -920,17 +920,17 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_TRY(scope.alloc(&work_a, work_cap));
         KC_TRY(scope.alloc(&work_b, work_cap));
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL((kc_mutual_scan_kernel<true>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, link, NID, ncount, nstride, work_a,
+        KC_LAUNCH((kc_mutual_scan_kernel<true>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, link, NID, ncount, nstride, work_a,
                            work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));
     }
     while (nwork) {
         ++rounds;
         if (rounds > 100000) return kc_fail(ctx, KC_E_NO_DEVICE, "simplitig matching did not converge");
-        hipLaunchKernelGGL((kc_choose_kernel<W, false, 0>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
+        KC_LAUNCH((kc_choose_kernel<W, false, 0>), dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, sv, link, k, compl_,
                            (const u64 *)work_a, nwork, 0, heads, heads_cap, heads_cursor);
         KC_HIP(ctx, hipMemsetAsync(work_cursor, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(kc_accept_kernel, dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
+        KC_LAUNCH(kc_accept_kernel, dim3(kc_grid(nwork, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)work_a,
                            nwork, work_b, work_cap, work_cursor);
         KC_TRY(read_u64(ctx, work_cursor, &nwork));   // shrinks every round, so work_cap still bounds it
         std::swap(work_a, work_b);
@@ -947,12 +947,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (nheads > heads_cap) {   // overflow: exact count + fill
         scope.release(heads);
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<false>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, NID, ncount, nstride, compl_,
+        KC_LAUNCH((kc_heads_kernel<false>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, NID, ncount, nstride, compl_,
                            (u64 *)nullptr, cnt);
         KC_TRY(read_u64(ctx, cnt, &nheads));
         KC_TRY(scope.alloc(&heads, nheads + 1));
         KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
-        hipLaunchKernelGGL((kc_heads_kernel<true>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, NID, ncount, nstride, compl_, heads,
+        KC_LAUNCH((kc_heads_kernel<true>), kc_grid2((NID + 31) / 32, 256), dim3(256), 0, ctx->stream, (const u64 *)link, NID, ncount, nstride, compl_, heads,
                            cnt);
     }
     // ---- chain discovery.  Pass 0 works on the heads round 1..n produced.  K-mers on cycles (every port matched) are
@@ -984,13 +984,13 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         const u64 *sc = mode == 2 ? (const u64 *)seg_chain : (const u64 *)nullptr;
         const u32 st = mode == 0 ? 0u : sparse_stride;
         if (hop) {
-            if (mode == 0) hipLaunchKernelGGL(kc_segment_hop_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
-            else if (mode == 1) hipLaunchKernelGGL(kc_segment_hop_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
-            else hipLaunchKernelGGL(kc_segment_hop_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
+            if (mode == 0) KC_LAUNCH(kc_segment_hop_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
+            else if (mode == 1) KC_LAUNCH(kc_segment_hop_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
+            else KC_LAUNCH(kc_segment_hop_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, nstride, compl_);
         } else {
-            if (mode == 0) hipLaunchKernelGGL(kc_segment_walk_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
-            else if (mode == 1) hipLaunchKernelGGL(kc_segment_walk_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
-            else hipLaunchKernelGGL(kc_segment_walk_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
+            if (mode == 0) KC_LAUNCH(kc_segment_walk_kernel<0>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
+            else if (mode == 1) KC_LAUNCH(kc_segment_walk_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
+            else KC_LAUNCH(kc_segment_walk_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
         }
     };
     // (more k-mers per chain head than the limit: some chain is longer than it, whatever the per-chain pass would find -- the 4 ms it
@@ -1030,10 +1030,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_HIP(ctx, hipMemsetAsync(fcur, 0, 2 * 64 * 16 * 8, ctx->stream));
             const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
             KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
+            KC_LAUNCH((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
                                flog, log_cap, fcur + 64 * 16, fblog);
             const KcFrag fr{fpool, fbase, 0, 0};
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
+            KC_LAUNCH((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                KC_CHAIN_LIMIT, rec, fr);
             KC_HIP(ctx, hipGetLastError());
@@ -1048,7 +1048,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             if (!clean) {
                 // a chain beyond the limit, or k-mers on cycles (reached from no head): put the replaced link words back and
                 // let the classic flow below run on the original links
-                hipLaunchKernelGGL(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog,
+                KC_LAUNCH(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog,
                                    (const u64 *)fblog, set->bshift, (u64)0, nstride);
                 KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
                 if (hf[7]) known_long = true;
@@ -1058,11 +1058,11 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         }
         if (nheads && !known_long && !use_frag) {
             if (want_rec)
-                hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
+                KC_LAUNCH((kc_walk_measure_kernel<W, false, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                    (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                    KC_CHAIN_LIMIT, rec);
             else
-                hipLaunchKernelGGL((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
+                KC_LAUNCH((kc_walk_measure_kernel<W, false, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                    (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                    KC_CHAIN_LIMIT, no_rec);
         }
@@ -1095,7 +1095,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 }
                 const size_t lds = (size_t)2 * ((size_t)1 << set->bshift) * 4 + KC_FRAG_LONGS * 8 + KC_FRAG_ENTRIES * 2;
                 KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_frag_contract_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, hpool, pool_cap, hcur, hbase,
+                KC_LAUNCH((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, hpool, pool_cap, hcur, hbase,
                                    hlog, log_cap, hcur + 64 * 16, hblog, (u64 *)nullptr, (u64)0, (u64 *)nullptr, 1, hop ? 1 : 0);
                 hop = true;
             }
@@ -1107,10 +1107,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_HIP(ctx, hipMemcpyAsync(starts_raw, heads, nheads * 8, hipMemcpyDeviceToDevice, ctx->stream));
             KC_HIP(ctx, hipMemcpyAsync(cnt + 6, &nheads, 8, hipMemcpyHostToDevice, ctx->stream));
             if (hop)
-                hipLaunchKernelGGL(kc_split_starts_hop_kernel, kc_grid2(nsplit_hop, 256), dim3(256), 0, ctx->stream, (const u64 *)link,
+                KC_LAUNCH(kc_split_starts_hop_kernel, kc_grid2(nsplit_hop, 256), dim3(256), 0, ctx->stream, (const u64 *)link,
                                    NID, ncount, nstride, compl_, starts_raw, cnt + 6);
             else
-                hipLaunchKernelGGL(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
+                KC_LAUNCH(kc_split_starts_kernel, dim3(kc_grid(nsplit_max, 256)), dim3(256), 0, ctx->stream, (const u64 *)link,
                                    NID, ncount, nstride, compl_, starts_raw, cnt + 6);
             KC_TRY(read_u64(ctx, cnt + 6, &nstarts));
             int start_bits = 2;   // (a start is node id << 1 | orientation)
@@ -1132,7 +1132,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             }
             if (nstarts) {
                 seg_walk(seg_marks ? 1 : 0, seg_marks);
-                hipLaunchKernelGGL((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
+                KC_LAUNCH((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                                    (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
                                    seg_off, chain_head, chain_len, chain_key, cnt);
             }
@@ -1164,7 +1164,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 seg_walk(2, visited);
             }
         } else if (nheads) {
-            hipLaunchKernelGGL((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
+            KC_LAUNCH((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,
                                compl_, (const u64 *)heads, nheads, visited, chain_head, chain_len, chain_key, cnt, ~(u64)0, no_rec);
         }
         // (hop: the links stay contracted; kc_frag_unvisited_kernel works from the log and restores the blocks that hold cycles)
@@ -1180,7 +1180,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             for (int attempt = 0; attempt < 2; ++attempt) {
                 KC_TRY(scope.alloc(&ulist, ucap));
                 KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-                hipLaunchKernelGGL((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, link, compl_,
+                KC_LAUNCH((kc_frag_unvisited_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_unv, ctx->stream, sv, link, compl_,
                                    (const u8 *)visited, ulist, ucap, cnt + 1, hop ? (const u64 *)hlog : (const u64 *)nullptr, hop ? hblog : (u64 *)nullptr);
                 KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
                 if (nunvis <= ucap) break;
@@ -1188,12 +1188,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 ucap = nunvis;
             }
         } else {
-            hipLaunchKernelGGL((kc_unvisited_kernel<false>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited,
+            KC_LAUNCH((kc_unvisited_kernel<false>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited,
                                (u64 *)nullptr, cnt + 1);
             KC_TRY(read_u64(ctx, cnt + 1, &nunvis));
             KC_TRY(scope.alloc(&ulist, nunvis + 1));
             KC_HIP(ctx, hipMemsetAsync(cnt + 1, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_unvisited_kernel<true>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited, ulist,
+            KC_LAUNCH((kc_unvisited_kernel<true>), kc_grid2(NID, 256), dim3(256), 0, ctx->stream, NID, ncount, nstride, (const u8 *)visited, ulist,
                                cnt + 1);
         }
         if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] pass %d: %llu k-mers on cycles (%s marks)\n", pass, (unsigned long long)nunvis, sparse_marks ? "sparse" : "dense");
@@ -1206,8 +1206,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             const u64 cand_cap = nunvis + 65536;
             KC_TRY(scope.alloc(&rows_d, nunvis * RW)); KC_TRY(scope.alloc(&cand_d, cand_cap * CW));
             KC_HIP(ctx, hipMemsetAsync(cnt + 6, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows_d);
-            hipLaunchKernelGGL((kc_cycle_cand_kernel<W>), kc_grid2(2 * nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, compl_, (const u64 *)ulist, nunvis,
+            KC_LAUNCH((kc_cycle_rows_kernel<W, true>), kc_grid2(nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, (const u64 *)ulist, nunvis, rows_d);
+            KC_LAUNCH((kc_cycle_cand_kernel<W>), kc_grid2(2 * nunvis, 256), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, compl_, (const u64 *)ulist, nunvis,
                                cand_d, cand_cap, cnt + 6);
             KC_HIP(ctx, hipGetLastError());
             u64 ncand = 0;
@@ -1224,8 +1224,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_TRY(scope.alloc(&heads2, nheads + nfix + 1));
             KC_HIP(ctx, hipMemcpyAsync(fix_d, fix.data(), fix.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
-            hipLaunchKernelGGL((kc_cycle_fix_kernel<W>), kc_grid2(nfix, 256), dim3(256), 0, ctx->stream, sv, link, (const u64 *)fix_d, nfix);
-            hipLaunchKernelGGL(kc_heads_refresh_kernel, kc_grid2(nheads + nfix, 256), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)heads, nheads, (const u64 *)fix_d, nfix,
+            KC_LAUNCH((kc_cycle_fix_kernel<W>), kc_grid2(nfix, 256), dim3(256), 0, ctx->stream, sv, link, (const u64 *)fix_d, nfix);
+            KC_LAUNCH(kc_heads_refresh_kernel, kc_grid2(nheads + nfix, 256), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)heads, nheads, (const u64 *)fix_d, nfix,
                                compl_, heads2, cnt);
             KC_HIP(ctx, hipGetLastError());
             KC_TRY(read_u64(ctx, cnt, &nheads));   // (synchronises: fix is a host vector)
@@ -1257,7 +1257,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->firstK, S * W);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->lastK, S * W);
     if (rc != KC_OK) return rc;
-    hipLaunchKernelGGL(kc_chain_sizes_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)chain_len, (const u64 *)perm, S, k,
+    KC_LAUNCH(kc_chain_sizes_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)chain_len, (const u64 *)perm, S, k,
                        s->lens, nwords);
     KC_TRY(kcu_exclusive_scan(ctx, nwords, s->woff, S));   // (woff[S] = total)
     KC_TRY(read_u64(ctx, s->woff + S, &s->nwords));
@@ -1268,23 +1268,23 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         u64 *rank = nullptr;
         KC_TRY(scope.alloc(&rank, S + 1));
         KC_HIP(ctx, hipMemsetAsync(s->words, 0, (s->nwords + 1) * 8, ctx->stream));
-        hipLaunchKernelGGL(kc_inverse_perm_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)perm, S, rank);
+        KC_LAUNCH(kc_inverse_perm_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)perm, S, rank);
         if (hop)
-            hipLaunchKernelGGL((kc_segment_hop_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)hpool,
+            KC_LAUNCH((kc_segment_hop_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)hpool,
                                (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
                                s->words, s->firstK, s->lastK);
         else
-            hipLaunchKernelGGL((kc_segment_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
+            KC_LAUNCH((kc_segment_emit_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
                                (const u64 *)starts, nstarts, (const u64 *)seg_chain, (const u64 *)seg_off, (const u64 *)rank, (const u64 *)s->woff,
                                s->words, s->firstK, s->lastK);
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(rank);
     } else if (use_stream) {
-        hipLaunchKernelGGL((kc_stream_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
+        KC_LAUNCH((kc_stream_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
                            (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
                            (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
     } else {
-        hipLaunchKernelGGL((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
+        KC_LAUNCH((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
                            (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
     }
     scope.release(starts); scope.release(seg_len); scope.release(seg_next); scope.release(seg_tail); scope.release(seg_chain);
@@ -1415,13 +1415,13 @@ int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 le
     KC_HIP(ctx, hipMemcpyAsync(s->woff, woff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     KC_HIP(ctx, hipMemcpyAsync(d_recoff, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(kc_pack_records_kernel, dim3(kc_grid(w, 256)), dim3(256), 0, ctx->stream, d_seq, (const u64 *)d_recoff,
+    KC_LAUNCH(kc_pack_records_kernel, dim3(kc_grid(w, 256)), dim3(256), 0, ctx->stream, d_seq, (const u64 *)d_recoff,
                        (const u64 *)s->lens, (const u64 *)s->woff, n, w, s->words, bad);
     unsigned g = kc_grid(n, 256);
     switch (W) {
-        case 1: hipLaunchKernelGGL((kc_end_kmers_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
-        case 2: hipLaunchKernelGGL((kc_end_kmers_kernel<2>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
-        default: hipLaunchKernelGGL((kc_end_kmers_kernel<4>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
+        case 1: KC_LAUNCH((kc_end_kmers_kernel<1>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
+        case 2: KC_LAUNCH((kc_end_kmers_kernel<2>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
+        default: KC_LAUNCH((kc_end_kmers_kernel<4>), dim3(g), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff, (const u64 *)s->lens, n, k, s->firstK, s->lastK); break;
     }
     KC_HIP(ctx, hipGetLastError());
     u64 hbad = 0;
@@ -1477,7 +1477,7 @@ extern "C" int kc_simplitigs_export(kc_simplitigs *s, char *seqs, uint64_t *offs
     KC_TRY(kc_alloc(ctx, &d_off, s->n + 1));
     KC_TRY(kc_alloc(ctx, &d_out, o + 1));
     KC_HIP(ctx, hipMemcpyAsync(d_off, offsets, (s->n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(kc_unpack_kernel, dim3(kc_grid(s->n * 64, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+    KC_LAUNCH(kc_unpack_kernel, dim3(kc_grid(s->n * 64, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
                        (const u64 *)s->lens, (const u64 *)d_off, s->n, d_out);
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipMemcpyAsync(seqs, d_out, o, hipMemcpyDeviceToHost, ctx->stream));
@@ -1516,7 +1516,7 @@ int kcp_insert_simplitig_kmers(kc_set *set, kc_simplitigs *s) {
     KC_TRY(kc_alloc(ctx, &brk, nbrk + 1));
     KC_TRY(kc_alloc(ctx, &low, nbrk + 1));
     KC_HIP(ctx, hipMemsetAsync(low, 0, (nbrk + 1) * 8, ctx->stream));
-    hipLaunchKernelGGL(kc_padding_breaks_kernel, dim3(kc_grid(nbrk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->woff,
+    KC_LAUNCH(kc_padding_breaks_kernel, dim3(kc_grid(nbrk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->woff,
                        (const u64 *)s->lens, s->n, s->nwords, brk, nbrk);
     int rc = kcs_insert_packed(set, s->words, brk, low, s->nwords * 32, 0);
     if (rc == KC_OK) rc = kcs_refresh_size(set);
@@ -1570,7 +1570,7 @@ template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
     u64 *cnt = nullptr, *koff = nullptr;
     KC_TRY(kc_alloc(ctx, &cnt, n + 1));
     KC_TRY(kc_alloc(ctx, &koff, n + 1));
-    hipLaunchKernelGGL(kc_kmer_counts_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->lens, n, k, cnt);
+    KC_LAUNCH(kc_kmer_counts_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->lens, n, k, cnt);
     KC_TRY(kcu_exclusive_scan(ctx, cnt, koff, n));   // (koff[n] = total)
     u64 nk = 0;
     KC_TRY(read_u64(ctx, koff + n, &nk));
@@ -1579,9 +1579,9 @@ template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
     KC_TRY(kc_alloc(ctx, &kmers, nk * W));
     KC_TRY(kc_alloc(ctx, &sk, nk)); KC_TRY(kc_alloc(ctx, &sk2, nk));
     KC_TRY(kc_alloc(ctx, &perm, nk)); KC_TRY(kc_alloc(ctx, &perm2, nk));
-    hipLaunchKernelGGL((kc_expand_kmers_kernel<W>), dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words,
+    KC_LAUNCH((kc_expand_kmers_kernel<W>), dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, (const u64 *)s->words,
                        (const u64 *)s->woff, (const u64 *)s->lens, (const u64 *)koff, n, k, nk, kmers, sk);
-    hipLaunchKernelGGL(kc_iota_kernel, dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, perm, nk);
+    KC_LAUNCH(kc_iota_kernel, dim3(kc_grid(nk, 256)), dim3(256), 0, ctx->stream, perm, nk);
     KC_TRY(kcu_sort_pairs(ctx, sk, sk2, perm, perm2, nk, 0, 8));
     kc_simplitigs *r = new kc_simplitigs();
     int wpk = k / 32 + 1;
@@ -1592,7 +1592,7 @@ template <int W> static int to_sparse_w(kc_simplitigs *s, kc_simplitigs **out) {
     if (rc == KC_OK) rc = kc_alloc(ctx, &r->firstK, nk * W);
     if (rc == KC_OK) rc = kc_alloc(ctx, &r->lastK, nk * W);
     if (rc != KC_OK) { kc_simplitigs_destroy(r); return rc; }
-    hipLaunchKernelGGL((kc_sparse_fill_kernel<W>), dim3(kc_grid(nk + 1, 256)), dim3(256), 0, ctx->stream, (const u64 *)kmers,
+    KC_LAUNCH((kc_sparse_fill_kernel<W>), dim3(kc_grid(nk + 1, 256)), dim3(256), 0, ctx->stream, (const u64 *)kmers,
                        (const u64 *)perm2, nk, k, wpk, r->lens, r->woff, r->words, r->firstK, r->lastK);
     KC_HIP(ctx, hipGetLastError());
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -32,16 +32,16 @@ int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n, bool sync) {
     if (n == 0) { KC_HIP(ctx, hipMemsetAsync(out, 0, 8, ctx->stream)); return KC_OK; }
     const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
     if (ntiles == 1) {
-        hipLaunchKernelGGL(kc_scan_tile_kernel, dim3(1), dim3(256), 0, ctx->stream, in, n, (const u64 *)nullptr, out, (u64)1);
+        KC_LAUNCH(kc_scan_tile_kernel, dim3(1), dim3(256), 0, ctx->stream, in, n, (const u64 *)nullptr, out, (u64)1);
         KC_HIP(ctx, hipGetLastError());
         return KC_OK;
     }
     u64 *sums = nullptr;
     KC_TRY(kc_alloc(ctx, &sums, ntiles + 1));
-    hipLaunchKernelGGL(kc_scan_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, sums);
+    KC_LAUNCH(kc_scan_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, sums);
     int rc = kcu_exclusive_scan(ctx, sums, sums, ntiles, sync);
     if (rc == KC_OK) {
-        hipLaunchKernelGGL(kc_scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, (const u64 *)sums, out, ntiles);
+        KC_LAUNCH(kc_scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, (const u64 *)sums, out, ntiles);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "scan launch failed");
     }
     // (sync = false: the temporaries go back to the pool at once; whoever gets them next works on the same stream, behind us)
@@ -80,10 +80,10 @@ int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *
     const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
     u64 *counts = nullptr;
     KC_TRY(kc_alloc(ctx, &counts, ntiles + 1));
-    hipLaunchKernelGGL(kc_flag_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, flags, n, counts);
+    KC_LAUNCH(kc_flag_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, flags, n, counts);
     int rc = kcu_exclusive_scan(ctx, counts, counts, ntiles, sync);
     if (rc == KC_OK) {
-        hipLaunchKernelGGL(kc_flag_write_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, flags, n, (const u64 *)counts, out);
+        KC_LAUNCH(kc_flag_write_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, flags, n, (const u64 *)counts, out);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "compaction launch failed");
         if (rc == KC_OK && d_total && hipMemcpyAsync(d_total, counts + ntiles, 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     }
@@ -170,10 +170,10 @@ int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *va
         const bool to_out = ((passes - 1 - p) & 1) == 0;
         u64 *dk = to_out ? keys_out : tk, *dv = to_out ? vals_out : tv;
         const int shift = begin_bit + 4 * p;
-        hipLaunchKernelGGL(kc_radix_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, n, shift, ntiles, counts);
+        KC_LAUNCH(kc_radix_hist_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, n, shift, ntiles, counts);
         rc = kcu_exclusive_scan(ctx, counts, counts, 16 * ntiles, sync);
         if (rc != KC_OK) break;
-        hipLaunchKernelGGL(kc_radix_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, sv, n, shift, ntiles, (const u64 *)counts, dk, dv);
+        KC_LAUNCH(kc_radix_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, sk, sv, n, shift, ntiles, (const u64 *)counts, dk, dv);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "radix sort launch failed");
         sk = dk; sv = dv;
     }
@@ -301,12 +301,12 @@ int kcu_sort_rows_bucketed(kc_ctx *ctx, const u64 *keys, const u64 *ids, u64 n, 
     if (rc != KC_OK) return done(rc);
     if (hipMemsetAsync(counts, 0, (size_t)nb * cstride * 4, ctx->stream) != hipSuccess || hipMemsetAsync(d_flag, 0, 8, ctx->stream) != hipSuccess)
         return done(kc_fail(ctx, KC_E_NO_DEVICE, "memset failed"));
-    hipLaunchKernelGGL(kc_bkt_hist_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, n, W, total_bits, nb_bits, counts, cstride);
-    hipLaunchKernelGGL(kc_bkt_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)counts, nb, cap, offsets, cursors, d_flag, cstride);
-    hipLaunchKernelGGL(kc_bkt_scatter_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, n, W, total_bits, nb_bits, cursors, tk, tv, cstride);
+    KC_LAUNCH(kc_bkt_hist_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, n, W, total_bits, nb_bits, counts, cstride);
+    KC_LAUNCH(kc_bkt_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const u32 *)counts, nb, cap, offsets, cursors, d_flag, cstride);
+    KC_LAUNCH(kc_bkt_scatter_kernel, dim3(kc_grid(n, 256)), dim3(256), 0, ctx->stream, keys, ids, n, W, total_bits, nb_bits, cursors, tk, tv, cstride);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kc_bkt_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return done(kc_fail(ctx, KC_E_NO_DEVICE, "LDS size refused"));
-    hipLaunchKernelGGL(kc_bkt_sort_kernel, dim3(nb), dim3(KC_BKT_THREADS), lds, ctx->stream, (const u64 *)tk, (const u64 *)tv, (const u32 *)offsets, W, cap,
+    KC_LAUNCH(kc_bkt_sort_kernel, dim3(nb), dim3(KC_BKT_THREADS), lds, ctx->stream, (const u64 *)tk, (const u64 *)tv, (const u32 *)offsets, W, cap,
                        (const u64 *)d_flag, keys_out, ids_out);
     if (hipGetLastError() != hipSuccess) return done(kc_fail(ctx, KC_E_NO_DEVICE, "bucketed sort launch failed"));
     return done(KC_OK);
@@ -341,7 +341,7 @@ int kcu_compact_shards(kc_ctx *ctx, const u64 *src, u64 shard_cap, const u64 *d_
     for (int s = 0; s < nshards; ++s) { u64 c = h[(size_t)s * stride]; if (c > shard_cap) { ovf = true; c = shard_cap; } t += c; }
     *total = t; *overflow = ovf;
     if (t == 0 || ovf) return KC_OK;
-    hipLaunchKernelGGL(kc_compact_shards_kernel, dim3(64, nshards), dim3(256), 0, ctx->stream, src, shard_cap, d_cursors, nshards, stride, E, dst);
+    KC_LAUNCH(kc_compact_shards_kernel, dim3(64, nshards), dim3(256), 0, ctx->stream, src, shard_cap, d_cursors, nshards, stride, E, dst);
     KC_HIP(ctx, hipGetLastError());
     return KC_OK;
 }
@@ -404,7 +404,7 @@ int kcr_build(kc_comm *c, const u8 *dest, u64 n, KcRoute *r) {
     KC_HIP(ctx, hipMemsetAsync(cnt, 0, 3 * KC_MAX_RANKS * 8, ctx->stream));
     if (n) {
         unsigned g = kc_grid(n, 256 * 16);
-        hipLaunchKernelGGL(kc_route_count_kernel, dim3(g), dim3(256), 0, ctx->stream, dest, n, cnt);
+        KC_LAUNCH(kc_route_count_kernel, dim3(g), dim3(256), 0, ctx->stream, dest, n, cnt);
     }
     u64 h[KC_MAX_RANKS];
     KC_HIP(ctx, hipMemcpyAsync(h, cnt, (size_t)G * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -424,7 +424,7 @@ int kcr_build(kc_comm *c, const u8 *dest, u64 n, KcRoute *r) {
         rc = kc_alloc(ctx, &r->perm, n);
         if (rc != KC_OK) { kc_release(ctx, cnt); return rc; }
         KC_HIP(ctx, hipMemcpyAsync(cnt + KC_MAX_RANKS, r->soff.data(), (size_t)G * 8, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(kc_route_perm_kernel, dim3(kc_grid(n, 2048)), dim3(256), 0, ctx->stream, dest, n, (const u64 *)(cnt + KC_MAX_RANKS), cnt + 2 * KC_MAX_RANKS, r->perm);
+        KC_LAUNCH(kc_route_perm_kernel, dim3(kc_grid(n, 2048)), dim3(256), 0, ctx->stream, dest, n, (const u64 *)(cnt + KC_MAX_RANKS), cnt + 2 * KC_MAX_RANKS, r->perm);
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the offsets were copied from a host vector)
     }
@@ -441,7 +441,7 @@ int kcr_forward(kc_comm *c, const KcRoute &r, const u64 *items, int E, int strid
     KC_TRY(kc_alloc(ctx, &send, r.n * (u64)E + 1));
     int rc = kc_alloc(ctx, &recv, r.n_recv * (u64)E + 1);
     if (rc != KC_OK) { kc_release(ctx, send); return rc; }
-    if (r.n) hipLaunchKernelGGL(kc_route_gather_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, items, (const u64 *)r.perm, r.n, E, stride, send);
+    if (r.n) KC_LAUNCH(kc_route_gather_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, items, (const u64 *)r.perm, r.n, E, stride, send);
     std::vector<u64> so(G), sc(G), ro(G), rcv(G);
     for (int p = 0; p < G; ++p) { so[p] = r.soff[p] * E * 8; sc[p] = r.scnt[p] * E * 8; ro[p] = r.roff[p] * E * 8; rcv[p] = r.rcnt[p] * E * 8; }
     rc = kcc_alltoallv(c, send, so.data(), sc.data(), recv, ro.data(), rcv.data());
@@ -461,7 +461,7 @@ int kcr_backward(kc_comm *c, const KcRoute &r, const u64 *answers, int A, u64 *o
     for (int p = 0; p < G; ++p) { so[p] = r.roff[p] * A * 8; sc[p] = r.rcnt[p] * A * 8; ro[p] = r.soff[p] * A * 8; rcv[p] = r.scnt[p] * A * 8; }
     int rc = kcc_alltoallv(c, answers, so.data(), sc.data(), tmp, ro.data(), rcv.data());
     if (rc == KC_OK && r.n) {
-        hipLaunchKernelGGL(kc_route_scatter_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, (const u64 *)tmp, (const u64 *)r.perm, r.n, A, out);
+        KC_LAUNCH(kc_route_scatter_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, (const u64 *)tmp, (const u64 *)r.perm, r.n, A, out);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "route scatter launch failed");
     }
     (void)hipStreamSynchronize(ctx->stream);

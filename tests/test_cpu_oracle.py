@@ -212,6 +212,24 @@ def test_abi_fails_loudly_without_gpu():
     assert e.value.code == kc.api.KC_E_NO_DEVICE
 
 
+def test_launch_guard_refuses_2pow32_threads_at_the_call_site():
+    """kc_grid / KC_LAUNCH / KC_HIP (csrc/kc_internal.h): a 1-D launch of 2^32 or more threads returns KC_E_ARG from the calling function
+    before anything is launched, and the overflow flag never goes stale (tests/sim/grid_check.hip, host only: nothing reaches a GPU)."""
+    exe = os.path.join(ROOT, "tests", "sim", "grid_check")
+    src = os.path.join(ROOT, "tests", "sim", "grid_check.hip")
+    hdr = os.path.join(ROOT, "kmercamel_amd", "csrc", "kc_internal.h")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["hipcc", "-std=c++17", "-O1", "--offload-arch=gfx950", "-o", exe, src, "-L" + os.path.join(ROOT, "kmercamel_amd"),
+                               "-lkmercamel_amd", "-Wl,-rpath,$ORIGIN/../../kmercamel_amd"], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "grid_check ok" in out.stdout, out.stdout + out.stderr
+    # and no kernel of the library is launched any other way
+    for f in os.listdir(os.path.join(ROOT, "kmercamel_amd", "csrc")):
+        if f.endswith((".hip", ".h")) and f != "kc_internal.h":
+            txt = open(os.path.join(ROOT, "kmercamel_amd", "csrc", f)).read()
+            assert "hipLaunchKernelGGL" not in txt and "<<<" not in txt, f
+
+
 def test_product_never_touches_the_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, "kmercamel_amd")):
         for f in files:

@@ -367,6 +367,30 @@ def test_randomised_parity_run():
     assert p.returncode == 0 and "fuzz ok" in p.stdout, p.stdout + p.stderr
 
 
+def test_a_launch_beyond_the_grid_limit_fails_the_call_with_e_arg():
+    """The launch guard through a real call: with KC_TEST_GRID_LIMIT the library treats launches of that many threads as it
+    treats 2^32 -- the call comes back with KC_E_ARG and the '2^32' message, whatever launch trips first, instead of running on with the
+    output of a skipped kernel; small inputs in the same process stay unaffected (the flag does not go stale)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import kmercamel_amd as kc, gen\n"
+        "c = kc.Context(0)\n"
+        "small = b'\\n'.join(gen.random_records(4, 60, seed=1))\n"
+        "big = b'\\n'.join(gen.random_records(3000, 400, seed=2))\n"
+        "a = kc.compute(c, small, 31, True).strings()[0]\n"
+        "for want_mask in (False, True):\n"
+        "    try:\n"
+        "        kc.compute(c, big, 31, True, want_mask=want_mask); print('NO ERROR')\n"
+        "    except kc.KcError as e:\n"
+        "        print('CODE', e.code, '2^32' in str(e))\n"
+        "    assert kc.compute(c, small, 31, True).strings()[0] == a\n"
+        "print('done')\n" % (root, os.path.join(root, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, KC_TEST_GRID_LIMIT="300000"))
+    assert p.returncode == 0 and p.stdout.count("CODE %d True" % kc.api.KC_E_ARG) == 2 and "done" in p.stdout, p.stdout + p.stderr
+
+
 def _export_keys_np(s):
     """the set's keys as a numpy array (single-word keys), through the C ABI"""
     import ctypes
