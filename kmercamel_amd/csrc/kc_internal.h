@@ -34,7 +34,16 @@ struct kc_ctx {
     hipEvent_t ev[8] = {nullptr};
     // dominant-kernel timing (filled by the pipeline)
     double dom_us = 0; uint64_t dom_launches = 0;
+    // streamed CLI I/O (kc_io.hip): a second stream so that the host <-> device copy of chunk i+1 runs under the kernels of chunk i, and
+    // the pinned chunks themselves, kept for the life of the context (measured on the MI355X box: hipHostMalloc 0.15 ms per MB,
+    // hipHostFree 0.11 ms per MB -- the input's chunks serve the output again)
+    hipStream_t copy_stream = nullptr;
+    struct Pin { void *p; size_t bytes; bool busy; };
+    std::vector<Pin> pinned;
 };
+void *kc_pin_acquire(kc_ctx *ctx, size_t bytes);   // kc_io.hip; nullptr on failure
+void kc_pin_release(kc_ctx *ctx, void *p);
+void kc_pin_free_all(kc_ctx *ctx);
 
 struct kc_set {
     kc_ctx *ctx = nullptr;

@@ -22,6 +22,8 @@
 #include <deque>
 #include <atomic>
 #include <vector>
+#include <functional>
+#include <algorithm>
 
 namespace {
 
@@ -175,13 +177,59 @@ __global__ void __launch_bounds__(256) tok_write_kernel(const u8 *__restrict__ r
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+bool io_trace() { static const bool t = getenv("KC_CLI_TRACE") != nullptr; return t; }
 
-// ---- reader: plain files by read(), gzip (and anything zlib passes through) by gzread, "-" = stdin
-// copy threads per pinned chunk (reads from the page cache into it, copies out of it): KC_IO_THREADS, default 4
-static int kc_io_threads() {
-    static const int t = [] { const char *e = getenv("KC_IO_THREADS"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 64 ? v : 4; }();
-    return t;
+// copy threads per pinned chunk (reads from the page cache into it, copies out of it): KC_IO_THREADS, default 8 (measured on the
+// 256-core MI355X box, 2.6 GB from tmpfs through 32 MB pinned chunks to the device: 4 threads 34 GB/s, 8 threads 44 GB/s, 16 threads 45 GB/s
+// against 57 GB/s for the bare H2D copy; tools/io_probe.hip)
+int kc_io_threads() {
+    static const int t = [] { const char *e = getenv("KC_IO_THREADS"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();
+    return getenv("KC_IO_SERIAL") ? 1 : t;
 }
+
+// A few threads that stay for the whole transfer: run(f) executes f(0..T-1), the caller taking part as thread 0, and returns when all
+// are through (a chunk is 1-2 ms of copying: starting threads per chunk showed in the totals).
+struct Workers {
+    int T;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    u64 gen = 0;
+    int pending = 0;
+    bool quit = false;
+    explicit Workers(int t) : T(t < 1 ? 1 : t) {
+        for (int i = 1; i < T; ++i) th.emplace_back([this, i] {
+            u64 seen = 0;
+            for (;;) {
+                const std::function<void(int)> *j;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_go.wait(lk, [&] { return quit || gen != seen; });
+                    if (quit) return;
+                    seen = gen; j = job;
+                }
+                (*j)(i);
+                { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) cv_done.notify_one(); }
+            }
+        });
+    }
+    void run(const std::function<void(int)> &f) {
+        if (T == 1) { f(0); return; }
+        { std::lock_guard<std::mutex> lk(mu); job = &f; pending = T - 1; ++gen; }
+        cv_go.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~Workers() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+
+// ---- reader: plain files by pread(), gzip (and anything zlib passes through) by gzread, "-" = stdin
 struct Reader {
     int fd = -1;
     gzFile gz = nullptr;
@@ -197,14 +245,16 @@ struct Reader {
         if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) size = st.st_size;
         return true;
     }
-    long read_some(u8 *dst, size_t cap) {
+    bool parallel() const { return !gz && size >= 0; }
+    long read_some(u8 *dst, size_t cap, Workers *wk) {
         if (gz) return gzread(gz, dst, (unsigned)cap);
-        if (size >= 0 && !getenv("KC_IO_SERIAL")) {
-            // page-cache / tmpfs reads are memory copies in the kernel: one thread moves ~5 GB/s, four move the chunk in a quarter of the time
+        if (size >= 0) {
+            // page-cache / tmpfs reads are memory copies in the kernel: one thread moves ~5 GB/s, eight move the chunk at ~44 GB/s
             const size_t want = (size_t)std::min<off_t>((off_t)cap, size > pos ? size - pos : 0);
-            const int T = want >= ((size_t)8 << 20) ? kc_io_threads() : 1;
+            const int T = (wk && want >= ((size_t)8 << 20)) ? wk->T : 1;
             std::atomic<bool> bad{false};
-            auto part = [&](int t) {
+            const std::function<void(int)> part = [&](int t) {
+                if (t >= T) return;
                 size_t lo = want * (size_t)t / (size_t)T, hi = want * (size_t)(t + 1) / (size_t)T;
                 while (lo < hi) {
                     const ssize_t r = pread(fd, dst + lo, hi - lo, pos + (off_t)lo);
@@ -212,10 +262,7 @@ struct Reader {
                     lo += (size_t)r;
                 }
             };
-            std::vector<std::thread> th;
-            for (int t = 1; t < T; ++t) th.emplace_back(part, t);
-            part(0);
-            for (auto &x : th) x.join();
+            if (T > 1) wk->run(part); else part(0);
             if (bad) return -1;
             pos += (off_t)want;
             return (long)want;
@@ -232,42 +279,59 @@ struct Reader {
     void close() { if (gz) gzclose(gz); else if (fd >= 0) ::close(fd); gz = nullptr; fd = -1; }
 };
 
+int ensure_copy_stream(kc_ctx *ctx) {
+    if (!ctx->copy_stream) KC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    return KC_OK;
+}
+
 }  // namespace
+
+// ---- pinned chunks of the context
+void *kc_pin_acquire(kc_ctx *ctx, size_t bytes) {
+    for (auto &b : ctx->pinned) if (!b.busy && b.bytes >= bytes) { b.busy = true; return b.p; }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->pinned.push_back(kc_ctx::Pin{p, bytes, true});
+    return p;
+}
+void kc_pin_release(kc_ctx *ctx, void *p) {
+    for (auto &b : ctx->pinned) if (b.p == p) b.busy = false;
+}
+void kc_pin_free_all(kc_ctx *ctx) {
+    for (auto &b : ctx->pinned) (void)hipHostFree(b.p);
+    ctx->pinned.clear();
+}
 
 // *d_seq (kc_alloc'd; release with kc_device_free) = the record sequences joined by '\n', *len bytes.
 // *is_fastq = 1: the input is FASTQ (or could not be handled here) -- nothing is returned, use the host parser.
+// Pipeline per 32 MB chunk: [reader thread + its helpers] pread into a pinned chunk -> [copy stream] H2D -> [context stream] the three
+// tokeniser kernels; the copy of chunk i+1 runs under the kernels of chunk i, the read of chunk i+2 under both.
 extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *len, int *is_fastq) {
     if (!ctx || !path || !d_seq || !len || !is_fastq) return KC_E_ARG;
     *d_seq = nullptr; *len = 0; *is_fastq = 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
+    const double t_begin = now_s();
     Reader rd;
     std::string err;
     if (!rd.open(path, err)) return kc_fail(ctx, KC_E_IO, err.empty() ? std::string("couldn't open file ") + path : err);
     const size_t CH = (size_t)32 << 20;
     const int NB = 3;
     u8 *hbuf[NB] = {nullptr, nullptr, nullptr};
-    hipEvent_t done[NB];
+    hipEvent_t done[NB], copied[NB];
+    bool have_ev[NB] = {false, false, false};
     u8 *d_raw = nullptr, *out = nullptr;
     TokFn *blocks = nullptr;
     u64 *aux = nullptr;   // [0..1] carry, [2..3] flags, then bstate / boff
     const u64 nbmax = (CH + 16383) / 16384 + 1;
-    int rc = KC_OK;
+    int rc = ensure_copy_stream(ctx);
     for (int i = 0; i < NB && rc == KC_OK; ++i) {
-        if (hipHostMalloc((void **)&hbuf[i], CH + 64, hipHostMallocDefault) != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
-        if (rc == KC_OK && hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess) rc = KC_E_NO_DEVICE;
+        hbuf[i] = (u8 *)kc_pin_acquire(ctx, CH + 64);
+        if (!hbuf[i]) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
+        if (rc == KC_OK && (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess)) rc = KC_E_NO_DEVICE;
+        else if (rc == KC_OK) have_ev[i] = true;
     }
-    if (rc == KC_OK) rc = kc_alloc(ctx, &d_raw, NB * (CH + 256));
-    if (rc == KC_OK) rc = kc_alloc(ctx, &blocks, nbmax);
-    if (rc == KC_OK) rc = kc_alloc(ctx, &aux, 4 + 2 * nbmax);
-    u64 out_cap = 0;
-    {   // plain files: the joined sequence is never longer than the file; streams: grow as needed
-        struct stat st;
-        if (rc == KC_OK && !rd.gz && fstat(rd.fd, &st) == 0 && st.st_size > 0) out_cap = (u64)st.st_size + 64;
-        else out_cap = (u64)256 << 20;
-    }
-    if (rc == KC_OK) rc = kc_alloc(ctx, &out, out_cap);
-    if (rc == KC_OK && hipMemsetAsync(aux, 0, 32, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
-    // reader thread: fills free pinned buffers, hands them over in order
+    // reader thread: fills free pinned buffers, hands them over in order (started before the device buffers are allocated: the first
+    // chunks are read while hipMalloc and the first kernel launch -- which loads the code object -- run)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<int, long>> ready;   // (buffer, bytes); bytes <= 0: end / error
@@ -276,6 +340,7 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
     std::thread reader;
     if (rc == KC_OK) {
         reader = std::thread([&] {
+            Workers wk(rd.parallel() ? kc_io_threads() : 1);
             u8 held = 0; bool have_held = false;   // a '\r' that ended a chunk waits for the next one ("\r\n" must stay together)
             for (int b = 0;; b = (b + 1) % NB) {
                 {
@@ -286,7 +351,7 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
                 }
                 size_t off = 0;
                 if (have_held) { hbuf[b][0] = held; off = 1; have_held = false; }
-                long got = rd.read_some(hbuf[b] + off, CH - off);
+                long got = rd.read_some(hbuf[b] + off, CH - off, &wk);
                 long total = got < 0 ? -1 : (long)off + got;
                 if (got > 0 && (size_t)got == CH - off && hbuf[b][total - 1] == '\r') { held = '\r'; have_held = true; --total; }
                 {
@@ -303,11 +368,31 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
             }
         });
     }
+    if (rc == KC_OK) rc = kc_alloc(ctx, &d_raw, NB * (CH + 256));
+    if (rc == KC_OK) rc = kc_alloc(ctx, &blocks, nbmax);
+    if (rc == KC_OK) rc = kc_alloc(ctx, &aux, 4 + 2 * nbmax);
+    u64 out_cap = 0;
+    {   // plain files: the joined sequence is never longer than the file; streams: grow as needed
+        struct stat st;
+        if (rc == KC_OK && !rd.gz && fstat(rd.fd, &st) == 0 && st.st_size > 0) out_cap = (u64)st.st_size + 64;
+        else out_cap = (u64)256 << 20;
+    }
+    if (rc == KC_OK) rc = kc_alloc(ctx, &out, out_cap);
+    if (rc == KC_OK && hipMemsetAsync(aux, 0, 32, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
+    const double t_setup = now_s();
+    double t_first = 0;
     u64 total_in = 0;
     bool first = true, fastq = false;
     u8 last_byte = (u8)'\n';        // the byte before the next chunk ('\n': the input starts at a line start)
     std::deque<int> inflight;       // buffers whose copy / kernels are still running, oldest first
     auto give_back = [&](int b) { { std::lock_guard<std::mutex> lk(mu); free_buf[b] = true; } cv.notify_all(); };
+    // (the launches sit in a lambda: KC_LAUNCH returns from its caller on a refused grid, and this function has a reader thread to stop first)
+    auto tokenise = [&](const u8 *dr, u64 n, u64 nb) -> int {
+        KC_LAUNCH(tok_summary_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dr, n, blocks, aux + 2);
+        KC_LAUNCH(tok_chain_kernel, dim3(1), dim3(256), 0, ctx->stream, (const TokFn *)blocks, nb, aux, aux + 4, aux + 4 + nbmax);
+        KC_LAUNCH(tok_write_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, dr, n, (const u64 *)(aux + 4), (const u64 *)(aux + 4 + nbmax), out, out_cap, aux + 2);
+        return KC_OK;
+    };
     while (rc == KC_OK) {
         while (!inflight.empty() && hipEventQuery(done[inflight.front()]) == hipSuccess) { give_back(inflight.front()); inflight.pop_front(); }
         std::pair<int, long> item;
@@ -356,21 +441,23 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
         u8 *dr = d_raw + (size_t)b * (CH + 256) + 128;   // dr[-1] = the byte before this chunk
         u8 *stash = hbuf[b] + CH + 2;                    // (pinned, and not refilled before this chunk is through)
         stash[0] = last_byte;
-        if (hipMemcpyAsync(dr - 1, stash, 1, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipMemcpyAsync(dr, src, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        // (d_raw's piece b is free: buffer b came back from the reader only after done[b], the end of its previous kernels)
+        if (hipMemcpyAsync(dr - 1, stash, 1, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess || hipMemcpyAsync(dr, src, n, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess ||
+            hipEventRecord(copied[b], ctx->copy_stream) != hipSuccess || hipStreamWaitEvent(ctx->stream, copied[b], 0) != hipSuccess) {
             rc = kc_fail(ctx, KC_E_NO_DEVICE, "H2D copy failed");
             break;
         }
         last_byte = src[n - 1];
         const u64 nb = (n + 16383) / 16384;
-        KC_LAUNCH(tok_summary_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const u8 *)dr, n, blocks, aux + 2);
-        KC_LAUNCH(tok_chain_kernel, dim3(1), dim3(256), 0, ctx->stream, (const TokFn *)blocks, nb, aux, aux + 4, aux + 4 + nbmax);
-        KC_LAUNCH(tok_write_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const u8 *)dr, n, (const u64 *)(aux + 4), (const u64 *)(aux + 4 + nbmax), out, out_cap,
-                           aux + 2);
+        rc = tokenise((const u8 *)dr, n, nb);
+        if (rc != KC_OK) break;
         if (hipGetLastError() != hipSuccess || hipEventRecord(done[b], ctx->stream) != hipSuccess) { rc = kc_fail(ctx, KC_E_NO_DEVICE, "tokeniser launch failed"); break; }
+        if (total_in == 0 && io_trace()) { (void)hipEventSynchronize(done[b]); t_first = now_s(); }
         total_in += n;
         inflight.push_back(b);
     }
     u64 h[4] = {0, 0, 0, 0};
+    (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(ctx->stream);
     { std::lock_guard<std::mutex> lk(mu); stop = true; for (int i = 0; i < NB; ++i) free_buf[i] = true; }
     cv.notify_all();
@@ -381,8 +468,11 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
         if (rc == KC_OK && h[2]) fastq = true;
     }
     rd.close();
-    for (int i = 0; i < NB; ++i) { if (hbuf[i]) (void)hipHostFree(hbuf[i]); (void)hipEventDestroy(done[i]); }
+    for (int i = 0; i < NB; ++i) { if (hbuf[i]) kc_pin_release(ctx, hbuf[i]); if (have_ev[i]) { (void)hipEventDestroy(done[i]); (void)hipEventDestroy(copied[i]); } }
     kc_release(ctx, d_raw); kc_release(ctx, blocks); kc_release(ctx, aux);
+    if (io_trace())
+        fprintf(stderr, "[io] read: setup (pinned chunks, device buffers) %.1f ms, first chunk tokenised after %.1f ms more, %.2f GB in %.1f ms in all\n", (t_setup - t_begin) * 1e3,
+                t_first > 0 ? (t_first - t_setup) * 1e3 : 0.0, total_in / 1e9, (now_s() - t_begin) * 1e3);
     if (rc != KC_OK || fastq) { kc_release(ctx, out); *is_fastq = fastq ? 1 : 0; return rc; }
     *d_seq = out; *len = h[1];
     return KC_OK;
@@ -394,91 +484,71 @@ extern "C" void kc_device_free(kc_ctx *ctx, void *d_ptr) {
     kc_release(ctx, d_ptr);
 }
 
-// result -> file descriptor through two pinned chunks: the device-to-host copy of piece i+1 overlaps the write() of piece i.
-// (Measured on the MI355X box, 2.5 GB to tmpfs: this sequential stream 0.42 s; four threads with pwrite 0.68 s -- buffered
-// writes to one file queue on the inode lock; eight threads copying into a shared mapping 1.2 s -- the page faults are slower
-// than write()'s page allocation.  The single memcpy-bound writer is the fastest of the three.)
+namespace {
+// result -> host, chunk by chunk through the context's pinned chunks: the device-to-host copy of the next chunks runs while `sink`
+// disposes of the current one (sink(chunk, bytes, offset in the string) -> false: stop with KC_E_IO)
+int drain_result(kc_ctx *ctx, const char *src, u64 total, const std::function<bool(const char *, u64, u64)> &sink) {
+    const size_t CH = (size_t)32 << 20;
+    const int NB = 3;
+    char *hb[NB] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[NB];
+    bool have_ev[NB] = {false, false, false};
+    int rc = KC_OK;
+    for (int i = 0; i < NB && rc == KC_OK; ++i) {
+        hb[i] = (char *)kc_pin_acquire(ctx, CH + 64);
+        if (!hb[i]) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
+        if (rc == KC_OK && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = KC_E_NO_DEVICE;
+        else if (rc == KC_OK) have_ev[i] = true;
+    }
+    u64 sent = 0, done = 0;
+    u64 len_in[NB] = {0, 0, 0};
+    u64 nsent = 0, ndone = 0;   // chunks
+    auto send_next = [&]() -> bool {
+        const int s = (int)(nsent % NB);
+        len_in[s] = total - sent < CH ? total - sent : CH;
+        if (hipMemcpyAsync(hb[s], src + sent, len_in[s], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[s], ctx->stream) != hipSuccess) return false;
+        sent += len_in[s]; ++nsent;
+        return true;
+    };
+    while (rc == KC_OK && done < total) {
+        while (sent < total && nsent - ndone < (u64)NB) if (!send_next()) { rc = KC_E_NO_DEVICE; break; }
+        if (rc != KC_OK) break;
+        const int s = (int)(ndone % NB);
+        if (hipEventSynchronize(ev[s]) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
+        if (!sink(hb[s], len_in[s], done)) { rc = kc_fail(ctx, KC_E_IO, "write failed"); break; }
+        done += len_in[s]; ++ndone;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < NB; ++i) { if (hb[i]) kc_pin_release(ctx, hb[i]); if (have_ev[i]) (void)hipEventDestroy(ev[i]); }
+    return rc;
+}
+}  // namespace
+
+// result -> file descriptor.  (Measured on the MI355X box, 2.5 GB to tmpfs: one sequential write() stream moves ~5 GB/s with page
+// allocation and ~7 GB/s into allocated pages, and more writers do not help -- buffered writes to one file queue on the inode lock.  The
+// CLI therefore goes through kc_result_write_mem and a mapping whenever the output is a regular file; this is the path for pipes, stdout
+// and everything unusual.)
 extern "C" int kc_result_write_fd(kc_result *r, int fd, int which) {
     if (!r || fd < 0) return KC_E_ARG;
     kc_ctx *ctx = r->ctx;
     KC_HIP(ctx, hipSetDevice(ctx->device));
     const char *src = which ? r->d_mask : r->d_out;
     if (!src) return kc_fail(ctx, KC_E_ARG, "the result holds no such string");
-    const u64 total = r->slice_len;
-    const size_t CH = (size_t)32 << 20;
-    char *hb[2] = {nullptr, nullptr};
-    hipEvent_t ev[2];
-    int rc = KC_OK;
-    for (int i = 0; i < 2 && rc == KC_OK; ++i) {
-        if (hipHostMalloc((void **)&hb[i], CH, hipHostMallocDefault) != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
-        if (rc == KC_OK && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = KC_E_NO_DEVICE;
-    }
-    // A regular file whose blocks are already allocated up to the end of this write (the CLI preallocates the output while the
-    // GPU computes) takes its chunks through four pwrite()s at once: into allocated pages a write is a plain memory copy and
-    // scales with threads; where pages still have to be allocated, parallel writers only contend (measured: slower than one).
-    off_t fpos = -1;
-    {
-        struct stat st;
-        if (!getenv("KC_IO_SERIAL") && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(fcntl(fd, F_GETFL) & O_APPEND)) {
-            const off_t cur = lseek(fd, 0, SEEK_CUR);
-            if (cur >= 0 && (u64)st.st_blocks * 512 >= (u64)cur + total) fpos = cur;
+    return drain_result(ctx, src, r->slice_len, [&](const char *buf, u64 n, u64) {
+        u64 off = 0;
+        while (off < n) {
+            const ssize_t w = ::write(fd, buf + off, n - off);
+            if (w < 0) return false;
+            off += (u64)w;
         }
-    }
-    u64 sent = 0, written = 0;
-    int slot = 0;
-    u64 len_in[2] = {0, 0};
-    if (rc == KC_OK && total) {
-        len_in[0] = total < CH ? total : CH;
-        if (hipMemcpyAsync(hb[0], src, len_in[0], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[0], ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
-        sent = len_in[0];
-    }
-    while (rc == KC_OK && written < total) {
-        const int nxt = slot ^ 1;
-        if (sent < total) {
-            len_in[nxt] = total - sent < CH ? total - sent : CH;
-            if (hipMemcpyAsync(hb[nxt], src + sent, len_in[nxt], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[nxt], ctx->stream) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
-            sent += len_in[nxt];
-        }
-        if (hipEventSynchronize(ev[slot]) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
-        if (fpos >= 0) {
-            const int T = len_in[slot] >= ((u64)8 << 20) ? 4 : 1;
-            std::atomic<bool> bad{false};
-            const char *buf = hb[slot];
-            const u64 n = len_in[slot];
-            const off_t at = fpos + (off_t)written;
-            auto part = [&](int t) {
-                u64 lo = n * (u64)t / (u64)T, hi = n * (u64)(t + 1) / (u64)T;
-                while (lo < hi) {
-                    const ssize_t w = pwrite(fd, buf + lo, hi - lo, at + (off_t)lo);
-                    if (w <= 0) { bad = true; return; }
-                    lo += (u64)w;
-                }
-            };
-            std::vector<std::thread> th;
-            for (int t = 1; t < T; ++t) th.emplace_back(part, t);
-            part(0);
-            for (auto &x : th) x.join();
-            if (bad) { rc = kc_fail(ctx, KC_E_IO, "write failed"); break; }
-        } else {
-            u64 off = 0;
-            while (off < len_in[slot]) {
-                const ssize_t w = ::write(fd, hb[slot] + off, len_in[slot] - off);
-                if (w < 0) { rc = kc_fail(ctx, KC_E_IO, "write failed"); break; }
-                off += (u64)w;
-            }
-        }
-        written += len_in[slot];
-        slot = nxt;
-    }
-    if (fpos >= 0 && rc == KC_OK) (void)lseek(fd, fpos + (off_t)total, SEEK_SET);   // the caller goes on writing behind the string
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; ++i) { if (hb[i]) (void)hipHostFree(hb[i]); (void)hipEventDestroy(ev[i]); }
-    return rc;
+        return true;
+    });
 }
 
-// Same pipeline, destination = host memory: chunk i is copied on by four threads while chunk i+1 arrives.  For a pageable
-// destination this beats one big hipMemcpy (which stages through a single thread's copies), and it is what the CLI uses to
-// fill the (prefaulted) shared mapping of its output file -- stores into a mapping take no inode lock, so they scale.
+// Destination = host memory: every chunk is copied on by eight threads while the next ones arrive.  For a pageable destination this
+// beats one big hipMemcpy (which stages through a single thread's copies), and it is what the CLI uses to fill the shared mapping of
+// its output file -- stores into a mapping take no inode lock, so they scale where write() does not (tmpfs, fallocate'd but untouched
+// pages: 27 GB/s with eight threads against 7 GB/s for write(); tools/io_probe2.cpp).
 extern "C" int kc_result_write_mem(kc_result *r, void *dst_v, int which) {
     if (!r || !dst_v) return KC_E_ARG;
     kc_ctx *ctx = r->ctx;
@@ -486,44 +556,18 @@ extern "C" int kc_result_write_mem(kc_result *r, void *dst_v, int which) {
     const char *src = which ? r->d_mask : r->d_out;
     if (!src) return kc_fail(ctx, KC_E_ARG, "the result holds no such string");
     char *dst = static_cast<char *>(dst_v);
-    const u64 total = r->slice_len;
-    const size_t CH = (size_t)32 << 20;
-    char *hb[2] = {nullptr, nullptr};
-    hipEvent_t ev[2];
-    int rc = KC_OK;
-    for (int i = 0; i < 2 && rc == KC_OK; ++i) {
-        if (hipHostMalloc((void **)&hb[i], CH, hipHostMallocDefault) != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
-        if (rc == KC_OK && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) rc = KC_E_NO_DEVICE;
-    }
-    u64 sent = 0, done = 0;
-    int slot = 0;
-    u64 len_in[2] = {0, 0};
-    if (rc == KC_OK && total) {
-        len_in[0] = total < CH ? total : CH;
-        if (hipMemcpyAsync(hb[0], src, len_in[0], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[0], ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
-        sent = len_in[0];
-    }
-    while (rc == KC_OK && done < total) {
-        const int nxt = slot ^ 1;
-        if (sent < total) {
-            len_in[nxt] = total - sent < CH ? total - sent : CH;
-            if (hipMemcpyAsync(hb[nxt], src + sent, len_in[nxt], hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipEventRecord(ev[nxt], ctx->stream) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
-            sent += len_in[nxt];
-        }
-        if (hipEventSynchronize(ev[slot]) != hipSuccess) { rc = KC_E_NO_DEVICE; break; }
-        const u64 n = len_in[slot];
-        const int T = (n >= ((u64)8 << 20) && !getenv("KC_IO_SERIAL")) ? kc_io_threads() : 1;
-        const char *buf = hb[slot];
-        char *at = dst + done;
-        auto part = [&](int t) { const u64 lo = n * (u64)t / (u64)T, hi = n * (u64)(t + 1) / (u64)T; memcpy(at + lo, buf + lo, hi - lo); };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(part, t);
-        part(0);
-        for (auto &x : th) x.join();
-        done += n;
-        slot = nxt;
-    }
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; ++i) { if (hb[i]) (void)hipHostFree(hb[i]); (void)hipEventDestroy(ev[i]); }
+    Workers wk(r->slice_len >= ((u64)8 << 20) ? kc_io_threads() : 1);
+    const double t0 = now_s();
+    const int rc = drain_result(ctx, src, r->slice_len, [&](const char *buf, u64 n, u64 at) {
+        const int T = n >= ((u64)4 << 20) ? wk.T : 1;
+        const std::function<void(int)> part = [&](int t) {
+            if (t >= T) return;
+            const u64 lo = n * (u64)t / (u64)T, hi = n * (u64)(t + 1) / (u64)T;
+            memcpy(dst + at + lo, buf + lo, hi - lo);
+        };
+        if (T > 1) wk.run(part); else part(0);
+        return true;
+    });
+    if (io_trace()) fprintf(stderr, "[io] result -> host memory: %.2f GB in %.1f ms\n", r->slice_len / 1e9, (now_s() - t0) * 1e3);
     return rc;
 }

@@ -10,6 +10,9 @@
 #include <sys/mman.h>
 #include <sstream>
 #include <cstring>
+#include <cerrno>
+#include <ctime>
+#include <cstdio>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -246,12 +249,12 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
     };
     kcamd::warm_context();   // the device comes up while the file is read
-    // The output file is sized (about the input's length), mapped and its pages are faulted in by eight threads while the GPU
-    // computes; the result then goes straight into the page cache through the mapping (kc_result_write_mem: stores into a
-    // mapping take no inode lock, so several threads move each chunk) and the file is cut to its final length.  A single
-    // write() stream to tmpfs / the page cache moves ~6 GB/s, page allocation included; this way the allocation is off the
-    // critical path and the copy is parallel.  Anything unusual (not a regular file, small input, mapping refused, result
-    // longer than estimated) falls back to the plain descriptor path below.
+    // The output file gets its pages while the device comes up and computes -- fallocate(), one call, one thread: measured on the MI355X
+    // box for 2.55 GB on tmpfs 125 ms, against 370 ms for faulting the pages in through a mapping with one thread and 630 ms with eight
+    // (page allocation for ONE file serialises on the inode; tools/io_probe2.cpp) -- and is mapped.  The result then goes straight into
+    // the page cache through the mapping (kc_result_write_mem: stores into a mapping take no inode lock, eight threads move each chunk at
+    // ~27 GB/s, first-touch faults included; a write() stream manages 7 GB/s) and the file is cut to its final length.  Anything unusual
+    // (not a regular file, small input, mapping refused, result longer than estimated) falls back to the plain descriptor path below.
     struct OutMap {
         int fd = -1; char *map = nullptr; size_t cap = 0; bool ok = false, committed = false;
         std::thread th;
@@ -278,18 +281,22 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
                 if (m != MAP_FAILED) {
                     om.map = static_cast<char *>(m);
                     om.ok = true;
-                    // the pages are faulted in by eight threads, front of the file first (piece i goes to thread i mod 8), and
-                    // without changing a byte: the result may already be arriving in the front while the back is still being
-                    // populated (the copy then meets a populated page nearly everywhere, and simply faults where it does not)
-                    om.th = std::thread([&om] {
-                        const int T = 8;
+                    // Then the pages are mapped in by four threads with write touches that change nothing (an atomic OR of 0: the result may
+                    // already be arriving in the front of the file while the back is still being touched).  Touches of allocated pages
+                    // scale with threads where allocation does not, and a copy into mapped pages runs at the speed of the PCIe transfer
+                    // (measured: 2.55 GB in ~50 ms against 105-200 ms when every store of the copy first had to fault its page in).
+                    // MADV_POPULATE_WRITE is NOT used: unmapping pages it brought in took twice as long (90-110 ms against 43 ms).
+                    // (a file system without fallocate: the pages then come with these touches, as for any mapping)
+                    om.th = std::thread([&om, trace, t_start] {
+                        const int rc = ::fallocate(om.fd, 0, 0, (off_t)om.cap) == 0 ? 0 : errno;
+                        if (trace) std::cerr << "[cli] output pages allocated (rc " << rc << "): " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+                        const char *te = std::getenv("KC_CLI_TOUCH_THREADS");
+                        const int T = te ? std::atoi(te) : 4;
+                        if (T < 1) return;
                         const size_t PIECE = (size_t)8 << 20;
-                        auto part = [&](int t) {
+                        auto part = [&om, T, PIECE](int t) {
                             for (size_t lo = (size_t)t * PIECE; lo < om.cap; lo += (size_t)T * PIECE) {
                                 const size_t hi = lo + PIECE < om.cap ? lo + PIECE : om.cap;
-#ifdef MADV_POPULATE_WRITE
-                                if (::madvise(om.map + lo, hi - lo, MADV_POPULATE_WRITE) == 0) continue;
-#endif
                                 for (size_t p = lo; p < hi; p += 4096) __atomic_fetch_or(om.map + p, (char)0, __ATOMIC_RELAXED);
                             }
                         };
@@ -297,6 +304,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
                         for (int t = 1; t < T; ++t) th.emplace_back(part, t);
                         part(0);
                         for (auto &x : th) x.join();
+                        if (trace) std::cerr << "[cli] output pages mapped: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
                     });
                 }
             } else if (fd >= 0) ::close(fd);
@@ -415,7 +423,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         memcpy(om.map, hdr.data(), hdr.size());
         kcamd::check(kc_result_write_mem(res, om.map + hdr.size(), 0));
         mark("result in the mapping");
-        om.settle();   // (the populating threads are through, or nearly: every page has been touched by the copy)
+        om.settle();
         om.map[hdr.size() + st[2]] = '\n';   // main.cpp:210
         ::munmap(om.map, om.cap); om.map = nullptr;
         if (::ftruncate(om.fd, (off_t)(hdr.size() + st[2] + 1)) != 0) throw std::runtime_error("cannot size " + out_path);
@@ -636,13 +644,30 @@ int camel_spss(int argc, char **argv, bool to_spss) {
 
 }  // namespace
 
+static void trace_epoch(const char *what) {
+    if (!std::getenv("KC_CLI_TRACE")) return;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    char buf[96];
+    snprintf(buf, sizeof buf, "[cli] epoch %s %.6f\n", what, (double)ts.tv_sec + ts.tv_nsec * 1e-9);
+    std::cerr << buf;
+}
+
 int main(int argc, char **argv) {
+    trace_epoch("main");
     if (argc == 1 || std::string(argv[1]) == "-h") { usage(); return 0; }
     std::string cmd = argv[1];
     if (cmd == "-v" || cmd == "--version") { std::cerr << KC_CLI_VERSION << std::endl; return 0; }
     // the device-backed subcommands leave through done(): all output files are closed by then, and tearing the HIP runtime
     // down at exit costs ~0.1 s that a command-line run has no use for
-    auto done = [](int rc) -> int { std::cout.flush(); std::cerr.flush(); _exit(rc); return rc; };
+    // (KC_CLI_NO_FAST_EXIT: profilers write their results from exit handlers)
+    auto done = [](int rc) -> int {
+        if (std::getenv("KC_CLI_DESTROY_AT_EXIT")) { trace_epoch("before destroy"); kc_ctx_destroy(kcamd::context()); }   // (experiment: explicit hipFree of the pool)
+        trace_epoch("exit");
+        std::cout.flush(); std::cerr.flush();
+        if (!std::getenv("KC_CLI_NO_FAST_EXIT")) _exit(rc);
+        return rc;
+    };
     if (cmd == "compute") return done(camel_compute(argc - 1, argv + 1, false));
     if (cmd == "lowerbound") return done(camel_compute(argc - 1, argv + 1, true));
     if (cmd == "maskopt") return done(camel_optimize(argc - 1, argv + 1));

@@ -377,7 +377,7 @@ def test_a_launch_beyond_the_grid_limit_fails_the_call_with_e_arg():
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import kmercamel_amd as kc, gen\n"
         "c = kc.Context(0)\n"
-        "small = b'\\n'.join(gen.random_records(4, 60, seed=1))\n"
+        "small = b'\\n'.join(gen.random_records(2, 50, seed=1))\n"
         "big = b'\\n'.join(gen.random_records(3000, 400, seed=2))\n"
         "a = kc.compute(c, small, 31, True).strings()[0]\n"
         "for want_mask in (False, True):\n"
@@ -387,7 +387,7 @@ def test_a_launch_beyond_the_grid_limit_fails_the_call_with_e_arg():
         "        print('CODE', e.code, '2^32' in str(e))\n"
         "    assert kc.compute(c, small, 31, True).strings()[0] == a\n"
         "print('done')\n" % (root, os.path.join(root, "tests")))
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, KC_TEST_GRID_LIMIT="300000"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, KC_TEST_GRID_LIMIT="4000"))
     assert p.returncode == 0 and p.stdout.count("CODE %d True" % kc.api.KC_E_ARG) == 2 and "done" in p.stdout, p.stdout + p.stderr
 
 
