@@ -1009,10 +1009,16 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     // all-gather the edges they logged and apply the others'; verification, repair and the shrinking of the active lists run
     // on the combined log, identically everywhere.  Exactness is untouched: buckets of one level never shared state except
     // through the verified path ends (that is what the verify / repair step is for), whether they run on one GPU or on eight.
-    const bool split = comm && comm->world > 1 && !lower_bound && !getenv("KC_SHARD_REPLICATE_PHASE2");
-    const u32 PG = split ? (u32)comm->world : 1u, pme = split ? (u32)comm->rank : 0u;
+    // Up to 2^23 vertices (KC_SHARD_SPLIT_MIN) the ranks do NOT divide the work: every rank runs the whole phase on its own, through the
+    // single-GPU path (windowed hit counts, grouped levels) and without a single collective.  Measured with 8 ranks on 10^8 k-mers
+    // (2 10^5 vertices): divided 20 ms and 52 collectives, against 5 ms for the phase on one GPU; at 5 10^6 vertices (2.5 10^9 k-mers) the
+    // division saves the replays (~10 of 27 ms) and pays ~60 collectives for it.  KC_SHARD_REPLICATE_PHASE2=1: never divide.
     const int k = s->k;
     const u64 S = s->n, V = S * (complements ? 2 : 1);
+    u64 split_min = (u64)1 << 23;
+    if (const char *e = getenv("KC_SHARD_SPLIT_MIN")) split_min = (u64)atoll(e);
+    const bool split = comm && comm->world > 1 && !lower_bound && !getenv("KC_SHARD_REPLICATE_PHASE2") && V >= split_min;
+    const u32 PG = split ? (u32)comm->world : 1u, pme = split ? (u32)comm->rank : 0u;
     if (S == 0) return kc_fail_agreed(ctx, KC_E_EMPTY, "input cannot be empty");
     if (V >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_ARG, "more than 2^32 overlap-graph vertices are not supported (32-bit writer tags of the path-end entries)");
     OvWork w; w.ctx = ctx;

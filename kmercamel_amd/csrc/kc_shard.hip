@@ -24,6 +24,7 @@
 #include "kc_simp_dev.h"
 #include "kc_scan_dev.h"
 #include <algorithm>
+#include <chrono>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -334,6 +335,184 @@ __global__ void __launch_bounds__(256) kc_shard_wave_finish_kernel(u64 n, const 
     last[t] = ok ? pay[tw] : KC_NONE64;
     nxt[t] = ok ? KC_NONE64 : f_partner[t];
     unreached[t] = ok ? 0 : 1;
+}
+
+// ---- slotted exchange: ONE collective per routed exchange.  kcr_build / kcr_forward need the exact count matrix before any data moves
+// (a count all-gather, then the all-to-all: two collectives, three stream drains).  Here every rank sends every peer a slot of the SAME
+// agreed size -- a 4-word header {items in the slot, the sender's largest per-peer count, overflow flag, items the sender has in all}
+// and `cap` items -- so no count exchange is needed, and since every rank receives every rank's header, all ranks know the global
+// maximum, the global item count and whether anybody overflowed without a collective of their own: an overflow is repaired by all ranks
+// doubling `cap` and repeating the exchange (consumers run only after a clean exchange).  `cap` itself is derived from replicated
+// values only (an all-reduced bound, or the previous exchange's global maximum).  Measured on the thread transport (8 ranks on one GPU):
+// a wave round cost 0.5 ms through flag / compaction / count exchange / permutation / gather; rounds, not bytes, were what the
+// ranking of the chain fragments took its time for.
+#define KC_SLOT_HW 4
+__global__ void __launch_bounds__(256) kc_slot_pack_kernel(const u64 *__restrict__ items, const u8 *__restrict__ dest, u64 n, int E, u64 *cnt, u64 *send, u64 cap, u64 stride,
+                                                           u64 *slotpos) {
+    __shared__ u32 h[KC_MAX_RANKS_SH];
+    __shared__ u64 base[KC_MAX_RANKS_SH];
+    const u64 tile = (u64)blockIdx.x * 2048;
+    if (threadIdx.x < KC_MAX_RANKS_SH) h[threadIdx.x] = 0;
+    __syncthreads();
+    u32 mine[8]; u8 d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 i = tile + (u64)j * 256 + threadIdx.x;
+        d[j] = 0; mine[j] = 0;
+        if (i < n) { d[j] = dest[i]; mine[j] = atomicAdd(&h[d[j]], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < KC_MAX_RANKS_SH && h[threadIdx.x]) base[threadIdx.x] = atomicAdd((ull *)&cnt[threadIdx.x], (ull)h[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u64 i = tile + (u64)j * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const u64 pos = base[d[j]] + mine[j];
+        if (slotpos) slotpos[i] = (u64)d[j] * cap + pos;
+        if (pos >= cap) continue;   // (counted all the same: the header reports the overflow)
+        u64 *o = send + (u64)d[j] * stride + KC_SLOT_HW + pos * (u64)E;
+        for (int w = 0; w < E; ++w) o[w] = items[i * (u64)E + w];
+    }
+}
+__global__ void __launch_bounds__(64) kc_slot_header_kernel(u64 *cnt, int G, u64 cap, u64 *send, u64 stride) {
+    const int p = threadIdx.x;
+    const u64 c = p < G ? cnt[p] : 0;
+    u64 mx = c, tot = c;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const u64 a = __shfl_xor(mx, o, 64), b = __shfl_xor(tot, o, 64); mx = a > mx ? a : mx; tot += b; }
+    if (p < G) {
+        u64 *hd = send + (u64)p * stride;
+        hd[0] = c < cap ? c : cap; hd[1] = mx; hd[2] = mx > cap ? 1 : 0; hd[3] = tot;
+        cnt[p] = 0;
+    }
+}
+// out[0] = somebody overflowed, [1] = largest per-peer count anywhere, [2] = items of all ranks, [3] = items received here
+__global__ void __launch_bounds__(64) kc_slot_summary_kernel(const u64 *__restrict__ recv, int G, u64 stride, u64 *out) {
+    const int p = threadIdx.x;
+    u64 ov = 0, mx = 0, tot = 0, here = 0;
+    if (p < G) { const u64 *hd = recv + (u64)p * stride; here = hd[0]; mx = hd[1]; ov = hd[2]; tot = hd[3]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const u64 a = __shfl_xor(mx, o, 64);
+        mx = a > mx ? a : mx; ov |= __shfl_xor(ov, o, 64); tot += __shfl_xor(tot, o, 64); here += __shfl_xor(here, o, 64);
+    }
+    if (p == 0) { out[0] = ov; out[1] = mx; out[2] = tot; out[3] = here; }
+}
+// (consumers of a slotted buffer: thread t looks at item t % cap of the slot from rank t / cap)
+#define KC_SLOT_ITEM(recv, stride, cap, E, t, valid, ptr)                                           \
+    const u64 sl__ = (t) / (cap), it__ = (t) % (cap);                                               \
+    const bool valid = it__ < (recv)[sl__ * (stride)];                                              \
+    const u64 *ptr = (recv) + sl__ * (stride) + KC_SLOT_HW + it__ * (u64)(E)
+
+// ---- sampled ranking of the chain fragments (bidirectional sets whose chains are long in fragments).  The plain waves below need as
+// many rounds as the longest chain has fragments (1 kbp reads over 8 ranks: ~145 rounds, each a collective); pointer jumping needs
+// log2 of that but keeps every fragment exchanging 24 bytes per round.  Here the waves stop at SPLITTERS -- chain heads and every
+// fragment whose entry port hashes to 0 mod C -- so R rounds cover all gaps up to R fragments; what is still unreached after R rounds
+// turns into splitters of its own (round R + 1: every receiver then is a splitter, all waves end).  Every splitter now knows the
+// splitter before it and the nodes between them: that reduced list (1/C of the fragments + the few unreached ones) is ranked by
+// pointer jumping TOWARDS THE HEADS (log2 of the splitters per chain rounds), and every other fragment pulls {payload, nodes before}
+// of its splitter once.  The result is what the plain waves leave behind -- pay = the head's payload, poff = nodes before the
+// fragment -- so kc_shard_wave_finish_kernel and everything downstream are unchanged.  Fragments on cycles across ranks end with
+// pay = none, as with the waves (splitters on a cycle never reach a head: the jumping is bounded by log2 of all splitters).
+// spl: 0 fragment, 1 hashed splitter, 2 unreached after R rounds, 3 chain head.
+#define KC_SR_RESOLVED (~(u64)0 - 1)
+__global__ void __launch_bounds__(256) kc_shard_sr_init_kernel(const u64 *__restrict__ link, const u64 *__restrict__ entries, u64 n, const u64 *__restrict__ f_exit,
+                                                               const u64 *__restrict__ f_partner, const u32 *__restrict__ fidx, u64 rlo2, int me, u32 C, u64 *pay, u64 *poff,
+                                                               u64 *sjump, u8 *spl, u64 *act, u64 *cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool head = LK_STATE(link[entries[t]]) == LK_DEAD;
+    const bool hs = !head && kc_mix64(entries[t] ^ 0x5bd1e9955bd1e995ULL) % C == 0;
+    spl[t] = head ? 3 : (hs ? 1 : 0);
+    pay[t] = head ? KC_GID(me, fidx[f_exit[t] - rlo2]) : KC_NONE64;
+    poff[t] = 0;
+    sjump[t] = KC_NONE64;
+    if ((head || hs) && f_partner[t] != KC_NONE64) act[atomicAdd((ull *)cursor, 1ULL)] = t;
+}
+// round R + 1: fragments no wave has reached become splitters and start waves of their own
+__global__ void __launch_bounds__(256) kc_shard_sr_unreached_kernel(u64 n, const u64 *__restrict__ f_partner, const u64 *__restrict__ pay, u8 *spl, u64 *act, u64 *cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || spl[t] || pay[t] != KC_NONE64) return;
+    spl[t] = 2;
+    if (f_partner[t] != KC_NONE64) act[atomicAdd((ull *)cursor, 1ULL)] = t;
+}
+__global__ void __launch_bounds__(256) kc_shard_sr_send_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ f_partner, const u64 *__restrict__ f_len,
+                                                               const u64 *__restrict__ pay, const u64 *__restrict__ poff, const u8 *__restrict__ spl, int me, u64 rcap2, u64 *msgs,
+                                                               u8 *dest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = act[t], p = f_partner[e];
+    const bool s = spl[e] != 0;
+    msgs[3 * t] = p; msgs[3 * t + 1] = s ? KC_GID(me, e) : pay[e]; msgs[3 * t + 2] = s ? f_len[e] : poff[e] + f_len[e];
+    dest[t] = (u8)(p / rcap2);
+}
+__global__ void __launch_bounds__(256) kc_shard_sr_recv_kernel(const u64 *__restrict__ recv, u64 stride, u64 cap, int G, const u32 *__restrict__ fidx, u64 rlo2,
+                                                               const u64 *__restrict__ f_partner, const u8 *__restrict__ spl, u64 *pay, u64 *poff, u64 *sjump, u64 *act, u64 *cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)G * cap) return;
+    KC_SLOT_ITEM(recv, stride, cap, 3, t, valid, m);
+    if (!valid) return;
+    const u32 e = fidx[m[0] - rlo2];
+    poff[e] = m[2];
+    if (spl[e]) { sjump[e] = m[1]; return; }   // the wave ends here: this splitter now knows the one before it and the nodes between
+    pay[e] = m[1];
+    if (f_partner[e] != KC_NONE64) act[atomicAdd((ull *)cursor, 1ULL)] = e;
+}
+// the splitters that have a splitter before them (everything but the heads): the reduced list, jumped towards the heads
+__global__ void __launch_bounds__(256) kc_shard_sr_list_kernel(u64 n, const u8 *__restrict__ spl, const u64 *__restrict__ sjump, const u64 *__restrict__ pay, int what, u64 *act,
+                                                               u64 *cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool take = what == 0 ? ((spl[t] == 1 || spl[t] == 2) && sjump[t] != KC_NONE64)   // splitters still jumping
+                                : (spl[t] == 0 && pay[t] != KC_NONE64);                       // fragments that pull from their splitter
+    if (take) act[atomicAdd((ull *)cursor, 1ULL)] = t;
+}
+__global__ void __launch_bounds__(256) kc_shard_sr_req_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ ref, u64 *req, u8 *dest) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 g = ref[act[t]];
+    req[t] = KC_GID_IDX(g);
+    dest[t] = (u8)KC_GID_RANK(g);
+}
+// answers in the slots the requests came in: {the splitter before the asked one (KC_SR_RESOLVED: it knows its head), its nodes before, its payload}
+__global__ void __launch_bounds__(256) kc_shard_sr_ans_kernel(const u64 *__restrict__ recv, u64 stride, u64 cap, int G, const u64 *__restrict__ sjump, const u64 *__restrict__ poff,
+                                                              const u64 *__restrict__ pay, u64 *ans) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)G * cap) return;
+    KC_SLOT_ITEM(recv, stride, cap, 1, t, valid, m);
+    if (!valid) return;
+    const u64 u = m[0];
+    u64 *a = ans + t * 3;
+    a[0] = sjump[u] == KC_NONE64 ? KC_SR_RESOLVED : sjump[u];
+    a[1] = poff[u];
+    a[2] = pay[u];
+}
+__global__ void __launch_bounds__(256) kc_shard_sr_apply_jump_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ slotpos, const u64 *__restrict__ ansb, u64 *sjump,
+                                                                     u64 *poff, u64 *pay, u64 *act_next, u64 *cursor) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = act[t];
+    const u64 *a = ansb + slotpos[t] * 3;
+    poff[e] += a[1];
+    if (a[0] == KC_SR_RESOLVED) { pay[e] = a[2]; sjump[e] = KC_NONE64; }
+    else { sjump[e] = a[0]; act_next[atomicAdd((ull *)cursor, 1ULL)] = e; }
+}
+__global__ void __launch_bounds__(256) kc_shard_sr_apply_pull_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ slotpos, const u64 *__restrict__ ansb, u64 *poff,
+                                                                     u64 *pay) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u64 e = act[t];
+    const u64 *a = ansb + slotpos[t] * 3;
+    // (a splitter on a cycle never found a head: its payload is none, and so is that of the fragments behind it)
+    const bool ok = a[0] == KC_SR_RESOLVED && a[2] != KC_NONE64;
+    pay[e] = ok ? a[2] : KC_NONE64;
+    poff[e] += a[1];
+}
+// splitters that are still jumping when the bound is reached lie on cycles
+__global__ void __launch_bounds__(256) kc_shard_sr_giveup_kernel(const u64 *__restrict__ act, u64 n, u64 *pay) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) pay[act[t]] = KC_NONE64;
 }
 
 // ---- cycles.  K-mers that no fragment reaches lie on cycles inside this rank, fragments that the ranking never connects to a
@@ -679,6 +858,61 @@ int allgather_rows(kc_comm *c, const u64 *d_rows, u64 n_local, int words, u64 **
     return KC_OK;
 }
 
+// Host side of the slotted exchange (see kc_slot_pack_kernel): buffers for G slots of `cap` items, grown when an exchange overflows.
+struct SlotX {
+    kc_ctx *ctx; kc_comm *c; KcScope *scope;
+    int G, E = 0;
+    u64 cap = 0, stride = 0;
+    u64 *send = nullptr, *recv = nullptr, *cnt = nullptr;   // cnt: G counters, then 4 summary words
+    u64 exchanges = 0, redone = 0;
+    u64 sent_to[KC_MAX_RANKS_SH] = {0}, got_from[KC_MAX_RANKS_SH] = {0};   // items per peer of the last exchange
+    SlotX(kc_ctx *x, kc_comm *cm, KcScope *sc) : ctx(x), c(cm), scope(sc), G(cm->world) {}
+    int ensure(int e, u64 want_cap) {
+        if (!cnt) { KC_TRY(scope->alloc(&cnt, KC_MAX_RANKS_SH + 8)); KC_HIP(ctx, hipMemsetAsync(cnt, 0, (KC_MAX_RANKS_SH + 8) * 8, ctx->stream)); }
+        if (want_cap < 64) want_cap = 64;
+        const u64 st = KC_SLOT_HW + want_cap * (u64)e;
+        if (send && st * (u64)G <= words_) { E = e; cap = want_cap; stride = st; return KC_OK; }
+        if (send) { KC_HIP(ctx, hipStreamSynchronize(ctx->stream)); scope->release(send); scope->release(recv); send = recv = nullptr; }
+        words_ = st * (u64)G;
+        KC_TRY(scope->alloc(&send, words_ + 1)); KC_TRY(scope->alloc(&recv, words_ + 1));
+        E = e; cap = want_cap; stride = st;
+        return KC_OK;
+    }
+    // items: n rows of E words, row i to rank dest[i].  On return recv holds the G slots; h4 = {0, largest per-peer count anywhere, items
+    // of all ranks, items received here}.  An overflow anywhere makes every rank double cap and repeat (all see the same headers).
+    int exchange(const u64 *items, const u8 *dest, u64 n, u64 *slotpos, u64 h4[4]) {
+        for (int attempt = 0;; ++attempt) {
+            if (attempt == 24) return kc_fail(ctx, KC_E_CAPACITY, "slotted exchange: the slots keep overflowing");
+            if (n) KC_LAUNCH(kc_slot_pack_kernel, dim3(kc_grid(n, 2048)), dim3(256), 0, ctx->stream, items, dest, n, E, cnt, send, cap, stride, slotpos);
+            KC_LAUNCH(kc_slot_header_kernel, dim3(1), dim3(64), 0, ctx->stream, cnt, G, cap, send, stride);
+            std::vector<u64> off(G), sz(G, stride * 8);
+            for (int p = 0; p < G; ++p) off[p] = (u64)p * stride * 8;
+            KC_TRY(kcc_alltoallv(c, send, off.data(), sz.data(), recv, off.data(), sz.data()));
+            KC_LAUNCH(kc_slot_summary_kernel, dim3(1), dim3(64), 0, ctx->stream, (const u64 *)recv, G, stride, cnt + KC_MAX_RANKS_SH);
+            KC_HIP(ctx, hipGetLastError());
+            KC_HIP(ctx, hipMemcpyAsync(h4, cnt + KC_MAX_RANKS_SH, 32, hipMemcpyDeviceToHost, ctx->stream));
+            // (how many items went to / came from every peer: the answers travel back in exactly those numbers)
+            KC_HIP(ctx, hipMemcpy2DAsync(sent_to, 8, send, stride * 8, 8, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipMemcpy2DAsync(got_from, 8, recv, stride * 8, 8, (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ++exchanges;
+            if (!h4[0]) return KC_OK;
+            ++redone;
+            KC_TRY(ensure(E, h4[1] + h4[1] / 4 + 64));   // (the largest count is known to everybody: the repeat fits)
+        }
+    }
+    // answers of A words in the slots the requests arrived in (ans: G * cap rows) -> back[slotpos[i]] on the asking side
+    int answer(const u64 *ans, int A, u64 *back) {
+        std::vector<u64> off(G), ssz(G), rsz(G);
+        for (int p = 0; p < G; ++p) { off[p] = (u64)p * cap * (u64)A * 8; ssz[p] = got_from[p] * (u64)A * 8; rsz[p] = sent_to[p] * (u64)A * 8; }
+        KC_TRY(kcc_alltoallv(c, ans, off.data(), ssz.data(), back, off.data(), rsz.data()));
+        ++exchanges;
+        return KC_OK;
+    }
+private:
+    u64 words_ = 0;
+};
+
 template <int W> bool hkey_lt(const u64 *a, const u64 *b) {
     for (int i = W - 1; i >= 0; --i) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; }
     return false;
@@ -744,6 +978,16 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     KC_HIP(ctx, hipEventCreate(&eend));
     struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } evg{eend};
     KC_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    // KC_SHARD_TRACE: wall time of every step of the flow on rank 0 (stream drained at each mark), with the collectives and bytes so far
+    auto t_mark = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        if (!trace || me != 0) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[shard 0/%d] step %-28s %8.3f ms   (collectives so far %llu, %.1f MB sent, %.3f ms inside them)\n", G, what,
+                std::chrono::duration<double, std::milli>(now - t_mark).count(), (unsigned long long)c->calls, c->bytes_sent / 1e6, c->seconds * 1e3);
+        t_mark = now;
+    };
     // ---------------- phase 0
     kc_set *set = nullptr;
     const u64 occ_local = len >= (u64)k ? len - k + 1 : 0;
@@ -764,6 +1008,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     if (N == 0) return kc_fail_agreed(ctx, KC_E_NO_KMERS, "input contains no k-mers");
     if (c->test_fail_rank == me) return kc_fail(ctx, KC_E_NO_DEVICE, "test: this rank fails on its own");   // (kc_comm::test_fail_rank, a test knob: between two exchanges)
     KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    tick("set build (phase 0)");
     // Ports are numbered by DENSE node id (kc_set_dev.h): block * nstride + the k-mer's rank among the block's occupied slots, with
     // the same nstride on every rank -- so rank r holds the ids [r * rcap, (r + 1) * rcap) with rcap = blocks per rank * nstride, and
     // everything below addresses links, fragments and visit marks in that id space exactly as it used to in the slot space (at
@@ -902,6 +1147,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     }
     if (trace) fprintf(stderr, "[shard %d/%d] N_local=%llu N=%llu queries=%llu branch edges (all ranks)=%llu\n", me, G, (unsigned long long)N_local,
                        (unsigned long long)N, (unsigned long long)nq, (unsigned long long)n_branch_edges);
+    tick("links (probe, queries, branch)");
     // ---------------- phase 1b: fragments (the discovery restarts after a cycle has been cut)
     u64 *entries = nullptr, n_ent = 0;
     u64 *f_exit = nullptr, *f_partner = nullptr, *f_len = nullptr, *nxt = nullptr, *dist = nullptr, *last = nullptr, *iota = nullptr, *act = nullptr;
@@ -1006,6 +1252,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_LAUNCH(kc_shard_iota_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, iota, n_ent);
         }
         KC_HIP(ctx, hipGetLastError());
+        tick("contraction + fragment walks");
         // ---- ranking by waves (see kc_shard_wave_init_kernel) when the set is bidirectional and the chains are short in fragments
         u64 prev_active = ~(u64)0, n_act = 0;
         bool stalled = false, ranked = false;
@@ -1026,7 +1273,115 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             // a chain has tot[0] / tot[1] fragments on average: waves only when that many rounds are affordable
             bool wave = complements && wave_max && tot[1] && tot[0] / tot[1] <= wave_max / 8;
             u64 wrounds = 0;
-            while (wave) {
+            // ---- sampled ranking (see kc_shard_sr_init_kernel): when the plain waves would need more rounds than R + log2 of it.
+            // KC_RANK_SAMPLED=0 / 1: never / always (tests); KC_RANK_C, KC_RANK_R: splitter rate and wave rounds.
+            u32 SR_C = 8, SR_R = 24;
+            if (const char *e = getenv("KC_RANK_C")) { const int v = atoi(e); if (v >= 1 && v <= 4096) SR_C = (u32)v; }
+            if (const char *e = getenv("KC_RANK_R")) { const int v = atoi(e); if (v >= 1 && v <= 4096) SR_R = (u32)v; }
+            bool sampled = complements && wave_max && tot[1] && tot[0] / tot[1] > 2 * SR_R / 3;
+            if (const char *e = getenv("KC_RANK_SAMPLED")) sampled = complements && wave_max && atoi(e) != 0;
+            if (sampled) {
+                u64 *sjump = nullptr, *act2 = nullptr, *items = nullptr, *slotpos = nullptr, *ansbuf = nullptr, *ansback = nullptr;
+                u8 *spl = nullptr, *sdest = nullptr;
+                KC_TRY(scope.alloc(&sjump, n_ent + 1)); KC_TRY(scope.alloc(&act2, n_ent + 1)); KC_TRY(scope.alloc(&items, 3 * (n_ent + 1)));
+                KC_TRY(scope.alloc(&slotpos, n_ent + 1)); KC_TRY(scope.alloc(&spl, n_ent + 1)); KC_TRY(scope.alloc(&sdest, n_ent + 1));
+                u64 *acur = cur + 3 * KC_USTRIDE;   // [0], [1]: cursors of the two active lists
+                KC_HIP(ctx, hipMemsetAsync(acur, 0, 16, ctx->stream));
+                if (n_ent) KC_LAUNCH(kc_shard_sr_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, (const u64 *)f_exit,
+                                              (const u64 *)f_partner, (const u32 *)fidx, 2 * rlo, me, SR_C, pay, poff, sjump, spl, act, acur);
+                u64 n_cur = 0;
+                KC_TRY(read_words(ctx, acur, &n_cur, 1));
+                // slot sizes come from replicated values only: the largest rank's counts now, the previous exchange's maximum later
+                u64 mx[2] = {n_cur, n_ent};
+                KC_TRY(kcc_allreduce_max(c, mx, 2));
+                const u64 peers = G > 1 ? (u64)(G - 1) : 1;
+                const u64 cap0 = mx[0] / peers + mx[0] / (4 * peers) + 1024;
+                SlotX sx(ctx, c, &scope);
+                u64 *la = act, *lb = act2;   // this round's senders, the next round's
+                int ca = 0;                  // cursor of la
+                u64 h4[4] = {0, 0, 0, 0};
+                u64 capw = cap0;
+                for (u32 r = 1; r <= SR_R + 1; ++r) {
+                    if (r == SR_R + 1) {
+                        if (n_ent) KC_LAUNCH(kc_shard_sr_unreached_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, n_ent, (const u64 *)f_partner, (const u64 *)pay, spl, la, acur + ca);
+                        KC_TRY(read_words(ctx, acur + ca, &n_cur, 1));
+                        capw = cap0;
+                    }
+                    KC_TRY(sx.ensure(3, capw));
+                    if (n_cur) KC_LAUNCH(kc_shard_sr_send_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)la, n_cur, (const u64 *)f_partner, (const u64 *)f_len,
+                                                  (const u64 *)pay, (const u64 *)poff, (const u8 *)spl, me, 2 * rcap, items, sdest);
+                    KC_TRY(sx.exchange(items, sdest, n_cur, nullptr, h4));
+                    ++rounds;
+                    KC_HIP(ctx, hipMemsetAsync(acur + (ca ^ 1), 0, 8, ctx->stream));
+                    if (h4[3]) KC_LAUNCH(kc_shard_sr_recv_kernel, dim3(kc_grid((u64)G * sx.cap, 256)), dim3(256), 0, ctx->stream, (const u64 *)sx.recv, sx.stride, sx.cap, G, (const u32 *)fidx,
+                                                  2 * rlo, (const u64 *)f_partner, (const u8 *)spl, pay, poff, sjump, lb, acur + (ca ^ 1));
+                    KC_TRY(read_words(ctx, acur + (ca ^ 1), &n_cur, 1));
+                    std::swap(la, lb); ca ^= 1;
+                    capw = h4[1] + h4[1] / 16 + 256;   // (waves only end: a round rarely sends more to a peer than the one before -- if one does, the exchange repeats)
+                    if (h4[2] == 0 && r < SR_R) r = SR_R;   // every wave has ended early (all ranks see the same total): straight to the last round
+                }
+                // the reduced list: pointer jumping towards the heads
+                KC_HIP(ctx, hipMemsetAsync(acur, 0, 16, ctx->stream));
+                la = act; lb = act2; ca = 0;
+                if (n_ent) KC_LAUNCH(kc_shard_sr_list_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, n_ent, (const u8 *)spl, (const u64 *)sjump, (const u64 *)pay, 0, la, acur);
+                KC_TRY(read_words(ctx, acur, &n_cur, 1));
+                u64 tspl[2] = {n_cur, n_cur};
+                KC_TRY(kcc_allreduce_sum(c, tspl, 1));
+                KC_TRY(kcc_allreduce_max(c, tspl + 1, 1));
+                int max_jumps = 2;
+                for (u64 v = tspl[0]; v > 1; v >>= 1) ++max_jumps;   // (a chain has at most that many splitters: log2 of it rounds reach any head)
+                capw = tspl[1] / peers + tspl[1] / (4 * peers) + 1024;
+                for (int j = 0; tspl[0] != 0; ++j) {
+                    KC_TRY(sx.ensure(1, capw));
+                    if (n_cur) KC_LAUNCH(kc_shard_sr_req_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)la, n_cur, (const u64 *)sjump, items, sdest);
+                    KC_TRY(sx.exchange(items, sdest, n_cur, slotpos, h4));
+                    ++rounds;
+                    if (h4[2] == 0) break;   // nobody asks any more
+                    const u64 aw = (u64)G * sx.cap * 3 + 1;
+                    KC_TRY(scope.alloc(&ansbuf, aw)); KC_TRY(scope.alloc(&ansback, aw));
+                    if (h4[3]) KC_LAUNCH(kc_shard_sr_ans_kernel, dim3(kc_grid((u64)G * sx.cap, 256)), dim3(256), 0, ctx->stream, (const u64 *)sx.recv, sx.stride, sx.cap, G, (const u64 *)sjump,
+                                                  (const u64 *)poff, (const u64 *)pay, ansbuf);
+                    KC_TRY(sx.answer(ansbuf, 3, ansback));
+                    KC_HIP(ctx, hipMemsetAsync(acur + (ca ^ 1), 0, 8, ctx->stream));
+                    if (j + 1 >= max_jumps) {   // still jumping after log2(all splitters) rounds: on a cycle
+                        if (n_cur) KC_LAUNCH(kc_shard_sr_giveup_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)la, n_cur, pay);
+                        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                        scope.release(ansbuf); scope.release(ansback);
+                        break;
+                    }
+                    if (n_cur) KC_LAUNCH(kc_shard_sr_apply_jump_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)la, n_cur, (const u64 *)slotpos, (const u64 *)ansback,
+                                                  sjump, poff, pay, lb, acur + (ca ^ 1));
+                    KC_TRY(read_words(ctx, acur + (ca ^ 1), &n_cur, 1));
+                    scope.release(ansbuf); scope.release(ansback);
+                    std::swap(la, lb); ca ^= 1;
+                    capw = h4[1] + h4[1] / 8 + 256;
+                }
+                // every other fragment pulls payload and nodes-before of its splitter
+                KC_HIP(ctx, hipMemsetAsync(acur, 0, 16, ctx->stream));
+                if (n_ent) KC_LAUNCH(kc_shard_sr_list_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, n_ent, (const u8 *)spl, (const u64 *)sjump, (const u64 *)pay, 1, act, acur);
+                KC_TRY(read_words(ctx, acur, &n_cur, 1));
+                {
+                    KC_TRY(sx.ensure(1, mx[1] / peers + mx[1] / (4 * peers) + 1024));
+                    if (n_cur) KC_LAUNCH(kc_shard_sr_req_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_cur, (const u64 *)pay, items, sdest);
+                    KC_TRY(sx.exchange(items, sdest, n_cur, slotpos, h4));
+                    const u64 aw = (u64)G * sx.cap * 3 + 1;
+                    KC_TRY(scope.alloc(&ansbuf, aw)); KC_TRY(scope.alloc(&ansback, aw));
+                    if (h4[3]) KC_LAUNCH(kc_shard_sr_ans_kernel, dim3(kc_grid((u64)G * sx.cap, 256)), dim3(256), 0, ctx->stream, (const u64 *)sx.recv, sx.stride, sx.cap, G, (const u64 *)sjump,
+                                                  (const u64 *)poff, (const u64 *)pay, ansbuf);
+                    KC_TRY(sx.answer(ansbuf, 3, ansback));
+                    if (n_cur) KC_LAUNCH(kc_shard_sr_apply_pull_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_cur, (const u64 *)slotpos, (const u64 *)ansback, poff, pay);
+                    KC_HIP(ctx, hipGetLastError());
+                    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    scope.release(ansbuf); scope.release(ansback);
+                    rounds += 1;
+                }
+                if (trace && me == 0) fprintf(stderr, "[shard 0/%d] sampled ranking: C=%u R=%u, %llu slotted exchanges (%llu repeated after an overflow)\n", G, SR_C, SR_R,
+                                              (unsigned long long)sx.exchanges, (unsigned long long)sx.redone);
+                scope.release(sx.send); scope.release(sx.recv); scope.release(sx.cnt);
+                scope.release(sjump); scope.release(act2); scope.release(items); scope.release(slotpos); scope.release(spl); scope.release(sdest);
+                wave = true;   // (what follows the plain waves -- kc_shard_wave_finish_kernel -- follows here too)
+            }
+            while (wave && !sampled) {
                 u64 n_send = 0;
                 if (n_ent) {
                     KC_LAUNCH(kc_shard_wave_flag_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u8 *)reach_a, (const u64 *)f_partner, n_ent, flags8);
@@ -1111,6 +1466,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             KC_TRY(rc);
             ++rounds;
         }
+        tick("fragment ranking");
         {
             u64 any_missing = missing;
             KC_TRY(kcc_allreduce_max(c, &any_missing, 1));
@@ -1261,11 +1617,13 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         scope.release(perm); scope.release(perm2); scope.release(kw); scope.release(kw2); scope.release(nw); scope.release(fin); scope.release(idx);
     }
     KC_HIP(ctx, hipEventRecord(e2, ctx->stream));
+    tick("chain records, simplitig list");
     // ---------------- phase 2 (replicated) and the path ranking of phase 3
     KcPathDev path;
     KC_TRY(kco_overlap_path_device(simp, complements, 0, &path, c));
     struct PathGuard { kc_ctx *c; KcPathDev *p; ~PathGuard() { kco_path_release(c, p); } } pathg{ctx, &path};
     KC_HIP(ctx, hipEventRecord(e3, ctx->stream));
+    tick("overlap path (phase 2)");
     KcRank rk;
     KC_TRY(kce_rank_path(simp, &path, &rk));
     struct RankGuard { kc_ctx *c; KcRank *r; ~RankGuard() { kce_rank_release(c, r); } } rankg{ctx, &rk};
@@ -1381,6 +1739,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     r->stats[10] = (u64)(1000.0 * ev_ms(ctx->ev[4], ctx->ev[5]));   // neighbour-probe kernel (kc_shard_choose_kernel)
     r->stats[12] = set->cap; r->stats[13] = path.repairs; r->stats[14] = (u64)(1000.0 * ev_ms(e0, eend));
     r->stats_ext[0] = cycles_cut; r->stats_ext[1] = N_local; r->stats_ext[2] = nq;
+    tick("path ranking, bases to their ranks, emit");
     if (trace) fprintf(stderr, "[shard %d/%d] entries=%llu jump rounds=%llu chains(local winners)=%llu S=%llu messages=%llu slice=[%llu,%llu) of %llu\n", me, G,
                        (unsigned long long)n_ent, (unsigned long long)rounds, (unsigned long long)n_chains, (unsigned long long)S, (unsigned long long)n_msg,
                        (unsigned long long)lo, (unsigned long long)hi, (unsigned long long)Ltot);

@@ -73,12 +73,13 @@ def test_ranks_emit_one_identical_superstring_random_reads(ctx, tmp_path, world)
 @pytest.mark.parametrize("k", [23, 63, 127])
 def test_ranks_wide_keys_and_branching_reads(ctx, tmp_path, k):
     """overlapping reads from both strands with errors: branch ports, chains that span many reads; phase 2 with the overlap
-    keys divided among the ranks (default) and with every rank doing all of it (KC_SHARD_REPLICATE_PHASE2=1)"""
+    keys divided among the ranks (KC_SHARD_SPLIT_MIN=0: the default from 2^23 overlap-graph vertices on) and with every rank doing all of
+    it (the default below that)"""
     recs = [r for r in gen.stress_reads(genome_len=30000, n_reads=600, read_len=max(200, 2 * k), seed=k, n_frac=0.002, lower_frac=0.05) if len(r) >= k]
     fa = str(tmp_path / "in.fa")
     write_fasta(fa, recs)
     want = single(ctx, fa, k, True)
-    for world, env in ((2, None), (3, None), (2, {"KC_SHARD_REPLICATE_PHASE2": "1"})):
+    for world, env in ((2, {"KC_SHARD_SPLIT_MIN": "0"}), (3, {"KC_SHARD_SPLIT_MIN": "0"}), (2, None)):
         got = run_ranks(world, fa, k, "bi", str(tmp_path / "out.npy"), extra_env=env)
         assert np.array_equal(got, want), (world, env)
 
@@ -89,7 +90,7 @@ def test_ranks_real_genome_with_cycles(ctx, golden_dir, tmp_path, world, k, mode
     where their best edge to a chain end is, whether they stay on one rank or span several.  One record, so some ranks hold no
     input at all."""
     fa = os.path.join(golden_dir, "spneumoniae.fa.gz")
-    got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), timeout=900)
+    got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), timeout=900, extra_env={"KC_SHARD_SPLIT_MIN": "0"} if world != 3 else None)
     assert np.array_equal(got, single(ctx, fa, k, mode == "bi")), (world, k, mode)
 
 
@@ -305,18 +306,27 @@ def test_fragment_ranking_variants(ctx, golden_dir, tmp_path):
     fa = str(tmp_path / "reads.fa")
     write_fasta(fa, recs)
     want = single(ctx, fa, 31, True)
-    for knob in ({}, {"KC_WAVE_MAX": "0"}):
+    # (default: the sampled ranking, these chains have ~60 fragments; KC_RANK_SAMPLED=0: plain waves; C / R small: nearly every fragment
+    # is unreached after R rounds and becomes a splitter of its own; C huge: no hashed splitters at all)
+    for knob in ({}, {"KC_WAVE_MAX": "0"}, {"KC_RANK_SAMPLED": "0"}, {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "3", "KC_RANK_R": "2"},
+                 {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "4096", "KC_RANK_R": "5"}):
         assert np.array_equal(run_ranks(3, fa, 31, "bi", str(tmp_path / "o.npy"), extra_env=knob), want), knob
     g = os.path.join(golden_dir, "spneumoniae.fa.gz")
-    assert np.array_equal(run_ranks(2, g, 31, "bi", str(tmp_path / "g.npy"), extra_env={"KC_WAVE_MAX": "100000000"}, timeout=900), single(ctx, g, 31, True))
+    wantg = single(ctx, g, 31, True)
+    assert np.array_equal(run_ranks(2, g, 31, "bi", str(tmp_path / "g.npy"), extra_env={"KC_RANK_SAMPLED": "0", "KC_WAVE_MAX": "100000000"}, timeout=900), wantg)
+    # the genome (chains of > 10^5 k-mers, cycles inside and across ranks) through the sampled ranking: splitters on cycles never
+    # reach a head and are given up after log2(all splitters) rounds, the cycle rule then opens them
+    for knob in ({"KC_RANK_SAMPLED": "1"}, {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "2", "KC_RANK_R": "3"}):
+        assert np.array_equal(run_ranks(3, g, 31, "bi", str(tmp_path / "g.npy"), extra_env=knob, timeout=900), wantg), knob
 
 
 def test_exchange_volume_per_kmer(ctx, tmp_path):
-    """Bytes a rank sends per k-mer it owns (kc_comm_stats), 4 ranks, 2*10^6 31-mers of random reads.  Measured with per-port
-    queries (one query per remote port, answered with the finished link word) and the fragment ranking by waves (one 24-byte
-    message per fragment): 17.5 B at 4 ranks (37.9 with pointer jumping, ~45 before the per-port queries) -- k-mer buckets 6,
-    port queries and answers ~4.2, waves ~4.2, tails / output messages / counts ~3.  The bound keeps the
-    volume from creeping back up."""
+    """Collectives and bytes a rank sends per k-mer it owns (kc_comm_stats), 4 and 8 ranks, 2*10^6 31-mers of random 1 kbp reads.
+    Round 4: 17.5 B at 4 ranks with the fragment ranking by plain waves -- and one collective pair per fragment of the longest chain
+    (341 / 371 collectives at 4 / 8 ranks, most of the flow's wall time).  Round 5: the sampled ranking (waves that stop at splitters,
+    pointer jumping over the splitters, one pull per fragment; slotted exchanges without a count exchange) and phase 2 without
+    collectives below 2^23 vertices: <= 80 collectives whatever the number of ranks, for ~1.7x the bytes.  The
+    bounds keep both from creeping back up."""
     import json
     sys.path.insert(0, ROOT)
     import bench
@@ -328,4 +338,15 @@ def test_exchange_volume_per_kmer(ctx, tmp_path):
     assert np.array_equal(got, want.array())
     want.close()
     st = json.load(open(out + ".stats.json"))
-    assert st["world"] == 4 and max(st["bytes_sent_per_owned_kmer"]) <= 20.0, st
+    print("4 ranks:", st)
+    assert st["world"] == 4 and max(st["bytes_sent_per_owned_kmer"]) <= 32.0 and st["collectives"] <= 80, st
+    # the same over 8 ranks sharing the GPU: the number of collectives does not grow with the ranks (the plain waves needed one round per
+    # fragment of the longest chain: 295 collectives of 371 at 8 ranks), and the volume stays bounded
+    got = run_ranks(8, fa, 31, "bi", out, timeout=900)
+    assert np.array_equal(got, np.asarray(np.load(out)))
+    st8 = json.load(open(out + ".stats.json"))
+    print("8 ranks:", st8)
+    w2 = kc.compute(ctx, seq, 31, True)
+    assert np.array_equal(got, w2.array())
+    w2.close()
+    assert st8["world"] == 8 and max(st8["bytes_sent_per_owned_kmer"]) <= 46.0 and st8["collectives"] <= 80, st8
