@@ -416,7 +416,6 @@ __global__ void __launch_bounds__(64) kc_slot_summary_kernel(const u64 *__restri
 // fragment -- so kc_shard_wave_finish_kernel and everything downstream are unchanged.  Fragments on cycles across ranks end with
 // pay = none, as with the waves (splitters on a cycle never reach a head: the jumping is bounded by log2 of all splitters).
 // spl: 0 fragment, 1 hashed splitter, 2 unreached after R rounds, 3 chain head.
-#define KC_SR_RESOLVED (~(u64)0 - 1)
 __global__ void __launch_bounds__(256) kc_shard_sr_init_kernel(const u64 *__restrict__ link, const u64 *__restrict__ entries, u64 n, const u64 *__restrict__ f_exit,
                                                                const u64 *__restrict__ f_partner, const u32 *__restrict__ fidx, u64 rlo2, int me, u32 C, u64 *pay, u64 *poff,
                                                                u64 *sjump, u8 *spl, u64 *act, u64 *cursor) {
@@ -437,26 +436,31 @@ __global__ void __launch_bounds__(256) kc_shard_sr_unreached_kernel(u64 n, const
     spl[t] = 2;
     if (f_partner[t] != KC_NONE64) act[atomicAdd((ull *)cursor, 1ULL)] = t;
 }
+// a wave message is two words: {target port (38 bits) | nodes, high 26 bits} {origin splitter (46 bits) | nodes, low 18 bits}
 __global__ void __launch_bounds__(256) kc_shard_sr_send_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ f_partner, const u64 *__restrict__ f_len,
                                                                const u64 *__restrict__ pay, const u64 *__restrict__ poff, const u8 *__restrict__ spl, int me, u64 rcap2, u64 *msgs,
-                                                               u8 *dest) {
+                                                               u8 *dest, u64 *flags) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 e = act[t], p = f_partner[e];
     const bool s = spl[e] != 0;
-    msgs[3 * t] = p; msgs[3 * t + 1] = s ? KC_GID(me, e) : pay[e]; msgs[3 * t + 2] = s ? f_len[e] : poff[e] + f_len[e];
+    const u64 org = s ? KC_GID(me, e) : pay[e], acc = s ? f_len[e] : poff[e] + f_len[e];
+    if ((acc >> 44) || (p >> 38)) flags[0] = 1;   // (2^44 nodes between two splitters, 2^38 ports: beyond any table this library builds)
+    msgs[2 * t] = p | ((acc >> 18) << 38);
+    msgs[2 * t + 1] = org | ((acc & (((u64)1 << 18) - 1)) << 46);
     dest[t] = (u8)(p / rcap2);
 }
 __global__ void __launch_bounds__(256) kc_shard_sr_recv_kernel(const u64 *__restrict__ recv, u64 stride, u64 cap, int G, const u32 *__restrict__ fidx, u64 rlo2,
                                                                const u64 *__restrict__ f_partner, const u8 *__restrict__ spl, u64 *pay, u64 *poff, u64 *sjump, u64 *act, u64 *cursor) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (u64)G * cap) return;
-    KC_SLOT_ITEM(recv, stride, cap, 3, t, valid, m);
+    KC_SLOT_ITEM(recv, stride, cap, 2, t, valid, m);
     if (!valid) return;
-    const u32 e = fidx[m[0] - rlo2];
-    poff[e] = m[2];
-    if (spl[e]) { sjump[e] = m[1]; return; }   // the wave ends here: this splitter now knows the one before it and the nodes between
-    pay[e] = m[1];
+    const u64 port = m[0] & (((u64)1 << 38) - 1), org = m[1] & (((u64)1 << 46) - 1), acc = ((m[0] >> 38) << 18) | (m[1] >> 46);
+    const u32 e = fidx[port - rlo2];
+    poff[e] = acc;
+    if (spl[e]) { sjump[e] = org; return; }   // the wave ends here: this splitter now knows the one before it and the nodes between
+    pay[e] = org;
     if (f_partner[e] != KC_NONE64) act[atomicAdd((ull *)cursor, 1ULL)] = e;
 }
 // the splitters that have a splitter before them (everything but the heads): the reduced list, jumped towards the heads
@@ -475,7 +479,10 @@ __global__ void __launch_bounds__(256) kc_shard_sr_req_kernel(const u64 *__restr
     req[t] = KC_GID_IDX(g);
     dest[t] = (u8)KC_GID_RANK(g);
 }
-// answers in the slots the requests came in: {the splitter before the asked one (KC_SR_RESOLVED: it knows its head), its nodes before, its payload}
+// answers in the slots the requests came in, two words: {the splitter before the asked one, its nodes before}; an asked splitter that
+// knows its head sends {payload | bit 63, nodes before} instead (ids use 46 bits; payload none: bit 62 -- a splitter nobody reached)
+#define KC_SR_RES_BIT ((u64)1 << 63)
+#define KC_SR_NOPAY_BIT ((u64)1 << 62)
 __global__ void __launch_bounds__(256) kc_shard_sr_ans_kernel(const u64 *__restrict__ recv, u64 stride, u64 cap, int G, const u64 *__restrict__ sjump, const u64 *__restrict__ poff,
                                                               const u64 *__restrict__ pay, u64 *ans) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -483,19 +490,18 @@ __global__ void __launch_bounds__(256) kc_shard_sr_ans_kernel(const u64 *__restr
     KC_SLOT_ITEM(recv, stride, cap, 1, t, valid, m);
     if (!valid) return;
     const u64 u = m[0];
-    u64 *a = ans + t * 3;
-    a[0] = sjump[u] == KC_NONE64 ? KC_SR_RESOLVED : sjump[u];
+    u64 *a = ans + t * 2;
+    a[0] = sjump[u] != KC_NONE64 ? sjump[u] : (pay[u] == KC_NONE64 ? (KC_SR_RES_BIT | KC_SR_NOPAY_BIT) : (KC_SR_RES_BIT | pay[u]));
     a[1] = poff[u];
-    a[2] = pay[u];
 }
 __global__ void __launch_bounds__(256) kc_shard_sr_apply_jump_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ slotpos, const u64 *__restrict__ ansb, u64 *sjump,
                                                                      u64 *poff, u64 *pay, u64 *act_next, u64 *cursor) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 e = act[t];
-    const u64 *a = ansb + slotpos[t] * 3;
+    const u64 *a = ansb + slotpos[t] * 2;
     poff[e] += a[1];
-    if (a[0] == KC_SR_RESOLVED) { pay[e] = a[2]; sjump[e] = KC_NONE64; }
+    if (a[0] & KC_SR_RES_BIT) { pay[e] = (a[0] & KC_SR_NOPAY_BIT) ? KC_NONE64 : (a[0] & ~KC_SR_RES_BIT); sjump[e] = KC_NONE64; }
     else { sjump[e] = a[0]; act_next[atomicAdd((ull *)cursor, 1ULL)] = e; }
 }
 __global__ void __launch_bounds__(256) kc_shard_sr_apply_pull_kernel(const u64 *__restrict__ act, u64 n, const u64 *__restrict__ slotpos, const u64 *__restrict__ ansb, u64 *poff,
@@ -503,10 +509,10 @@ __global__ void __launch_bounds__(256) kc_shard_sr_apply_pull_kernel(const u64 *
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const u64 e = act[t];
-    const u64 *a = ansb + slotpos[t] * 3;
-    // (a splitter on a cycle never found a head: its payload is none, and so is that of the fragments behind it)
-    const bool ok = a[0] == KC_SR_RESOLVED && a[2] != KC_NONE64;
-    pay[e] = ok ? a[2] : KC_NONE64;
+    const u64 *a = ansb + slotpos[t] * 2;
+    // (a splitter on a cycle never found a head: it is still jumping or was given up -- no payload for the fragments behind it either)
+    const bool ok = (a[0] & KC_SR_RES_BIT) && !(a[0] & KC_SR_NOPAY_BIT);
+    pay[e] = ok ? (a[0] & ~KC_SR_RES_BIT) : KC_NONE64;
     poff[e] += a[1];
 }
 // splitters that are still jumping when the bound is reached lie on cycles
@@ -1283,10 +1289,10 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
             if (sampled) {
                 u64 *sjump = nullptr, *act2 = nullptr, *items = nullptr, *slotpos = nullptr, *ansbuf = nullptr, *ansback = nullptr;
                 u8 *spl = nullptr, *sdest = nullptr;
-                KC_TRY(scope.alloc(&sjump, n_ent + 1)); KC_TRY(scope.alloc(&act2, n_ent + 1)); KC_TRY(scope.alloc(&items, 3 * (n_ent + 1)));
+                KC_TRY(scope.alloc(&sjump, n_ent + 1)); KC_TRY(scope.alloc(&act2, n_ent + 1)); KC_TRY(scope.alloc(&items, 2 * (n_ent + 1)));
                 KC_TRY(scope.alloc(&slotpos, n_ent + 1)); KC_TRY(scope.alloc(&spl, n_ent + 1)); KC_TRY(scope.alloc(&sdest, n_ent + 1));
-                u64 *acur = cur + 3 * KC_USTRIDE;   // [0], [1]: cursors of the two active lists
-                KC_HIP(ctx, hipMemsetAsync(acur, 0, 16, ctx->stream));
+                u64 *acur = cur + 3 * KC_USTRIDE;   // [0], [1]: cursors of the two active lists, [2]: a wave message did not fit its two words
+                KC_HIP(ctx, hipMemsetAsync(acur, 0, 24, ctx->stream));
                 if (n_ent) KC_LAUNCH(kc_shard_sr_init_kernel, dim3(kc_grid(n_ent, 256)), dim3(256), 0, ctx->stream, (const u64 *)link, (const u64 *)entries, n_ent, (const u64 *)f_exit,
                                               (const u64 *)f_partner, (const u32 *)fidx, 2 * rlo, me, SR_C, pay, poff, sjump, spl, act, acur);
                 u64 n_cur = 0;
@@ -1307,9 +1313,9 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                         KC_TRY(read_words(ctx, acur + ca, &n_cur, 1));
                         capw = cap0;
                     }
-                    KC_TRY(sx.ensure(3, capw));
+                    KC_TRY(sx.ensure(2, capw));
                     if (n_cur) KC_LAUNCH(kc_shard_sr_send_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)la, n_cur, (const u64 *)f_partner, (const u64 *)f_len,
-                                                  (const u64 *)pay, (const u64 *)poff, (const u8 *)spl, me, 2 * rcap, items, sdest);
+                                                  (const u64 *)pay, (const u64 *)poff, (const u8 *)spl, me, 2 * rcap, items, sdest, acur + 2);
                     KC_TRY(sx.exchange(items, sdest, n_cur, nullptr, h4));
                     ++rounds;
                     KC_HIP(ctx, hipMemsetAsync(acur + (ca ^ 1), 0, 8, ctx->stream));
@@ -1319,6 +1325,12 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                     std::swap(la, lb); ca ^= 1;
                     capw = h4[1] + h4[1] / 16 + 256;   // (waves only end: a round rarely sends more to a peer than the one before -- if one does, the exchange repeats)
                     if (h4[2] == 0 && r < SR_R) r = SR_R;   // every wave has ended early (all ranks see the same total): straight to the last round
+                }
+                {   // (the ranks find out together)
+                    u64 bad = 0;
+                    KC_TRY(read_words(ctx, acur + 2, &bad, 1));
+                    KC_TRY(kcc_allreduce_max(c, &bad, 1));
+                    if (bad) return kc_fail_agreed(ctx, KC_E_CAPACITY, "sampled fragment ranking: a wave message does not fit its two words (on some rank)");
                 }
                 // the reduced list: pointer jumping towards the heads
                 KC_HIP(ctx, hipMemsetAsync(acur, 0, 16, ctx->stream));
@@ -1337,11 +1349,11 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                     KC_TRY(sx.exchange(items, sdest, n_cur, slotpos, h4));
                     ++rounds;
                     if (h4[2] == 0) break;   // nobody asks any more
-                    const u64 aw = (u64)G * sx.cap * 3 + 1;
+                    const u64 aw = (u64)G * sx.cap * 2 + 1;
                     KC_TRY(scope.alloc(&ansbuf, aw)); KC_TRY(scope.alloc(&ansback, aw));
                     if (h4[3]) KC_LAUNCH(kc_shard_sr_ans_kernel, dim3(kc_grid((u64)G * sx.cap, 256)), dim3(256), 0, ctx->stream, (const u64 *)sx.recv, sx.stride, sx.cap, G, (const u64 *)sjump,
                                                   (const u64 *)poff, (const u64 *)pay, ansbuf);
-                    KC_TRY(sx.answer(ansbuf, 3, ansback));
+                    KC_TRY(sx.answer(ansbuf, 2, ansback));
                     KC_HIP(ctx, hipMemsetAsync(acur + (ca ^ 1), 0, 8, ctx->stream));
                     if (j + 1 >= max_jumps) {   // still jumping after log2(all splitters) rounds: on a cycle
                         if (n_cur) KC_LAUNCH(kc_shard_sr_giveup_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)la, n_cur, pay);
@@ -1364,11 +1376,11 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                     KC_TRY(sx.ensure(1, mx[1] / peers + mx[1] / (4 * peers) + 1024));
                     if (n_cur) KC_LAUNCH(kc_shard_sr_req_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_cur, (const u64 *)pay, items, sdest);
                     KC_TRY(sx.exchange(items, sdest, n_cur, slotpos, h4));
-                    const u64 aw = (u64)G * sx.cap * 3 + 1;
+                    const u64 aw = (u64)G * sx.cap * 2 + 1;
                     KC_TRY(scope.alloc(&ansbuf, aw)); KC_TRY(scope.alloc(&ansback, aw));
                     if (h4[3]) KC_LAUNCH(kc_shard_sr_ans_kernel, dim3(kc_grid((u64)G * sx.cap, 256)), dim3(256), 0, ctx->stream, (const u64 *)sx.recv, sx.stride, sx.cap, G, (const u64 *)sjump,
                                                   (const u64 *)poff, (const u64 *)pay, ansbuf);
-                    KC_TRY(sx.answer(ansbuf, 3, ansback));
+                    KC_TRY(sx.answer(ansbuf, 2, ansback));
                     if (n_cur) KC_LAUNCH(kc_shard_sr_apply_pull_kernel, dim3(kc_grid(n_cur, 256)), dim3(256), 0, ctx->stream, (const u64 *)act, n_cur, (const u64 *)slotpos, (const u64 *)ansback, poff, pay);
                     KC_HIP(ctx, hipGetLastError());
                     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));

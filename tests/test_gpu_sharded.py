@@ -339,7 +339,7 @@ def test_exchange_volume_per_kmer(ctx, tmp_path):
     want.close()
     st = json.load(open(out + ".stats.json"))
     print("4 ranks:", st)
-    assert st["world"] == 4 and max(st["bytes_sent_per_owned_kmer"]) <= 32.0 and st["collectives"] <= 80, st
+    assert st["world"] == 4 and max(st["bytes_sent_per_owned_kmer"]) <= 28.0 and st["collectives"] <= 80, st
     # the same over 8 ranks sharing the GPU: the number of collectives does not grow with the ranks (the plain waves needed one round per
     # fragment of the longest chain: 295 collectives of 371 at 8 ranks), and the volume stays bounded
     got = run_ranks(8, fa, 31, "bi", out, timeout=900)
@@ -349,4 +349,4 @@ def test_exchange_volume_per_kmer(ctx, tmp_path):
     w2 = kc.compute(ctx, seq, 31, True)
     assert np.array_equal(got, w2.array())
     w2.close()
-    assert st8["world"] == 8 and max(st8["bytes_sent_per_owned_kmer"]) <= 46.0 and st8["collectives"] <= 80, st8
+    assert st8["world"] == 8 and max(st8["bytes_sent_per_owned_kmer"]) <= 38.0 and st8["collectives"] <= 80, st8
