@@ -1009,16 +1009,23 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     // all-gather the edges they logged and apply the others'; verification, repair and the shrinking of the active lists run
     // on the combined log, identically everywhere.  Exactness is untouched: buckets of one level never shared state except
     // through the verified path ends (that is what the verify / repair step is for), whether they run on one GPU or on eight.
-    // Up to 2^23 vertices (KC_SHARD_SPLIT_MIN) the ranks do NOT divide the work: every rank runs the whole phase on its own, through the
-    // single-GPU path (windowed hit counts, grouped levels) and without a single collective.  Measured with 8 ranks on 10^8 k-mers
-    // (2 10^5 vertices): divided 20 ms and 52 collectives, against 5 ms for the phase on one GPU; at 5 10^6 vertices (2.5 10^9 k-mers) the
-    // division saves the replays (~10 of 27 ms) and pays ~60 collectives for it.  KC_SHARD_REPLICATE_PHASE2=1: never divide.
+    // WHICH levels the ranks divide (round 5): only the levels that build a table of their own while more than 2^20 vertices are live
+    // (KC_OVG_MAX) -- the mid levels of a large read set, where a level costs sweeps, sorts and hundreds of thousands of small replays, all
+    // of which divide by the number of ranks.  Every other level runs WHOLE on every rank, through the single-GPU path and without a
+    // collective: the levels d >= 16 through the 16-mer table (one cheap sweep each, few hits), and everything from 2^20 live vertices
+    // down (the grouped levels: bound by launches, and at d <= 3 by a few huge buckets that one wavefront replays -- nothing to divide).
+    // All ranks hold identical vertex arrays after every level (the divided ones all-gather and apply their edges), and what decides the
+    // mode -- d, the live counts, whether the 16-mer table is in use -- is replicated, so the ranks switch together.  Measured with 8 ranks
+    // on 10^8 k-mers (2 10^5 vertices): every level divided 20 ms and 52 collectives, against 5 ms for the phase on one GPU; at cfg[3]
+    // (5 10^6 vertices) the whole phase is 27 ms on one GPU, of which the 8 divided levels d = 16 .. 9 are 15.
+    // KC_SHARD_REPLICATE_PHASE2=1: never divide; KC_SHARD_SPLIT_MIN=v: only from v vertices on (default 0).
     const int k = s->k;
     const u64 S = s->n, V = S * (complements ? 2 : 1);
-    u64 split_min = (u64)1 << 23;
+    u64 split_min = 0;
     if (const char *e = getenv("KC_SHARD_SPLIT_MIN")) split_min = (u64)atoll(e);
-    const bool split = comm && comm->world > 1 && !lower_bound && !getenv("KC_SHARD_REPLICATE_PHASE2") && V >= split_min;
-    const u32 PG = split ? (u32)comm->world : 1u, pme = split ? (u32)comm->rank : 0u;
+    const bool can_split = comm && comm->world > 1 && !lower_bound && !getenv("KC_SHARD_REPLICATE_PHASE2") && V >= split_min;
+    bool split = false;      // the level at hand is divided (set per level in the loop at the end)
+    u32 PG = 1u, pme = 0u;
     if (S == 0) return kc_fail_agreed(ctx, KC_E_EMPTY, "input cannot be empty");
     if (V >= ((u64)1 << 32)) return kc_fail(ctx, KC_E_ARG, "more than 2^32 overlap-graph vertices are not supported (32-bit writer tags of the path-end entries)");
     OvWork w; w.ctx = ctx;
@@ -1114,7 +1121,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     // sharded new-edge log (see ov_add_event): every shard could hold a whole level's edges of an evenly spread load four times over
     u64 *ne_sh = nullptr, *ne_shcur = nullptr;
     const u64 ne_shcap = (2 * V) / 16 + 1024;
-    const bool log_sharded = (V >= ((u64)1 << 16) && !getenv("KC_NO_SHARDED_LOG")) || (!lower_bound && !split && !getenv("KC_OV_HOST_LOOP"));   // (the grouped levels always log through the shards)
+    const bool log_sharded = (V >= ((u64)1 << 16) && !getenv("KC_NO_SHARDED_LOG")) || (!lower_bound && !getenv("KC_OV_HOST_LOOP"));   // (the grouped levels always log through the shards)
     if (log_sharded) { KC_TRY(scope.alloc(&ne_sh, 64 * ne_shcap * 5)); KC_TRY(scope.alloc(&ne_shcur, 65 * 16)); }
     g.ne_sh = nullptr; g.ne_shcur = ne_shcur; g.ne_shcap = ne_shcap;
     u64 nS = V, nP = V, repairs = 0, tag_base = 0;
@@ -1124,7 +1131,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     KC_TRY(scope.alloc(&whist, 64));
     int win_hi = -1, win_lo = 0;
     u64 wcount[32] = {0};
-    bool win_on = t16_on && !split && !getenv("KC_OV_NO_WINDOW");
+    bool win_on = t16_on && !getenv("KC_OV_NO_WINDOW");   // (the levels through the 16-mer table are never divided among ranks)
     bool t16_sampled = false;
     std::vector<u64> h_bl;
     if (!lower_bound) {   // tag 0xffffffff = written by nobody
@@ -1135,7 +1142,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     KC_HIP(ctx, hipHostMalloc((void **)&hp, 1024, hipHostMallocDefault));   // (hp[64..96): the window counts)
     w.h_flag = hp + 15;   // (the level loop reads back at most 9 words; hp[32..] are staging words of the sharded flow)
     u64 *ne_all = nullptr;
-    if (split) KC_TRY(scope.alloc(&ne_all, V * 10 + 10));
+    if (can_split) KC_TRY(scope.alloc(&ne_all, V * 10 + 10));
     auto run_level_host = [&](const int d) -> int {   // one level of the host-driven loop
         g.d = d;
         const bool trace = getenv("KC_OV_TRACE") != nullptr;
@@ -1231,7 +1238,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
         // 3. ... and sort them by key (stable: ids ascending inside a key).  Few hits: the probe kernels have listed them
         // already (unordered); one workgroup derives the keys and sorts the rows by (key, id) in LDS.
         const bool small_ok = !getenv("KC_NO_SMALL_SORT");
-        auto small_side = [&](bool suffix_side, const u64 *ids_in, u64 n, u64 *keys_o, u64 *ids_o) {
+        auto small_side = [&](bool suffix_side, const u64 *ids_in, u64 n, u64 *keys_o, u64 *ids_o) -> int {
             u32 P = 2;
             while (P < n) P <<= 1;
             const size_t lds = (size_t)P * (W + 1) * 8;
@@ -1241,13 +1248,14 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             else
                 KC_LAUNCH((ov_small_sort_kernel<W, 2>), dim3(1), dim3(1024), lds, ctx->stream, (const u64 *)nullptr, ids_in, (u32)n, P,
                                    (const u64 *)pre, k, d, keys_o, ids_o);
+            return KC_OK;
         };
         // a bucketed sort that overflows (skewed keys) leaves its flag word set and its output void; the match kernels then
         // stand down, the flag comes back with their counters, and the side is sorted again by the LSD sort (no sync of its own)
         bool bkS = false, bkP = false;
         KC_HIP(ctx, hipMemsetAsync(w.d_flag, 0, 16, ctx->stream));
         if (!local_any) { /* nothing of ours at this level: only the exchange below */ }
-        else if (small_ok && nHS <= KC_SMALL_ROWS) small_side(true, hs_ids, nHS, hs_keys2, hs_ids2);
+        else if (small_ok && nHS <= KC_SMALL_ROWS) KC_TRY(small_side(true, hs_ids, nHS, hs_keys2, hs_ids2));
         else {
             KC_TRY(select_flagged_nosync(w, actS, hitS, hs_ids, lenS));
             KC_LAUNCH((ov_hit_keys_kernel<W, true>), dim3(kc_grid(nHS, 256)), dim3(256), 0, ctx->stream, (const u64 *)hs_ids, nHS,
@@ -1255,7 +1263,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             KC_TRY(sort_rows(w, hs_keys, hs_ids, nHS, W, d, hs_keys2, hs_ids2, sc0, sc1, sc2, sc3, 0, true, &bkS));
         }
         if (!local_any) { }
-        else if (small_ok && nHP <= KC_SMALL_ROWS) small_side(false, hp_ids, nHP, hp_keys2, hp_ids2);
+        else if (small_ok && nHP <= KC_SMALL_ROWS) KC_TRY(small_side(false, hp_ids, nHP, hp_keys2, hp_ids2));
         else {
             KC_TRY(select_flagged_nosync(w, actP, hitP, hp_ids, lenP));
             KC_LAUNCH((ov_hit_keys_kernel<W, false>), dim3(kc_grid(nHP, 256)), dim3(256), 0, ctx->stream, (const u64 *)hp_ids, nHP,
@@ -1418,7 +1426,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     };
     // ---- the grouped levels (no host in the loop; see OVG_* above): every level that builds a table of its own, i.e. all but the
     // levels d >= 16 that go through the 16-mer table.  KC_OV_HOST_LOOP=1: the host-driven loop for everything.
-    const bool grouped_ok = !lower_bound && !split && !getenv("KC_OV_HOST_LOOP");
+    const bool grouped_ok = !lower_bound && !getenv("KC_OV_HOST_LOOP");
     u64 *ovg_st = nullptr, *ovg_lcnt = nullptr;
     OvgBuf ob{};
     bool lists_unsorted = false;
@@ -1522,10 +1530,12 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     // which the grouped levels are used.
     u64 ovg_max = (u64)1 << 20;
     if (const char *e = getenv("KC_OVG_MAX")) ovg_max = (u64)atoll(e);
+    auto set_split = [&](bool on) { split = on; PG = on ? (u32)comm->world : 1u; pme = on ? (u32)comm->rank : 0u; };
     for (int d = k - 1; d >= 0 && nS > 0 && nP > 0;) {
         const bool t16_level = t16_on && !t16_dead && d >= 16;
         if (grouped_ok && !t16_level && nS + nP <= ovg_max) {
             int next = -1;
+            set_split(false);
             KC_TRY(run_grouped(d, &next));
             if (next < 0) break;
             KC_TRY(sort_lists());
@@ -1533,6 +1543,8 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             d = next - 1;
             continue;
         }
+        // (t16_dead can only change inside a level that is not divided, so every rank sees the same t16_level here)
+        set_split(can_split && !t16_level && nS + nP > ovg_max);
         KC_TRY(run_level_host(d));
         --d;
     }

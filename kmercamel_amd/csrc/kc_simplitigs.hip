@@ -979,7 +979,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     bool hop = false;   // the links are contracted right now
     u64 *hpool = nullptr, *hbase = nullptr, *hcur = nullptr, *hlog = nullptr, *hblog = nullptr;
     // one thread per segment start: mode 0 measure, 1 measure + mark, 2 the segments of no chain take their marks back
-    auto seg_walk = [&](int mode, u8 *marks) {
+    auto seg_walk = [&](int mode, u8 *marks) -> int {
         const dim3 g(kc_grid(nstarts, 256)), b(256);
         const u64 *sc = mode == 2 ? (const u64 *)seg_chain : (const u64 *)nullptr;
         const u32 st = mode == 0 ? 0u : sparse_stride;
@@ -992,6 +992,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             else if (mode == 1) KC_LAUNCH(kc_segment_walk_kernel<1>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
             else KC_LAUNCH(kc_segment_walk_kernel<2>, g, b, 0, ctx->stream, (const u64 *)link, (const u64 *)starts, nstarts, seg_len, seg_next, seg_tail, marks, sc, NID, st);
         }
+        return KC_OK;
     };
     // (more k-mers per chain head than the limit: some chain is longer than it, whatever the per-chain pass would find -- the 4 ms it
     // takes to give up on a genome are saved; k-mers on cycles only make this a cautious guess: the segment path serves short chains too)
@@ -1131,7 +1132,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 KC_HIP(ctx, hipMemsetAsync(seg_marks, 0, NID, ctx->stream));
             }
             if (nstarts) {
-                seg_walk(seg_marks ? 1 : 0, seg_marks);
+                KC_TRY(seg_walk(seg_marks ? 1 : 0, seg_marks));
                 KC_LAUNCH((kc_chain_reduce_kernel<W>), dim3(kc_grid(nstarts, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, compl_,
                                    (const u64 *)starts, nstarts, (const u64 *)seg_len, (const u64 *)seg_next, (const u64 *)seg_tail, seg_chain,
                                    seg_off, chain_head, chain_len, chain_key, cnt);
@@ -1151,7 +1152,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             visited = seg_marks;
             seg_marks = nullptr;
             marked = true;
-            if (nstarts) seg_walk(2, visited);
+            if (nstarts) KC_TRY(seg_walk(2, visited));
         } else {
             KC_TRY(scope.alloc(&visited, NID));
             KC_HIP(ctx, hipMemsetAsync(visited, 0, NID, ctx->stream));
@@ -1160,8 +1161,8 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         if (too_long && marked) {
         } else if (too_long) {
             if (nstarts) {   // (a marking walk of its own, then the segments of no chain take their marks back)
-                seg_walk(1, visited);
-                seg_walk(2, visited);
+                KC_TRY(seg_walk(1, visited));
+                KC_TRY(seg_walk(2, visited));
             }
         } else if (nheads) {
             KC_LAUNCH((kc_walk_measure_kernel<W, true, false>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link,

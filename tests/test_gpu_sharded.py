@@ -73,13 +73,13 @@ def test_ranks_emit_one_identical_superstring_random_reads(ctx, tmp_path, world)
 @pytest.mark.parametrize("k", [23, 63, 127])
 def test_ranks_wide_keys_and_branching_reads(ctx, tmp_path, k):
     """overlapping reads from both strands with errors: branch ports, chains that span many reads; phase 2 with the overlap
-    keys divided among the ranks (KC_SHARD_SPLIT_MIN=0: the default from 2^23 overlap-graph vertices on) and with every rank doing all of
-    it (the default below that)"""
+    keys divided among the ranks (KC_OVG_MAX=0: every level that builds a table of its own, as the levels with more than 2^20 live
+    vertices are by default) and with every rank doing all of it (what these small inputs get by default)"""
     recs = [r for r in gen.stress_reads(genome_len=30000, n_reads=600, read_len=max(200, 2 * k), seed=k, n_frac=0.002, lower_frac=0.05) if len(r) >= k]
     fa = str(tmp_path / "in.fa")
     write_fasta(fa, recs)
     want = single(ctx, fa, k, True)
-    for world, env in ((2, {"KC_SHARD_SPLIT_MIN": "0"}), (3, {"KC_SHARD_SPLIT_MIN": "0"}), (2, None)):
+    for world, env in ((2, {"KC_OVG_MAX": "0"}), (3, {"KC_OVG_MAX": "300"}), (2, None)):
         got = run_ranks(world, fa, k, "bi", str(tmp_path / "out.npy"), extra_env=env)
         assert np.array_equal(got, want), (world, env)
 
@@ -90,7 +90,7 @@ def test_ranks_real_genome_with_cycles(ctx, golden_dir, tmp_path, world, k, mode
     where their best edge to a chain end is, whether they stay on one rank or span several.  One record, so some ranks hold no
     input at all."""
     fa = os.path.join(golden_dir, "spneumoniae.fa.gz")
-    got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), timeout=900, extra_env={"KC_SHARD_SPLIT_MIN": "0"} if world != 3 else None)
+    got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), timeout=900, extra_env={"KC_OVG_MAX": "0"} if world != 3 else None)
     assert np.array_equal(got, single(ctx, fa, k, mode == "bi")), (world, k, mode)
 
 
@@ -178,6 +178,10 @@ def test_ranks_cfg1_full_size(ctx, tmp_path):
     w = want.array().copy()
     want.close()
     got = run_ranks(4, fa, 31, "bi", str(tmp_path / "out.npy"), timeout=1200)
+    assert np.array_equal(got, w)
+    # phase 2 in its mixed form, as a 2.5 10^9-k-mer set takes it by default: the levels through the 16-mer table whole on every rank, the
+    # table levels with more than KC_OVG_MAX live vertices divided among the ranks, the rest (grouped levels) whole again
+    got = run_ranks(3, fa, 31, "bi", str(tmp_path / "out.npy"), timeout=1200, extra_env={"KC_OVG_MAX": "60000"})
     assert np.array_equal(got, w)
 
 
