@@ -35,10 +35,15 @@ CHUNK_RECORDS = 100000  # the record set is generated in chunks of this many rec
 def traffic_from_profile(kernel_substr, records, k):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS workload (separate FETCH_SIZE /
     WRITE_SIZE passes, tools/collect_profile.sh -> tools/summarize_profile.py); None when no profile of it is committed."""
-    name = {(2500000, 31): "r04_cfg2_2p5G_traffic.json", (100000, 31): "r04_cfg1_traffic.json", (100000, 63): "r04_k63_traffic.json",
-            (100000, 127): "r04_k127_traffic.json"}.get((records, k))
-    path = os.path.join(ROOT, "profiles", name) if name else None
-    if not path or not os.path.exists(path):
+    name = {(2500000, 31): "cfg2_2p5G_traffic.json", (100000, 31): "cfg1_traffic.json", (100000, 63): "k63_traffic.json",
+            (100000, 127): "k127_traffic.json"}.get((records, k))
+    path = None
+    for rnd in ("r05_", "r04_"):   # the newest round that profiled this workload (the kernels of the pass have not changed since round 4)
+        cand = os.path.join(ROOT, "profiles", rnd + name) if name else None
+        if cand and os.path.exists(cand):
+            path = cand
+            break
+    if not path:
         return None, None
     try:
         t = json.load(open(path))

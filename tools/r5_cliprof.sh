@@ -9,9 +9,6 @@ d = "/dev/shm/kc_r5"; os.makedirs(d, exist_ok=True)
 bench.generate(2, 0, 2500000, 1030, fasta=d + "/in.fa")
 PY
 R=$(pwd)
-for i in 1 2 3; do sleep 5; /usr/bin/time -f "wall %e s" env KC_CLI_TRACE=1 kmercamel_amd/bin/kmercamel compute -k 31 -o /dev/shm/kc_r5/out.txt /dev/shm/kc_r5/in.fa 2>&1 | grep -v "^\[2" ; done > gpurun_out/r5/cli_trace2.txt 2>&1
-md5sum /dev/shm/kc_r5/out.txt >> gpurun_out/r5/cli_trace2.txt
-cat gpurun_out/r5/cli_trace2.txt
 cd /tmp && export TMPDIR=/tmp
 KC_CLI_NO_FAST_EXIT=1 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $R/gpurun_out/r5/cli_prof -- $R/kmercamel_amd/bin/kmercamel compute -k 31 -o /dev/shm/kc_r5/out.txt /dev/shm/kc_r5/in.fa > $R/gpurun_out/r5/cli_prof.log 2>&1
 cd $R
@@ -37,3 +34,4 @@ for s, e, n in rows[:60]:
 print("last event ends at %.3f ms" % ((rows[-1][1] - t0) / 1e6))
 PY
 find gpurun_out/r5/cli_prof -name "*_trace.csv" -delete
+rm -rf gpurun_out/r5/cli_prof
