@@ -12,10 +12,14 @@
 //            ports") contribute their edges to a small replicated subgraph that every rank settles identically by the
 //            sequential form of the rule (edges by descending priority) -- branch ports are rare on read-like input.
 //   phase 1b chains: every rank contracts the chain pieces that stay inside it ("fragments", kc_shard_walk_kernel, bases
-//            recorded 2 bits per step), fragments are ranked across ranks by pointer jumping (log2 rounds of
-//            request/answer all-to-alls), chain heads gather their tails and decide orientation; the chain records
-//            (head/tail k-mers, length) are all-gathered and sorted by head key on every rank = the simplitig list.
-//   phase 2  overlap path: replicated (it needs only the 2 end k-mers per simplitig; V ~ 2 * 10^-3 N).
+//            recorded 2 bits per step); the fragments are ranked across ranks -- by SAMPLED WAVES where chains are long in
+//            fragments (waves that stop at splitters, pointer jumping over the splitters only, one pull per fragment: ~40
+//            single-collective rounds whatever the chain length, kc_shard_sr_*), by plain waves where they are short (one
+//            round per fragment of the longest chain), by pointer jumping on unidirectional sets; chain heads gather their
+//            tails and decide orientation; the chain records (head/tail k-mers, length) are all-gathered and sorted by head
+//            key on every rank = the simplitig list.
+//   phase 2  overlap path on the replicated list of end k-mers (V ~ 2 * 10^-3 N): the table levels with more than 2^20 live
+//            vertices are divided among the ranks by key, every other level runs whole on every rank without a collective.
 //   phase 3  every simplitig is emitted by the rank that owns the output range it starts in: the winning fragments send
 //            their recorded bases (32 per message) there, the owner assembles the packed simplitigs and runs the ordinary
 //            emit kernel into its slice of the superstring.

@@ -223,6 +223,41 @@ def test_cli_streamed_fasta_tokeniser_equals_host_parser(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_large_input_takes_the_mapped_output_path(tmp_path):
+    """Inputs beyond 64 MB with `-o FILE`: the output file is fallocate'd and mapped while the GPU works, its pages are touched by
+    background threads, and the result arrives through kc_result_write_mem (pinned chunks, copy threads).  Same bytes as the plain
+    descriptor path (KC_CLI_NOPREALLOC=1), as stdout, and with the helpers switched off or odd (no touching threads, 3 I/O threads, one
+    serial thread); the input has CRLF lines, so that a '\\r' now and then ends a 32 MB chunk and has to wait for its '\\n'."""
+    import random
+    rng = random.Random(5)
+    path = str(tmp_path / "large.fa")
+    with open(path, "w", newline="") as f:
+        for r in range(6200):
+            s = "".join(rng.choices("ACGT", k=12000))
+            eol = "\r\n" if r % 3 == 0 else "\n"
+            f.write(">rec%d%s" % (r, eol))
+            f.write(eol.join(s[i:i + 61] for i in range(0, len(s), 61)) + eol)
+    assert os.path.getsize(path) > (64 << 20)
+    ref = run("compute", "-k", "31", path)
+    assert ref.returncode == 0
+    want = ref.stdout.split("\n")
+    assert len(want) == 3 and want[2] == ""
+    for env in ({}, {"KC_CLI_NOPREALLOC": "1"}, {"KC_CLI_TOUCH_THREADS": "0"}, {"KC_IO_THREADS": "3"}, {"KC_IO_SERIAL": "1"}):
+        o = str(tmp_path / "o.fa")
+        if os.path.exists(o):
+            os.unlink(o)
+        p = subprocess.run([BIN, "compute", "-k", "31", "-o", o, path], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert p.returncode == 0, (env, p.stderr[-400:])
+        got = open(o).read().split("\n")
+        assert got[0].startswith(">maskedsuperstring") and got[1] == want[1] and got[2] == "" and len(got) == 3, env
+    # an output file that already holds something longer is cut to the new length
+    with open(o, "w") as f:
+        f.write("x" * (len(want[1]) + 5000000))
+    assert subprocess.run([BIN, "compute", "-k", "31", "-o", o, path], capture_output=True).returncode == 0
+    assert open(o).read().split("\n")[1] == want[1]
+
+
+@pytest.mark.gpu
 def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
     """`compute --gpus N` (new long option / KMERCAMEL_GPUS): N rank threads in one process, the k-mer set
     hash-sharded over them, exchanges through the in-process thread transport (ranks beyond the device count share the GPU).
