@@ -190,7 +190,7 @@ int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *
 void kc_device_free(kc_ctx *ctx, void *d_ptr);
 /* write the result's characters (which = 0) or its -M mask (which = 1) to a file descriptor */
 int kc_result_write_fd(kc_result *r, int fd, int which);
-/* the same into host memory (e.g. a shared mapping of the output file whose pages are already there): pinned chunks, each
+/* the same into host memory (e.g. a shared mapping of the output file whose pages fallocate() has provided): pinned chunks, each
  * moved on by several threads while the next one arrives from the device.  dst must hold the slice (kc_result_slice). */
 int kc_result_write_mem(kc_result *r, void *dst, int which);
 

@@ -876,10 +876,16 @@ struct SlotX {
     u64 *send = nullptr, *recv = nullptr, *cnt = nullptr;   // cnt: G counters, then 4 summary words
     u64 exchanges = 0, redone = 0;
     u64 sent_to[KC_MAX_RANKS_SH] = {0}, got_from[KC_MAX_RANKS_SH] = {0};   // items per peer of the last exchange
-    SlotX(kc_ctx *x, kc_comm *cm, KcScope *sc) : ctx(x), c(cm), scope(sc), G(cm->world) {}
-    int ensure(int e, u64 want_cap) {
+    // KC_SLOT_TEST_SHRINK=n (tests; read when the exchange object is set up, never on the data path): every requested slot size is divided
+    // by n, so that exchanges overflow and the agreed repeat with the larger size runs
+    u64 test_shrink = 1;
+    SlotX(kc_ctx *x, kc_comm *cm, KcScope *sc) : ctx(x), c(cm), scope(sc), G(cm->world) {
+        if (const char *e = getenv("KC_SLOT_TEST_SHRINK")) { const long v = atol(e); if (v >= 1) test_shrink = (u64)v; }
+    }
+    int ensure(int e, u64 want_cap, bool after_overflow = false) {
+        if (!after_overflow) want_cap /= test_shrink;
         if (!cnt) { KC_TRY(scope->alloc(&cnt, KC_MAX_RANKS_SH + 8)); KC_HIP(ctx, hipMemsetAsync(cnt, 0, (KC_MAX_RANKS_SH + 8) * 8, ctx->stream)); }
-        if (want_cap < 64) want_cap = 64;
+        if (want_cap < (test_shrink > 1 ? 1 : 64)) want_cap = test_shrink > 1 ? 1 : 64;
         const u64 st = KC_SLOT_HW + want_cap * (u64)e;
         if (send && st * (u64)G <= words_) { E = e; cap = want_cap; stride = st; return KC_OK; }
         if (send) { KC_HIP(ctx, hipStreamSynchronize(ctx->stream)); scope->release(send); scope->release(recv); send = recv = nullptr; }
@@ -908,7 +914,7 @@ struct SlotX {
             ++exchanges;
             if (!h4[0]) return KC_OK;
             ++redone;
-            KC_TRY(ensure(E, h4[1] + h4[1] / 4 + 64));   // (the largest count is known to everybody: the repeat fits)
+            KC_TRY(ensure(E, h4[1] + h4[1] / 4 + 64, true));   // (the largest count is known to everybody: the repeat fits)
         }
     }
     // answers of A words in the slots the requests arrived in (ans: G * cap rows) -> back[slotpos[i]] on the asking side

@@ -313,7 +313,9 @@ def test_fragment_ranking_variants(ctx, golden_dir, tmp_path):
     # (default: the sampled ranking, these chains have ~60 fragments; KC_RANK_SAMPLED=0: plain waves; C / R small: nearly every fragment
     # is unreached after R rounds and becomes a splitter of its own; C huge: no hashed splitters at all)
     for knob in ({}, {"KC_WAVE_MAX": "0"}, {"KC_RANK_SAMPLED": "0"}, {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "3", "KC_RANK_R": "2"},
-                 {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "4096", "KC_RANK_R": "5"}):
+                 {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "4096", "KC_RANK_R": "5"},
+                 # slots a hundredth of what was asked for: the exchanges overflow, all ranks see it in the headers and repeat with the known maximum
+                 {"KC_RANK_SAMPLED": "1", "KC_SLOT_TEST_SHRINK": "100"}, {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "3", "KC_RANK_R": "4", "KC_SLOT_TEST_SHRINK": "7"}):
         assert np.array_equal(run_ranks(3, fa, 31, "bi", str(tmp_path / "o.npy"), extra_env=knob), want), knob
     g = os.path.join(golden_dir, "spneumoniae.fa.gz")
     wantg = single(ctx, g, 31, True)

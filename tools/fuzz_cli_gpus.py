@@ -52,6 +52,7 @@ def main():
             if rng.random() < 0.5: knobs["KC_OVG_MAX"] = rng.choice(["0", "0", "40", "400", "4000"])   # phase 2 with the keys of every table level divided among the ranks (by default only while more than 2^20 vertices are live)
             if rng.random() < 0.4:   # the sampled fragment ranking forced, now and then with tiny rates / rounds (everything unreached, no hashed splitter at all)
                 knobs["KC_RANK_SAMPLED"] = rng.choice(["0", "1", "1"])
+                if rng.random() < 0.3: knobs["KC_SLOT_TEST_SHRINK"] = rng.choice(["2", "9", "1000"])   # slotted exchanges that overflow and repeat
                 if rng.random() < 0.5: knobs["KC_RANK_C"] = rng.choice(["1", "2", "3", "64", "4096"]); knobs["KC_RANK_R"] = rng.choice(["1", "2", "5", "40"])
             if rng.random() < 0.15: knobs["KC_SCATTER_ROLL"] = "1"
             for extra in ([], ["--gpus", str(gpus)]):
