@@ -242,7 +242,7 @@ def test_cli_large_input_takes_the_mapped_output_path(tmp_path):
     assert ref.returncode == 0
     want = ref.stdout.split("\n")
     assert len(want) == 3 and want[2] == ""
-    for env in ({}, {"KC_CLI_NOPREALLOC": "1"}, {"KC_CLI_TOUCH_THREADS": "0"}, {"KC_IO_THREADS": "3"}, {"KC_IO_SERIAL": "1"}):
+    for env in ({}, {"KC_CLI_NOPREALLOC": "1"}, {"KC_CLI_TOUCH_THREADS": "0"}, {"KC_IO_THREADS": "3"}, {"KC_IO_SERIAL": "1"}, {"KC_CLI_NO_ZAP": "1"}):
         o = str(tmp_path / "o.fa")
         if os.path.exists(o):
             os.unlink(o)

@@ -13,7 +13,7 @@ if not os.path.exists(fa):
 exe = os.path.join(ROOT, "kmercamel_amd", "bin", "kmercamel")
 variants = [{}] * runs
 if "--exit-variants" in sys.argv:
-    variants = [{}, {"KC_CLI_TOUCH_THREADS": "0"}, {"KC_CLI_TOUCH_THREADS": "2"}, {"KC_CLI_TOUCH_THREADS": "8"}, {}, {"KC_IO_THREADS": "16"}]
+    variants = [{}, {"KC_CLI_NO_ZAP": "1"}, {}, {"KC_CLI_NO_ZAP": "1"}, {}, {"KC_CLI_NO_ZAP": "1"}]
 for v in variants:
     time.sleep(6)
     if os.path.exists(d + "/out.txt"):
