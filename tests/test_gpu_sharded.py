@@ -60,6 +60,32 @@ def test_self_comm_equals_single_gpu(ctx, tmp_path):
     comm.close()
 
 
+def test_ranks_against_the_oracle_directly(ctx, oracle, golden_dir, tmp_path):
+    """The sharded flow against the CPU oracle itself (canonical-order restatement, oracle/kc_oracle.cpp), not only against the single-GPU
+    HIP path: random reads, overlapping error-laden reads with branch ports, and the first 120 kbp of S. pneumoniae (long chains, a
+    cycle); 2 - 4 ranks, both strand modes, k = 23 / 31 / 63, with the sampled fragment ranking, the plain waves and pointer jumping, and
+    with the table levels of phase 2 divided among the ranks."""
+    import gzip
+    cases = []
+    fa1 = str(tmp_path / "reads.fa")
+    write_fasta(fa1, gen.random_records(300, 450, seed=21))
+    cases += [(fa1, 31, "bi", 3, None), (fa1, 31, "uni", 2, None), (fa1, 63, "bi", 2, {"KC_RANK_SAMPLED": "0"})]
+    fa2 = str(tmp_path / "stress.fa")
+    write_fasta(fa2, [r for r in gen.stress_reads(genome_len=25000, n_reads=500, read_len=180, seed=9, n_frac=0.002, lower_frac=0.05) if len(r) >= 63])
+    cases += [(fa2, 23, "bi", 4, {"KC_OVG_MAX": "0"}), (fa2, 31, "bi", 3, {"KC_WAVE_MAX": "0"}), (fa2, 63, "uni", 2, None)]
+    fa3 = str(tmp_path / "spn.fa")
+    with gzip.open(os.path.join(golden_dir, "spneumoniae.fa.gz"), "rt") as f:
+        text = "".join(l.strip() for l in f if not l.startswith(">"))
+    with open(fa3, "w") as f:
+        f.write(">spn_head\n%s\n" % text[:120000])
+    cases += [(fa3, 31, "bi", 3, {"KC_RANK_SAMPLED": "1", "KC_RANK_C": "4", "KC_RANK_R": "6"}), (fa3, 23, "bi", 2, None)]
+    for fa, k, mode, world, env in cases:
+        rc, want, _, st = oracle.compute_file(fa, k, mode == "bi", False, mode=1, want_mask=False)
+        assert rc == 0
+        got = run_ranks(world, fa, k, mode, str(tmp_path / "out.npy"), extra_env=env)
+        assert bytes(got).decode() == want, (os.path.basename(fa), k, mode, world, env)
+
+
 @pytest.mark.parametrize("world", [2, 3, 4])
 def test_ranks_emit_one_identical_superstring_random_reads(ctx, tmp_path, world):
     recs = gen.random_records(400, 600, seed=3)
