@@ -846,7 +846,10 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     constexpr int KSPEC = W == 1 ? 31 : (W == 2 ? 63 : 127);
     const bool kspec = k == KSPEC && set->mlen == KC_MSPEC && !getenv("KC_NO_KSPEC");
     u64 *spill = nullptr, *spill_cursor = cnt + 6;
-    const u64 spill_cap = N / 64 + 65536;
+    // ports the block kernel hands on to the generic lookups: ~0.1 % of the ports of a table at load 0.5, 1.6 % (3.2 % of N) at the load
+    // 0.66 that sets beyond ~3.2 10^9 k-mers are built with to stay inside the device memory -- measured at 4.4 10^9 k-mers: 1.41 10^8.  A list
+    // that overflows means round 1 again by the generic kernel (1.4 s there against 0.17 s for the block kernel): sized for the load at hand.
+    const u64 spill_cap = (cap >= N + N / 2 + N / 3 ? N / 64 : N / 12) + 65536;
     if (set->mlen) {
         KC_TRY(scope.alloc(&spill, spill_cap));
         // middle-based homes: one workgroup per block, tags (and single-word keys of blocks up to 8192 slots) staged in LDS
@@ -883,7 +886,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     if (set->mlen) {
         // the ports the block kernel handed on (window search not applicable, external list full); if even their list overflowed,
         // round 1 is redone by generic lookups
-        KC_LAUNCH((kc_probe_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)spill, spill_cap,
+        KC_LAUNCH((kc_probe_spill_kernel<W>), dim3(4096), dim3(256), 0, ctx->stream, sv, link, k, compl_, (const u64 *)spill, spill_cap,   // (grid-stride; 16 workgroups per CU: the lookups are dependent scattered reads)
                            (const u64 *)spill_cursor, heads_sh, heads_shard_cap, heads_cursors, branch_sh, branch_shard_cap, branch_cursors);
         u64 nspill = 0;
         KC_TRY(read_u64(ctx, spill_cursor, &nspill));

@@ -544,6 +544,57 @@ def test_full_size_properties_cfg2(ctx):
     a.close()
 
 
+def test_full_size_beyond_2pow32_positions(ctx):
+    """4.4 * 10^9 k-mers (4 400 000 records x 1 030 bp = 4.53 * 10^9 input positions, more than 2^32; ~215 GB of the 288 GB): every kernel
+    that sweeps positions or table slots runs on 2-D grids here, the table is built at load 0.66 instead of 0.5 (the memory rule of
+    kc_set_create), and ~1.4 * 10^8 ports go to the generic lookups -- whose list once overflowed at this size, sending all of round 1 through
+    the generic kernel (1.9 s per pass instead of 0.45 s: round 5).  Oracle-free properties as for cfg2, plus a bound on the phase that fell
+    off the cliff."""
+    import sys
+    import numpy as np
+    import ctypes
+    free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    hip = ctypes.CDLL("libamdhip64.so")   # (the context of the suite has the device open: this only asks for its size)
+    if hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) != 0 or total_b.value < 250 * (1 << 30):
+        pytest.skip("needs a 288 GB device")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    k, R = 31, 4400000
+    seq = bench.generate(2, 0, R, 1030)
+    assert len(seq) > (1 << 32)
+    r = kc.compute(ctx, seq, k, True, want_mask=False)
+    N, S, L = r.stats["n_kmers"], r.stats["n_simplitigs"], r.length
+    o = r.array()
+    r.close()
+    assert R * 1000 - 200 <= N <= R * 1000 and R <= S <= R + 200
+    assert N + k - 1 <= L <= N + S * (k - 1)
+    assert int(np.count_nonzero(o < 97)) == N
+    b = kc.KmerSet(ctx, k, True, capacity_hint=L)
+    b.AddKMers(o, case_sensitive=True)
+    assert b.size() == N
+    rng = np.random.default_rng(3)
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    qs = []
+    for p0 in rng.integers(0, len(seq) - k, size=1500):   # sampled input k-mers (also from beyond position 2^32) are represented
+        w = code[seq[p0:p0 + k]]
+        if (w == 255).any():
+            continue
+        f = 0; rc = 0
+        for j, c in enumerate(w.tolist()):
+            f = (f << 2) | c
+            rc |= (3 - c) << (2 * j)
+        qs.append(min(f, rc))
+    assert len(qs) > 1000 and all(b.contains(qs))
+    b.close()
+    del o
+    r2 = kc.compute(ctx, seq, k, True, want_mask=False)   # (pool warm: the phase times are those of a steady pass)
+    t1 = r2.stats["us_simplitig_phase"]
+    r2.close()
+    assert t1 < 900000, "phase 1 took %.0f ms at 4.4 G k-mers (0.29 s when the spill list holds)" % (t1 / 1e3)
+
+
 def test_simplitigs_reference_kats(ctx):
     # tests/simplitigs_unittest.h:183-208 (order-tolerant there: sorted by length)
     enc = oracle_lib.encode_kmer
