@@ -132,8 +132,13 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
             // by then: obtain the larger of the two now, so that both phases use the same memory.  The links are 16 B per node id,
             // nstride ids per block (the largest block: ~0.64 of a block's slots on uniform data at load 0.5): 0.7 x 16 B per slot is
             // reserved; a table with a fuller block simply obtains a larger block of its own when phase 1 starts.
+            // (Beyond ~3.2 10^9 k-mers the table is built at load 0.66 and its fullest block holds 0.86 of a block's slots -- 7 068 of 8 192 at
+            // 4.4 10^9 k-mers: 0.9 x 16 B per slot then.  With 0.7 there the links missed the reserved block by 18 GB, the pool held 77 GB it
+            // could not use, ran out of device memory, trimmed and allocated again behind the driver's scrub: 2.0 - 2.4 s inside hipMalloc
+            // of a fresh process, 269 GB allocated for a peak of 182.)
             void *arena = nullptr;
-            const size_t arena_bytes = set->W == 1 ? (size_t)(set->cap / 4 * 45) : (size_t)set->cap * 16;
+            const bool dense_load = (double)occ > 0.55 * (double)set->cap;
+            const size_t arena_bytes = set->W == 1 ? (size_t)(set->cap / 4 * (dense_load ? 58 : 45)) : (size_t)set->cap * 16;
             if (ctx->pool.alloc(&arena, arena_bytes) == hipSuccess) ctx->pool.release(arena); else (void)hipGetLastError();
             rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
             if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, 0);
