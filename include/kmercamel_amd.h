@@ -197,6 +197,11 @@ int kc_result_write_mem(kc_result *r, void *dst, int which);
 /* ---- next row 1: maskopt -t max-one / min-one (masks.h:40-78, 239-261) ---- */
 /* ms: one masked superstring (ACGTacgt, else KC_E_INVALID_CHAR after output like the reference). out: len bytes. */
 int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out);
+/* the same with the masked superstring on the device (e.g. from kc_read_fasta_device: header and line breaks already cut out) and the
+ * result left there, to leave through kc_result_write_fd / kc_result_write_mem / kc_result_copy -- `maskopt` on multi-gigabyte files
+ * (masks.h:239-261 reads and writes through iostreams).  KC_E_ARG when the sequence holds a record separator ('\n': more than one
+ * FASTA record, masks.h:258); KC_E_INVALID_CHAR is returned WITH a result (masks.h:75-77 prints the string, then reports). */
+int kc_maskopt_device(kc_ctx *ctx, const void *d_ms, uint64_t len, int k, int complements, int minimize, kc_result **out);
 
 /* number of HIP devices visible to the process (0 when there is none) */
 int kc_device_count(void);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "kc_result_write_fd": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "kc_result_write_mem": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     "kc_maskopt_ones": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "kc_maskopt_device": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vpp]),
     "kc_version": (ctypes.c_char_p, []),
 }
 

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(256) mo_kernel(const char *__restrict__ ms, u6
         code ^= code >> 1;
         x = key_append(x, (u64)code, k);
     }
-    if (invalid) { if (PASS == 0) atomicExch((ull *)bad, 1ULL); if (PASS == 1) out[p] = c; return; }
+    if (invalid) { if (PASS == 0 || !minimize) atomicExch((ull *)bad, 1ULL); if (PASS == 1) out[p] = c; return; }   // (max-one runs pass 1 only)
     if (complements) { Key<W> r = key_rc(x, k); if (key_lt(r, x)) x = r; }
     u64 slot = set_find(set, x);
     bool on = slot != KC_NONE64;
@@ -327,40 +327,94 @@ __global__ void __launch_bounds__(256) mo_kernel(const char *__restrict__ ms, u6
     out[p] = on ? (upper ? c : (char)(c - ('a' - 'A'))) : (upper ? (char)(c + ('a' - 'A')) : c);
 }
 
-template <int W> static int maskopt_w(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out) {
+// count of the bytes equal to `what` (the record separator '\n' of a tokenised FASTA: more than one record)
+__global__ void __launch_bounds__(256) mo_count_byte_kernel(const char *__restrict__ s, u64 len, char what, u64 *out) {
+    u64 c = 0;
+    for (u64 i = kc_gtid(); i < len; i += (u64)gridDim.x * gridDim.y * blockDim.x) c += s[i] == what ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd((ull *)out, (ull)c);
+}
+// d_ms (device, len characters) -> d_out (device, len characters); *bad = an invalid character was met (the output is still complete:
+// such positions keep their character, masks.h:75-77 reports after printing)
+template <int W> static int maskopt_dev(kc_ctx *ctx, const char *d_ms, u64 len, int k, int complements, int minimize, char *d_out, u64 *hbad) {
+    KcScope scope(ctx);
     kc_set *set = nullptr;
     KC_TRY(kc_set_create(ctx, k, complements, len, &set));
-    char *d_ms = nullptr, *d_out = nullptr; u64 *firstpos = nullptr, *bad = nullptr;
-    int rc = kc_alloc(ctx, &d_ms, len + 64);
-    if (rc == KC_OK) rc = kc_alloc(ctx, &d_out, len + 64);
-    if (rc == KC_OK) rc = kc_alloc(ctx, &bad, 1);
-    if (rc == KC_OK && hipMemcpyAsync(d_ms, ms, len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
-    if (rc == KC_OK) rc = kc_set_add_sequence_device(set, d_ms, len, 1);
-    if (rc == KC_OK) rc = kc_alloc(ctx, &firstpos, set->cap);
-    if (rc != KC_OK) { kc_set_destroy(set); return rc; }
-    KC_HIP(ctx, hipMemsetAsync(firstpos, 0xff, set->cap * 8, ctx->stream));
+    struct SetGuard { kc_set *s; ~SetGuard() { kc_set_destroy(s); } } sg{set};
+    u64 *firstpos = nullptr, *bad = nullptr;
+    KC_TRY(scope.alloc(&bad, 1));
+    KC_TRY(kc_set_add_sequence_device(set, d_ms, len, 1));
+    if (minimize) {
+        KC_TRY(scope.alloc(&firstpos, set->cap));
+        KC_HIP(ctx, hipMemsetAsync(firstpos, 0xff, set->cap * 8, ctx->stream));
+    }
     KC_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
     SetView<W> sv = kc_view<W>(set);
     const dim3 g = kc_grid2(len, 256);
-    KC_LAUNCH((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
-    KC_LAUNCH((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, (const char *)d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
+    // (pass 0 finds the first occurrence of every k-mer: only min-one needs it)
+    if (minimize) KC_LAUNCH((mo_kernel<W, 0>), dim3(g), dim3(256), 0, ctx->stream, d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
+    KC_LAUNCH((mo_kernel<W, 1>), dim3(g), dim3(256), 0, ctx->stream, d_ms, len, k, complements, minimize, sv, firstpos, d_out, bad);
     KC_HIP(ctx, hipGetLastError());
-    u64 hbad = 0;
-    KC_HIP(ctx, hipMemcpyAsync(out, d_out, len, hipMemcpyDeviceToHost, ctx->stream));
-    KC_HIP(ctx, hipMemcpyAsync(&hbad, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipMemcpyAsync(hbad, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    kc_release(ctx, d_ms); kc_release(ctx, d_out); kc_release(ctx, firstpos); kc_release(ctx, bad);
-    kc_set_destroy(set);
+    return KC_OK;
+}
+static int maskopt_dev_any(kc_ctx *ctx, const char *d_ms, u64 len, int k, int complements, int minimize, char *d_out, u64 *hbad) {
+    switch (kc_words_for_k(k)) {
+        case 1: return maskopt_dev<1>(ctx, d_ms, len, k, complements, minimize, d_out, hbad);
+        case 2: return maskopt_dev<2>(ctx, d_ms, len, k, complements, minimize, d_out, hbad);
+        default: return maskopt_dev<4>(ctx, d_ms, len, k, complements, minimize, d_out, hbad);
+    }
+}
+
+int kce_maskopt(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out) {
+    KcScope scope(ctx);
+    char *d_ms = nullptr, *d_out = nullptr;
+    KC_TRY(scope.alloc(&d_ms, len + 64)); KC_TRY(scope.alloc(&d_out, len + 64));
+    KC_HIP(ctx, hipMemcpyAsync(d_ms, ms, len, hipMemcpyHostToDevice, ctx->stream));
+    u64 hbad = 0;
+    KC_TRY(maskopt_dev_any(ctx, d_ms, len, k, complements, minimize, d_out, &hbad));
+    KC_HIP(ctx, hipMemcpyAsync(out, d_out, len, hipMemcpyDeviceToHost, ctx->stream));
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (hbad) return kc_fail(ctx, KC_E_INVALID_CHAR, "Masked superstring contains invalid characters.");
     return KC_OK;
 }
 
-int kce_maskopt(kc_ctx *ctx, const char *ms, u64 len, int k, int complements, int minimize, char *out) {
-    switch (kc_words_for_k(k)) {
-        case 1: return maskopt_w<1>(ctx, ms, len, k, complements, minimize, out);
-        case 2: return maskopt_w<2>(ctx, ms, len, k, complements, minimize, out);
-        default: return maskopt_w<4>(ctx, ms, len, k, complements, minimize, out);
+// The same with the masked superstring already on the device (kc_read_fasta_device) and the result staying there (kc_result_write_*):
+// what `maskopt` on a multi-gigabyte file needs -- the host-string form moves 2 x len bytes through pageable memory.  KC_E_ARG with
+// "single FASTA record" when the sequence holds a record separator (masks.h:258: the caller then takes the host parser, which treats the
+// first record as the reference does); KC_E_INVALID_CHAR comes WITH a result (masks.h:75-77 prints before it reports).
+extern "C" int kc_maskopt_device(kc_ctx *ctx, const void *d_ms, uint64_t len, int k, int complements, int minimize, kc_result **out) {
+    if (!ctx || !d_ms || !out) return KC_E_ARG;
+    *out = nullptr;
+    if (k < 1 || k > 127) return kc_fail(ctx, KC_E_ARG, "k must be in 1..127");
+    if (len < (u64)k) return kc_fail(ctx, KC_E_ARG, "masked superstring shorter than k");
+    KC_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        // (the device tokeniser writes one separator per header line, so the sequence of a single record begins with one: skipped)
+        KcScope scope(ctx);
+        u64 *cnt = nullptr, h = 0;
+        char first = 0;
+        KC_TRY(scope.alloc(&cnt, 1));
+        KC_HIP(ctx, hipMemsetAsync(cnt, 0, 8, ctx->stream));
+        KC_LAUNCH(mo_count_byte_kernel, dim3(1024, 4), dim3(256), 0, ctx->stream, (const char *)d_ms, len, '\n', cnt);
+        KC_HIP(ctx, hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipMemcpyAsync(&first, d_ms, 1, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (first == '\n') { d_ms = (const char *)d_ms + 1; --len; --h; }
+        if (h) return kc_fail(ctx, KC_E_ARG, "Expecting only a single FASTA record -- the masked superstring.");
+        if (len < (u64)k) return kc_fail(ctx, KC_E_ARG, "masked superstring shorter than k");
     }
+    kc_result *r = new kc_result();
+    r->ctx = ctx; r->length = len; r->slice_off = 0; r->slice_len = len;
+    int rc = kc_alloc(ctx, &r->d_out, len + 64);
+    u64 hbad = 0;
+    if (rc == KC_OK) rc = maskopt_dev_any(ctx, (const char *)d_ms, len, k, complements ? 1 : 0, minimize ? 1 : 0, r->d_out, &hbad);
+    if (rc != KC_OK) { kc_result_destroy(r); return rc; }
+    *out = r;
+    if (hbad) return kc_fail(ctx, KC_E_INVALID_CHAR, "Masked superstring contains invalid characters.");
+    return KC_OK;
 }
 
 extern "C" int kc_maskopt_ones(kc_ctx *ctx, const char *ms, uint64_t len, int k, int complements, int minimize, char *out) {

@@ -21,6 +21,7 @@
 #include <fcntl.h>
 #include <getopt.h>
 #include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <mutex>
 #include "global.h"
@@ -224,6 +225,98 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
     return 0;
 }
 
+// The output file of a large run gets its pages while the device comes up and computes -- fallocate(), one call, one thread: measured on the
+// MI355X box for 2.55 GB on tmpfs 125 ms, against 370 ms for faulting the pages in through a mapping with one thread and 630 ms with eight
+// (page allocation for ONE file serialises on the inode; tools/io_probe2.cpp) -- and is mapped.  The result then goes straight into
+// the page cache through the mapping (kc_result_write_mem: stores into a mapping take no inode lock, eight threads move each chunk at
+// ~27 GB/s, first-touch faults included; a write() stream manages 7 GB/s) and the file is cut to its final length.  Anything unusual
+// (not a regular file, small input, mapping refused, result longer than estimated) leaves `ok` unset: the caller takes the plain
+// descriptor path.  Used by `compute` and `maskopt`.
+struct MappedOutput {
+    int fd = -1; char *map = nullptr; size_t cap = 0; bool ok = false, committed = false;
+    std::thread th;
+    void settle() { if (th.joinable()) th.join(); }
+    ~MappedOutput() {
+        settle();
+        if (map) ::munmap(map, cap);
+        if (fd >= 0) { if (!committed && ::ftruncate(fd, 0) != 0) {} ::close(fd); }
+    }
+    // in_path: the input file (its size bounds the output's: header + that + slack); out_path: the -o file, already created by the caller
+    void prepare(const std::string &in_path, const std::string &out_path, size_t hdr_bytes, bool trace, std::chrono::steady_clock::time_point t_start) {
+        if (std::getenv("KC_CLI_NOPREALLOC")) return;
+        struct stat sti, sto;
+        if (!(::stat(in_path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode) && sti.st_size > (off_t)(64 << 20) && ::stat(out_path.c_str(), &sto) == 0 && S_ISREG(sto.st_mode))) return;
+        cap = hdr_bytes + (size_t)sti.st_size + 4096;
+        const int f = ::open(out_path.c_str(), O_RDWR);
+        if (f < 0) return;
+        if (::ftruncate(f, (off_t)cap) != 0) { ::close(f); return; }
+        fd = f;   // (from here on the destructor restores the empty file unless the result is committed)
+        void *m = ::mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) return;
+        map = static_cast<char *>(m);
+        ok = true;
+        // Then the pages are mapped in by four threads with write touches that change nothing (an atomic OR of 0: the result may
+        // already be arriving in the front of the file while the back is still being touched).  Touches of allocated pages
+        // scale with threads where allocation does not, and a copy into mapped pages runs at the speed of the PCIe transfer
+        // (measured: 2.55 GB in ~50 ms against 105-200 ms when every store of the copy first had to fault its page in).
+        // MADV_POPULATE_WRITE is NOT used: unmapping pages it brought in took twice as long (90-110 ms against 43 ms).
+        // (a file system without fallocate: the pages then come with these touches, as for any mapping)
+        th = std::thread([this, trace, t_start] {
+            const int rc = ::fallocate(fd, 0, 0, (off_t)cap) == 0 ? 0 : errno;
+            if (trace) std::cerr << "[cli] output pages allocated (rc " << rc << "): " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+            const char *te = std::getenv("KC_CLI_TOUCH_THREADS");
+            const int T = te ? std::atoi(te) : 4;
+            if (T < 1) return;
+            const size_t PIECE = (size_t)8 << 20;
+            auto part = [this, T, PIECE](int t) {
+                for (size_t lo = (size_t)t * PIECE; lo < cap; lo += (size_t)T * PIECE) {
+                    const size_t hi = lo + PIECE < cap ? lo + PIECE : cap;
+                    for (size_t p = lo; p < hi; p += 4096) __atomic_fetch_or(map + p, (char)0, __ATOMIC_RELAXED);
+                }
+            };
+            std::vector<std::thread> ths;
+            for (int t = 1; t < T; ++t) ths.emplace_back(part, t);
+            part(0);
+            for (auto &x : ths) x.join();
+            if (trace) std::cerr << "[cli] output pages mapped: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+        });
+    }
+    // the mapping cannot take this result (or is not wanted after all): the file goes back to empty, the caller writes through the descriptor
+    void abandon() {
+        settle();
+        if (map) { ::munmap(map, cap); map = nullptr; }
+        if (fd >= 0) { if (::ftruncate(fd, 0) != 0) {} ::close(fd); fd = -1; }
+        ok = false;
+    }
+    // header line, the result's characters (which: 0 string, 1 mask), '\n'; the file is cut to that length
+    void commit(kc_result *res, const std::string &hdr, uint64_t length, int which, const std::function<void(const char *)> &mark) {
+        memcpy(map, hdr.data(), hdr.size());
+        kcamd::check(kc_result_write_mem(res, map + hdr.size(), which));
+        mark("result in the mapping");
+        settle();
+        map[hdr.size() + length] = '\n';   // main.cpp:210
+        // munmap tears the 6 10^5 page-table entries of the mapping down under the exclusive mmap lock, 40 - 100 ms for this file; the same
+        // entries dropped by MADV_DONTNEED -- which takes the lock shared, so eight threads work side by side, and which leaves the data
+        // of a shared file mapping where it is, in the page cache -- make the munmap behind them a formality.  (KC_CLI_NO_ZAP: A/B knob)
+        if (!std::getenv("KC_CLI_NO_ZAP")) {
+            const int T = 8;
+            const size_t per = ((cap / T) + 4095) & ~(size_t)4095;
+            std::vector<std::thread> zap;
+            for (int t = 0; t < T; ++t) {
+                const size_t lo = (size_t)t * per;
+                if (lo >= cap) break;
+                const size_t n = lo + per < cap ? per : cap - lo;
+                zap.emplace_back([this, lo, n] { (void)::madvise(map + lo, n, MADV_DONTNEED); });
+            }
+            for (auto &z : zap) z.join();
+            mark("mapping dropped");
+        }
+        ::munmap(map, cap); map = nullptr;
+        if (::ftruncate(fd, (off_t)(hdr.size() + length + 1)) != 0) throw std::runtime_error("cannot size the output file");
+        committed = true;
+    }
+};
+
 int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
                 int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1, bool gpus_explicit = true) {
     bool started_logged = false;
@@ -249,66 +342,13 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
     };
     kcamd::warm_context();   // the device comes up while the file is read
-    // The output file gets its pages while the device comes up and computes -- fallocate(), one call, one thread: measured on the MI355X
-    // box for 2.55 GB on tmpfs 125 ms, against 370 ms for faulting the pages in through a mapping with one thread and 630 ms with eight
-    // (page allocation for ONE file serialises on the inode; tools/io_probe2.cpp) -- and is mapped.  The result then goes straight into
-    // the page cache through the mapping (kc_result_write_mem: stores into a mapping take no inode lock, eight threads move each chunk at
-    // ~27 GB/s, first-touch faults included; a write() stream manages 7 GB/s) and the file is cut to its final length.  Anything unusual
-    // (not a regular file, small input, mapping refused, result longer than estimated) falls back to the plain descriptor path below.
-    struct OutMap {
-        int fd = -1; char *map = nullptr; size_t cap = 0; bool ok = false, committed = false;
-        std::thread th;
-        void settle() { if (th.joinable()) th.join(); }
-        ~OutMap() {
-            settle();
-            if (map) ::munmap(map, cap);
-            if (fd >= 0) { if (!committed && ::ftruncate(fd, 0) != 0) {} ::close(fd); }
-        }
-    } om;
+    MappedOutput om;
     std::string hdr;
-    if (!lower_bound && !out_path.empty() && !std::getenv("KC_CLI_NOPREALLOC")) {
-        struct stat sti, sto;
-        if (::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode) && sti.st_size > (off_t)(64 << 20) && ::stat(out_path.c_str(), &sto) == 0 &&
-            S_ISREG(sto.st_mode)) {
-            std::ostringstream hs;
-            WriteName(path, "greedy", k, false, !complements, hs);
-            hdr = hs.str();
-            om.cap = hdr.size() + (size_t)sti.st_size + 4096;
-            const int fd = ::open(out_path.c_str(), O_RDWR);
-            if (fd >= 0 && ::ftruncate(fd, (off_t)om.cap) == 0) {
-                om.fd = fd;   // (from here on the destructor restores the empty file unless the result is committed)
-                void *m = ::mmap(nullptr, om.cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-                if (m != MAP_FAILED) {
-                    om.map = static_cast<char *>(m);
-                    om.ok = true;
-                    // Then the pages are mapped in by four threads with write touches that change nothing (an atomic OR of 0: the result may
-                    // already be arriving in the front of the file while the back is still being touched).  Touches of allocated pages
-                    // scale with threads where allocation does not, and a copy into mapped pages runs at the speed of the PCIe transfer
-                    // (measured: 2.55 GB in ~50 ms against 105-200 ms when every store of the copy first had to fault its page in).
-                    // MADV_POPULATE_WRITE is NOT used: unmapping pages it brought in took twice as long (90-110 ms against 43 ms).
-                    // (a file system without fallocate: the pages then come with these touches, as for any mapping)
-                    om.th = std::thread([&om, trace, t_start] {
-                        const int rc = ::fallocate(om.fd, 0, 0, (off_t)om.cap) == 0 ? 0 : errno;
-                        if (trace) std::cerr << "[cli] output pages allocated (rc " << rc << "): " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
-                        const char *te = std::getenv("KC_CLI_TOUCH_THREADS");
-                        const int T = te ? std::atoi(te) : 4;
-                        if (T < 1) return;
-                        const size_t PIECE = (size_t)8 << 20;
-                        auto part = [&om, T, PIECE](int t) {
-                            for (size_t lo = (size_t)t * PIECE; lo < om.cap; lo += (size_t)T * PIECE) {
-                                const size_t hi = lo + PIECE < om.cap ? lo + PIECE : om.cap;
-                                for (size_t p = lo; p < hi; p += 4096) __atomic_fetch_or(om.map + p, (char)0, __ATOMIC_RELAXED);
-                            }
-                        };
-                        std::vector<std::thread> th;
-                        for (int t = 1; t < T; ++t) th.emplace_back(part, t);
-                        part(0);
-                        for (auto &x : th) x.join();
-                        if (trace) std::cerr << "[cli] output pages mapped: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
-                    });
-                }
-            } else if (fd >= 0) ::close(fd);
-        }
+    if (!lower_bound && !out_path.empty()) {
+        std::ostringstream hs;
+        WriteName(path, "greedy", k, false, !complements, hs);
+        hdr = hs.str();
+        om.prepare(path, out_path, hdr.size(), trace, t_start);
     }
     kc_ctx *ctx = nullptr;
     void *d_seq = nullptr;
@@ -402,7 +442,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     kc_result_stats(res, st);
     if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     const bool mapped = om.ok && hdr.size() + st[2] + 1 <= om.cap;
-    if (!mapped && om.fd >= 0) { om.settle(); if (om.map) { ::munmap(om.map, om.cap); om.map = nullptr; } if (::ftruncate(om.fd, 0) != 0) {} ::close(om.fd); om.fd = -1; }
+    if (!mapped && om.fd >= 0) om.abandon();
     if (!mapped) WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
@@ -420,30 +460,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (!p.empty()) ::close(fd);
     };
     if (mapped) {
-        memcpy(om.map, hdr.data(), hdr.size());
-        kcamd::check(kc_result_write_mem(res, om.map + hdr.size(), 0));
-        mark("result in the mapping");
-        om.settle();
-        om.map[hdr.size() + st[2]] = '\n';   // main.cpp:210
-        // munmap tears the 6 10^5 page-table entries of the mapping down under the exclusive mmap lock, 40 - 100 ms for this file; the same
-        // entries dropped by MADV_DONTNEED -- which takes the lock shared, so eight threads work side by side, and which leaves the data
-        // of a shared file mapping where it is, in the page cache -- make the munmap behind them a formality.  (KC_CLI_NO_ZAP: A/B knob)
-        if (!std::getenv("KC_CLI_NO_ZAP")) {
-            const int T = 8;
-            const size_t per = ((om.cap / T) + 4095) & ~(size_t)4095;
-            std::vector<std::thread> zap;
-            for (int t = 0; t < T; ++t) {
-                const size_t lo = (size_t)t * per;
-                if (lo >= om.cap) break;
-                const size_t n = lo + per < om.cap ? per : om.cap - lo;
-                zap.emplace_back([&om, lo, n] { (void)::madvise(om.map + lo, n, MADV_DONTNEED); });
-            }
-            for (auto &z : zap) z.join();
-            mark("mapping dropped");
-        }
-        ::munmap(om.map, om.cap); om.map = nullptr;
-        if (::ftruncate(om.fd, (off_t)(hdr.size() + st[2] + 1)) != 0) throw std::runtime_error("cannot size " + out_path);
-        om.committed = true;
+        om.commit(res, hdr, st[2], 0, mark);
     } else emit(out_path, 0);
     if (maskf != nullptr) emit(mask_path, 1);
     kc_result_destroy(res);
@@ -523,12 +540,12 @@ int camel_optimize(int argc, char **argv) {
     int k = 0, opt;
     std::ofstream output;
     std::ostream *of = &std::cout;
-    std::string algorithm = "max-one";
+    std::string algorithm = "max-one", out_path;
     bool complements = true;
     try {
         while ((opt = getopt(argc, argv, "k:t:o:hu")) != -1) {
             switch (opt) {
-                case 'o': output.open(optarg); of = &output; break;
+                case 'o': output.open(optarg); of = &output; out_path = optarg; break;
                 case 'k': k = std::stoi(optarg); break;
                 case 't': algorithm = optarg; break;
                 case 'u': complements = false; break;
@@ -547,6 +564,80 @@ int camel_optimize(int argc, char **argv) {
     WriteLog("Started optimization of a masked superstring from '" + path + "'.");
     if (algorithm == "min-run" || algorithm == "approx-min-run") return fail("Algorithm '" + algorithm + "' (GLPK ILP) is outside the MI355X build's scope.");
     if (algorithm != "max-one" && algorithm != "min-one") return fail("Algorithm '" + algorithm + "' not recognized.");
+    // Large plain files take the streamed path of `compute`: the masked superstring goes to the device in pinned chunks and is tokenised
+    // there (kc_read_fasta_device), optimised there (kc_maskopt_device) and leaves through the mapping of the fallocate'd output file --
+    // 2.55 GB in and out in ~0.6 s where the iostream path below takes ~4 s.  Everything else (small inputs, gzip, stdin, FASTQ-looking
+    // input, several records) goes through the host parser as before.
+    {
+        struct stat sti;
+        const bool trace = std::getenv("KC_CLI_TRACE") != nullptr;
+        const auto t_start = std::chrono::steady_clock::now();
+        auto mark = [&](const char *what) {
+            if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+        };
+        if (path != "-" && !std::getenv("KC_CLI_NOSTREAM") && ::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode) && sti.st_size > (off_t)(64 << 20)) {
+            // the header line, parsed as the host tokenizer parses it (name up to the first white space, then the comment)
+            std::string head;
+            bool plain = false;
+            if (FILE *f = fopen(path.c_str(), "rb")) {
+                head.resize(1 << 20);
+                head.resize(fread(&head[0], 1, head.size(), f));
+                fclose(f);
+                plain = head.size() >= 2 && !((unsigned char)head[0] == 0x1f && (unsigned char)head[1] == 0x8b);
+            }
+            size_t p0 = 0;
+            while (p0 < head.size() && head[p0] != '>' && head[p0] != '@') ++p0;
+            const size_t eol = head.find('\n', p0);
+            if (plain && p0 < head.size() && head[p0] == '>' && eol != std::string::npos) {
+                const auto hrec = kcamd::parse_records(head.substr(p0, eol - p0 + 1));
+                if (hrec.size() == 1) {
+                    std::string hdr = ">" + hrec[0].name + " reoptimized=" + algorithm;   // ReprintSequenceHeader (masks.h:27-37)
+                    if (!hrec[0].comment.empty()) hdr += " " + hrec[0].comment;
+                    hdr += "\n";
+                    kcamd::warm_context();
+                    MappedOutput om;
+                    if (!out_path.empty()) om.prepare(path, out_path, hdr.size(), trace, t_start);
+                    kc_ctx *ctx = kcamd::context();
+                    mark("device context ready");
+                    void *d_seq = nullptr;
+                    uint64_t d_len = 0;
+                    int is_fastq = 0;
+                    int rc = kc_read_fasta_device(ctx, path.c_str(), &d_seq, &d_len, &is_fastq);
+                    kc_result *res = nullptr;
+                    if (rc == KC_OK && !is_fastq) {
+                        mark("input on the device");
+                        rc = kc_maskopt_device(ctx, d_seq, d_len, k, complements, algorithm == "min-one", &res);
+                        kc_device_free(ctx, d_seq);
+                        mark("kc_maskopt_device returned");
+                        if (res) {
+                            uint64_t r_off = 0, r_len = 0;
+                            kc_result_slice(res, &r_off, &r_len);   // (the result's own length: the tokeniser's leading separator is not part of it)
+                            d_len = r_len;
+                            if (om.ok && hdr.size() + d_len + 1 <= om.cap) om.commit(res, hdr, d_len, 0, mark);
+                            else {
+                                if (om.fd >= 0) om.abandon();
+                                *of << hdr;
+                                of->flush();
+                                int fd = out_path.empty() ? 1 : ::open(out_path.c_str(), O_WRONLY | O_APPEND);
+                                if (fd < 0) throw std::runtime_error("cannot reopen " + out_path);
+                                kcamd::check(kc_result_write_fd(res, fd, 0));
+                                write_all(fd, "\n", 1);
+                                if (!out_path.empty()) ::close(fd);
+                            }
+                            kc_result_destroy(res);
+                            mark("result written");
+                            if (rc == KC_E_INVALID_CHAR) throw std::invalid_argument("Masked superstring contains invalid characters.");   // masks.h:75-77
+                            kcamd::check(rc);
+                            WriteLog("Finished optimization.");
+                            return 0;
+                        }
+                        // (several records, or an error before anything was produced: the host path below decides what to say)
+                    } else if (rc == KC_OK) { /* FASTQ-looking input: host parser */ }
+                    if (om.fd >= 0) om.abandon();
+                }
+            }
+        }
+    }
     auto recs = kcamd::read_records(path);
     if (recs.empty()) throw std::invalid_argument("couldn't read a masked superstring from " + path);
     const kcamd::Record &ms = recs[0];

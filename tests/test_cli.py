@@ -255,6 +255,27 @@ def test_cli_large_input_takes_the_mapped_output_path(tmp_path):
         f.write("x" * (len(want[1]) + 5000000))
     assert subprocess.run([BIN, "compute", "-k", "31", "-o", o, path], capture_output=True).returncode == 0
     assert open(o).read().split("\n")[1] == want[1]
+    # `maskopt` on that 74 MB masked superstring: the streamed path (device tokeniser, kc_maskopt_device, mapped output) against the host
+    # parser + kc_maskopt_ones (KC_CLI_NOSTREAM=1), both algorithms, into a file and to stdout; a comment on the header line is kept
+    ms = str(tmp_path / "ms.fa")
+    with open(ms, "w") as f:
+        f.write(">superstring some comment here\n" + want[1] + "\n")
+    for alg in ("max-one", "min-one"):
+        ref = subprocess.run([BIN, "maskopt", "-t", alg, "-k", "31", ms], capture_output=True, text=True, env=dict(os.environ, KC_CLI_NOSTREAM="1"))
+        assert ref.returncode == 0, ref.stderr[-300:]
+        assert ref.stdout.startswith(">superstring reoptimized=%s some comment here\n" % alg)
+        got = subprocess.run([BIN, "maskopt", "-t", alg, "-k", "31", ms], capture_output=True, text=True)
+        assert got.returncode == 0 and got.stdout == ref.stdout, alg
+        mo = str(tmp_path / "mo.fa")
+        p = subprocess.run([BIN, "maskopt", "-t", alg, "-k", "31", "-o", mo, ms], capture_output=True, text=True, env=dict(os.environ, KC_CLI_TRACE="1"))
+        assert p.returncode == 0 and open(mo).read() == ref.stdout, alg
+        assert "result in the mapping" in p.stderr and "result written" in p.stderr, p.stderr[-600:]   # (the streamed path did run, all the way)
+    # two records: the reference optimises the first and then objects (masks.h:258); the streamed path hands such files to the host parser
+    with open(ms, "a") as f:
+        f.write(">second\nACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n")
+    a = subprocess.run([BIN, "maskopt", "-k", "31", ms], capture_output=True, text=True)
+    b = subprocess.run([BIN, "maskopt", "-k", "31", ms], capture_output=True, text=True, env=dict(os.environ, KC_CLI_NOSTREAM="1"))
+    assert a.returncode == b.returncode and a.stdout == b.stdout and a.returncode != 0
 
 
 @pytest.mark.gpu
