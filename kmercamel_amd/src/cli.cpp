@@ -361,7 +361,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         struct stat sti;
         reopenable = path != "-" && ::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode);
     }
-    if (!assume_simplitigs && !lower_bound && reopenable && !have_recs && !std::getenv("KC_CLI_NOSTREAM")) {
+    if (!assume_simplitigs && reopenable && !have_recs && !std::getenv("KC_CLI_NOSTREAM")) {   // (`lowerbound` on raw FASTA too)
         // FASTA goes to the device in pinned chunks and is tokenised there while the next chunk is read (no joined host copy)
         ctx = kcamd::context();
         mark("device context ready");
@@ -388,9 +388,10 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         if (assume_simplitigs) kcamd::check(kc_simplitigs_from_strings(ctx, k, recs.joined.data(), recs.offsets.data(), recs.n, &s));
         else {
             kc_set *set = nullptr;
-            kcamd::check(kc_set_create(ctx, k, complements, recs.joined.size(), &set));
+            kcamd::check(kc_set_create(ctx, k, complements, streamed ? d_len : recs.joined.size(), &set));
             if (min_frequency > 1) kcamd::check(kc_set_enable_counting(set));
-            kcamd::check(kc_set_add_sequence(set, recs.joined.data(), recs.joined.size(), 0));
+            if (streamed) { kcamd::check(kc_set_add_sequence_device(set, d_seq, d_len, 0)); kc_device_free(ctx, d_seq); d_seq = nullptr; }
+            else kcamd::check(kc_set_add_sequence(set, recs.joined.data(), recs.joined.size(), 0));
             if (min_frequency > 1) kcamd::check(kc_set_filter_min_frequency(set, min_frequency));
             uint64_t n = 0;
             kcamd::check(kc_set_size(set, &n));
