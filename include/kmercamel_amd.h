@@ -109,8 +109,10 @@ void kc_free(void *p);
 #define KC_FLAG_WANT_MASK 4u         /* -M: also produce the max-one mask */
 #define KC_FLAG_INPUT_ON_DEVICE 8u   /* seq points to device memory */
 #define KC_FLAG_MIN_FREQUENCY(z) (((uint32_t)(z) & 0xffu) << 8) /* -z INT (1..255; 0/1 = no filter; not with -S) */
-/* seq: record sequences separated by one '\n' (any non-ACGT byte separates k-mers); for -S `offsets` (host, n+1) is
- * required.  The result stays on the device until copied out. */
+/* seq: record sequences separated by one '\n' (any non-ACGT byte separates k-mers).  -S: the records are the simplitigs -- either
+ * packed back to back with `offsets` (host, n+1), or, with KC_FLAG_INPUT_ON_DEVICE and offsets == NULL, separated by '\n' as
+ * kc_read_fasta_device leaves them (simplitigs_from_fasta, simplitigs.h:78-103: one record per simplitig).  The result stays on the
+ * device until copied out. */
 int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint64_t *offsets, uint64_t n_records, int k, uint32_t flags,
                kc_result **out);
 /* stats[16]: 0 n_kmers, 1 n_simplitigs, 2 length, 3 sparse_branch, 4 n_vertices, 5 matching_rounds,

@@ -87,7 +87,15 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     const bool on_device = (flags & KC_FLAG_INPUT_ON_DEVICE) != 0;
     const int min_frequency = (int)((flags >> 8) & 0xff);
     if (min_frequency > 1 && from_simplitigs) return kc_fail(ctx, KC_E_ARG, "Inputting simplitigs is not compatible with frequency filterring.");
-    if (from_simplitigs && !offsets) return kc_fail(ctx, KC_E_ARG, "-S input needs record offsets");
+    if (from_simplitigs && !offsets && !on_device) return kc_fail(ctx, KC_E_ARG, "-S input needs record offsets");
+    // (-S with the sequence on the device and no offsets: the records are separated by '\n', as kc_read_fasta_device leaves them)
+    std::vector<u64> sep_offs;
+    int gap = 0;
+    if (from_simplitigs && !offsets) {
+        KC_TRY(kcp_record_starts_from_separators(ctx, (const u8 *)seq, len, sep_offs));
+        if (sep_offs.size() < 2) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
+        offsets = sep_offs.data(); n_records = sep_offs.size() - 1; gap = 1;
+    }
 
     hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1], e2 = ctx->ev[2], e3 = ctx->ev[3];
     hipEvent_t eend;
@@ -155,7 +163,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     } else {
         KC_HIP(ctx, hipEventRecord(e1, ctx->stream));
         // simplitigs_from_fasta (simplitigs.h:89-103)
-        rc = kcp_simplitigs_from_device_ascii(ctx, k, d_seq, len, offsets, n_records, 1, &simp);
+        rc = kcp_simplitigs_from_device_ascii(ctx, k, d_seq, len, offsets, n_records, 1, &simp, gap);
         if (rc == KC_OK) n_kmers = simp->total_bases - simp->n * (u64)(k - 1);
         if (rc == KC_OK && want_mask) {
             rc = kc_set_create(ctx, k, complements, simp->total_bases, &set);

@@ -248,7 +248,8 @@ int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_
 // kc_simplitigs.hip
 int kcp_build_simplitigs(kc_set *set, kc_simplitigs **out, u64 *rounds, u64 *cycles_cut);
 int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 len, const u64 *h_offsets, u64 n, int offsets_are_host_positions,
-                                     kc_simplitigs **out);
+                                     kc_simplitigs **out, int gap = 0);
+int kcp_record_starts_from_separators(kc_ctx *ctx, const u8 *d_seq, u64 len, std::vector<u64> &offs);
 int kcp_to_sparse(kc_simplitigs *s, kc_simplitigs **out);
 int kcp_insert_simplitig_kmers(kc_set *set, kc_simplitigs *s);
 // kc_overlap.hip

@@ -1389,15 +1389,69 @@ __global__ void __launch_bounds__(256) kc_end_kmers_kernel(const u64 *__restrict
     for (int i = 0; i < W; ++i) { firstK[t * W + i] = f.w[i]; lastK[t * W + i] = l.w[i]; }
 }
 
+// positions of the bytes equal to '\n' in a device sequence, ascending (two passes over 16 KB tiles: count, scan, write)
+template <bool FILL>
+__global__ void __launch_bounds__(256) kc_sep_positions_kernel(const u8 *__restrict__ seq, u64 len, const u64 *__restrict__ tile_off, u64 *out) {
+    const u64 base = ((u64)blockIdx.y * gridDim.x + blockIdx.x) * 16384 + (u64)threadIdx.x * 64;
+    u64 m = 0;
+    if (base < len) {
+        const u64 n = len - base < 64 ? len - base : 64;
+        for (u64 i = 0; i < n; ++i) m |= (u64)(seq[base + i] == (u8)'\n') << i;
+    }
+    u64 tot;
+    const u64 ex = kc_block_excl_scan((u64)__popcll(m), &tot);
+    const u64 tile = (u64)blockIdx.y * gridDim.x + blockIdx.x;
+    if (!FILL) { if (threadIdx.x == 0) out[tile] = tot; return; }
+    u64 pos = tile_off[tile] + ex;
+    while (m) { out[pos++] = base + (u64)__builtin_ctzll(m); m &= m - 1; }
+}
+// Record starts of a device sequence whose records are separated by '\n' (what kc_read_fasta_device leaves behind: one separator per
+// header line, the first of them in front): offs[i] = first character of record i, offs[n] = one past the last record's end + 1, so that
+// record i has offs[i + 1] - offs[i] - 1 characters.  An empty stretch in front of the first separator or behind the last is no record.
+int kcp_record_starts_from_separators(kc_ctx *ctx, const u8 *d_seq, u64 len, std::vector<u64> &offs) {
+    KcScope scope(ctx);
+    offs.clear();
+    if (len == 0) return KC_OK;
+    const u64 ntiles = (len + 16383) / 16384;
+    u64 *tcount = nullptr, *pos = nullptr;
+    KC_TRY(scope.alloc(&tcount, ntiles + 2));
+    const dim3 g = kc_grid2(ntiles * 256, 256);   // (one workgroup per tile)
+    KC_LAUNCH((kc_sep_positions_kernel<false>), g, dim3(256), 0, ctx->stream, d_seq, len, (const u64 *)nullptr, tcount);
+    KC_TRY(kcu_exclusive_scan(ctx, tcount, tcount, ntiles));
+    u64 nsep = 0;
+    KC_TRY(read_u64(ctx, tcount + ntiles, &nsep));
+    std::vector<u64> seps(nsep);
+    if (nsep) {
+        KC_TRY(scope.alloc(&pos, nsep + 1));
+        KC_LAUNCH((kc_sep_positions_kernel<true>), g, dim3(256), 0, ctx->stream, d_seq, len, (const u64 *)tcount, pos);
+        KC_HIP(ctx, hipGetLastError());
+        KC_HIP(ctx, hipMemcpyAsync(seps.data(), pos, nsep * 8, hipMemcpyDeviceToHost, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    // records = the stretches between consecutive separators (and the two ends)
+    offs.reserve(nsep + 2);
+    u64 start = 0;   // first character of the record at hand
+    for (u64 i = 0; i <= nsep; ++i) {
+        const u64 end = i < nsep ? seps[i] : len;   // one past its last character
+        const bool edge = (i == 0 || i == nsep) && end == start;   // nothing in front of the first / behind the last separator
+        if (!edge) offs.push_back(start);
+        start = end + 1;
+    }
+    if (!offs.empty()) offs.push_back(len + 1);
+    // (interior records keep their true extents: offs[i + 1] - offs[i] - 1 is right because every record but the last is followed by
+    // exactly one separator, and the last ends at len = (len + 1) - 1)
+    return KC_OK;
+}
+
 int kcp_simplitigs_from_device_ascii(kc_ctx *ctx, int k, const u8 *d_seq, u64 len, const u64 *h_offsets, u64 n,
-                                     int offsets_are_host_positions, kc_simplitigs **out) {
+                                     int offsets_are_host_positions, kc_simplitigs **out, int gap) {
     (void)len; (void)offsets_are_host_positions;
     if (n == 0) return kc_fail(ctx, KC_E_EMPTY, "input cannot be empty");
     const int W = kc_words_for_k(k);
     std::vector<u64> lens(n), woff(n + 1);
     u64 total = 0, w = 0;
     for (u64 i = 0; i < n; ++i) {
-        lens[i] = h_offsets[i + 1] - h_offsets[i];
+        lens[i] = h_offsets[i + 1] - h_offsets[i] - (u64)gap;   // (gap 1: the records are followed by a separator each, kcp_record_starts_from_separators)
         if (lens[i] < (u64)k) return kc_fail(ctx, KC_E_ARG, "simplitig record shorter than k");
         woff[i] = w;
         w += lens[i] / 32 + 1;

@@ -361,7 +361,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         struct stat sti;
         reopenable = path != "-" && ::stat(path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode);
     }
-    if (!assume_simplitigs && reopenable && !have_recs && !std::getenv("KC_CLI_NOSTREAM")) {   // (`lowerbound` on raw FASTA too)
+    if (!(assume_simplitigs && lower_bound) && reopenable && !have_recs && !std::getenv("KC_CLI_NOSTREAM")) {   // (`lowerbound` on raw FASTA and `compute -S` too)
         // FASTA goes to the device in pinned chunks and is tokenised there while the next chunk is read (no joined host copy)
         ctx = kcamd::context();
         mark("device context ready");

@@ -213,6 +213,27 @@ def test_cli_streamed_fasta_tokeniser_equals_host_parser(tmp_path):
     with open(fqf, "wb") as f:
         f.write(fq)
     assert run("compute", "-k", "31", fqf).stdout.split("\n")[1] == want_q   # a regular FASTQ file: tokeniser says FASTQ, host parser re-opens it
+    # -S (simplitigs_from_fasta, simplitigs.h:78-103) reads through the device tokeniser too: the records then reach kc_compute separated
+    # by '\n' on the device and their extents are found there; same bytes as the host loader on multi-line / CRLF / blank-line records, with
+    # and without -M, and the same complaint about a record shorter than k
+    srecs = [seq(rng.randrange(31, 260)).upper().replace("N", "A") for _ in range(120)]
+    stexts = {
+        "s_plain.fa": "".join(">s%d\n%s\n" % (i, r) for i, r in enumerate(srecs)),
+        "s_multiline_crlf.fa": "".join(">s%d some words\r\n%s\r\n" % (i, "\r\n".join(r[j:j + 50] for j in range(0, len(r), 50))) for i, r in enumerate(srecs)),
+        "s_blank_and_tail.fa": "\n".join(">s%d\n\n%s\n" % (i, "\n".join(r[j:j + 70] for j in range(0, len(r), 70))) for i, r in enumerate(srecs)) + "\n>last\n" + srecs[0],
+        "s_short_record.fa": ">a\n" + srecs[0] + "\n>b\nACGTACGT\n>c\n" + srecs[1] + "\n",
+    }
+    for name, text in stexts.items():
+        sp = str(tmp_path / name)
+        with open(sp, "w", newline="") as f:
+            f.write(text)
+        for extra in ([], ["-M", str(tmp_path / "sm.fa")]):
+            a = subprocess.run([BIN, "compute", "-k", "31", "-S"] + extra + [sp], capture_output=True, text=True)
+            ma = open(extra[1]).read() if extra and os.path.exists(extra[1]) else None
+            b = subprocess.run([BIN, "compute", "-k", "31", "-S"] + extra + [sp], capture_output=True, text=True, env=dict(os.environ, KC_CLI_NOSTREAM="1"))
+            mb = open(extra[1]).read() if extra and os.path.exists(extra[1]) else None
+            assert a.returncode == b.returncode and a.stdout == b.stdout and ma == mb, (name, extra, a.stderr[-300:], b.stderr[-300:])
+            assert (a.returncode == 0) == (name != "s_short_record.fa"), (name, a.returncode)
     # -o / -M files: header line, data, newline -- through the descriptor path
     o, m = str(tmp_path / "o.fa"), str(tmp_path / "m.fa")
     p = run("compute", "-k", "31", "-o", o, "-M", m, path)
