@@ -350,6 +350,14 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         hdr = hs.str();
         om.prepare(path, out_path, hdr.size(), trace, t_start);
     }
+    MappedOutput omm;   // -M: the mask file the same way
+    std::string mhdr;
+    if (!lower_bound && maskf != nullptr && !mask_path.empty()) {
+        std::ostringstream hs;
+        WriteName(path, "greedy", k, true, !complements, hs);
+        mhdr = hs.str();
+        omm.prepare(path, mask_path, mhdr.size(), trace, t_start);
+    }
     kc_ctx *ctx = nullptr;
     void *d_seq = nullptr;
     uint64_t d_len = 0;
@@ -445,7 +453,9 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     const bool mapped = om.ok && hdr.size() + st[2] + 1 <= om.cap;
     if (!mapped && om.fd >= 0) om.abandon();
     if (!mapped) WriteName(path, "greedy", k, false, !complements, *of);
-    if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);
+    const bool mmapped = omm.ok && mhdr.size() + st[2] + 1 <= omm.cap;
+    if (!mmapped && omm.fd >= 0) omm.abandon();
+    if (maskf != nullptr && !mmapped) WriteName(path, "greedy", k, true, !complements, *maskf);
     WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
     if (st[3]) WriteLog("2. part: Number of simplitigs over threshold, computing directly from k-mers.");
     WriteLog("Finished 2. part: Hamiltonian path.");
@@ -463,7 +473,7 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
     if (mapped) {
         om.commit(res, hdr, st[2], 0, mark);
     } else emit(out_path, 0);
-    if (maskf != nullptr) emit(mask_path, 1);
+    if (maskf != nullptr) { if (mmapped) omm.commit(res, mhdr, st[2], 1, mark); else emit(mask_path, 1); }
     kc_result_destroy(res);
     mark("result written");
     WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");

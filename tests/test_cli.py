@@ -271,6 +271,19 @@ def test_cli_large_input_takes_the_mapped_output_path(tmp_path):
         assert p.returncode == 0, (env, p.stderr[-400:])
         got = open(o).read().split("\n")
         assert got[0].startswith(">maskedsuperstring") and got[1] == want[1] and got[2] == "" and len(got) == 3, env
+    # -M: the mask file takes the mapped path as well
+    outs = []
+    for env in ({}, {"KC_CLI_NOPREALLOC": "1"}):
+        o2, m2 = str(tmp_path / "o2.fa"), str(tmp_path / "m2.fa")
+        for f in (o2, m2):
+            if os.path.exists(f):
+                os.unlink(f)
+        p = subprocess.run([BIN, "compute", "-k", "31", "-o", o2, "-M", m2, path], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert p.returncode == 0, (env, p.stderr[-400:])
+        outs.append((open(o2).read(), open(m2).read()))
+    assert outs[0] == outs[1] and outs[0][0].split("\n")[1] == want[1]
+    ml = outs[0][1].split("\n")
+    assert "mask=max-one" in ml[0] and ml[1].upper() == want[1].upper() and ml[2] == "" and len(ml) == 3
     # an output file that already holds something longer is cut to the new length
     with open(o, "w") as f:
         f.write("x" * (len(want[1]) + 5000000))
