@@ -189,6 +189,9 @@ int kc_result_slice(kc_result *r, uint64_t *offset, uint64_t *slice_len);
  * kc_device_free), ready for kc_compute(..., KC_FLAG_INPUT_ON_DEVICE).  *is_fastq = 1 (and nothing returned) when the input
  * is FASTQ: use the host parser.  KC_E_IO when the file cannot be opened (parser.h:95-97). */
 int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *len, int *is_fastq);
+/* the same for the bytes [offset, offset + nbytes) of a plain regular file: the share of the input that one rank of the multi-GPU
+ * `compute` reads for itself (the reference reads one stream in one thread, parser.h:88-118); the range should begin at a header line */
+int kc_read_fasta_device_range(kc_ctx *ctx, const char *path, uint64_t offset, uint64_t nbytes, void **d_seq, uint64_t *len, int *is_fastq);
 void kc_device_free(kc_ctx *ctx, void *d_ptr);
 /* write the result's characters (which = 0) or its -M mask (which = 1) to a file descriptor */
 int kc_result_write_fd(kc_result *r, int fd, int which);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "kc_compute_sharded_simplitigs": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, _u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, _vpp]),
     "kc_result_slice": (ctypes.c_int, [_vp, _u64p, _u64p]),
     "kc_read_fasta_device": (ctypes.c_int, [_vp, ctypes.c_char_p, _vpp, _u64p, ctypes.POINTER(ctypes.c_int)]),
+    "kc_read_fasta_device_range": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint64, _vpp, _u64p, ctypes.POINTER(ctypes.c_int)]),
     "kc_device_free": (None, [_vp, _vp]),
     "kc_result_write_fd": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "kc_result_write_mem": (ctypes.c_int, [_vp, _vp, ctypes.c_int]),

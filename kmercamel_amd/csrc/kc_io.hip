@@ -306,7 +306,7 @@ void kc_pin_free_all(kc_ctx *ctx) {
 // *is_fastq = 1: the input is FASTQ (or could not be handled here) -- nothing is returned, use the host parser.
 // Pipeline per 32 MB chunk: [reader thread + its helpers] pread into a pinned chunk -> [copy stream] H2D -> [context stream] the three
 // tokeniser kernels; the copy of chunk i+1 runs under the kernels of chunk i, the read of chunk i+2 under both.
-extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *len, int *is_fastq) {
+static int read_fasta_device_impl(kc_ctx *ctx, const char *path, u64 range_off, u64 range_len, bool ranged, void **d_seq, uint64_t *len, int *is_fastq) {
     if (!ctx || !path || !d_seq || !len || !is_fastq) return KC_E_ARG;
     *d_seq = nullptr; *len = 0; *is_fastq = 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
@@ -314,6 +314,13 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
     Reader rd;
     std::string err;
     if (!rd.open(path, err)) return kc_fail(ctx, KC_E_IO, err.empty() ? std::string("couldn't open file ") + path : err);
+    if (ranged) {
+        // a byte range of a plain regular file (a rank's share of the input: kc_read_fasta_device_range)
+        if (!rd.parallel()) { rd.close(); return kc_fail(ctx, KC_E_ARG, "a byte range can only be read from a plain regular file"); }
+        const off_t end = (off_t)(range_off + range_len) < rd.size ? (off_t)(range_off + range_len) : rd.size;
+        rd.pos = (off_t)range_off < end ? (off_t)range_off : end;
+        rd.size = end;
+    }
     const size_t CH = (size_t)32 << 20;
     const int NB = 3;
     u8 *hbuf[NB] = {nullptr, nullptr, nullptr};
@@ -374,7 +381,8 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
     u64 out_cap = 0;
     {   // plain files: the joined sequence is never longer than the file; streams: grow as needed
         struct stat st;
-        if (rc == KC_OK && !rd.gz && fstat(rd.fd, &st) == 0 && st.st_size > 0) out_cap = (u64)st.st_size + 64;
+        if (rc == KC_OK && ranged) out_cap = (u64)(rd.size - rd.pos) + 64;
+        else if (rc == KC_OK && !rd.gz && fstat(rd.fd, &st) == 0 && st.st_size > 0) out_cap = (u64)st.st_size + 64;
         else out_cap = (u64)256 << 20;
     }
     if (rc == KC_OK) rc = kc_alloc(ctx, &out, out_cap);
@@ -476,6 +484,16 @@ extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq,
     if (rc != KC_OK || fastq) { kc_release(ctx, out); *is_fastq = fastq ? 1 : 0; return rc; }
     *d_seq = out; *len = h[1];
     return KC_OK;
+}
+
+extern "C" int kc_read_fasta_device(kc_ctx *ctx, const char *path, void **d_seq, uint64_t *len, int *is_fastq) {
+    return read_fasta_device_impl(ctx, path, 0, 0, false, d_seq, len, is_fastq);
+}
+// The bytes [offset, offset + nbytes) of a plain regular file (clipped to its end): the share of the input one rank of `compute --gpus N`
+// reads for itself, all ranks at once.  The range should begin at a header line -- what lies before the first '>' in it is skipped, as at
+// the start of a file (kseq.h:190-193).
+extern "C" int kc_read_fasta_device_range(kc_ctx *ctx, const char *path, uint64_t offset, uint64_t nbytes, void **d_seq, uint64_t *len, int *is_fastq) {
+    return read_fasta_device_impl(ctx, path, offset, nbytes, true, d_seq, len, is_fastq);
 }
 
 extern "C" void kc_device_free(kc_ctx *ctx, void *d_ptr) {

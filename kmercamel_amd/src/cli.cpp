@@ -126,11 +126,260 @@ static void write_all(int fd, const char *data, size_t n) {
     }
 }
 
+// The output file of a large run gets its pages while the device comes up and computes -- fallocate(), one call, one thread: measured on the
+// MI355X box for 2.55 GB on tmpfs 125 ms, against 370 ms for faulting the pages in through a mapping with one thread and 630 ms with eight
+// (page allocation for ONE file serialises on the inode; tools/io_probe2.cpp) -- and is mapped.  The result then goes straight into
+// the page cache through the mapping (kc_result_write_mem: stores into a mapping take no inode lock, eight threads move each chunk at
+// ~27 GB/s, first-touch faults included; a write() stream manages 7 GB/s) and the file is cut to its final length.  Anything unusual
+// (not a regular file, small input, mapping refused, result longer than estimated) leaves `ok` unset: the caller takes the plain
+// descriptor path.  Used by `compute` and `maskopt`.
+struct MappedOutput {
+    int fd = -1; char *map = nullptr; size_t cap = 0; bool ok = false, committed = false;
+    std::thread th;
+    void settle() { if (th.joinable()) th.join(); }
+    ~MappedOutput() {
+        settle();
+        if (map) ::munmap(map, cap);
+        if (fd >= 0) { if (!committed && ::ftruncate(fd, 0) != 0) {} ::close(fd); }
+    }
+    // in_path: the input file (its size bounds the output's: header + that + slack); out_path: the -o file, already created by the caller
+    void prepare(const std::string &in_path, const std::string &out_path, size_t hdr_bytes, bool trace, std::chrono::steady_clock::time_point t_start) {
+        if (std::getenv("KC_CLI_NOPREALLOC")) return;
+        struct stat sti, sto;
+        if (!(::stat(in_path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode) && sti.st_size > (off_t)(64 << 20) && ::stat(out_path.c_str(), &sto) == 0 && S_ISREG(sto.st_mode))) return;
+        cap = hdr_bytes + (size_t)sti.st_size + 4096;
+        const int f = ::open(out_path.c_str(), O_RDWR);
+        if (f < 0) return;
+        if (::ftruncate(f, (off_t)cap) != 0) { ::close(f); return; }
+        fd = f;   // (from here on the destructor restores the empty file unless the result is committed)
+        void *m = ::mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) return;
+        map = static_cast<char *>(m);
+        ok = true;
+        // Then the pages are mapped in by four threads with write touches that change nothing (an atomic OR of 0: the result may
+        // already be arriving in the front of the file while the back is still being touched).  Touches of allocated pages
+        // scale with threads where allocation does not, and a copy into mapped pages runs at the speed of the PCIe transfer
+        // (measured: 2.55 GB in ~50 ms against 105-200 ms when every store of the copy first had to fault its page in).
+        // MADV_POPULATE_WRITE is NOT used: unmapping pages it brought in took twice as long (90-110 ms against 43 ms).
+        // (a file system without fallocate: the pages then come with these touches, as for any mapping)
+        th = std::thread([this, trace, t_start] {
+            const int rc = ::fallocate(fd, 0, 0, (off_t)cap) == 0 ? 0 : errno;
+            if (trace) std::cerr << "[cli] output pages allocated (rc " << rc << "): " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+            const char *te = std::getenv("KC_CLI_TOUCH_THREADS");
+            const int T = te ? std::atoi(te) : 4;
+            if (T < 1) return;
+            const size_t PIECE = (size_t)8 << 20;
+            auto part = [this, T, PIECE](int t) {
+                for (size_t lo = (size_t)t * PIECE; lo < cap; lo += (size_t)T * PIECE) {
+                    const size_t hi = lo + PIECE < cap ? lo + PIECE : cap;
+                    for (size_t p = lo; p < hi; p += 4096) __atomic_fetch_or(map + p, (char)0, __ATOMIC_RELAXED);
+                }
+            };
+            std::vector<std::thread> ths;
+            for (int t = 1; t < T; ++t) ths.emplace_back(part, t);
+            part(0);
+            for (auto &x : ths) x.join();
+            if (trace) std::cerr << "[cli] output pages mapped: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+        });
+    }
+    // the mapping cannot take this result (or is not wanted after all): the file goes back to empty, the caller writes through the descriptor
+    void abandon() {
+        settle();
+        if (map) { ::munmap(map, cap); map = nullptr; }
+        if (fd >= 0) { if (::ftruncate(fd, 0) != 0) {} ::close(fd); fd = -1; }
+        ok = false;
+    }
+    // header line, the result's characters (which: 0 string, 1 mask), '\n'; the file is cut to that length
+    void commit(kc_result *res, const std::string &hdr, uint64_t length, int which, const std::function<void(const char *)> &mark) {
+        kcamd::check(kc_result_write_mem(res, map + hdr.size(), which));
+        mark("result in the mapping");
+        finish(hdr, length, mark);
+    }
+    // the characters are in place behind where the header goes (written by one caller, or slice by slice by the ranks of `--gpus N`)
+    void finish(const std::string &hdr, uint64_t length, const std::function<void(const char *)> &mark) {
+        memcpy(map, hdr.data(), hdr.size());
+        settle();
+        map[hdr.size() + length] = '\n';   // main.cpp:210
+        // munmap tears the 6 10^5 page-table entries of the mapping down under the exclusive mmap lock, 40 - 100 ms for this file; the same
+        // entries dropped by MADV_DONTNEED -- which takes the lock shared, so eight threads work side by side, and which leaves the data
+        // of a shared file mapping where it is, in the page cache -- make the munmap behind them a formality.  (KC_CLI_NO_ZAP: A/B knob)
+        if (!std::getenv("KC_CLI_NO_ZAP")) {
+            const int T = 8;
+            const size_t per = ((cap / T) + 4095) & ~(size_t)4095;
+            std::vector<std::thread> zap;
+            for (int t = 0; t < T; ++t) {
+                const size_t lo = (size_t)t * per;
+                if (lo >= cap) break;
+                const size_t n = lo + per < cap ? per : cap - lo;
+                zap.emplace_back([this, lo, n] { (void)::madvise(map + lo, n, MADV_DONTNEED); });
+            }
+            for (auto &z : zap) z.join();
+            mark("mapping dropped");
+        }
+        ::munmap(map, cap); map = nullptr;
+        if (::ftruncate(fd, (off_t)(hdr.size() + length + 1)) != 0) throw std::runtime_error("cannot size the output file");
+        committed = true;
+    }
+};
+
+// `compute --gpus N` on a large plain FASTA file: every rank thread reads ITS byte range of the file through the device tokeniser
+// (kc_read_fasta_device_range: the ranges begin at header lines), the ranks compute one superstring (kc_compute_sharded on device input),
+// and every rank copies its slice straight into the mapping of the fallocate'd output file -- no host copy of the input, no host copy of the
+// output, nothing done by one thread for all.  Returns KC_CLI_STREAM_NA (nothing read, nothing written) when the input is not a plain
+// regular file of more than 64 MB or some rank's share does not look like FASTA: the caller then takes the host-parser form below.
+static const int KC_CLI_SHARDED_FALLBACK = -1000, KC_CLI_STREAM_NA = -1001;
+static int run_compute_sharded_streamed(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus, int min_frequency,
+                                        const std::string &out_path, const std::string &mask_path, std::string *why) {
+    struct stat sti;
+    if (path == "-" || std::getenv("KC_CLI_NOSTREAM") || ::stat(path.c_str(), &sti) != 0 || !S_ISREG(sti.st_mode) || sti.st_size <= (off_t)(64 << 20)) return KC_CLI_STREAM_NA;
+    const uint64_t fsize = (uint64_t)sti.st_size;
+    // rank r reads [cut[r], cut[r + 1]): cut[r] = the first header line that starts at or after fsize * r / N
+    std::vector<uint64_t> cut(gpus + 1, fsize);
+    cut[0] = 0;
+    {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) return KC_CLI_STREAM_NA;
+        unsigned char magic[2] = {0, 0};
+        if (fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { fclose(f); return KC_CLI_STREAM_NA; }   // gzip: one stream
+        std::vector<char> win((size_t)4 << 20);
+        for (int r = 1; r < gpus; ++r) {
+            uint64_t p = fsize / (uint64_t)gpus * (uint64_t)r;
+            if (p < cut[r - 1]) p = cut[r - 1];
+            uint64_t found = fsize;
+            // (look at the byte before p too: a '>' exactly at p counts only if a line starts there)
+            for (uint64_t at = p ? p - 1 : 0; at < fsize && found == fsize; at += win.size() - 1) {
+                if (fseeko(f, (off_t)at, SEEK_SET) != 0) break;
+                const size_t got = fread(win.data(), 1, win.size(), f);
+                if (got < 2) break;
+                for (size_t i = (at == 0 && p == 0) ? 0 : 1; i < got; ++i)
+                    if (win[i] == '>' && (at + i == 0 || win[i - 1] == '\n') && at + i >= p) { found = at + i; break; }
+            }
+            cut[r] = found;
+        }
+        fclose(f);
+    }
+    const bool trace = std::getenv("KC_CLI_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (trace) std::cerr << "[cli] " << what << ": " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
+    };
+    WriteLog("Started computation of a masked superstring from '" + path + "'.");
+    MappedOutput om, omm;
+    std::string hdr, mhdr;
+    if (!out_path.empty()) {
+        std::ostringstream hs;
+        WriteName(path, "greedy", k, false, !complements, hs);
+        hdr = hs.str();
+        om.prepare(path, out_path, hdr.size(), trace, t_start);
+    }
+    if (maskf != nullptr && !mask_path.empty()) {
+        std::ostringstream hs;
+        WriteName(path, "greedy", k, true, !complements, hs);
+        mhdr = hs.str();
+        omm.prepare(path, mask_path, mhdr.size(), trace, t_start);
+    }
+    const int ndev = kc_device_count();
+    if (ndev <= 0) throw std::runtime_error("kmercamel_amd: no usable MI355X / HIP device");
+    kc_thread_group *group = nullptr;
+    if (kc_thread_group_create(gpus, &group) != KC_OK) throw std::runtime_error("kmercamel_amd: cannot create the rank group");
+    std::vector<kc_result *> res(gpus, nullptr);
+    std::vector<std::string> err(gpus);
+    std::vector<int> rcs(gpus, KC_OK);
+    std::vector<uint64_t> st(16, 0);
+    std::string out, mask;   // (only when the output cannot be mapped)
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, not_fasta = 0;
+    bool out_ready = false, mapped = false, mmapped = false;
+    auto rank_main = [&](int r) {
+        kc_ctx *ctx = nullptr;
+        kc_comm *comm = nullptr;
+        int rc = kc_ctx_create(r % ndev, &ctx);
+        if (rc == KC_OK) rc = kc_comm_create_threads(ctx, group, r, &comm);
+        if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; _exit(1); }   // (the others would wait for it forever)
+        void *d_seq = nullptr;
+        uint64_t d_len = 0;
+        int fq = 0;
+        rc = kc_read_fasta_device_range(ctx, path.c_str(), cut[r], cut[r + 1] - cut[r], &d_seq, &d_len, &fq);
+        {   // the ranks agree on whether this is input for the streamed path before any of them enters the collective
+            std::unique_lock<std::mutex> lk(mu);
+            if (rc != KC_OK || fq) ++not_fasta;
+            if (++arrived == gpus) cv.notify_all(); else cv.wait(lk, [&] { return arrived == gpus; });
+        }
+        if (not_fasta) { if (d_seq) kc_device_free(ctx, d_seq); rcs[r] = KC_CLI_STREAM_NA; kc_comm_destroy(comm); kc_ctx_destroy(ctx); return; }
+        if (r == 0) mark("every rank has its share of the input on its device");
+        rc = kc_compute_sharded(ctx, comm, d_seq, d_len, k, (complements ? KC_FLAG_COMPLEMENTS : 0) | (maskf ? KC_FLAG_WANT_MASK : 0) | KC_FLAG_INPUT_ON_DEVICE |
+                                (min_frequency > 1 ? KC_FLAG_MIN_FREQUENCY(min_frequency) : 0), &res[r]);
+        if (d_seq) kc_device_free(ctx, d_seq);
+        rcs[r] = rc;
+        if (rc != KC_OK) err[r] = kc_last_error(ctx);
+        const bool sparse_case = rc == KC_E_ARG && err[r].find("not part of the hash-sharded path") != std::string::npos;
+        if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
+        if (rc == KC_OK) {
+            if (r == 0) {
+                mark("kc_compute_sharded returned");
+                kc_result_stats(res[0], st.data());
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    mapped = om.ok && hdr.size() + st[2] + 1 <= om.cap;
+                    mmapped = omm.ok && mhdr.size() + st[2] + 1 <= omm.cap;
+                    if (!mapped) out.resize(st[2]);
+                    if (maskf && !mmapped) mask.resize(st[2]);
+                    out_ready = true;
+                }
+                cv.notify_all();
+            } else {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return out_ready; });
+            }
+            uint64_t off = 0, n = 0;
+            kc_result_slice(res[r], &off, &n);
+            int wrc = KC_OK;
+            if (n) {
+                // every rank moves its slice itself: into the mapping where there is one (pinned chunks, eight copy threads per rank)
+                if (mapped) wrc = kc_result_write_mem(res[r], om.map + hdr.size() + off, 0);
+                else wrc = kc_result_copy(res[r], &out[off], nullptr);
+                if (wrc == KC_OK && maskf) {
+                    if (mmapped) wrc = kc_result_write_mem(res[r], omm.map + mhdr.size() + off, 1);
+                    else { std::vector<char> tmp(n); wrc = kc_result_copy(res[r], tmp.data(), &mask[off]); }
+                }
+            }
+            if (wrc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot copy its slice" << std::endl; _exit(1); }
+            kc_result_destroy(res[r]);
+        }
+        kc_comm_destroy(comm);
+        kc_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < gpus; ++r) th.emplace_back(rank_main, r);
+    rank_main(0);
+    for (auto &t : th) t.join();
+    kc_thread_group_destroy(group);
+    if (rcs[0] == KC_CLI_STREAM_NA) { om.abandon(); omm.abandon(); return KC_CLI_STREAM_NA; }
+    if (rcs[0] == KC_E_NO_KMERS) {
+        om.abandon(); omm.abandon();
+        std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
+        return usage_subcommand("compute");
+    }
+    if (rcs[0] == KC_E_ARG) { om.abandon(); omm.abandon(); *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }
+    mark("every slice is in place");
+    WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
+    if (!mapped) { if (om.fd >= 0) om.abandon(); WriteName(path, "greedy", k, false, !complements, *of); }
+    if (maskf != nullptr && !mmapped) { if (omm.fd >= 0) omm.abandon(); WriteName(path, "greedy", k, true, !complements, *maskf); }
+    WriteLog("Finished 1. part: simplitigs (" + std::to_string(st[1]) + " simplitigs).");
+    WriteLog("Finished 2. part: Hamiltonian path.");
+    if (mapped) om.finish(hdr, st[2], mark); else of->write(out.data(), (std::streamsize)out.size());
+    if (maskf != nullptr) { if (mmapped) omm.finish(mhdr, st[2], mark); else { maskf->write(mask.data(), (std::streamsize)mask.size()); *maskf << std::endl; } }   // global.h:206-208
+    WriteLog("Finished 3. part: masked superstring (l=" + std::to_string(st[2]) + ").");
+    if (!mapped) *of << std::endl;
+    mark("output written");
+    return 0;
+}
+
 // `compute` over several GPUs (--gpus N / KMERCAMEL_GPUS; the reference is one thread, main.cpp:122-212): one rank thread per GPU (ranks
 // beyond the number of devices share them round robin), each with its own context and a communicator of the in-process
 // thread transport; the records are cut into N contiguous parts, kc_compute_sharded builds ONE masked superstring --
 // byte-identical to the single-GPU result -- and every rank copies its slice into place.
-static const int KC_CLI_SHARDED_FALLBACK = -1000;
 static int run_compute_sharded(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, int gpus, int min_frequency, bool assume_simplitigs,
                                std::string *why, Records *loaded) {
     WriteLog("Started computation of a masked superstring from '" + path + "'.");
@@ -225,98 +474,6 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
     return 0;
 }
 
-// The output file of a large run gets its pages while the device comes up and computes -- fallocate(), one call, one thread: measured on the
-// MI355X box for 2.55 GB on tmpfs 125 ms, against 370 ms for faulting the pages in through a mapping with one thread and 630 ms with eight
-// (page allocation for ONE file serialises on the inode; tools/io_probe2.cpp) -- and is mapped.  The result then goes straight into
-// the page cache through the mapping (kc_result_write_mem: stores into a mapping take no inode lock, eight threads move each chunk at
-// ~27 GB/s, first-touch faults included; a write() stream manages 7 GB/s) and the file is cut to its final length.  Anything unusual
-// (not a regular file, small input, mapping refused, result longer than estimated) leaves `ok` unset: the caller takes the plain
-// descriptor path.  Used by `compute` and `maskopt`.
-struct MappedOutput {
-    int fd = -1; char *map = nullptr; size_t cap = 0; bool ok = false, committed = false;
-    std::thread th;
-    void settle() { if (th.joinable()) th.join(); }
-    ~MappedOutput() {
-        settle();
-        if (map) ::munmap(map, cap);
-        if (fd >= 0) { if (!committed && ::ftruncate(fd, 0) != 0) {} ::close(fd); }
-    }
-    // in_path: the input file (its size bounds the output's: header + that + slack); out_path: the -o file, already created by the caller
-    void prepare(const std::string &in_path, const std::string &out_path, size_t hdr_bytes, bool trace, std::chrono::steady_clock::time_point t_start) {
-        if (std::getenv("KC_CLI_NOPREALLOC")) return;
-        struct stat sti, sto;
-        if (!(::stat(in_path.c_str(), &sti) == 0 && S_ISREG(sti.st_mode) && sti.st_size > (off_t)(64 << 20) && ::stat(out_path.c_str(), &sto) == 0 && S_ISREG(sto.st_mode))) return;
-        cap = hdr_bytes + (size_t)sti.st_size + 4096;
-        const int f = ::open(out_path.c_str(), O_RDWR);
-        if (f < 0) return;
-        if (::ftruncate(f, (off_t)cap) != 0) { ::close(f); return; }
-        fd = f;   // (from here on the destructor restores the empty file unless the result is committed)
-        void *m = ::mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) return;
-        map = static_cast<char *>(m);
-        ok = true;
-        // Then the pages are mapped in by four threads with write touches that change nothing (an atomic OR of 0: the result may
-        // already be arriving in the front of the file while the back is still being touched).  Touches of allocated pages
-        // scale with threads where allocation does not, and a copy into mapped pages runs at the speed of the PCIe transfer
-        // (measured: 2.55 GB in ~50 ms against 105-200 ms when every store of the copy first had to fault its page in).
-        // MADV_POPULATE_WRITE is NOT used: unmapping pages it brought in took twice as long (90-110 ms against 43 ms).
-        // (a file system without fallocate: the pages then come with these touches, as for any mapping)
-        th = std::thread([this, trace, t_start] {
-            const int rc = ::fallocate(fd, 0, 0, (off_t)cap) == 0 ? 0 : errno;
-            if (trace) std::cerr << "[cli] output pages allocated (rc " << rc << "): " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
-            const char *te = std::getenv("KC_CLI_TOUCH_THREADS");
-            const int T = te ? std::atoi(te) : 4;
-            if (T < 1) return;
-            const size_t PIECE = (size_t)8 << 20;
-            auto part = [this, T, PIECE](int t) {
-                for (size_t lo = (size_t)t * PIECE; lo < cap; lo += (size_t)T * PIECE) {
-                    const size_t hi = lo + PIECE < cap ? lo + PIECE : cap;
-                    for (size_t p = lo; p < hi; p += 4096) __atomic_fetch_or(map + p, (char)0, __ATOMIC_RELAXED);
-                }
-            };
-            std::vector<std::thread> ths;
-            for (int t = 1; t < T; ++t) ths.emplace_back(part, t);
-            part(0);
-            for (auto &x : ths) x.join();
-            if (trace) std::cerr << "[cli] output pages mapped: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
-        });
-    }
-    // the mapping cannot take this result (or is not wanted after all): the file goes back to empty, the caller writes through the descriptor
-    void abandon() {
-        settle();
-        if (map) { ::munmap(map, cap); map = nullptr; }
-        if (fd >= 0) { if (::ftruncate(fd, 0) != 0) {} ::close(fd); fd = -1; }
-        ok = false;
-    }
-    // header line, the result's characters (which: 0 string, 1 mask), '\n'; the file is cut to that length
-    void commit(kc_result *res, const std::string &hdr, uint64_t length, int which, const std::function<void(const char *)> &mark) {
-        memcpy(map, hdr.data(), hdr.size());
-        kcamd::check(kc_result_write_mem(res, map + hdr.size(), which));
-        mark("result in the mapping");
-        settle();
-        map[hdr.size() + length] = '\n';   // main.cpp:210
-        // munmap tears the 6 10^5 page-table entries of the mapping down under the exclusive mmap lock, 40 - 100 ms for this file; the same
-        // entries dropped by MADV_DONTNEED -- which takes the lock shared, so eight threads work side by side, and which leaves the data
-        // of a shared file mapping where it is, in the page cache -- make the munmap behind them a formality.  (KC_CLI_NO_ZAP: A/B knob)
-        if (!std::getenv("KC_CLI_NO_ZAP")) {
-            const int T = 8;
-            const size_t per = ((cap / T) + 4095) & ~(size_t)4095;
-            std::vector<std::thread> zap;
-            for (int t = 0; t < T; ++t) {
-                const size_t lo = (size_t)t * per;
-                if (lo >= cap) break;
-                const size_t n = lo + per < cap ? per : cap - lo;
-                zap.emplace_back([this, lo, n] { (void)::madvise(map + lo, n, MADV_DONTNEED); });
-            }
-            for (auto &z : zap) z.join();
-            mark("mapping dropped");
-        }
-        ::munmap(map, cap); map = nullptr;
-        if (::ftruncate(fd, (off_t)(hdr.size() + length + 1)) != 0) throw std::runtime_error("cannot size the output file");
-        committed = true;
-    }
-};
-
 int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *maskf, bool complements, bool assume_simplitigs, bool lower_bound,
                 int min_frequency, const std::string &out_path, const std::string &mask_path, int gpus = 1, bool gpus_explicit = true) {
     bool started_logged = false;
@@ -326,11 +483,13 @@ int run_compute(const std::string &path, int k, std::ostream *of, std::ostream *
         // what the hash-sharded path does not cover runs on one GPU, as without the option
         if (!lower_bound && (assume_simplitigs ? maskf == nullptr : k >= 18)) {
             std::string why;
-            const int rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, assume_simplitigs, &why, &recs);
+            int rc = assume_simplitigs ? KC_CLI_STREAM_NA : run_compute_sharded_streamed(path, k, of, maskf, complements, gpus, min_frequency, out_path, mask_path, &why);
+            const bool streamed_ranks = rc != KC_CLI_STREAM_NA;
+            if (!streamed_ranks) rc = run_compute_sharded(path, k, of, maskf, complements, gpus, min_frequency, assume_simplitigs, &why, &recs);
             if (rc != KC_CLI_SHARDED_FALLBACK) return rc;
             std::cerr << "Note: " << why << "; running on one GPU." << std::endl;
             started_logged = true;
-            have_recs = true;
+            have_recs = !streamed_ranks;   // (the host-parser form has read the records; after the streamed form the file is simply read again)
         } else if (gpus_explicit) std::cerr << "Note: --gpus applies to `compute -k K [-M F] [-z N]` with K >= 18 and to `compute -S` without -M; running on one GPU." << std::endl;
     }
     if (started_logged) { /* run_compute_sharded has logged the start */ }

@@ -284,6 +284,19 @@ def test_cli_large_input_takes_the_mapped_output_path(tmp_path):
     assert outs[0] == outs[1] and outs[0][0].split("\n")[1] == want[1]
     ml = outs[0][1].split("\n")
     assert "mask=max-one" in ml[0] and ml[1].upper() == want[1].upper() and ml[2] == "" and len(ml) == 3
+    # --gpus N on a large plain file: every rank reads its own byte range through the device tokeniser and writes its own slice of the
+    # mapped output (run_compute_sharded_streamed); 2 and 3 ranks sharing the GPU, with -M, into files and to stdout
+    for gp in ("2", "3"):
+        o3, m3 = str(tmp_path / "o3.fa"), str(tmp_path / "m3.fa")
+        for f in (o3, m3):
+            if os.path.exists(f):
+                os.unlink(f)
+        p = subprocess.run([BIN, "compute", "-k", "31", "--gpus", gp, "-o", o3, "-M", m3, path], capture_output=True, text=True, env=dict(os.environ, KC_CLI_TRACE="1"))
+        assert p.returncode == 0, p.stderr[-600:]
+        assert "every rank has its share of the input on its device" in p.stderr and "every slice is in place" in p.stderr, p.stderr[-800:]
+        assert (open(o3).read(), open(m3).read()) == outs[0], gp
+    p = subprocess.run([BIN, "compute", "-k", "31", "--gpus", "2", path], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout == ref.stdout
     # an output file that already holds something longer is cut to the new length
     with open(o, "w") as f:
         f.write("x" * (len(want[1]) + 5000000))
