@@ -1,6 +1,7 @@
 // C-ABI glue: Global / SuperstringFromPath entry points and the fused, device-resident greedy branch of
 // kmercamel<>() (main.cpp:122-212).
 #include "kc_internal.h"
+#include "kc_comm.h"
 
 static int copy_out_string(kc_ctx *ctx, const char *d, u64 L, char **out) {
     char *h = (char *)malloc(L + 1);
@@ -97,6 +98,21 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         offsets = sep_offs.data(); n_records = sep_offs.size() - 1; gap = 1;
     }
 
+    // -z (ReadKMersFiltered, parser.h:122-141) counts occurrences.  The direct path below does that with one global compare-and-swap and
+    // one global counter update per OCCURRENCE (2.3 G/s measured on 10x reads: 213 ms for 5 10^8 occurrences, 24 times the bucketed build
+    // without -z).  The hash-sharded flow counts where a block's occurrences meet, in LDS (kc_block_build_filter_kernel): with a
+    // single-rank communicator it is the same computation on one GPU, byte-identical by its contract (tests/test_gpu_sharded.py), so -z
+    // takes that route.  What it does not cover (k < 18, blocks that overflow, the sparse branch -- errors all ranks take together) falls
+    // through to the direct path.  KC_Z_DIRECT=1: the direct path only.
+    if (min_frequency > 1 && !from_simplitigs && k >= 18 && !getenv("KC_Z_DIRECT")) {
+        kc_comm *self = nullptr;
+        if (kc_comm_create_self(ctx, &self) == KC_OK) {
+            const int rc = kc_compute_sharded(ctx, self, seq, len, k, flags, out);
+            kc_comm_destroy(self);
+            if (rc == KC_OK || !(ctx->err_agreed && (rc == KC_E_ARG || rc == KC_E_CAPACITY))) return rc;
+            *out = nullptr;
+        }
+    }
     hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1], e2 = ctx->ev[2], e3 = ctx->ev[3];
     hipEvent_t eend;
     KC_HIP(ctx, hipEventCreate(&eend));
