@@ -839,18 +839,28 @@ def test_min_frequency_filter(ctx, oracle, golden_dir, tmp_path):
     reads = gen.stress_reads(3000, 300, 100, seed=5)
     fa = tmp_path / "cov.fa"
     fa.write_bytes(b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads)))
-    for k in (9, 31, 40):
-        for c in (True, False):
-            for z in (2, 3, 7):
-                rc, want, wmask, st = oracle.compute_file_z(str(fa), k, c, 1, z)
-                if rc != 0:
-                    with pytest.raises(kc.KcError):
-                        kc.compute_file(ctx, str(fa), k, c, want_mask=True, min_frequency=z)
-                    continue
-                r = kc.compute_file(ctx, str(fa), k, c, want_mask=True, min_frequency=z)
-                out, mask = r.strings(want_mask=True)
-                assert (out, mask) == (want, wmask) and r.stats["n_kmers"] == st[0]
-                r.close()
+    # both routes of kc_compute's -z: the LDS counting build of the sharded flow on one rank (default for k >= 18) and the direct counting
+    # insert (KC_Z_DIRECT=1; k < 18 takes it anyway) -- each against the oracle
+    for direct in ("", "1"):
+        if direct:
+            os.environ["KC_Z_DIRECT"] = "1"
+        else:
+            os.environ.pop("KC_Z_DIRECT", None)
+        try:
+            for k in (9, 31, 40):
+                for c in (True, False):
+                    for z in (2, 3, 7):
+                        rc, want, wmask, st = oracle.compute_file_z(str(fa), k, c, 1, z)
+                        if rc != 0:
+                            with pytest.raises(kc.KcError):
+                                kc.compute_file(ctx, str(fa), k, c, want_mask=True, min_frequency=z)
+                            continue
+                        r = kc.compute_file(ctx, str(fa), k, c, want_mask=True, min_frequency=z)
+                        out, mask = r.strings(want_mask=True)
+                        assert (out, mask) == (want, wmask) and r.stats["n_kmers"] == st[0], (direct, k, c, z)
+                        r.close()
+        finally:
+            os.environ.pop("KC_Z_DIRECT", None)
     # growing while counting (many small adds) keeps the counters
     s = kc.KmerSet(ctx, 21, True)
     ctx.check(ctx.lib.kc_set_enable_counting(s.h))
