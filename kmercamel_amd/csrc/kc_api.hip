@@ -98,21 +98,6 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
         offsets = sep_offs.data(); n_records = sep_offs.size() - 1; gap = 1;
     }
 
-    // -z (ReadKMersFiltered, parser.h:122-141) counts occurrences.  The direct path below does that with one global compare-and-swap and
-    // one global counter update per OCCURRENCE (2.3 G/s measured on 10x reads: 213 ms for 5 10^8 occurrences, 24 times the bucketed build
-    // without -z).  The hash-sharded flow counts where a block's occurrences meet, in LDS (kc_block_build_filter_kernel): with a
-    // single-rank communicator it is the same computation on one GPU, byte-identical by its contract (tests/test_gpu_sharded.py), so -z
-    // takes that route.  What it does not cover (k < 18, blocks that overflow, the sparse branch -- errors all ranks take together) falls
-    // through to the direct path.  KC_Z_DIRECT=1: the direct path only.
-    if (min_frequency > 1 && !from_simplitigs && k >= 18 && !getenv("KC_Z_DIRECT")) {
-        kc_comm *self = nullptr;
-        if (kc_comm_create_self(ctx, &self) == KC_OK) {
-            const int rc = kc_compute_sharded(ctx, self, seq, len, k, flags, out);
-            kc_comm_destroy(self);
-            if (rc == KC_OK || !(ctx->err_agreed && (rc == KC_E_ARG || rc == KC_E_CAPACITY))) return rc;
-            *out = nullptr;
-        }
-    }
     hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1], e2 = ctx->ev[2], e3 = ctx->ev[3];
     hipEvent_t eend;
     KC_HIP(ctx, hipEventCreate(&eend));
@@ -148,10 +133,26 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
     if (!from_simplitigs) {
         // phase 0: ReadKMers/AddKMers (parser.h:22-49,106-118)
         u64 occ = len >= (u64)k ? len - k + 1 : 0;
-        rc = kc_set_create(ctx, k, complements, occ, &set);
-        if (rc == KC_OK && min_frequency > 1) rc = kc_set_enable_counting(set);
         u64 *codes = nullptr, *brk = nullptr, *low = nullptr;
-        if (rc == KC_OK && len >= (u64)k) {
+        // -z (ReadKMersFiltered, parser.h:122-141) counts occurrences.  The direct insert does that with one global compare-and-swap and one
+        // global counter update per OCCURRENCE (2.3 G/s measured on 10x reads: 213 ms for 5 10^8 occurrences, 24 times the bucketed build
+        // without -z); the hash-sharded flow's build counts where a block's occurrences meet, in LDS (kcs_build_counted).  What that does
+        // not cover (k < 18, blocks that overflow) falls through to the direct insert.  KC_Z_DIRECT=1: the direct insert only.
+        bool counted = false;
+        if (min_frequency > 1 && k >= 18 && len >= (u64)k && !getenv("KC_Z_DIRECT")) {
+            rc = kcs_pack(ctx, d_seq, len, &codes, &brk, &low);
+            if (rc == KC_OK) {
+                (void)hipEventRecord(ctx->ev[6], ctx->stream);
+                rc = kcs_build_counted(ctx, k, complements, codes, brk, low, len, min_frequency, &set);
+                (void)hipEventRecord(ctx->ev[7], ctx->stream);
+                if (rc == KC_OK) counted = true;
+                else if (ctx->err_agreed && (rc == KC_E_ARG || rc == KC_E_CAPACITY)) { rc = KC_OK; set = nullptr; }
+            }
+            if (!counted) { kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low); codes = brk = low = nullptr; }
+        }
+        if (rc == KC_OK && !counted) rc = kc_set_create(ctx, k, complements, occ, &set);
+        if (rc == KC_OK && !counted && min_frequency > 1) rc = kc_set_enable_counting(set);
+        if (rc == KC_OK && !counted && len >= (u64)k) {
             // the port links of phase 1 are the largest block of the run and the build buckets of phase 0 (8 W B per slot) are gone
             // by then: obtain the larger of the two now, so that both phases use the same memory.  The links are 16 B per node id,
             // nstride ids per block (the largest block: ~0.64 of a block's slots on uniform data at load 0.5): 0.7 x 16 B per slot is
@@ -168,7 +169,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
             if (rc == KC_OK) rc = kcs_insert_packed(set, codes, brk, low, len, 0);
         }
         if (rc == KC_OK) rc = kcs_refresh_size(set);
-        if (rc == KC_OK && min_frequency > 1) rc = kc_set_filter_min_frequency(set, min_frequency);   // ReadKMersFiltered (parser.h:122-141)
+        if (rc == KC_OK && min_frequency > 1 && !counted) rc = kc_set_filter_min_frequency(set, min_frequency);   // ReadKMersFiltered (parser.h:122-141)
         kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low);
         if (rc == KC_OK && set->size_host == 0) rc = kc_fail(ctx, KC_E_NO_KMERS, "input contains no k-mers");
         if (rc == KC_OK) { n_kmers = set->size_host; dom_us += 1000.0 * ev_ms(ctx->ev[6], ctx->ev[7]); }

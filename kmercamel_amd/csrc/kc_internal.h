@@ -240,6 +240,7 @@ int kcs_pack(kc_ctx *ctx, const void *d_seq, u64 len, u64 **d_codes, u64 **d_brk
 int kcs_reserve(kc_set *set, u64 additional);
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive);
 int kcs_refresh_size(kc_set *set);
+int kcs_build_counted(kc_ctx *ctx, int k, int complements, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int min_count, kc_set **out);   // -z through the LDS counting build
 struct kc_comm;
 int kcs_prepare_dense_sharded(kc_set *set, kc_comm *c);   // the same on a hash-sharded set + one nstride for all ranks (collective)
 int kcs_prepare_dense(kc_set *set);   // dense node ids for phase 1: counts in the empty slots, set->ncount / nstride (no-op when still valid)

@@ -1505,6 +1505,40 @@ int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_
     }
 }
 
+// -z on one GPU: the counted build of the hash-sharded flow (kc_block_build_filter_kernel: occurrences counted in LDS, where the
+// k-mers of a block meet) with a single-rank communicator, turned into an ordinary set -- the whole table is this rank's -- and moved into
+// a table of the survivors' size when the filter left it nearly empty (a table sized for 30x the k-mers it holds makes every later
+// sweep 30x too long).  KC_E_ARG / KC_E_CAPACITY with ctx->err_agreed set: not applicable here (blocks that overflow, geometry): the
+// caller counts with the direct insert instead.
+int kcs_build_counted(kc_ctx *ctx, int k, int complements, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int min_count, kc_set **out) {
+    *out = nullptr;
+    ctx->err_agreed = false;
+    kc_comm *self = nullptr;
+    KC_TRY(kc_comm_create_self(ctx, &self));
+    auto guard = kc_defer([&] { kc_comm_destroy(self); });
+    kc_set *set = nullptr;
+    const u64 occ = len >= (u64)k ? len - k + 1 : 0;
+    KC_TRY(kcs_create_sharded(ctx, self, k, complements, occ, &set));
+    u64 moved = 0;
+    int rc = kcs_build_sharded(set, self, d_codes, d_brk, d_low, len, &moved, min_count);
+    if (rc != KC_OK) { kc_set_destroy(set); return rc; }
+    set->rlo = 0; set->rcap = 0;   // (one rank: its slot range is the table)
+    rc = kcs_refresh_size(set);
+    if (rc == KC_OK && set->size_host && set->size_host * 4 < set->cap) {
+        u64 ncap = set->size_host * 2 + 1024;
+        u64 nnblocks = (ncap + (((u64)1 << set->bshift) - 1)) >> set->bshift;
+        if (nnblocks >= 4096) nnblocks = (nnblocks + 63) / 64 * 64;
+        ncap = nnblocks << set->bshift;
+        u64 *nkeys = nullptr; u32 *nstate = nullptr; u8 *ntags = nullptr;
+        rc = set_alloc_table(set, ncap, &nkeys, &nstate, &ntags);
+        if (rc == KC_OK) rc = kcs_rebuild(set, ncap, nnblocks, nkeys, nstate, ntags, 0);
+        if (rc == KC_OK) rc = kcs_refresh_size(set);
+    }
+    if (rc != KC_OK) { kc_set_destroy(set); return rc; }
+    *out = set;
+    return KC_OK;
+}
+
 int kcs_insert_packed(kc_set *set, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, int case_sensitive) {
     kc_ctx *ctx = set->ctx;
     if (len == 0) return KC_OK;
