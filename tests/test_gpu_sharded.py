@@ -72,7 +72,7 @@ def test_ranks_against_the_oracle_directly(ctx, oracle, golden_dir, tmp_path):
     cases += [(fa1, 31, "bi", 3, None), (fa1, 31, "uni", 2, None), (fa1, 63, "bi", 2, {"KC_RANK_SAMPLED": "0"})]
     fa2 = str(tmp_path / "stress.fa")
     write_fasta(fa2, [r for r in gen.stress_reads(genome_len=25000, n_reads=500, read_len=180, seed=9, n_frac=0.002, lower_frac=0.05) if len(r) >= 63])
-    cases += [(fa2, 23, "bi", 4, {"KC_OVG_MAX": "0"}), (fa2, 31, "bi", 3, {"KC_WAVE_MAX": "0"}), (fa2, 63, "uni", 2, None)]
+    cases += [(fa2, 23, "bi", 4, {"KC_OVG_MAX": "0"}), (fa2, 31, "bi", 3, {"KC_WAVE_MAX": "0"}), (fa2, 63, "uni", 2, None), (fa2, 31, "bi", 2, {"KC_BRANCH_HOST": "1"})]
     fa3 = str(tmp_path / "spn.fa")
     with gzip.open(os.path.join(golden_dir, "spneumoniae.fa.gz"), "rt") as f:
         text = "".join(l.strip() for l in f if not l.startswith(">"))
@@ -105,7 +105,8 @@ def test_ranks_wide_keys_and_branching_reads(ctx, tmp_path, k):
     fa = str(tmp_path / "in.fa")
     write_fasta(fa, recs)
     want = single(ctx, fa, k, True)
-    for world, env in ((2, {"KC_OVG_MAX": "0"}), (3, {"KC_OVG_MAX": "300"}), (2, None)):
+    # (KC_BRANCH_HOST=1: the branch subgraph settled by the host version -- sort + hash maps -- instead of the device matching)
+    for world, env in ((2, {"KC_OVG_MAX": "0"}), (3, {"KC_OVG_MAX": "300"}), (2, None), (3, {"KC_BRANCH_HOST": "1"})):
         got = run_ranks(world, fa, k, "bi", str(tmp_path / "out.npy"), extra_env=env)
         assert np.array_equal(got, want), (world, env)
 

@@ -55,6 +55,7 @@ def main():
                 if rng.random() < 0.3: knobs["KC_SLOT_TEST_SHRINK"] = rng.choice(["2", "9", "1000"])   # slotted exchanges that overflow and repeat
                 if rng.random() < 0.5: knobs["KC_RANK_C"] = rng.choice(["1", "2", "3", "64", "4096"]); knobs["KC_RANK_R"] = rng.choice(["1", "2", "5", "40"])
             if rng.random() < 0.15: knobs["KC_SCATTER_ROLL"] = "1"
+            if rng.random() < 0.25: knobs["KC_BRANCH_HOST"] = "1"   # the branch subgraph settled on the host (the device matching is the default)
             for extra in ([], ["--gpus", str(gpus)]):
                 o = os.path.join(d, "o%d" % len(outs)); m = os.path.join(d, "m%d" % len(outs))
                 for f in (o, m):
