@@ -342,6 +342,8 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
                                                                      int complements, int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters,
                                                                      int chunks) {
     const int lane = threadIdx.x & 63;
+    const int exp_ = chunks >> 16;   // (timing experiments only: 1 no atomics, 2 no stores, 3 neither -- tools/r5_build_ab.py; results are wrong then)
+    chunks &= 0xffff;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 P0 = wave * (u64)chunks * 64;
     if (P0 >= len) return;
@@ -400,6 +402,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
         if (!R.starts) return 0;
         const unsigned long long stop = (R.sm | ~R.vm) >> lane >> 1;   // the run ends before the next start or invalid lane (two shifts: lane 63 shifts by 64 in all)
         const int rl = stop ? __builtin_ctzll(stop) + 1 : 64 - lane;
+        if (exp_ & 1) return (kc_mix64(P0 + (u64)lane) >> 20) % (bs - 64);
         return atomicAdd((ull *)&bcursor[R.blk], (ull)rl);
     };
     // ... the others get the base by shuffle and store their own key
@@ -409,7 +412,8 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
         base = __shfl(base, leader, 64);
         if (R.valid) {
             const u64 at2 = base + (u64)(lane - leader);
-            if (at2 < bs) bucket[(R.blk << set.bshift) + at2] = R.key;
+            if (exp_ & 2) { if (at2 == ~(u64)0) bucket[0] = R.key; }
+            else if (at2 < bs) bucket[(R.blk << set.bshift) + at2] = R.key;
             else overflow = true;   // (the bucket keeps the keys that still fit; the caller re-inserts through the global path)
         }
     };
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const 
 #define KC_MAX_SEG 64
 #define KC_MAX_DYN_LDS (160 * 1024 - 4096)   /* dynamic LDS limit requested for the build kernels (their static LDS is ~1 KB) */
 template <int W, bool IDS = false>
-__global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
+__global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(SetView<W> set, const u64 *__restrict__ bucket, const u64 *__restrict__ bcursor,
                                                               int fresh, u64 *counters, u64 *ovf_list, u64 ovf_cap,
                                                               const u64 *__restrict__ seg_scan, int nseg, int merge_r, int sample_stride,
                                                               u32 *ncount_out = nullptr) {
@@ -542,56 +546,77 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
     // block index is a range reduction of the minimizer hash, so dividing the number of blocks by r maps bucket i to block i / r).
     // sample_stride > 0: count only -- workgroup i inserts scatter bucket i * sample_stride into LDS and adds the number of
     // distinct keys to counters[2] and the bucket's occurrences to counters[3]; nothing is written to the table.
+    // Round 5 (PMC counters of this kernel at 10^9 keys): it is bound by instruction ISSUE -- 986 vector and 1158 scalar instructions per
+    // wave, the scalar ones mostly exec-mask bookkeeping of the divergent probe loop; LDS 32 % busy, HBM at 2.3 TB/s.  Persistent
+    // workgroups that fetch the next block's keys under the write-out of the current one were built and measured: slower (26.6 against
+    // 23.5 ms at 2.5 * 10^9), so a block is a workgroup.
     extern __shared__ u64 kc_blk[];
     __shared__ u64 seg_lo[KC_MAX_SEG], seg_pre[KC_MAX_SEG + 1];
     const u32 bs = 1u << set.bshift;
     u64 *lk = kc_blk;
+    // (wide keys publish a slot through its tag byte while other lanes spin on it: volatile accesses.  The compiler turns those into FLAT
+    // instructions with system-scope bits, each followed by a wait for ALL outstanding memory operations of the wave -- in the write-out
+    // that serialised a wave's rows behind its own global stores.  Single-word keys need no such protocol: `ltp` is the plain LDS pointer,
+    // every access of theirs goes through it; round 5: 28.8 -> see DESIGN.md)
     volatile u8 *lt = reinterpret_cast<volatile u8 *>(kc_blk + (size_t)bs * W);
+    u8 *ltp = reinterpret_cast<u8 *>(kc_blk + (size_t)bs * W);
     __shared__ u32 added_s;
-    const u64 src_blk = sample_stride ? (u64)blockIdx.x * (u64)sample_stride : (u64)blockIdx.x;
-    const u64 base = set.rlo + (src_blk << set.bshift);
     if (merge_r) nseg = merge_r;
+    // single-word keys of a plain bucket: all keys of a thread (8 x 1024 = a whole bucket of 2^13 keys; more are loaded in the loop)
+    // are on their way while the LDS table is set up
+    const bool pf = W == 1 && nseg == 0 && !(fresh & 2);   // (bit 1 of `fresh`: test knob, no prefetch)
+    const bool st16 = !(fresh & 4);                          // (bit 2: test knob, 8-byte stores in the write-out)
+    fresh &= 1;
+    constexpr int NPRE = 8;
+    u64 pre[NPRE];
+#pragma unroll
+    for (int t = 0; t < NPRE; ++t) pre[t] = 0;
+    const u32 nblk = gridDim.x, vb = blockIdx.x;
+    const u64 src_blk = sample_stride ? (u64)vb * (u64)sample_stride : (u64)vb;
+    const u64 base = set.rlo + (src_blk << set.bshift);
+    u64 n_pre = 0;                                           // keys of the block (pf)
+    auto prefetch = [&](u64 n0) {
+        const u64 *bk = bucket + base;
+        // (no branches: a conditional load is a basic block of its own, and the compiler put a wait for ALL outstanding memory operations
+        // in front of each -- eight round trips in a row; the threads beyond the count re-read key 0)
+#pragma unroll
+        for (int t = 0; t < NPRE; ++t) {
+            const u32 j = threadIdx.x + 1024u * (u32)t;
+            pre[t] = bk[j < n0 ? j : 0u];
+        }
+    };
+    if (pf) {
+        n_pre = bcursor[src_blk];
+        if (n_pre > bs) n_pre = bs;
+        prefetch(n_pre);
+    }
     if (threadIdx.x == 0) {
         added_s = 0;
         u64 a = 0;
         for (int q = 0; q < nseg; ++q) {
             u64 lo, hi;
             if (merge_r) {
-                const u64 sb = (u64)blockIdx.x * (u64)merge_r + (u64)q;
+                const u64 sb = (u64)vb * (u64)merge_r + (u64)q;
                 u64 c = bcursor[sb];
                 if (c > bs) c = bs;
                 lo = sb << set.bshift; hi = lo + c;
-            } else { lo = seg_scan[(u64)q * gridDim.x + blockIdx.x]; hi = seg_scan[(u64)q * gridDim.x + blockIdx.x + 1]; }
+            } else { lo = seg_scan[(u64)q * nblk + vb]; hi = seg_scan[(u64)q * nblk + vb + 1]; }
             seg_lo[q] = lo; seg_pre[q] = a; a += hi - lo;
         }
         seg_pre[nseg] = a;
     }
-    // single-word keys of a plain bucket: the first four keys of every thread are on their way while the LDS table is set up
-    // (the block is otherwise one global latency after the other: counts, keys, then the stores)
-    const bool pf = W == 1 && nseg == 0 && !(fresh & 2);   // (bit 1 of `fresh`: test knob, no prefetch)
-    const bool st16 = !(fresh & 4);                          // (bit 2: test knob, 8-byte stores in the write-out)
-    fresh &= 1;
-    u64 pre0 = 0, pre1 = 0, pre2 = 0, pre3 = 0;
-    if (pf) {
-        u64 n0 = bcursor[src_blk];
-        if (n0 > bs) n0 = bs;
-        const u64 *bk = bucket + base;
-        if (threadIdx.x < n0) pre0 = bk[threadIdx.x];
-        if (threadIdx.x + 1024u < n0) pre1 = bk[threadIdx.x + 1024u];
-        if (threadIdx.x + 2048u < n0) pre2 = bk[threadIdx.x + 2048u];
-        if (threadIdx.x + 3072u < n0) pre3 = bk[threadIdx.x + 3072u];
-    }
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
-        reinterpret_cast<u64 *>(const_cast<u8 *>(lt))[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
-    __syncthreads();
+        reinterpret_cast<u64 *>(ltp)[i] = fresh ? 0 : reinterpret_cast<const u64 *>(set.tags + base)[i];
+    if (!fresh) __syncthreads();   // (a fresh block's keys do not look at the tags)
     for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) {
         // keys of empty slots are undefined in the wide-key table (their state says so): only the claim word matters here
-        const bool occupied = !fresh && lt[i / W] != 0;
+        const bool occupied = !fresh && ltp[i / W] != 0;
         lk[i] = occupied ? set.keys[base * W + i] : ~(u64)0;
     }
     __syncthreads();
     u64 n;
     if (nseg) n = seg_pre[nseg];
+    else if (pf) n = n_pre;
     else { n = bcursor[src_blk]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
     u32 added = 0;
     int it = 0;
@@ -603,30 +628,61 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
             while (q + 1 < nseg && j >= seg_pre[q + 1]) ++q;
             src = seg_lo[q] + (j - seg_pre[q]);
         }
-        if (pf && it < 4) key.w[0] = it == 0 ? pre0 : (it == 1 ? pre1 : (it == 2 ? pre2 : pre3));
-        else
+        if (pf && it < NPRE) {
+            u64 v = pre[0];
+#pragma unroll
+            for (int t = 1; t < NPRE; ++t) v = it == t ? pre[t] : v;
+            key.w[0] = v;
+        } else
             for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
         const u64 top = key.w[W - 1];
         u32 off; u8 tag;
         set_place_local(set, key, &off, &tag);
         bool done = false;
         u32 p = 0;
+        if constexpr (W == 1) {
+            // Straight-line probe rounds (round 5): the kernel is bound by instruction issue, not by LDS or HBM (PMC: 986 vector + 1158
+            // scalar instructions per wave, the scalar ones mostly exec-mask bookkeeping of the divergent loop below; LDS 32 % busy).
+            // Every lane of the wave issues the compare-and-swap in every round: a lane that is through keeps issuing it at its last slot,
+            // which holds a key by then -- its own, its duplicate, or the key in the way where it gave up -- so the swap fails and changes
+            // nothing (no per-lane selects, no exec-mask bookkeeping); the wave leaves when no lane moves on, and the tag is written once,
+            // behind the rounds.
+            u32 sl = off;
+            const u32 lim = off + set.local_probes;
+            bool took = false, gave_up = false, adv;
+            do {
+                const u64 cur = atomicCAS((ull *)&lk[sl], ~0ULL, (ull)top);
+                took = took || cur == ~(u64)0;
+                const bool miss = cur != ~(u64)0 && cur != top;   // another key lives here
+                adv = miss && sl + 1 < lim;
+                gave_up = gave_up || (miss && !adv);
+                sl += adv ? 1u : 0u;
+            } while (__ballot(adv));
+            if (took) { ltp[sl] = tag; ++added; }
+            done = !gave_up;
+        } else
         while (p < set.local_probes && !done) {
             const u32 s = off + p;
             u64 cur = lk[(size_t)s * W + W - 1];
             if (cur == ~(u64)0) cur = atomicCAS((ull *)&lk[(size_t)s * W + W - 1], ~0ULL, (ull)top);
             if (cur == ~(u64)0) {   // claimed: publish
-                for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                lt[s] = tag;
+                if constexpr (W == 1) ltp[s] = tag;   // (nobody reads a tag before the barrier behind the loop)
+                else {
+                    for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lt[s] = tag;
+                }
                 ++added;
                 done = true;
             } else if (cur == top) {
-                if (W > 1 && lt[s] == 0) continue;   // being published by another lane: look again (p unchanged)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                bool eq = true;
-                for (int w = 0; w < W - 1; ++w) eq = eq && (lk[(size_t)s * W + w] == key.w[w]);
-                if (eq) done = true; else ++p;
+                if constexpr (W == 1) done = true;
+                else {
+                    if (lt[s] == 0) continue;   // being published by another lane: look again (p unchanged)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    bool eq = true;
+                    for (int w = 0; w < W - 1; ++w) eq = eq && (lk[(size_t)s * W + w] == key.w[w]);
+                    if (eq) done = true; else ++p;
+                }
             } else ++p;
         }
         if (!done && !sample_stride) {   // block-local run exhausted: the global insert (second home) takes it after all blocks are written
@@ -652,7 +708,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         // barrier, no waiting for one another -- the block's other workgroup on the CU is in its insert phase meanwhile)
         u32 at = 0;
         {
-            const u64 *lt64 = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt));
+            const u64 *lt64 = reinterpret_cast<const u64 *>(ltp);
             const u32 words_before = wv * per_wave / 8;
             for (u32 i = lane; i < words_before; i += 64) at += (u32)__popcll(lt64[i] & 0x8080808080808080ULL);   // (tag bytes of occupied slots have bit 7 set)
 #pragma unroll
@@ -662,7 +718,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
             // two neighbouring slots per lane: 16-byte LDS loads and 16-byte stores (1 KB per wave instruction)
             for (u32 r = 0; r < per_wave / 128; ++r) {
                 const u32 sl = wv * per_wave + r * 128 + 2 * lane;
-                const u32 tg = *reinterpret_cast<const volatile unsigned short *>(lt + sl);
+                const u32 tg = *reinterpret_cast<const unsigned short *>(ltp + sl);
                 const bool occ0 = (tg & 0xffu) != 0, occ1 = (tg >> 8) != 0;
                 const unsigned long long mk0 = __ballot(occ0), mk1 = __ballot(occ1);
                 const u64 cnt0 = (u64)(at + (u32)__popcll(mk0 & ltm) + (u32)__popcll(mk1 & ltm)), cnt1 = cnt0 + (occ0 ? 1 : 0);
@@ -676,7 +732,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
         } else
         for (u32 r = 0; r < rows; ++r) {
             const u32 off = r * 64 + lane, sl = wv * per_wave + off;
-            const bool in = off < per_wave, occ = in && lt[sl] != 0;
+            const bool in = off < per_wave, occ = in && ltp[sl] != 0;
             const unsigned long long mk = __ballot(occ);
             if (in) {
                 const u64 cnt = (u64)(at + (u32)__popcll(mk & ltm));
@@ -691,16 +747,16 @@ __global__ void __launch_bounds__(1024) kc_block_build_kernel(SetView<W> set, co
             at += (u32)__popcll(mk);
         }
         for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
-            reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
-        if (threadIdx.x == blockDim.x - 64) ncount_out[blockIdx.x] = at;   // (the last wave ends on the block's total; the largest block: kc_max_u32_kernel)
+            reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(ltp)[i];
+        if (threadIdx.x == blockDim.x - 64) ncount_out[vb] = at;   // (the last wave ends on the block's total; the largest block: kc_max_u32_kernel)
     } else {
         for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
         for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
-            reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
+            reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(ltp)[i];
         if (W > 1)
-            for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
+            for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = ltp[i] ? KC_ST_FULL : KC_ST_EMPTY;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at the end of the range
+    if (vb == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = ltp[threadIdx.x];   // mirror for window loads that wrap at the end of the range
     if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
 }
 
@@ -1125,8 +1181,10 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             int chunks = 16;   // (even)
             if (const char *e = getenv("KC_SCATTER_CHUNKS")) { const int v = atoi(e); if (v >= 2 && v <= 4096) chunks = v & ~1; }   // tuning knob
             const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+            int exp_ = 0;
+            if (const char *e = getenv("KC_SCATTER_EXP")) exp_ = atoi(e) & 3;   // (timing experiments: see the kernel)
             KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
-                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks);
+                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks | (exp_ << 16));
         }
     }
     if constexpr (W > 1) {
