@@ -429,6 +429,152 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
     if (overflow) atomicExch((ull *)&counters[3], 1ULL);
 }
 
+// ---- round 5: the wave-cooperative scatter again, leaner.  Measured on the form above at 2.5 * 10^9 31-mers (tools/r5_build_ab.sh,
+// KC_SCATTER_EXP): 24.5 ms as it is, 24.0 without the reservations, 20.5 without the stores, 18.2 with neither -- the kernel is its own
+// arithmetic and the waits for its per-lane loads (PMC: 174 vector + 76 scalar instructions per chunk of 64 positions, waves waiting 74 % of
+// their time: four to seven dependent global loads per chunk for words that are the same for the whole wave).  Here
+//  * a chunk is exactly one block of the packed sequence (64 positions = two code words, one break word, one lower-case word), and
+//    everything that is the same for the 64 lanes is scalar: the break and lower-case words are scalar loads, and WHICH lanes hold a
+//    valid k-mer / m-mer is mask arithmetic on them in the scalar unit (a break smeared over the k - 1 positions behind it), handed to the
+//    lanes as a lane mask -- no per-lane bit extraction, no per-lane position tests;
+//  * a lane takes its k-mer out of ONE 16-byte load (the two code words around it; lanes of one half of the wave read the same 16
+//    bytes), issued a whole trip ahead; the m-mer that ends at a lane is the low word of its k-mer;
+//  * reservations as before (the first lane of a run of equal blocks reserves for the run, two chunks in flight).
+// Same buckets as the form above, key for key (tests/test_gpu_parity.py compares the sets; KC_SCATTER_V1=1 runs the old form).
+struct KcCover { u64 hi, lo; };   // a 128-bit position mask of two neighbouring blocks: hi = this chunk's 64 positions, lo = the 64 before
+__device__ __forceinline__ KcCover kc_cover_shl(KcCover x, int d) {   // d in [0, 63]
+    KcCover r;
+    r.hi = d ? (x.hi << d) | (x.lo >> (64 - d)) : x.hi;
+    r.lo = x.lo << d;
+    return r;
+}
+// OR of x shifted up by 0 .. w - 1 (w in [1, 32]): bit j of the result = some bit of x among the w positions ending at j
+__device__ __forceinline__ KcCover kc_cover_smear(KcCover x, int w) {
+    KcCover t = x, acc{0, 0};     // t = smear of width 2^j
+    int done = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        if (w & (1 << j)) { const KcCover s = kc_cover_shl(t, done); acc.hi |= s.hi; acc.lo |= s.lo; done += 1 << j; }
+        const KcCover u = kc_cover_shl(t, 1 << j);
+        t.hi |= u.hi; t.lo |= u.lo;
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
+                                                                      int complements, int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters,
+                                                                      int chunks) {
+    const int lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane((u32)((((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
+    const u64 nblk = (len + 63) >> 6;                      // blocks of the packed sequence (bytes behind `len` in the last one are breaks)
+    const u64 T0 = (u64)wave * (u64)chunks;                // this wave's first block
+    if (T0 >= nblk) return;
+    const int m = set.m, win = k - m - 1;
+    const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
+    const u64 maskk = k >= 32 ? ~(u64)0 : (((u64)1 << (2 * k)) - 1);
+    const u32 bs = 1u << set.bshift;
+    const u32 nblocks = (u32)set.nblocks;
+    const int half = lane >> 5, sh = 2 * (31 - (lane & 31));
+    const unsigned long long lane_le = ((unsigned long long)2 << lane) - 1;   // lanes at or below this one
+    u32 a1p = ~0u, a2p = ~0u, a4p = ~0u, a8p = ~0u;
+    bool overflow = false;
+    // the two code words a lane's k-mer lies in (block t: lanes 0..31 -> words 2t-1, 2t; lanes 32..63 -> 2t, 2t+1)
+    auto load_codes = [&](u64 t) -> ulonglong2 {
+        ulonglong2 v;
+        if (t == 0) {   // (wave-uniform: no word in front of the sequence; k-mers of block 0 that are valid lie in the second word of their pair)
+            v.x = half ? codes[0] : 0;
+            v.y = half ? codes[1] : codes[0];
+        } else {
+            const u64 *src = codes + 2 * t - 1 + half;
+            __builtin_memcpy(&v, src, 16);   // (8-byte aligned)
+        }
+        return v;
+    };
+    struct Chunk { u64 key; u32 blk; unsigned long long vm, sm; bool valid, starts; };
+    // one chunk: hashes, sliding minimum, this lane's canonical k-mer and block, the wave's run structure.  only_hash: the chunk in
+    // front of the wave's first one, for the minima of its first lanes
+    auto compute = [&](u64 t, ulonglong2 cw, bool only_hash) -> Chunk {
+        Chunk R{0, ~0u, 0, 0, false, false};
+        // validity masks (scalar): a position is fine for a k-mer (m-mer) when no break lies among the k (m) positions ending at it
+        KcCover B;
+        B.hi = brk[t];
+        B.lo = t ? brk[t - 1] : ~(u64)0;
+        const u64 okm = ~kc_cover_smear(B, m).hi;
+        u64 okk = ~kc_cover_smear(B, k).hi;
+        if (case_sensitive) {   // the k-mer's FIRST base must be upper case (parser.h:41-42)
+            KcCover L;
+            L.hi = low[t];
+            L.lo = t ? low[t - 1] : 0;
+            okk &= ~kc_cover_shl(L, k - 1).hi;
+        }
+        // the 32 bases ending at this lane, right-aligned
+        const u64 v = (cw.y >> sh) | ((cw.x << 1) << (63 - sh));
+        const u32 mm = (u32)v & maskm;
+        u32 r = __brev(~mm);
+        r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+        r >>= 32 - 2 * m;
+        const u32 hh = kc_mmer_hash(mm, r);
+        const u32 a1 = __builtin_amdgcn_inverse_ballot_w64(okm) ? hh : ~0u;
+        // sliding minimum over the win lanes before this one
+        u32 tt = kc_halo_get(a1p, a1, lane - 1); const u32 a2 = a1 < tt ? a1 : tt;
+        tt = kc_halo_get(a2p, a2, lane - 2); const u32 a4 = a2 < tt ? a2 : tt;
+        tt = kc_halo_get(a4p, a4, lane - 4); const u32 a8 = a4 < tt ? a4 : tt;
+        u32 pm = ~0u;
+        int at = lane - 1;
+        if (win & 8) { tt = kc_halo_get(a8p, a8, at); pm = tt < pm ? tt : pm; at -= 8; }
+        if (win & 4) { tt = kc_halo_get(a4p, a4, at); pm = tt < pm ? tt : pm; at -= 4; }
+        if (win & 2) { tt = kc_halo_get(a2p, a2, at); pm = tt < pm ? tt : pm; at -= 2; }
+        if (win & 1) { tt = kc_halo_get(a1p, a1, at); pm = tt < pm ? tt : pm; }
+        a1p = a1; a2p = a2; a4p = a4; a8p = a8;
+        if (only_hash) return R;
+        R.valid = __builtin_amdgcn_inverse_ballot_w64(okk);
+        R.vm = okk;
+        Key<1> f; f.w[0] = v & maskk;
+        R.key = f.w[0];
+        if (complements) { const Key<1> rc = key_rc(f, k); if (rc.w[0] < R.key) R.key = rc.w[0]; }
+        // block of the minimizer (set_block_home's block part)
+        u32 u = pm * 0x85EBCA6Bu; u ^= u >> 16; u *= 0xC2B2AE35u;
+        R.blk = R.valid ? __umulhi(u, nblocks) : ~0u;
+        const u32 blk_before = (u32)__builtin_amdgcn_update_dpp((int)~0u, (int)R.blk, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        R.starts = R.valid && (lane == 0 || blk_before != R.blk);
+        R.sm = __ballot(R.starts);
+        return R;
+    };
+    auto reserve = [&](const Chunk &R) -> u32 {
+        if (!R.starts) return 0;
+        const unsigned long long stop = (R.sm | ~R.vm) >> lane >> 1;   // the run ends before the next start or invalid lane
+        const int rl = stop ? __builtin_ctzll(stop) + 1 : 64 - lane;
+        const u64 b = atomicAdd((ull *)&bcursor[R.blk], (ull)rl);
+        return b > 0xffffffffULL ? 0xffffffffu : (u32)b;               // (anything from the block size on is an overflow)
+    };
+    auto commit = [&](const Chunk &R, u32 base) {
+        const unsigned long long below = R.sm & lane_le;
+        const int leader = below ? 63 - __builtin_clzll(below) : 0;
+        base = (u32)__shfl((int)base, leader, 64);
+        if (R.valid) {
+            const u64 at2 = (u64)base + (u64)(lane - leader);
+            if (at2 < bs) bucket[((u64)R.blk << set.bshift) + at2] = R.key;
+            else overflow = true;   // (the bucket keeps the keys that still fit; the caller re-inserts through the global path)
+        }
+    };
+    if (T0) (void)compute(T0 - 1, load_codes(T0 - 1), true);
+    u64 tend = T0 + (u64)chunks;
+    if (tend > nblk) tend = nblk;
+    ulonglong2 ca = load_codes(T0), cb = load_codes(T0 + 1 < tend ? T0 + 1 : T0);
+    // two chunks per trip: both reservations are in flight before either is waited for; the next trip's code words are on their way
+    for (u64 t = T0; t < tend; t += 2) {
+        const bool two = t + 1 < tend;
+        const ulonglong2 na = load_codes(t + 2 < tend ? t + 2 : t), nb = load_codes(t + 3 < tend ? t + 3 : t);
+        const Chunk A = compute(t, ca, false);
+        Chunk Bc{0, ~0u, 0, 0, false, false};
+        if (two) Bc = compute(t + 1, cb, false);
+        const u32 ba = reserve(A), bb = reserve(Bc);
+        commit(A, ba);
+        commit(Bc, bb);
+        ca = na; cb = nb;
+    }
+    if (overflow) atomicExch((ull *)&counters[3], 1ULL);
+}
+
 // The same for wide keys (k up to 127: the window of the sliding minimum has up to k - 17 = 110 positions, i.e. it reaches two
 // chunks back; the rolling form keeps 2 * 110 hashes per thread in LDS there and runs 64 threads per workgroup).
 __device__ __forceinline__ bool kc_any_break_long(const u64 *__restrict__ brk, u64 s, int n) {
@@ -1183,8 +1329,12 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
             int exp_ = 0;
             if (const char *e = getenv("KC_SCATTER_EXP")) exp_ = atoi(e) & 3;   // (timing experiments: see the kernel)
+            if (getenv("KC_SCATTER_V1") || exp_)
             KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
                                case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks | (exp_ << 16));
+            else
+            KC_LAUNCH(kc_bucket_scatter_wave2_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks);
         }
     }
     if constexpr (W > 1) {
@@ -1437,7 +1587,11 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
             if (wave_form) {
                 const int chunks = 16;
                 const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+                if (getenv("KC_SCATTER_V1"))
                 KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+                                   0, kc_view_raw<1>(set), fixed, bcount, set->counters, chunks);
+                else
+                KC_LAUNCH(kc_bucket_scatter_wave2_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
                                    0, kc_view_raw<1>(set), fixed, bcount, set->counters, chunks);
             }
         }

@@ -10,7 +10,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/gpurun_out/r5/bab/**/*kernel_trace.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-for name in ("kc_bucket_scatter_wave_kernel", "kc_block_build_kernel<1, true>", "kc_block_build_kernel<1, false>", "kc_pack2bit"):
+for name in ("kc_bucket_scatter_wave_kernel", "kc_bucket_scatter_wave2_kernel", "kc_block_build_kernel<1, true>", "kc_block_build_kernel<1, false>", "kc_pack2bit"):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if name in r["Kernel_Name"]]
     print(name, " ".join("%.2f" % x for x in d))
 PY
