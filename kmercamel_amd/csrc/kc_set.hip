@@ -921,7 +921,8 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
     const u32 bs = 1u << set.bshift;
     u64 *lk = kc_blk;
     volatile u8 *lt = reinterpret_cast<volatile u8 *>(kc_blk + (size_t)bs * W);
-    u32 *cnt = reinterpret_cast<u32 *>(const_cast<u8 *>(lt) + bs);   // bs / 2 words
+    u8 *ltp = reinterpret_cast<u8 *>(kc_blk + (size_t)bs * W);
+    u32 *cnt = reinterpret_cast<u32 *>(ltp + bs);   // bs / 2 words
     const u64 base = set.rlo + ((u64)blockIdx.x << set.bshift);
     if (threadIdx.x == 0) {
         added_s = 0;
@@ -933,7 +934,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
         seg_pre[nseg] = a;
     }
     auto clear = [&]() {
-        for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x) reinterpret_cast<u64 *>(const_cast<u8 *>(lt))[i] = 0;
+        for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x) reinterpret_cast<u64 *>(ltp)[i] = 0;
         for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) lk[i] = ~(u64)0;
     };
     clear();
@@ -957,12 +958,16 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
             u64 cur = lk[(size_t)s * W + W - 1];
             if (cur == ~(u64)0) cur = atomicCAS((ull *)&lk[(size_t)s * W + W - 1], ~0ULL, (ull)top);
             if (cur == ~(u64)0) {   // claimed: publish
-                for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                lt[s] = tag;
+                if constexpr (W == 1) ltp[s] = tag;   // (single-word keys: nobody waits on a tag; plain LDS store, see kc_block_build_kernel)
+                else {
+                    for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lt[s] = tag;
+                }
                 *claimed = true;
                 return s;
             } else if (cur == top) {
+                if constexpr (W == 1) return s;
                 if (W > 1 && lt[s] == 0) continue;   // being published by another lane: look again (p unchanged)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 bool eq = true;
@@ -984,7 +989,7 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
         if (s == 0xffffu) { lost = true; continue; }
         u32 *c = &cnt[s >> 1];
         const u32 sh = 16u * (s & 1u);
-        if (((*reinterpret_cast<volatile u32 *>(c) >> sh) & 0xffffu) < 256u) atomicAdd(c, 1u << sh);
+        if (((__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xffffu) < 256u) atomicAdd(c, 1u << sh);
     }
     if (lost) atomicExch((ull *)&counters[3], 1ULL);
     __syncthreads();
@@ -1008,10 +1013,10 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
     __syncthreads();
     for (u32 i = threadIdx.x; i < bs * W; i += blockDim.x) set.keys[base * W + i] = lk[i];
     for (u32 i = threadIdx.x; i < bs / 8; i += blockDim.x)
-        reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(const_cast<u8 *>(lt))[i];
+        reinterpret_cast<u64 *>(set.tags + base)[i] = reinterpret_cast<const u64 *>(ltp)[i];
     if (W > 1)
-        for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = lt[i] ? KC_ST_FULL : KC_ST_EMPTY;
-    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = lt[threadIdx.x];   // mirror for window loads that wrap at the end of the range
+        for (u32 i = threadIdx.x; i < bs; i += blockDim.x) set.state[base + i] = ltp[i] ? KC_ST_FULL : KC_ST_EMPTY;
+    if (blockIdx.x == 0 && threadIdx.x < 8) set.tags[set.rlo + set.rcap + threadIdx.x] = ltp[threadIdx.x];   // mirror for window loads that wrap at the end of the range
     if (threadIdx.x == 0 && added_s) atomicAdd((ull *)&counters[0], (ull)added_s);
 }
 

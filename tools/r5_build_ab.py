@@ -26,7 +26,8 @@ for v in variants:
     for a, b in env.items(): os.environ[a] = b
     ts = []
     size = None
-    for i in range(3):
+    for i in range(int(os.environ.get("AB_REPS", "3"))):
+        if os.environ.get("AB_SLEEP"): time.sleep(float(os.environ["AB_SLEEP"]))   # (an idle device runs the scatter faster: see DESIGN.md)
         s = kc.KmerSet(ctx, k, True, capacity_hint=len(seq))
         torch.cuda.synchronize()
         t0 = time.time()
