@@ -197,17 +197,51 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(const u64 *__restrict__ l
             if ((m >> j) & 1) heads[pos++] = (n0 << 1) + (u64)j;
 }
 
+#define KC_WALK_CLASSES 4
+__device__ __forceinline__ u32 kc_walk_class(u64 head) { return (u32)(kc_mix64(head) >> 20) & (KC_WALK_CLASSES - 1); }
+// the heads dealt into their classes: out[c * n ...] = the heads of class c (any order), counts[c] of them
+__global__ void __launch_bounds__(256) kc_heads_by_class_kernel(const u64 *__restrict__ heads, u64 n, u64 *out, u64 *counts) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = t < n;
+    const u64 h = in ? heads[t] : 0;
+    const u32 c = in ? kc_walk_class(h) : KC_WALK_CLASSES;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (u32 q = 0; q < KC_WALK_CLASSES; ++q) {
+        const unsigned long long m = __ballot(c == q);
+        if (!m) continue;
+        const int leader = __builtin_ctzll(m);
+        u64 base = 0;
+        if (lane == leader) base = atomicAdd((ull *)&counts[q], (ull)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (c == q) out[(u64)q * n + base + (u64)__popcll(m & (((unsigned long long)1 << lane) - 1))] = h;
+    }
+}
+#define LK_WALKED (1ull << 62)          /* on a dead port: the chain that ends here was walked from its other end (kc_walk_measure_kernel) */
+#define KC_STREAM_TURNED (1ull << 63)   /* chain_stream: the recording runs from the chain's LAST k-mer: the emit writes its reverse complement */
 template <int W, bool MARK, bool REC, bool FRAG = false>
 __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
                                                               const u64 *__restrict__ heads, u64 nheads, u8 *visited,
                                                               u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit, KcRec rec,
-                                                              KcFrag frag = KcFrag{nullptr, nullptr, 0, 0}) {
+                                                              KcFrag frag = KcFrag{nullptr, nullptr, 0, 0}, u64 *link_marks = nullptr, int cls_pass = 0,
+                                                              u64 t0 = 0, u64 nheads_all = 0) {
     // limit: give up (cursor[7] = 1) on a chain longer than this; the caller then switches to the segment-parallel path
     // Nodes are dense ids.  The two places that need a KEY -- the chain's two end k-mers -- find its slot in the word of the dead
     // port there: the head's entry port, and the exit port the walk ends on.
+    // link_marks != nullptr (bidirectional sets, round 5): ONE WALK PER CHAIN where possible.  Both ends of a chain are heads, and a walk
+    // reads the whole chain's link words -- the kernel moves 130 GB at HBM speed for 2.5 * 10^9 k-mers, half of it for the walks whose
+    // recording is thrown away because the other end has the smaller key.  The heads are dealt into KC_WALK_CLASSES classes by a hash of
+    // their id and the kernel runs once per class: a walk whose far end belongs to a LATER class marks that end's dead port (LK_WALKED in
+    // link_marks = the link words) and the far end never starts; it keeps its recording whichever end has the smaller key, and says so
+    // (bit 63 of chain_stream: the emit turns the recording round).  Two ends of the same class both walk, as before: 1 + 1 / classes
+    // walks per chain.  `heads` is then the list of ONE class (kc_heads_by_class_kernel: full waves), t0 its offset among all
+    // nheads_all heads -- walk numbers, i.e. first chunks, stay unique over the launches.
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nheads) return;
     u64 h = heads[t];
+    if (link_marks && cls_pass && (link_marks[h] & LK_WALKED)) return;   // the chain was walked from its other end
+    t += t0;
+    if (!nheads_all) nheads_all = nheads;
     u64 cur = h >> 1;
     int o = (int)(h & 1), co = o;
     u64 len = 1;
@@ -222,7 +256,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
             chunk = first_chunk = (u32)t;
             wi = 0;
         } else if (wi == KC_CHUNK_WORDS) {
-            const u64 nc = nheads + atomicAdd((ull *)rec.pool_cursor, 1ULL);
+            const u64 nc = nheads_all + atomicAdd((ull *)rec.pool_cursor, 1ULL);
             if (nc >= rec.pool_cap) { rec_ok = false; return; }
             rec.chunk_next[chunk] = (u32)nc;
             chunk = (u32)nc;
@@ -296,8 +330,18 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     // here w is the word of the port the walk ends on: dead, carrying the slot of the tail k-mer (as the head's entry port does)
     const u64 hslot = LK_SLOT(link[h]), tslot = LK_SLOT(w);
     Key<W> hk = set_key_at(set, hslot);
-    bool winner = true;
-    if (complements) winner = (len == 1) ? (o == 0) : key_lt(hk, set_key_at(set, tslot));
+    bool winner = true, turned = false;
+    if (complements) {
+        const Key<W> tk = set_key_at(set, tslot);
+        winner = (len == 1) ? (o == 0) : key_lt(hk, tk);
+        const u64 far = (cur << 1) | (u64)(co == 0 ? 1 : 0);   // the dead port the walk ended on = the head at the other end
+        if (link_marks && kc_walk_class(far) != (u32)cls_pass) {
+            // (a later class: an earlier one would have marked this head) -- the only walk of this chain
+            link_marks[far] = w | LK_WALKED;
+            if (!winner) { turned = true; hk = tk; }
+            winner = true;
+        }
+    }
     if (!winner) return;
     if (REC) {
         if (nacc && rec_ok) flush_word(acc << (64 - 2 * nacc));
@@ -308,7 +352,7 @@ __global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, co
     chain_head[pos] = h;
     chain_len[pos] = len;
     for (int i = 0; i < W; ++i) chain_key[pos * W + i] = hk.w[i];
-    if (REC) { rec.chain_stream[pos] = first_chunk; rec.chain_tail[pos] = (tslot << 1) | (u64)co; }   // (the tail by SLOT: the stream emit only needs its key)
+    if (REC) { rec.chain_stream[pos] = (u64)first_chunk | (turned ? KC_STREAM_TURNED : 0); rec.chain_tail[pos] = (tslot << 1) | (u64)co; }   // (the tail by SLOT: the stream emit only needs its key)
 }
 
 template <bool FILL>
@@ -387,12 +431,52 @@ __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, con
     if (t >= n) return;
     const u64 p = perm[t];
     const u64 h = chain_head[p], len = chain_len[p], tail = chain_tail[p];
+    const bool turned = (chain_stream[p] & KC_STREAM_TURNED) != 0;
     Key<W> kx = set_key_at(set, LK_SLOT(link[h]));   // (the head's entry port is dead: its word carries the slot; the tail is listed by slot)
     if (h & 1) kx = key_rc(kx, k);
-    for (int i = 0; i < W; ++i) firstK[t * W + i] = kx.w[i];
     Key<W> kl = set_key_at(set, tail >> 1);
     if (tail & 1) kl = key_rc(kl, k);
-    for (int i = 0; i < W; ++i) lastK[t * W + i] = kl.w[i];
+    {
+        const Key<W> fk = turned ? key_rc(kl, k) : kx, lk = turned ? key_rc(kx, k) : kl;
+        for (int i = 0; i < W; ++i) { firstK[t * W + i] = fk.w[i]; lastK[t * W + i] = lk.w[i]; }
+    }
+    u32 chunk = (u32)chain_stream[p];
+    u64 left = len - 1;
+    int wi = 0;
+    if (turned) {
+        // The recording runs from the chain's last k-mer to its first: the simplitig is the reverse complement of (head key, recorded
+        // bases).  The groups are taken in recording order, each turned round, and laid down from the END of the simplitig's words
+        // towards their start; the last word is filled from the top like everywhere (so the run starts with its unused low bases).
+        const u64 L = (u64)k + len - 1;
+        const u64 w0 = woff[t];
+        u64 wcur = w0 + ((L - 1) >> 5);
+        if ((L & 31) == 0) words[w0 + (L >> 5)] = 0;       // (the forward form ends every simplitig on a pending word, empty or not)
+        u64 acc = 0;
+        int nacc = 31 - (int)((L - 1) & 31);               // low bases of the last word that stay empty
+        auto put = [&](u64 bits, int nb) {                  // nb (1..32) bases right-aligned in `bits`, in recording order
+            const u64 g = kc_rc_word(bits << (64 - 2 * nb)) & (nb == 32 ? ~(u64)0 : (((u64)1 << (2 * nb)) - 1));   // turned round, right-aligned
+            const int room = 32 - nacc;
+            if (nb < room) { acc |= g << (2 * nacc); nacc += nb; return; }
+            words[wcur--] = room == 32 ? g : (acc | (g << (2 * nacc)));   // the LAST `room` bases of g complete the word
+            const int rest = nb - room;
+            acc = rest ? (g >> (2 * room)) : 0;
+            nacc = rest;
+        };
+        for (int i = 0; i < k; i += 32) {                   // the head key, 32 bases at a time
+            const int nb = k - i >= 32 ? 32 : k - i;
+            u64 bits = 0;
+            for (int j = 0; j < nb; ++j) bits = (bits << 2) | key_at(kx, k, i + j);
+            put(bits, nb);
+        }
+        while (left) {
+            if (wi == KC_CHUNK_WORDS) { chunk = chunk_next[chunk]; wi = 0; }
+            const u64 sw = pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++];
+            const int nb = left >= 32 ? 32 : (int)left;      // valid bases in sw (left-aligned)
+            left -= (u64)nb;
+            put(sw >> (64 - 2 * nb), nb);
+        }
+        return;                                              // (padding + L bases = whole words: nothing is pending)
+    }
     u64 wp = woff[t], acc = 0;
     int nacc = 0;
     for (int i = 0; i < k; ++i) {
@@ -400,9 +484,6 @@ __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, con
         if (++nacc == 32) { words[wp++] = acc; acc = 0; nacc = 0; }
     }
     // the remaining len-1 bases: whole recorded words, shifted by the nacc bases already pending
-    u32 chunk = (u32)chain_stream[p];
-    u64 left = len - 1;
-    int wi = 0;
     while (left) {
         if (wi == KC_CHUNK_WORDS) { chunk = chunk_next[chunk]; wi = 0; }
         const u64 sw = pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++];
@@ -1037,6 +1118,28 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             KC_LAUNCH((kc_frag_contract_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds, ctx->stream, sv, link, compl_, fpool, pool_cap, fcur, fbase,
                                flog, log_cap, fcur + 64 * 16, fblog);
             const KcFrag fr{fpool, fbase, 0, 0};
+            // bidirectional sets: one launch per class of heads, so that most chains are walked from one end only (see the kernel);
+            // KC_WALK_BOTH=1: every head walks, as before round 5
+            if (compl_ && !getenv("KC_WALK_BOTH")) {
+                u64 *hcls = nullptr, *hcnt = nullptr;
+                KC_TRY(scope.alloc(&hcls, (u64)KC_WALK_CLASSES * nheads));
+                KC_TRY(scope.alloc(&hcnt, KC_WALK_CLASSES));
+                KC_HIP(ctx, hipMemsetAsync(hcnt, 0, KC_WALK_CLASSES * 8, ctx->stream));
+                KC_LAUNCH(kc_heads_by_class_kernel, dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, (const u64 *)heads, nheads, hcls, hcnt);
+                u64 hn[KC_WALK_CLASSES];
+                KC_HIP(ctx, hipMemcpyAsync(hn, hcnt, sizeof hn, hipMemcpyDeviceToHost, ctx->stream));
+                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                u64 t0 = 0;
+                for (int cp = 0; cp < KC_WALK_CLASSES; ++cp) {
+                    if (hn[cp])
+                        KC_LAUNCH((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(hn[cp], 256)), dim3(256), 0, ctx->stream, sv,
+                                           (const u64 *)link, compl_, (const u64 *)(hcls + (u64)cp * nheads), hn[cp], (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
+                                           KC_CHAIN_LIMIT, rec, fr, link, cp, t0, nheads);
+                    t0 += hn[cp];
+                }
+                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (hcls belongs to this block)
+                scope.release(hcls); scope.release(hcnt);
+            } else
             KC_LAUNCH((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, sv,
                                (const u64 *)link, compl_, (const u64 *)heads, nheads, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                KC_CHAIN_LIMIT, rec, fr);
