@@ -199,23 +199,33 @@ __global__ void __launch_bounds__(256) kc_heads_kernel(const u64 *__restrict__ l
 
 #define KC_WALK_CLASSES 4
 __device__ __forceinline__ u32 kc_walk_class(u64 head) { return (u32)(kc_mix64(head) >> 20) & (KC_WALK_CLASSES - 1); }
-// the heads dealt into their classes: out[c * n ...] = the heads of class c (any order), counts[c] of them
-__global__ void __launch_bounds__(256) kc_heads_by_class_kernel(const u64 *__restrict__ heads, u64 n, u64 *out, u64 *counts) {
+// the heads dealt into their classes: out[c * n ...] = the heads of class c (any order), counts[c] of them.  One reservation per class
+// and WORKGROUP of 1024 (a reservation per wave was 3.8 ms of same-address atomics for 5 * 10^6 heads)
+__global__ void __launch_bounds__(1024) kc_heads_by_class_kernel(const u64 *__restrict__ heads, u64 n, u64 *out, u64 *counts) {
+    __shared__ u32 wg_cnt[KC_WALK_CLASSES];
+    __shared__ u64 wg_base[KC_WALK_CLASSES];
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = t < n;
     const u64 h = in ? heads[t] : 0;
     const u32 c = in ? kc_walk_class(h) : KC_WALK_CLASSES;
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x < KC_WALK_CLASSES) wg_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    u32 mine = 0;   // this lane's place among the workgroup's heads of its class
 #pragma unroll
     for (u32 q = 0; q < KC_WALK_CLASSES; ++q) {
         const unsigned long long m = __ballot(c == q);
         if (!m) continue;
         const int leader = __builtin_ctzll(m);
-        u64 base = 0;
-        if (lane == leader) base = atomicAdd((ull *)&counts[q], (ull)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (c == q) out[(u64)q * n + base + (u64)__popcll(m & (((unsigned long long)1 << lane) - 1))] = h;
+        u32 base = 0;
+        if (lane == leader) base = atomicAdd(&wg_cnt[q], (u32)__popcll(m));
+        base = (u32)__shfl((int)base, leader, 64);
+        if (c == q) mine = base + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1));
     }
+    __syncthreads();
+    if (threadIdx.x < KC_WALK_CLASSES && wg_cnt[threadIdx.x]) wg_base[threadIdx.x] = atomicAdd((ull *)&counts[threadIdx.x], (ull)wg_cnt[threadIdx.x]);
+    __syncthreads();
+    if (in) out[(u64)c * n + wg_base[c] + (u64)mine] = h;
 }
 #define LK_WALKED (1ull << 62)          /* on a dead port: the chain that ends here was walked from its other end (kc_walk_measure_kernel) */
 #define KC_STREAM_TURNED (1ull << 63)   /* chain_stream: the recording runs from the chain's LAST k-mer: the emit writes its reverse complement */
@@ -1125,7 +1135,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 KC_TRY(scope.alloc(&hcls, (u64)KC_WALK_CLASSES * nheads));
                 KC_TRY(scope.alloc(&hcnt, KC_WALK_CLASSES));
                 KC_HIP(ctx, hipMemsetAsync(hcnt, 0, KC_WALK_CLASSES * 8, ctx->stream));
-                KC_LAUNCH(kc_heads_by_class_kernel, dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, (const u64 *)heads, nheads, hcls, hcnt);
+                KC_LAUNCH(kc_heads_by_class_kernel, dim3(kc_grid(nheads, 1024)), dim3(1024), 0, ctx->stream, (const u64 *)heads, nheads, hcls, hcnt);
                 u64 hn[KC_WALK_CLASSES];
                 KC_HIP(ctx, hipMemcpyAsync(hn, hcnt, sizeof hn, hipMemcpyDeviceToHost, ctx->stream));
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
