@@ -320,6 +320,17 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
 // before it: doubling steps with shuffles, the lanes below 0 come from the previous chunk's registers (a wave walks `chunks`
 // consecutive 64-position chunks, one extra in front for those).  Runs of equal blocks are found with a ballot; the first lane
 // of a run reserves for all of it, the others get the base by shuffle and store their own key.  No LDS at all.
+// A key that finds its block's bucket full goes to a side list (counters[5] counts them; they are inserted like the keys that find no
+// room in their block's probe run).  Returns true when there is no such list or it is full as well: the caller then raises the flag that
+// sends the blocks concerned through a second sweep of the whole input.  (Round 5: one overflowing bucket of 10^8 127-mers -- block sizes
+// vary by a factor of two there -- cost 15 ms of a 40 ms pass.)
+template <int W> __device__ __forceinline__ bool kc_scatter_aside(const u64 *key, u64 *sovf, u64 sovf_cap, u64 *counters) {
+    if (!sovf) return true;
+    const u64 pos = atomicAdd((ull *)&counters[5], 1ULL);
+    if (pos >= sovf_cap) return true;
+    for (int w = 0; w < W; ++w) sovf[pos * W + w] = key[w];
+    return false;
+}
 __device__ __forceinline__ u64 kc_extract_bases(const u64 *__restrict__ codes, u64 s, int nb) {   // the nb <= 32 bases from position s on, right-aligned
     const u64 wi = s >> 5;
     const int o = (int)(s & 31);
@@ -340,7 +351,7 @@ __device__ __forceinline__ u32 kc_halo_get(u32 prev, u32 cur, int idx) {   // va
 }
 __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
                                                                      int complements, int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters,
-                                                                     int chunks) {
+                                                                     int chunks, u64 *sovf = nullptr, u64 sovf_cap = 0) {
     const int lane = threadIdx.x & 63;
     const int exp_ = chunks >> 16;   // (timing experiments only: 1 no atomics, 2 no stores, 3 neither -- tools/r5_build_ab.py; results are wrong then)
     chunks &= 0xffff;
@@ -414,7 +425,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
             const u64 at2 = base + (u64)(lane - leader);
             if (exp_ & 2) { if (at2 == ~(u64)0) bucket[0] = R.key; }
             else if (at2 < bs) bucket[(R.blk << set.bshift) + at2] = R.key;
-            else overflow = true;   // (the bucket keeps the keys that still fit; the caller re-inserts through the global path)
+            else overflow = kc_scatter_aside<1>(&R.key, sovf, sovf_cap, counters) || overflow;
         }
     };
     (void)compute(-1);
@@ -462,7 +473,7 @@ __device__ __forceinline__ KcCover kc_cover_smear(KcCover x, int w) {
 }
 __global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
                                                                       int complements, int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters,
-                                                                      int chunks) {
+                                                                      int chunks, u64 *sovf = nullptr, u64 sovf_cap = 0) {
     const int lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane((u32)((((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
     const u64 nblk = (len + 63) >> 6;                      // blocks of the packed sequence (bytes behind `len` in the last one are breaks)
@@ -553,7 +564,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 
         if (R.valid) {
             const u64 at2 = (u64)base + (u64)(lane - leader);
             if (at2 < bs) bucket[((u64)R.blk << set.bshift) + at2] = R.key;
-            else overflow = true;   // (the bucket keeps the keys that still fit; the caller re-inserts through the global path)
+            else overflow = kc_scatter_aside<1>(&R.key, sovf, sovf_cap, counters) || overflow;
         }
     };
     if (T0) (void)compute(T0 - 1, load_codes(T0 - 1), true);
@@ -589,7 +600,7 @@ __device__ __forceinline__ u32 kc_halo_get3(u32 p2, u32 p1, u32 cur, int idx) { 
 template <int W>
 __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
                                                                           int complements, int case_sensitive, SetView<W> set, u64 *bucket, u64 *bcursor, u64 *counters,
-                                                                          int chunks) {
+                                                                          int chunks, u64 *sovf = nullptr, u64 sovf_cap = 0) {
     const int lane = threadIdx.x & 63;
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u64 P0 = wave * (u64)chunks * 64;
@@ -665,7 +676,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const 
                 u64 *dst = bucket + ((blk << set.bshift) + at2) * W;
 #pragma unroll
                 for (int w = 0; w < W; ++w) dst[w] = key.w[w];
-            } else overflow = true;
+            } else overflow = kc_scatter_aside<W>(key.w, sovf, sovf_cap, counters) || overflow;
         }
     }
     if (overflow) atomicExch((ull *)&counters[3], 1ULL);
@@ -1309,8 +1320,13 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_TRY(scope.alloc(&bucket, set->cap * W));
     KC_TRY(scope.alloc(&bcursor, set->nblocks));
     KC_TRY(scope.alloc(&ovf, ovf_cap * W));
+    // keys beyond a full bucket (kc_scatter_aside; the wave-cooperative scatters): a list of their own, inserted with the spilled keys
+    const u64 sovf_cap = (u64)1 << 16;
+    u64 *sovf = nullptr;
+    KC_TRY(scope.alloc(&sovf, sovf_cap * W));
     KC_HIP(ctx, hipMemsetAsync(bcursor, 0, set->nblocks * 8, ctx->stream));
     KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
+    KC_HIP(ctx, hipMemsetAsync(set->counters + 5, 0, 8, ctx->stream));
     const int win = kc_roll_win(set->k, set->mlen);
     // positions per thread: every thread first rolls over the k-1 bases before its range, so wide k wants long ranges
     // (every thread first rolls over the k - 1 bases before its range: longer ranges waste less of that, shorter ones give
@@ -1336,10 +1352,10 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             if (const char *e = getenv("KC_SCATTER_EXP")) exp_ = atoi(e) & 3;   // (timing experiments: see the kernel)
             if (getenv("KC_SCATTER_V1") || exp_)
             KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
-                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks | (exp_ << 16));
+                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks | (exp_ << 16), sovf, sovf_cap);
             else
             KC_LAUNCH(kc_bucket_scatter_wave2_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
-                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks);
+                               case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks, sovf, sovf_cap);
         }
     }
     if constexpr (W > 1) {
@@ -1348,7 +1364,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             const int chunks = 16;
             const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
             KC_LAUNCH(kc_bucket_scatter_wave_wide_kernel<W>, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k,
-                               set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, chunks);
+                               set->complements, case_sensitive, kc_view_raw<W>(set), bucket, bcursor, set->counters, chunks, sovf, sovf_cap);
         }
     }
     if (!wave_form)
@@ -1411,41 +1427,48 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
         KC_LAUNCH(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
     }
     KC_HIP(ctx, hipGetLastError());
-    u64 h[5] = {0, 0, 0, 0, 0};
+    u64 h[6] = {0, 0, 0, 0, 0, 0};
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     h[3] |= scatter_ovf;
-    if (!h[2] && !h[3] && !getenv("KC_NO_BUILD_IDS")) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (KC_NO_BUILD_IDS: test knob, the sweep of kcs_prepare_dense instead)
+    const u64 aside = h[3] ? 0 : (h[5] < sovf_cap ? h[5] : sovf_cap);   // keys beyond a full bucket (with the flag up the second sweep takes those blocks whole)
+    if (!h[2] && !h[3] && !aside && !getenv("KC_NO_BUILD_IDS")) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (KC_NO_BUILD_IDS: test knob, the sweep of kcs_prepare_dense instead)
     if (getenv("KC_SET_TRACE"))
-        fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu, largest block %llu k-mers\n", W,
-                (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[4]);
+        fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu (%llu keys aside), largest block %llu k-mers\n", W,
+                (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[5],
+                (unsigned long long)h[4]);
     if (h[2] > ovf_cap)   // the spill list overflowed: the global path inserts whatever is still missing
         return insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive);
     if (h[3]) {           // some buckets overflowed (blocks hit by high-multiplicity repeats): a second sweep inserts only those blocks' k-mers
         KC_TRY(insert_direct(set, d_codes, d_brk, d_low, len, case_sensitive, bcursor, bs));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (bcursor belongs to this scope)
     }
-    if (h[2]) {
+    if (h[2] || aside) {
         // the spilled keys go to their second homes by the global insert; the build kernel has numbered the blocks' nodes already, so the
         // few blocks that take a key now are numbered again (k = 127 on 10^8 reads: 254 spills -- the sweep over the whole table that a
         // voided numbering costs was 3.6 ms of a 27 ms pass)
         // (a renumbering workgroup rewrites a whole block: with spills in more than 1/16 of the blocks the one sweep of kcs_prepare_dense,
         // which phase 1 runs when dense_ok is unset, is cheaper than block-by-block repairs)
         const u64 nblk_here = (set->rcap ? set->rcap : set->cap) >> set->bshift;
-        const bool renumber = !h[3] && !getenv("KC_NO_BUILD_IDS") && set->ncount && fresh && h[2] * 16 <= nblk_here;
+        const u64 nlist = h[2] + aside;
+        const bool renumber = !h[3] && !getenv("KC_NO_BUILD_IDS") && set->ncount && fresh && nlist * 16 <= nblk_here;
         u64 *touched = nullptr;
         u32 *claim = nullptr;
         auto rel = kc_defer([&] { if (touched || claim) { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, touched); kc_release(ctx, claim); } });
         if (renumber) {
-            KC_TRY(kc_alloc(ctx, &touched, h[2]));
+            KC_TRY(kc_alloc(ctx, &touched, nlist));
             KC_TRY(kc_alloc(ctx, &claim, nblk_here));
             KC_HIP(ctx, hipMemsetAsync(claim, 0, nblk_here * sizeof(u32), ctx->stream));
         }
-        KC_LAUNCH(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)ovf, h[2],
-                           set->counters, touched);
+        if (h[2])
+            KC_LAUNCH(kc_insert_list_kernel<W>, dim3(kc_grid(h[2], 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)ovf, h[2],
+                               set->counters, touched);
+        if (aside)
+            KC_LAUNCH(kc_insert_list_kernel<W>, dim3(kc_grid(aside, 256)), dim3(256), 0, ctx->stream, view_of<W>(set), (const u64 *)sovf, aside,
+                               set->counters, touched ? touched + h[2] : (u64 *)nullptr);
         KC_HIP(ctx, hipGetLastError());
         if (renumber) {
-            KC_LAUNCH(kc_annotate_kernel<W>, dim3((unsigned)h[2]), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), set->ncount, set->counters + 4, (const u64 *)touched, claim);
+            KC_LAUNCH(kc_annotate_kernel<W>, dim3((unsigned)nlist), dim3(256), 0, ctx->stream, kc_view_raw<W>(set), set->ncount, set->counters + 4, (const u64 *)touched, claim);
             KC_HIP(ctx, hipGetLastError());
             u64 h2[5] = {0, 0, 0, 0, 0};
             KC_HIP(ctx, hipMemcpyAsync(h2, set->counters, sizeof h2, hipMemcpyDeviceToHost, ctx->stream));
