@@ -321,12 +321,23 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_kernel(const u64 *__res
 // consecutive 64-position chunks, one extra in front for those).  Runs of equal blocks are found with a ballot; the first lane
 // of a run reserves for all of it, the others get the base by shuffle and store their own key.  No LDS at all.
 // A key that finds its block's bucket full goes to a side list (counters[5] counts them; they are inserted like the keys that find no
-// room in their block's probe run).  Returns true when there is no such list or it is full as well: the caller then raises the flag that
-// sends the blocks concerned through a second sweep of the whole input.  (Round 5: one overflowing bucket of 10^8 127-mers -- block sizes
-// vary by a factor of two there -- cost 15 ms of a 40 ms pass.)
-template <int W> __device__ __forceinline__ bool kc_scatter_aside(const u64 *key, u64 *sovf, u64 sovf_cap, u64 *counters) {
-    if (!sovf) return true;
-    const u64 pos = atomicAdd((ull *)&counters[5], 1ULL);
+// room in their block's probe run).  Called by ALL lanes of a wave (`need`: this lane has such a key); returns true for a lane whose key
+// was NOT saved -- no list, or the list is full: the caller then raises the flag that sends the blocks concerned through a second sweep
+// of the whole input.  One reservation per wave and call, none once the wave has seen the list full (`full`, wave-uniform): a repeat that
+// sends 10^7 occurrences to one block must not turn into as many same-address atomics.  (Round 5: one overflowing bucket of 10^8
+// 127-mers -- block sizes vary by a factor of two there -- had cost 15 ms of a 40 ms pass.)
+template <int W> __device__ __forceinline__ bool kc_scatter_aside(bool need, const u64 *key, u64 *sovf, u64 sovf_cap, u64 *counters, bool &full, int lane) {
+    const unsigned long long m = __ballot(need);
+    if (!m) return false;
+    if (!sovf || full) return need;
+    const int leader = __builtin_ctzll(m);
+    const u64 n = (u64)__popcll(m);
+    u64 base = 0;
+    if (lane == leader) base = atomicAdd((ull *)&counters[5], (ull)n);
+    base = __shfl(base, leader, 64);
+    if (base + n >= sovf_cap) full = true;
+    if (!need) return false;
+    const u64 pos = base + (u64)__popcll(m & (((unsigned long long)1 << lane) - 1));
     if (pos >= sovf_cap) return true;
     for (int w = 0; w < W; ++w) sovf[pos * W + w] = key[w];
     return false;
@@ -362,7 +373,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     const u64 bs = (u64)1 << set.bshift;
     u32 a1p = ~0u, a2p = ~0u, a4p = ~0u, a8p = ~0u;
-    bool overflow = false;
+    bool overflow = false, aside_full = false;
     struct Chunk { bool valid, starts; u64 key, blk; unsigned long long vm, sm; };
     // one chunk: this lane's k-mer and block, the wave's run structure (c = -1: only the hashes, for the halo of chunk 0)
     auto compute = [&](int c) -> Chunk {
@@ -421,12 +432,12 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_kernel(const u64 *
         const unsigned long long below = R.sm & (((unsigned long long)2 << lane) - 1);   // the starts at or below this lane
         const int leader = below ? 63 - __builtin_clzll(below) : 0;
         base = __shfl(base, leader, 64);
+        const u64 at2 = base + (u64)(lane - leader);
         if (R.valid) {
-            const u64 at2 = base + (u64)(lane - leader);
             if (exp_ & 2) { if (at2 == ~(u64)0) bucket[0] = R.key; }
             else if (at2 < bs) bucket[(R.blk << set.bshift) + at2] = R.key;
-            else overflow = kc_scatter_aside<1>(&R.key, sovf, sovf_cap, counters) || overflow;
         }
+        if (kc_scatter_aside<1>(R.valid && !(exp_ & 2) && at2 >= bs, &R.key, sovf, sovf_cap, counters, aside_full, lane)) overflow = true;
     };
     (void)compute(-1);
     // two chunks per trip: both reservations are in flight before either is waited for
@@ -487,7 +498,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 
     const int half = lane >> 5, sh = 2 * (31 - (lane & 31));
     const unsigned long long lane_le = ((unsigned long long)2 << lane) - 1;   // lanes at or below this one
     u32 a1p = ~0u, a2p = ~0u, a4p = ~0u, a8p = ~0u;
-    bool overflow = false;
+    bool overflow = false, aside_full = false;
     // the two code words a lane's k-mer lies in (block t: lanes 0..31 -> words 2t-1, 2t; lanes 32..63 -> 2t, 2t+1)
     auto load_codes = [&](u64 t) -> ulonglong2 {
         ulonglong2 v;
@@ -561,11 +572,9 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 
         const unsigned long long below = R.sm & lane_le;
         const int leader = below ? 63 - __builtin_clzll(below) : 0;
         base = (u32)__shfl((int)base, leader, 64);
-        if (R.valid) {
-            const u64 at2 = (u64)base + (u64)(lane - leader);
-            if (at2 < bs) bucket[((u64)R.blk << set.bshift) + at2] = R.key;
-            else overflow = kc_scatter_aside<1>(&R.key, sovf, sovf_cap, counters) || overflow;
-        }
+        const u64 at2 = (u64)base + (u64)(lane - leader);
+        if (R.valid && at2 < bs) bucket[((u64)R.blk << set.bshift) + at2] = R.key;
+        if (kc_scatter_aside<1>(R.valid && at2 >= bs, &R.key, sovf, sovf_cap, counters, aside_full, lane)) overflow = true;
     };
     if (T0) (void)compute(T0 - 1, load_codes(T0 - 1), true);
     u64 tend = T0 + (u64)chunks;
@@ -612,7 +621,7 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const 
     u32 A[7], p1[7], p2[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) { p1[j] = ~0u; p2[j] = ~0u; }
-    bool overflow = false;
+    bool overflow = false, aside_full = false;
     for (int c = -2; c < chunks; ++c) {
         const long long pp = (long long)P0 + 64LL * c + lane;
         const bool inr = pp >= 0 && (u64)pp < len;
@@ -670,14 +679,13 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave_wide_kernel(const 
         const unsigned long long below = sm & (((unsigned long long)2 << lane) - 1);
         const int leader = below ? 63 - __builtin_clzll(below) : 0;
         base = __shfl(base, leader, 64);
-        if (valid) {
-            const u64 at2 = base + (u64)(lane - leader);
-            if (at2 < bs) {
-                u64 *dst = bucket + ((blk << set.bshift) + at2) * W;
+        const u64 at2 = base + (u64)(lane - leader);
+        if (valid && at2 < bs) {
+            u64 *dst = bucket + ((blk << set.bshift) + at2) * W;
 #pragma unroll
-                for (int w = 0; w < W; ++w) dst[w] = key.w[w];
-            } else overflow = kc_scatter_aside<W>(key.w, sovf, sovf_cap, counters) || overflow;
+            for (int w = 0; w < W; ++w) dst[w] = key.w[w];
         }
+        if (kc_scatter_aside<W>(valid && at2 >= bs, key.w, sovf, sovf_cap, counters, aside_full, lane)) overflow = true;
     }
     if (overflow) atomicExch((ull *)&counters[3], 1ULL);
 }
