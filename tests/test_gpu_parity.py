@@ -149,15 +149,19 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, links, monkeypatch):
                                    {"KC_BUCKET_MIN": "0", "KC_LOCAL_PROBES": "2"}, {"KC_NOFRAG": "1"}, {"KC_CHAIN_LIMIT": "600"},
                                    {"KC_BUCKET_MIN": "0", "KC_SCATTER_ROLL": "1"}, {"KC_BUCKET_MIN": "0", "KC_PROBE_LISTED_GLOBAL": "1"},
                                    {"KC_BUCKET_MIN": "0", "KC_BUILD_NOPREFETCH": "1", "KC_SCATTER_CHUNKS": "2"},
-                                   {"KC_BUCKET_MIN": "0", "KC_NO_BUILD_IDS": "1"}],
+                                   {"KC_BUCKET_MIN": "0", "KC_NO_BUILD_IDS": "1"}, {"KC_BUCKET_MIN": "0", "KC_SCATTER_V1": "1"},
+                                   {"KC_WALK_BOTH": "1"}],
                          ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "plain-walk",
                               "fragment-contraction-then-restore", "rolling-scatter", "listed-ports-from-the-table", "no-build-prefetch",
-                              "node-ids-by-a-sweep-of-their-own"])
+                              "node-ids-by-a-sweep-of-their-own", "wave-scatter-of-round-4", "every-head-walks"])
 def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
     """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
     walk, LDS tag staging; the wave-cooperative bucket scatter -- default with KC_BUCKET_MIN=0 for single-word keys on minimizer
     tables -- against the rolling one) must give the same set and the same simplitigs; KC_LOCAL_PROBES=2 makes block-local probe
-    runs overflow, so the spill list + global second home of the bucketed build are exercised too."""
+    runs overflow, so the spill list + global second home of the bucketed build are exercised too.  Round 5: the scatter of round 4
+    against the leaner one (the default here), every head walking its chain against one walk per chain with turned recordings (the
+    default).  (Buckets that run full and send keys to the scatter's side list: the low-complexity and repeat cases of this file -- 900
+    to 1 500 keys aside each, and 10^6 where the list runs full and the second sweep takes over; `KC_SET_TRACE=1` shows them.)"""
     for name, value in knobs.items():
         monkeypatch.setenv(name, value)
     rng = random.Random(4242)
