@@ -731,6 +731,7 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
     // are on their way while the LDS table is set up
     const bool pf = W == 1 && nseg == 0 && !(fresh & 2);   // (bit 1 of `fresh`: test knob, no prefetch)
     const bool st16 = !(fresh & 4);                          // (bit 2: test knob, 8-byte stores in the write-out)
+    const int exp_ = fresh >> 4;                             // (timing experiments, KC_BUILD_EXP: 1 no inserts, 2 no write-out, 4 no key loads -- the results are wrong then)
     fresh &= 1;
     constexpr int NPRE = 8;
     u64 pre[NPRE];
@@ -753,7 +754,7 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
     if (pf) {
         n_pre = bcursor[src_blk];
         if (n_pre > bs) n_pre = bs;
-        prefetch(n_pre);
+        if (!(exp_ & 4)) prefetch(n_pre);
     }
     if (threadIdx.x == 0) {
         added_s = 0;
@@ -783,6 +784,7 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
     if (nseg) n = seg_pre[nseg];
     else if (pf) n = n_pre;
     else { n = bcursor[src_blk]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
+    if (exp_ & 1) n = 0;
     u32 added = 0;
     int it = 0;
     for (u64 j = threadIdx.x; j < n; j += blockDim.x, ++it) {
@@ -824,6 +826,9 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
                 sl += adv ? 1u : 0u;
             } while (__ballot(adv));
             if (took) { ltp[sl] = tag; ++added; }
+            // (rounds that look at the tags of 8 slots and go straight for the first empty slot or the first with the key's own tag -- ~1.3
+            // rounds per key instead of ~8 -- were built and measured: 23.4 against 23.3 ms.  KC_BUILD_EXP: of the 23.3 ms, 2.0 set the LDS
+            // table up, 1.9-3.5 load the keys, 3.9 write the block out and 11.5 insert -- and most of that is the key's place hash.)
             done = !gave_up;
         } else
         while (p < set.local_probes && !done) {
@@ -862,6 +867,7 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
         if (threadIdx.x == 0) { atomicAdd((ull *)&counters[2], (ull)added_s); atomicAdd((ull *)&counters[3], (ull)n); }
         return;
     }
+    if (exp_ & 2) return;
     if (IDS) {
         // Write-out with the dense node ids prepared on the way: wave w owns the slots [w bs/16, (w+1) bs/16) and writes them in
         // rows of 64 (512 contiguous bytes per row of single-word keys); an empty slot leaves with the number of occupied slots
@@ -1427,11 +1433,11 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
     if (getenv("KC_NO_BUILD_IDS"))   // (test knob: the sweep of kcs_prepare_dense instead)
         KC_LAUNCH(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0) | (getenv("KC_BUILD_EXP") ? (atoi(getenv("KC_BUILD_EXP")) & 7) << 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
     else {
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
         KC_LAUNCH((kc_block_build_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0) | (getenv("KC_BUILD_EXP") ? (atoi(getenv("KC_BUILD_EXP")) & 7) << 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
         KC_LAUNCH(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
     }
     KC_HIP(ctx, hipGetLastError());
