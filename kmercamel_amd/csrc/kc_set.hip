@@ -786,22 +786,7 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
     else { n = bcursor[src_blk]; if (n > bs) n = bs; }   // (the scatter kernel has flagged the overflow; the caller re-inserts everything through the global path)
     if (exp_ & 1) n = 0;
     u32 added = 0;
-    int it = 0;
-    for (u64 j = threadIdx.x; j < n; j += blockDim.x, ++it) {
-        Key<W> key;
-        u64 src = base + j;
-        if (nseg) {
-            int q = 0;
-            while (q + 1 < nseg && j >= seg_pre[q + 1]) ++q;
-            src = seg_lo[q] + (j - seg_pre[q]);
-        }
-        if (pf && it < NPRE) {
-            u64 v = pre[0];
-#pragma unroll
-            for (int t = 1; t < NPRE; ++t) v = it == t ? pre[t] : v;
-            key.w[0] = v;
-        } else
-            for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
+    auto insert_key = [&](const Key<W> &key) {
         const u64 top = key.w[W - 1];
         u32 off; u8 tag;
         set_place_local(set, key, &off, &tag);
@@ -860,6 +845,25 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
             if (pos < ovf_cap)
                 for (int w = 0; w < W; ++w) ovf_list[pos * W + w] = key.w[w];
         }
+    };
+    u64 jrest = threadIdx.x;
+    if (pf) {
+        // the prefetched keys by their register (a select chain over pre[] per trip was 14 instructions of every insert)
+#pragma unroll
+        for (int t = 0; t < NPRE; ++t)
+            if ((u64)threadIdx.x + 1024u * (u64)t < n) { Key<W> key; key.w[0] = pre[t]; insert_key(key); }
+        jrest += 1024u * (u64)NPRE;
+    }
+    for (u64 j = jrest; j < n; j += blockDim.x) {
+        Key<W> key;
+        u64 src = base + j;
+        if (nseg) {
+            int q = 0;
+            while (q + 1 < nseg && j >= seg_pre[q + 1]) ++q;
+            src = seg_lo[q] + (j - seg_pre[q]);
+        }
+        for (int w = 0; w < W; ++w) key.w[w] = bucket[src * W + w];
+        insert_key(key);
     }
     if (added) atomicAdd(&added_s, added);
     __syncthreads();
