@@ -484,7 +484,9 @@ __device__ __forceinline__ KcCover kc_cover_smear(KcCover x, int w) {
 }
 __global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 *__restrict__ codes, const u64 *__restrict__ brk, const u64 *__restrict__ low, u64 len, int k,
                                                                       int complements, int case_sensitive, SetView<1> set, u64 *bucket, u64 *bcursor, u64 *counters,
-                                                                      int chunks, u64 *sovf = nullptr, u64 sovf_cap = 0) {
+                                                                      int chunks, u64 *sovf = nullptr, u64 sovf_cap = 0, const u64 *__restrict__ boff = nullptr) {
+    // boff != nullptr (second pass of the hash-sharded build): the keys of block b land at bucket[boff[b] + position] -- the exact layout,
+    // no bucket can run full
     const int lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane((u32)((((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6)));
     const u64 nblk = (len + 63) >> 6;                      // blocks of the packed sequence (bytes behind `len` in the last one are breaks)
@@ -573,6 +575,10 @@ __global__ void __launch_bounds__(256) kc_bucket_scatter_wave2_kernel(const u64 
         const int leader = below ? 63 - __builtin_clzll(below) : 0;
         base = (u32)__shfl((int)base, leader, 64);
         const u64 at2 = (u64)base + (u64)(lane - leader);
+        if (boff) {
+            if (R.valid) bucket[boff[R.blk] + at2] = R.key;
+            return;
+        }
         if (R.valid && at2 < bs) bucket[((u64)R.blk << set.bshift) + at2] = R.key;
         if (kc_scatter_aside<1>(R.valid && at2 >= bs, &R.key, sovf, sovf_cap, counters, aside_full, lane)) overflow = true;
     };
@@ -1619,6 +1625,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     // every k-mer twice: +12 ms per 10^9.)  A bucket that overflows (a block that receives more than 2^bshift occurrences from
     // this rank alone) sends the rank back to the two-pass form.
     u64 *fixed = nullptr;
+    bool counted = false;   // bcount holds the per-block counts already
     bool one_pass = have && !getenv("KC_SHARD_TWO_PASS");
     if (one_pass) {
         size_t free_b = 0, total_b = 0;
@@ -1657,13 +1664,16 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         KC_HIP(ctx, hipMemcpyAsync(&hovf, set->counters + 3, 8, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hovf) {
+            // (the cursors of the failed pass ARE the per-block counts -- every run was reserved, whether it fitted or not: no counting
+            // pass; round 5, `-z` on reads with coverage, where blocks of twice the mean are common: 26 ms per call)
             one_pass = false;
+            counted = wave_form;
             scope.release(fixed); fixed = nullptr;
-            KC_HIP(ctx, hipMemsetAsync(bcount, 0, (nblocks + 1) * 8, ctx->stream));
+            if (!counted) KC_HIP(ctx, hipMemsetAsync(bcount, 0, (nblocks + 1) * 8, ctx->stream));
             KC_HIP(ctx, hipMemsetAsync(set->counters + 2, 0, 16, ctx->stream));
         }
     }
-    if (have && !one_pass)
+    if (have && !one_pass && !counted)
         KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
                            set->complements, 0, kc_view_raw<W>(set), (u64 *)nullptr, bcount, set->counters, ppt, stage_cap, (const u64 *)nullptr, 1);
     KC_TRY(kcu_exclusive_scan(ctx, bcount, boff, nblocks));
@@ -1677,9 +1687,21 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(fixed);
-    } else if (have)
-        KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
-                           set->complements, 0, kc_view_raw<W>(set), bucket, bcur, set->counters, ppt, stage_cap, (const u64 *)boff, 0);
+    } else if (have) {
+        bool by_wave = false;
+        if constexpr (W == 1) {   // the exact layout by the wave-cooperative scatter where it applies (17 against 26 ms per 2.5 * 10^9 positions)
+            by_wave = set->mlen == 16 && set->k >= 18 && set->k <= 32 && !getenv("KC_SCATTER_ROLL") && !getenv("KC_SCATTER_V1");
+            if (by_wave) {
+                const int chunks = 16;
+                const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
+                KC_LAUNCH(kc_bucket_scatter_wave2_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
+                                   0, kc_view_raw<1>(set), bucket, bcur, set->counters, chunks, (u64 *)nullptr, (u64)0, (const u64 *)boff);
+            }
+        }
+        if (!by_wave)
+            KC_LAUNCH(kc_bucket_scatter_kernel<W>, dim3(kc_grid(nthreads, tb)), dim3(tb), lds_scatter, ctx->stream, d_codes, d_brk, d_low, len, set->k,
+                               set->complements, 0, kc_view_raw<W>(set), bucket, bcur, set->counters, ppt, stage_cap, (const u64 *)boff, 0);
+    }
     KC_HIP(ctx, hipGetLastError());
     // exchange 1: the per-block counts of every owner's blocks
     std::vector<u64> so(G), sc(G), ro(G), rcv(G);
