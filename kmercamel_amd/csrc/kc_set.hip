@@ -831,14 +831,14 @@ __global__ void __launch_bounds__(1024, W == 1 ? 8 : 4) kc_block_build_kernel(Se
                 else {
                     for (int w = 0; w < W - 1; ++w) lk[(size_t)s * W + w] = key.w[w];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    lt[s] = tag;
+                    __hip_atomic_store(&ltp[s], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (an LDS store; the volatile one was a FLAT instruction behind a full wait)
                 }
                 ++added;
                 done = true;
             } else if (cur == top) {
                 if constexpr (W == 1) done = true;
                 else {
-                    if (lt[s] == 0) continue;   // being published by another lane: look again (p unchanged)
+                    if (__hip_atomic_load(&ltp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) continue;   // being published by another lane: look again (p unchanged)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     bool eq = true;
                     for (int w = 0; w < W - 1; ++w) eq = eq && (lk[(size_t)s * W + w] == key.w[w]);
