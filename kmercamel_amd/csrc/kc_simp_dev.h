@@ -576,7 +576,8 @@ template <int W> struct KcCand2 {
 // x, RC(x) and the minimizer hashes of the two candidate middles: m-mer starts 2..k-m (append side) / 0..k-m-2 (prepend side) of x
 template <int W, int KC>
 __device__ __forceinline__ void kc_kmer_mins(const Key<W> &x, const Key<W> &xr, int k, int m, u32 &minL, u32 &minR) {
-    minR = ~0u; minL = ~0u;
+    // (the two windows share all but their two outer m-mers: one running minimum over the shared ones, the outer ones joined at the end)
+    u32 both = ~0u, onlyL = ~0u, onlyR = ~0u;
     const u32 maskm = (m >= 16) ? ~0u : ((1u << (2 * m)) - 1u);
     const int top = 2 * (m - 1);
     u32 f = 0, r = 0;
@@ -599,9 +600,12 @@ __device__ __forceinline__ void kc_kmer_mins(const Key<W> &x, const Key<W> &xr, 
             r = (r >> 2) | ((3u - b) << top);
         }
         const u32 h = kc_mmer_hash(f, r);
-        if (i >= 2) minR = h < minR ? h : minR;
-        if (i <= k - m - 2) minL = h < minL ? h : minL;
+        if (i >= 2 && i <= k - m - 2) both = h < both ? h : both;
+        else if (i < 2) { if (i <= k - m - 2) onlyL = h < onlyL ? h : onlyL; }
+        else onlyR = h < onlyR ? h : onlyR;
     }
+    minL = both < onlyL ? both : onlyL;
+    minR = both < onlyR ? both : onlyR;
 }
 template <int W, int KC, bool SH>
 __device__ __forceinline__ void kc_cand_lookup_mid(const SetView<W> &set, int k_rt, int complements, const u64 slot, const u8 *stage_tags, const u64 sblk,
