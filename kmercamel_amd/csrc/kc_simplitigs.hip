@@ -227,29 +227,6 @@ __global__ void __launch_bounds__(1024) kc_heads_by_class_kernel(const u64 *__re
     __syncthreads();
     if (in) out[(u64)c * n + wg_base[c] + (u64)mine] = h;
 }
-// the heads of a class whose chain has not been walked from its other end yet (full waves for the launch of that class)
-__global__ void __launch_bounds__(1024) kc_heads_unwalked_kernel(const u64 *__restrict__ heads, u64 n, const u64 *__restrict__ link, u64 *out, u64 *count) {
-    __shared__ u32 wg_cnt;
-    __shared__ u64 wg_base;
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 h = t < n ? heads[t] : 0;
-    const bool keep = t < n && !(link[h] & (1ull << 62));   // LK_WALKED
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) wg_cnt = 0;
-    __syncthreads();
-    const unsigned long long m = __ballot(keep);
-    u32 base = 0;
-    if (m) {
-        const int leader = __builtin_ctzll(m);
-        if (lane == leader) base = atomicAdd(&wg_cnt, (u32)__popcll(m));
-        base = (u32)__shfl((int)base, leader, 64);
-    }
-    const u32 mine = base + (u32)__popcll(m & (((unsigned long long)1 << lane) - 1));
-    __syncthreads();
-    if (threadIdx.x == 0 && wg_cnt) wg_base = atomicAdd((ull *)count, (ull)wg_cnt);
-    __syncthreads();
-    if (keep) out[wg_base + (u64)mine] = h;
-}
 #define LK_WALKED (1ull << 62)          /* on a dead port: the chain that ends here was walked from its other end (kc_walk_measure_kernel) */
 #define KC_STREAM_TURNED (1ull << 63)   /* chain_stream: the recording runs from the chain's LAST k-mer: the emit writes its reverse complement */
 template <int W, bool MARK, bool REC, bool FRAG = false>
@@ -1163,28 +1140,13 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 KC_HIP(ctx, hipMemcpyAsync(hn, hcnt, sizeof hn, hipMemcpyDeviceToHost, ctx->stream));
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 u64 t0 = 0;
-                u64 *hlive = nullptr, *hlive_n = nullptr;
-                const bool compact = !getenv("KC_WALK_NOCOMPACT");
-                if (compact) { KC_TRY(scope.alloc(&hlive, nheads)); KC_TRY(scope.alloc(&hlive_n, 1)); }
                 for (int cp = 0; cp < KC_WALK_CLASSES; ++cp) {
-                    const u64 *hl = hcls + (u64)cp * nheads;
-                    u64 nl = hn[cp];
-                    if (cp && compact && nl) {
-                        // the later classes start from the heads that are still unmarked, compacted: full waves (the marked ones
-                        // left 25 / 50 / 75 % of the lanes of those launches idle)
-                        KC_HIP(ctx, hipMemsetAsync(hlive_n, 0, 8, ctx->stream));
-                        KC_LAUNCH(kc_heads_unwalked_kernel, dim3(kc_grid(nl, 1024)), dim3(1024), 0, ctx->stream, hl, nl, (const u64 *)link, hlive, hlive_n);
-                        KC_TRY(read_u64(ctx, hlive_n, &nl));
-                        hl = hlive;
-                    }
-                    if (nl)
-                        KC_LAUNCH((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(nl, 256)), dim3(256), 0, ctx->stream, sv,
-                                           (const u64 *)link, compl_, hl, nl, (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
+                    if (hn[cp])
+                        KC_LAUNCH((kc_walk_measure_kernel<W, false, true, true>), dim3(kc_grid(hn[cp], 256)), dim3(256), 0, ctx->stream, sv,
+                                           (const u64 *)link, compl_, (const u64 *)(hcls + (u64)cp * nheads), hn[cp], (u8 *)nullptr, chain_head, chain_len, chain_key, cnt,
                                            KC_CHAIN_LIMIT, rec, fr, link, cp, t0, nheads);
                     t0 += hn[cp];
                 }
-                KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                scope.release(hlive); scope.release(hlive_n);
                 KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (hcls belongs to this block)
                 scope.release(hcls); scope.release(hcnt);
             } else
