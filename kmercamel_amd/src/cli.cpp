@@ -291,12 +291,19 @@ static int run_compute_sharded_streamed(const std::string &path, int k, std::ost
     std::condition_variable cv;
     int arrived = 0, not_fasta = 0;
     bool out_ready = false, mapped = false, mmapped = false;
+    // a rank that cannot go on ends the process (its peers would wait for it forever) -- but not with output files of the preallocated
+    // size and whatever the pages hold: they go back to empty first (ftruncate is all this does: no destructors run behind _exit)
+    auto die = [&]() {
+        if (om.fd >= 0 && ::ftruncate(om.fd, 0) != 0) {}
+        if (omm.fd >= 0 && ::ftruncate(omm.fd, 0) != 0) {}
+        _exit(1);
+    };
     auto rank_main = [&](int r) {
         kc_ctx *ctx = nullptr;
         kc_comm *comm = nullptr;
         int rc = kc_ctx_create(r % ndev, &ctx);
         if (rc == KC_OK) rc = kc_comm_create_threads(ctx, group, r, &comm);
-        if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; _exit(1); }   // (the others would wait for it forever)
+        if (rc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot start (code " << rc << ")" << std::endl; die(); }   // (the others would wait for it forever)
         void *d_seq = nullptr;
         uint64_t d_len = 0;
         int fq = 0;
@@ -314,7 +321,7 @@ static int run_compute_sharded_streamed(const std::string &path, int k, std::ost
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
         const bool sparse_case = rc == KC_E_ARG && err[r].find("not part of the hash-sharded path") != std::string::npos;
-        if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
+        if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; die(); }
         if (rc == KC_OK) {
             if (r == 0) {
                 mark("kc_compute_sharded returned");
@@ -344,7 +351,7 @@ static int run_compute_sharded_streamed(const std::string &path, int k, std::ost
                     else { std::vector<char> tmp(n); wrc = kc_result_copy(res[r], tmp.data(), &mask[off]); }
                 }
             }
-            if (wrc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot copy its slice" << std::endl; _exit(1); }
+            if (wrc != KC_OK) { std::cerr << "kmercamel_amd: rank " << r << " cannot copy its slice" << std::endl; die(); }
             kc_result_destroy(res[r]);
         }
         kc_comm_destroy(comm);

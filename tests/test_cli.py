@@ -297,6 +297,13 @@ def test_cli_large_input_takes_the_mapped_output_path(tmp_path):
         assert (open(o3).read(), open(m3).read()) == outs[0], gp
     p = subprocess.run([BIN, "compute", "-k", "31", "--gpus", "2", path], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout == ref.stdout
+    # a rank that fails ends the process -- and leaves EMPTY output files behind, not the preallocated 74 MB of whatever the pages held
+    for f in (o3, m3):
+        os.unlink(f)
+    p = subprocess.run([BIN, "compute", "-k", "31", "--gpus", "2", "-o", o3, "-M", m3, path], capture_output=True, text=True,
+                       env=dict(os.environ, KC_TEST_FAIL_RANK="1"))
+    assert p.returncode != 0 and "kmercamel_amd: rank" in p.stderr, p.stderr[-400:]   # (rank 1's own message, or a peer's that was released: whichever leaves first)
+    assert os.path.getsize(o3) == 0 and os.path.getsize(m3) == 0
     # an output file that already holds something longer is cut to the new length
     with open(o, "w") as f:
         f.write("x" * (len(want[1]) + 5000000))
