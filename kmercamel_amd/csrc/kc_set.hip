@@ -987,6 +987,22 @@ __global__ void __launch_bounds__(1024) kc_block_build_filter_kernel(SetView<W> 
         u32 off; u8 tag;
         set_place_local(set, key, &off, &tag);
         *claimed = false;
+        if constexpr (W == 1) {   // straight-line probe rounds, as in kc_block_build_kernel (every lane of the wave swaps every round)
+            u32 sl = off;
+            const u32 lim = off + set.local_probes;
+            bool took = false, gave_up = false, adv;
+            do {
+                const u64 cur = atomicCAS((ull *)&lk[sl], ~0ULL, (ull)top);
+                took = took || cur == ~(u64)0;
+                const bool miss = cur != ~(u64)0 && cur != top;   // another key lives here
+                adv = miss && sl + 1 < lim;
+                gave_up = gave_up || (miss && !adv);
+                sl += adv ? 1u : 0u;
+            } while (__ballot(adv));
+            if (took) ltp[sl] = tag;
+            *claimed = took;
+            return gave_up ? 0xffffu : sl;
+        }
         u32 p = 0;
         while (p < set.local_probes) {
             const u32 s = off + p;
