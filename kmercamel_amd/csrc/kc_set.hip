@@ -1707,6 +1707,9 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
         bool by_wave = false;
         if constexpr (W == 1) {   // the exact layout by the wave-cooperative scatter where it applies (17 against 26 ms per 2.5 * 10^9 positions)
             by_wave = set->mlen == 16 && set->k >= 18 && set->k <= 32 && !getenv("KC_SCATTER_ROLL") && !getenv("KC_SCATTER_V1");
+            // (that kernel hands a run's base on in 32 bits: a block with 2^32 occurrences or more -- some 4.3 * 10^9 copies of one k-mer -- is
+            // left to the rolling form)
+            for (u64 b2 = 0; by_wave && b2 < nblocks; ++b2) by_wave = h_off[b2 + 1] - h_off[b2] < ((u64)1 << 32);
             if (by_wave) {
                 const int chunks = 16;
                 const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
