@@ -22,5 +22,7 @@ cd $R
 timeout 300 bash tools/r5_cliprof.sh > gpurun_out/profiles_r05/r05_cli_kernel_and_copy_stats.txt 2>&1
 cd $R
 timeout 300 bash tools/r5_shard_trace.sh > gpurun_out/profiles_r05/r05_shard_steps_thread_ranks.txt 2>&1
+timeout 600 python3 tools/shapes.py genome --check --passes 2 > gpurun_out/profiles_r05/r05_shape_genome_2p5G.json 2> gpurun_out/profiles_r05/r05_shape_genome.err
+timeout 600 python3 tools/shapes.py coverage --check --passes 2 > gpurun_out/profiles_r05/r05_shape_coverage_1G.json 2> gpurun_out/profiles_r05/r05_shape_coverage.err
 timeout 900 python3 bench.py > gpurun_out/profiles_r05/r05_default_bench.json 2> gpurun_out/profiles_r05/r05_default_bench.err
 tail -c 1500 gpurun_out/profiles_r05/r05_default_bench.json
