@@ -65,6 +65,8 @@ struct kc_set {
     u32 nstride = 0;         // ids per block = the largest ncount, rounded up to a multiple of 8
     float occ_ratio = 0;     // occurrences per distinct k-mer in the sample the bucketed build took of a fresh set (0: not sampled)
     bool dense_ok = false;   // ncount / nstride and the counts in the empty slots describe the table as it is (any insertion voids them)
+    bool homes_primary = false;   // every key sits in the local probe run of its PRIMARY home (a fresh bucketed build without spills, nothing inserted
+                                  // since): what the probe kernel's in-block guess (kc_probe_block_kernel<..., GP>) relies on
     mutable bool unclean = false;   // table allocated but not filled with EMPTY yet (a bucketed build of a fresh set overwrites every
                                     // slot, so the 9 B/slot fill is deferred until something else needs the table)
 };

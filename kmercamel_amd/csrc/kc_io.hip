@@ -321,6 +321,8 @@ static int read_fasta_device_impl(kc_ctx *ctx, const char *path, u64 range_off, 
         rd.pos = (off_t)range_off < end ? (off_t)range_off : end;
         rd.size = end;
     }
+    // (sized BEFORE the reader thread exists: that thread advances rd.pos, and the main thread must not look at rd.pos / rd.size again)
+    const u64 range_bytes = ranged ? (u64)(rd.size - rd.pos) : 0;
     const size_t CH = (size_t)32 << 20;
     const int NB = 3;
     u8 *hbuf[NB] = {nullptr, nullptr, nullptr};
@@ -381,7 +383,7 @@ static int read_fasta_device_impl(kc_ctx *ctx, const char *path, u64 range_off, 
     u64 out_cap = 0;
     {   // plain files: the joined sequence is never longer than the file; streams: grow as needed
         struct stat st;
-        if (rc == KC_OK && ranged) out_cap = (u64)(rd.size - rd.pos) + 64;
+        if (rc == KC_OK && ranged) out_cap = range_bytes + 64;
         else if (rc == KC_OK && !rd.gz && fstat(rd.fd, &st) == 0 && st.st_size > 0) out_cap = (u64)st.st_size + 64;
         else out_cap = (u64)256 << 20;
     }

@@ -1202,6 +1202,7 @@ extern "C" void kc_set_destroy(kc_set *set) {
 // words behind on its way (dense_ok stays set); this sweep serves tables that saw a direct insert since.
 static void kcs_void_dense(kc_set *set) {
     set->dense_ok = false;
+    set->homes_primary = false;
     if (set->ncount) { (void)hipStreamSynchronize(set->ctx->stream); kc_release(set->ctx, set->ncount); set->ncount = nullptr; }
 }
 template <int W>
@@ -1473,6 +1474,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     h[3] |= scatter_ovf;
     const u64 aside = h[3] ? 0 : (h[5] < sovf_cap ? h[5] : sovf_cap);   // keys beyond a full bucket (with the flag up the second sweep takes those blocks whole)
     if (!h[2] && !h[3] && !aside && !getenv("KC_NO_BUILD_IDS")) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (KC_NO_BUILD_IDS: test knob, the sweep of kcs_prepare_dense instead)
+    set->homes_primary = fresh && !h[2] && !h[3] && !aside;   // no key left its block (spills and keys beyond a full bucket take the global insert)
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] bucketed build W=%d blocks=%llu (2^%d slots): size %llu, spills %llu, bucket overflow %llu (%llu keys aside), largest block %llu k-mers\n", W,
                 (unsigned long long)set->nblocks, set->bshift, (unsigned long long)h[0], (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[5],

@@ -352,8 +352,11 @@ struct KcPortDesc {
     u32 flags;       // bit 0: the middle is read reversed; bit 1: the fixed outer character is field a; bit 2: palindromic middle (generic lookups)
 };
 // descriptor of port `port` (0 = L / prepend side, 1 = R / append side) of x; mmh = minimizer hash of the candidates' middle
-template <int W, int KC>
-__device__ __forceinline__ KcPortDesc kc_port_desc(const SetView<W> &set, const Key<W> &x, const Key<W> &xr, int k, int complements, int port, u32 mmh) {
+// LOCAL: the home is taken INSIDE the block that starts at slot `local_base` (offset = range reduction of the middle's hash, as
+// set_block_home has it) and no minimizer is needed: the guess "the candidates live in my own block" of the GP probe kernel.
+template <int W, int KC, bool LOCAL = false>
+__device__ __forceinline__ KcPortDesc kc_port_desc(const SetView<W> &set, const Key<W> &x, const Key<W> &xr, int k, int complements, int port, u32 mmh,
+                                                   const u64 local_base = 0) {
     const Key<W> lm = key_lowmask<W>(2 * (k - 2));
     const Key<W> mf = port ? key_and(x, lm) : key_shr(x, 4);
     const Key<W> mr = port ? key_shr(xr, 4) : key_and(xr, lm);
@@ -368,7 +371,7 @@ __device__ __forceinline__ KcPortDesc kc_port_desc(const SetView<W> &set, const 
     const bool fa = port ? !rev : rev;
     const u32 fval = rev ? 3u - fx : fx;
     KcPortDesc d;
-    d.home = set_block_home(set, mmh, mh);
+    d.home = LOCAL ? (local_base | (((u64)(u32)mh * set_block_span(set)) >> 32)) : set_block_home(set, mmh, mh);
     d.pat = 0x80u | ((u32)mh & 7u) | (fa ? fval << 5 : fval << 3);
     d.msk = fa ? 0xE7u : 0x9Fu;
     d.flags = (rev ? 1u : 0u) | (fa ? 2u : 0u) | (tie ? 4u : 0u);
@@ -836,18 +839,24 @@ static inline size_t kc_probe_lds_bytes(int bshift, int W, bool stage_keys, int 
 // SH (hash-sharded flow): the workgroups sweep this rank's blocks; a port whose home lies in another rank's range becomes ONE query
 // {x, port id, home} (the owner answers with the finished link word); ports are settled by kc_shard_settle_port (plain link
 // words, branch ports list their edges in L), nothing is listed for the single-GPU chain discovery.
-template <int W, int KC, bool SK, int NT, bool MM, bool SH = false>
+// GP (round 6; only for tables all of whose keys sit at their PRIMARY home -- kc_set::homes_primary): the sweep does not compute a
+// k-mer's minimizers at all.  It GUESSES that the candidates of a port live in the k-mer's own block (87 % do), searches the window
+// at the in-block offset the middle's hash gives, and keeps the result only when a neighbour is FOUND there: a key found at a
+// primary home inside this block proves that the port's home IS in this block, so the window held all candidates.  Anything else --
+// nothing found (the home is in another block, or the port is dead), an unsettled window -- is listed, and the listed pass computes
+// the one minimizer it needs, as it always did.  16 m-mer hashes per k-mer become 14 per listed port (0.17 ports per k-mer).
+template <int W, int KC, bool SK, int NT, bool MM, bool SH = false, bool GP = false>
 __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(SetView<W> set, u64 *__restrict__ link, int k_rt, int complements, int xcd_aware,
                                                             u64 *heads, u64 heads_shard_cap, u64 *heads_cursors, u64 *branch,
                                                             u64 branch_shard_cap, u64 *branch_cursors, u64 *spill, u64 spill_cap,
                                                             u64 *spill_cursor, ShLists L = ShLists{}) {
-    constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM), WBYTES = KC_PROBE_SSTACK * 2 + ECAP * (MM ? 6 : 2);
+    constexpr int KC_PROBE_THREADS = NT, KC_PROBE_WAVES = NT / 64, ECAP = KC_PROBE_ESTACK(MM);
     // DN (single-GPU flow): link words are addressed by DENSE node ids and carry dense ids -- 16 bytes per K-MER, written
     // contiguously (the k-mers of a block are numbered in slot order from block * set.nstride on), not 16 bytes per slot of a table at
     // load 0.5 written in 64-byte pieces.  The hash-sharded flow (SH) numbers its ports the same way (nstride is the same on every
     // rank, so a node id says which rank holds it); its words also carry the slot offset of their own k-mer (LK_OWN).
     constexpr bool DN = true;
-    // One workgroup per table block; after the staging barrier its 8 wavefronts work on their own: wave w sweeps the slots
+    // One workgroup per table block; after the staging barrier its wavefronts work on their own: wave w sweeps the slots
     // [w bs/8, (w+1) bs/8) in rows of 64, queues the occupied ones and takes 64 off the queue whenever that many wait, so
     // every step runs with all lanes busy and no wave ever waits for another (with block-wide lists and barriers every stretch
     // ended in a nearly empty step that the other seven waves sat out: 4.1 ms against 3.6 ms per 10^8 k-mers).  A port that the
@@ -855,11 +864,15 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     // the wave's port stack with the minimizer hash of its middle, and is looked up in global memory 64 at a time.
     // The slot queue is first-in first-out (a ring of 128): the j-th k-mer a wave takes is the j-th occupied slot of its share, so a
     // lane knows its dense id without looking anything up, and the 64 lanes of a step write 1 KB of consecutive link words.
-    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][per wave: slot ring u16 x 128, port stack u16 x ECAP (+ u32 x ECAP)]
+    // What a wave has LEFT when its share is swept (< 64 k-mers, < 64 listed ports) is not worked off in two nearly empty steps per
+    // wave (round 6: with 16 waves per block that was 32 half-empty steps of ~100 per workgroup): the leftovers of all waves are
+    // handed over to ONE list of the workgroup -- each k-mer with its rank -- and taken from there 64 at a time by the waves in turn,
+    // first the k-mers, then the listed ports (two barriers per hand-over; the lists live where the rings / the stacks were).
+    // dynamic LDS: [tags: bs][keys: bs * W words, if SK][slot rings: u16 x 128 per wave][port stacks: u16 x ECAP per wave][MM: u32 x ECAP per wave]
     // Single-word keys: 1024 threads and port stacks without the hash = 79 KB, two workgroups per CU = 8 waves per SIMD (the kernel
     // waits on LDS and memory more than it issues: at 4 waves per SIMD its VALU pipes were half idle).
     extern __shared__ ulonglong2 kc_pb[];
-    __shared__ u32 kc_wcnt[NT / 64];
+    __shared__ u32 kc_wcnt[NT / 64], kc_wleft[2][NT / 64];
     const int k = KC ? KC : k_rt;
     const int m = KC ? KC_MSPEC : set.m;
     const u64 lblk = kc_xcd_block_id(xcd_aware & 1);   // (SH: index among this rank's blocks)
@@ -869,11 +882,14 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     const u64 base = blk << set.bshift;
     u8 *st = reinterpret_cast<u8 *>(kc_pb);
     u64 *sk = reinterpret_cast<u64 *>(st + bs);
-    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    u8 *wbase = st + bs + (SK ? (size_t)bs * W * 8 : 0) + (size_t)wv * WBYTES;
-    unsigned short *sstack = reinterpret_cast<unsigned short *>(wbase);
-    unsigned short *epid = reinterpret_cast<unsigned short *>(wbase + KC_PROBE_SSTACK * 2);
-    u32 *emmh = reinterpret_cast<u32 *>(wbase + KC_PROBE_SSTACK * 2 + ECAP * 2);   // (MM only; 4-byte aligned: ECAP is even)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);   // (wv: wave-uniform, kept in a scalar register)
+    u8 *lists = st + bs + (SK ? (size_t)bs * W * 8 : 0);
+    unsigned short *sstack = reinterpret_cast<unsigned short *>(lists) + (size_t)wv * KC_PROBE_SSTACK;
+    unsigned short *epid = reinterpret_cast<unsigned short *>(lists + (size_t)KC_PROBE_WAVES * KC_PROBE_SSTACK * 2) + (size_t)wv * ECAP;
+    u32 *emmh = reinterpret_cast<u32 *>(lists + (size_t)KC_PROBE_WAVES * (KC_PROBE_SSTACK * 2 + ECAP * 2)) + (size_t)wv * ECAP;   // (MM only; 4-byte aligned: ECAP is even)
+    // the workgroup's lists of leftovers: k-mers {slot offset, rank << 16} where the rings were, listed ports where the stacks were
+    u32 *sh_k = reinterpret_cast<u32 *>(lists);                                                                       // WAVES x 64 entries
+    unsigned short *sh_p = reinterpret_cast<unsigned short *>(lists + (size_t)KC_PROBE_WAVES * KC_PROBE_SSTACK * 2);   // WAVES x ECAP entries
     {
         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(set.tags + base);
         for (u32 j = threadIdx.x; j < bs / 16; j += KC_PROBE_THREADS) kc_pb[j] = src[j];
@@ -897,6 +913,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         if (lane == 0) kc_wcnt[wv] = mine;
         __syncthreads();
         for (int i = 0; i < wv; ++i) wfirst += kc_wcnt[i];
+        wfirst = __builtin_amdgcn_readfirstlane(wfirst);
         nb0 = blk * (u64)set.nstride;
     }
     auto load_x = [&](u32 so) {
@@ -935,8 +952,8 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     // a listed port (called by all lanes of the wave that are in the current step; `on` = this lane has one): the window search
-    // in global memory, or -- SH, home on another rank -- a query
-    auto settle_listed = [&](bool on, u32 so, int port, u32 mmh_in) {
+    // in global memory, or -- SH, home on another rank -- a query.  have_mm: mmh_in is the minimizer hash the sweep stacked (MM, not GP)
+    auto settle_listed = [&](bool on, u32 so, int port, u32 mmh_in, bool have_mm) {
         const u64 slot = base + so;
         bool remote = false;
         Key<W> x = key_zero<W>(), xr = x;
@@ -945,7 +962,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             x = load_x(so);
             xr = key_rc(x, k);
             u32 mmh = mmh_in;
-            if (!MM) {
+            if (!MM || GP || !have_mm) {
                 const Key<W> lm = key_lowmask<W>(2 * (k - 2));
                 const Key<W> mid = port ? key_and(x, lm) : key_shr(x, 4), midr = port ? key_shr(xr, 4) : key_and(xr, lm);
                 mmh = kc_mid_min<W, KC>(mid, midr, k, m);
@@ -1002,86 +1019,134 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         }
     };
     u32 shead = 0, stail = 0, ecnt = 0;   // slot ring: taken / queued so far; entries on the port stack (all wave-uniform)
+    // phase 0: the wave sweeps its share; 1: the workgroup's left-over k-mers, chunk by chunk; 2: the workgroup's left-over listed ports
+    u32 row = 0, phase = 0, chunk = (u32)wv, nk_sh = 0, np_sh = 0;
 #pragma unroll 1
-    for (u32 row = 0; row <= rows; ++row) {
-        const bool drain = row == rows;
-        if (!drain) {
+    for (;;) {
+        // what this wave does next (wave-uniform): 0 = a step of 64 k-mers, 1 = a step of 64 listed ports, 2 = queue a row of slots,
+        // 3 = hand the leftovers over to the workgroup's list, 4 = done
+        int act;
+        if (ecnt >= 64) act = 1;
+        else if (phase == 0) act = (stail - shead >= 64) ? 0 : (row < rows ? 2 : 3);
+        else if (phase == 1) act = (chunk * 64u < nk_sh) ? 0 : 3;
+        else act = (chunk * 64u < np_sh) ? 1 : 4;
+        if (act == 4) break;
+        if (act == 2) {
             const u32 off = row * 64 + (u32)lane, so = (u32)wv * per_wave + off;
             const bool occ = off < per_wave && st[so] != 0;
             const unsigned long long mk = __ballot(occ);
             if (occ) sstack[(stail + (u32)__popcll(mk & ltm)) & (KC_PROBE_SSTACK - 1)] = (unsigned short)so;
             stail += (u32)__popcll(mk);
+            ++row;
             wave_sync();
+            continue;
         }
-#pragma unroll 1
-        while (stail - shead >= 64 || ecnt >= 64 || (drain && ((stail - shead) | ecnt))) {
-            if (ecnt >= 64 || (drain && stail == shead)) {
-                // ---- 64 listed ports (fewer when draining): generic window search in global memory
-                const u32 take = ecnt < 64 ? ecnt : 64;
-                ecnt -= take;
-                const bool on = (u32)lane < take;
-                const u32 e = on ? epid[ecnt + lane] : 0u;
-                settle_listed(on, e >> 1, (int)(e & 1u), (MM && on) ? emmh[ecnt + lane] : 0u);
-                wave_sync();
-                continue;
+        if (act == 3) {
+            // every lane takes one left-over entry into a register, the waves agree on their places in the workgroup's list (which lies
+            // where the rings / stacks were: nobody writes before everybody has read), then the entries go there
+            const u32 cnt = phase == 0 ? stail - shead : ecnt;   // (< 64)
+            u32 ent = 0;
+            if ((u32)lane < cnt) {
+                if (phase == 0) ent = (u32)sstack[(shead + (u32)lane) & (KC_PROBE_SSTACK - 1)] | ((wfirst + shead + (u32)lane) << 16);
+                else ent = epid[lane];
             }
-            // ---- 64 k-mers (fewer when draining), oldest first
-            const u32 scnt = stail - shead;
-            const u32 take = scnt < 64 ? scnt : 64;
-            const bool active = (u32)lane < take;
-            const u32 so = active ? sstack[(shead + (u32)lane) & (KC_PROBE_SSTACK - 1)] : 0u;
-            const u64 slot = base + so;
-            const u32 rank = wfirst + shead + (u32)lane;                           // (DN) this k-mer's number within the block
-            shead += take;
-            auto own = [&]() -> u64 { return DN ? nb0 + (u64)rank : slot; };        // what a port of this k-mer is numbered by
-            const Key<W> x = load_x(so);
-            const Key<W> xr = key_rc(x, k);
-            const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
-            const bool split = !SH && (((u32)nb0 + rank) & 0xffu) == 0;            // every 256th k-mer is a splitter of the segment-parallel walks
-            const u64 ownbits = SH ? LK_OWN_BITS(so) : 0;                           // (hash-sharded flow: the words carry the slot offset of their k-mer)
-            auto deadw = [&]() -> u64 { return LK_MAKE(LK_DEAD, 0, 0, slot) | ownbits; };   // (a dead port's word carries the slot of its k-mer)
-            u32 minL, minR;
-            kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
-            u64 wd0 = 0, wd1 = 0;
-            u32 have = 0;
+            if (lane == 0) kc_wleft[phase][wv] = cnt;
+            __syncthreads();
+            u32 at = 0, tot = 0;
+#pragma unroll
+            for (int i = 0; i < KC_PROBE_WAVES; ++i) { const u32 c = kc_wleft[phase][i]; at += i < wv ? c : 0u; tot += c; }
+            at = __builtin_amdgcn_readfirstlane(at); tot = __builtin_amdgcn_readfirstlane(tot);
+            if ((u32)lane < cnt) {
+                if (phase == 0) sh_k[at + (u32)lane] = ent;
+                else sh_p[at + (u32)lane] = (unsigned short)ent;
+            }
+            __syncthreads();
+            if (phase == 0) { nk_sh = tot; shead = stail; } else { np_sh = tot; ecnt = 0; }
+            ++phase;
+            chunk = (u32)wv;
+            continue;
+        }
+        if (act == 1) {
+            // ---- 64 listed ports (the last chunk of the workgroup's list: fewer): generic window search in global memory
+            bool on = true, have_mm = false;
+            u32 e, mm_in = 0;
+            if (phase < 2) {
+                ecnt -= 64;
+                e = epid[ecnt + lane];
+                if (MM && !GP) { mm_in = emmh[ecnt + lane]; have_mm = true; }
+            } else {
+                const u32 idx = chunk * 64u + (u32)lane;
+                on = idx < np_sh;
+                e = on ? sh_p[idx] : 0u;
+                chunk += (u32)KC_PROBE_WAVES;
+            }
+            settle_listed(on, e >> 1, (int)(e & 1u), mm_in, have_mm);
+            wave_sync();
+            continue;
+        }
+        // ---- 64 k-mers, oldest first (the last chunk of the workgroup's list: fewer)
+        bool active = true;
+        u32 so, rank;                                                            // slot offset in the block; (DN) this k-mer's number within the block
+        if (phase == 0) {
+            so = sstack[(shead + (u32)lane) & (KC_PROBE_SSTACK - 1)];
+            rank = wfirst + shead + (u32)lane;
+            shead += 64;
+        } else {
+            const u32 idx = chunk * 64u + (u32)lane;
+            active = idx < nk_sh;
+            const u32 ent = active ? sh_k[idx] : 0u;
+            so = ent & 0xffffu; rank = ent >> 16;
+            chunk += (u32)KC_PROBE_WAVES;
+        }
+        const u64 slot = base + so;
+        auto own = [&]() -> u64 { return DN ? nb0 + (u64)rank : slot; };        // what a port of this k-mer is numbered by
+        const Key<W> x = load_x(so);
+        const Key<W> xr = key_rc(x, k);
+        const bool xpal = (KC & 1) ? false : (complements && key_eq(x, xr));   // odd k: no palindromes
+        const bool split = !SH && (((u32)nb0 + rank) & 0xffu) == 0;            // every 256th k-mer is a splitter of the segment-parallel walks
+        const u64 ownbits = SH ? LK_OWN_BITS(so) : 0;                           // (hash-sharded flow: the words carry the slot offset of their k-mer)
+        auto deadw = [&]() -> u64 { return LK_MAKE(LK_DEAD, 0, 0, slot) | ownbits; };   // (a dead port's word carries the slot of its k-mer)
+        u32 minL = 0, minR = 0;
+        if (!GP) kc_kmer_mins<W, KC>(x, xr, k, m, minL, minR);
+        u64 wd0 = 0, wd1 = 0;
+        u32 have = 0;
 #pragma unroll 1
-            for (int port = 0; port < 2; ++port) {
-                bool defer = false, done = false;
-                u64 word = 0;
-                const u32 mmh = port ? minR : minL;
-                if (active) {
-                    if (port == 1 && xpal) {   // palindromes link on port L only
-                        word = deadw();
+        for (int port = 0; port < 2; ++port) {
+            bool defer = false, done = false;
+            u64 word = 0;
+            const u32 mmh = port ? minR : minL;
+            if (active) {
+                if (port == 1 && xpal) {   // palindromes link on port L only
+                    word = deadw();
+                    done = true;
+                    if (!SH && complements) kc_push_sharded((own() << 1) | 1, heads, heads_shard_cap, heads_cursors);
+                } else {
+                    const KcPortDesc d = kc_port_desc<W, KC, GP>(set, x, xr, k, complements, port, mmh, base);
+                    bool found; u32 c, q; u64 sl;
+                    if ((GP || (d.home >> set.bshift) == blk) && kc_port_search_one<W, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl, nb0) && (!GP || found)) {
+                        word = found ? (LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) | ownbits) : deadw();
                         done = true;
-                        if (!SH && complements) kc_push_sharded((own() << 1) | 1, heads, heads_shard_cap, heads_cursors);
-                    } else {
-                        const KcPortDesc d = kc_port_desc<W, KC>(set, x, xr, k, complements, port, mmh);
-                        bool found; u32 c, q; u64 sl;
-                        if ((d.home >> set.bshift) == blk && kc_port_search_one<W, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, found, c, q, sl, nb0)) {
-                            word = found ? (LK_MAKE(LK_CHOICE, q, port ? c : 3u - c, sl) | ownbits) : deadw();
-                            done = true;
-                            if (!SH && !found && (complements || port == 0)) kc_push_sharded((own() << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
-                        } else defer = true;
-                    }
+                        if (!SH && !found && (complements || port == 0)) kc_push_sharded((own() << 1) | (u64)port, heads, heads_shard_cap, heads_cursors);   // cf. kc_push_head
+                    } else defer = true;
                 }
-                const unsigned long long dm = __ballot(defer);
-                if (dm) {
-                    const u32 nd = (u32)__popcll(dm);
-                    if (ecnt + nd <= (u32)ECAP) {
-                        if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); if (MM) emmh[at] = mmh; }
-                        ecnt += nd;
-                    } else if (defer) to_spill((slot << 1) | (u64)port);   // (no room on the stack; SH: the spill kernel turns remote ones into queries)
-                }
-                if (done) { if (port) wd1 = word; else wd0 = word; have |= 1u << port; }
             }
-            // both words of a k-mer in one 16-byte store whenever both ports were settled here
-            if (split) { wd0 |= LK_SPLIT; wd1 |= LK_SPLIT; }
-            u64 *lw = link + (own() << 1);
-            if (have == 3u) *reinterpret_cast<ulonglong2 *>(lw) = make_ulonglong2(wd0, wd1);
-            else if (have == 1u) lw[0] = wd0;
-            else if (have == 2u) lw[1] = wd1;
-            wave_sync();
+            const unsigned long long dm = __ballot(defer);
+            if (dm) {
+                const u32 nd = (u32)__popcll(dm);
+                if (ecnt + nd <= (u32)ECAP) {
+                    if (defer) { const u32 at = ecnt + (u32)__popcll(dm & ltm); epid[at] = (unsigned short)((so << 1) | (u32)port); if (MM && !GP) emmh[at] = mmh; }
+                    ecnt += nd;
+                } else if (defer) to_spill((slot << 1) | (u64)port);   // (no room on the stack; SH: the spill kernel turns remote ones into queries)
+            }
+            if (done) { if (port) wd1 = word; else wd0 = word; have |= 1u << port; }
         }
+        // both words of a k-mer in one 16-byte store whenever both ports were settled here
+        if (split) { wd0 |= LK_SPLIT; wd1 |= LK_SPLIT; }
+        u64 *lw = link + (own() << 1);
+        if (have == 3u) *reinterpret_cast<ulonglong2 *>(lw) = make_ulonglong2(wd0, wd1);
+        else if (have == 1u) lw[0] = wd0;
+        else if (have == 2u) lw[1] = wd1;
+        wave_sync();
     }
 }
 // the ports the block kernel handed on (rare): generic lookups, one thread per port, grid-stride over the device-side count

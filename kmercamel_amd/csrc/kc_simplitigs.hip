@@ -961,12 +961,19 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                                heads_cursors, branch_sh, branch_shard_cap, branch_cursors, spill, spill_cap, spill_cursor, ShLists{});
             return KC_OK;
         };
+        // GP: every key sits at its primary home (a fresh bucketed build without spills): the sweep guesses "the candidates live in my
+        // own block" and computes no minimizers (see the kernel); KC_PROBE_NO_GUESS=1: the form that computes them for every k-mer
+        const bool gp = set->homes_primary && !getenv("KC_PROBE_NO_GUESS");
+        if (getenv("KC_SIMP_TRACE")) fprintf(stderr, "[simp] probe kernel: in-block guess %s\n", gp ? "on" : "off");
         if (stage_keys) {
             if constexpr (W == 1) {
-                if (nt == 1024) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false>));
-                else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 512, true>) : launch(kc_probe_block_kernel<W, 0, true, 512, true>));
+                if (nt == 1024) {
+                    if (gp) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false, false, true>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false, false, true>));
+                    else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false>));
+                } else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 512, true>) : launch(kc_probe_block_kernel<W, 0, true, 512, true>));
             }
-        } else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true>));
+        } else if (gp) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true, false, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true, false, true>));
+        else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true>));
     } else {
         // plain hashing (k < 18): per-key homes, 8 lookups per k-mer
         const unsigned cgrid = kc_grid8(cap, KC_CHOOSE_SLOTS);

@@ -4,7 +4,10 @@
 
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 exactly 1/2 of a wide coalesced streaming read (calibrated here on kc_pack2bit_kernel, whose read volume is known:
-it reads every input byte once with 16-B loads), so reads are doubled; WRITE_SIZE is taken as is."""
+it reads every input byte once with 16-B loads), so reads are doubled; WRITE_SIZE is taken as is.
+Round 6 (profiles/r06_fetch_calibration.txt, tools/fetch_calib.hip): FETCH_SIZE is TCC_EA0_RDREQ x 64 B for every access class, and
+every request is one 128-byte line, scattered or streamed -- so the x2 gives the bytes of the lines requested for scattered lookups too,
+and `fetch_requests` (raw / 64) is the number to hold against the ~50 G requests/s this GPU sustains for either class."""
 import csv
 import glob
 import json
@@ -32,7 +35,7 @@ def main(src, tag):
         fetch, write = a.get("FETCH_SIZE", 0.0) * 1024 / n, a.get("WRITE_SIZE", 0.0) * 1024 / n
         hit, miss = a.get("TCC_HIT_sum", 0.0), a.get("TCC_MISS_sum", 0.0)
         out[k] = {"launches_per_pass": n, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
-                  "hbm_bytes_per_launch": 2 * fetch + write, "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
+                  "hbm_bytes_per_launch": 2 * fetch + write, "fetch_requests": fetch / 64, "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
     pk = [k for k in out if "kc_pack2bit_kernel" in k]
     if pk:
         # calibration: the pack kernel reads `len` input bytes exactly once
