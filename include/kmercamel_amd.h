@@ -28,6 +28,8 @@ extern "C" {
 #define KC_E_IO (-6)          /* "couldn't open file" (parser.h:95-97) */
 #define KC_E_NO_KMERS (-7)    /* input holds no k-mers (main.cpp:155-158) */
 #define KC_E_TRANSPORT (-8)   /* an exchange of the hash-sharded path failed (RCCL error, transport callback, peer copy) */
+#define KC_E_UNSUPPORTED_SHARDED (-9) /* a valid request that the hash-sharded path does not serve (every rank returns it together, nothing has been
+                                         exchanged): run it through kc_compute on one GPU -- the CLI does that by itself */
 
 typedef struct kc_ctx kc_ctx;
 typedef struct kc_set kc_set;
@@ -168,7 +170,7 @@ int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, ui
 int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner);
 /* The greedy branch of kmercamel<>() over all ranks' records: `seq`/`len` are THIS rank's records (joined by '\n', may be
  * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE, KC_FLAG_WANT_MASK, KC_FLAG_MIN_FREQUENCY
- * (k >= 18; -S input: kc_compute_sharded_simplitigs).  KC_E_ARG with a message ending in "not part of the hash-sharded path" is
+ * (k >= 18; -S input: kc_compute_sharded_simplitigs).  KC_E_UNSUPPORTED_SHARDED is
  * returned by ALL ranks together for inputs the path does not cover (the sparse branch, main.cpp:175; -z with overflowing table
  * blocks): the caller then runs kc_compute on one GPU.  The result holds this rank's slice; stats as kc_result_stats with global
  * counts. */

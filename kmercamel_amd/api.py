@@ -11,10 +11,11 @@ import gzip
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmercamel_amd.so")
+# (KMERCAMEL_AMD_LIB: the tools' A/B runs point this at another in-tree build, e.g. `make experiments` -> libkmercamel_amd_exp.so)
+LIB_PATH = os.environ.get("KMERCAMEL_AMD_LIB") or os.path.join(_HERE, "libkmercamel_amd.so")
 
 KC_OK = 0
-KC_E_NO_DEVICE, KC_E_EMPTY, KC_E_INVALID_CHAR, KC_E_ARG, KC_E_CAPACITY, KC_E_IO, KC_E_NO_KMERS, KC_E_TRANSPORT = -1, -2, -3, -4, -5, -6, -7, -8
+KC_E_NO_DEVICE, KC_E_EMPTY, KC_E_INVALID_CHAR, KC_E_ARG, KC_E_CAPACITY, KC_E_IO, KC_E_NO_KMERS, KC_E_TRANSPORT, KC_E_UNSUPPORTED_SHARDED = -1, -2, -3, -4, -5, -6, -7, -8, -9
 FLAG_COMPLEMENTS, FLAG_SIMPLITIGS_INPUT, FLAG_WANT_MASK, FLAG_INPUT_ON_DEVICE = 1, 2, 4, 8
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)

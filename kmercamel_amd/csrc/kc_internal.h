@@ -105,6 +105,15 @@ struct kc_result {
     u64 stats_ext[16] = {0};   // [0] cycles cut by the simplitig rule, [1] k-mers on this rank, [2] neighbour queries sent (sharded runs)
 };
 
+// Timing experiments that SKIP work (stores, inserts, loads) and therefore produce WRONG results exist only in the tools' build
+// (`make experiments` -> libkmercamel_amd_exp.so, -DKC_EXPERIMENTS): in the shipped library the macro is a null pointer and the
+// variable's name is not even in the binary (tests/test_cpu_oracle.py checks `strings`).
+#ifdef KC_EXPERIMENTS
+#define KC_EXP_KNOB(name) getenv(name)
+#else
+#define KC_EXP_KNOB(name) ((const char *)nullptr)
+#endif
+
 // Set by kc_grid when a launch would need 2^32 or more threads in one dimension (a dispatch carries its size as 32 bits per
 // dimension).  KC_LAUNCH -- the only way this library launches a kernel -- tests it right after the grid expression has been
 // evaluated and returns KC_E_ARG from the calling function BEFORE anything is launched, so no later kernel ever sees the output a

@@ -1390,7 +1390,7 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
             if (const char *e = getenv("KC_SCATTER_CHUNKS")) { const int v = atoi(e); if (v >= 2 && v <= 4096) chunks = v & ~1; }   // tuning knob
             const u64 nwaves = (len + 64 * (u64)chunks - 1) / (64 * (u64)chunks);
             int exp_ = 0;
-            if (const char *e = getenv("KC_SCATTER_EXP")) exp_ = atoi(e) & 3;   // (timing experiments: see the kernel)
+            if (const char *e = KC_EXP_KNOB("KC_SCATTER_EXP")) exp_ = atoi(e) & 3;   // (timing experiments: see the kernel)
             if (getenv("KC_SCATTER_V1") || exp_)
             KC_LAUNCH(kc_bucket_scatter_wave_kernel, dim3(kc_grid(nwaves * 64, 256)), dim3(256), 0, ctx->stream, d_codes, d_brk, d_low, len, set->k, set->complements,
                                case_sensitive, kc_view_raw<1>(set), bucket, bcursor, set->counters, chunks | (exp_ << 16), sovf, sovf_cap);
@@ -1460,11 +1460,11 @@ template <int W> static int insert_bucketed_w(kc_set *set, const u64 *d_codes, c
     KC_HIP(ctx, hipMemsetAsync(set->counters + 4, 0, 8, ctx->stream));
     if (getenv("KC_NO_BUILD_IDS"))   // (test knob: the sweep of kcs_prepare_dense instead)
         KC_LAUNCH(kc_block_build_kernel<W>, dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0) | (getenv("KC_BUILD_EXP") ? (atoi(getenv("KC_BUILD_EXP")) & 7) << 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0) | (KC_EXP_KNOB("KC_BUILD_EXP") ? (atoi(KC_EXP_KNOB("KC_BUILD_EXP")) & 7) << 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, (u32 *)nullptr);
     else {
         KC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kc_block_build_kernel<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KC_MAX_DYN_LDS));
         KC_LAUNCH((kc_block_build_kernel<W, true>), dim3((unsigned)set->nblocks), dim3(1024), lds_build, ctx->stream, kc_view_raw<W>(set), (const u64 *)bucket,
-                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0) | (getenv("KC_BUILD_EXP") ? (atoi(getenv("KC_BUILD_EXP")) & 7) << 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
+                           (const u64 *)bcursor, fresh | (getenv("KC_BUILD_NOPREFETCH") ? 2 : 0) | (getenv("KC_BUILD_ST8") ? 4 : 0) | (KC_EXP_KNOB("KC_BUILD_EXP") ? (atoi(KC_EXP_KNOB("KC_BUILD_EXP")) & 7) << 4 : 0), set->counters, ovf, ovf_cap, (const u64 *)nullptr, 0, merge_r, 0, set->ncount);
         KC_LAUNCH(kc_max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, (const u32 *)set->ncount, set->nblocks, set->counters + 4);
     }
     KC_HIP(ctx, hipGetLastError());
@@ -1778,7 +1778,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     if (min_count > 1) {   // (collective: a rank whose blocks overflowed takes everybody out of the sharded path)
         u64 lost = h[3];
         KC_TRY(kcc_allreduce_max(c, &lost, 1));
-        if (lost) return kc_fail_agreed(ctx, KC_E_ARG, "-z with table blocks that overflow is not part of the hash-sharded path");
+        if (lost) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "-z with table blocks that overflow is not part of the hash-sharded path");
     }
     if (getenv("KC_SET_TRACE"))
         fprintf(stderr, "[set] rank %d/%d sharded build W=%d: %llu of %llu blocks (2^%d slots), %llu occurrences in, %llu received, size %llu, spills %llu\n", c->rank, G, W,
@@ -1798,7 +1798,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
 int kcs_build_sharded(kc_set *set, kc_comm *c, const u64 *d_codes, const u64 *d_brk, const u64 *d_low, u64 len, u64 *moved, int min_count) {
     kcs_void_dense(set);
     if (min_count > 1 && (((size_t)1 << set->bshift) * (8 * (size_t)set->W + 3) > KC_MAX_DYN_LDS || set->bshift > 15))
-        return kc_fail_agreed(set->ctx, KC_E_ARG, "-z with this table geometry is not part of the hash-sharded path");
+        return kc_fail_agreed(set->ctx, KC_E_UNSUPPORTED_SHARDED, "-z with this table geometry is not part of the hash-sharded path");
     switch (set->W) {
         case 1: return build_sharded_w<1>(set, c, d_codes, d_brk, d_low, len, moved, min_count);
         case 2: return build_sharded_w<2>(set, c, d_codes, d_brk, d_low, len, moved, min_count);

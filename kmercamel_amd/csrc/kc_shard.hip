@@ -547,12 +547,13 @@ __global__ void __launch_bounds__(256) kc_br_mark_kernel(const u64 *__restrict__
     if (j >= n) return;
     const u64 *e = rows + perm[j] * (u64)EW;
     bool k = e[0] != e[1];
-    if (j > 0) {
-        const u64 *p = rows + perm[j - 1] * (u64)EW;
-        if (p[2] == e[2]) {
-            const bool same = (p[0] == e[1] && p[1] == e[0]) || (p[0] == e[0] && p[1] == e[1]);
-            if (same) k = false; else if (e[0] != e[1] && p[0] != p[1]) flags[0] = 1;
-        }
+    // every earlier row of the same priority is looked at (a run is one or two rows unless 64-bit priorities collide): the second
+    // listing of an edge need not sit right behind the first when a third row -- a self-loop, another edge -- shares the priority
+    for (u64 i = j; i > 0; --i) {
+        const u64 *p = rows + perm[i - 1] * (u64)EW;
+        if (p[2] != e[2]) break;
+        const bool same = (p[0] == e[1] && p[1] == e[0]) || (p[0] == e[0] && p[1] == e[1]);
+        if (same) k = false; else if (e[0] != e[1] && p[0] != p[1]) flags[0] = 1;
     }
     keep[j] = k ? 1 : 0;
 }
@@ -1784,7 +1785,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     u64 *all_chains = nullptr, S = 0;
     KC_TRY(allgather_rows(c, chains, n_chains, CW, &all_chains, &S, nullptr));
     scope.release(chains);
-    if (S * 5 >= N) { kc_release(ctx, all_chains); return kc_fail_agreed(ctx, KC_E_ARG, "too many simplitigs for the dense overlap graph (main.cpp:175): the sparse branch is not part of the hash-sharded path"); }
+    if (S * 5 >= N) { kc_release(ctx, all_chains); return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "too many simplitigs for the dense overlap graph (main.cpp:175): the sparse branch is not part of the hash-sharded path"); }
     kc_simplitigs *simp = new kc_simplitigs();
     simp->ctx = ctx; simp->k = k; simp->W = W; simp->n = S;
     struct SimpGuard { kc_simplitigs *s; ~SimpGuard() { if (s) kc_simplitigs_destroy(s); } } simpg{simp};
@@ -2064,8 +2065,9 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     *out = nullptr;
     ctx->err_agreed = false;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
-    if (k < 18 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
-    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail_agreed(ctx, KC_E_ARG, "-S is not part of the hash-sharded path (use kc_compute)");
+    if (k >= 1 && k < 18) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "k < 18 (plain hashing, no minimizer blocks) is not part of the hash-sharded path");
+    if (k < 1 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
+    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "-S is not part of the hash-sharded path (use kc_compute)");
     const int min_frequency = ((flags >> 8) & 0xff) ? (int)((flags >> 8) & 0xff) : 1;   // -z (parser.h:122-141): counted where all occurrences of a k-mer meet, at its owner
     const int want_mask = (flags & KC_FLAG_WANT_MASK) ? 1 : 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
@@ -2098,7 +2100,7 @@ extern "C" int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const v
     ctx->err_agreed = false;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
     if (k < 1 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "k must be in 1..127");
-    if (flags & KC_FLAG_WANT_MASK) return kc_fail_agreed(ctx, KC_E_ARG, "-S with -M is not part of the hash-sharded path");
+    if (flags & KC_FLAG_WANT_MASK) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "-S with -M is not part of the hash-sharded path");
     if (((flags >> 8) & 0xff) > 1) return kc_fail(ctx, KC_E_ARG, "Inputting simplitigs is not compatible with frequency filterring.");
     KC_HIP(ctx, hipSetDevice(ctx->device));
     const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;

@@ -973,8 +973,19 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 u64 cs[4]; u32 qb;
                 u32 eoff = 0;
                 const u64 sblk = (xcd_aware & 2) ? ~(u64)0 : blk;   // (bit 1: test knob, table reads only)
-                const bool ok = kc_port_search<W, 2, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, cs, qb, sblk, &eoff);
-                if (!ok) to_spill((slot << 1) | (u64)port);   // (rare: generic lookups in a kernel of their own keep this one lean)
+                // (tried in round 6 and dropped: a home in another block looked up from its first four KEY words alone -- one line instead of
+                // tag line + key line whenever the run ends inside them -- measured 73.2 ms against 71.1 for this form at 2.5 10^9 k-mers)
+                bool ok, skipped = false;
+#ifdef KC_EXPERIMENTS
+                // KC_PROBE_DOWN_SPILL (timing experiment, results stay right): what the sweep costs without half of its cross-block lookups --
+                // a port whose home lies in an EARLIER block is not looked up; the spill list is declared overflowed instead, so that the
+                // generic kernel redoes round 1 afterwards
+                if ((xcd_aware & 16) && (d.home >> set.bshift) < blk) { skipped = true; *spill_cursor = spill_cap + 1; }
+#endif
+                ok = skipped ? true : kc_port_search<W, 2, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, cs, qb, sblk, &eoff);
+                auto delta_of = [&]() -> u64 { return kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk); };
+                if (skipped) { }
+                else if (!ok) to_spill((slot << 1) | (u64)port);   // (rare: generic lookups in a kernel of their own keep this one lean)
                 else if (SH) {
                     // at most one candidate: the word; a branch port is settled (and lists its edges) in the spill kernel
                     u32 nf = 0, bc = 0;
@@ -985,12 +996,12 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                     if (nf >= 2) to_spill((slot << 1) | (u64)port);
                     else {
                         const u64 nid = nb0 + local_rank(so);
-                        const u64 tgt = nf ? bs1 + kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk) : slot;
+                        const u64 tgt = nf ? bs1 + delta_of() : slot;
                         link[(nid << 1) | (u64)port] = (nf ? LK_MAKE(LK_CHOICE, (qb >> bc) & 1u, port ? bc : 3 - bc, tgt) : LK_MAKE(LK_DEAD, 0, 0, tgt)) | LK_OWN_BITS(so);
                     }
                 }
                 else {
-                    const u64 delta = kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk);
+                    const u64 delta = delta_of();
                     const u64 nid = nb0 + local_rank(so);
                     link[(nid << 1) | (u64)port] = kc_choose_port<W>(k, complements, nid, slot, port, x, xr, cs, qb, heads, heads_shard_cap, heads_cursors, branch,
                                                                      branch_shard_cap, branch_cursors, delta, KC_WK_TAG(so));
@@ -1021,6 +1032,10 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     u32 shead = 0, stail = 0, ecnt = 0;   // slot ring: taken / queued so far; entries on the port stack (all wave-uniform)
     // phase 0: the wave sweeps its share; 1: the workgroup's left-over k-mers, chunk by chunk; 2: the workgroup's left-over listed ports
     u32 row = 0, phase = 0, chunk = (u32)wv, nk_sh = 0, np_sh = 0;
+    // (xcd_aware bit 2, A/B knob KC_PROBE_NO_SHARE: every wave keeps its leftovers to itself -- a list of its own inside the shared
+    // area, worked off in one nearly empty step each, as before round 6)
+    const bool own_left = (xcd_aware & 4) != 0;
+    u32 lbase_k = 0, lbase_p = 0;
 #pragma unroll 1
     for (;;) {
         // what this wave does next (wave-uniform): 0 = a step of 64 k-mers, 1 = a step of 64 listed ports, 2 = queue a row of slots,
@@ -1056,14 +1071,15 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
 #pragma unroll
             for (int i = 0; i < KC_PROBE_WAVES; ++i) { const u32 c = kc_wleft[phase][i]; at += i < wv ? c : 0u; tot += c; }
             at = __builtin_amdgcn_readfirstlane(at); tot = __builtin_amdgcn_readfirstlane(tot);
+            if (own_left) { at = (u32)wv * (phase == 0 ? 64u : (u32)ECAP); tot = cnt; }
             if ((u32)lane < cnt) {
                 if (phase == 0) sh_k[at + (u32)lane] = ent;
                 else sh_p[at + (u32)lane] = (unsigned short)ent;
             }
             __syncthreads();
-            if (phase == 0) { nk_sh = tot; shead = stail; } else { np_sh = tot; ecnt = 0; }
+            if (phase == 0) { nk_sh = tot; shead = stail; lbase_k = own_left ? at : 0u; } else { np_sh = tot; ecnt = 0; lbase_p = own_left ? at : 0u; }
             ++phase;
-            chunk = (u32)wv;
+            chunk = own_left ? 0u : (u32)wv;
             continue;
         }
         if (act == 1) {
@@ -1077,7 +1093,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             } else {
                 const u32 idx = chunk * 64u + (u32)lane;
                 on = idx < np_sh;
-                e = on ? sh_p[idx] : 0u;
+                e = on ? sh_p[lbase_p + idx] : 0u;
                 chunk += (u32)KC_PROBE_WAVES;
             }
             settle_listed(on, e >> 1, (int)(e & 1u), mm_in, have_mm);
@@ -1094,7 +1110,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
         } else {
             const u32 idx = chunk * 64u + (u32)lane;
             active = idx < nk_sh;
-            const u32 ent = active ? sh_k[idx] : 0u;
+            const u32 ent = active ? sh_k[lbase_k + idx] : 0u;
             so = ent & 0xffffu; rank = ent >> 16;
             chunk += (u32)KC_PROBE_WAVES;
         }

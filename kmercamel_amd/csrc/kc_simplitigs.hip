@@ -229,8 +229,14 @@ __global__ void __launch_bounds__(1024) kc_heads_by_class_kernel(const u64 *__re
 }
 #define LK_WALKED (1ull << 62)          /* on a dead port: the chain that ends here was walked from its other end (kc_walk_measure_kernel) */
 #define KC_STREAM_TURNED (1ull << 63)   /* chain_stream: the recording runs from the chain's LAST k-mer: the emit writes its reverse complement */
+// the class passes were voided (a chain beyond the limit, cycles): the marks they left on dead ports go away with them, so that bit 62 of
+// a link word means nothing outside kc_walk_measure_kernel's own launches
+static __global__ void __launch_bounds__(256) kc_clear_walked_kernel(u64 *link, const u64 *__restrict__ heads, u64 n) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { const u64 w = link[heads[t]]; if (w & LK_WALKED) link[heads[t]] = w & ~LK_WALKED; }
+}
 template <int W, bool MARK, bool REC, bool FRAG = false>
-__global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *__restrict__ link, int complements,
+__global__ void __launch_bounds__(256) kc_walk_measure_kernel(SetView<W> set, const u64 *link, int complements,   // (no __restrict__: link_marks may alias link)
                                                               const u64 *__restrict__ heads, u64 nheads, u8 *visited,
                                                               u64 *chain_head, u64 *chain_len, u64 *chain_key, u64 *cursor, u64 limit, KcRec rec,
                                                               KcFrag frag = KcFrag{nullptr, nullptr, 0, 0}, u64 *link_marks = nullptr, int cls_pass = 0,
@@ -957,7 +963,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), nt, lds);
                 fprintf(stderr, "[simp] probe kernel: %d threads, %zu bytes of LDS per workgroup, %d workgroups per CU\n", nt, lds, nb);
             }
-            KC_LAUNCH(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware | (getenv("KC_PROBE_LISTED_GLOBAL") ? 2 : 0), heads_sh, heads_shard_cap,
+            KC_LAUNCH(kern, dim3(pgrid), dim3(nt), lds, ctx->stream, sv, link, k, compl_, xcd_aware | (getenv("KC_PROBE_LISTED_GLOBAL") ? 2 : 0) | (getenv("KC_PROBE_NO_SHARE") ? 4 : 0) | (KC_EXP_KNOB("KC_PROBE_DOWN_SPILL") ? 16 : 0), heads_sh, heads_shard_cap,
                                heads_cursors, branch_sh, branch_shard_cap, branch_cursors, spill, spill_cap, spill_cursor, ShLists{});
             return KC_OK;
         };
@@ -1174,6 +1180,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
                 // let the classic flow below run on the original links
                 KC_LAUNCH(kc_frag_restore_kernel, dim3((unsigned)set->nblocks), dim3(256), 0, ctx->stream, link, (const u64 *)flog,
                                    (const u64 *)fblog, set->bshift, (u64)0, nstride);
+                if (compl_ && !getenv("KC_WALK_BOTH")) KC_LAUNCH(kc_clear_walked_kernel, dim3(kc_grid(nheads, 256)), dim3(256), 0, ctx->stream, link, (const u64 *)heads, nheads);
                 KC_HIP(ctx, hipMemsetAsync(cnt, 0, 64, ctx->stream));
                 if (hf[7]) known_long = true;
                 use_frag = false;

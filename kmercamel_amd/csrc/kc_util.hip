@@ -38,15 +38,15 @@ int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n, bool sync) {
     }
     u64 *sums = nullptr;
     KC_TRY(kc_alloc(ctx, &sums, ntiles + 1));
+    // (on every way out, a launch that KC_LAUNCH refused included: sync = false hands the temporaries back at once -- whoever gets them
+    // next works on the same stream, behind us)
+    auto rel = kc_defer([&] { if (sync) (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, sums); });
     KC_LAUNCH(kc_scan_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, sums);
     int rc = kcu_exclusive_scan(ctx, sums, sums, ntiles, sync);
     if (rc == KC_OK) {
         KC_LAUNCH(kc_scan_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, in, n, (const u64 *)sums, out, ntiles);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "scan launch failed");
     }
-    // (sync = false: the temporaries go back to the pool at once; whoever gets them next works on the same stream, behind us)
-    if (sync) (void)hipStreamSynchronize(ctx->stream);
-    kc_release(ctx, sums);
     return rc;
 }
 
@@ -80,6 +80,7 @@ int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *
     const u64 ntiles = (n + KC_SCAN_TILE - 1) / KC_SCAN_TILE;
     u64 *counts = nullptr;
     KC_TRY(kc_alloc(ctx, &counts, ntiles + 1));
+    auto rel = kc_defer([&] { if (sync) (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, counts); });   // (on every way out)
     KC_LAUNCH(kc_flag_counts_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, flags, n, counts);
     int rc = kcu_exclusive_scan(ctx, counts, counts, ntiles, sync);
     if (rc == KC_OK) {
@@ -87,8 +88,6 @@ int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "compaction launch failed");
         if (rc == KC_OK && d_total && hipMemcpyAsync(d_total, counts + ntiles, 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) rc = KC_E_NO_DEVICE;
     }
-    if (sync) (void)hipStreamSynchronize(ctx->stream);
-    kc_release(ctx, counts);
     return rc;
 }
 
@@ -441,13 +440,14 @@ int kcr_forward(kc_comm *c, const KcRoute &r, const u64 *items, int E, int strid
     KC_TRY(kc_alloc(ctx, &send, r.n * (u64)E + 1));
     int rc = kc_alloc(ctx, &recv, r.n_recv * (u64)E + 1);
     if (rc != KC_OK) { kc_release(ctx, send); return rc; }
+    bool keep_recv = false;
+    auto rel = kc_defer([&] { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, send); if (!keep_recv) kc_release(ctx, recv); });   // (a refused launch included)
     if (r.n) KC_LAUNCH(kc_route_gather_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, items, (const u64 *)r.perm, r.n, E, stride, send);
     std::vector<u64> so(G), sc(G), ro(G), rcv(G);
     for (int p = 0; p < G; ++p) { so[p] = r.soff[p] * E * 8; sc[p] = r.scnt[p] * E * 8; ro[p] = r.roff[p] * E * 8; rcv[p] = r.rcnt[p] * E * 8; }
     rc = kcc_alltoallv(c, send, so.data(), sc.data(), recv, ro.data(), rcv.data());
-    (void)hipStreamSynchronize(ctx->stream);
-    kc_release(ctx, send);
-    if (rc != KC_OK) { kc_release(ctx, recv); return rc; }
+    if (rc != KC_OK) return rc;
+    keep_recv = true;
     *recv_out = recv;
     return KC_OK;
 }
@@ -457,6 +457,7 @@ int kcr_backward(kc_comm *c, const KcRoute &r, const u64 *answers, int A, u64 *o
     const int G = c->world;
     u64 *tmp = nullptr;
     KC_TRY(kc_alloc(ctx, &tmp, r.n * (u64)A + 1));
+    auto rel = kc_defer([&] { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, tmp); });   // (a refused launch included)
     std::vector<u64> so(G), sc(G), ro(G), rcv(G);
     for (int p = 0; p < G; ++p) { so[p] = r.roff[p] * A * 8; sc[p] = r.rcnt[p] * A * 8; ro[p] = r.soff[p] * A * 8; rcv[p] = r.scnt[p] * A * 8; }
     int rc = kcc_alltoallv(c, answers, so.data(), sc.data(), tmp, ro.data(), rcv.data());
@@ -464,7 +465,5 @@ int kcr_backward(kc_comm *c, const KcRoute &r, const u64 *answers, int A, u64 *o
         KC_LAUNCH(kc_route_scatter_kernel, dim3(kc_grid(r.n, 256)), dim3(256), 0, ctx->stream, (const u64 *)tmp, (const u64 *)r.perm, r.n, A, out);
         if (hipGetLastError() != hipSuccess) rc = kc_fail(ctx, KC_E_NO_DEVICE, "route scatter launch failed");
     }
-    (void)hipStreamSynchronize(ctx->stream);
-    kc_release(ctx, tmp);
     return rc;
 }

@@ -182,6 +182,13 @@ struct MappedOutput {
             if (trace) std::cerr << "[cli] output pages mapped: " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() << " ms" << std::endl;
         });
     }
+    // the process is about to end abnormally while other threads may still be storing into the mapping (the touch threads, other ranks'
+    // copy threads): anonymous memory takes the mapping's place FIRST -- a store past the new end of a truncated MAP_SHARED file would
+    // raise SIGBUS -- then the file goes back to empty.  No destructor runs behind this (the caller leaves through _exit).
+    void neutralise() {
+        if (map) (void)::mmap(map, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_FIXED, -1, 0);
+        if (fd >= 0 && ::ftruncate(fd, 0) != 0) {}
+    }
     // the mapping cannot take this result (or is not wanted after all): the file goes back to empty, the caller writes through the descriptor
     void abandon() {
         settle();
@@ -292,10 +299,10 @@ static int run_compute_sharded_streamed(const std::string &path, int k, std::ost
     int arrived = 0, not_fasta = 0;
     bool out_ready = false, mapped = false, mmapped = false;
     // a rank that cannot go on ends the process (its peers would wait for it forever) -- but not with output files of the preallocated
-    // size and whatever the pages hold: they go back to empty first (ftruncate is all this does: no destructors run behind _exit)
+    // size and whatever the pages hold: they go back to empty first (MappedOutput::neutralise; no destructors run behind _exit)
     auto die = [&]() {
-        if (om.fd >= 0 && ::ftruncate(om.fd, 0) != 0) {}
-        if (omm.fd >= 0 && ::ftruncate(omm.fd, 0) != 0) {}
+        om.neutralise();    // (both mappings turned harmless and both files emptied before anything can fault)
+        omm.neutralise();
         _exit(1);
     };
     auto rank_main = [&](int r) {
@@ -320,7 +327,7 @@ static int run_compute_sharded_streamed(const std::string &path, int k, std::ost
         if (d_seq) kc_device_free(ctx, d_seq);
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
-        const bool sparse_case = rc == KC_E_ARG && err[r].find("not part of the hash-sharded path") != std::string::npos;
+        const bool sparse_case = rc == KC_E_UNSUPPORTED_SHARDED;   // (a request the sharded path does not serve: one GPU takes it)
         if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; die(); }
         if (rc == KC_OK) {
             if (r == 0) {
@@ -440,7 +447,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         rcs[r] = rc;
         if (rc != KC_OK) err[r] = kc_last_error(ctx);
         // S >= N / 5 (main.cpp:175, the sparse branch): every rank learns it from the same replicated simplitig list and returns together
-        const bool sparse_case = rc == KC_E_ARG && err[r].find("not part of the hash-sharded path") != std::string::npos;
+        const bool sparse_case = rc == KC_E_UNSUPPORTED_SHARDED;   // (a request the sharded path does not serve: one GPU takes it)
         if (rc != KC_OK && rc != KC_E_NO_KMERS && !sparse_case) { std::cerr << "kmercamel_amd: rank " << r << ": " << err[r] << " (code " << rc << ")" << std::endl; _exit(1); }
         if (rc == KC_OK) {
             if (r == 0) {

@@ -230,6 +230,19 @@ def test_launch_guard_refuses_2pow32_threads_at_the_call_site():
             assert "hipLaunchKernelGGL" not in txt and "<<<" not in txt, f
 
 
+def test_shipped_library_has_no_wrong_result_knobs():
+    """Timing experiments that skip stores / inserts (KC_SCATTER_EXP, KC_BUILD_EXP: the results are wrong then) are compiled only into
+    the tools' build (-DKC_EXPERIMENTS, `make experiments`); the shipped library does not even contain their names."""
+    lib = os.path.join(ROOT, "kmercamel_amd", "libkmercamel_amd.so")
+    data = open(lib, "rb").read()
+    assert b"_EXP" not in data.replace(b"KC_EXPERIMENTS", b""), "an experiment knob is compiled into the release library"
+    # and the sources read them through KC_EXP_KNOB only
+    for f in os.listdir(os.path.join(ROOT, "kmercamel_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(ROOT, "kmercamel_amd", "csrc", f)).read()
+            assert not re.search(r'getenv\("KC_[A-Z_]*_EXP"\)', txt), f
+
+
 def test_product_never_touches_the_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, "kmercamel_amd")):
         for f in files:

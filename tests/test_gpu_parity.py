@@ -447,6 +447,70 @@ def test_full_size_properties_cfg1(ctx):
     a.close(); b.close()
 
 
+def _export_key_words_np(s, W):
+    """the set's keys as an (n, W) numpy array of 64-bit words (kc_set_export: W words per key), through the C ABI"""
+    import ctypes
+    import numpy as np
+    n = s.size()
+    buf = np.empty(max(1, n * W), dtype=np.uint64)
+    s.ctx.check(s.ctx.lib.kc_set_export(s.h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    return buf[: n * W].reshape(n, W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [63, 127])
+def test_full_size_properties_wide_keys(ctx, k):
+    """BASELINE configs[4] at full size: the wide-key paths (k = 63: two key words, k = 127: four) on 100 000 synthetic records of
+    k - 1 + 1000 bp (10^8 k-mers), through the same oracle-free properties as test_full_size_properties_cfg1: two runs give identical
+    bytes, ones == N, the length bounds, -M has at least as many ones over the same characters, and the k-mer set read back off the
+    output equals the input's set (sizes, order-free checksums over every key word, spot checks both ways)."""
+    import hashlib
+    import numpy as np
+    W = 2 if k < 64 else 4
+    seq = gen.random_joined(100000, k - 1 + 1000, seed=1)
+    raw = seq.tobytes()
+    r = kc.compute(ctx, raw, k, True, want_mask=True)
+    N, S, L = r.stats["n_kmers"], r.stats["n_simplitigs"], r.length
+    out, mask = r.strings(want_mask=True)
+    r.close()
+    assert N == 100000 * 1000                                   # i.i.d. sequence: no duplicate among 10^8 k-mers of 63 / 127 bases
+    assert N + k - 1 <= L <= N + S * (k - 1)
+    o = np.frombuffer(out.encode(), dtype=np.uint8)
+    m = np.frombuffer(mask.encode(), dtype=np.uint8)
+    assert int((o < 97).sum()) == N
+    assert int((m < 97).sum()) >= N and np.array_equal(o & 0xDF, m & 0xDF)
+    r2 = kc.compute(ctx, raw, k, True, want_mask=False)
+    out2, _ = r2.strings()
+    r2.close()
+    assert hashlib.md5(out2.encode()).hexdigest() == hashlib.md5(out.encode()).hexdigest()
+    a = kc.KmerSet(ctx, k, True, capacity_hint=len(raw))
+    a.AddKMers(raw)
+    b = kc.KmerSet(ctx, k, True, capacity_hint=len(out))
+    b.AddKMers(out, case_sensitive=True)
+    assert a.size() == N and b.size() == N
+    ka, kb = _export_key_words_np(a, W), _export_key_words_np(b, W)
+    mix = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        for w in range(W):
+            assert int(ka[:, w].sum(dtype=np.uint64)) == int(kb[:, w].sum(dtype=np.uint64))
+        # a checksum that ties the words of one key together (a per-word sum would not notice words swapped between keys)
+        ha = ka[:, 0] * mix
+        hb = kb[:, 0] * mix
+        for w in range(1, W):
+            ha = (ha ^ ka[:, w]) * mix
+            hb = (hb ^ kb[:, w]) * mix
+        assert int(np.bitwise_xor.reduce(ha)) == int(np.bitwise_xor.reduce(hb)) and int(ha.sum(dtype=np.uint64)) == int(hb.sum(dtype=np.uint64))
+
+    def as_int(row):
+        v = 0
+        for w in range(W):
+            v |= int(row[w]) << (64 * w)
+        return v
+    step = max(1, N // 500)
+    assert all(b.contains([as_int(x) for x in ka[::step][:500]])) and all(a.contains([as_int(x) for x in kb[::step][:500]]))
+    a.close(); b.close()
+
+
 def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
     """The shape real sequencing data has and the benchmark's i.i.d. reads do not: 10x coverage of a 5 Mbp genome by 150 bp
     reads from both strands with 1 % substitution errors -- every k-mer many times over, millions of branch ports, overlaps
