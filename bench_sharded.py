@@ -10,6 +10,19 @@ import sys
 import time
 
 
+def shard_traffic(k):
+    """HBM bytes per launch of the probe kernel on ONE rank's share, from this round's PMC profile of that share (null when absent)."""
+    import bench
+    path = os.path.join(bench.ROOT, "profiles", bench.TRAFFIC_ROUND + "shard_one_traffic.json")
+    try:
+        for kn, v in json.load(open(path)).items():
+            if "kc_probe_block_kernel" in kn:
+                return int(v["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def main(args, world, rank, local_rank, read_len):
     import numpy as np
     import torch
@@ -144,8 +157,10 @@ def main(args, world, rank, local_rank, read_len):
                        "transport": transport},
             "fragment_jump_rounds": st["matching_rounds"], "overlap_repairs": st["overlap_repairs"],
             "per_rank": per_rank,
-            "roofline": {"bound": "hbm", "kernel": "kc_shard_choose_kernel<W,K> (neighbour probe of the slowest rank's shard)", "achieved": round(achieved, 2),
-                         "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / bench.HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "kc_probe_block_kernel<W,K,SK,NT,MM,SH=true> (neighbour probe of the slowest rank's shard: the single-GPU round-1 kernel in its sharded form)",
+                         "achieved": round(achieved, 2),
+                         "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / bench.HBM_PEAK_GBS, 5), "traffic": shard_traffic(k),
+                         "traffic_source": "profiles/%sshard_one_traffic.json (PMC passes of ONE rank's share, tools/shard_one_stats.sh; null: not collected this round)" % bench.TRAFFIC_ROUND,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(us_probe, 1)},
         }
         if checks:

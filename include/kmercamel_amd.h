@@ -170,10 +170,13 @@ int kc_shard_geometry(int k, uint64_t total_occurrences, int world, int rank, ui
 int kc_shard_owner_of(int k, uint64_t total_occurrences, int world, const uint64_t *keys, uint64_t n, uint8_t *owner);
 /* The greedy branch of kmercamel<>() over all ranks' records: `seq`/`len` are THIS rank's records (joined by '\n', may be
  * empty), collective call.  Supported flags: KC_FLAG_COMPLEMENTS, KC_FLAG_INPUT_ON_DEVICE, KC_FLAG_WANT_MASK, KC_FLAG_MIN_FREQUENCY
- * (k >= 18; -S input: kc_compute_sharded_simplitigs).  KC_E_UNSUPPORTED_SHARDED is
- * returned by ALL ranks together for inputs the path does not cover (the sparse branch, main.cpp:175; -z with overflowing table
- * blocks): the caller then runs kc_compute on one GPU.  The result holds this rank's slice; stats as kc_result_stats with global
- * counts. */
+ * (-S input: kc_compute_sharded_simplitigs).  What the hash-sharded flow does not serve itself -- k < 18 (plain hashing: no
+ * minimizer blocks to shard by), the sparse branch (main.cpp:175-181, found out by all ranks together after phase 1), -z with
+ * overflowing table blocks, -S with -M -- stays inside the collective: the ranks' records go to rank 0, which runs kc_compute, and
+ * every rank receives its slice [L r / G, L (r + 1) / G) of the one result (no speed-up for these, but the same contract).  With
+ * KC_SHARD_NO_ROOT_FALLBACK=1 in the environment such a request comes back as KC_E_UNSUPPORTED_SHARDED from ALL ranks together, before
+ * anything is exchanged, and the caller runs kc_compute on one GPU itself (the CLI does).  The result holds this rank's slice; stats
+ * as kc_result_stats with global counts. */
 int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out);
 /* -S over all ranks (simplitigs_from_fasta, simplitigs.h:89-103; main.cpp:150-160): THIS rank's simplitig records one after the other
  * (no separators) with their offsets[0..n_records], as kc_compute takes them; the ranks' records in rank order are the simplitig

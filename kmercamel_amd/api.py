@@ -657,7 +657,7 @@ def compute_sharded(ctx, comm, seq, k, complements=True, device_ptr=None, length
     return ComputeResult(ctx, h)
 
 
-def compute_sharded_simplitigs(ctx, comm, records, k, complements=True):
+def compute_sharded_simplitigs(ctx, comm, records, k, complements=True, want_mask=False):
     """kc_compute_sharded_simplitigs (-S): `records` = THIS rank's simplitigs (list of bytes); collective over comm's ranks."""
     offs, o = [], 0
     for r in records:
@@ -667,7 +667,8 @@ def compute_sharded_simplitigs(ctx, comm, records, k, complements=True):
     arr = (ctypes.c_uint64 * len(offs))(*offs)
     ptr, n, _keep = _host_bytes(b"".join(records))
     h = ctypes.c_void_p()
-    ctx.check(ctx.lib.kc_compute_sharded_simplitigs(ctx.h, comm.h, ptr, n, arr, len(records), k, FLAG_COMPLEMENTS if complements else 0, ctypes.byref(h)))
+    ctx.check(ctx.lib.kc_compute_sharded_simplitigs(ctx.h, comm.h, ptr, n, arr, len(records), k, (FLAG_COMPLEMENTS if complements else 0) | (FLAG_WANT_MASK if want_mask else 0),
+                                                    ctypes.byref(h)))
     return ComputeResult(ctx, h)
 
 

@@ -146,7 +146,7 @@ extern "C" int kc_compute(kc_ctx *ctx, const void *seq, uint64_t len, const uint
                 rc = kcs_build_counted(ctx, k, complements, codes, brk, low, len, min_frequency, &set);
                 (void)hipEventRecord(ctx->ev[7], ctx->stream);
                 if (rc == KC_OK) counted = true;
-                else if (ctx->err_agreed && (rc == KC_E_ARG || rc == KC_E_CAPACITY)) { rc = KC_OK; set = nullptr; }
+                else if (ctx->err_agreed && (rc == KC_E_UNSUPPORTED_SHARDED || rc == KC_E_ARG || rc == KC_E_CAPACITY)) { rc = KC_OK; set = nullptr; }   // (the direct insert takes it)
             }
             if (!counted) { kc_release(ctx, codes); kc_release(ctx, brk); kc_release(ctx, low); codes = brk = low = nullptr; }
         }

@@ -2058,6 +2058,96 @@ template <int W> int compute_sharded_simplitigs_w(kc_ctx *ctx, kc_comm *c, const
     return KC_OK;
 }
 
+// ---- what the hash-sharded flow does not serve itself: k < 18 (plain hashing, no minimizer blocks), the sparse branch (main.cpp:175-181:
+// found out by all ranks together after phase 1), -S with -M (global.h:185-195), -z on table blocks that overflow.  The ranks STAY in
+// the collective: their records go to rank 0, which runs the single-GPU path (kc_compute, the same entry point a one-GPU caller uses),
+// and every rank receives its slice [L r / G, L (r + 1) / G) of the one result -- the contract of every other sharded call, at the
+// speed of one GPU.  (Round 6; until then these requests came back as an error and the CLI ran them on one GPU by itself.)
+static int compute_on_root(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, const u64 *offsets, u64 n_records, int k, uint32_t flags, kc_result **out) {
+    const int G = c->world, me = c->rank;
+    const bool simp = (flags & KC_FLAG_SIMPLITIGS_INPUT) != 0, want_mask = (flags & KC_FLAG_WANT_MASK) != 0;
+    KcScope scope(ctx);
+    u64 mine[2] = {len, n_records}, all[2 * KC_MAX_RANKS_SH];
+    KC_TRY(kcc_allgather_words(c, mine, all, 2));
+    // rank 0 takes the pieces in rank order: plain input with a '\n' behind every piece (a record boundary: any non-ACGT byte separates
+    // k-mers, kmers.h:15-32), simplitig records back to back with their offsets
+    u64 total = 0, nrec = 0;
+    std::vector<u64> so(G, 0), sc(G, 0), ro(G, 0), rcv(G, 0), piece_at(G, 0), rec_at(G, 0);
+    for (int r = 0; r < G; ++r) { piece_at[r] = total; rec_at[r] = nrec; total += all[2 * r] + (simp ? 0 : 1); nrec += all[2 * r + 1]; }
+    u8 *gathered = nullptr;
+    u64 *d_lens = nullptr, *d_all_lens = nullptr;
+    if (me == 0) {
+        KC_TRY(scope.alloc(&gathered, total + 64));
+        KC_HIP(ctx, hipMemsetAsync(gathered, '\n', total + 64, ctx->stream));
+        for (int r = 0; r < G; ++r) { ro[r] = piece_at[r]; rcv[r] = all[2 * r]; }
+    }
+    sc[0] = len;
+    KC_TRY(kcc_alltoallv(c, d_seq, so.data(), sc.data(), gathered, ro.data(), rcv.data()));
+    std::vector<u64> h_offs;
+    if (simp) {   // the records' lengths travel the same way (device words), rank 0 turns them back into offsets
+        std::vector<u64> lens(n_records + 1, 0);
+        for (u64 i = 0; i < n_records; ++i) lens[i] = offsets[i + 1] - offsets[i];
+        KC_TRY(scope.alloc(&d_lens, n_records + 1));
+        if (n_records) KC_HIP(ctx, hipMemcpyAsync(d_lens, lens.data(), n_records * 8, hipMemcpyHostToDevice, ctx->stream));
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (lens is a local)
+        if (me == 0) {
+            KC_TRY(scope.alloc(&d_all_lens, nrec + 1));
+            for (int r = 0; r < G; ++r) { ro[r] = rec_at[r] * 8; rcv[r] = all[2 * r + 1] * 8; }
+        }
+        sc[0] = n_records * 8;
+        KC_TRY(kcc_alltoallv(c, d_lens, so.data(), sc.data(), d_all_lens, ro.data(), rcv.data()));
+        if (me == 0) {
+            h_offs.assign(nrec + 1, 0);
+            if (nrec) KC_HIP(ctx, hipMemcpyAsync(h_offs.data() + 1, d_all_lens, nrec * 8, hipMemcpyDeviceToHost, ctx->stream));
+            KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (u64 i = 0; i < nrec; ++i) h_offs[i + 1] += h_offs[i];
+        }
+    }
+    // rank 0 computes; the others learn the outcome (code, length, statistics) from it
+    kc_result *res0 = nullptr;
+    u64 head[20] = {0}, heads[20 * KC_MAX_RANKS_SH];
+    std::string msg0;
+    if (me == 0) {
+        KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int rc0 = kc_compute(ctx, gathered, total, simp ? h_offs.data() : nullptr, simp ? nrec : 0, k, (flags | KC_FLAG_INPUT_ON_DEVICE), &res0);
+        if (rc0 != KC_OK) msg0 = ctx->err;
+        head[0] = (u64)(long long)rc0;
+        if (rc0 == KC_OK) { head[1] = res0->length; for (int i = 0; i < 16; ++i) head[2 + i] = res0->stats[i]; }
+    }
+    auto drop0 = kc_defer([&] { if (res0) kc_result_destroy(res0); });
+    KC_TRY(kcc_allgather_words(c, head, heads, 20));
+    const int rc0 = (int)(long long)heads[0];
+    if (rc0 != KC_OK) return kc_fail_agreed(ctx, rc0, me == 0 ? msg0 : std::string("rank 0 could not run the request on one GPU (its message says why)"));
+    const u64 L = heads[1];
+    kc_result *r = new kc_result();
+    r->ctx = ctx; r->length = L;
+    r->slice_off = L / (u64)G * (u64)me + (L % (u64)G * (u64)me) / (u64)G;   // = floor(L me / G) without a 128-bit product
+    {
+        const u64 nxt = me + 1 == G ? L : L / (u64)G * (u64)(me + 1) + (L % (u64)G * (u64)(me + 1)) / (u64)G;
+        r->slice_len = nxt - r->slice_off;
+    }
+    for (int i = 0; i < 16; ++i) r->stats[i] = heads[2 + i];
+    auto slice_lo = [&](int p) -> u64 { return p >= G ? L : L / (u64)G * (u64)p + (L % (u64)G * (u64)p) / (u64)G; };
+    int rc = kc_alloc(ctx, &r->d_out, r->slice_len + 8);
+    if (rc == KC_OK && want_mask) rc = kc_alloc(ctx, &r->d_mask, r->slice_len + 8);
+    {   // (agreed: a rank that returned alone here would leave its peers waiting in the exchange below)
+        u64 bad = rc != KC_OK ? 1 : 0;
+        const int rc2 = kcc_allreduce_max(c, &bad, 1);
+        if (rc2 != KC_OK || bad) { kc_result_destroy(r); return rc2 != KC_OK ? rc2 : kc_fail_agreed(ctx, KC_E_NO_DEVICE, "no device memory for a slice of the result (on some rank)"); }
+    }
+    for (int which = 0; which < (want_mask ? 2 : 1); ++which) {
+        for (int p = 0; p < G; ++p) { so[p] = 0; sc[p] = 0; ro[p] = 0; rcv[p] = 0; }
+        if (me == 0) for (int p = 0; p < G; ++p) { so[p] = slice_lo(p); sc[p] = slice_lo(p + 1) - slice_lo(p); }
+        rcv[0] = r->slice_len;
+        const void *src = me == 0 ? (which ? (const void *)res0->d_mask : (const void *)res0->d_out) : nullptr;
+        rc = kcc_alltoallv(c, src, so.data(), sc.data(), which ? (void *)r->d_mask : (void *)r->d_out, ro.data(), rcv.data());
+        if (rc != KC_OK) { kc_result_destroy(r); return rc; }
+    }
+    KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = r;
+    return KC_OK;
+}
+
 }  // namespace
 
 extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, uint64_t len, int k, uint32_t flags, kc_result **out) {
@@ -2065,9 +2155,8 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
     *out = nullptr;
     ctx->err_agreed = false;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
-    if (k >= 1 && k < 18) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "k < 18 (plain hashing, no minimizer blocks) is not part of the hash-sharded path");
-    if (k < 1 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "the hash-sharded path needs 18 <= k <= 127");
-    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "-S is not part of the hash-sharded path (use kc_compute)");
+    if (k < 1 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "k must be in 1..127");
+    if (flags & KC_FLAG_SIMPLITIGS_INPUT) return kc_fail_agreed(ctx, KC_E_ARG, "-S input goes through kc_compute_sharded_simplitigs (records + offsets)");
     const int min_frequency = ((flags >> 8) & 0xff) ? (int)((flags >> 8) & 0xff) : 1;   // -z (parser.h:122-141): counted where all occurrences of a k-mer meet, at its owner
     const int want_mask = (flags & KC_FLAG_WANT_MASK) ? 1 : 0;
     KC_HIP(ctx, hipSetDevice(ctx->device));
@@ -2079,11 +2168,20 @@ extern "C" int kc_compute_sharded(kc_ctx *ctx, kc_comm *comm, const void *seq, u
         if (len) KC_HIP(ctx, hipMemcpyAsync(d_own, seq, len, hipMemcpyHostToDevice, ctx->stream));
         d_seq = d_own;
     }
-    int rc;
-    switch (kc_words_for_k(k)) {
+    int rc = KC_E_UNSUPPORTED_SHARDED;
+    // KC_SHARD_NO_ROOT_FALLBACK=1 (test knob): the requests the sharded flow does not serve come back as KC_E_UNSUPPORTED_SHARDED
+    const bool root_ok = !getenv("KC_SHARD_NO_ROOT_FALLBACK");
+    if (k < 18) ctx->err_agreed = true;   // (k < 18: plain hashing, no minimizer blocks to shard by -- known to every rank without an exchange)
+    else switch (kc_words_for_k(k)) {
         case 1: rc = compute_sharded_w<1>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
         case 2: rc = compute_sharded_w<2>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
         default: rc = compute_sharded_w<4>(ctx, comm, d_seq, len, k, complements, want_mask, min_frequency, out); break;
+    }
+    // every rank holds the same KC_E_UNSUPPORTED_SHARDED here (agreed errors are taken together, before any further exchange): rank 0
+    // runs the request, everybody gets its slice
+    if (rc == KC_E_UNSUPPORTED_SHARDED && ctx->err_agreed) {
+        if (root_ok) { (void)hipStreamSynchronize(ctx->stream); ctx->err_agreed = false; rc = compute_on_root(ctx, comm, d_seq, len, nullptr, 0, k, flags, out); }
+        else if (k < 18) rc = kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "k < 18 (plain hashing, no minimizer blocks) is not part of the hash-sharded path");
     }
     (void)hipStreamSynchronize(ctx->stream);
     kc_release(ctx, d_own);
@@ -2100,8 +2198,8 @@ extern "C" int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const v
     ctx->err_agreed = false;
     if (comm->ctx != ctx) return kc_fail(ctx, KC_E_ARG, "the communicator belongs to another context");
     if (k < 1 || k > 127) return kc_fail_agreed(ctx, KC_E_ARG, "k must be in 1..127");
-    if (flags & KC_FLAG_WANT_MASK) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "-S with -M is not part of the hash-sharded path");
     if (((flags >> 8) & 0xff) > 1) return kc_fail(ctx, KC_E_ARG, "Inputting simplitigs is not compatible with frequency filterring.");
+    if ((flags & KC_FLAG_WANT_MASK) && getenv("KC_SHARD_NO_ROOT_FALLBACK")) return kc_fail_agreed(ctx, KC_E_UNSUPPORTED_SHARDED, "-S with -M is not part of the hash-sharded path");
     KC_HIP(ctx, hipSetDevice(ctx->device));
     const int complements = (flags & KC_FLAG_COMPLEMENTS) ? 1 : 0;
     u8 *d_own = nullptr;
@@ -2112,7 +2210,9 @@ extern "C" int kc_compute_sharded_simplitigs(kc_ctx *ctx, kc_comm *comm, const v
         d_seq = d_own;
     }
     int rc;
-    switch (kc_words_for_k(k)) {
+    // -S with -M (global.h:185-195: the mask needs the k-mer set of all simplitigs): rank 0 runs it, everybody gets its slice
+    if (flags & KC_FLAG_WANT_MASK) rc = compute_on_root(ctx, comm, d_seq, len, offsets, n_records, k, flags | KC_FLAG_SIMPLITIGS_INPUT, out);
+    else switch (kc_words_for_k(k)) {
         case 1: rc = compute_sharded_simplitigs_w<1>(ctx, comm, d_seq, len, offsets, n_records, k, complements, out); break;
         case 2: rc = compute_sharded_simplitigs_w<2>(ctx, comm, d_seq, len, offsets, n_records, k, complements, out); break;
         default: rc = compute_sharded_simplitigs_w<4>(ctx, comm, d_seq, len, offsets, n_records, k, complements, out); break;

@@ -980,7 +980,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 // KC_PROBE_DOWN_SPILL (timing experiment, results stay right): what the sweep costs without half of its cross-block lookups --
                 // a port whose home lies in an EARLIER block is not looked up; the spill list is declared overflowed instead, so that the
                 // generic kernel redoes round 1 afterwards
-                if ((xcd_aware & 16) && (d.home >> set.bshift) < blk) { skipped = true; *spill_cursor = spill_cap + 1; }
+                if ((xcd_aware & 16) && (d.home >> set.bshift) < blk) skipped = true;   // (the overflow is declared once per workgroup, below)
 #endif
                 ok = skipped ? true : kc_port_search<W, 2, SK, DN>(set, k, complements, x, xr, slot, port, d, st, sk, cs, qb, sblk, &eoff);
                 auto delta_of = [&]() -> u64 { return kc_port_delta<W, SK>(set, d.home, eoff, (d.home >> set.bshift) == sblk, sk); };
@@ -1029,6 +1029,9 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             }
         }
     };
+#ifdef KC_EXPERIMENTS
+    if ((xcd_aware & 16) && threadIdx.x == 0 && lblk == 0) *spill_cursor = spill_cap + 1;   // (KC_PROBE_DOWN_SPILL: the generic kernel redoes round 1)
+#endif
     u32 shead = 0, stail = 0, ecnt = 0;   // slot ring: taken / queued so far; entries on the port stack (all wave-uniform)
     // phase 0: the wave sweeps its share; 1: the workgroup's left-over k-mers, chunk by chunk; 2: the workgroup's left-over listed ports
     u32 row = 0, phase = 0, chunk = (u32)wv, nk_sh = 0, np_sh = 0;

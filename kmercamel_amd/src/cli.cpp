@@ -375,7 +375,7 @@ static int run_compute_sharded_streamed(const std::string &path, int k, std::ost
         std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
         return usage_subcommand("compute");
     }
-    if (rcs[0] == KC_E_ARG) { om.abandon(); omm.abandon(); *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }
+    if (rcs[0] == KC_E_UNSUPPORTED_SHARDED) { om.abandon(); omm.abandon(); *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }
     mark("every slice is in place");
     WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     if (!mapped) { if (om.fd >= 0) om.abandon(); WriteName(path, "greedy", k, false, !complements, *of); }
@@ -475,7 +475,7 @@ static int run_compute_sharded(const std::string &path, int k, std::ostream *of,
         std::cerr << "Path '" << path << "' contains no k-mers. Make sure that your file is a FASTA or gzipped FASTA." << std::endl;
         return usage_subcommand("compute");
     }
-    if (rcs[0] == KC_E_ARG) { *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }   // (what the ranks found out together, e.g. the sparse branch: the caller runs the input on one GPU)
+    if (rcs[0] == KC_E_UNSUPPORTED_SHARDED) { *why = err[0]; return KC_CLI_SHARDED_FALLBACK; }   // (what the ranks found out together, e.g. the sparse branch: the caller runs the input on one GPU)
     if (!assume_simplitigs) WriteLog("Finished collecting k-mers: " + std::to_string(st[0]) + " " + std::to_string(k) + "-mers.");
     WriteName(path, "greedy", k, false, !complements, *of);
     if (maskf != nullptr) WriteName(path, "greedy", k, true, !complements, *maskf);

@@ -38,29 +38,39 @@ def main():
     comm = kc.Comm.rccl(ctx, dist) if backend == "nccl" else kc.Comm.torch_host(ctx, dist)
     recs = [r[2] for r in kc.read_records(path)]
     mine = b"\n".join(split_records(recs, rank, world))
-    # mode: "bi" / "uni", optionally with "-zN" (minimum frequency N) or "-S" (the records are simplitigs)
+    # mode: "bi" / "uni", optionally with "-zN" (minimum frequency N) or "-S" (the records are simplitigs), and "-M" (the mask too:
+    # stored behind the string in <out>.mask.npy)
+    want_mask = "-M" in mode
+    mode = mode.replace("-M", "")
     if mode.endswith("-S"):
-        r = kc.compute_sharded_simplitigs(ctx, comm, split_records(recs, rank, world), k, mode.startswith("bi"))
+        r = kc.compute_sharded_simplitigs(ctx, comm, split_records(recs, rank, world), k, mode.startswith("bi"), want_mask=want_mask)
     else:
         strand, _, z = mode.partition("-z")
-        r = kc.compute_sharded(ctx, comm, mine, k, strand == "bi", min_frequency=int(z) if z else 1)
+        r = kc.compute_sharded(ctx, comm, mine, k, strand == "bi", min_frequency=int(z) if z else 1, want_mask=want_mask)
     off, n = r.slice()
-    piece = r.array().copy()
+    if want_mask:
+        o_s, m_s = r.strings(want_mask=True)
+        piece, mpiece = np.frombuffer(o_s.encode(), dtype=np.uint8), m_s.encode()
+    else:
+        piece, mpiece = r.array().copy(), b""
     stats = dict(r.stats)
     r.close()
     gathered = [None] * world if rank == 0 else None
-    dist.gather_object((off, n, piece.tobytes(), stats, comm.stats()), gathered, dst=0)
+    dist.gather_object((off, n, piece.tobytes(), stats, comm.stats(), mpiece), gathered, dst=0)
     if rank == 0:
         gathered.sort(key=lambda g: (g[0], g[1]))
-        pos, parts = 0, []
-        for off_r, n_r, b, _, _ in gathered:
+        pos, parts, mparts = 0, [], []
+        for off_r, n_r, b, _, _, mb in gathered:
             if n_r == 0:
                 continue
             assert off_r == pos, "slices do not tile the superstring: offset %d, expected %d" % (off_r, pos)
             parts.append(b)
+            mparts.append(mb)
             pos += n_r
         assert pos == stats["length"], "slices cover %d of %d characters" % (pos, stats["length"])
         np.save(out_path, np.frombuffer(b"".join(parts), dtype=np.uint8))
+        if want_mask:
+            np.save(out_path + ".mask.npy", np.frombuffer(b"".join(mparts), dtype=np.uint8))
         per_rank = [g[4]["bytes_sent"] / max(1, g[3]["n_kmers_rank"]) for g in gathered]
         print("sharded ok: world=%d N=%d S=%d L=%d jump_rounds=%d bytes_sent(rank0)=%d max bytes sent per owned k-mer=%.2f collectives=%d" % (
             world, stats["n_kmers"], stats["n_simplitigs"], stats["length"], stats["matching_rounds"], gathered[0][4]["bytes_sent"], max(per_rank),

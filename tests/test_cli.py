@@ -401,13 +401,18 @@ def test_cli_gpus_option_is_byte_identical(tmp_path, golden_dir):
         for i, r in enumerate(gen.random_records(4000, 33, seed=5)):   # 3 k-mers per record at k = 31
             f.write(b">s%d\n%s\n" % (i, r))
     p = run("compute", "-k", "31", "--gpus", "2", sp)
+    # (round 6: the library keeps such a request inside the collective -- rank 0 runs it and every rank gets its slice -- so the CLI's own
+    # one-GPU fallback with its note is only taken when the library hands the request back, KC_SHARD_NO_ROOT_FALLBACK=1)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert p.stdout == run("compute", "-k", "31", sp).stdout
+    p = subprocess.run([BIN, "compute", "-k", "31", "--gpus", "2", sp], capture_output=True, text=True, env=dict(os.environ, KC_SHARD_NO_ROOT_FALLBACK="1"))
     assert p.returncode == 0 and "sparse branch" in p.stderr and "running on one GPU" in p.stderr, p.stderr[-500:]
     assert p.stdout == run("compute", "-k", "31", sp).stdout
     # the same through stdin: the ranks have consumed the stream, the one-GPU run must work from what they read (a second read of `-`,
     # a FIFO or a process substitution finds nothing)
     with open(sp, "rb") as f:
         q = subprocess.run([BIN, "compute", "-k", "31", "--gpus", "2", "-"], stdin=f, capture_output=True)
-    assert q.returncode == 0 and b"running on one GPU" in q.stderr, q.stderr[-500:]
+    assert q.returncode == 0, q.stderr[-500:]
     assert q.stdout.split(b"\n", 1)[1] == p.stdout.encode().split(b"\n", 1)[1]   # (the header names the path)
     assert run("compute", "-k", "31", "--gpus", "0", fa).returncode == 1
     # KMERCAMEL_GPUS: a value that is no number between 1 and 64 is ignored with a warning (not "--gpus must be ..."), and the

@@ -151,6 +151,53 @@ def test_ranks_simplitigs_input(ctx, tmp_path, k):
     assert np.array_equal(run_ranks(4, few, k, "bi-S", str(tmp_path / "out.npy")), want)
 
 
+def test_requests_the_sharded_flow_does_not_serve_run_on_rank_0(ctx, tmp_path):
+    """k < 18 (plain hashing: no minimizer blocks to shard by), the sparse branch (S >= N / 5, main.cpp:175-181: the ranks find out
+    together after phase 1), -S with -M (global.h:185-195) and -M / -z combined with them: kc_compute_sharded does not leave the
+    collective for these -- the ranks' records go to rank 0, which runs kc_compute, and every rank gets its slice of the one result
+    (round 6; KC_SHARD_NO_ROOT_FALLBACK=1 gives the error code KC_E_UNSUPPORTED_SHARDED back instead).  Byte-identical to one GPU,
+    string and mask, 2 - 4 ranks, some of them without a record."""
+    def single_both(fa, k, bi, **kw):
+        r = kc.compute_file(ctx, fa, k, bi, want_mask=True, **kw)
+        o, m = r.strings(want_mask=True)
+        r.close()
+        return np.frombuffer(o.encode(), dtype=np.uint8), np.frombuffer(m.encode(), dtype=np.uint8)
+    out = str(tmp_path / "out.npy")
+    # k < 18
+    fa = str(tmp_path / "reads.fa")
+    write_fasta(fa, gen.random_records(120, 300, seed=4))
+    for k, mode, world in ((15, "bi", 3), (9, "uni", 2), (17, "bi", 4)):
+        wo, wm = single_both(fa, k, mode == "bi")
+        got = run_ranks(world, fa, k, mode + "-M", out)
+        assert np.array_equal(got, wo) and np.array_equal(np.load(out + ".mask.npy"), wm), (k, mode, world)
+    # the sparse branch: 3 k-mers per record at k = 31
+    sp = str(tmp_path / "sparse.fa")
+    write_fasta(sp, gen.random_records(3000, 33, seed=5))
+    wo, wm = single_both(sp, 31, True)
+    for world in (2, 3):
+        got = run_ranks(world, sp, 31, "bi-M", out)
+        assert np.array_equal(got, wo) and np.array_equal(np.load(out + ".mask.npy"), wm), world
+    r = kc.compute_file(ctx, sp, 31, True)
+    assert r.stats["sparse_branch"] == 1
+    r.close()
+    # -S with -M
+    import random
+    rng = random.Random(77)
+    recs = [bytes(rng.choice(b"ACGT") for _ in range(rng.choice([31, 40, 95]))) for _ in range(400)]
+    sf = str(tmp_path / "simp.fa")
+    write_fasta(sf, recs)
+    for k, mode in ((31, "bi"), (21, "uni")):
+        wo, wm = single_both(sf, k, mode == "bi", assume_simplitigs=True)
+        for world in (2, 4):
+            got = run_ranks(world, sf, k, mode + "-S-M", out)
+            assert np.array_equal(got, wo) and np.array_equal(np.load(out + ".mask.npy"), wm), (k, mode, world)
+    # and with the knob the code comes back, from every rank together
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29977",
+                        os.path.join(ROOT, "tests", "shard_worker.py"), fa, "15", "bi", out], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, KC_SHARD_NO_ROOT_FALLBACK="1"))
+    assert p.returncode != 0 and "-9" in (p.stdout + p.stderr) and "not part of the hash-sharded path" in (p.stdout + p.stderr), (p.stdout + p.stderr)[-1500:]
+
+
 @pytest.mark.parametrize("k", [23, 63])
 def test_ranks_min_frequency_filter(ctx, tmp_path, k):
     """-z on the sharded path (ReadKMersFiltered, parser.h:122-141): every occurrence of a k-mer, whichever rank read it, is counted
