@@ -603,9 +603,17 @@ __device__ __forceinline__ void kc_kmer_mins(const Key<W> &x, const Key<W> &xr, 
             r = (r >> 2) | ((3u - b) << top);
         }
         const u32 h = kc_mmer_hash(f, r);
-        if (i >= 2 && i <= k - m - 2) both = h < both ? h : both;
-        else if (i < 2) { if (i <= k - m - 2) onlyL = h < onlyL ? h : onlyL; }
-        else onlyR = h < onlyR ? h : onlyR;
+        if constexpr (W == 1) {
+            if (i >= 2 && i <= k - m - 2) both = h < both ? h : both;
+            else if (i < 2) { if (i <= k - m - 2) onlyL = h < onlyL ? h : onlyL; }
+            else onlyR = h < onlyR ? h : onlyR;
+        } else {
+            // (wide keys: two plain running minima.  The three-way form above, one instruction per position cheaper, cost the 127-mer
+            // kernel its register budget in round 5 -- 123 registers and no spill became 128 + 98 spilled, 7.6 -> 22 ms per 10^8
+            // k-mers -- and nobody measured wide keys that round; found and undone in round 6)
+            if (i >= 2) onlyR = h < onlyR ? h : onlyR;
+            if (i <= k - m - 2) onlyL = h < onlyL ? h : onlyL;
+        }
     }
     minL = both < onlyL ? both : onlyL;
     minR = both < onlyR ? both : onlyR;
@@ -890,6 +898,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
     // the workgroup's lists of leftovers: k-mers {slot offset, rank << 16} where the rings were, listed ports where the stacks were
     u32 *sh_k = reinterpret_cast<u32 *>(lists);                                                                       // WAVES x 64 entries
     unsigned short *sh_p = reinterpret_cast<unsigned short *>(lists + (size_t)KC_PROBE_WAVES * KC_PROBE_SSTACK * 2);   // WAVES x ECAP entries
+    u32 *sh_m = reinterpret_cast<u32 *>(lists + (size_t)KC_PROBE_WAVES * (KC_PROBE_SSTACK * 2 + ECAP * 2));            // (MM: their minimizer hashes, where the waves' emmh were)
     {
         const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(set.tags + base);
         for (u32 j = threadIdx.x; j < bs / 16; j += KC_PROBE_THREADS) kc_pb[j] = src[j];
@@ -1063,10 +1072,10 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             // every lane takes one left-over entry into a register, the waves agree on their places in the workgroup's list (which lies
             // where the rings / stacks were: nobody writes before everybody has read), then the entries go there
             const u32 cnt = phase == 0 ? stail - shead : ecnt;   // (< 64)
-            u32 ent = 0;
+            u32 ent = 0, ent_m = 0;
             if ((u32)lane < cnt) {
                 if (phase == 0) ent = (u32)sstack[(shead + (u32)lane) & (KC_PROBE_SSTACK - 1)] | ((wfirst + shead + (u32)lane) << 16);
-                else ent = epid[lane];
+                else { ent = epid[lane]; if (MM && !GP) ent_m = emmh[lane]; }   // (wide keys: the minimizer hash travels with its port -- recomputing it is a serial pass over the key)
             }
             if (lane == 0) kc_wleft[phase][wv] = cnt;
             __syncthreads();
@@ -1077,7 +1086,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
             if (own_left) { at = (u32)wv * (phase == 0 ? 64u : (u32)ECAP); tot = cnt; }
             if ((u32)lane < cnt) {
                 if (phase == 0) sh_k[at + (u32)lane] = ent;
-                else sh_p[at + (u32)lane] = (unsigned short)ent;
+                else { sh_p[at + (u32)lane] = (unsigned short)ent; if (MM && !GP) sh_m[at + (u32)lane] = ent_m; }
             }
             __syncthreads();
             if (phase == 0) { nk_sh = tot; shead = stail; lbase_k = own_left ? at : 0u; } else { np_sh = tot; ecnt = 0; lbase_p = own_left ? at : 0u; }
@@ -1097,6 +1106,7 @@ __global__ void __launch_bounds__(NT, NT == 1024 ? 8 : 4) kc_probe_block_kernel(
                 const u32 idx = chunk * 64u + (u32)lane;
                 on = idx < np_sh;
                 e = on ? sh_p[lbase_p + idx] : 0u;
+                if (MM && !GP) { mm_in = on ? sh_m[lbase_p + idx] : 0u; have_mm = true; }
                 chunk += (u32)KC_PROBE_WAVES;
             }
             settle_listed(on, e >> 1, (int)(e & 1u), mm_in, have_mm);

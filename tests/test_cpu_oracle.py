@@ -243,6 +243,29 @@ def test_shipped_library_has_no_wrong_result_knobs():
             assert not re.search(r'getenv\("KC_[A-Z_]*_EXP"\)', txt), f
 
 
+def test_probe_kernel_variants_do_not_spill_vector_registers(tmp_path):
+    """Every instantiation of the dominant kernel (kc_probe_block_kernel: single / double / quadruple-word keys, compile-time and run-time k,
+    the sharded form) must fit its register budget without spilling VECTOR registers to scratch memory: the kernel sits on that cliff --
+    in round 5 a one-instruction-per-position saving in the minimizer pass took the 127-mer form from 123 registers and no spill to
+    128 + 98 spilled, 7.6 -> 22 ms per 10^8 k-mers, and nothing noticed (no GPU needed for this check: hipcc cross-compiles)."""
+    import subprocess
+    out = []
+    for src in ("kc_simplitigs.hip", "kc_shard.hip"):
+        asm = str(tmp_path / (src + ".s"))
+        subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result", "--cuda-device-only", "-S", "-o", asm,
+                               os.path.join(ROOT, "kmercamel_amd", "csrc", src)], stderr=subprocess.DEVNULL)
+        name = None
+        for line in open(asm):
+            line = line.strip()
+            if line.startswith(".name:"):
+                name = line.split()[1]
+            elif line.startswith(".vgpr_spill_count:") and name and "kc_probe_block_kernel" in name:
+                out.append((name, int(line.split()[1])))
+    assert len(out) >= 20, "the probe kernel's instantiations were not found in the assembly"
+    bad = [(n, c) for n, c in out if c != 0]
+    assert not bad, "probe kernel variants spill vector registers: %s" % bad
+
+
 def test_product_never_touches_the_oracle():
     for dp, _, files in os.walk(os.path.join(ROOT, "kmercamel_amd")):
         for f in files:
