@@ -1775,6 +1775,7 @@ template <int W> static int build_sharded_w(kc_set *set, kc_comm *c, const u64 *
     KC_HIP(ctx, hipMemcpyAsync(h, set->counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ids_built && !h[2]) { set->nstride = kcs_stride_for(h[4]); set->dense_ok = true; }   // (spills are inserted behind the kernel's back: the sweep of kcs_prepare_dense then)
+    set->homes_primary = ids_built && !h[2];   // (a fresh build whose keys all stayed in their blocks: the probe kernel's in-block guess applies on this rank)
     if (min_count > 1) {   // (collective: a rank whose blocks overflowed takes everybody out of the sharded path)
         u64 lost = h[3];
         KC_TRY(kcc_allreduce_max(c, &lost, 1));

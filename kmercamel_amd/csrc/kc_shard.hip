@@ -1246,9 +1246,16 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                 KC_LAUNCH((kc_shard_spill_kernel<W>), dim3(256), dim3(256), 0, ctx->stream, sv, link, k, complements, (const u64 *)spill, spill_cap, (const u64 *)spill_cur, L);
                 return KC_OK;
             };
+            // (GP: this rank's keys all sit at their primary homes -- the sweep guesses "in my own block" and computes no minimizers, see the
+            // kernel; a rank decides that for itself, the results do not depend on it)
+            const bool gp = set->homes_primary && !getenv("KC_PROBE_NO_GUESS");
             if (stage_keys) {
-                if constexpr (W == 1) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false, true>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false, true>));
-            } else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true, true>));
+                if constexpr (W == 1) {
+                    if (gp) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false, true, true>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false, true, true>));
+                    else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, true, 1024, false, true>) : launch(kc_probe_block_kernel<W, 0, true, 1024, false, true>));
+                }
+            } else if (gp) KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true, true, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true, true, true>));
+            else KC_TRY(kspec ? launch(kc_probe_block_kernel<W, KSPEC, false, 512, true, true>) : launch(kc_probe_block_kernel<W, 0, false, 512, true, true>));
         }
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
