@@ -333,18 +333,23 @@ static int read_fasta_device_impl(kc_ctx *ctx, const char *path, u64 range_off, 
     u64 *aux = nullptr;   // [0..1] carry, [2..3] flags, then bstate / boff
     const u64 nbmax = (CH + 16383) / 16384 + 1;
     int rc = ensure_copy_stream(ctx);
-    for (int i = 0; i < NB && rc == KC_OK; ++i) {
-        hbuf[i] = (u8 *)kc_pin_acquire(ctx, CH + 64);
-        if (!hbuf[i]) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
-        if (rc == KC_OK && (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess)) rc = KC_E_NO_DEVICE;
-        else if (rc == KC_OK) have_ev[i] = true;
-    }
+    // (only the FIRST pinned chunk before the reader starts: a fresh process pays ~5 ms per 32 MB of hipHostMalloc, and the reader can fill
+    // chunk 0 while chunks 1 and 2 -- and the device buffers -- are being obtained; round 6)
+    auto get_chunk = [&](int i) -> int {
+        u8 *p = (u8 *)kc_pin_acquire(ctx, CH + 64);
+        if (!p) return KC_E_NO_DEVICE;   // (no message from here: the helper thread below must not write the context's error string)
+        hbuf[i] = p;
+        if (hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess) return KC_E_NO_DEVICE;
+        have_ev[i] = true;
+        return KC_OK;
+    };
+    if (rc == KC_OK && get_chunk(0) != KC_OK) rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed");
     // reader thread: fills free pinned buffers, hands them over in order (started before the device buffers are allocated: the first
     // chunks are read while hipMalloc and the first kernel launch -- which loads the code object -- run)
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<int, long>> ready;   // (buffer, bytes); bytes <= 0: end / error
-    bool free_buf[NB] = {true, true, true};
+    bool free_buf[NB] = {true, false, false};   // (chunks 1 and 2 become free once they exist, below)
     bool stop = false;
     std::thread reader;
     if (rc == KC_OK) {
@@ -376,6 +381,13 @@ static int read_fasta_device_impl(kc_ctx *ctx, const char *path, u64 range_off, 
                 }
             }
         });
+    }
+    // (chunks 1 and 2 while the reader fills chunk 0.  Pinning them from a helper thread, so that this one could go on to the device buffers,
+    // was measured and dropped: the two threads' HIP calls serialise, the input arrived 20 - 40 ms later)
+    for (int i = 1; i < NB && rc == KC_OK; ++i) {
+        if (get_chunk(i) != KC_OK) { rc = kc_fail(ctx, KC_E_NO_DEVICE, "pinned buffer allocation failed"); break; }
+        { std::lock_guard<std::mutex> lk(mu); free_buf[i] = true; }
+        cv.notify_all();
     }
     if (rc == KC_OK) rc = kc_alloc(ctx, &d_raw, NB * (CH + 256));
     if (rc == KC_OK) rc = kc_alloc(ctx, &blocks, nbmax);
