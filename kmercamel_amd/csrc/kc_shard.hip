@@ -2083,10 +2083,14 @@ static int compute_on_root(kc_ctx *ctx, kc_comm *c, const u8 *d_seq, u64 len, co
     for (int r = 0; r < G; ++r) { piece_at[r] = total; rec_at[r] = nrec; total += all[2 * r] + (simp ? 0 : 1); nrec += all[2 * r + 1]; }
     u8 *gathered = nullptr;
     u64 *d_lens = nullptr, *d_all_lens = nullptr;
-    if (me == 0) {
-        KC_TRY(scope.alloc(&gathered, total + 64));
-        KC_HIP(ctx, hipMemsetAsync(gathered, '\n', total + 64, ctx->stream));
-        for (int r = 0; r < G; ++r) { ro[r] = piece_at[r]; rcv[r] = all[2 * r]; }
+    {   // (rank 0's buffer for everybody's records: whether it exists is agreed before anybody enters the exchange)
+        u64 bad = 0;
+        if (me == 0) {
+            if (scope.alloc(&gathered, total + 64) != KC_OK || hipMemsetAsync(gathered, '\n', total + 64, ctx->stream) != hipSuccess) bad = 1;
+            for (int r = 0; r < G; ++r) { ro[r] = piece_at[r]; rcv[r] = all[2 * r]; }
+        }
+        KC_TRY(kcc_allreduce_max(c, &bad, 1));
+        if (bad) return kc_fail_agreed(ctx, KC_E_NO_DEVICE, "rank 0 has no device memory for the records of all ranks (a request the hash-sharded flow hands to one GPU)");
     }
     sc[0] = len;
     KC_TRY(kcc_alltoallv(c, d_seq, so.data(), sc.data(), gathered, ro.data(), rcv.data()));
