@@ -11,6 +11,7 @@ and `fetch_requests` (raw / 64) is the number to hold against the ~50 G requests
 import csv
 import glob
 import json
+import re
 import shutil
 import sys
 
@@ -40,8 +41,9 @@ def main(src, tag):
     if pk:
         # calibration: the pack kernel reads `len` input bytes exactly once
         cfg = bench["config"]
-        nk = cfg.get("n_kmers", cfg.get("n_kmers_per_gpu"))
-        nbytes = nk / 1000 * 1031 if nk else None
+        # (records x (bases + the separator): read off the workload string, so that k = 63 / 127 -- 1 062 / 1 126 bases per record -- calibrate right)
+        mw = re.search(r"(\d+) records x (\d+) bp", cfg.get("workload", ""))
+        nbytes = int(mw.group(1)) * (int(mw.group(2)) + 1) if mw else None
         out["_calibration"] = {"kernel": pk[0], "known_read_bytes": nbytes, "fetch_size_bytes_raw": out[pk[0]]["fetch_size_bytes_raw"],
                                "ratio_known_over_raw": round(nbytes / out[pk[0]]["fetch_size_bytes_raw"], 3) if nbytes else None}
     json.dump(out, open("profiles/%s_traffic.json" % tag, "w"), indent=1, sort_keys=True)
