@@ -230,6 +230,7 @@ static inline unsigned kc_grid8(u64 n, unsigned block) { u64 g = (n + block - 1)
 // ---- kc_util.hip: scan / ordered compaction / sharded lists / message routing (hand-written, no library calls) ----
 int kcu_exclusive_scan(kc_ctx *ctx, const u64 *in, u64 *out, u64 n, bool sync = true);   // out[0..n], out[n] = total; out may alias in
 int kcu_select_flagged(kc_ctx *ctx, const u64 *in, const u8 *flags, u64 n, u64 *out, u64 *d_total, bool sync = true);   // stable
+int kcp_sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out);   // kc_simplitigs.hip: *perm_out (kc_alloc'd) = the rows of d_keys (n x W words) in ascending key order
 int kcu_sort_rows_bucketed(kc_ctx *ctx, const u64 *keys, const u64 *ids, u64 n, int W, int total_bits, u64 *keys_out, u64 *ids_out, u64 *d_flag);   // MSD bucket pass + LDS sorts; KC_E_ARG: not applicable
 int kcu_sort_pairs(kc_ctx *ctx, const u64 *keys_in, u64 *keys_out, const u64 *vals_in, u64 *vals_out, u64 n, int begin_bit, int end_bit, bool sync = true);   // stable LSD radix sort
 int kcu_compact_shards(kc_ctx *ctx, const u64 *src, u64 shard_cap, const u64 *d_cursors, int nshards, int stride, int E, u64 *dst, u64 *total, bool *overflow);

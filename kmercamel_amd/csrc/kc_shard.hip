@@ -740,9 +740,9 @@ __global__ void __launch_bounds__(256) kc_shard_chain_kernel(SetView<W> set, con
 
 // ---- the replicated simplitig list: chain records sorted by head key (device radix sort over the key words) -> lens / word
 // counts / firstK / lastK / final fragment ids; the final-fragment ids sorted once more for the fragments' membership test
-__global__ void __launch_bounds__(256) kc_shard_row_word_kernel(const u64 *__restrict__ rows, const u64 *__restrict__ perm, u64 n, int CW, int word, u64 *out) {
+__global__ void __launch_bounds__(256) kc_shard_row_keys_kernel(const u64 *__restrict__ rows, u64 n, int CW, int W, u64 *out) {   // the head keys of the chain records, n x W words
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[t] = rows[perm[t] * (u64)CW + word];
+    if (t < n) for (int w = 0; w < W; ++w) out[t * (u64)W + w] = rows[t * (u64)CW + 3 + w];
 }
 __global__ void __launch_bounds__(256) kc_shard_simp_fill_kernel(const u64 *__restrict__ rows, const u64 *__restrict__ perm, u64 S, int CW, int W, int k, u64 *lens,
                                                                  u64 *nwords, u64 *firstK, u64 *lastK, u64 *fin, u64 *idx) {
@@ -1798,19 +1798,15 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
     struct SimpGuard { kc_simplitigs *s; ~SimpGuard() { if (s) kc_simplitigs_destroy(s); } } simpg{simp};
     u64 *fin_sorted = nullptr, *fin_simp = nullptr;
     {
-        // order by head key: stable LSD radix sort over the key words, least significant word first (as the single-GPU flow)
-        u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr, *nw = nullptr, *fin = nullptr, *idx = nullptr;
-        KC_TRY(scope.alloc(&perm, S + 1)); KC_TRY(scope.alloc(&perm2, S + 1)); KC_TRY(scope.alloc(&kw, S + 1)); KC_TRY(scope.alloc(&kw2, S + 1));
+        // order by head key, by the single-GPU flow's own routine (round 6: one MSD bucket pass + LDS sorts where the keys allow it, the
+        // stable LSD radix sort otherwise -- the 16 four-bit passes over 62-bit keys were 48 launches, 5 ms of a rank's 39 at its 8-rank
+        // share of cfg[3]; the head keys are distinct k-mers, so the order is the same whichever sort makes it)
+        u64 *perm = nullptr, *hk = nullptr, *nw = nullptr, *fin = nullptr, *idx = nullptr;
+        KC_TRY(scope.alloc(&hk, S * (u64)W + 1));
         KC_TRY(scope.alloc(&nw, S + 1)); KC_TRY(scope.alloc(&fin, S + 1)); KC_TRY(scope.alloc(&idx, S + 1));
-        KC_LAUNCH(kc_shard_iota_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, perm, S);
-        for (int word = 0; word < W; ++word) {
-            int bits = 2 * k - 64 * word;
-            if (bits <= 0) break;
-            if (bits > 64) bits = 64;
-            KC_LAUNCH(kc_shard_row_word_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, (const u64 *)perm, S, CW, 3 + word, kw);
-            KC_TRY(kcu_sort_pairs(ctx, kw, kw2, perm, perm2, S, 0, bits, false));   // (no sync of its own: everything below queues behind it)
-            std::swap(perm, perm2);
-        }
+        KC_LAUNCH(kc_shard_row_keys_kernel, dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, (const u64 *)all_chains, S, CW, W, hk);
+        KC_TRY(kcp_sort_perm_by_keys(ctx, hk, S, W, k, &perm));
+        auto perm_back = kc_defer([&] { (void)hipStreamSynchronize(ctx->stream); kc_release(ctx, perm); });
         KC_TRY(kc_alloc(ctx, &simp->lens, S + 1)); KC_TRY(kc_alloc(ctx, &simp->woff, S + 1));
         KC_TRY(kc_alloc(ctx, &simp->firstK, S * W + 1)); KC_TRY(kc_alloc(ctx, &simp->lastK, S * W + 1));
         KC_TRY(scope.alloc(&fin_sorted, S + 1)); KC_TRY(scope.alloc(&fin_simp, S + 1));
@@ -1818,7 +1814,9 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
                            simp->firstK, simp->lastK, fin, idx);
         KC_HIP(ctx, hipGetLastError());
         KC_TRY(kcu_exclusive_scan(ctx, nw, simp->woff, S, false));                       // woff[S] = words in total
-        KC_TRY(kcu_sort_pairs(ctx, fin, fin_sorted, idx, fin_simp, S, 0, 46, false));     // final fragment id (46 bits) -> simplitig
+        // (final fragment id -> simplitig.  The ids are small numbers in 46 bits -- rank and fragment index -- so an MSD bucket pass on their top
+        // bits puts everything into one bucket: measured 3.6 ms of hammering one counter before its overflow flag sent it here anyway)
+        KC_TRY(kcu_sort_pairs(ctx, fin, fin_sorted, idx, fin_simp, S, 0, 46, false));
         u64 wsum = 0;
         KC_TRY(read_words(ctx, simp->woff + S, &wsum, 1));
         simp->nwords = wsum; simp->total_bases = N + S * (u64)(k - 1);
@@ -1826,7 +1824,7 @@ template <int W> int compute_sharded_w(kc_ctx *ctx, kc_comm *c, const u8 *d_seq,
         KC_HIP(ctx, hipMemsetAsync(simp->words, 0, (wsum + 2) * 8, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         kc_release(ctx, all_chains);
-        scope.release(perm); scope.release(perm2); scope.release(kw); scope.release(kw2); scope.release(nw); scope.release(fin); scope.release(idx);
+        scope.release(hk); scope.release(nw); scope.release(fin); scope.release(idx);
     }
     KC_HIP(ctx, hipEventRecord(e2, ctx->stream));
     tick("chain records, simplitig list");

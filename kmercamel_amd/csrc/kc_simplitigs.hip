@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(256) kc_segment_hop_emit_kernel(SetView<W> set
 
 // ---------------------------------------------------------------------------------------------------------
 static int read_u64(kc_ctx *ctx, const u64 *d, u64 *h);
-static int sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out) {
+int kcp_sort_perm_by_keys(kc_ctx *ctx, const u64 *d_keys, u64 n, int W, int k, u64 **perm_out) {   // (also the sharded flow's simplitig order: kc_shard.hip)
     // LSD over the key words (least significant word first), each pass a stable radix sort of (word, perm).
     u64 *perm = nullptr, *perm2 = nullptr, *kw = nullptr, *kw2 = nullptr;
     KcScope scope(ctx);
@@ -1381,7 +1381,7 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
     bool built = false;
     auto cleanup = kc_defer([&] { if (!built) kc_simplitigs_destroy(s); });
     u64 *perm = nullptr, *nwords = nullptr;
-    int rc = sort_perm_by_keys(ctx, chain_key, S, W, k, &perm);
+    int rc = kcp_sort_perm_by_keys(ctx, chain_key, S, W, k, &perm);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->lens, S + 1);
     if (rc == KC_OK) rc = kc_alloc(ctx, &s->woff, S + 1);
     if (rc == KC_OK) rc = scope.alloc(&nwords, S + 1);
