@@ -587,21 +587,39 @@ struct OvgBuf {
 __device__ __forceinline__ void ovg_poison(u64 *st, int d, int reason) {
     atomicCAS((ull *)&st[OVG_STATUS], 0ULL, (ull)((u64)(d + 1) | ((u64)reason << 8)));
 }
-// one thread: sizes of the level
-template <int W> __global__ void ovg_begin_kernel(u64 *st, u64 *shcur, u64 tcap) {
-    if (st[OVG_STATUS]) return;
-    if (threadIdx.x == 0) {
-        st[OVG_NB] = 0; st[OVG_TOTS] = 0; st[OVG_TOTP] = 0; st[OVG_COVERED] = 0; st[OVG_NE] = 0; st[OVG_BIG] = 0; st[OVG_HUGE] = 0; st[OVG_COMPACT] = 0;
-        u64 lcap = 64;
-        while (lcap < 2 * st[OVG_LIVEP] + 16 && lcap < tcap) lcap <<= 1;
-        st[OVG_MASK] = lcap - 1;
-    }
-    for (int i = threadIdx.x; i < 65 * 16; i += blockDim.x) shcur[i] = 0;
+// The level's book-keeping rides on the kernels that are launched anyway (round 6: four single-thread launches per level -- begin, decide,
+// end, swap -- were a fifth of the launches of an input of 10^8 k-mers, whose grouped levels are bound by launch latency):
+//  * ovg_clear_kernel: thread 0 of block 0 first finishes the PREVIOUS level (the swap of the active lists after a compaction) and sets
+//    this level's sizes; every block derives the table size itself from the live count, which the swap does not touch;
+//  * ovg_write_kernel: every thread takes the verdict of the level (acyclic iff every new edge was covered) from the same words,
+//    thread 0 of block 0 records it and closes the level's accounts.
+__device__ __forceinline__ u64 ovg_level_cap(const u64 *st, u64 tcap) {
+    u64 lcap = 64;
+    while (lcap < 2 * st[OVG_LIVEP] + 16 && lcap < tcap) lcap <<= 1;
+    return lcap;
 }
-template <int W> __global__ void __launch_bounds__(256) ovg_clear_kernel(const u64 *__restrict__ st, LevelTable<W> t, u32 *cnt2) {
+__device__ __forceinline__ void ovg_swap_lists(u64 *st) {   // one thread: a compaction of the level before has filled the other pair of lists
+    if (!st[OVG_COMPACT]) return;
+    st[OVG_LENS] = st[OVG_NEWS]; st[OVG_LENP] = st[OVG_NEWP];
+    st[OVG_CUR] ^= 1; st[OVG_UNSORTED] = 1; st[OVG_COMPACT] = 0;
+}
+template <int W> __global__ void __launch_bounds__(256) ovg_clear_kernel(u64 *st, LevelTable<W> t, u32 *cnt2, u64 *shcur, u64 tcap) {
     if (st[OVG_STATUS]) return;
-    const u64 n = st[OVG_MASK] + 1;
+    const u64 n = ovg_level_cap(st, tcap);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            ovg_swap_lists(st);
+            st[OVG_NB] = 0; st[OVG_TOTS] = 0; st[OVG_TOTP] = 0; st[OVG_COVERED] = 0; st[OVG_NE] = 0; st[OVG_BIG] = 0; st[OVG_HUGE] = 0;
+            st[OVG_MASK] = n - 1;
+        }
+        for (int i = threadIdx.x; i < 65 * 16; i += blockDim.x) shcur[i] = 0;
+    }
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) { t.slot[i] = LV_EMPTY; cnt2[i] = 0; }
+}
+// (behind the last level of a run: the swap that the next level's clear would have done)
+__global__ void ovg_finish_kernel(u64 *st) {
+    if (st[OVG_STATUS]) return;
+    ovg_swap_lists(st);
 }
 // insert-or-find that also says whether this call created the slot
 template <int W>
@@ -804,19 +822,26 @@ __global__ void __launch_bounds__(256) ovg_cover_kernel(u64 *st, const u64 *__re
     }
     if (mine) atomicAdd((ull *)&st[OVG_COVERED], (ull)mine);
 }
-// one thread: the level is acyclic iff every new edge was covered by a walk from a path's tail; else the host repairs it
-__global__ void ovg_decide_kernel(u64 *st, const u64 *__restrict__ n_ptr, const u64 *__restrict__ shflag, int d) {
+// new path ends + coverage marks cleared (ov_fix_write_clear_kernel, any grid) -- and the level's verdict and book-keeping: the level is
+// acyclic iff every new edge was covered by a walk from a path's tail (else the host repairs it); every new edge removes exactly one
+// suffix vertex and one prefix vertex
+__global__ void __launch_bounds__(256) ovg_write_kernel(u64 *st, const u64 *__restrict__ ne, const u64 *__restrict__ n_ptr, const u64 *__restrict__ shflag,
+                                                        const u64 *__restrict__ edge_from, const u64 *__restrict__ pred, u64 *first_snap, u64 *last_snap, u8 *cov, int d) {
     if (st[OVG_STATUS]) return;
     const u64 n = *n_ptr;
-    st[OVG_NE] = n;
-    if (*shflag) { ovg_poison(st, d, OVG_REASON_LOG); return; }
-    if (st[OVG_COVERED] != n) { ovg_poison(st, d, OVG_REASON_REPAIR); return; }
-}
-// new path ends + coverage marks cleared (ov_fix_write_clear_kernel, any grid); then the level's book-keeping
-__global__ void __launch_bounds__(256) ovg_write_kernel(const u64 *__restrict__ st, const u64 *__restrict__ ne, const u64 *__restrict__ edge_from, const u64 *__restrict__ pred,
-                                                        u64 *first_snap, u64 *last_snap, u8 *cov) {
-    if (st[OVG_STATUS]) return;
-    const u64 n = st[OVG_NE];
+    const bool log_lost = *shflag != 0, cyclic = st[OVG_COVERED] != n;   // (the same for every thread: nothing in this kernel writes these words)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st[OVG_NE] = n;
+        if (log_lost) ovg_poison(st, d, OVG_REASON_LOG);
+        else if (cyclic) ovg_poison(st, d, OVG_REASON_REPAIR);
+        else {
+            st[OVG_LIVES] -= n; st[OVG_LIVEP] -= n; st[OVG_EDGES] += n;
+            st[OVG_LEVELS_DONE] = (u64)d;
+            st[OVG_NEWS] = 0; st[OVG_NEWP] = 0;
+            st[OVG_COMPACT] = ((st[OVG_LENS] - st[OVG_LIVES]) * 4 > st[OVG_LENS] || (st[OVG_LENP] - st[OVG_LIVEP]) * 4 > st[OVG_LENP]) ? 1 : 0;
+        }
+    }
+    if (log_lost || cyclic) return;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (u64)gridDim.x * blockDim.x) {
         const u64 y = ne[t * 5 + 1];
         cov[y] = 0;
@@ -831,14 +856,6 @@ __global__ void __launch_bounds__(256) ovg_write_kernel(const u64 *__restrict__ 
         }
         first_snap[l0] = f; last_snap[f] = l0;
     }
-}
-__global__ void ovg_end_kernel(u64 *st, int d) {
-    if (st[OVG_STATUS]) return;
-    const u64 n = st[OVG_NE];   // every new edge removes exactly one suffix vertex and one prefix vertex
-    st[OVG_LIVES] -= n; st[OVG_LIVEP] -= n; st[OVG_EDGES] += n;
-    st[OVG_LEVELS_DONE] = (u64)d;
-    st[OVG_NEWS] = 0; st[OVG_NEWP] = 0;
-    st[OVG_COMPACT] = ((st[OVG_LENS] - st[OVG_LIVES]) * 4 > st[OVG_LENS] || (st[OVG_LENP] - st[OVG_LIVEP]) * 4 > st[OVG_LENP]) ? 1 : 0;
 }
 // lazy compaction of the active lists (the order inside them does not matter to the grouped levels)
 __global__ void __launch_bounds__(256) ovg_compact_kernel(u64 *st, OvgBuf b, const u64 *__restrict__ edge_from, const u64 *__restrict__ pred) {
@@ -859,12 +876,6 @@ __global__ void __launch_bounds__(256) ovg_compact_kernel(u64 *st, OvgBuf b, con
         if (keepP) dstP[pP] = v;
     }
 }
-__global__ void ovg_swap_kernel(u64 *st) {
-    if (st[OVG_STATUS] || !st[OVG_COMPACT]) return;
-    st[OVG_LENS] = st[OVG_NEWS]; st[OVG_LENP] = st[OVG_NEWP];
-    st[OVG_CUR] ^= 1; st[OVG_UNSORTED] = 1; st[OVG_COMPACT] = 0;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 struct OvWork;
 static int read_back(kc_ctx *ctx, u64 *h_pinned, const u64 *d, int n) {
@@ -1469,8 +1480,7 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             gcnt = ovg_lcnt + 16 * (size_t)d;
             level_cnt[(size_t)d] = gcnt;
             g.ne_count = gcnt;
-            KC_LAUNCH((ovg_begin_kernel<W>), dim3(1), dim3(256), 0, ctx->stream, ovg_st, ne_shcur, tcap);
-            KC_LAUNCH((ovg_clear_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, tab, ob.cnt2);
+            KC_LAUNCH((ovg_clear_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob.cnt2, ne_shcur, tcap);   // (+ the level's sizes, the previous level's swap)
             KC_LAUNCH((ovg_insert_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, (const u64 *)pred, k, d);
             KC_LAUNCH((ovg_probe_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)suf, (const u64 *)pre, (const u64 *)edge_from, k, d);
             KC_LAUNCH((ovg_buckets_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, k, d, complements);
@@ -1481,13 +1491,11 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             if (shl) KC_LAUNCH(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, gcnt);
             KC_LAUNCH(ovg_cover_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, (const u64 *)ne, (const u64 *)gcnt, (const u64 *)edge_from, (const u64 *)pred,
                                (const u64 *)first_snap, (const u64 *)last_snap, cov);
-            KC_LAUNCH(ovg_decide_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, (const u64 *)gcnt, (const u64 *)(ne_shcur + 64 * 16), d);
-            KC_LAUNCH(ovg_write_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, (const u64 *)ne, (const u64 *)edge_from, (const u64 *)pred, first_snap,
-                               last_snap, cov);
-            KC_LAUNCH(ovg_end_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st, d);
+            KC_LAUNCH(ovg_write_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, (const u64 *)ne, (const u64 *)gcnt, (const u64 *)(ne_shcur + 64 * 16),
+                               (const u64 *)edge_from, (const u64 *)pred, first_snap, last_snap, cov, d);   // (+ the level's verdict and accounts)
             KC_LAUNCH(ovg_compact_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, ob, (const u64 *)edge_from, (const u64 *)pred);
-            KC_LAUNCH(ovg_swap_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st);
         }
+        KC_LAUNCH(ovg_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, ovg_st);
         KC_HIP(ctx, hipGetLastError());
         KC_HIP(ctx, hipMemcpyAsync(h_st, ovg_st, sizeof h_st, hipMemcpyDeviceToHost, ctx->stream));
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
