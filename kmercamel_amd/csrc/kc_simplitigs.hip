@@ -1143,7 +1143,12 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
             const KcFrag fr{fpool, fbase, 0, 0};
             // bidirectional sets: one launch per class of heads, so that most chains are walked from one end only (see the kernel);
             // KC_WALK_BOTH=1: every head walks, as before round 5
-            if (compl_ && !getenv("KC_WALK_BOTH")) {
+            // (the class passes trade walks for launches: four launches whose walks each take ~0.3 ms whatever their number -- ~110 dependent
+            // hops -- against 0.27 N scattered lines saved.  Below ~1.3 10^8 k-mers the launches cost more than the lines: every head walks,
+            // one launch (cfg[1]: walks 1.33 -> 0.4 ms of a 13 ms pass).  KC_WALK_CLASSES_MIN: the k-mer count from which the classes are used)
+            u64 classes_min = (u64)1 << 27;
+            if (const char *e = getenv("KC_WALK_CLASSES_MIN")) classes_min = (u64)atoll(e);
+            if (compl_ && !getenv("KC_WALK_BOTH") && N >= classes_min) {
                 u64 *hcls = nullptr, *hcnt = nullptr;
                 KC_TRY(scope.alloc(&hcls, (u64)KC_WALK_CLASSES * nheads));
                 KC_TRY(scope.alloc(&hcnt, KC_WALK_CLASSES));

@@ -150,10 +150,10 @@ def test_segment_parallel_walks_forced(ctx, oracle, k, links, monkeypatch):
                                    {"KC_BUCKET_MIN": "0", "KC_SCATTER_ROLL": "1"}, {"KC_BUCKET_MIN": "0", "KC_PROBE_LISTED_GLOBAL": "1"},
                                    {"KC_BUCKET_MIN": "0", "KC_BUILD_NOPREFETCH": "1", "KC_SCATTER_CHUNKS": "2"},
                                    {"KC_BUCKET_MIN": "0", "KC_NO_BUILD_IDS": "1"}, {"KC_BUCKET_MIN": "0", "KC_SCATTER_V1": "1"},
-                                   {"KC_WALK_BOTH": "1"}],
+                                   {"KC_WALK_BOTH": "1"}, {"KC_WALK_CLASSES_MIN": "0"}],
                          ids=["bucketed-build", "direct-insert", "no-recording", "no-tag-staging", "bucketed-with-spills", "plain-walk",
                               "fragment-contraction-then-restore", "rolling-scatter", "listed-ports-from-the-table", "no-build-prefetch",
-                              "node-ids-by-a-sweep-of-their-own", "wave-scatter-of-round-4", "every-head-walks"])
+                              "node-ids-by-a-sweep-of-their-own", "wave-scatter-of-round-4", "every-head-walks", "walk-classes-on-a-small-input"])
 def test_alternative_device_paths_give_identical_results(ctx, oracle, knobs, monkeypatch):
     """Every path the library picks by input size (bucketed LDS build vs direct CAS inserts, recorded-stream emit vs chain
     walk, LDS tag staging; the wave-cooperative bucket scatter -- default with KC_BUCKET_MIN=0 for single-word keys on minimizer
@@ -243,7 +243,8 @@ def test_fragment_contraction_path(ctx, k, monkeypatch):
             monkeypatch.delenv("KC_NOFRAG")
             assert (cycles > 0) == (name == "reads+cycles")
             for env in ({}, {"KC_CHAIN_LIMIT": "1200"}, {"KC_CHAIN_LIMIT": "1200", "KC_SEG_PLAIN": "1"}, {"KC_CHAIN_LIMIT": "40", "KC_BSHIFT": "10"}, {"KC_BSHIFT": "10"},
-                        {"KC_EMIT_LANES": "64"}, {"KC_EMIT_LANES": "8"}):   # (phase 3: a wavefront / 8 lanes per vertex)
+                        {"KC_EMIT_LANES": "64"}, {"KC_EMIT_LANES": "8"},    # (phase 3: a wavefront / 8 lanes per vertex)
+                        {"KC_WALK_CLASSES_MIN": "0"}, {"KC_WALK_CLASSES_MIN": "0", "KC_BSHIFT": "10"}):   # (the class passes of the walks, which inputs this small do not take by themselves)
                 for var, value in env.items():
                     monkeypatch.setenv(var, value)
                 got = kc.compute(ctx, seq, k, complements)

@@ -51,6 +51,9 @@ def main():
             if rng.random() < 0.3: os.environ["KC_SEG_PLAIN"] = "1"      # long chains: plain segment walks instead of hops over contracted runs
             else: os.environ.pop("KC_SEG_PLAIN", None)
             # small blocks / short local probe runs: block-local spills, second homes, bucket overflows
+            # (the class passes of the chain walks are only taken from 2^27 k-mers on by default: half of the cases force them)
+            if rng.random() < 0.5: os.environ["KC_WALK_CLASSES_MIN"] = "0"
+            else: os.environ.pop("KC_WALK_CLASSES_MIN", None)
             if rng.random() < 0.2: os.environ["KC_BSHIFT"] = str(rng.choice([9, 10, 11]))
             else: os.environ.pop("KC_BSHIFT", None)
             if rng.random() < 0.2: os.environ["KC_LOCAL_PROBES"] = str(rng.choice([2, 8, 16]))
