@@ -1525,8 +1525,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     // the host-driven levels want their lists ascending (the grouped ones compact them in any order)
     auto sort_lists = [&]() -> int {
         if (!lists_unsorted) return KC_OK;
-        KC_TRY(kcu_sort_pairs(ctx, actS, actS2, nullptr, nullptr, lenS, 0, 40, false));
-        KC_TRY(kcu_sort_pairs(ctx, actP, actP2, nullptr, nullptr, lenP, 0, 40, false));
+        int vbits = 4;   // (vertex ids are below V: no more radix passes than their bits need -- 5 instead of 10 at 2 10^5 vertices)
+        while (vbits < 40 && (V >> vbits) != 0) vbits += 4;
+        KC_TRY(kcu_sort_pairs(ctx, actS, actS2, nullptr, nullptr, lenS, 0, vbits, false));
+        KC_TRY(kcu_sort_pairs(ctx, actP, actP2, nullptr, nullptr, lenP, 0, vbits, false));
         std::swap(actS, actS2); std::swap(actP, actP2);
         lists_unsorted = false;
         return KC_OK;
