@@ -372,27 +372,37 @@ template <int W> __device__ __forceinline__ int cmp_rows(const u64 *a, u64 i, co
     return key_eq(x, key) ? 0 : 1;
 }
 
+// first index >= start whose row is greater than key, in sorted rows none of which from `start` on is smaller than key
+template <int W> __device__ __forceinline__ u64 ov_run_end(const u64 *a, u64 start, u64 n, const Key<W> &key) {
+    u64 lo = start, step = 1;
+    while (lo + step <= n && cmp_rows<W>(a, lo + step - 1, key) <= 0) { lo += step; step <<= 1; }
+    u64 hi = lo + step - 1 < n ? lo + step - 1 : n;   // (row hi is greater than key, or hi = n)
+    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (cmp_rows<W>(a, mid, key) <= 0) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
 // one thread per sorted suffix hit; the first hit of a key run replays the whole bucket (pair)
 template <int W>
 __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__restrict__ hsk, const u64 *__restrict__ hsv, u64 nHS,
                                                       const u64 *__restrict__ hpk, const u64 *__restrict__ hpv, u64 nHP, u64 *scrS, u64 *scrP,
                                                       u64 *big, u64 big_cap, u64 *big_count, u64 *huge, u64 huge_cap, u64 *huge_count) {
+    __shared__ __attribute__((aligned(16))) unsigned char lane_lds[64 * KC_LANE_STRIDE];
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHS) return;
     if (g.abort2 && (g.abort2[0] | g.abort2[1])) return;   // a bucketed sort overflowed: the host redoes the level's sorts
     Key<W> key = load_key<W>(hsk, t);
     if (t > 0 && key_eq(load_key<W>(hsk, t - 1), key)) return;
-    // bucket ends by binary search (a linear scan is one dependent global load per member: 0.3 ms for the single bucket of d = 0)
-    u64 lo = t + 1, hi = nHS;
-    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (cmp_rows<W>(hsk, mid, key) <= 0) lo = mid + 1; else hi = mid; }
-    const u64 a1 = lo;
-    lo = 0; hi = nHP;
+    // bucket ends: the run of equal keys is followed in doubling steps and then bisected (a linear scan is one dependent global load per
+    // member: 0.3 ms for the single bucket of d = 0; a bisection of the whole list is 20 dependent loads for a run of two)
+    const u64 a1 = ov_run_end<W>(hsk, t + 1, nHS, key);
+    u64 lo = 0, hi = nHP;
     while (lo < hi) { u64 mid = (lo + hi) >> 1; if (cmp_rows<W>(hpk, mid, key) < 0) lo = mid + 1; else hi = mid; }
     const u64 b0 = lo;
-    hi = nHP;
-    while (lo < hi) { u64 mid = (lo + hi) >> 1; if (cmp_rows<W>(hpk, mid, key) <= 0) lo = mid + 1; else hi = mid; }
-    const u64 b1 = lo;
+    const u64 b1 = ov_run_end<W>(hpk, b0, nHP, key);
     if (b1 == b0) return;
+#ifdef KC_EXPERIMENTS
+    if (g.exp & 1) return;
+#endif
     int mode = KC_MODE_UNI;
     if (g.complements) mode = (g.d == 0 || key_eq(key_rc(key, g.d), key)) ? KC_MODE_PAL : KC_MODE_PAIR;
     const u64 members = (a1 - t) + (b1 - b0);
@@ -411,6 +421,10 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
             dsc[0] = t; dsc[1] = a1; dsc[2] = b0; dsc[3] = b1; dsc[4] = (u64)mode;
             return;
         }
+    }
+    if (members <= KC_LANE_MAX && !(g.lane_off)) {   // (nearly all of them: two to four members)
+        kc_match_bucket_lane(g, hsv + t, (u32)(a1 - t), hpv + b0, (u32)(b1 - b0), mode, lane_lds + (threadIdx.x & 63) * KC_LANE_STRIDE, false, g.tag_base + (u32)t);
+        return;
     }
     kc_match_bucket(g, hsv + t, a1 - t, hpv + b0, b1 - b0, mode, g.tag_base + (u32)t, scrS + t, scrP + b0);
 }
@@ -759,6 +773,7 @@ __device__ __forceinline__ void ovg_insertion_sort(u64 *a, u32 n) {
 // one thread per bucket: small ones are put in order and replayed here, the others are handed to a wavefront each
 template <int W>
 __global__ void __launch_bounds__(64) ovg_match_kernel(OvArgs g, u64 *st, OvgBuf b, const u64 *__restrict__ suf) {
+    __shared__ __attribute__((aligned(16))) unsigned char lane_lds[64 * KC_LANE_STRIDE];
     if (st[OVG_STATUS]) return;
     const u64 nb = st[OVG_NB];
     const u32 lds_min = (st[OVG_TOTS] + st[OVG_TOTP] <= 32768) ? 4u : g.lds_min;   // (few hits: even small buckets get a wavefront and LDS)
@@ -779,6 +794,10 @@ __global__ void __launch_bounds__(64) ovg_match_kernel(OvArgs g, u64 *st, OvgBuf
                 continue;
             }
             ovg_poison(st, g.d, OVG_REASON_BIG);   // (cannot happen with the caller's sizing)
+            continue;
+        }
+        if (members <= KC_LANE_MAX && !(g.lane_off)) {
+            kc_match_bucket_lane(g, b.memS + oS, cS, b.memP + oP, cP, mode, lane_lds + (threadIdx.x & 63) * KC_LANE_STRIDE, true, g.tag_base + (u32)t);
             continue;
         }
         ovg_insertion_sort(b.memS + oS, cS);
@@ -1129,6 +1148,10 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
     g.edge_from = edge_from; g.overlaps = overlaps; g.pred = pred; g.first = first; g.last = last;
     g.first_snap = first_snap; g.last_snap = last_snap;
     g.ne = ne; g.ne_count = cnt; g.bl = bl; g.nbl = 0; g.lds_min = (u32)lds_min; g.abort2 = nullptr;
+    g.lane_off = getenv("KC_OV_NO_LANE_REPLAY") ? 1u : 0u;   // (test knob: small buckets replayed from global memory, one thread each -- the path of buckets between KC_LANE_MAX and lds_min members)
+#ifdef KC_EXPERIMENTS
+    if (const char *e = KC_EXP_KNOB("KC_MATCH_EXP")) g.exp = (u32)atoi(e);
+#endif
     // sharded new-edge log (see ov_add_event): every shard could hold a whole level's edges of an evenly spread load four times over
     u64 *ne_sh = nullptr, *ne_shcur = nullptr;
     const u64 ne_shcap = (2 * V) / 16 + 1024;

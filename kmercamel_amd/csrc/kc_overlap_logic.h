@@ -43,6 +43,10 @@ struct OvArgs {
     u64 nbl;
     u32 tag_base = 0;   // first writer tag of the current launch (tags are never reused between launches)
     u32 lds_min = 12;   // buckets with at least this many members are replayed out of LDS by a wavefront of their own
+    u32 lane_off = 0;   // 1: no lane-per-bucket LDS replay of the small buckets (kc_match_bucket_lane): they take kc_match_bucket
+#ifdef KC_EXPERIMENTS
+    u32 exp = 0;        // timing experiments (tools' build only): 1 = ov_match_kernel stops after finding its bucket
+#endif
 };
 
 #define KC_MODE_UNI 0

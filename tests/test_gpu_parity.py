@@ -555,6 +555,8 @@ def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
                 # them (every larger bucket sends its level back to the host-driven loop) / eager compaction, no level windows
                 {"KC_OV_HOST_LOOP": "1"}, {"KC_OVG_MAX": "1000000000000"}, {"KC_OVG_MAX": "1000000000000", "KC_OVG_NO_LDS": "1"},
                 {"KC_OV_EAGER_SHRINK": "1", "KC_OV_NO_WINDOW": "1"},
+                # small buckets replayed from global memory by one thread each (not out of a lane's LDS), in both loops
+                {"KC_OV_NO_LANE_REPLAY": "1"}, {"KC_OV_NO_LANE_REPLAY": "1", "KC_OVG_MAX": "1000000000000"},
                 # phase 3: 8 lanes per vertex (the form for short simplitigs) on these 1 030-character ones
                 {"KC_EMIT_LANES": "8"}):
         for name, value in env.items():

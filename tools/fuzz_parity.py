@@ -54,6 +54,8 @@ def main():
             # (the class passes of the chain walks are only taken from 2^27 k-mers on by default: half of the cases force them)
             if rng.random() < 0.5: os.environ["KC_WALK_CLASSES_MIN"] = "0"
             else: os.environ.pop("KC_WALK_CLASSES_MIN", None)
+            if rng.random() < 0.25: os.environ["KC_OV_NO_LANE_REPLAY"] = "1"   # phase 2: small buckets from global memory, one thread each
+            else: os.environ.pop("KC_OV_NO_LANE_REPLAY", None)
             if rng.random() < 0.2: os.environ["KC_BSHIFT"] = str(rng.choice([9, 10, 11]))
             else: os.environ.pop("KC_BSHIFT", None)
             if rng.random() < 0.2: os.environ["KC_LOCAL_PROBES"] = str(rng.choice([2, 8, 16]))

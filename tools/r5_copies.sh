@@ -1,8 +1,8 @@
 #!/bin/bash
 # which device-to-device copies of a pass are long?  kernel trace of one bench pass; copyBuffer dispatches over 50 us with their neighbours
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5/copies; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-cli > /dev/null 2>&1
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r5/copies; ARGS="$@"; rm -rf $OUT; mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-cli $ARGS > /dev/null 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
