@@ -26,6 +26,7 @@
 #define LV_EMPTY (~(u64)0)
 #define KC_CNT_BLOCKS 256
 #define KC_LDS_MIN 12      /* buckets with fewer members are replayed by a single thread straight from global memory */
+#define KC_LDS_MID 128     /* the size class of most listed buckets: 5 KB, 32 workgroups to a CU */
 #define KC_LDS_MAX 1200    /* 39 B of LDS per member: 46 KB */
 #define KC_LDS_HUGE 3800   /* the few buckets beyond that (d <= 2: one or two buckets hold every vertex that is left) get a CU's whole LDS: 145 KB */
 
@@ -430,13 +431,17 @@ __global__ void __launch_bounds__(64) ov_match_kernel(OvArgs g, const u64 *__res
 }
 
 // one wavefront per medium bucket (descriptors listed by ov_match_kernel); the grid is an upper bound, surplus blocks exit
+// (lo, hi]: the bucket sizes this launch takes -- the LDS a workgroup asks for is its launch's largest bucket, and most listed buckets
+// have a few dozen members: those run 32 to a CU instead of 3)
 __global__ void __launch_bounds__(64) ov_match_lds_kernel(OvArgs g, const u64 *__restrict__ hsv, const u64 *__restrict__ hpv,
-                                                          const u64 *__restrict__ big, u64 big_cap, const u64 *__restrict__ big_count) {
+                                                          const u64 *__restrict__ big, u64 big_cap, const u64 *__restrict__ big_count, u32 lo, u32 hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char kc_lds[];
     u64 nb = *big_count;
     if (nb > big_cap) nb = big_cap;
     if ((u64)blockIdx.x >= nb) return;   // (no descriptors when the match kernel stood down: abort2)
     const u64 *dsc = big + (u64)blockIdx.x * 5;
+    const u64 members = (dsc[1] - dsc[0]) + (dsc[3] - dsc[2]);
+    if (members <= lo || members > hi) return;
     kc_match_bucket_lds(g, hsv + dsc[0], (u32)(dsc[1] - dsc[0]), hpv + dsc[2], (u32)(dsc[3] - dsc[2]), (int)dsc[4], kc_lds);
 }
 
@@ -806,7 +811,7 @@ __global__ void __launch_bounds__(64) ovg_match_kernel(OvArgs g, u64 *st, OvgBuf
     }
 }
 // one wavefront per listed bucket (workgroups of 64 take the descriptors in turn)
-__global__ void __launch_bounds__(64) ovg_match_lds_kernel(OvArgs g, const u64 *__restrict__ st, OvgBuf b, int huge) {
+__global__ void __launch_bounds__(64) ovg_match_lds_kernel(OvArgs g, const u64 *__restrict__ st, OvgBuf b, int huge, u32 lo, u32 hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char kc_lds[];
     if (st[OVG_STATUS]) return;
     u64 nb = st[huge ? OVG_HUGE : OVG_BIG];
@@ -815,6 +820,8 @@ __global__ void __launch_bounds__(64) ovg_match_lds_kernel(OvArgs g, const u64 *
     const u64 *list = huge ? b.huge : b.big;
     for (u64 i = blockIdx.x; i < nb; i += gridDim.x) {
         const u64 *dsc = list + i * 5;
+        const u64 members = (dsc[1] - dsc[0]) + (dsc[3] - dsc[2]);
+        if (members <= lo || members > hi) continue;   // (another launch's size class: see ov_match_lds_kernel)
         kc_match_bucket_lds(g, b.memS + dsc[0], (u32)(dsc[1] - dsc[0]), b.memP + dsc[2], (u32)(dsc[3] - dsc[2]), (int)dsc[4], kc_lds, true);
         __syncthreads();
     }
@@ -1345,13 +1352,17 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
                                    (const u64 *)hs_ids2, nHS, (const u64 *)hp_keys2, (const u64 *)hp_ids2, nHP, hs_ids, hp_ids, big, big_cap, cnt + 8, huge, huge_cap, cnt + 9);
                 u64 nblk = (nHS + nHP) / (u64)g.lds_min + 1;
                 if (nblk > big_cap) nblk = big_cap;
-                KC_LAUNCH(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
-                                   (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8));
+                KC_LAUNCH(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MID), ctx->stream, g,
+                                   (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8), 0u, (u32)KC_LDS_MID);
+                if (nHS + nHP > KC_LDS_MID) {
+                    KC_LAUNCH(ov_match_lds_kernel, dim3((unsigned)nblk), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g,
+                                       (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)big, big_cap, (const u64 *)(cnt + 8), (u32)KC_LDS_MID, (u32)KC_LDS_MAX);
+                }
                 if (nHS + nHP > KC_LDS_MAX) {   // only then can a bucket be that large
                     u64 nh = (nHS + nHP) / KC_LDS_MAX + 1;
                     if (nh > huge_cap) nh = huge_cap;
                     KC_LAUNCH(ov_match_lds_kernel, dim3((unsigned)nh), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g,
-                                       (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)huge, huge_cap, (const u64 *)(cnt + 9));
+                                       (const u64 *)hs_ids2, (const u64 *)hp_ids2, (const u64 *)huge, huge_cap, (const u64 *)(cnt + 9), 0u, (u32)KC_LDS_HUGE);
                 }
             }
             if (shlog) {
@@ -1509,8 +1520,9 @@ template <int W> static int overlap_path_w(kc_simplitigs *s, int complements, in
             KC_LAUNCH((ovg_buckets_kernel<W>), dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, tab, ob, (const u64 *)pre, k, d, complements);
             KC_LAUNCH(ovg_scatter_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, (const u64 *)ovg_st, ob);
             KC_LAUNCH((ovg_match_kernel<W>), dim3(4 * OVG_GRID), dim3(64), 0, ctx->stream, g, ovg_st, ob, (const u64 *)suf);
-            KC_LAUNCH(ovg_match_lds_kernel, dim3(2 * OVG_GRID), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g, (const u64 *)ovg_st, ob, 0);
-            KC_LAUNCH(ovg_match_lds_kernel, dim3(64), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g, (const u64 *)ovg_st, ob, 1);
+            KC_LAUNCH(ovg_match_lds_kernel, dim3(8 * OVG_GRID), dim3(64), kc_lds_bytes_bound(KC_LDS_MID), ctx->stream, g, (const u64 *)ovg_st, ob, 0, 0u, (u32)KC_LDS_MID);
+            KC_LAUNCH(ovg_match_lds_kernel, dim3(2 * OVG_GRID), dim3(64), kc_lds_bytes_bound(KC_LDS_MAX), ctx->stream, g, (const u64 *)ovg_st, ob, 0, (u32)KC_LDS_MID, (u32)KC_LDS_MAX);
+            KC_LAUNCH(ovg_match_lds_kernel, dim3(64), dim3(64), kc_lds_bytes_bound(KC_LDS_HUGE), ctx->stream, g, (const u64 *)ovg_st, ob, 1, 0u, (u32)KC_LDS_HUGE);
             if (shl) KC_LAUNCH(ov_gather_log_kernel, dim3(16, 64), dim3(256), 0, ctx->stream, (const u64 *)ne_sh, (const u64 *)ne_shcur, ne_shcap, ne, gcnt);
             KC_LAUNCH(ovg_cover_kernel, dim3(OVG_GRID), dim3(256), 0, ctx->stream, ovg_st, (const u64 *)ne, (const u64 *)gcnt, (const u64 *)edge_from, (const u64 *)pred,
                                (const u64 *)first_snap, (const u64 *)last_snap, cov);

@@ -4,7 +4,7 @@
 SECS=${1:-420}; NP=${2:-6}
 mkdir -p gpurun_out/r6_fuzz
 for i in $(seq $NP); do
-  timeout $((SECS + 120)) python3 tools/fuzz_parity.py $SECS $((6100 + i)) > gpurun_out/r6_fuzz/fuzz_$i.log 2>&1 &
+  timeout $((SECS + 120)) python3 tools/fuzz_parity.py $SECS $((${3:-6100} + i)) > gpurun_out/r6_fuzz/fuzz_$i.log 2>&1 &
 done
 wait
 for i in $(seq $NP); do tail -2 gpurun_out/r6_fuzz/fuzz_$i.log | cut -c1-300; done
