@@ -17,8 +17,6 @@
 #pragma once
 #include "kc_overlap_logic.h"
 
-#if defined(__HIPCC__)
-
 #define KC_LDS_NONE 0xffffffffu
 struct LdsEnd { u32 v, i1, i2; };   // vertex, index in its natural list, index of its mirror in the other list
 
@@ -34,24 +32,25 @@ struct LdsBucket {
     u8 *usedA, *usedB, *evPart;
 };
 
-__device__ __forceinline__ size_t kc_lds_bytes(u64 nA, u64 nB) {
+KC_HD size_t kc_lds_bytes(u64 nA, u64 nB) {
     u64 n = nA + nB;
     return (size_t)(n * 8 + n * sizeof(LdsEnd) + n * 4 + n * 4 * 3 + n * 3 + 64);
 }
-__host__ __device__ __forceinline__ size_t kc_lds_bytes_bound(u64 n) { return (size_t)(n * 8 + n * 12 + n * 4 + n * 12 + n * 3 + 64); }
+KC_HD size_t kc_lds_bytes_bound(u64 n) { return (size_t)(n * 8 + n * 12 + n * 4 + n * 12 + n * 3 + 64); }
 
-__device__ __forceinline__ u32 lds_find(const u32 *a, u32 n, u32 v) {   // index of v in the ascending list a, or NONE
+KC_HD u32 lds_find(const u32 *a, u32 n, u32 v) {   // index of v in the ascending list a, or NONE
     u32 lo = 0, hi = n;
     while (lo < hi) { u32 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
     return (lo < n && a[lo] == v) ? lo : KC_LDS_NONE;
 }
-__device__ __forceinline__ u32 lds_lower(const u32 *a, u32 lo, u32 n, u32 v) {   // first index >= lo with a[idx] >= v
+KC_HD u32 lds_lower(const u32 *a, u32 lo, u32 n, u32 v) {   // first index >= lo with a[idx] >= v
     u32 hi = n;
     while (lo < hi) { u32 mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
     return lo;
 }
-__device__ __forceinline__ u32 lds_mirror(u32 v, u32 S) { return v < S ? v + S : v - S; }
+KC_HD u32 lds_mirror(u32 v, u32 S) { return v < S ? v + S : v - S; }
 
+#if defined(__HIPCC__)
 // ascending order of the n vertex ids in a[] (LDS), by their rank among themselves (ids are distinct), for the member lists of the
 // grouped levels, which arrive unordered; tmp[] = n words of LDS.  Every lane keeps Q of the elements in registers and runs ONCE over the
 // list for them (four broadcast reads in flight): n^2 / 64 compares per lane, two instructions each.  (One element per lane and one
@@ -87,13 +86,15 @@ __device__ __forceinline__ void kc_lds_rank_sort(u32 *a, u32 n, u32 *tmp) {
     __syncthreads();
 }
 
+#endif  // __HIPCC__
+
 // The sequential replay of one bucket (reference event order: part, then suffix vertex ascending; candidates descending), run by ONE lane
 // out of LDS; returns the number of accepted events (listed in evU / evC / evPart).  Live events are kept in two linked lists in
 // reference order (list 1: the members of A ascending; list 2, PAIR only: the members of B viewed through mirror(), ascending): a matched
 // (or otherwise consumed) event is unlinked, so later parts never see it again, and a list whose candidates are exhausted in the
 // current part is not traversed at all.
 template <int MODE, bool LB>
-__device__ u32 kc_lds_replay(const OvArgs &g, const LdsBucket &b, const u32 nA, const u32 nB, const u32 splitA, const u32 splitB) {
+KC_HD u32 kc_lds_replay(const OvArgs &g, const LdsBucket &b, const u32 nA, const u32 nB, const u32 splitA, const u32 splitB) {
     constexpr bool BI = MODE != KC_MODE_UNI, PAIR = MODE == KC_MODE_PAIR;
     const u32 S = (u32)g.S, batch = (u32)g.batch;
     const u32 n2 = PAIR ? nA : 0, hi2 = n2 - splitA;   // the candidates of list 2: A viewed through mirror(), ascending: element t sits at ...
@@ -219,6 +220,7 @@ __device__ u32 kc_lds_replay(const OvArgs &g, const LdsBucket &b, const u32 nA, 
     return nev;
 }
 
+#if defined(__HIPCC__)
 // one wavefront (blockDim = 64); smem = dynamic LDS of at least kc_lds_bytes(nA, nB).  unsorted: gA / gB come in any order (the
 // grouped levels scatter the members of a bucket through atomic cursors) and are put in ascending order here.
 __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, const u64 *gB, u32 nB, int mode, unsigned char *smem, bool unsorted = false) {
@@ -332,13 +334,15 @@ __device__ void kc_match_bucket_lds(const OvArgs &g, const u64 *gA, u32 nA, cons
 }
 
 
+#endif  // __HIPCC__
+
 // ---- small buckets: ONE LANE per bucket, out of that lane's own stretch of LDS.  The thread-per-bucket replay from global memory
 // (kc_match_bucket) pays ~7 dependent memory round trips per event, and the lanes of a wavefront wait for each other's: 0.4 - 1.1 ms per
 // level for the 3 - 5 10^5 two-to-four-member buckets of the mid levels at cfg[2].  Here a lane loads its bucket's ids and path ends with
 // all loads in flight at once, replays out of LDS (kc_lds_replay, the same code as a wavefront's bucket) and writes the edges back.
 #define KC_LANE_MAX 11          /* members; larger buckets that reach the thread-per-bucket kernels keep the global replay */
 #define KC_LANE_STRIDE 380      /* bytes per lane: 34 per member; 95 words -- odd, so lanes at the same offset use different banks */
-__device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, const u64 *gB, u32 nB, int mode, unsigned char *smem, bool unsorted, u32 tag) {
+KC_HD void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, const u64 *gB, u32 nB, int mode, unsigned char *smem, bool unsorted, u32 tag) {
     const u32 S = (u32)g.S;
     const bool bi = g.complements != 0;
     const u32 n = nA + nB;
@@ -356,6 +360,7 @@ __device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, con
     b.usedA = (u8 *)p; p += nA;
     b.usedB = (u8 *)p; p += nB;
     b.evPart = (u8 *)p;
+#if defined(__HIP_DEVICE_COMPILE__)
     {
         u32 id[KC_LANE_MAX];
 #pragma unroll
@@ -363,6 +368,9 @@ __device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, con
 #pragma unroll
         for (int q = 0; q < KC_LANE_MAX; ++q) if ((u32)q < n) { b.A[q] = id[q]; b.usedA[q] = 0; }
     }
+#else   // (the host build -- tests/sim -- runs the same replay on buckets of any size out of ordinary memory)
+    for (u32 q = 0; q < n; ++q) { b.A[q] = (u32)(q < nA ? gA[q] : gB[q - nA]); b.usedA[q] = 0; }
+#endif
     if (unsorted) {
         for (u32 h = 0; h < 2; ++h) {
             u32 *a = h ? b.B : b.A;
@@ -376,11 +384,15 @@ __device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, con
         }
     }
     if (!g.lower_bound) {
+#if defined(__HIP_DEVICE_COMPILE__)
         u32 sn[KC_LANE_MAX];
 #pragma unroll
         for (int q = 0; q < KC_LANE_MAX; ++q) sn[q] = (u32)q < n ? (u32)((u32)q < nA ? g.first_snap[b.A[q]] : g.last_snap[b.A[q]]) : 0u;
 #pragma unroll
         for (int q = 0; q < KC_LANE_MAX; ++q) if ((u32)q < n) b.firstA[q].v = sn[q];
+#else
+        for (u32 q = 0; q < n; ++q) b.firstA[q].v = (u32)(q < nA ? g.first_snap[b.A[q]] : g.last_snap[b.A[q]]);
+#endif
     }
     for (u32 i = 0; i < nA; ++i) {
         const u32 F = g.lower_bound ? 0 : b.firstA[i].v;
@@ -422,6 +434,7 @@ __device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, con
     if (nev == 0) return;
     const u64 want = (u64)nev * (bi ? 2 : 1);
     u64 *logp;
+#if defined(__HIP_DEVICE_COMPILE__)
     if (g.ne_sh) {   // sharded log (see ov_add_event)
         const u32 sh = (tag * 0x9E3779B1u) >> 26;
         const u64 pos = atomicAdd((unsigned long long *)&g.ne_shcur[sh * 16], (unsigned long long)want);
@@ -429,6 +442,10 @@ __device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, con
         if (!fits) g.ne_shcur[64 * 16] = 1;
         logp = fits ? g.ne_sh + ((u64)sh * g.ne_shcap + pos) * 5 : nullptr;
     } else logp = g.ne + atomicAdd((unsigned long long *)g.ne_count, (unsigned long long)want) * 5;
+#else
+    (void)tag;
+    logp = g.ne + *g.ne_count * 5; *g.ne_count += want;
+#endif
     for (u32 e = 0; e < nev; ++e) {
         const u32 ev = b.evU[e], eidx = ev & 0x7fffffffu, ci = b.evC[e];
         const bool from2 = (ev >> 31) != 0;
@@ -445,5 +462,3 @@ __device__ void kc_match_bucket_lane(const OvArgs &g, const u64 *gA, u32 nA, con
         }
     }
 }
-
-#endif  // __HIPCC__

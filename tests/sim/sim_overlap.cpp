@@ -10,12 +10,13 @@
 #include <cstring>
 #include <cstdint>
 #include "../../kmercamel_amd/csrc/kc_overlap_logic.h"
+#include "../../kmercamel_amd/csrc/kc_overlap_lds.h"   // the LDS replay (kc_lds_replay through kc_match_bucket_lane), compiled for the host
 
 namespace {
 template <int W> struct KLess { bool operator()(const Key<W> &a, const Key<W> &b) const { return key_lt(a, b); } };
 
 template <int W>
-int sim(const char **strs, u64 n, int k, int complements, int lower_bound, u64 *edge_from, u8 *overlaps, u64 seed, u64 *repairs_out) {
+int sim(const char **strs, u64 n, int k, int complements, int lower_bound, u64 *edge_from, u8 *overlaps, u64 seed, u64 *repairs_out, int lds_replay) {
     const u64 S = n, V = S * (complements ? 2 : 1);
     std::vector<Key<W>> pre(V), suf(V);
     auto enc = [&](const char *s, size_t off) { Key<W> x = key_zero<W>(); for (int i = 0; i < k; ++i) { int c = s[off + i]; u64 b = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; x = key_append(x, b, k); } return x; };
@@ -58,6 +59,19 @@ int sim(const char **strs, u64 n, int k, int complements, int lower_bound, u64 *
             ne_count = 0;
             if (!lower_bound) { std::fill(first.begin(), first.end(), ~0ull); std::fill(last.begin(), last.end(), ~0ull); }
             for (size_t t = 0; t < todo.size(); ++t) {
+                if (lds_replay) {
+                    // the replay the device runs out of LDS (one lane's form of it: the wavefront's form differs in who loads the
+                    // bucket, not in the replay); every other bucket arrives in scrambled order, as in the grouped levels
+                    std::vector<u64> A(*todo[t].A), B(*todo[t].Bp);
+                    const bool unsorted = (t & 1) != 0;
+                    if (unsorted) {
+                        for (size_t i = A.size(); i > 1; --i) { rng = rng * 6364136223846793005ULL + 1442695040888963407ULL; std::swap(A[i - 1], A[(rng >> 33) % i]); }
+                        for (size_t i = B.size(); i > 1; --i) { rng = rng * 6364136223846793005ULL + 1442695040888963407ULL; std::swap(B[i - 1], B[(rng >> 33) % i]); }
+                    }
+                    std::vector<unsigned char> mem(kc_lds_bytes(A.size(), B.size()) + 64);
+                    kc_match_bucket_lane(g, A.data(), (u32)A.size(), B.data(), (u32)B.size(), todo[t].mode, mem.data(), unsorted, (u32)t);
+                    continue;
+                }
                 std::vector<u64> sA(todo[t].A->size() + 1), sB(todo[t].Bp->size() + 1);
                 kc_match_bucket(g, todo[t].A->data(), todo[t].A->size(), todo[t].Bp->data(), todo[t].Bp->size(), todo[t].mode, (u32)t, sA.data(), sB.data());
             }
@@ -109,11 +123,15 @@ int sim(const char **strs, u64 n, int k, int complements, int lower_bound, u64 *
 }
 }  // namespace
 
+extern "C" int sim_overlap_path2(const char **strs, uint64_t n, int k, int complements, int lower_bound, uint64_t *edge_from, uint8_t *overlaps,
+                                 uint64_t seed, uint64_t *repairs, int lds_replay) {
+    switch (kc_words_for_k(k)) {
+        case 1: return sim<1>(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs, lds_replay);
+        case 2: return sim<2>(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs, lds_replay);
+        default: return sim<4>(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs, lds_replay);
+    }
+}
 extern "C" int sim_overlap_path(const char **strs, uint64_t n, int k, int complements, int lower_bound, uint64_t *edge_from, uint8_t *overlaps,
                                 uint64_t seed, uint64_t *repairs) {
-    switch (kc_words_for_k(k)) {
-        case 1: return sim<1>(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs);
-        case 2: return sim<2>(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs);
-        default: return sim<4>(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs);
-    }
+    return sim_overlap_path2(strs, n, k, complements, lower_bound, edge_from, overlaps, seed, repairs, 0);
 }

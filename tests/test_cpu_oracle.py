@@ -284,19 +284,20 @@ def _sim():
     so = os.path.join(ROOT, "tests", "sim", "libkcsim.so")
     src = os.path.join(ROOT, "tests", "sim", "sim_overlap.cpp")
     hdr = os.path.join(ROOT, "kmercamel_amd", "csrc", "kc_overlap_logic.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdr2 = os.path.join(ROOT, "kmercamel_amd", "csrc", "kc_overlap_lds.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so, src])
     return ctypes.CDLL(so)
 
 
-def _sim_path(lib, strs, k, c, lb, seed):
+def _sim_path(lib, strs, k, c, lb, seed, lds=False):
     n = len(strs)
     V = n * (2 if c else 1)
     arr = (ctypes.c_char_p * n)(*[s.encode() for s in strs])
     ef = (ctypes.c_uint64 * V)()
     ov = (ctypes.c_uint8 * V)()
     rep = ctypes.c_uint64(0)
-    rc = lib.sim_overlap_path(arr, ctypes.c_uint64(n), k, int(c), int(lb), ef, ov, ctypes.c_uint64(seed), ctypes.byref(rep))
+    rc = lib.sim_overlap_path2(arr, ctypes.c_uint64(n), k, int(c), int(lb), ef, ov, ctypes.c_uint64(seed), ctypes.byref(rep), int(lds))
     return rc, list(ef), list(ov), rep.value
 
 
@@ -304,6 +305,7 @@ def test_bucket_logic_simulation_matches_oracle(oracle):
     lib = _sim()
     for strs, k, c, lb, ef, ov in OHP_KATS:
         assert _sim_path(lib, strs, k, c, lb, 1)[:3] == (0, ef, ov)
+        assert _sim_path(lib, strs, k, c, lb, 1, lds=True)[:3] == (0, ef, ov)
     rng = random.Random(12)
     repairs = 0
     for it in range(120):
@@ -325,6 +327,9 @@ def test_bucket_logic_simulation_matches_oracle(oracle):
                 rc, ef, ov, rep = _sim_path(lib, strs, k, c, lb, it + 7)
                 assert rc == 0 and (ef, ov) == want, (k, n, c, lb)
                 repairs += rep
+                # the same through the replay the device runs out of LDS (32-bit ids, linked event lists, one body per bucket kind)
+                rc, ef, ov, rep = _sim_path(lib, strs, k, c, lb, it + 7, lds=True)
+                assert rc == 0 and (ef, ov) == want, ("lds replay", k, n, c, lb)
     assert repairs > 0   # the verify/repair loop was exercised
 
 
