@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(256) em_emit_kernel(const u64 *__restrict__ wo
                                                       u64 out_lo, int nranks, int me) {
     // nranks > 1 (hash-sharded flow): this rank emits the vertices whose block starts in its share of the output, into a
     // buffer that begins at output offset out_lo
-    constexpr int LG = G == 64 ? 6 : 3;
-    static_assert(G == 64 || G == 8, "lanes per vertex");
+    constexpr int LG = G == 64 ? 6 : G == 16 ? 4 : 3;
+    static_assert(G == 64 || G == 16 || G == 8, "lanes per vertex");
     u64 v = (((u64)blockIdx.z * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) >> LG;   // (x, z): vertices; y: slices of long vertices
     int lane = threadIdx.x & (G - 1);
     if (v >= V) return;
@@ -246,12 +246,17 @@ int kce_emit_ranked(kc_simplitigs *s, const KcRank *r, u64 out_lo, int nranks, i
     if (V && L / V > 16384) { u64 y = L / V / 8192; slices = (unsigned)(y > 256 ? 256 : y); }
     // one wavefront per vertex: from 2^26 vertices on the block count no longer fits one grid dimension's 2^32 work-items
     bool short_ones = V && L / V < 256;   // (L / V: half the mean block, the mirror vertices are not on the path)
-    if (const char *e = getenv("KC_EMIT_LANES")) short_ones = atoi(e) == 8;   // (test knob: 8 or 64)
-    const u64 lanes = short_ones ? 8 : 64;
+    // (in between -- reads of a kilobase: 16 lanes, so that a wavefront has four vertices' dependent loads in flight instead of one's)
+    bool mid_ones = V && !short_ones && L / V < 2048;
+    if (const char *e = getenv("KC_EMIT_LANES")) { short_ones = atoi(e) == 8; mid_ones = atoi(e) == 16; }   // (test knob: 8, 16 or 64)
+    const u64 lanes = short_ones ? 8 : mid_ones ? 16 : 64;
     const u64 gv = (V * lanes + 255) / 256 ? (V * lanes + 255) / 256 : 1;
     const unsigned gx = gv > ((u64)1 << 22) ? (1u << 22) : (unsigned)gv, gz = (unsigned)((gv + gx - 1) / gx);
     if (short_ones)
         KC_LAUNCH(em_emit_kernel<8>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
+                           (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
+    else if (mid_ones)
+        KC_LAUNCH(em_emit_kernel<16>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,
                            (const u64 *)s->lens, s->n, V, s->k, (const u64 *)r->dist, (const u64 *)r->endv, (const u64 *)r->weight, r->start, out, out_lo, nranks, me);
     else
         KC_LAUNCH(em_emit_kernel<64>, dim3(gx, slices, gz), dim3(256), 0, ctx->stream, (const u64 *)s->words, (const u64 *)s->woff,

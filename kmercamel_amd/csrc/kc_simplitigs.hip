@@ -436,92 +436,82 @@ __global__ void __launch_bounds__(256) kc_walk_emit_kernel(SetView<W> set, const
     for (int i = 0; i < W; ++i) lastK[t * W + i] = kx.w[i];
 }
 
-// emit from the recordings of the measure pass: first k bases from the head key, then the recorded appended bases
-template <int W>
+// emit from the recordings of the measure pass: first k bases from the head key, then the recorded appended bases.  EIGHT LANES PER
+// SIMPLITIG: output word j holds the bases 32 j .. 32 j + 31 of the simplitig (the last word, always written, the remainder or
+// nothing), so every lane can build its words on its own -- from the head key, two recorded words and a shift -- and the lanes of a group
+// read and write consecutive words.  (One thread per simplitig, walking its recording word by word, had every lane of a wavefront in a
+// line of its own for reads and writes alike: each 8-byte access moved a whole line between L2 and the CU -- 2.5 ms for the 0.6 GB of
+// cfg[2].)  A turned chain (the recording runs from the chain's last k-mer to its first) is the reverse complement of (head key,
+// recorded bases): its word j is the turned-round window that ends L - 32 j bases into that source.
+template <int W, int LG>
 __global__ void __launch_bounds__(256) kc_stream_emit_kernel(SetView<W> set, const u64 *__restrict__ link, int k, const u64 *__restrict__ chain_head,
                                                              const u64 *__restrict__ chain_len, const u64 *__restrict__ chain_stream,
                                                              const u64 *__restrict__ chain_tail, const u64 *__restrict__ perm, u64 n,
                                                              const u64 *__restrict__ pool, const u32 *__restrict__ chunk_next,
                                                              const u64 *__restrict__ woff, u64 *words, u64 *firstK, u64 *lastK) {
-    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 gt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr u32 G = 1u << LG;   // lanes per simplitig: 8 for reads of a kilobase, fewer for simplitigs of a few words
+    const u64 t = gt >> LG;
+    const u32 g = (u32)(gt & (G - 1));
     if (t >= n) return;
     const u64 p = perm[t];
-    const u64 h = chain_head[p], len = chain_len[p], tail = chain_tail[p];
+    const u64 h = chain_head[p], len = chain_len[p];
     const bool turned = (chain_stream[p] & KC_STREAM_TURNED) != 0;
     Key<W> kx = set_key_at(set, LK_SLOT(link[h]));   // (the head's entry port is dead: its word carries the slot; the tail is listed by slot)
     if (h & 1) kx = key_rc(kx, k);
-    Key<W> kl = set_key_at(set, tail >> 1);
-    if (tail & 1) kl = key_rc(kl, k);
-    {
+    if (g == 0) {
+        const u64 tail = chain_tail[p];
+        Key<W> kl = set_key_at(set, tail >> 1);
+        if (tail & 1) kl = key_rc(kl, k);
         const Key<W> fk = turned ? key_rc(kl, k) : kx, lk = turned ? key_rc(kx, k) : kl;
         for (int i = 0; i < W; ++i) { firstK[t * W + i] = fk.w[i]; lastK[t * W + i] = lk.w[i]; }
     }
-    u32 chunk = (u32)chain_stream[p];
-    u64 left = len - 1;
-    int wi = 0;
-    if (turned) {
-        // The recording runs from the chain's last k-mer to its first: the simplitig is the reverse complement of (head key, recorded
-        // bases).  The groups are taken in recording order, each turned round, and laid down from the END of the simplitig's words
-        // towards their start; the last word is filled from the top like everywhere (so the run starts with its unused low bases).
-        const u64 L = (u64)k + len - 1;
-        const u64 w0 = woff[t];
-        u64 wcur = w0 + ((L - 1) >> 5);
-        if ((L & 31) == 0) words[w0 + (L >> 5)] = 0;       // (the forward form ends every simplitig on a pending word, empty or not)
-        u64 acc = 0;
-        int nacc = 31 - (int)((L - 1) & 31);               // low bases of the last word that stay empty
-        auto put = [&](u64 bits, int nb) {                  // nb (1..32) bases right-aligned in `bits`, in recording order
-            const u64 g = kc_rc_word(bits << (64 - 2 * nb)) & (nb == 32 ? ~(u64)0 : (((u64)1 << (2 * nb)) - 1));   // turned round, right-aligned
-            const int room = 32 - nacc;
-            if (nb < room) { acc |= g << (2 * nacc); nacc += nb; return; }
-            words[wcur--] = room == 32 ? g : (acc | (g << (2 * nacc)));   // the LAST `room` bases of g complete the word
-            const int rest = nb - room;
-            acc = rest ? (g >> (2 * room)) : 0;
-            nacc = rest;
-        };
-        for (int i = 0; i < k; i += 32) {                   // the head key, 32 bases at a time
-            const int nb = k - i >= 32 ? 32 : k - i;
-            u64 bits = 0;
-            for (int j = 0; j < nb; ++j) bits = (bits << 2) | key_at(kx, k, i + j);
-            put(bits, nb);
+    const u64 L = (u64)k + len - 1, nw = (L >> 5) + 1, nrec = (len - 1 + 31) >> 5, w0 = woff[t];
+    // recorded word r (none beyond the recording); asked for in ascending order only: the chunks are a singly linked list
+    u32 chunk = (u32)chain_stream[p], ci = 0;
+    auto rec = [&](u64 r) -> u64 {
+        if (r >= nrec) return 0;
+        const u32 c = (u32)(r / KC_CHUNK_WORDS);
+        while (ci < c) { chunk = chunk_next[chunk]; ++ci; }
+        return pool[(u64)chunk * KC_CHUNK_WORDS + (r % KC_CHUNK_WORDS)];
+    };
+    // the 32 bases of the source (head key, then the recording) from position i0 on, first one in the highest pair
+    auto src32 = [&](u64 i0) -> u64 {
+        u64 x = 0;
+        int have = 0;
+        if (i0 < (u64)k) {
+            have = (u64)k - i0 >= 32 ? 32 : (int)((u64)k - i0);
+            for (int j = 0; j < have; ++j) x = (x << 2) | key_at(kx, k, (int)i0 + j);
+            if (have < 32) x <<= 64 - 2 * have;
         }
-        while (left) {
-            if (wi == KC_CHUNK_WORDS) { chunk = chunk_next[chunk]; wi = 0; }
-            const u64 sw = pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++];
-            const int nb = left >= 32 ? 32 : (int)left;      // valid bases in sw (left-aligned)
-            left -= (u64)nb;
-            put(sw >> (64 - 2 * nb), nb);
+        if (have < 32) {
+            const u64 o = i0 + (u64)have - (u64)k, r = o >> 5;
+            const int sh = (int)(o & 31) * 2;
+            const u64 a = rec(r);
+            const u64 y = sh ? ((a << sh) | (rec(r + 1) >> (64 - sh))) : a;
+            x |= have ? (y >> (2 * have)) : y;
         }
-        return;                                              // (padding + L bases = whole words: nothing is pending)
-    }
-    u64 wp = woff[t], acc = 0;
-    int nacc = 0;
-    for (int i = 0; i < k; ++i) {
-        acc = (acc << 2) | key_at(kx, k, i);
-        if (++nacc == 32) { words[wp++] = acc; acc = 0; nacc = 0; }
-    }
-    // the remaining len-1 bases: whole recorded words, shifted by the nacc bases already pending
-    while (left) {
-        if (wi == KC_CHUNK_WORDS) { chunk = chunk_next[chunk]; wi = 0; }
-        const u64 sw = pool[(u64)chunk * KC_CHUNK_WORDS + (u64)wi++];
-        const int nb = left >= 32 ? 32 : (int)left;          // valid bases in sw (left-aligned)
-        left -= (u64)nb;
-        if (nacc == 0) {
-            if (nb == 32) words[wp++] = sw;
-            else { acc = sw >> (64 - 2 * nb); nacc = nb; }
-        } else {
-            const int room = 32 - nacc;                        // bases still missing in the pending word
-            if (nb >= room) {
-                words[wp++] = (acc << (2 * room)) | (sw >> (64 - 2 * room));
-                const int rest = nb - room;
-                acc = rest ? ((sw << (2 * room)) >> (64 - 2 * rest)) : 0;
-                nacc = rest;
-            } else {
-                acc = (acc << (2 * nb)) | (sw >> (64 - 2 * nb));
-                nacc += nb;
-            }
+        return x;
+    };
+    if (!turned) {
+        for (u64 j = g; j < nw; j += G) {
+            const u64 valid = L - 32 * j >= 32 ? 32 : L - 32 * j;
+            u64 x = valid ? src32(32 * j) : 0;
+            if (valid && valid < 32) x &= ~(u64)0 << (64 - 2 * valid);
+            words[w0 + j] = x;
         }
+        return;
     }
-    words[wp] = nacc ? (acc << (64 - 2 * nacc)) : 0;
+    // turned: the words from the last one down, so that the source positions -- and the recorded words asked for -- ascend
+    const u64 jtop = nw - 1;                                   // (word jtop holds the L & 31 last bases of the turned simplitig: the source's first ones)
+    for (u64 q = g; q < nw; q += G) {
+        const u64 j = jtop - q;
+        const u64 valid = L - 32 * j >= 32 ? 32 : L - 32 * j;
+        u64 x = 0;
+        if (valid == 32) x = kc_rc_word(src32(L - 32 * j - 32));
+        else if (valid) x = kc_rc_word(src32(0) & (~(u64)0 << (64 - 2 * valid))) << (2 * (32 - valid));
+        words[w0 + j] = x;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1416,9 +1406,21 @@ template <int W> static int build_simplitigs_w(kc_set *set, kc_simplitigs **out,
         KC_HIP(ctx, hipStreamSynchronize(ctx->stream));
         scope.release(rank);
     } else if (use_stream) {
-        KC_LAUNCH((kc_stream_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
-                           (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
-                           (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
+        // lanes per simplitig by the mean number of words (KC_STREAM_LANES: test knob, 1 / 2 / 8)
+        int lanes = s->nwords >= 6 * S ? 8 : s->nwords >= 2 * S ? 2 : 1;   // (measured on 150-bp reads with errors -- 2.5 words a simplitig: 3.80 / 3.57 / 4.42 ms with 1 / 2 / 8)
+        if (const char *e = getenv("KC_STREAM_LANES")) lanes = atoi(e);
+        if (lanes >= 8)
+            KC_LAUNCH((kc_stream_emit_kernel<W, 3>), dim3(kc_grid(S * 8, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
+                               (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
+                               (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
+        else if (lanes >= 2)
+            KC_LAUNCH((kc_stream_emit_kernel<W, 1>), dim3(kc_grid(S * 2, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
+                               (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
+                               (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
+        else
+            KC_LAUNCH((kc_stream_emit_kernel<W, 0>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k, (const u64 *)chain_head,
+                               (const u64 *)chain_len, (const u64 *)chain_stream, (const u64 *)chain_tail, (const u64 *)perm, S, (const u64 *)pool,
+                               (const u32 *)chunk_next, (const u64 *)s->woff, s->words, s->firstK, s->lastK);
     } else {
         KC_LAUNCH((kc_walk_emit_kernel<W>), dim3(kc_grid(S, 256)), dim3(256), 0, ctx->stream, sv, (const u64 *)link, k,
                            (const u64 *)chain_head, (const u64 *)perm, S, (const u64 *)s->woff, s->words, s->firstK, s->lastK);

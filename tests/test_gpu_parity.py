@@ -558,7 +558,9 @@ def test_coverage_reads_with_errors_at_scale(ctx, monkeypatch):
                 # small buckets replayed from global memory by one thread each (not out of a lane's LDS), in both loops
                 {"KC_OV_NO_LANE_REPLAY": "1"}, {"KC_OV_NO_LANE_REPLAY": "1", "KC_OVG_MAX": "1000000000000"},
                 # phase 3: 8 lanes per vertex (the form for short simplitigs) on these 1 030-character ones
-                {"KC_EMIT_LANES": "8"}):
+                {"KC_EMIT_LANES": "8"}, {"KC_EMIT_LANES": "64"},
+                # phase 1, simplitigs out of the recordings: one / two lanes per simplitig (the forms for short ones) on these 33-word ones
+                {"KC_STREAM_LANES": "1"}, {"KC_STREAM_LANES": "2"}):
         for name, value in env.items():
             monkeypatch.setenv(name, value)
         r2 = kc.compute(ctx, seq, k, True)

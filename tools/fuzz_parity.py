@@ -56,6 +56,10 @@ def main():
             else: os.environ.pop("KC_WALK_CLASSES_MIN", None)
             if rng.random() < 0.25: os.environ["KC_OV_NO_LANE_REPLAY"] = "1"   # phase 2: small buckets from global memory, one thread each
             else: os.environ.pop("KC_OV_NO_LANE_REPLAY", None)
+            if rng.random() < 0.5: os.environ["KC_STREAM_LANES"] = rng.choice(["1", "2", "8"])   # lanes per simplitig when the recordings are copied out
+            else: os.environ.pop("KC_STREAM_LANES", None)
+            if rng.random() < 0.3: os.environ["KC_EMIT_LANES"] = rng.choice(["8", "16", "64"])   # lanes per vertex when the superstring is spelt
+            else: os.environ.pop("KC_EMIT_LANES", None)
             if rng.random() < 0.2: os.environ["KC_BSHIFT"] = str(rng.choice([9, 10, 11]))
             else: os.environ.pop("KC_BSHIFT", None)
             if rng.random() < 0.2: os.environ["KC_LOCAL_PROBES"] = str(rng.choice([2, 8, 16]))
