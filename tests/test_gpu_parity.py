@@ -55,6 +55,37 @@ def test_set_contents_match_oracle(ctx, oracle, k, complements):
         s1.close(); s2.close()
 
 
+def test_device_input_at_any_alignment(ctx, tmp_path):
+    """kc_compute with the input already on the device (KC_FLAG_INPUT_ON_DEVICE), at pointers that are not 16-byte aligned: the 2-bit
+    packing reads 16-byte pieces where it may and single bytes where it must.  The buffer comes from kc_read_fasta_device; computing from
+    `shift` bytes into it is computing on the joined records without their first `shift` characters.  Mixed case, N, ragged records, an
+    input that ends inside a piece."""
+    import ctypes
+    rng = random.Random(77)
+    for k in (5, 31, 40):
+        parts = [_rand_seq(rng, rng.choice([k - 1, k, k + 1, 3 * k, 200, 1030]), "ACGTacgtN" if rng.random() < 0.3 else "ACGT") for _ in range(60)]
+        path = str(tmp_path / ("in%d.fa" % k))
+        with open(path, "w") as f:
+            for i, p_ in enumerate(parts):
+                f.write(">r%d\n%s\n" % (i, p_))
+        joined = "\n".join(parts).encode()
+        d, n, fq = ctypes.c_void_p(), ctypes.c_uint64(0), ctypes.c_int(0)
+        ctx.check(ctx.lib.kc_read_fasta_device(ctx.h, path.encode(), ctypes.byref(d), ctypes.byref(n), ctypes.byref(fq)))
+        assert n.value == len(joined) + 1 and not fq.value   # (every record is preceded by a separator: where its header line was)
+        content = b"\n" + joined
+        try:
+            for shift in (0, 1, 3, 8, 15, 16, 21):
+                want = kc.compute(ctx, content[shift:], k, True)
+                ref = want.array().copy()
+                want.close()
+                r = kc.compute(ctx, None, k, True, device_ptr=d.value + shift, length=n.value - shift)
+                same = np.array_equal(r.array(), ref)
+                r.close()
+                assert same, (k, shift)
+        finally:
+            ctx.lib.kc_device_free(ctx.h, d)
+
+
 def test_read_kmers_counts_reference_kats(ctx, golden_dir):
     # tests/parser_unittest.h:38-63 on tests/testdata/test.fa
     path = os.path.join(golden_dir, "test.fa")
